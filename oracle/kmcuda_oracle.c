@@ -1,0 +1,839 @@
+/*
+ * kmcuda_oracle.c -- TEST INFRASTRUCTURE ONLY (see kmcuda_oracle.h).
+ *
+ * Plain-C CPU restatement of the arithmetic of src-d/kmcuda's distance/assignment hot
+ * path.  fp32 semantics restated from fp_abstraction.h:23-98:
+ *   _fma(acc,a,b) = __fmaf_rd(a,b,acc)  -> fused multiply-add rounded toward -inf
+ *   _add/_sub/_mul                      -> IEEE round-to-nearest
+ *   _sqrt = __fsqrt_rn, _reciprocal = __frcp_rn -> correctly rounded (sqrtf, 1.0f/x)
+ * Build with -ffp-contract=off and without -ffast-math (oracle/Makefile).
+ *
+ * Parity pinning: reference is CUDA-only => no oracle/_ref; pinned on the reference's own
+ * known-answer tests (src/test.py iteration counts + sklearn agreement).  The angular
+ * metric goes through libm acosf, which is not bit-identical to CUDA's acosf
+ * ("parity unpinned" for angular beyond the reference's own loose thresholds).
+ */
+#include "kmcuda_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+/* ------------------------------------------------------------------------------------ */
+/* round-down FMA                                                                       */
+/* ------------------------------------------------------------------------------------ */
+
+float kmo_fma_rd_portable(float a, float b, float c) {
+  /* a*b is exact in binary64 (24+24 <= 53 bits, exponent range suffices). */
+  const double p = (double)a * (double)b;
+  const double cd = (double)c;
+  const double z = p + cd;                       /* RN(p + c) */
+  if (z != z) return (float)z;                   /* NaN */
+  if (isinf(z)) {
+    if (isinf(p) || isinf(cd)) return (float)z;  /* genuine infinity */
+  }
+  /* TwoSum: p + cd == z + e exactly (when finite). */
+  const double bb = z - p;
+  const double e = (p - (z - bb)) + (cd - bb);
+  if (z == 0.0 && e == 0.0) {
+    /* exact zero: round-down gives -0 unless both addends are zeros of the same sign */
+    if (p == 0.0 && cd == 0.0 && (signbit(p) == signbit(cd))) return signbit(p) ? -0.0f : 0.0f;
+    return -0.0f;
+  }
+  float f = (float)z;                            /* RN to binary32 */
+  const double fd = (double)f;
+  if (fd > z || (fd == z && e < 0.0)) f = nextafterf(f, -INFINITY);
+  return f;
+}
+
+#if defined(__x86_64__)
+__attribute__((target("avx512f"))) static float fma_rd_avx512(float a, float b, float c) {
+  __m128 r = _mm_fmadd_round_ss(_mm_set_ss(a), _mm_set_ss(b), _mm_set_ss(c),
+                                _MM_FROUND_TO_NEG_INF | _MM_FROUND_NO_EXC);
+  return _mm_cvtss_f32(r);
+}
+#endif
+
+static int g_avx512 = -1;
+int kmo_have_avx512(void) {
+  if (g_avx512 < 0) {
+#if defined(__x86_64__)
+    g_avx512 = __builtin_cpu_supports("avx512f") ? 1 : 0;
+    if (getenv("KMO_FORCE_PORTABLE")) g_avx512 = 0;
+#else
+    g_avx512 = 0;
+#endif
+  }
+  return g_avx512;
+}
+
+float kmo_fma_rd(float a, float b, float c) {
+#if defined(__x86_64__)
+  if (kmo_have_avx512()) return fma_rd_avx512(a, b, c);
+#endif
+  return kmo_fma_rd_portable(a, b, c);
+}
+
+/* Kahan step, kmeans.cu:335-340: y=fma_rd(a,b,corr); t=acc+y; corr=y-(t-acc); acc=t */
+#define KAHAN_STEP(FMA, acc, corr, a, b)        \
+  do {                                          \
+    const float y_ = FMA((a), (b), (corr));     \
+    const float t_ = (acc) + y_;                \
+    (corr) = y_ - (t_ - (acc));                 \
+    (acc) = t_;                                 \
+  } while (0)
+
+static float kahan_dot_portable(const float *a, const float *b, uint32_t D) {
+  float acc = 0.f, corr = 0.f;
+  for (uint32_t f = 0; f < D; f++) KAHAN_STEP(kmo_fma_rd_portable, acc, corr, a[f], b[f]);
+  return acc;
+}
+static float kahan_sqdiff_portable(const float *a, const float *b, uint32_t D) {
+  float acc = 0.f, corr = 0.f;
+  for (uint32_t f = 0; f < D; f++) {
+    const float d = a[f] - b[f];
+    KAHAN_STEP(kmo_fma_rd_portable, acc, corr, d, d);
+  }
+  return acc;
+}
+#if defined(__x86_64__)
+__attribute__((target("avx512f"))) static float kahan_dot_avx512(const float *a, const float *b, uint32_t D) {
+  float acc = 0.f, corr = 0.f;
+  for (uint32_t f = 0; f < D; f++) KAHAN_STEP(fma_rd_avx512, acc, corr, a[f], b[f]);
+  return acc;
+}
+__attribute__((target("avx512f"))) static float kahan_sqdiff_avx512(const float *a, const float *b, uint32_t D) {
+  float acc = 0.f, corr = 0.f;
+  for (uint32_t f = 0; f < D; f++) {
+    const float d = a[f] - b[f];
+    KAHAN_STEP(fma_rd_avx512, acc, corr, d, d);
+  }
+  return acc;
+}
+#endif
+
+float kmo_kahan_dot(const float *a, const float *b, uint32_t D) {
+#if defined(__x86_64__)
+  if (kmo_have_avx512()) return kahan_dot_avx512(a, b, D);
+#endif
+  return kahan_dot_portable(a, b, D);
+}
+static float kahan_sqdiff(const float *a, const float *b, uint32_t D) {
+#if defined(__x86_64__)
+  if (kmo_have_avx512()) return kahan_sqdiff_avx512(a, b, D);
+#endif
+  return kahan_sqdiff_portable(a, b, D);
+}
+
+/* metric_abstraction.h:171-177 / :248-253: angular distance from a dot product */
+static float cos_dist_from_prod(float fp) {
+  if (fp >= 1.f) return 0.f;
+  if (fp <= -1.f) return (float)M_PI;
+  return acosf(fp);
+}
+
+/* metric_abstraction.h:59-101 (L2: sqrt of Kahan sum of squared differences),
+ * :179-218 (cos: acos of Kahan dot).  distance, distance_t and distance_tt share it. */
+float kmo_distance(int metric, const float *a, const float *b, uint32_t D) {
+  if (metric == KMO_L2) return sqrtf(kahan_sqdiff(a, b, D));
+  return cos_dist_from_prod(kmo_kahan_dot(a, b, D));
+}
+
+/* metric_abstraction.h:21-36: ssqr = Kahan sum fma_rd(v,v,corr);  :149-158: cos -> 1 */
+void kmo_sum_squares(int metric, uint32_t K, uint32_t D, const float *centroids, float *csqr) {
+  for (uint32_t c = 0; c < K; c++) {
+    csqr[c] = (metric == KMO_L2) ? kmo_kahan_dot(centroids + (size_t)c * D, centroids + (size_t)c * D, D) : 1.f;
+  }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Lloyd assignment, kmeans.cu:293-364                                                   */
+/* ------------------------------------------------------------------------------------ */
+
+/* metric_abstraction.h:55-57: distance(sqr1=0, sqr2=csqr, prod) = fma_rd(-2, prod, 0+csqr) */
+static inline float lloyd_dist_scalar(int metric, float csqr, float prod) {
+  if (metric == KMO_L2) return kmo_fma_rd(-2.f, prod, 0.f + csqr);
+  return cos_dist_from_prod(prod);
+}
+
+static void lloyd_finish_row(uint32_t s, int insane, uint32_t nearest, uint32_t K, uint32_t *assignments,
+                             uint32_t *assignments_prev, uint32_t *changed) {
+  if (nearest == UINT32_MAX) {              /* kmeans.cu:349-357 */
+    if (!insane) return;                    /* "nearest neighbor search failed": leaves everything untouched */
+    nearest = K;
+  }
+  const uint32_t ass = assignments[s];      /* kmeans.cu:358-363 */
+  assignments_prev[s] = ass;
+  if (ass != nearest) {
+    assignments[s] = nearest;
+    (*changed)++;
+  }
+}
+
+static void lloyd_assign_portable(int metric, uint32_t N, uint32_t D, uint32_t K, const float *X,
+                                  const float *C, const float *csqr, uint32_t *asg, uint32_t *prev,
+                                  uint32_t *changed) {
+  uint32_t total = 0;
+#pragma omp parallel for schedule(static) reduction(+ : total)
+  for (uint32_t s = 0; s < N; s++) {
+    const float *x = X + (size_t)s * D;
+    const int insane = (x[0] != x[0]);      /* kmeans.cu:312 */
+    float min_dist = FLT_MAX;
+    uint32_t nearest = UINT32_MAX;
+    if (!insane) {
+      for (uint32_t c = 0; c < K; c++) {
+        const float prod = kahan_dot_portable(x, C + (size_t)c * D, D);
+        const float dist = (metric == KMO_L2) ? kmo_fma_rd_portable(-2.f, prod, 0.f + csqr[c])
+                                              : cos_dist_from_prod(prod);
+        if (dist < min_dist) {              /* strict <, ascending c: first minimum wins */
+          min_dist = dist;
+          nearest = c;
+        }
+      }
+    }
+    uint32_t ch = 0;
+    lloyd_finish_row(s, insane, nearest, K, asg, prev, &ch);
+    total += ch;
+  }
+  *changed += total;
+}
+
+#if defined(__x86_64__)
+/* 16 centroids per vector lane group; CT is the centroid matrix transposed and padded:
+ * CT[f*K16 + c].  Per-lane arithmetic is exactly the scalar chain above. */
+__attribute__((target("avx512f"))) static void lloyd_assign_avx512(
+    int metric, uint32_t N, uint32_t D, uint32_t K, const float *X, const float *CT, uint32_t K16,
+    const float *csqr16, uint32_t *asg, uint32_t *prev, uint32_t *changed) {
+  const int RD = _MM_FROUND_TO_NEG_INF | _MM_FROUND_NO_EXC;
+  uint32_t total = 0;
+#pragma omp parallel for schedule(static) reduction(+ : total)
+  for (uint32_t s = 0; s < N; s++) {
+    const float *x = X + (size_t)s * D;
+    const int insane = (x[0] != x[0]);
+    float min_dist = FLT_MAX;
+    uint32_t nearest = UINT32_MAX;
+    if (!insane) {
+      for (uint32_t cb = 0; cb < K16; cb += 64) {
+        __m512 acc[4], corr[4];
+        const int nv = (K16 - cb) >= 64 ? 4 : (int)((K16 - cb) / 16);
+        for (int v = 0; v < 4; v++) { acc[v] = _mm512_setzero_ps(); corr[v] = _mm512_setzero_ps(); }
+        for (uint32_t f = 0; f < D; f++) {
+          const __m512 xv = _mm512_set1_ps(x[f]);
+          const float *ct = CT + (size_t)f * K16 + cb;
+          for (int v = 0; v < nv; v++) {
+            const __m512 cv = _mm512_loadu_ps(ct + 16 * v);
+            const __m512 y = _mm512_fmadd_round_ps(xv, cv, corr[v], RD);
+            const __m512 t = _mm512_add_ps(acc[v], y);
+            corr[v] = _mm512_sub_ps(y, _mm512_sub_ps(t, acc[v]));
+            acc[v] = t;
+          }
+        }
+        for (int v = 0; v < nv; v++) {
+          float dist[16] __attribute__((aligned(64)));
+          if (metric == KMO_L2) {
+            const __m512 cs = _mm512_add_ps(_mm512_setzero_ps(), _mm512_loadu_ps(csqr16 + cb + 16 * v));
+            _mm512_store_ps(dist, _mm512_fmadd_round_ps(_mm512_set1_ps(-2.f), acc[v], cs, RD));
+          } else {
+            float pr[16] __attribute__((aligned(64)));
+            _mm512_store_ps(pr, acc[v]);
+            for (int j = 0; j < 16; j++) dist[j] = cos_dist_from_prod(pr[j]);
+          }
+          for (int j = 0; j < 16; j++) {
+            const uint32_t c = cb + 16 * v + j;
+            if (c < K && dist[j] < min_dist) {
+              min_dist = dist[j];
+              nearest = c;
+            }
+          }
+        }
+      }
+    }
+    uint32_t ch = 0;
+    lloyd_finish_row(s, insane, nearest, K, asg, prev, &ch);
+    total += ch;
+  }
+  *changed += total;
+}
+#endif
+
+void kmo_lloyd_assign(int metric, uint32_t N, uint32_t D, uint32_t K, const float *samples,
+                      const float *centroids, uint32_t *assignments, uint32_t *assignments_prev,
+                      uint32_t *changed) {
+  float *csqr = (float *)malloc(sizeof(float) * (K + 64));
+  kmo_sum_squares(metric, K, D, centroids, csqr);
+#if defined(__x86_64__)
+  if (kmo_have_avx512()) {
+    const uint32_t K16 = (K + 15) / 16 * 16;
+    float *CT = (float *)calloc((size_t)D * K16, sizeof(float));
+    float *csqr16 = (float *)calloc(K16 + 64, sizeof(float));
+    for (uint32_t c = 0; c < K; c++) {
+      csqr16[c] = csqr[c];
+      for (uint32_t f = 0; f < D; f++) CT[(size_t)f * K16 + c] = centroids[(size_t)c * D + f];
+    }
+    lloyd_assign_avx512(metric, N, D, K, samples, CT, K16, csqr16, assignments, assignments_prev, changed);
+    free(CT);
+    free(csqr16);
+    free(csqr);
+    return;
+  }
+#endif
+  lloyd_assign_portable(metric, N, D, K, samples, centroids, csqr, assignments, assignments_prev, changed);
+  free(csqr);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Centroid update, kmeans.cu:366-429                                                    */
+/* ------------------------------------------------------------------------------------ */
+
+void kmo_adjust(int metric, uint32_t N, uint32_t D, uint32_t K, const float *samples,
+                const uint32_t *assignments_prev, const uint32_t *assignments,
+                float *centroids, uint32_t *ccounts) {
+  /* Per-centroid event lists (sample, sign) in ascending sample order == the serial scan of
+   * kmeans.cu:389-424 restricted to the samples that touch this centroid. */
+  uint32_t *cnt = (uint32_t *)calloc((size_t)K + 1, sizeof(uint32_t));
+  for (uint32_t s = 0; s < N; s++) {
+    const uint32_t p = assignments_prev[s], a = assignments[s];
+    if (p == a) continue;
+    if (p < K) cnt[p + 1]++;
+    if (a < K) cnt[a + 1]++;
+  }
+  for (uint32_t c = 0; c < K; c++) cnt[c + 1] += cnt[c];
+  const uint32_t total = cnt[K];
+  uint32_t *ev = (uint32_t *)malloc(sizeof(uint32_t) * (total ? total : 1));
+  int8_t *sg = (int8_t *)malloc(total ? total : 1);
+  uint32_t *fill = (uint32_t *)malloc(sizeof(uint32_t) * K);
+  memcpy(fill, cnt, sizeof(uint32_t) * K);
+  for (uint32_t s = 0; s < N; s++) {
+    const uint32_t p = assignments_prev[s], a = assignments[s];
+    if (p == a) continue;
+    if (p < K) { ev[fill[p]] = s; sg[fill[p]++] = -1; }
+    if (a < K) { ev[fill[a]] = s; sg[fill[a]++] = 1; }
+  }
+#pragma omp parallel for schedule(dynamic, 4)
+  for (uint32_t c = 0; c < K; c++) {
+    float *cen = centroids + (size_t)c * D;
+    uint32_t my_count = ccounts[c];
+    const float fmy = (float)my_count;                      /* _const<F>(my_count) */
+    for (uint32_t f = 0; f < D; f++) cen[f] = cen[f] * fmy; /* kmeans.cu:381-385 */
+    float corr = 0.f;                                       /* ONE corr for all f and s, :388 */
+    for (uint32_t e = cnt[c]; e < cnt[c + 1]; e++) {
+      const float *x = samples + (size_t)ev[e] * D;
+      const float fsign = (float)sg[e];
+      if (sg[e] < 0) my_count--; else my_count++;
+      for (uint32_t f = 0; f < D; f++) {
+        const float y = kmo_fma_rd(x[f], fsign, corr);
+        const float t = cen[f] + y;
+        corr = y - (t - cen[f]);
+        cen[f] = t;
+      }
+    }
+    if (metric == KMO_L2) {                                 /* metric_abstraction.h:138-144 */
+      const float rc = 1.0f / (float)my_count;
+      for (uint32_t f = 0; f < D; f++) cen[f] = cen[f] * rc;
+    } else {                                                /* metric_abstraction.h:255-272 */
+      float norm = 0.f, ncorr = 0.f;
+      for (uint32_t f = 0; f < D; f++) KAHAN_STEP(kmo_fma_rd, norm, ncorr, cen[f], cen[f]);
+      norm = 1.0f / sqrtf(norm);
+      for (uint32_t f = 0; f < D; f++) cen[f] = cen[f] * norm;
+    }
+    ccounts[c] = my_count;
+  }
+  free(cnt); free(ev); free(sg); free(fill);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Yinyang kernels, kmeans.cu:431-672.  bounds layout: bounds[(1+g)*N + s], bounds[s]=upper */
+/* ------------------------------------------------------------------------------------ */
+
+void kmo_yy_init(int metric, uint32_t N, uint32_t D, uint32_t K, uint32_t G, const float *samples,
+                 const float *centroids, const uint32_t *assignments, const uint32_t *groups,
+                 float *bounds) {
+#pragma omp parallel for schedule(static)
+  for (uint32_t s = 0; s < N; s++) {
+    for (uint32_t i = 0; i < G + 1; i++) bounds[(size_t)N * i + s] = FLT_MAX;
+    const uint32_t nearest = assignments[s];
+    for (uint32_t c = 0; c < K; c++) {
+      const uint32_t group = groups[c];
+      if (group >= G) continue;                            /* NaN centroid, :468-471 */
+      const float dist = kmo_distance(metric, samples + (size_t)s * D, centroids + (size_t)c * D, D);
+      if (c != nearest) {
+        const size_t gi = (size_t)N * (1 + group) + s;
+        if (dist < bounds[gi]) bounds[gi] = dist;
+      } else {
+        bounds[s] = dist;
+      }
+    }
+  }
+}
+
+void kmo_yy_calc_drifts(int metric, uint32_t D, uint32_t K, const float *centroids, float *drifts) {
+  for (uint32_t c = 0; c < K; c++) {
+    drifts[(size_t)K * D + c] = kmo_distance(metric, centroids + (size_t)c * D, drifts + (size_t)c * D, D);
+  }
+}
+
+void kmo_yy_group_max_drifts(uint32_t D, uint32_t K, uint32_t G, const uint32_t *groups, float *drifts) {
+  const size_t doffset = (size_t)K * D;
+  float *gm = (float *)malloc(sizeof(float) * (G ? G : 1));
+  for (uint32_t g = 0; g < G; g++) {
+    float my_max = -FLT_MAX;
+    for (uint32_t c = 0; c < K; c++) {
+      if (groups[c] == g) {
+        const float d = drifts[doffset + c];
+        if (my_max < d) my_max = d;
+      }
+    }
+    gm[g] = my_max;
+  }
+  for (uint32_t g = 0; g < G; g++) drifts[g] = gm[g];      /* overlays old centroids, :537 */
+  free(gm);
+}
+
+uint32_t kmo_yy_global_filter(int metric, uint32_t N, uint32_t D, uint32_t K, uint32_t G,
+                              const float *samples, const float *centroids, const uint32_t *groups,
+                              const float *drifts, const uint32_t *assignments,
+                              uint32_t *assignments_prev, float *bounds, uint32_t *passed) {
+  (void)groups;
+  const size_t doffset = (size_t)K * D;
+  uint8_t *flag = (uint8_t *)calloc(N ? N : 1, 1);
+#pragma omp parallel for schedule(static)
+  for (uint32_t s = 0; s < N; s++) {
+    const uint32_t cluster = assignments[s];
+    assignments_prev[s] = cluster;
+    float upper_bound = bounds[s];
+    const float cluster_drift = drifts[doffset + cluster];
+    upper_bound += cluster_drift;
+    float min_lower_bound = FLT_MAX;
+    for (uint32_t g = 0; g < G; g++) {
+      const size_t gi = (size_t)N * (1 + g) + s;
+      const float lower_bound = bounds[gi] - drifts[g];
+      bounds[gi] = lower_bound;
+      if (lower_bound < min_lower_bound) min_lower_bound = lower_bound;
+    }
+    if (min_lower_bound >= upper_bound) {                  /* group filter try #1 */
+      bounds[s] = upper_bound;
+      continue;
+    }
+    upper_bound = kmo_distance(metric, samples + (size_t)s * D, centroids + (size_t)cluster * D, D);
+    bounds[s] = upper_bound;
+    if (min_lower_bound >= upper_bound) continue;          /* try #2 */
+    flag[s] = 1;
+  }
+  /* The reference appends with a warp-aggregated atomic (order nondeterministic); the passed
+   * list is a set as far as results go (every entry is processed independently). */
+  uint32_t np = 0;
+  for (uint32_t s = 0; s < N; s++) if (flag[s]) passed[np++] = s;
+  free(flag);
+  return np;
+}
+
+uint32_t kmo_yy_local_filter(int metric, uint32_t N, uint32_t D, uint32_t K, uint32_t G,
+                             const float *samples, const uint32_t *passed, uint32_t npassed,
+                             const float *centroids, const uint32_t *groups, const float *drifts,
+                             uint32_t *assignments, float *bounds) {
+  const size_t doffset = (size_t)K * D;
+  uint32_t changed = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : changed)
+  for (uint32_t pi = 0; pi < npassed; pi++) {
+    const uint32_t s = passed[pi];
+    const float upper_bound = bounds[s];
+    const uint32_t cluster = assignments[s];
+    float min_dist = upper_bound, second_min_dist = FLT_MAX;
+    uint32_t nearest = cluster;
+    for (uint32_t c = 0; c < K; c++) {
+      if (c == cluster) continue;
+      const uint32_t group = groups[c];
+      if (group >= G) continue;
+      float lower_bound = bounds[(size_t)N * (1 + group) + s];
+      if (lower_bound >= upper_bound) {
+        if (lower_bound < second_min_dist) second_min_dist = lower_bound;
+        continue;
+      }
+      lower_bound += drifts[group] - drifts[doffset + c];
+      if (second_min_dist < lower_bound) continue;
+      const float dist = kmo_distance(metric, samples + (size_t)s * D, centroids + (size_t)c * D, D);
+      if (dist < min_dist) {
+        second_min_dist = min_dist;
+        min_dist = dist;
+        nearest = c;
+      } else if (dist < second_min_dist) {
+        second_min_dist = dist;
+      }
+    }
+    const uint32_t nearest_group = groups[nearest];
+    const uint32_t previous_group = groups[cluster];
+    bounds[(size_t)N * (1 + nearest_group) + s] = second_min_dist;
+    if (nearest_group != previous_group) {
+      const size_t gi = (size_t)N * (1 + previous_group) + s;
+      const float pb = bounds[gi];
+      if (pb > upper_bound) bounds[gi] = upper_bound;
+    }
+    bounds[s] = min_dist;
+    if (cluster != nearest) {
+      assignments[s] = nearest;
+      changed++;
+    }
+  }
+  return changed;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Seeding, kmcuda.cc:222-336 + kmeans.cu:42-67,774-828                                  */
+/* ------------------------------------------------------------------------------------ */
+
+/* kmeans.cu:42-67: one k-means++ step; returns the sum as the reference forms it:
+ * float butterfly (shfl_down 16..1) over each aligned group of 32 samples, then a double
+ * accumulation of the per-warp sums (atomicAdd on double; order-insensitive to ~1e-16). */
+static double kmpp_step(int metric, uint32_t N, uint32_t D, uint32_t cc, const float *samples,
+                        const float *centroid, float *dists) {
+#pragma omp parallel for schedule(static)
+  for (uint32_t s = 0; s < N; s++) {
+    const float *x = samples + (size_t)s * D;
+    float dist = 0.f;
+    if (x[0] == x[0]) dist = kmo_distance(metric, x, centroid, D);
+    if (cc == 1 || dist < dists[s]) dists[s] = dist;
+  }
+  double sum = 0.0;
+  for (uint32_t base = 0; base < N; base += 32) {
+    float lane[32];
+    for (int l = 0; l < 32; l++) lane[l] = (base + l < N) ? dists[base + l] : 0.f;
+    for (int off = 16; off > 0; off /= 2)
+      for (int l = 0; l < 32; l++)                 /* val += shfl_down(val, off) */
+        lane[l] = lane[l] + ((l + off < 32) ? lane[l + off] : lane[l]);
+    sum += (double)lane[0];
+  }
+  return sum;
+}
+
+int kmo_init_centroids(int method, int metric, uint32_t N, uint32_t D, uint32_t K, uint32_t seed,
+                       const float *samples, float *centroids) {
+  srand(seed);                                               /* kmcuda.cc:222 */
+  if (method == KMO_INIT_IMPORT) return 0;
+  if (method == KMO_INIT_RANDOM) {                           /* kmcuda.cc:245-261 */
+    uint32_t *chosen = (uint32_t *)malloc(sizeof(uint32_t) * N);
+    for (uint32_t s = 0; s < N; s++) chosen[s] = s;
+    /* libstdc++ std::random_shuffle(first,last): for i=1..N-1: swap(a[i], a[rand() % (i+1)]) */
+    for (uint32_t i = 1; i < N; i++) {
+      const uint32_t j = (uint32_t)(rand() % (long)(i + 1));
+      const uint32_t tmp = chosen[i]; chosen[i] = chosen[j]; chosen[j] = tmp;
+    }
+    for (uint32_t c = 0; c < K; c++)
+      memcpy(centroids + (size_t)c * D, samples + (size_t)chosen[c] * D, sizeof(float) * D);
+    free(chosen);
+    return 0;
+  }
+  if (method == KMO_INIT_PLUSPLUS) {                         /* kmcuda.cc:262-336 */
+    uint32_t first_index;
+    float smoke = NAN;
+    while (smoke != smoke) {
+      first_index = (uint32_t)(rand() % (long)N);
+      smoke = samples[(size_t)first_index * D];              /* feature 0 of that sample */
+    }
+    memcpy(centroids, samples + (size_t)first_index * D, sizeof(float) * D);
+    float *host_dists = (float *)malloc(sizeof(float) * N);
+    for (uint32_t i = 1; i < K; i++) {
+      const double dist_sum = kmpp_step(metric, N, D, i, samples, centroids + (size_t)(i - 1) * D, host_dists);
+      const double choice = ((rand() + .0) / RAND_MAX);
+      const uint32_t choice_approx = (uint32_t)(choice * N);
+      const double choice_sum = choice * dist_sum;
+      uint32_t j;
+      if (choice_approx < 100) {
+        double dist_sum2 = 0;
+        for (j = 0; j < N && dist_sum2 < choice_sum; j++) dist_sum2 += host_dists[j];
+      } else {
+        double dist_sum2 = 0;
+        for (uint32_t t = 0; t < choice_approx; t++) dist_sum2 += host_dists[t];
+        if (dist_sum2 < choice_sum) {
+          for (j = choice_approx; j < N && dist_sum2 < choice_sum; j++) dist_sum2 += host_dists[j];
+        } else {
+          for (j = choice_approx; j > 1 && dist_sum2 >= choice_sum; j--) dist_sum2 -= host_dists[j];
+          j++;
+        }
+      }
+      if (j == 0 || j > N) { free(host_dists); return 2; }
+      memcpy(centroids + (size_t)i * D, samples + (size_t)(j - 1) * D, sizeof(float) * D);
+    }
+    free(host_dists);
+    return 0;
+  }
+  return 3; /* AFK-MC2 is out of scope (cuRAND-bound) */
+}
+
+/* kmeans.cu:674-691: float warp butterfly sums, double accumulation, / N */
+float kmo_average_distance(int metric, uint32_t N, uint32_t D, const float *samples,
+                           const float *centroids, const uint32_t *assignments) {
+  float *d = (float *)malloc(sizeof(float) * (N ? N : 1));
+#pragma omp parallel for schedule(static)
+  for (uint32_t s = 0; s < N; s++)
+    d[s] = kmo_distance(metric, samples + (size_t)s * D, centroids + (size_t)assignments[s] * D, D);
+  double sum = 0.0;
+  for (uint32_t base = 0; base < N; base += 32) {
+    float lane[32];
+    for (int l = 0; l < 32; l++) lane[l] = (base + l < N) ? d[base + l] : 0.f;
+    for (int off = 16; off > 0; off /= 2)
+      for (int l = 0; l < 32; l++) lane[l] = lane[l] + ((l + off < 32) ? lane[l + off] : lane[l]);
+    sum += (double)lane[0];
+  }
+  free(d);
+  return (float)(sum / N);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Drivers, kmeans.cu:934-1263                                                           */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct {
+  uint32_t *log; uint32_t cap; uint32_t n;
+} iterlog_t;
+
+static void log_iter(iterlog_t *L, uint32_t changed) {
+  if (L && L->log && L->n < L->cap) L->log[L->n] = changed;
+  if (L) L->n++;
+}
+
+/* kmeans.cu:697-717: returns 1 to stop */
+static int check_changed(float tolerance, uint32_t N, uint32_t *changed, iterlog_t *L, int print) {
+  if (print) log_iter(L, *changed);
+  if (*changed <= tolerance * N) return 1;     /* float * uint32 in float, :707; NOT zeroed */
+  *changed = 0;
+  return 0;
+}
+
+/* kmeans.cu:934-1026 */
+static int lloyd_loop(float tolerance, int metric, uint32_t N, uint32_t D, uint32_t K, int resume,
+                      const float *samples, float *centroids, uint32_t *ccounts, uint32_t *prev,
+                      uint32_t *asg, uint32_t *changed, iterlog_t *L) {
+  *changed = 0;                                 /* prepare_mem, :719-746 */
+  if (!resume) {
+    memset(ccounts, 0, sizeof(uint32_t) * K);
+    memset(asg, 0xff, sizeof(uint32_t) * N);
+    memset(prev, 0xff, sizeof(uint32_t) * N);
+  }
+  for (int iter = 1;; iter++) {
+    if (!resume || iter > 1) {
+      kmo_lloyd_assign(metric, N, D, K, samples, centroids, asg, prev, changed);
+      if (check_changed(tolerance, N, changed, L, 1)) return iter;
+    }
+    kmo_adjust(metric, N, D, K, samples, prev, asg, centroids, ccounts);
+  }
+}
+
+int kmo_kmeans(int init, float tolerance, float yinyang_t, int metric, uint32_t N, uint32_t D,
+               uint32_t K, uint32_t seed, const float *samples, float *centroids,
+               uint32_t *assignments, float *average_distance,
+               uint32_t *iter_log, uint32_t iter_log_cap, uint32_t *n_iter_log) {
+  /* kmcuda.cc:19-61 */
+  if (K < 2 || K == UINT32_MAX || D == 0 || N < K) return 1;
+  if (!samples || !centroids || !assignments) return 1;
+  if (tolerance < 0 || tolerance > 1) return 1;
+  if (yinyang_t < 0 || yinyang_t > 0.5) return 1;
+  iterlog_t L = {iter_log, iter_log_cap, 0};
+  const uint32_t G = (uint32_t)(yinyang_t * K);             /* kmcuda.cc:417, float product */
+  uint32_t *prev = (uint32_t *)malloc(sizeof(uint32_t) * N);
+  uint32_t *ccounts = (uint32_t *)malloc(sizeof(uint32_t) * K);
+  uint32_t changed = 0;
+  int rc = kmo_init_centroids(init, metric, N, D, K, seed, samples, centroids);
+  if (rc) { free(prev); free(ccounts); return rc; }
+
+  if (G == 0 || 0.11 <= tolerance) {                         /* kmeans.cu:1037-1050 */
+    lloyd_loop(tolerance, metric, N, D, K, 0, samples, centroids, ccounts, prev, assignments, &changed, &L);
+  } else {
+    int iter = lloyd_loop(0.11f, metric, N, D, K, 0, samples, centroids, ccounts, prev, assignments,
+                          &changed, &L);                     /* :1054-1057 */
+    if (!check_changed(tolerance, N, &changed, &L, 0)) {     /* :1058 */
+      /* groups: k-means++(seed 0) + Lloyd(tol .02) on the centroids themselves, :1062-1100 */
+      uint32_t *groups = (uint32_t *)malloc(sizeof(uint32_t) * K);
+      float *cyy = (float *)malloc(sizeof(float) * (size_t)G * D);
+      {
+        uint32_t *gprev = (uint32_t *)malloc(sizeof(uint32_t) * K);
+        uint32_t *gcnt = (uint32_t *)malloc(sizeof(uint32_t) * G);
+        uint32_t gchanged = 0;
+        kmo_init_centroids(KMO_INIT_PLUSPLUS, metric, K, D, G, 0, centroids, cyy);
+        lloyd_loop(0.02f, metric, K, D, G, 0, centroids, cyy, gcnt, gprev, groups, &gchanged, &L);
+        free(gprev); free(gcnt);
+      }
+      float *bounds = (float *)malloc(sizeof(float) * (size_t)N * (G + 1));
+      float *drifts = (float *)malloc(sizeof(float) * ((size_t)K * D + K));
+      uint32_t *passed = (uint32_t *)malloc(sizeof(uint32_t) * N);
+      changed = 0;                                           /* prepare_mem(resume=true) */
+      int refresh = 1;
+      uint32_t npassed = 0;
+      for (;; iter++) {                                      /* :1119-1262 */
+        if (!refresh) {
+          if (check_changed(tolerance, N, &changed, &L, 1)) break;
+          if (1.f - (npassed + 0.f) / N < 1e-4) refresh = 1; /* YINYANG_REFRESH_EPSILON, :1136 */
+        }
+        if (refresh) {
+          kmo_yy_init(metric, N, D, K, G, samples, centroids, assignments, groups, bounds);
+          refresh = 0;
+        }
+        memcpy(drifts, centroids, sizeof(float) * (size_t)K * D);
+        kmo_adjust(metric, N, D, K, samples, prev, assignments, centroids, ccounts);
+        kmo_yy_calc_drifts(metric, D, K, centroids, drifts);
+        kmo_yy_group_max_drifts(D, K, G, groups, drifts);
+        npassed = kmo_yy_global_filter(metric, N, D, K, G, samples, centroids, groups, drifts,
+                                       assignments, prev, bounds, passed);
+        changed += kmo_yy_local_filter(metric, N, D, K, G, samples, passed, npassed, centroids,
+                                       groups, drifts, assignments, bounds);
+      }
+      free(groups); free(cyy); free(bounds); free(drifts); free(passed);
+    }
+  }
+  if (average_distance)
+    *average_distance = kmo_average_distance(metric, N, D, samples, centroids, assignments);
+  if (n_iter_log) *n_iter_log = L.n;
+  free(prev); free(ccounts);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* k-NN, knn.cu + kmcuda.cc:648-691                                                      */
+/* ------------------------------------------------------------------------------------ */
+
+/* kmcuda.cc:648-691: std::sort of (cluster, index) tuples => members ascending by index;
+ * offsets[c] .. offsets[c+1].  Assignments >= K (NaN samples) sort last and are dropped by
+ * the offsets construction (offsets[K] = first index with cluster >= K ... the reference sets
+ * offsets[icls]=s for icls<=newcls<=K only when newcls<=K; with newcls==K offsets[K]=s). */
+void kmo_knn_inverse(uint32_t N, uint32_t K, const uint32_t *assignments, uint32_t *inv, uint32_t *offsets) {
+  uint32_t *cnt = (uint32_t *)calloc((size_t)K + 2, sizeof(uint32_t));
+  for (uint32_t s = 0; s < N; s++) { const uint32_t a = assignments[s] < K ? assignments[s] : K; cnt[a + 1]++; }
+  for (uint32_t c = 0; c <= K; c++) cnt[c + 1] += cnt[c];
+  for (uint32_t c = 0; c <= K; c++) offsets[c] = cnt[c];
+  uint32_t *fill = (uint32_t *)malloc(sizeof(uint32_t) * (K + 1));
+  memcpy(fill, cnt, sizeof(uint32_t) * (K + 1));
+  for (uint32_t s = 0; s < N; s++) { const uint32_t a = assignments[s] < K ? assignments[s] : K; inv[fill[a]++] = s; }
+  free(cnt); free(fill);
+}
+
+/* metric_abstraction.h:103-136 / :220-253: partial / finalize */
+static float knn_partial(int metric, const float *a, const float *b, uint32_t n) {
+  if (metric == KMO_L2) return kahan_sqdiff(a, b, n);
+  return kmo_kahan_dot(a, b, n);
+}
+static float knn_finalize(int metric, float p) {
+  if (metric == KMO_L2) return sqrtf(p);
+  return cos_dist_from_prod(p);
+}
+
+/* knn.cu:19-58: chunks of cent_step=min(8192/512, D) features, sample_dists += partial */
+void kmo_knn_radiuses(int metric, uint32_t N, uint32_t D, uint32_t K, const float *samples,
+                      const float *centroids, const uint32_t *inv, const uint32_t *offsets, float *radiuses) {
+  (void)N;
+  const uint32_t cent_step = D < 16 ? D : 16;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (uint32_t ci = 0; ci < K; ci++) {
+    float max_dist = -1.f;
+    for (uint32_t a = offsets[ci]; a < offsets[ci + 1]; a++) {
+      const float *x = samples + (size_t)inv[a] * D;
+      float sd = 0.f;
+      for (uint32_t cfi = 0; cfi < D; cfi += cent_step) {
+        const uint32_t fsize = (D - cfi) < cent_step ? (D - cfi) : cent_step;
+        sd += knn_partial(metric, x + cfi, centroids + (size_t)ci * D + cfi, fsize);
+      }
+      const float dist = knn_finalize(metric, sd);
+      if (dist > max_dist) max_dist = dist;
+    }
+    radiuses[ci] = max_dist > -1.f ? max_dist : NAN;
+  }
+}
+
+/* knn.cu:61-131: fstep = 12288/512 = 24-feature chunks, distances += partial; finalize; mirror */
+void kmo_knn_cluster_distances(int metric, uint32_t D, uint32_t K, const float *centroids, float *dists) {
+  const uint32_t fstep = 24;
+#pragma omp parallel for schedule(static)
+  for (uint32_t i = 0; i < K; i++) {
+    for (uint32_t j = 0; j < K; j++) {
+      float acc = 0.f;
+      for (uint32_t fpos = 0; fpos < D; fpos += fstep) {
+        const uint32_t fsize = (D - fpos) < fstep ? (D - fpos) : fstep;
+        acc += knn_partial(metric, centroids + (size_t)i * D + fpos, centroids + (size_t)j * D + fpos, fsize);
+      }
+      dists[(size_t)i * K + j] = knn_finalize(metric, acc);
+    }
+  }
+}
+
+/* knn.cu:133-175 */
+static void push_sample(uint32_t k, float dist, uint32_t index, float *heap) {
+  uint32_t pos = 0;
+  uint32_t *heapi = (uint32_t *)heap;
+  for (;;) {
+    float left = 0, right = 0;
+    int left_le, right_le;
+    if ((2 * pos + 1) < k) { left = heap[4 * pos + 2]; left_le = dist >= left; } else left_le = 1;
+    if ((2 * pos + 2) < k) { right = heap[4 * pos + 4]; right_le = dist >= right; } else right_le = 1;
+    if (left_le && right_le) {
+      heap[2 * pos] = dist;
+      heapi[2 * pos + 1] = index;
+      break;
+    }
+    if (!left_le && !right_le) {
+      if (left <= right) {
+        heap[2 * pos] = right; heapi[2 * pos + 1] = heapi[4 * pos + 5]; pos = 2 * pos + 2;
+      } else {
+        heap[2 * pos] = left; heapi[2 * pos + 1] = heapi[4 * pos + 3]; pos = 2 * pos + 1;
+      }
+    } else if (left_le) {
+      heap[2 * pos] = right; heapi[2 * pos + 1] = heapi[4 * pos + 5]; pos = 2 * pos + 2;
+    } else {
+      heap[2 * pos] = left; heapi[2 * pos + 1] = heapi[4 * pos + 3]; pos = 2 * pos + 1;
+    }
+  }
+}
+
+/* knn.cu:177-243 (knn_assign_shmem; the gmem variant yields the same list) */
+int kmo_knn(uint32_t k, int metric, uint32_t N, uint32_t D, uint32_t K, const float *samples,
+            const float *centroids, const uint32_t *assignments, uint32_t *neighbors,
+            uint64_t *dists_calced) {
+  if (k == 0 || K < 2 || D == 0 || N < K) return 1;
+  uint32_t *inv = (uint32_t *)malloc(sizeof(uint32_t) * N);
+  uint32_t *offsets = (uint32_t *)malloc(sizeof(uint32_t) * (K + 2));
+  float *radiuses = (float *)malloc(sizeof(float) * K);
+  float *cdist = (float *)malloc(sizeof(float) * (size_t)K * K);
+  kmo_knn_inverse(N, K, assignments, inv, offsets);
+  kmo_knn_radiuses(metric, N, D, K, samples, centroids, inv, offsets, radiuses);
+  kmo_knn_cluster_distances(metric, D, K, centroids, cdist);
+  uint64_t calced = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : calced)
+  for (uint32_t s = 0; s < N; s++) {
+    float *heap = (float *)malloc(sizeof(float) * 2 * k);
+    const float *x = samples + (size_t)s * D;
+    const uint32_t mycls = assignments[s];
+    const float mydist = kmo_distance(metric, x, centroids + (size_t)mycls * D, D);
+    float mndist = FLT_MAX;
+    for (uint32_t i = 0; i < k; i++) { heap[2 * i] = FLT_MAX; ((uint32_t *)heap)[2 * i + 1] = 0; }
+    calced += offsets[mycls + 1] - offsets[mycls];
+    for (uint32_t pos = offsets[mycls]; pos < offsets[mycls + 1]; pos++) {
+      const uint32_t other = inv[pos];
+      if (other == s) continue;
+      const float dist = kmo_distance(metric, x, samples + (size_t)other * D, D);
+      if (dist <= mndist) { push_sample(k, dist, other, heap); mndist = heap[0]; }
+    }
+    for (uint32_t cls = 0; cls < K; cls++) {
+      if (cls == mycls) continue;
+      const float cd = cdist[(size_t)cls * K + mycls];
+      if (cd != cd) continue;
+      const float lim = cd - mydist - radiuses[cls];
+      if (lim > mndist) continue;
+      calced += offsets[cls + 1] - offsets[cls];
+      for (uint32_t pos = offsets[cls]; pos < offsets[cls + 1]; pos++) {
+        const uint32_t other = inv[pos];
+        const float dist = kmo_distance(metric, x, samples + (size_t)other * D, D);
+        if (dist <= mndist) { push_sample(k, dist, other, heap); mndist = heap[0]; }
+      }
+    }
+    for (int i = (int)k - 1; i >= 0; i--) {
+      neighbors[(size_t)s * k + i] = ((uint32_t *)heap)[1];
+      push_sample(k, -1.f, UINT32_MAX, heap);
+    }
+    free(heap);
+  }
+  if (dists_calced) *dists_calced = calced;
+  free(inv); free(offsets); free(radiuses); free(cdist);
+  return 0;
+}

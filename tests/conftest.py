@@ -1,0 +1,31 @@
+import os
+import sys
+
+import numpy
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def reference_fixture():
+    """The 13000x2 fixture of the reference's own tests (src/test.py:158-169, :581-592)."""
+    numpy.random.seed(0)
+    arr = numpy.empty((13000, 2), dtype=numpy.float32)
+    arr[:2000] = numpy.random.rand(2000, 2) + [0, 0.5]
+    arr[2000:4000] = numpy.random.rand(2000, 2) + [0, 1.5]
+    arr[4000:6000] = numpy.random.rand(2000, 2) - [0, 0.5]
+    arr[6000:8000] = numpy.random.rand(2000, 2) + [0.5, 0]
+    arr[8000:10000] = numpy.random.rand(2000, 2) - [0.5, 0]
+    arr[10000:] = numpy.random.rand(3000, 2) * 5 - [2, 2]
+    return arr
+
+
+@pytest.fixture(scope="session")
+def fixture13k():
+    return reference_fixture()

@@ -1,0 +1,155 @@
+"""Pins the CPU oracle on the reference's own known-answer tests (src/test.py).
+
+The reference cannot run here (CUDA-only), so these pins -- iteration counts parsed from the
+"iteration N: M reassignments" lines, scikit-learn agreement thresholds, exact k-NN equality with
+sklearn -- are what ties oracle/kmcuda_oracle.c to the reference's behaviour."""
+import numpy
+import pytest
+
+import oracle
+from conftest import reference_fixture
+
+
+def _validate(samples, centroids, assignments, tolerance):
+    # test.py:171-183
+    from sklearn.cluster import KMeans
+    nxt = KMeans(50, max_iter=1, init=centroids, n_init=1).fit_predict(samples)
+    assert (assignments != nxt).sum() / len(samples) < tolerance
+
+
+def test_fma_rd_known_answer():
+    # 0.1f*0.1f rounded down = 0x3c23d70a (RN gives 0x3c23d70b)
+    r = numpy.float32(oracle.fma_rd(numpy.float32(0.1), numpy.float32(0.1), 0.0))
+    assert r.view(numpy.uint32) == 0x3C23D70A
+    r = numpy.float32(oracle.fma_rd_portable(numpy.float32(0.1), numpy.float32(0.1), 0.0))
+    assert r.view(numpy.uint32) == 0x3C23D70A
+
+
+def test_fma_rd_portable_matches_hw():
+    if not oracle.lib().kmo_have_avx512():
+        pytest.skip("no AVX-512 embedded rounding on this host")
+    rs = numpy.random.RandomState(1)
+    vals = numpy.concatenate([
+        rs.randn(3000).astype(numpy.float32),
+        (rs.randn(3000) * 1e-20).astype(numpy.float32),
+        (rs.randn(3000) * 1e20).astype(numpy.float32),
+        numpy.array([0.0, -0.0, 1.0, -1.0, numpy.inf, -numpy.inf, 1e-45, -1e-45, 3.4e38, -3.4e38,
+                     1.17549435e-38], numpy.float32)])
+    a = rs.choice(vals, 20000)
+    b = rs.choice(vals, 20000)
+    c = rs.choice(vals, 20000)
+    # exact cancellations exercise the -0 rule
+    a[:100] = 1.0
+    c[:100] = -b[:100]
+    for x, y, z in zip(a, b, c):
+        hw = numpy.float32(oracle.fma_rd(x, y, z))
+        sw = numpy.float32(oracle.fma_rd_portable(x, y, z))
+        if hw != hw:
+            assert sw != sw
+        else:
+            assert hw.view(numpy.uint32) == sw.view(numpy.uint32), (x, y, z, hw, sw)
+
+
+def test_random_lloyd_7(fixture13k):
+    # test.py:207-218
+    c, a, log = oracle.kmeans(fixture13k, 50, init="random", seed=3, tolerance=0.05, yinyang_t=0)
+    assert list(log) == [13000, 2548, 1395, 1079, 871, 698, 616]
+    assert c.shape == (50, 2) and a.shape == (13000,)
+    _validate(fixture13k, c, a, 0.05)
+
+
+def test_kmeanspp_lloyd_4(fixture13k):
+    # test.py:220-226
+    c, a, log = oracle.kmeans(fixture13k, 50, init="kmeans++", seed=3, tolerance=0.05, yinyang_t=0)
+    assert len(log) == 4
+    _validate(fixture13k, c, a, 0.05)
+
+
+def test_kmeanspp_yinyang_15_3(fixture13k):
+    # test.py:228-234
+    c, a, log = oracle.kmeans(fixture13k, 50, init="kmeans++", seed=3, tolerance=0.01, yinyang_t=0.1)
+    assert len(log) == 15 + 3
+    _validate(fixture13k, c, a, 0.01)
+
+
+def test_yinyang_equals_lloyd_outcome(fixture13k):
+    # Yinyang only prunes distance evaluations; on the fixture it lands where Lloyd lands.
+    c1, a1, log1 = oracle.kmeans(fixture13k, 50, init="kmeans++", seed=3, tolerance=0.01, yinyang_t=0.1)
+    c2, a2, log2 = oracle.kmeans(fixture13k, 50, init="kmeans++", seed=3, tolerance=0.01, yinyang_t=0)
+    assert len(log2) == 15
+    assert (a1 != a2).mean() < 0.002
+
+
+def test_import_lloyd_8(fixture13k):
+    # test.py:236-246
+    c, a, log1 = oracle.kmeans(fixture13k, 50, init="random", seed=3, tolerance=0.25, yinyang_t=0)
+    c, a, log2 = oracle.kmeans(fixture13k, 50, init=c, seed=3, tolerance=0.05, yinyang_t=0)
+    assert len(log1) + len(log2) == 8
+    _validate(fixture13k, c, a, 0.05)
+
+
+def test_cosine_metric_5():
+    # test.py:426-448 and the README's printed log (README.md:300-306)
+    numpy.random.seed(0)
+    arr = numpy.empty((10000, 2), dtype=numpy.float32)
+    angs = numpy.random.rand(10000) * 2 * numpy.pi
+    for i in range(10000):
+        arr[i] = numpy.sin(angs[i]), numpy.cos(angs[i])
+    c, a, log = oracle.kmeans(arr, 4, init="kmeans++", metric="cos", seed=3)
+    assert list(log) == [10000, 926, 416, 187, 87]
+    for row in c:
+        assert 0.9999 < numpy.linalg.norm(row) < 1.0001
+    from sklearn.metrics.pairwise import cosine_distances
+    dists = numpy.round(cosine_distances(c)).astype(int)
+    assert (dists == [[0, 2, 1, 1], [2, 0, 1, 1], [1, 1, 0, 2], [1, 1, 2, 0]]).all()
+    assert a.min() == 0 and a.max() == 3
+
+
+def test_256_features_cosine_yinyang_9():
+    # test.py:459-466
+    numpy.random.seed(0)
+    arr = numpy.random.rand(1000, 256).astype(numpy.float32)
+    arr /= numpy.linalg.norm(arr, axis=1)[:, None]
+    c, a, log = oracle.kmeans(arr, 10, init="kmeans++", metric="cos", yinyang_t=0.1, seed=3)
+    assert len(log) == 9
+
+
+def test_average_distance(fixture13k):
+    # test.py:562-577
+    c, a, log, dist = oracle.kmeans(fixture13k, 50, init="kmeans++", seed=3, tolerance=0.05,
+                                    yinyang_t=0, average_distance=True)
+    valid = numpy.linalg.norm(fixture13k - c[a], axis=1).astype(numpy.float64).mean()
+    assert abs(valid - dist) < 1e-6
+
+
+def test_knn_equals_sklearn(fixture13k):
+    # test.py:594-615: exact equality for k=10, <= 2 mismatches for k=50
+    from sklearn.neighbors import NearestNeighbors
+    c, a, _ = oracle.kmeans(fixture13k, 50, seed=777)
+    nb, calced = oracle.knn(10, fixture13k, c, a)
+    bn = NearestNeighbors(n_neighbors=10).fit(fixture13k).kneighbors()[1]
+    assert (nb != bn).sum() == 0
+    assert 0 < calced < 13000 * 13000
+    nb, _ = oracle.knn(50, fixture13k, c, a)
+    bn = NearestNeighbors(n_neighbors=50).fit(fixture13k).kneighbors()[1]
+    assert (nb != bn).sum() <= 2
+
+
+def test_knn_large_property():
+    # test.py:653-699 scaled to 8000x48/K=160 so the CPU suite stays fast
+    rs = numpy.random.RandomState(0)
+    samples = rs.rand(8000, 48).astype(numpy.float32)
+    samples[:2000] += 1.0
+    samples[2000:4000] -= 1.0
+    samples[4000:6000, 0] += 2.0
+    samples[6000:, 0] -= 2.0
+    c, a, _ = oracle.kmeans(samples, 160, seed=777)
+    nb, _ = oracle.knn(10, samples, c, a)
+    for i in range(0, 8000, 97):
+        sn = nb[i]
+        d = numpy.linalg.norm(samples[i] - samples[sn], axis=1)
+        assert (d[:-1] - d[1:] <= 3e-7).all()
+        for r in rs.randint(0, 8000, 50):
+            if r == i or r in set(sn):
+                continue
+            assert d[-1] <= numpy.linalg.norm(samples[i] - samples[r])
