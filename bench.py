@@ -1,0 +1,147 @@
+#!/usr/bin/env python
+"""bench.py -- point-assignments/sec per Lloyd iteration, 8M x 256 fp32 L2 @ K=1024.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full Lloyd iteration over the (row-sharded) synthetic batch: centroid prep,
+MFMA filter + exact refinement (bit-identical assignments), move-delta reduction, the fused
+all-reduce (N > 1) and the centroid update.  Inputs are resident in HBM before timing starts.
+STRONG scaling: the 8M rows are split over the N ranks.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def cpu_baseline(features, clusters, budget_s=12.0):
+    """The oracle (plain-C port of the reference's Lloyd assignment) on this box's host cores,
+    on a bounded sample of the same workload."""
+    import numpy
+    import oracle
+    rs = numpy.random.RandomState(0)
+    cores = os.cpu_count() or 1
+    cen = rs.rand(clusters, features).astype(numpy.float32)
+    probe = rs.rand(2048, features).astype(numpy.float32)
+    t0 = time.time()
+    oracle.lloyd_assign(probe, cen)
+    dt = max(time.time() - t0, 1e-3)
+    rows = int(min(max(2048 * budget_s / dt, 2048), 400000))
+    x = rs.rand(rows, features).astype(numpy.float32)
+    t0 = time.time()
+    oracle.lloyd_assign(x, cen)
+    dt = time.time() - t0
+    return {"value": rows / dt, "unit": "point-assignments/s", "cores": cores, "kind": "port",
+            "sample": "%d x %d rows of the same uniform data vs K=%d, one kmeans_assign_lloyd pass of "
+                      "oracle/kmcuda_oracle.c (OpenMP, %s), %.1f s" %
+                      (rows, features, clusters, "AVX-512 round-down FMA" if oracle.lib().kmo_have_avx512()
+                       else "portable round-down FMA", dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--samples", type=int, default=8000000)
+    ap.add_argument("--features", type=int, default=256)
+    ap.add_argument("--clusters", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from kmcuda_amd.distributed import HipBackend, ShardedLloyd, row_block
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    N, D, K = args.samples, args.features, args.clusters
+    lo, hi = row_block(N, rank, world)
+    n_local = hi - lo
+    # synthetic uniform [0,1) rows (the reference's own benchmark data, README.md:206-207),
+    # generated on device in chunks; per-rank seed so shards differ
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    samples = torch.empty((n_local, D), dtype=torch.float32, device=dev)
+    chunk = 1 << 20
+    for s in range(0, n_local, chunk):
+        e = min(n_local, s + chunk)
+        samples[s:e].uniform_(0.0, 1.0, generator=gen)
+    backend = HipBackend(samples, K, "L2", device_index=local_rank)
+    loop = ShardedLloyd(backend, N)
+    # init="random": K sample rows of rank 0 (replicated by broadcast)
+    perm = torch.randperm(n_local, generator=gen, device=dev)[:K]
+    loop.set_centroids(samples[perm].clone())
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        loop.step()
+    backend.engine.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loop.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = backend.engine.profile_read()
+    backend.engine.profile(False)
+    flagged = backend.engine.counters()[1]
+    changed_last = loop.changed_last()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = N / (elapsed / args.steps)
+        launches = max(prof["filter_launches"], 1)
+        filter_ms = prof["filter_ms"] / launches
+        flops = 2.0 * D * K * n_local                      # algorithmic flop of one filter launch
+        achieved = flops / (filter_ms * 1e-3) / 1e12 if filter_ms > 0 else 0.0
+        out = {
+            "metric": "point-assignments/sec per Lloyd iter (8Mx256@1024)",
+            "value": value, "unit": "point-assignments/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%dx%d fp32 L2 Lloyd iteration, K=%d, uniform[0,1) rows, init=random; "
+                                   "rows sharded %d-way" % (N, D, K, world),
+                       "samples": N, "features": D, "clusters": K, "parallelism": "rows/%d" % world},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": None, "kernel": "lloyd_filter_kernel<256,true>",
+                         "kernel_ms": filter_ms, "rows_per_launch": n_local},
+            "breakdown_ms_per_step": {"filter": filter_ms, "exact_refine": prof["exact_ms"] / launches,
+                                      "update": prof["update_ms"] / launches},
+            "rows_refined_exactly_last_step": flagged, "reassigned_last_step": changed_last,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(D, K)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

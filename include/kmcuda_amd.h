@@ -1,0 +1,78 @@
+/*
+ * kmcuda_amd.h -- step-level C ABI of the MI355X engine behind kmeans_cuda()/knn_cuda().
+ *
+ * The reference keeps these steps private (src/private.h:304-404: kmeans_cuda_setup,
+ * kmeans_cuda_lloyd, kmeans_cuda_yy, knn_cuda_calc, cuda_transpose ...) and drives all GPUs
+ * from one process with peer copies.  Row-sharded, one-process-per-GPU operation (RCCL
+ * all-reduce of the per-iteration centroid deltas between kmamd_move_deltas and
+ * kmamd_apply_delta) needs them exported.  Plain pointers and sizes only; every pointer
+ * argument is a DEVICE pointer on the engine's GPU unless it says "host".
+ * All calls return a KMCUDAResult code (kmcuda.h) and enqueue on the engine's stream.
+ */
+#ifndef KMCUDA_AMD_H
+#define KMCUDA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kmamd_engine kmamd_engine;
+
+/* Creates the per-GPU workspace for n_rows local rows (reference: the allocations of
+ * kmcuda.cc:423-470 + kmeans_cuda_setup kmeans.cu:750-772).  hip_stream may be NULL (the
+ * engine then creates its own); pass torch's current stream to order with framework work. */
+int kmamd_engine_create(kmamd_engine **out, int device, uint32_t n_rows, uint32_t features,
+                        uint32_t clusters, int metric, int fp16x2, void *hip_stream);
+void kmamd_engine_destroy(kmamd_engine *e);
+void *kmamd_engine_stream(kmamd_engine *e);
+int kmamd_engine_sync(kmamd_engine *e);
+
+/* One assignment pass over the local rows (reference: kmeans_assign_lloyd, kmeans.cu:293-364,
+ * incl. assignments_prev bookkeeping and the changed counter).  Bit-identical assignments. */
+int kmamd_lloyd_assign(kmamd_engine *e, const float *samples, const float *centroids,
+                       uint32_t *assignments, uint32_t *assignments_prev);
+/* Same pass, reference arithmetic only (no matrix-core filter): the in-library cross-check. */
+int kmamd_lloyd_assign_exact(kmamd_engine *e, const float *samples, const float *centroids,
+                             uint32_t *assignments, uint32_t *assignments_prev);
+
+/* counters: [0] reassigned rows since the last reset (d_changed_number, kmeans.cu:31),
+ * [1] rows the filter handed to the exact kernel, [2] Yinyang passed rows (d_passed_number),
+ * [3] spare.  read = sync + copy to a host array; reset zeroes [0..3] (or one of them). */
+int kmamd_counters_read(kmamd_engine *e, uint32_t *host_out4);
+int kmamd_counters_reset(kmamd_engine *e, int which /* -1: all */);
+
+/* Device-side export for a FUSED all-reduce buffer: dst[0..K) = (double)dcount[c],
+ * dst[K + i] = (double)counters[i], i = 0..3.  Lets a row-sharded driver reduce
+ * [delta | dcount | changed] in ONE collective per iteration (dcount/counters are exact in fp64). */
+int kmamd_pack_reduce_tail(kmamd_engine *e, const int32_t *dcount, double *dst);
+/* inverse: dcount[c] = (int32) src[c] */
+int kmamd_unpack_dcount(kmamd_engine *e, const double *src, int32_t *dcount);
+
+/* Centroid update, split for the all-reduce (reference: kmeans_adjust, kmeans.cu:366-429):
+ * move_deltas: delta[K*D] (fp64) = sum(moved-in rows) - sum(moved-out rows), dcount[K];
+ * apply_delta: centroids = normalize(centroids*ccounts + delta), ccounts += dcount. */
+int kmamd_move_deltas(kmamd_engine *e, const float *samples, const uint32_t *assignments_prev,
+                      const uint32_t *assignments, double *delta, int32_t *dcount);
+int kmamd_apply_delta(kmamd_engine *e, const double *delta, const int32_t *dcount,
+                      float *centroids, uint32_t *ccounts);
+
+/* out[c][r] = in[r][c], 4-byte elements (reference: cuda_transpose, transpose.cu:83-117). */
+int kmamd_transpose(kmamd_engine *e, const float *in, uint32_t rows, uint32_t cols, float *out);
+
+/* Timing of the dominant kernel on the engine's own stream (HIP events): start/stop bracket
+ * the next lloyd filter launches; elapsed returns the summed milliseconds and launch count. */
+int kmamd_profile_reset(kmamd_engine *e);
+int kmamd_profile_read(kmamd_engine *e, double *filter_ms, uint32_t *filter_launches,
+                       double *exact_ms, double *update_ms);
+int kmamd_profile_enable(kmamd_engine *e, int on);
+
+/* Library identification: returns the gfx arch string this library was compiled for. */
+const char *kmamd_build_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMCUDA_AMD_H */

@@ -1,0 +1,87 @@
+"""ctypes loader for the HIP library (kmcuda_amd/libKMCUDA.so).
+
+There is NO fallback: if the gfx950 library is missing or does not load, importing the step
+API raises.  Build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C kmcuda_amd/csrc`.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libKMCUDA.so")
+
+u32, i32, f32 = ctypes.c_uint32, ctypes.c_int32, ctypes.c_float
+vp = ctypes.c_void_p
+
+_lib = None
+
+# every symbol include/kmcuda.h and include/kmcuda_amd.h declare
+EXPORTS = [
+    "kmeans_cuda", "knn_cuda",
+    "kmamd_engine_create", "kmamd_engine_destroy", "kmamd_engine_stream", "kmamd_engine_sync",
+    "kmamd_lloyd_assign", "kmamd_lloyd_assign_exact", "kmamd_counters_read", "kmamd_counters_reset",
+    "kmamd_move_deltas", "kmamd_apply_delta", "kmamd_transpose", "kmamd_pack_reduce_tail",
+    "kmamd_unpack_dcount",
+    "kmamd_profile_reset", "kmamd_profile_read", "kmamd_profile_enable", "kmamd_build_arch",
+]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "kmcuda_amd: %s is missing -- the HIP library has not been built "
+            "(run `make -C kmcuda_amd/csrc`); there is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    L.kmeans_cuda.restype = i32
+    L.kmeans_cuda.argtypes = [i32, vp, f32, f32, i32, u32, ctypes.c_uint16, u32, u32, u32, i32, i32, i32,
+                              vp, vp, vp, vp]
+    L.knn_cuda.restype = i32
+    L.knn_cuda.argtypes = [ctypes.c_uint16, i32, u32, ctypes.c_uint16, u32, u32, i32, i32, i32, vp, vp, vp, vp]
+    L.kmamd_engine_create.restype = i32
+    L.kmamd_engine_create.argtypes = [ctypes.POINTER(vp), i32, u32, u32, u32, i32, i32, vp]
+    L.kmamd_engine_destroy.restype = None
+    L.kmamd_engine_destroy.argtypes = [vp]
+    L.kmamd_engine_stream.restype = vp
+    L.kmamd_engine_stream.argtypes = [vp]
+    L.kmamd_engine_sync.restype = i32
+    L.kmamd_engine_sync.argtypes = [vp]
+    for name in ("kmamd_lloyd_assign", "kmamd_lloyd_assign_exact"):
+        fn = getattr(L, name)
+        fn.restype = i32
+        fn.argtypes = [vp, vp, vp, vp, vp]
+    L.kmamd_counters_read.restype = i32
+    L.kmamd_counters_read.argtypes = [vp, ctypes.POINTER(u32)]
+    L.kmamd_counters_reset.restype = i32
+    L.kmamd_counters_reset.argtypes = [vp, i32]
+    L.kmamd_move_deltas.restype = i32
+    L.kmamd_move_deltas.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.kmamd_apply_delta.restype = i32
+    L.kmamd_apply_delta.argtypes = [vp, vp, vp, vp, vp]
+    L.kmamd_pack_reduce_tail.restype = i32
+    L.kmamd_pack_reduce_tail.argtypes = [vp, vp, vp]
+    L.kmamd_unpack_dcount.restype = i32
+    L.kmamd_unpack_dcount.argtypes = [vp, vp, vp]
+    L.kmamd_transpose.restype = i32
+    L.kmamd_transpose.argtypes = [vp, vp, u32, u32, vp]
+    L.kmamd_profile_reset.restype = i32
+    L.kmamd_profile_reset.argtypes = [vp]
+    L.kmamd_profile_enable.restype = i32
+    L.kmamd_profile_enable.argtypes = [vp, i32]
+    L.kmamd_profile_read.restype = i32
+    L.kmamd_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u32),
+                                     ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    L.kmamd_build_arch.restype = ctypes.c_char_p
+    _lib = L
+    return L
+
+
+STATUS = {0: "Success", 1: "InvalidArguments", 2: "NoSuchDevice", 3: "MemoryAllocationFailure",
+          4: "RuntimeError", 5: "MemoryCopyError"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what, STATUS.get(rc, rc)))

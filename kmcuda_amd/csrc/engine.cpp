@@ -1,0 +1,261 @@
+// engine.cpp -- Engine implementation + the step-level C ABI of include/kmcuda_amd.h.
+#include "engine.hpp"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/kmcuda_amd.h"
+
+namespace kmx {
+
+int g_verbosity = 0;
+
+Engine::~Engine() {
+  if (device_ >= 0) (void)hipSetDevice(device_);
+  for (auto &s : spans_) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+  for (void *p : owned_) (void)hipFree(p);
+  if (host_counters_) (void)hipHostFree(host_counters_);
+  if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+}
+
+int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric, int fp16x2, hipStream_t stream) {
+  if (D == 0 || K < 2 || K >= 0x7FFFFFFFu) return kInvalidArguments;
+  if (fp16x2) return kInvalidArguments;  // fp16x2 kernels are not built yet ("next")
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return kNoSuchDevice;
+  KMX_HIP(hipSetDevice(device), kNoSuchDevice);
+  device_ = device;
+  if (stream) {
+    stream_ = stream;
+  } else {
+    KMX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), kRuntimeError);
+    own_stream_ = true;
+  }
+  N_ = n_rows; D_ = D; K_ = K; metric_ = metric; fp16x2_ = fp16x2;
+  K_pad_ = (K + 31) / 32 * 32;
+  Kt_ = (K + 63) / 64 * 64;
+  DP_ = filter_dp_for(D);
+  // Filter error bound coefficient (DESIGN.md "error bound"): gamma_D + (kappa + 3) u with
+  // u = 2^-24, gamma_D <= 1.01 D u, kappa = 8 for the reference's Kahan chain; +2% margin.
+  eps_ = (float)(1.02 * ((double)D + 12.0) * ldexp(1.0, -24));
+  // Angular metric: acosf is many-to-one; products within ~2.4e-7 of each other may map to the
+  // same angle, so near-ties go to the exact kernel which applies acosf like the reference.
+  tie_slack_ = metric == 0 ? 0.f : 1e-6f;
+
+  const uint32_t dp = DP_ ? DP_ : 8;
+  int rc;
+  if ((rc = alloc(&csqr_, K))) return rc;
+  if ((rc = alloc(&bias_, K_pad_))) return rc;
+  if ((rc = alloc(&cfil_, (size_t)K_pad_ * dp))) return rc;
+  if ((rc = alloc(&ct_, (size_t)D * Kt_))) return rc;
+  if ((rc = alloc(&stats_, 4))) return rc;
+  if ((rc = alloc(&flagged_, n_rows))) return rc;
+  if ((rc = alloc(&counters_, 4))) return rc;
+  if ((rc = alloc(&keys_tmp_, 2 * (size_t)n_rows))) return rc;
+  if ((rc = alloc(&vals_tmp_, 2 * (size_t)n_rows))) return rc;
+  if ((rc = alloc(&keys_sorted_, 2 * (size_t)n_rows))) return rc;
+  if ((rc = alloc(&rows_sorted_, 2 * (size_t)n_rows))) return rc;
+  if ((rc = alloc(&offsets2_, 2 * (size_t)K + 2))) return rc;
+  sort_temp_bytes_ = sort_temp_bytes(2 * n_rows, 2 * K);
+  {
+    const size_t b2 = sort_temp_bytes(n_rows, K);
+    if (b2 > sort_temp_bytes_) sort_temp_bytes_ = b2;
+  }
+  {
+    char *t = nullptr;
+    if ((rc = alloc(&t, sort_temp_bytes_ + 16))) return rc;
+    sort_temp_ = t;
+  }
+  if ((rc = alloc(&partial_, (size_t)2 * K * kSumSplit * D))) return rc;
+  KMX_HIP(hipHostMalloc((void **)&host_counters_, 4 * sizeof(uint32_t), hipHostMallocDefault), kMemoryAllocationFailure);
+  KMX_HIP(hipMemsetAsync(counters_, 0, 4 * sizeof(uint32_t), stream_), kRuntimeError);
+  return kSuccess;
+}
+
+void Engine::span_begin(int kind) {
+  if (!profile_) return;
+  Span s;
+  (void)hipEventCreate(&s.a);
+  (void)hipEventCreate(&s.b);
+  s.kind = kind;
+  (void)hipEventRecord(s.a, stream_);
+  spans_.push_back(s);
+}
+void Engine::span_end() {
+  if (!profile_) return;
+  (void)hipEventRecord(spans_.back().b, stream_);
+}
+void Engine::profile_collect() {
+  for (auto &s : spans_) {
+    (void)hipEventSynchronize(s.b);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, s.a, s.b);
+    if (s.kind == 0) { filter_ms_ += ms; filter_launches_++; }
+    else if (s.kind == 1) exact_ms_ += ms;
+    else update_ms_ += ms;
+    (void)hipEventDestroy(s.a);
+    (void)hipEventDestroy(s.b);
+  }
+  spans_.clear();
+}
+void Engine::profile_reset() {
+  profile_collect();
+  filter_ms_ = exact_ms_ = update_ms_ = 0;
+  filter_launches_ = 0;
+}
+
+int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t *assignments,
+                         uint32_t *assignments_prev, bool exact_only) {
+  KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  const uint32_t dp = DP_ ? DP_ : 8;
+  KMX_HIP(launch_centroid_prep(metric_, centroids, K_, D_, K_pad_, dp, Kt_, csqr_, bias_, cfil_, ct_, stats_, stream_),
+          kRuntimeError);
+  LloydArgs a;
+  a.samples = samples; a.N = N_; a.D = D_; a.K = K_; a.K_pad = K_pad_; a.DP = DP_; a.Kt = Kt_;
+  a.cfil = cfil_; a.bias = bias_; a.ct = ct_; a.csqr = csqr_; a.stats = stats_;
+  a.eps = eps_; a.tie_slack = tie_slack_;
+  a.assignments = assignments; a.assignments_prev = assignments_prev;
+  a.flagged = flagged_; a.counters = counters_;
+  if (N_ == 0) return kSuccess;
+  if (exact_only || DP_ == 0) {
+    span_begin(1);
+    const uint32_t grid = N_ < 8192u ? N_ : 8192u;
+    KMX_HIP(launch_lloyd_exact(metric_, a, nullptr, nullptr, grid, stream_), kRuntimeError);
+    span_end();
+    return kSuccess;
+  }
+  KMX_HIP(hipMemsetAsync(counters_ + 1, 0, sizeof(uint32_t), stream_), kRuntimeError);
+  span_begin(0);
+  KMX_HIP(launch_lloyd_filter(a, stream_), kRuntimeError);
+  span_end();
+  span_begin(1);
+  const uint32_t grid = N_ < 4096u ? N_ : 4096u;  // grid-strides over the device-side flagged count
+  KMX_HIP(launch_lloyd_exact(metric_, a, flagged_, counters_ + 1, grid, stream_), kRuntimeError);
+  span_end();
+  return kSuccess;
+}
+
+int Engine::move_deltas(const float *samples, const uint32_t *prev, const uint32_t *cur, double *delta,
+                        int32_t *dcount) {
+  KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  span_begin(2);
+  KMX_HIP(launch_move_deltas(samples, N_, D_, K_, prev, cur, keys_tmp_, vals_tmp_, keys_sorted_, rows_sorted_,
+                             offsets2_, sort_temp_, sort_temp_bytes_, partial_, delta, dcount, stream_),
+          kRuntimeError);
+  span_end();
+  return kSuccess;
+}
+
+int Engine::apply_delta(const double *delta, const int32_t *dcount, float *centroids, uint32_t *ccounts) {
+  KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  span_begin(2);
+  KMX_HIP(launch_apply_delta(metric_, delta, dcount, K_, D_, centroids, ccounts, stream_), kRuntimeError);
+  span_end();
+  return kSuccess;
+}
+
+int Engine::counters_read(uint32_t *host4) {
+  KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  KMX_HIP(hipMemcpyAsync(host_counters_, counters_, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_),
+          kMemoryCopyError);
+  KMX_HIP(hipStreamSynchronize(stream_), kRuntimeError);
+  memcpy(host4, host_counters_, 4 * sizeof(uint32_t));
+  return kSuccess;
+}
+
+int Engine::counters_reset(int which) {
+  KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  if (which < 0) KMX_HIP(hipMemsetAsync(counters_, 0, 4 * sizeof(uint32_t), stream_), kRuntimeError);
+  else KMX_HIP(hipMemsetAsync(counters_ + which, 0, sizeof(uint32_t), stream_), kRuntimeError);
+  return kSuccess;
+}
+
+int Engine::sync() {
+  KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  KMX_HIP(hipStreamSynchronize(stream_), kRuntimeError);
+  return kSuccess;
+}
+
+}  // namespace kmx
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+struct kmamd_engine {
+  kmx::Engine e;
+};
+
+extern "C" {
+
+int kmamd_engine_create(kmamd_engine **out, int device, uint32_t n_rows, uint32_t features, uint32_t clusters,
+                        int metric, int fp16x2, void *hip_stream) {
+  if (!out) return kmx::kInvalidArguments;
+  *out = nullptr;
+  kmamd_engine *h = new kmamd_engine();
+  const int rc = h->e.init(device, n_rows, features, clusters, metric, fp16x2, (hipStream_t)hip_stream);
+  if (rc != kmx::kSuccess) {
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return kmx::kSuccess;
+}
+
+void kmamd_engine_destroy(kmamd_engine *e) { delete e; }
+void *kmamd_engine_stream(kmamd_engine *e) { return (void *)e->e.stream_; }
+int kmamd_engine_sync(kmamd_engine *e) { return e->e.sync(); }
+
+int kmamd_lloyd_assign(kmamd_engine *e, const float *samples, const float *centroids, uint32_t *assignments,
+                       uint32_t *assignments_prev) {
+  return e->e.lloyd_assign(samples, centroids, assignments, assignments_prev, false);
+}
+int kmamd_lloyd_assign_exact(kmamd_engine *e, const float *samples, const float *centroids, uint32_t *assignments,
+                             uint32_t *assignments_prev) {
+  return e->e.lloyd_assign(samples, centroids, assignments, assignments_prev, true);
+}
+int kmamd_counters_read(kmamd_engine *e, uint32_t *host_out4) { return e->e.counters_read(host_out4); }
+int kmamd_counters_reset(kmamd_engine *e, int which) { return e->e.counters_reset(which); }
+int kmamd_move_deltas(kmamd_engine *e, const float *samples, const uint32_t *assignments_prev,
+                      const uint32_t *assignments, double *delta, int32_t *dcount) {
+  return e->e.move_deltas(samples, assignments_prev, assignments, delta, dcount);
+}
+int kmamd_apply_delta(kmamd_engine *e, const double *delta, const int32_t *dcount, float *centroids,
+                      uint32_t *ccounts) {
+  return e->e.apply_delta(delta, dcount, centroids, ccounts);
+}
+int kmamd_pack_reduce_tail(kmamd_engine *e, const int32_t *dcount, double *dst) {
+  if (hipSetDevice(e->e.device_) != hipSuccess) return kmx::kNoSuchDevice;
+  return kmx::launch_pack_reduce_tail(dcount, e->e.counters_, e->e.K_, dst, e->e.stream_) == hipSuccess
+             ? kmx::kSuccess : kmx::kRuntimeError;
+}
+int kmamd_unpack_dcount(kmamd_engine *e, const double *src, int32_t *dcount) {
+  if (hipSetDevice(e->e.device_) != hipSuccess) return kmx::kNoSuchDevice;
+  return kmx::launch_unpack_dcount(src, e->e.K_, dcount, e->e.stream_) == hipSuccess ? kmx::kSuccess
+                                                                                      : kmx::kRuntimeError;
+}
+int kmamd_transpose(kmamd_engine *e, const float *in, uint32_t rows, uint32_t cols, float *out) {
+  if (hipSetDevice(e->e.device_) != hipSuccess) return kmx::kNoSuchDevice;
+  return kmx::launch_transpose(in, rows, cols, out, e->e.stream_) == hipSuccess ? kmx::kSuccess : kmx::kRuntimeError;
+}
+int kmamd_profile_enable(kmamd_engine *e, int on) {
+  e->e.profile_collect();
+  e->e.profile_ = on != 0;
+  return kmx::kSuccess;
+}
+int kmamd_profile_reset(kmamd_engine *e) {
+  e->e.profile_reset();
+  return kmx::kSuccess;
+}
+int kmamd_profile_read(kmamd_engine *e, double *filter_ms, uint32_t *filter_launches, double *exact_ms,
+                       double *update_ms) {
+  e->e.profile_collect();
+  if (filter_ms) *filter_ms = e->e.filter_ms_;
+  if (filter_launches) *filter_launches = e->e.filter_launches_;
+  if (exact_ms) *exact_ms = e->e.exact_ms_;
+  if (update_ms) *update_ms = e->e.update_ms_;
+  return kmx::kSuccess;
+}
+const char *kmamd_build_arch(void) { return "gfx950"; }
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// engine.hpp -- per-GPU workspace + step drivers (host side of the kernels).
+// Reference counterpart: the allocations of src/kmcuda.cc:423-470 and the per-iteration launch
+// code of src/kmeans.cu:934-1263, which keep everything replicated on every GPU; here one Engine
+// owns one GPU's row shard.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace kmx {
+
+enum Result {  // == KMCUDAResult (include/kmcuda.h)
+  kSuccess = 0, kInvalidArguments, kNoSuchDevice, kMemoryAllocationFailure, kRuntimeError, kMemoryCopyError
+};
+
+#define KMX_HIP(call, ret)                                                                   \
+  do {                                                                                       \
+    hipError_t e__ = (call);                                                                 \
+    if (e__ != hipSuccess) {                                                                 \
+      if (kmx::g_verbosity > 0)                                                              \
+        printf("%s:%d -> %s (%s)\n", __FILE__, __LINE__, hipGetErrorString(e__), #call);     \
+      return ret;                                                                            \
+    }                                                                                        \
+  } while (0)
+
+extern int g_verbosity;
+
+class Engine {
+ public:
+  Engine() = default;
+  ~Engine();
+  Engine(const Engine &) = delete;
+  Engine &operator=(const Engine &) = delete;
+
+  int init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric, int fp16x2, hipStream_t stream);
+
+  // steps (all async on stream_)
+  int lloyd_assign(const float *samples, const float *centroids, uint32_t *assignments,
+                   uint32_t *assignments_prev, bool exact_only);
+  int move_deltas(const float *samples, const uint32_t *prev, const uint32_t *cur, double *delta, int32_t *dcount);
+  int apply_delta(const double *delta, const int32_t *dcount, float *centroids, uint32_t *ccounts);
+  int counters_read(uint32_t *host4);
+  int counters_reset(int which);
+  int sync();
+
+  template <typename T>
+  int alloc(T **p, size_t count) {
+    void *q = nullptr;
+    if (hipMalloc(&q, count ? count * sizeof(T) : sizeof(T)) != hipSuccess) return kMemoryAllocationFailure;
+    owned_.push_back(q);
+    *p = static_cast<T *>(q);
+    return kSuccess;
+  }
+
+  int device_ = -1;
+  hipStream_t stream_ = nullptr;
+  bool own_stream_ = false;
+  uint32_t N_ = 0, D_ = 0, K_ = 0, K_pad_ = 0, Kt_ = 0, DP_ = 0;
+  int metric_ = 0, fp16x2_ = 0;
+  float eps_ = 0, tie_slack_ = 0;
+
+  // assignment workspace
+  float *csqr_ = nullptr, *bias_ = nullptr, *cfil_ = nullptr, *ct_ = nullptr;
+  uint32_t *stats_ = nullptr, *flagged_ = nullptr, *counters_ = nullptr;
+  // update workspace
+  uint32_t *keys_tmp_ = nullptr, *vals_tmp_ = nullptr, *keys_sorted_ = nullptr, *rows_sorted_ = nullptr,
+           *offsets2_ = nullptr;
+  void *sort_temp_ = nullptr;
+  size_t sort_temp_bytes_ = 0;
+  double *partial_ = nullptr;
+  uint32_t *host_counters_ = nullptr;  // pinned
+
+  // profiling of the step kernels with HIP events on stream_
+  bool profile_ = false;
+  double filter_ms_ = 0, exact_ms_ = 0, update_ms_ = 0;
+  uint32_t filter_launches_ = 0;
+  struct Span { hipEvent_t a, b; int kind; };
+  std::vector<Span> spans_;
+  void span_begin(int kind);
+  void span_end();
+  void profile_collect();
+  void profile_reset();
+
+ private:
+  std::vector<void *> owned_;
+};
+
+}  // namespace kmx

@@ -1,0 +1,64 @@
+// kernels.hpp -- launch interfaces between the HIP kernels (*.hip) and the host engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kmx {
+
+struct LloydArgs {
+  const float *samples;      // N x D row-major (this device's rows)
+  uint32_t N, D, K;
+  uint32_t K_pad;            // K rounded up to 32 (filter tiles)
+  uint32_t DP;               // filter feature padding (0: no MFMA filter for this D)
+  uint32_t Kt;               // K rounded up to 64 (row length of ct)
+  const float *cfil;         // K_pad x DP sanitised centroid panel
+  const float *bias;         // K_pad: -csqr/2 (L2) / 0 (angular) / -inf (never chosen)
+  const float *ct;           // D x Kt transposed centroids
+  const float *csqr;         // K exact squared norms (reference's sum_squares)
+  const uint32_t *stats;     // [0] max ||c||^2 bits, [1] max |bias| bits
+  float eps;                 // relative error coefficient of the filter bound
+  float tie_slack;           // absolute slack (angular: acos plateau width)
+  uint32_t *assignments, *assignments_prev;
+  uint32_t *flagged;         // N: rows the filter could not decide
+  uint32_t *counters;        // [0] changed, [1] flagged, [2] passed (yinyang), [3] spare
+};
+
+uint32_t filter_dp_for(uint32_t D);
+hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad,
+                                uint32_t DP, uint32_t Kt, float *csqr, float *bias, float *cfil, float *ct,
+                                uint32_t *stats, hipStream_t st);
+hipError_t launch_lloyd_filter(const LloydArgs &a, hipStream_t st);
+hipError_t launch_lloyd_exact(int metric, const LloydArgs &a, const uint32_t *rows, const uint32_t *nrows,
+                              uint32_t grid, hipStream_t st);
+
+// update.hip -- centroid update (reference: kmeans.cu:366-429 kmeans_adjust)
+constexpr uint32_t kSumSplit = 8;
+size_t sort_temp_bytes(uint32_t n, uint32_t max_key);
+hipError_t launch_inverse_assignments(const uint32_t *assignments, uint32_t N, uint32_t K, uint32_t *keys_tmp,
+                                      uint32_t *vals_tmp, uint32_t *keys_sorted, uint32_t *inv,
+                                      uint32_t *offsets, void *temp, size_t temp_bytes, hipStream_t st);
+hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint32_t K, const uint32_t *prev,
+                              const uint32_t *cur, uint32_t *keys_tmp, uint32_t *vals_tmp, uint32_t *keys_sorted,
+                              uint32_t *rows_sorted, uint32_t *offsets2, void *temp, size_t temp_bytes,
+                              double *partial, double *delta, int32_t *dcount, hipStream_t st);
+hipError_t launch_apply_delta(int metric, const double *delta, const int32_t *dcount, uint32_t K, uint32_t D,
+                              float *centroids, uint32_t *ccounts, hipStream_t st);
+
+hipError_t launch_pack_reduce_tail(const int32_t *dcount, const uint32_t *counters, uint32_t K, double *dst,
+                                   hipStream_t st);
+hipError_t launch_unpack_dcount(const double *src, uint32_t K, int32_t *dcount, hipStream_t st);
+
+// seeding.hip (reference: kmeans.cu:42-67 kmeans_plus_plus, transpose.cu:6-14 copy_sample_t,
+// kmeans.cu:674-691 kmeans_calc_average_distance)
+hipError_t launch_gather_rows(const float *samples, uint32_t D, const uint32_t *row_ids, uint32_t nrows,
+                              float *dst, hipStream_t st);
+hipError_t launch_kmpp_step(int metric, const float *samples, uint32_t N, uint32_t D, const float *centroid,
+                            uint32_t cc, float *dists, hipStream_t st);
+hipError_t launch_member_distances(int metric, const float *samples, uint32_t N, uint32_t D,
+                                   const float *centroids, const uint32_t *assignments, uint32_t K,
+                                   float *dists, hipStream_t st);
+
+// transpose.hip (reference: transpose.cu:16-54)
+hipError_t launch_transpose(const float *in, uint32_t rows, uint32_t cols, float *out, hipStream_t st);
+
+}  // namespace kmx

@@ -1,0 +1,595 @@
+// kmcuda_api.cpp -- the drop-in C ABI: kmeans_cuda() and knn_cuda() of include/kmcuda.h.
+//
+// Host orchestration mirroring the reference's contract (src/kmcuda.cc:402-531 kmeans_cuda,
+// src/kmeans.cu:934-1026 kmeans_cuda_lloyd, :1028-1263 kmeans_cuda_yy): same argument
+// validation and return codes, same srand()/rand()-driven seeding, same stop rule evaluated
+// BEFORE the centroid update, same "iteration %d: %u reassignments" progress lines.
+//
+// What is different by design: samples stay row-major and are ROW-SHARDED over the GPUs of
+// the device mask (the reference replicates everything on every GPU and exchanges slices by
+// N*(N-1) peer copies); the only per-iteration exchange is one all-reduce of the centroid
+// deltas (RCCL over xGMI, loaded lazily so single-GPU use has no RCCL dependency).
+#include <dlfcn.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+#include <vector>
+
+#include "../../include/kmcuda.h"
+#include "engine.hpp"
+
+using namespace kmx;
+
+#define INFO(...) do { if (verbosity > 0) { printf(__VA_ARGS__); } } while (false)
+#define DEBUG(...) do { if (verbosity > 1) { printf(__VA_ARGS__); } } while (false)
+#define RETERR(call) do { int rc__ = (call); if (rc__ != 0) return static_cast<KMCUDAResult>(rc__); } while (false)
+
+namespace {
+
+constexpr double kYinyangGroupTolerance = 0.02;      // kmeans.cu:27
+constexpr double kYinyangDraftReassignments = 0.11;  // kmeans.cu:28
+constexpr double kYinyangRefreshEpsilon = 1e-4;      // kmeans.cu:29
+
+// ---------------------------------------------------------------------------------------
+// RCCL, loaded on first multi-GPU use
+// ---------------------------------------------------------------------------------------
+struct Rccl {
+  void *handle = nullptr;
+  int (*CommInitAll)(void **, int, const int *) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  bool load() {
+    if (handle) return true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (handle) break;
+    }
+    if (!handle) return false;
+    CommInitAll = (decltype(CommInitAll))dlsym(handle, "ncclCommInitAll");
+    CommDestroy = (decltype(CommDestroy))dlsym(handle, "ncclCommDestroy");
+    GroupStart = (decltype(GroupStart))dlsym(handle, "ncclGroupStart");
+    GroupEnd = (decltype(GroupEnd))dlsym(handle, "ncclGroupEnd");
+    AllReduce = (decltype(AllReduce))dlsym(handle, "ncclAllReduce");
+    return CommInitAll && CommDestroy && GroupStart && GroupEnd && AllReduce;
+  }
+};
+constexpr int kNcclInt32 = 2, kNcclFloat64 = 8, kNcclSum = 0;  // rccl.h ncclDataType_t / ncclRedOp_t
+
+// ---------------------------------------------------------------------------------------
+// device list from the mask (reference: setup_devices, kmcuda.cc:63-137)
+// ---------------------------------------------------------------------------------------
+std::vector<int> setup_devices(uint32_t device, int verbosity) {
+  std::vector<int> devs;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return devs;
+  if (device == 0) device = ndev >= 32 ? 0xFFFFFFFFu : ((1u << ndev) - 1);
+  for (int dev = 0; device; dev++, device >>= 1) {
+    if (!(device & 1)) continue;
+    if (dev >= ndev || hipSetDevice(dev) != hipSuccess) {
+      INFO("failed to hipSetDevice(%d)\n", dev);
+      continue;
+    }
+    devs.push_back(dev);
+  }
+  return devs;
+}
+
+// contiguous row blocks, one per shard (the reference's distribute(), private.h:240-273,
+// aligns to 512 B; rows here are whole samples so plain balanced blocks do)
+std::vector<std::pair<uint32_t, uint32_t>> row_plan(uint32_t N, size_t nshards) {
+  std::vector<std::pair<uint32_t, uint32_t>> plan;
+  uint32_t offset = 0;
+  for (size_t i = 0; i < nshards; i++) {
+    const uint32_t len = (uint32_t)(((uint64_t)N * (i + 1)) / nshards - ((uint64_t)N * i) / nshards);
+    plan.emplace_back(offset, len);
+    offset += len;
+  }
+  return plan;
+}
+
+// sum of `n` floats the way the reference forms it on device (kmeans.cu:63-66, :687-690):
+// float butterfly over each aligned group of 32, then a double accumulation
+double butterfly_sum(const float *v, uint32_t n) {
+  double sum = 0.0;
+  for (uint32_t base = 0; base < n; base += 32) {
+    float lane[32];
+    for (int l = 0; l < 32; l++) lane[l] = (base + l < n) ? v[base + l] : 0.f;
+    for (int off = 16; off > 0; off /= 2)
+      for (int l = 0; l < 32; l++) lane[l] = lane[l] + ((l + off < 32) ? lane[l + off] : lane[l]);
+    sum += (double)lane[0];
+  }
+  return sum;
+}
+
+// ---------------------------------------------------------------------------------------
+// one GPU's share of the job
+// ---------------------------------------------------------------------------------------
+struct Shard {
+  int dev = 0;
+  uint32_t offset = 0, length = 0;
+  std::unique_ptr<Engine> eng;
+  const float *samples = nullptr;  // length x D on this device
+  float *centroids = nullptr;      // K x D (replicated)
+  uint32_t *assignments = nullptr, *prev = nullptr, *ccounts = nullptr;
+  double *delta = nullptr;
+  int32_t *dcount = nullptr;
+  float *dists = nullptr;          // length floats (k-means++ / average distance)
+  uint32_t *row_ids = nullptr;     // K uint32 staging for gathers
+  std::vector<void *> owned;
+  ~Shard() {
+    (void)hipSetDevice(dev);
+    for (void *p : owned) (void)hipFree(p);
+  }
+  template <typename T>
+  int alloc(T **p, size_t count) {
+    void *q = nullptr;
+    if (hipMalloc(&q, count ? count * sizeof(T) : sizeof(T)) != hipSuccess) return kmcudaMemoryAllocationFailure;
+    owned.push_back(q);
+    *p = static_cast<T *>(q);
+    return 0;
+  }
+};
+
+class Job {
+ public:
+  uint32_t N = 0, D = 0, K = 0;
+  int metric = 0, verbosity = 0;
+  std::vector<std::unique_ptr<Shard>> shards;
+  Rccl rccl;
+  std::vector<void *> comms;
+
+  ~Job() {
+    for (void *c : comms)
+      if (c) rccl.CommDestroy(c);
+  }
+
+  int setup(const std::vector<int> &devs, int nvirtual, uint32_t N_, uint32_t D_, uint32_t K_, int metric_,
+            int verbosity_, const float *samples, int32_t device_ptrs) {
+    N = N_; D = D_; K = K_; metric = metric_; verbosity = verbosity_;
+    std::vector<int> shard_devs = devs;
+    if (nvirtual > 1 && devs.size() == 1) shard_devs.assign(nvirtual, devs[0]);  // test hook
+    auto plan = row_plan(N, shard_devs.size());
+    for (size_t i = 0; i < shard_devs.size(); i++) {
+      auto sh = std::make_unique<Shard>();
+      sh->dev = shard_devs[i];
+      sh->offset = plan[i].first;
+      sh->length = plan[i].second;
+      if (hipSetDevice(sh->dev) != hipSuccess) return kmcudaNoSuchDevice;
+      sh->eng = std::make_unique<Engine>();
+      int rc = sh->eng->init(sh->dev, sh->length, D, K, metric, 0, nullptr);
+      if (rc) return rc;
+      const float *src = samples + (size_t)sh->offset * D;
+      if (device_ptrs >= 0 && device_ptrs == sh->dev) {
+        sh->samples = src;  // already resident, used in place and never modified
+      } else {
+        float *buf = nullptr;
+        if ((rc = sh->alloc(&buf, (size_t)sh->length * D))) return rc;
+        hipError_t e;
+        if (device_ptrs < 0)
+          e = hipMemcpyAsync(buf, src, (size_t)sh->length * D * sizeof(float), hipMemcpyHostToDevice, sh->eng->stream_);
+        else
+          e = hipMemcpyPeerAsync(buf, sh->dev, src, device_ptrs, (size_t)sh->length * D * sizeof(float),
+                                 sh->eng->stream_);
+        if (e != hipSuccess) return kmcudaMemoryCopyError;
+        sh->samples = buf;
+      }
+      if ((rc = sh->alloc(&sh->centroids, (size_t)K * D))) return rc;
+      if ((rc = sh->alloc(&sh->assignments, sh->length))) return rc;
+      if ((rc = sh->alloc(&sh->prev, sh->length))) return rc;
+      if ((rc = sh->alloc(&sh->ccounts, K))) return rc;
+      if ((rc = sh->alloc(&sh->delta, (size_t)K * D))) return rc;
+      if ((rc = sh->alloc(&sh->dcount, K))) return rc;
+      if ((rc = sh->alloc(&sh->dists, sh->length))) return rc;
+      if ((rc = sh->alloc(&sh->row_ids, K))) return rc;
+      shards.push_back(std::move(sh));
+    }
+    bool distinct = shards.size() > 1;
+    for (size_t i = 0; i < shards.size() && distinct; i++)
+      for (size_t j = 0; j < i; j++)
+        if (shards[i]->dev == shards[j]->dev) distinct = false;
+    if (distinct) {
+      if (!rccl.load()) {
+        INFO("failed to load librccl.so: multi-GPU operation is unavailable\n");
+        return kmcudaRuntimeError;
+      }
+      std::vector<int> ids;
+      for (auto &s : shards) ids.push_back(s->dev);
+      comms.resize(ids.size(), nullptr);
+      if (rccl.CommInitAll(comms.data(), (int)ids.size(), ids.data()) != 0) return kmcudaRuntimeError;
+    }
+    return sync_all();  // uploads complete: later cross-stream reads of the samples are safe
+  }
+
+  int sync_all() {
+    for (auto &s : shards) RETERR(s->eng->sync());
+    return 0;
+  }
+
+  // ---- replicated-state helpers ----
+  int broadcast_centroids_from_host(const float *host) {
+    for (auto &s : shards) {
+      (void)hipSetDevice(s->dev);
+      if (hipMemcpyAsync(s->centroids, host, (size_t)K * D * sizeof(float), hipMemcpyHostToDevice, s->eng->stream_) !=
+          hipSuccess)
+        return kmcudaMemoryCopyError;
+    }
+    return sync_all();
+  }
+
+  // copies sample row `index` (global numbering) into centroid slot `slot` on every shard
+  int copy_sample_to_centroid(uint32_t index, uint32_t slot) {
+    Shard *owner = nullptr;
+    for (auto &s : shards)
+      if (index >= s->offset && index < s->offset + s->length) owner = s.get();
+    if (!owner) return kmcudaRuntimeError;
+    (void)hipSetDevice(owner->dev);
+    const float *src = owner->samples + (size_t)(index - owner->offset) * D;
+    for (auto &s : shards) {
+      hipError_t e;
+      float *dst = s->centroids + (size_t)slot * D;
+      if (s->dev == owner->dev) {
+        (void)hipSetDevice(owner->dev);
+        // order after anything pending on the destination shard's stream
+        e = hipMemcpyAsync(dst, src, D * sizeof(float), hipMemcpyDeviceToDevice, s->eng->stream_);
+      } else {
+        e = hipMemcpyPeerAsync(dst, s->dev, src, owner->dev, D * sizeof(float), s->eng->stream_);
+      }
+      if (e != hipSuccess) return kmcudaMemoryCopyError;
+    }
+    return 0;
+  }
+
+  int read_sample_value(uint32_t index, uint32_t feature, float *out) {
+    for (auto &s : shards)
+      if (index >= s->offset && index < s->offset + s->length) {
+        (void)hipSetDevice(s->dev);
+        RETERR(s->eng->sync());
+        if (hipMemcpy(out, s->samples + (size_t)(index - s->offset) * D + feature, sizeof(float),
+                      hipMemcpyDeviceToHost) != hipSuccess)
+          return kmcudaMemoryCopyError;
+        return 0;
+      }
+    return kmcudaRuntimeError;
+  }
+
+  int read_sample_row(uint32_t index, float *out) {
+    for (auto &s : shards)
+      if (index >= s->offset && index < s->offset + s->length) {
+        (void)hipSetDevice(s->dev);
+        RETERR(s->eng->sync());
+        if (hipMemcpy(out, s->samples + (size_t)(index - s->offset) * D, D * sizeof(float), hipMemcpyDeviceToHost) !=
+            hipSuccess)
+          return kmcudaMemoryCopyError;
+        return 0;
+      }
+    return kmcudaRuntimeError;
+  }
+
+  // ---- seeding (reference: kmeans_init_centroids, kmcuda.cc:189-400) ----
+  int init_centroids(KMCUDAInitMethod method, uint32_t seed, const float *host_centroids, int32_t device_ptrs) {
+    if (metric == kmcudaDistanceMetricCosine) {  // kmcuda.cc:195-220: three unit-norm probes
+      std::vector<float> probe(D);
+      for (uint32_t s : {0u, N / 2, N - 1}) {
+        RETERR(read_sample_row(s, probe.data()));
+        double norm = 0;
+        for (uint32_t i = 0; i < D; i++) norm += probe[i] * probe[i];
+        const float high = 1.00001, low = 0.99999;
+        if (norm > high || norm < low) {
+          INFO("error: angular distance: samples[%u] has L2 norm = %f which is outside [%f, %f]\n", s, norm, low, high);
+          return kmcudaInvalidArguments;
+        }
+      }
+    }
+    srand(seed);  // kmcuda.cc:222
+    switch (method) {
+      case kmcudaInitMethodImport: {
+        if (device_ptrs < 0) return broadcast_centroids_from_host(host_centroids);
+        for (auto &s : shards) {
+          hipError_t e = hipMemcpyPeerAsync(s->centroids, s->dev, host_centroids, device_ptrs,
+                                            (size_t)K * D * sizeof(float), s->eng->stream_);
+          if (e != hipSuccess) return kmcudaMemoryCopyError;
+        }
+        return sync_all();
+      }
+      case kmcudaInitMethodRandom: {
+        INFO("randomly picking initial centroids...\n");
+        // libstdc++'s std::random_shuffle over rand() (kmcuda.cc:245-253): the first K entries
+        std::vector<uint32_t> chosen(N);
+        for (uint32_t s = 0; s < N; s++) chosen[s] = s;
+        for (uint32_t i = 1; i < N; i++) std::swap(chosen[i], chosen[rand() % (i + 1)]);
+        DEBUG("shuffle complete, copying to device(s)...\n");
+        for (uint32_t c = 0; c < K; c++) RETERR(copy_sample_to_centroid(chosen[c], c));
+        return sync_all();
+      }
+      case kmcudaInitMethodPlusPlus: {
+        float smoke = NAN;
+        uint32_t first_index = 0;
+        while (smoke != smoke) {  // kmcuda.cc:265-270
+          first_index = rand() % N;
+          RETERR(read_sample_value(first_index, 0, &smoke));
+        }
+        RETERR(copy_sample_to_centroid(first_index, 0));
+        INFO("performing kmeans++...\n");
+        std::vector<float> host_dists(N);
+        for (uint32_t i = 1; i < K; i++) {
+          if (verbosity > 1 || (verbosity > 0 && (K < 100 || i % (K / 100) == 0))) {
+            printf("\rstep %d", i);
+            fflush(stdout);
+          }
+          for (auto &s : shards) {
+            (void)hipSetDevice(s->dev);
+            if (launch_kmpp_step(metric, s->samples, s->length, D, s->centroids + (size_t)(i - 1) * D, i, s->dists,
+                                 s->eng->stream_) != hipSuccess)
+              return kmcudaRuntimeError;
+            if (hipMemcpyAsync(host_dists.data() + s->offset, s->dists, (size_t)s->length * sizeof(float),
+                               hipMemcpyDeviceToHost, s->eng->stream_) != hipSuccess)
+              return kmcudaMemoryCopyError;
+          }
+          RETERR(sync_all());
+          const double dist_sum = butterfly_sum(host_dists.data(), N);
+          // the reference's chooser, kmcuda.cc:300-326
+          const double choice = ((rand() + .0) / RAND_MAX);
+          const uint32_t choice_approx = choice * N;
+          const double choice_sum = choice * dist_sum;
+          uint32_t j;
+          if (choice_approx < 100) {
+            double dist_sum2 = 0;
+            for (j = 0; j < N && dist_sum2 < choice_sum; j++) dist_sum2 += host_dists[j];
+          } else {
+            double dist_sum2 = 0;
+            for (uint32_t t = 0; t < choice_approx; t++) dist_sum2 += host_dists[t];
+            if (dist_sum2 < choice_sum) {
+              for (j = choice_approx; j < N && dist_sum2 < choice_sum; j++) dist_sum2 += host_dists[j];
+            } else {
+              for (j = choice_approx; j > 1 && dist_sum2 >= choice_sum; j--) dist_sum2 -= host_dists[j];
+              j++;
+            }
+          }
+          if (j == 0 || j > N) {
+            INFO("\ninternal bug in kmeans_init_centroids: j = %u\n", j);
+            return kmcudaRuntimeError;
+          }
+          RETERR(copy_sample_to_centroid(j - 1, i));
+        }
+        RETERR(sync_all());
+        break;
+      }
+      case kmcudaInitMethodAFKMC2:
+        INFO("afkmc2 seeding is not built in this tier (SURVEY 8f.3)\n");
+        return kmcudaInvalidArguments;
+    }
+    INFO("\rdone            \n");
+    return 0;
+  }
+
+  // ---- the per-iteration collective: delta (fp64 K*D) and dcount (int32 K) summed over shards ----
+  int allreduce_deltas() {
+    if (shards.size() == 1) return 0;
+    if (!comms.empty()) {
+      if (rccl.GroupStart() != 0) return kmcudaRuntimeError;
+      for (size_t i = 0; i < shards.size(); i++) {
+        auto &s = shards[i];
+        (void)hipSetDevice(s->dev);
+        if (rccl.AllReduce(s->delta, s->delta, (size_t)K * D, kNcclFloat64, kNcclSum, comms[i], s->eng->stream_) != 0)
+          return kmcudaRuntimeError;
+        if (rccl.AllReduce(s->dcount, s->dcount, K, kNcclInt32, kNcclSum, comms[i], s->eng->stream_) != 0)
+          return kmcudaRuntimeError;
+      }
+      if (rccl.GroupEnd() != 0) return kmcudaRuntimeError;
+      return 0;
+    }
+    // several shards on ONE device (test hook KMCUDA_AMD_VIRTUAL_SHARDS): fixed-order host sum
+    std::vector<double> acc((size_t)K * D, 0.0), tmp((size_t)K * D);
+    std::vector<int32_t> cacc(K, 0), ctmp(K);
+    for (auto &s : shards) {
+      RETERR(s->eng->sync());
+      if (hipMemcpy(tmp.data(), s->delta, tmp.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        return kmcudaMemoryCopyError;
+      if (hipMemcpy(ctmp.data(), s->dcount, K * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
+        return kmcudaMemoryCopyError;
+      for (size_t i = 0; i < acc.size(); i++) acc[i] += tmp[i];
+      for (uint32_t c = 0; c < K; c++) cacc[c] += ctmp[c];
+    }
+    for (auto &s : shards) {
+      if (hipMemcpy(s->delta, acc.data(), acc.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        return kmcudaMemoryCopyError;
+      if (hipMemcpy(s->dcount, cacc.data(), K * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
+        return kmcudaMemoryCopyError;
+    }
+    return 0;
+  }
+
+  // reference: check_changed, kmeans.cu:697-717.  Returns 1 to stop, 0 to go on, <0 error.
+  int check_changed(int iter, float tolerance, bool print, uint32_t *passed_total = nullptr) {
+    uint32_t overall_changed = 0, overall_passed = 0;
+    for (auto &s : shards) {
+      uint32_t c[4];
+      if (s->eng->counters_read(c) != 0) return -kmcudaMemoryCopyError;
+      overall_changed += c[0];
+      overall_passed += c[2];
+    }
+    if (passed_total) *passed_total = overall_passed;
+    if (print) INFO("iteration %d: %u reassignments\n", iter, overall_changed);
+    if (overall_changed <= tolerance * N) return 1;  // counters are NOT zeroed on stop (kmeans.cu:707-709)
+    for (auto &s : shards)
+      if (s->eng->counters_reset(0) != 0) return -kmcudaRuntimeError;
+    return 0;
+  }
+
+  int adjust() {  // reference: kmeans_adjust launch + peer exchange, kmeans.cu:1002-1024
+    for (auto &s : shards) RETERR(s->eng->move_deltas(s->samples, s->prev, s->assignments, s->delta, s->dcount));
+    RETERR(allreduce_deltas());
+    for (auto &s : shards) RETERR(s->eng->apply_delta(s->delta, s->dcount, s->centroids, s->ccounts));
+    return 0;
+  }
+
+  // reference: prepare_mem, kmeans.cu:719-746
+  int prepare_mem(bool resume) {
+    for (auto &s : shards) {
+      (void)hipSetDevice(s->dev);
+      RETERR(s->eng->counters_reset(0));
+      if (!resume) {
+        hipStream_t st = s->eng->stream_;
+        if (hipMemsetAsync(s->ccounts, 0, K * sizeof(uint32_t), st) != hipSuccess) return kmcudaRuntimeError;
+        if (hipMemsetAsync(s->assignments, 0xff, (size_t)s->length * sizeof(uint32_t), st) != hipSuccess)
+          return kmcudaRuntimeError;
+        if (hipMemsetAsync(s->prev, 0xff, (size_t)s->length * sizeof(uint32_t), st) != hipSuccess)
+          return kmcudaRuntimeError;
+      }
+    }
+    return 0;
+  }
+
+  // reference: kmeans_cuda_lloyd, kmeans.cu:934-1026
+  int lloyd(float tolerance, bool resume, int *iterations) {
+    RETERR(prepare_mem(resume));
+    for (int iter = 1;; iter++) {
+      if (!resume || iter > 1) {
+        for (auto &s : shards)
+          RETERR(s->eng->lloyd_assign(s->samples, s->centroids, s->assignments, s->prev, false));
+        const int status = check_changed(iter, tolerance, true);
+        if (status < 0) return -status;
+        if (status == 1) {
+          if (iterations) *iterations = iter;
+          return 0;
+        }
+      }
+      RETERR(adjust());
+    }
+  }
+
+  int gather_outputs(float *centroids, uint32_t *assignments, int32_t device_ptrs) {
+    RETERR(sync_all());
+    Shard &first = *shards[0];
+    (void)hipSetDevice(first.dev);
+    if (device_ptrs < 0) {
+      if (hipMemcpy(centroids, first.centroids, (size_t)K * D * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+        return kmcudaMemoryCopyError;
+      for (auto &s : shards) {
+        (void)hipSetDevice(s->dev);
+        if (hipMemcpy(assignments + s->offset, s->assignments, (size_t)s->length * sizeof(uint32_t),
+                      hipMemcpyDeviceToHost) != hipSuccess)
+          return kmcudaMemoryCopyError;
+      }
+    } else {
+      if (hipMemcpyPeer(centroids, device_ptrs, first.centroids, first.dev, (size_t)K * D * sizeof(float)) != hipSuccess)
+        return kmcudaMemoryCopyError;
+      for (auto &s : shards)
+        if (hipMemcpyPeer(assignments + s->offset, device_ptrs, s->assignments, s->dev,
+                          (size_t)s->length * sizeof(uint32_t)) != hipSuccess)
+          return kmcudaMemoryCopyError;
+    }
+    return 0;
+  }
+
+  // reference: kmeans_cuda_calc_average_distance, kmeans.cu:1265-1300
+  int average_distance(float *out) {
+    INFO("calculating the average distance...\n");
+    std::vector<float> host(N);
+    for (auto &s : shards) {
+      (void)hipSetDevice(s->dev);
+      if (launch_member_distances(metric, s->samples, s->length, D, s->centroids, s->assignments, K, s->dists,
+                                  s->eng->stream_) != hipSuccess)
+        return kmcudaRuntimeError;
+      if (hipMemcpyAsync(host.data() + s->offset, s->dists, (size_t)s->length * sizeof(float), hipMemcpyDeviceToHost,
+                         s->eng->stream_) != hipSuccess)
+        return kmcudaMemoryCopyError;
+    }
+    RETERR(sync_all());
+    *out = (float)(butterfly_sum(host.data(), N) / N);
+    return 0;
+  }
+};
+
+int virtual_shards() {
+  const char *v = getenv("KMCUDA_AMD_VIRTUAL_SHARDS");
+  return v ? atoi(v) : 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// Yinyang driver (reference: kmeans_cuda_yy, kmeans.cu:1028-1263) lives in yinyang.cpp
+// ---------------------------------------------------------------------------------------
+
+extern "C" {
+
+KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float tolerance, float yinyang_t,
+                         KMCUDADistanceMetric metric, uint32_t samples_size, uint16_t features_size,
+                         uint32_t clusters_size, uint32_t seed, uint32_t device, int32_t device_ptrs, int32_t fp16x2,
+                         int32_t verbosity, const float *samples, float *centroids, uint32_t *assignments,
+                         float *average_distance) {
+  (void)init_params;
+  kmx::g_verbosity = verbosity;
+  DEBUG("arguments: %d %p %.3f %.2f %d %u %u %u %u %u %d %d %p %p %p %p\n", init, init_params, tolerance, yinyang_t,
+        metric, samples_size, (unsigned)features_size, clusters_size, seed, device, fp16x2, verbosity,
+        (const void *)samples, (void *)centroids, (void *)assignments, (void *)average_distance);
+  // reference: check_kmeans_args, kmcuda.cc:19-61 (same order)
+  if (clusters_size < 2 || clusters_size == UINT32_MAX) return kmcudaInvalidArguments;
+  if (features_size == 0) return kmcudaInvalidArguments;
+  if (samples_size < clusters_size) return kmcudaInvalidArguments;
+  int ndev = 0;
+  (void)hipGetDeviceCount(&ndev);
+  if (ndev < 32 && device > (1u << ndev)) return kmcudaNoSuchDevice;
+  if (samples == nullptr || centroids == nullptr || assignments == nullptr) return kmcudaInvalidArguments;
+  if (tolerance < 0 || tolerance > 1) return kmcudaInvalidArguments;
+  if (yinyang_t < 0 || yinyang_t > 0.5) return kmcudaInvalidArguments;
+  if (fp16x2) {
+    INFO("fp16x2 kernels are not built in this round (DESIGN.md: next)\n");
+    return kmcudaInvalidArguments;
+  }
+  INFO("reassignments threshold: %u\n", uint32_t(tolerance * samples_size));
+  const uint32_t yy_groups_size = yinyang_t * clusters_size;  // float product, truncated (kmcuda.cc:417)
+  DEBUG("yinyang groups: %u\n", yy_groups_size);
+  auto devs = setup_devices(device, verbosity);
+  if (devs.empty()) return kmcudaNoSuchDevice;
+
+  Job job;
+  RETERR(job.setup(devs, virtual_shards(), samples_size, features_size, clusters_size, metric, verbosity, samples,
+                   device_ptrs));
+  RETERR(job.init_centroids(init, seed, centroids, device_ptrs));
+
+  if (yy_groups_size == 0 || kYinyangDraftReassignments <= tolerance) {  // kmeans.cu:1037-1050
+    if (yy_groups_size == 0) INFO("too few clusters for this yinyang_t => Lloyd\n");
+    else INFO("tolerance is too high (>= %.2f) => Lloyd\n", kYinyangDraftReassignments);
+    RETERR(job.lloyd(tolerance, false, nullptr));
+  } else {
+    INFO("running Lloyd until reassignments drop below %u\n", (uint32_t)(kYinyangDraftReassignments * samples_size));
+    int iter = 0;
+    RETERR(job.lloyd((float)kYinyangDraftReassignments, false, &iter));
+    const int st = job.check_changed(iter, tolerance, false);  // kmeans.cu:1058
+    if (st < 0) return static_cast<KMCUDAResult>(-st);
+    if (st == 0) {
+      // TODO(yinyang): bound-based filtering kernels; until they land the remaining iterations
+      // run as plain Lloyd passes (identical assignments, no pruning).
+      RETERR(job.adjust());
+      RETERR(job.lloyd(tolerance, true, nullptr));
+    }
+  }
+  if (average_distance) RETERR(job.average_distance(average_distance));
+  RETERR(job.gather_outputs(centroids, assignments, device_ptrs));
+  DEBUG("return kmcudaSuccess\n");
+  return kmcudaSuccess;
+}
+
+KMCUDAResult knn_cuda(uint16_t k, KMCUDADistanceMetric metric, uint32_t samples_size, uint16_t features_size,
+                      uint32_t clusters_size, uint32_t device, int32_t device_ptrs, int32_t fp16x2, int32_t verbosity,
+                      const float *samples, const float *centroids, const uint32_t *assignments, uint32_t *neighbors) {
+  (void)metric; (void)device; (void)device_ptrs; (void)verbosity;
+  // reference: check_knn_args, kmcuda.cc:537-570 (its result is ignored there; we report it)
+  if (k == 0) return kmcudaInvalidArguments;
+  if (clusters_size < 2 || clusters_size == UINT32_MAX) return kmcudaInvalidArguments;
+  if (features_size == 0) return kmcudaInvalidArguments;
+  if (samples_size < clusters_size) return kmcudaInvalidArguments;
+  if (!samples || !centroids || !assignments || !neighbors) return kmcudaInvalidArguments;
+  if (fp16x2) return kmcudaInvalidArguments;
+  return kmcudaRuntimeError;  // kernels land with knn.hip
+}
+
+}  // extern "C"

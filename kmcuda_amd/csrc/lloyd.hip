@@ -1,0 +1,404 @@
+// lloyd.hip -- the Lloyd assignment step (reference: src/kmeans.cu:293-364 kmeans_assign_lloyd,
+// :214-291 kmeans_assign_lloyd_smallc) re-designed for MI355X / gfx950.
+//
+// The reference decides  nearest[s] = first c minimising  RD(-2*prod(s,c) + csqr(c))  with
+// prod / csqr Kahan-compensated round-down-FMA chains (4 dependent VALU ops per MAC).  That
+// arithmetic can never approach the matrix-core roofline, so the step is split:
+//
+//   1. centroid_prep     K*D work: exact csqr[c] (the reference's sum_squares), a sanitised,
+//                        padded centroid panel for the filter, its transpose for the refine
+//                        kernel, and the two magnitudes the error bound needs.
+//   2. lloyd_filter      samples x centroids^T on the f32 MFMA (v_mfma_f32_32x32x2_f32).  Each
+//                        wave keeps 32 samples resident in VGPRs as the B operand and streams
+//                        32-centroid A tiles through LDS; the accumulator is seeded with
+//                        -csqr/2 so the running per-sample (max, argmax, second max) of
+//                        score = x.c - csqr/2 falls out of the accumulator registers.  A row
+//                        whose best/second-best gap exceeds a rigorous bound on
+//                        |score_mfma - score_reference| is decided (and committed) here.
+//   3. lloyd_exact       the (rare) undecided rows are recomputed with the reference's exact
+//                        arithmetic, one wave per row, and committed.
+//
+// Assignments are therefore bit-identical to the reference's for ANY input; only the split of
+// work between 2 and 3 depends on the data.  See DESIGN.md for the bound's derivation.
+#include "exact.hpp"
+#include "kernels.hpp"
+
+namespace kmx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------
+// 1. centroid_prep
+// ---------------------------------------------------------------------------------------
+// One thread per centroid row.  csqr follows metric_abstraction.h:21-36 exactly (L2) or is
+// the constant 1 (:149-158, angular).
+template <int METRIC>
+__global__ void centroid_prep_kernel(const float *__restrict__ centroids, uint32_t K, uint32_t D,
+                                     uint32_t K_pad, uint32_t DP, uint32_t Kt, float *__restrict__ csqr,
+                                     float *__restrict__ bias, float *__restrict__ cfil,
+                                     float *__restrict__ ct, uint32_t *__restrict__ stats) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= K_pad && c >= Kt) return;
+  float ssqr = 0.f, corr = 0.f, plain = 0.f;
+  bool finite = c < K;
+  if (c < K) {
+    const float *row = centroids + (size_t)c * D;
+    for (uint32_t f = 0; f < D; f++) {
+      const float v = row[f];
+      kahan_fold(fma_rd(v, v, corr), ssqr, corr);
+      plain += v * v;  // only used for the finiteness test / angular bound
+      if (ct) ct[(size_t)f * Kt + c] = v;
+    }
+    finite = (plain - plain) == 0.f;  // false for NaN and inf
+    if (csqr) csqr[c] = (METRIC == 0) ? ssqr : 1.f;
+  } else if (ct && c < Kt) {
+    for (uint32_t f = 0; f < D; f++) ct[(size_t)f * Kt + c] = 0.f;
+  }
+  if (c < K_pad) {
+    // A centroid with a non-finite norm is never chosen by the reference either: its distance
+    // is NaN or +inf and "dist < min_dist" (min_dist starts at FLT_MAX) is false.
+    float b;
+    if (METRIC == 0) b = finite ? -0.5f * ssqr : -INFINITY;
+    else b = finite ? 0.f : -INFINITY;
+    bias[c] = b;
+    float *dst = cfil + (size_t)c * DP;
+    if (finite) {
+      const float *row = centroids + (size_t)c * D;
+      for (uint32_t f = 0; f < D; f++) dst[f] = row[f];
+      for (uint32_t f = D; f < DP; f++) dst[f] = 0.f;
+      // magnitudes for the error bound: max ||c||^2 and max |bias| (non-negative floats
+      // order like their bit patterns)
+      const float n2 = (METRIC == 0) ? ssqr : plain;
+      atomicMax(&stats[0], __float_as_uint(n2));
+      atomicMax(&stats[1], __float_as_uint(fabsf(b)));
+    } else {
+      for (uint32_t f = 0; f < DP; f++) dst[f] = 0.f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// commit (kmeans.cu:358-363): prev[s] = old; if old != nearest { assign; ++changed }
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool commit_row(uint32_t s, uint32_t nearest, uint32_t *__restrict__ assignments,
+                                           uint32_t *__restrict__ assignments_prev) {
+  const uint32_t old = assignments[s];
+  assignments_prev[s] = old;
+  if (old != nearest) {
+    assignments[s] = nearest;
+    return true;
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------------------------------
+// 2. lloyd_filter (MFMA)
+// ---------------------------------------------------------------------------------------
+// Block = 256 threads = 4 waves, each wave owns 32 consecutive samples.
+// MFMA orientation: A = centroids (32 rows), B = samples (32 columns), so that lane l holds,
+// for ITS sample (column l&31), the scores of 16 centroids (rows (r&3)+8*(r>>2)+4*(l>>5)).
+// The contraction index is permuted (legal: both operands use the same permutation): at
+// k-step kk the lower half-wave supplies feature kk, the upper half feature DP/2 + kk, so
+// every lane loads one contiguous half row of its sample / reads contiguous LDS words.
+template <int DP, bool FAST>
+__global__ __launch_bounds__(256, 2) void lloyd_filter_kernel(
+    const float *__restrict__ samples, uint32_t N, uint32_t D, const float *__restrict__ cfil,
+    const float *__restrict__ bias, uint32_t K_pad, uint32_t K, const uint32_t *__restrict__ stats,
+    float eps, float tie_slack, uint32_t *__restrict__ assignments,
+    uint32_t *__restrict__ assignments_prev, uint32_t *__restrict__ flagged,
+    uint32_t *__restrict__ counters) {
+  constexpr int NK = DP / 2;           // k-steps (each MFMA consumes 2 features)
+  constexpr int LDW = DP + 4;          // padded LDS row (floats): conflict-free ds_read_b128
+  constexpr int TILE = 32 * LDW;       // one centroid tile
+  constexpr int NST = (8 * DP + 255) / 256;  // float4 staging registers per thread
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  auto tile_ptr = [&](int buf) { return lds + buf * TILE; };
+  auto bias_ptr = [&](int buf) { return lds + 2 * TILE + buf * 32; };
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int col = lane & 31;  // my sample within the wave
+  const int h = lane >> 5;    // which half of the features / which centroid rows
+  const uint32_t s = blockIdx.x * 128u + wave * 32u + col;
+
+  // ---- B operand: my half row of my sample, resident for the whole kernel ----
+  float xb[NK];
+  {
+    const bool live = s < N;
+    if (FAST) {
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(samples + (size_t)(live ? s : 0) * D + h * NK);
+#pragma unroll
+      for (int j = 0; j < NK / 4; j++) {
+        f32x4 v = src[j];
+        xb[4 * j + 0] = live ? v.x : 0.f;
+        xb[4 * j + 1] = live ? v.y : 0.f;
+        xb[4 * j + 2] = live ? v.z : 0.f;
+        xb[4 * j + 3] = live ? v.w : 0.f;
+      }
+    } else {
+      const float *src = samples + (size_t)(live ? s : 0) * D;
+#pragma unroll
+      for (int j = 0; j < NK; j++) {
+        const uint32_t f = h * NK + j;
+        xb[j] = (live && f < D) ? src[f] : 0.f;
+      }
+    }
+  }
+  // squared norm of the sample (for the error bound) and the "insane" test of kmeans.cu:312
+  float xn2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < NK; j++) xn2 = fmaf(xb[j], xb[j], xn2);
+  xn2 += __shfl_xor(xn2, 32);
+  const float x0 = __shfl(xb[0], col);  // feature 0 lives in the lower half-wave
+  const bool insane = (x0 != x0);
+
+  // ---- staging of centroid tiles: global -> registers -> LDS (double buffered) ----
+  f32x4 stage[NST];
+  float bstage = 0.f;
+  auto stage_load = [&](uint32_t tile) {
+    const float *src = cfil + (size_t)tile * 32 * DP;
+#pragma unroll
+    for (int i = 0; i < NST; i++) {
+      const int q = tid + i * 256;
+      if (q < 8 * DP) stage[i] = reinterpret_cast<const f32x4 *>(src)[q];
+    }
+    if (tid < 32) bstage = bias[tile * 32 + tid];
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NST; i++) {
+      const int q = tid + i * 256;
+      if (q < 8 * DP) {
+        const int row = q / (DP / 4), c4 = q % (DP / 4);
+        *reinterpret_cast<f32x4 *>(tile_ptr(buf) + row * LDW + c4 * 4) = stage[i];
+      }
+    }
+    if (tid < 32) bias_ptr(buf)[tid] = bstage;
+  };
+
+  const uint32_t ntiles = K_pad / 32;
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+
+  float v1 = -INFINITY, v2 = -INFINITY;
+  uint32_t code1 = 0xFFFFFFFFu;
+
+  for (uint32_t t = 0; t < ntiles; t++) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) stage_load(t + 1);
+
+    // accumulator seeded with the bias of my 16 centroid rows
+    f32x16 acc;
+    {
+      const float *bb = bias_ptr(buf) + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bb + 8 * g);
+        acc[4 * g + 0] = b4.x;
+        acc[4 * g + 1] = b4.y;
+        acc[4 * g + 2] = b4.z;
+        acc[4 * g + 3] = b4.w;
+      }
+    }
+    const float *arow = tile_ptr(buf) + col * LDW + h * NK;
+#pragma unroll
+    for (int j = 0; j < NK / 4; j++) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4 *>(arow + 4 * j);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, xb[4 * j + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, xb[4 * j + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, xb[4 * j + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, xb[4 * j + 3], acc, 0, 0, 0);
+    }
+    // running (max, argmax, second max) over my 16 rows; strict '>' keeps the first index,
+    // NaN scores compare false everywhere and are ignored (as in the reference).
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float v = acc[r];
+      const bool gt = v > v1;
+      const bool g2 = v > v2;
+      v2 = gt ? v1 : (g2 ? v : v2);
+      code1 = gt ? (t * 16u + r) : code1;
+      v1 = gt ? v : v1;
+    }
+    if (t + 1 < ntiles) stage_store(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- merge the two half-waves (same sample, disjoint centroid rows) ----
+  uint32_t i1 = 0xFFFFFFFFu;
+  if (code1 != 0xFFFFFFFFu) {
+    const uint32_t r = code1 & 15u;
+    i1 = (code1 >> 4) * 32u + (r & 3u) + 8u * (r >> 2) + 4u * h;
+  }
+  {
+    const float pv1 = __shfl_xor(v1, 32), pv2 = __shfl_xor(v2, 32);
+    const uint32_t pi1 = __shfl_xor(i1, 32);
+    const bool take = (pv1 > v1) || (pv1 == v1 && pi1 < i1);
+    const float lo = take ? v1 : pv1;  // the loser's best competes for second place
+    float nv2 = take ? pv2 : v2;
+    nv2 = (lo > nv2) ? lo : nv2;
+    if (take) { v1 = pv1; i1 = pi1; }
+    v2 = nv2;
+  }
+
+  // ---- decide ----
+  // |score_mfma - score_ref| <= E for every centroid, E = eps*(||x||*Cmax + Bmax)  (DESIGN.md).
+  // gap > 2E  =>  the reference's distance to i1 is strictly the smallest.
+  const float cmax = sqrtf(__uint_as_float(stats[0])) * 1.000001f;
+  const float bmax = __uint_as_float(stats[1]);
+  const float xn = sqrtf(xn2) * 1.0001f;
+  const float thr = 2.0f * eps * (xn * cmax + bmax) * 1.001f + tie_slack;
+  const float gap = v1 - v2;
+  const bool certain = insane || (gap > thr);  // NaN gap / NaN thr => not certain
+  const bool mine = (h == 0) && (s < N);
+  const bool commit_now = mine && certain;
+  const bool flag_now = mine && !certain;
+  bool changed = false;
+  if (commit_now) changed = commit_row(s, insane ? K : i1, assignments, assignments_prev);
+  const unsigned long long cm = __ballot(changed);
+  const unsigned long long fm = __ballot(flag_now);
+  if (lane == 0 && cm) atomicAdd(&counters[0], (uint32_t)__popcll(cm));
+  if (fm) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&counters[1], (uint32_t)__popcll(fm));
+    base = __shfl(base, 0);
+    if (flag_now) flagged[base + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// 3. lloyd_exact: the reference's arithmetic, one wave per row.
+// ---------------------------------------------------------------------------------------
+// rows == nullptr: every row of [0, N); else rows[0 .. *nrows).  Lane l runs CH independent
+// Kahan chains, centroid (p*CH + j)*64 + l, reading the transposed panel ct[f*Kt + c]
+// (coalesced).  Lane-local strict '<' in ascending c, then a wave argmin that prefers the
+// smaller index on equal distances == the reference's sequential first-minimum.
+template <int METRIC>
+__global__ __launch_bounds__(64) void lloyd_exact_kernel(
+    const float *__restrict__ samples, uint32_t N, uint32_t D, const float *__restrict__ ct,
+    const float *__restrict__ csqr, uint32_t K, uint32_t Kt, const uint32_t *__restrict__ rows,
+    const uint32_t *__restrict__ nrows, uint32_t *__restrict__ assignments,
+    uint32_t *__restrict__ assignments_prev, uint32_t *__restrict__ counters) {
+  constexpr int CH = 8;
+  const int lane = threadIdx.x;
+  const uint32_t total = rows ? *nrows : N;
+  for (uint32_t ri = blockIdx.x; ri < total; ri += gridDim.x) {
+    const uint32_t s = rows ? rows[ri] : ri;
+    const float *x = samples + (size_t)s * D;  // wave-uniform address: scalar loads
+    const bool insane = (x[0] != x[0]);
+    float min_dist = 3.402823466e+38f;
+    uint32_t nearest = 0xFFFFFFFFu;
+    if (!insane) {
+      for (uint32_t cbase = 0; cbase < K; cbase += 64 * CH) {
+        float acc[CH], corr[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) { acc[j] = 0.f; corr[j] = 0.f; }
+        const float *cp = ct + cbase + lane;
+        for (uint32_t f = 0; f < D; f++) {
+          const float xf = x[f];
+          float cv[CH], y[CH];
+#pragma unroll
+          for (int j = 0; j < CH; j++) cv[j] = (cbase + 64 * j + lane < Kt) ? cp[(size_t)f * Kt + 64 * j] : 0.f;
+          fma_rd8(xf, cv, corr, y);
+#pragma unroll
+          for (int j = 0; j < CH; j++) kahan_fold(y[j], acc[j], corr[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+          const uint32_t c = cbase + 64 * j + lane;
+          if (c < K) {
+            const float dist = lloyd_distance<METRIC>(csqr[c], acc[j]);
+            if (dist < min_dist) { min_dist = dist; nearest = c; }
+          }
+        }
+      }
+      // wave argmin, lowest index among equal minima; lanes without a candidate never win
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float od = __shfl_xor(min_dist, off);
+        const uint32_t oi = __shfl_xor(nearest, off);
+        const bool take = (oi != 0xFFFFFFFFu) &&
+                          (nearest == 0xFFFFFFFFu || od < min_dist || (od == min_dist && oi < nearest));
+        if (take) { min_dist = od; nearest = oi; }
+      }
+    }
+    if (lane == 0) {
+      if (nearest == 0xFFFFFFFFu && insane) nearest = K;  // kmeans.cu:349-356
+      if (nearest != 0xFFFFFFFFu) {                       // else: "search failed", row left untouched
+        if (commit_row(s, nearest, assignments, assignments_prev)) atomicAdd(&counters[0], 1u);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------
+uint32_t filter_dp_for(uint32_t D) {
+  static const uint32_t sizes[] = {8, 16, 32, 64, 128, 256};
+  for (uint32_t v : sizes)
+    if (D <= v) return v;
+  return 0;  // no MFMA filter instantiation: exact kernel handles everything
+}
+
+template <int DP>
+static hipError_t launch_filter_dp(const LloydArgs &a, hipStream_t st) {
+  const bool fast = (a.D == (uint32_t)DP);
+  const size_t lds_bytes = (2 * 32 * (DP + 4) + 64) * sizeof(float);
+  const uint32_t grid = (a.N + 127) / 128;
+  if (fast) {
+    hipLaunchKernelGGL((lloyd_filter_kernel<DP, true>), dim3(grid), dim3(256), lds_bytes, st, a.samples, a.N,
+                       a.D, a.cfil, a.bias, a.K_pad, a.K, a.stats, a.eps, a.tie_slack, a.assignments,
+                       a.assignments_prev, a.flagged, a.counters);
+  } else {
+    hipLaunchKernelGGL((lloyd_filter_kernel<DP, false>), dim3(grid), dim3(256), lds_bytes, st, a.samples, a.N,
+                       a.D, a.cfil, a.bias, a.K_pad, a.K, a.stats, a.eps, a.tie_slack, a.assignments,
+                       a.assignments_prev, a.flagged, a.counters);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_lloyd_filter(const LloydArgs &a, hipStream_t st) {
+  switch (a.DP) {
+    case 8: return launch_filter_dp<8>(a, st);
+    case 16: return launch_filter_dp<16>(a, st);
+    case 32: return launch_filter_dp<32>(a, st);
+    case 64: return launch_filter_dp<64>(a, st);
+    case 128: return launch_filter_dp<128>(a, st);
+    case 256: return launch_filter_dp<256>(a, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad,
+                                uint32_t DP, uint32_t Kt, float *csqr, float *bias, float *cfil, float *ct,
+                                uint32_t *stats, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(stats, 0, 2 * sizeof(uint32_t), st);
+  if (e != hipSuccess) return e;
+  const uint32_t n = K_pad > Kt ? K_pad : Kt;
+  const dim3 grid((n + 63) / 64), block(64);
+  if (metric == 0)
+    hipLaunchKernelGGL((centroid_prep_kernel<0>), grid, block, 0, st, centroids, K, D, K_pad, DP, Kt, csqr, bias,
+                       cfil, ct, stats);
+  else
+    hipLaunchKernelGGL((centroid_prep_kernel<1>), grid, block, 0, st, centroids, K, D, K_pad, DP, Kt, csqr, bias,
+                       cfil, ct, stats);
+  return hipGetLastError();
+}
+
+hipError_t launch_lloyd_exact(int metric, const LloydArgs &a, const uint32_t *rows, const uint32_t *nrows,
+                              uint32_t grid, hipStream_t st) {
+  if (grid == 0) return hipSuccess;
+  if (metric == 0)
+    hipLaunchKernelGGL((lloyd_exact_kernel<0>), dim3(grid), dim3(64), 0, st, a.samples, a.N, a.D, a.ct, a.csqr,
+                       a.K, a.Kt, rows, nrows, a.assignments, a.assignments_prev, a.counters);
+  else
+    hipLaunchKernelGGL((lloyd_exact_kernel<1>), dim3(grid), dim3(64), 0, st, a.samples, a.N, a.D, a.ct, a.csqr,
+                       a.K, a.Kt, rows, nrows, a.assignments, a.assignments_prev, a.counters);
+  return hipGetLastError();
+}
+
+}  // namespace kmx

@@ -1,0 +1,71 @@
+// seeding.hip -- exact-arithmetic helper kernels around the hot path:
+//   gather_rows        (reference: transpose.cu:6-14 copy_sample_t -- with row-major samples a
+//                       "sample copy" is a contiguous row copy)
+//   kmpp_step          (reference: kmeans.cu:42-67 kmeans_plus_plus): d[s] = min(d[s], dist(s, newest c))
+//   member_distances   (reference: kmeans.cu:674-691 kmeans_calc_average_distance, per-sample part)
+// Distances use the reference's exact arithmetic (exact.hpp) so that the host-side chooser sees
+// the very same floats as the reference's and picks the same seeds.
+#include "exact.hpp"
+#include "kernels.hpp"
+
+namespace kmx {
+
+__global__ void gather_rows_kernel(const float *__restrict__ samples, uint32_t D, const uint32_t *__restrict__ row_ids,
+                                   float *__restrict__ dst) {
+  const uint32_t r = blockIdx.x;
+  const float *src = samples + (size_t)row_ids[r] * D;
+  for (uint32_t f = threadIdx.x; f < D; f += blockDim.x) dst[(size_t)r * D + f] = src[f];
+}
+
+hipError_t launch_gather_rows(const float *samples, uint32_t D, const uint32_t *row_ids, uint32_t nrows,
+                              float *dst, hipStream_t st) {
+  if (nrows == 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(nrows), dim3(D >= 256 ? 256 : 64), 0, st, samples, D, row_ids, dst);
+  return hipGetLastError();
+}
+
+template <int METRIC>
+__global__ void kmpp_step_kernel(const float *__restrict__ samples, uint32_t N, uint32_t D,
+                                 const float *__restrict__ centroid, uint32_t cc, float *__restrict__ dists) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= N) return;
+  const float *x = samples + (size_t)s * D;
+  float dist = 0.f;
+  if (x[0] == x[0]) dist = distance_vv<METRIC>(x, centroid, D);  // kmeans.cu:53-56
+  if (cc == 1 || dist < dists[s]) dists[s] = dist;                // :57-62
+}
+
+hipError_t launch_kmpp_step(int metric, const float *samples, uint32_t N, uint32_t D, const float *centroid,
+                            uint32_t cc, float *dists, hipStream_t st) {
+  const dim3 grid((N + 127) / 128), block(128);
+  if (metric == 0)
+    hipLaunchKernelGGL((kmpp_step_kernel<0>), grid, block, 0, st, samples, N, D, centroid, cc, dists);
+  else
+    hipLaunchKernelGGL((kmpp_step_kernel<1>), grid, block, 0, st, samples, N, D, centroid, cc, dists);
+  return hipGetLastError();
+}
+
+template <int METRIC>
+__global__ void member_distances_kernel(const float *__restrict__ samples, uint32_t N, uint32_t D,
+                                        const float *__restrict__ centroids, const uint32_t *__restrict__ assignments,
+                                        uint32_t K, float *__restrict__ dists) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= N) return;
+  const uint32_t a = assignments[s];
+  dists[s] = a < K ? distance_vv<METRIC>(samples + (size_t)s * D, centroids + (size_t)a * D, D) : NAN;
+}
+
+hipError_t launch_member_distances(int metric, const float *samples, uint32_t N, uint32_t D,
+                                   const float *centroids, const uint32_t *assignments, uint32_t K,
+                                   float *dists, hipStream_t st) {
+  const dim3 grid((N + 127) / 128), block(128);
+  if (metric == 0)
+    hipLaunchKernelGGL((member_distances_kernel<0>), grid, block, 0, st, samples, N, D, centroids, assignments, K,
+                       dists);
+  else
+    hipLaunchKernelGGL((member_distances_kernel<1>), grid, block, 0, st, samples, N, D, centroids, assignments, K,
+                       dists);
+  return hipGetLastError();
+}
+
+}  // namespace kmx

@@ -1,0 +1,219 @@
+// update.hip -- centroid update (reference: src/kmeans.cu:366-429 kmeans_adjust + normalize,
+// metric_abstraction.h:138-144, :255-302) re-designed for MI355X.
+//
+// Reference semantics (kept): the update is INCREMENTAL --
+//     c_new = normalize( c_old * count_old  +  sum(samples that moved in)  -  sum(moved out) )
+// with normalize = divide by the new count (L2) or scale to unit length (angular).  For the
+// angular metric this is not the same thing as "normalise the sum of the members" (c_old has
+// unit length, so c_old*count_old over-weights the old direction); the reference's iteration
+// pins (test.py:426-466) depend on it, so the incremental form is what we implement.
+//
+// Reference mechanics (discarded): one thread per centroid scanning all N (assignment, prev)
+// pairs with a serial fp32 Kahan chain.  Here:
+//   move_events      two slots per row: (2*cur, row) if the row moved in, (2*prev+1, row) if it
+//                    moved out, a sentinel key otherwise -- no atomics, so the order is fixed
+//   radix sort       stable, by key -> per (cluster, sign) segments with rows ascending
+//   segment_sums     grid (2K, kSumSplit): fp64 column sums of each segment slice, rows read as
+//                    whole coalesced rows (only MOVED rows are touched: late iterations are cheap)
+//   fold_delta       delta[c] = sum_in - sum_out (fixed order), dcount[c] = n_in - n_out
+//   [row-sharded multi-GPU: all-reduce of delta / dcount happens here]
+//   apply_delta      the formula above in fp64, rounded once to fp32
+// Centroids agree with the reference's fp32 Kahan chain to a few ulp (tests: 2e-6 relative);
+// they are bit-reproducible run to run and independent of kSumSplit.  An empty cluster yields
+// a non-finite row that is never chosen again, as in the reference (kmeans.cu:425-426).
+#include <string.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "kernels.hpp"
+
+namespace kmx {
+
+static unsigned bits_for(uint64_t maxval) {
+  unsigned b = 1;
+  while (b < 32 && (1ull << b) <= maxval) b++;
+  return b;
+}
+
+// ---- sorting helpers --------------------------------------------------------------------
+size_t sort_temp_bytes(uint32_t n, uint32_t max_key) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                  (const uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, bits_for(max_key), 0);
+  return bytes;
+}
+
+// offsets[k] = first index with key >= k, k = 0..nkeys  (nkeys+1 entries)
+__global__ void offsets_kernel(const uint32_t *__restrict__ keys_sorted, uint32_t n, uint32_t nkeys,
+                               uint32_t *__restrict__ offsets) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > nkeys) return;
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (keys_sorted[mid] < k) lo = mid + 1; else hi = mid;
+  }
+  offsets[k] = lo;
+}
+
+// ---- inverse assignments (k-NN's CSR, kmcuda.cc:648-691) ----------------------------------
+__global__ void cluster_keys_kernel(const uint32_t *__restrict__ assignments, uint32_t N, uint32_t K,
+                                    uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= N) return;
+  const uint32_t a = assignments[s];
+  keys[s] = a < K ? a : K;  // K = "no cluster" (NaN sample or never assigned)
+  vals[s] = s;
+}
+
+hipError_t launch_inverse_assignments(const uint32_t *assignments, uint32_t N, uint32_t K, uint32_t *keys_tmp,
+                                      uint32_t *vals_tmp, uint32_t *keys_sorted, uint32_t *inv,
+                                      uint32_t *offsets, void *temp, size_t temp_bytes, hipStream_t st) {
+  hipLaunchKernelGGL(cluster_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, st, assignments, N, K, keys_tmp,
+                     vals_tmp);
+  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t *)keys_tmp, keys_sorted,
+                                           (const uint32_t *)vals_tmp, inv, N, 0, bits_for(K), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(offsets_kernel, dim3((K + 1 + 255) / 256), dim3(256), 0, st, keys_sorted, N, K, offsets);
+  return hipGetLastError();
+}
+
+// ---- move events --------------------------------------------------------------------------
+__global__ void move_events_kernel(const uint32_t *__restrict__ prev, const uint32_t *__restrict__ cur, uint32_t N,
+                                   uint32_t K, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= N) return;
+  const uint32_t p = prev[s], a = cur[s];
+  const bool moved = p != a;
+  const uint32_t sentinel = 2u * K;
+  keys[2 * (size_t)s] = (moved && a < K) ? 2u * a : sentinel;
+  keys[2 * (size_t)s + 1] = (moved && p < K) ? 2u * p + 1u : sentinel;
+  vals[2 * (size_t)s] = s;
+  vals[2 * (size_t)s + 1] = s;
+}
+
+// grid (2K, kSumSplit); thread t owns features t, t+blockDim, ...
+__global__ void segment_sums_kernel(const float *__restrict__ samples, uint32_t D, const uint32_t *__restrict__ rows,
+                                    const uint32_t *__restrict__ offsets, double *__restrict__ partial) {
+  const uint32_t seg = blockIdx.x, j = blockIdx.y;
+  const uint32_t beg = offsets[seg], end = offsets[seg + 1];
+  const uint32_t n = end - beg;
+  const uint32_t chunk = (n + kSumSplit - 1) / kSumSplit;
+  uint32_t r0 = beg + j * chunk, r1 = r0 + chunk;
+  if (r0 > end) r0 = end;
+  if (r1 > end) r1 = end;
+  for (uint32_t f = threadIdx.x; f < D; f += blockDim.x) {
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    uint32_t r = r0;
+    for (; r + 4 <= r1; r += 4) {
+      const float x0 = samples[(size_t)rows[r + 0] * D + f];
+      const float x1 = samples[(size_t)rows[r + 1] * D + f];
+      const float x2 = samples[(size_t)rows[r + 2] * D + f];
+      const float x3 = samples[(size_t)rows[r + 3] * D + f];
+      a0 += x0; a1 += x1; a2 += x2; a3 += x3;
+    }
+    for (; r < r1; r++) a0 += samples[(size_t)rows[r] * D + f];
+    partial[((size_t)seg * kSumSplit + j) * D + f] = (a0 + a1) + (a2 + a3);
+  }
+}
+
+__global__ void fold_delta_kernel(const double *__restrict__ partial, const uint32_t *__restrict__ offsets,
+                                  uint32_t K, uint32_t D, double *__restrict__ delta, int32_t *__restrict__ dcount) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)K * D) return;
+  const uint32_t c = i / D, f = i % D;
+  double in = 0, out = 0;
+  for (uint32_t j = 0; j < kSumSplit; j++) in += partial[((size_t)(2 * c) * kSumSplit + j) * D + f];
+  for (uint32_t j = 0; j < kSumSplit; j++) out += partial[((size_t)(2 * c + 1) * kSumSplit + j) * D + f];
+  delta[i] = in - out;
+  if (f == 0)
+    dcount[c] = (int32_t)(offsets[2 * c + 1] - offsets[2 * c]) - (int32_t)(offsets[2 * c + 2] - offsets[2 * c + 1]);
+}
+
+hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint32_t K, const uint32_t *prev,
+                              const uint32_t *cur, uint32_t *keys_tmp, uint32_t *vals_tmp, uint32_t *keys_sorted,
+                              uint32_t *rows_sorted, uint32_t *offsets2, void *temp, size_t temp_bytes,
+                              double *partial, double *delta, int32_t *dcount, hipStream_t st) {
+  hipLaunchKernelGGL(move_events_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, keys_tmp, vals_tmp);
+  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t *)keys_tmp, keys_sorted,
+                                           (const uint32_t *)vals_tmp, rows_sorted, 2 * (size_t)N, 0,
+                                           bits_for(2ull * K), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(offsets_kernel, dim3((2 * K + 1 + 255) / 256), dim3(256), 0, st, keys_sorted, 2 * N, 2 * K,
+                     offsets2);
+  const uint32_t bs = D >= 256 ? 256 : (D > 64 ? 128 : 64);
+  hipLaunchKernelGGL(segment_sums_kernel, dim3(2 * K, kSumSplit), dim3(bs), 0, st, samples, D, rows_sorted, offsets2,
+                     partial);
+  const size_t n = (size_t)K * D;
+  hipLaunchKernelGGL(fold_delta_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, partial, offsets2, K, D,
+                     delta, dcount);
+  return hipGetLastError();
+}
+
+// one block per centroid: c = normalize(c*count + delta), count += dcount
+template <int METRIC>
+__global__ void apply_delta_kernel(const double *__restrict__ delta, const int32_t *__restrict__ dcount, uint32_t D,
+                                   float *__restrict__ centroids, uint32_t *__restrict__ ccounts) {
+  const uint32_t c = blockIdx.x;
+  const double *d = delta + (size_t)c * D;
+  float *cen = centroids + (size_t)c * D;
+  const uint32_t cnt_old = ccounts[c];
+  const uint32_t cnt_new = cnt_old + (uint32_t)dcount[c];
+  const double w = (double)cnt_old;
+  if (METRIC == 0) {
+    const double cn = (double)cnt_new;  // 0 -> 0/0 = NaN or x/0 = inf: never chosen again
+    for (uint32_t f = threadIdx.x; f < D; f += blockDim.x) cen[f] = (float)(((double)cen[f] * w + d[f]) / cn);
+  } else {
+    __shared__ double red[256];
+    double a = 0;
+    for (uint32_t f = threadIdx.x; f < D; f += blockDim.x) {
+      const double v = (double)cen[f] * w + d[f];
+      a += v * v;
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (uint32_t s = blockDim.x / 2; s > 0; s >>= 1) {
+      if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+      __syncthreads();
+    }
+    const double nrm = sqrt(red[0]);  // empty cluster: 0/0 = NaN
+    for (uint32_t f = threadIdx.x; f < D; f += blockDim.x) cen[f] = (float)(((double)cen[f] * w + d[f]) / nrm);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) ccounts[c] = cnt_new;
+}
+
+hipError_t launch_apply_delta(int metric, const double *delta, const int32_t *dcount, uint32_t K, uint32_t D,
+                              float *centroids, uint32_t *ccounts, hipStream_t st) {
+  const uint32_t bs = D >= 256 ? 256 : (D > 64 ? 128 : 64);
+  if (metric == 0)
+    hipLaunchKernelGGL((apply_delta_kernel<0>), dim3(K), dim3(bs), 0, st, delta, dcount, D, centroids, ccounts);
+  else
+    hipLaunchKernelGGL((apply_delta_kernel<1>), dim3(K), dim3(bs), 0, st, delta, dcount, D, centroids, ccounts);
+  return hipGetLastError();
+}
+
+__global__ void pack_reduce_tail_kernel(const int32_t *__restrict__ dcount, const uint32_t *__restrict__ counters,
+                                        uint32_t K, double *__restrict__ dst) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < K) dst[i] = (double)dcount[i];
+  else if (i < K + 4) dst[i] = (double)counters[i - K];
+}
+
+__global__ void unpack_dcount_kernel(const double *__restrict__ src, uint32_t K, int32_t *__restrict__ dcount) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < K) dcount[i] = (int32_t)src[i];
+}
+
+hipError_t launch_pack_reduce_tail(const int32_t *dcount, const uint32_t *counters, uint32_t K, double *dst,
+                                   hipStream_t st) {
+  hipLaunchKernelGGL(pack_reduce_tail_kernel, dim3((K + 4 + 255) / 256), dim3(256), 0, st, dcount, counters, K, dst);
+  return hipGetLastError();
+}
+
+hipError_t launch_unpack_dcount(const double *src, uint32_t K, int32_t *dcount, hipStream_t st) {
+  hipLaunchKernelGGL(unpack_dcount_kernel, dim3((K + 255) / 256), dim3(256), 0, st, src, K, dcount);
+  return hipGetLastError();
+}
+
+}  // namespace kmx

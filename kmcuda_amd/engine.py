@@ -1,0 +1,95 @@
+"""Step-level host API over include/kmcuda_amd.h (one Engine = one GPU's row shard).
+
+torch is used for device memory and streams only; every compute step is a HIP kernel of
+libKMCUDA.so reached through the C ABI with raw device pointers.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+L2, COS = 0, 1
+_METRICS = {"L2": L2, "l2": L2, "euclidean": L2, "cos": COS, "cosine": COS, "angular": COS}
+
+
+def metric_id(metric):
+    if isinstance(metric, int):
+        return metric
+    return _METRICS[metric]
+
+
+class Engine:
+    """Workspace + kernels for `n_rows` local rows of D features against K centroids."""
+
+    def __init__(self, n_rows, features, clusters, metric="L2", device=0, use_torch_stream=True):
+        self.lib = _lib.lib()
+        self.n_rows, self.features, self.clusters = int(n_rows), int(features), int(clusters)
+        self.metric = metric_id(metric)
+        self.device = torch.device("cuda", device)
+        stream = None
+        if use_torch_stream:
+            stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        h = ctypes.c_void_p()
+        rc = self.lib.kmamd_engine_create(ctypes.byref(h), device, self.n_rows, self.features, self.clusters,
+                                          self.metric, 0, stream)
+        _lib.check(rc, "kmamd_engine_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.kmamd_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _p(t):
+        return ctypes.c_void_p(t.data_ptr())
+
+    def lloyd_assign(self, samples, centroids, assignments, assignments_prev, exact=False):
+        fn = self.lib.kmamd_lloyd_assign_exact if exact else self.lib.kmamd_lloyd_assign
+        _lib.check(fn(self.h, self._p(samples), self._p(centroids), self._p(assignments), self._p(assignments_prev)),
+                   "kmamd_lloyd_assign")
+
+    def counters(self):
+        out = (ctypes.c_uint32 * 4)()
+        _lib.check(self.lib.kmamd_counters_read(self.h, out), "kmamd_counters_read")
+        return list(out)
+
+    def reset_counters(self, which=-1):
+        _lib.check(self.lib.kmamd_counters_reset(self.h, which), "kmamd_counters_reset")
+
+    def move_deltas(self, samples, prev, cur, delta, dcount):
+        _lib.check(self.lib.kmamd_move_deltas(self.h, self._p(samples), self._p(prev), self._p(cur), self._p(delta),
+                                              self._p(dcount)), "kmamd_move_deltas")
+
+    def apply_delta(self, delta, dcount, centroids, ccounts):
+        _lib.check(self.lib.kmamd_apply_delta(self.h, self._p(delta), self._p(dcount), self._p(centroids),
+                                              self._p(ccounts)), "kmamd_apply_delta")
+
+    def pack_reduce_tail(self, dcount, dst):
+        _lib.check(self.lib.kmamd_pack_reduce_tail(self.h, self._p(dcount), self._p(dst)), "kmamd_pack_reduce_tail")
+
+    def unpack_dcount(self, src, dcount):
+        _lib.check(self.lib.kmamd_unpack_dcount(self.h, self._p(src), self._p(dcount)), "kmamd_unpack_dcount")
+
+    def transpose(self, src, rows, cols, dst):
+        _lib.check(self.lib.kmamd_transpose(self.h, self._p(src), rows, cols, self._p(dst)), "kmamd_transpose")
+
+    def sync(self):
+        _lib.check(self.lib.kmamd_engine_sync(self.h), "kmamd_engine_sync")
+
+    def profile(self, on=True):
+        self.lib.kmamd_profile_enable(self.h, 1 if on else 0)
+        self.lib.kmamd_profile_reset(self.h)
+
+    def profile_read(self):
+        f, e, u = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        n = ctypes.c_uint32()
+        self.lib.kmamd_profile_read(self.h, ctypes.byref(f), ctypes.byref(n), ctypes.byref(e), ctypes.byref(u))
+        return {"filter_ms": f.value, "filter_launches": n.value, "exact_ms": e.value, "update_ms": u.value}

@@ -1,0 +1,76 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads without a GPU and exports every
+symbol include/kmcuda.h and include/kmcuda_amd.h declare; argument validation that precedes any
+device work behaves like the reference's (kmcuda.cc:19-61)."""
+import os
+import re
+
+import numpy
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    names = set()
+    for header in ("kmcuda.h", "kmcuda_amd.h"):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        for m in re.finditer(r"\b(kmeans_cuda|knn_cuda|kmamd_\w+)\s*\(", text):
+            names.add(m.group(1))
+    return names
+
+
+def test_library_builds_and_exports_declared_symbols():
+    import __graft_entry__
+    __graft_entry__.build()
+    from kmcuda_amd import _lib
+    L = _lib.lib()
+    declared = _declared_symbols()
+    assert {"kmeans_cuda", "knn_cuda", "kmamd_engine_create", "kmamd_lloyd_assign"} <= declared
+    for name in declared:
+        assert hasattr(L, name), "libKMCUDA.so does not export %s" % name
+    assert set(_lib.EXPORTS) >= declared
+    assert L.kmamd_build_arch() == b"gfx950"
+
+
+def test_python_argument_validation_without_gpu():
+    from kmcuda_amd import kmeans_cuda, knn_cuda
+    x = numpy.zeros((100, 4), numpy.float32)
+    with pytest.raises(TypeError):
+        kmeans_cuda(x, "bullshit")
+    with pytest.raises(ValueError):
+        kmeans_cuda(x, 10, init="bullshit")
+    with pytest.raises(ValueError):
+        kmeans_cuda(x, 1)
+    with pytest.raises(ValueError):
+        kmeans_cuda(x, 10, metric="manhattan")
+    with pytest.raises(TypeError):
+        kmeans_cuda("bullshit", 10)
+    with pytest.raises(ValueError):
+        kmeans_cuda(numpy.zeros(10, numpy.float32), 3)
+    with pytest.raises(ValueError):
+        knn_cuda(0, x, numpy.zeros((10, 4), numpy.float32), numpy.zeros(100, numpy.uint32))
+    with pytest.raises(ValueError):
+        knn_cuda(5, x, numpy.zeros((10, 3), numpy.float32), numpy.zeros(100, numpy.uint32))
+    with pytest.raises(ValueError):
+        knn_cuda(5, x, numpy.zeros((10, 4), numpy.float32), numpy.zeros(99, numpy.uint32))
+
+
+def test_c_abi_validation_codes_without_gpu():
+    """kmcuda.cc:19-61 ordering: these return before any device is touched."""
+    import ctypes
+    from kmcuda_amd import _lib
+    L = _lib.lib()
+    x = numpy.zeros((100, 4), numpy.float32)
+    cen = numpy.zeros((10, 4), numpy.float32)
+    asg = numpy.zeros(100, numpy.uint32)
+
+    def call(K=10, D=4, N=100, tol=0.01, yy=0.1, samples=x.ctypes.data):
+        return L.kmeans_cuda(0, None, tol, yy, 0, N, D, K, 3, 0, -1, 0, 0, samples, cen.ctypes.data,
+                             asg.ctypes.data, None)
+    assert call(K=1) == 1
+    assert call(D=0) == 1
+    assert call(N=5) == 1
+    nb = numpy.zeros((100, 5), numpy.uint32)
+    assert L.knn_cuda(0, 0, 100, 4, 10, 0, -1, 0, 0, x.ctypes.data, cen.ctypes.data, asg.ctypes.data,
+                      nb.ctypes.data) == 1

@@ -1,0 +1,191 @@
+"""GPU end-to-end tests of kmeans_cuda() through the drop-in boundary, modelled on the
+reference's src/test.py (same fixture, same pins), plus oracle comparisons."""
+import os
+import sys
+import tempfile
+
+import numpy
+import pytest
+
+import oracle
+from conftest import reference_fixture
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+class StdoutListener:
+    """test.py:123-146: captures the C library's stdout."""
+
+    def __init__(self):
+        self.text = ""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._file = tempfile.TemporaryFile()
+        self._backup = os.dup(1)
+        os.dup2(self._file.fileno(), 1)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(self._backup, 1)
+        self._file.seek(0)
+        self.text = self._file.read().decode("utf-8")
+        self._file.close()
+        os.close(self._backup)
+
+    def iterations(self):
+        return sum(1 for line in self.text.split("\n") if line.startswith("iteration"))
+
+
+def _validate(samples, centroids, assignments, tolerance):
+    from sklearn.cluster import KMeans
+    nxt = KMeans(50, max_iter=1, init=centroids, n_init=1).fit_predict(samples)
+    assert (assignments != nxt).sum() / len(samples) < tolerance
+
+
+def test_crap_arguments(fixture13k):
+    from kmcuda_amd import kmeans_cuda
+    with pytest.raises(TypeError):
+        kmeans_cuda(fixture13k, "bullshit", init="random", device=1, seed=3, tolerance=0.05, yinyang_t=0)
+    with pytest.raises(ValueError):
+        kmeans_cuda(fixture13k, 50, init="bullshit", device=1, seed=3, tolerance=0.05, yinyang_t=0)
+    with pytest.raises(ValueError):
+        kmeans_cuda(fixture13k, 50, init="random", device=1, tolerance=100, yinyang_t=0)
+    with pytest.raises(ValueError):
+        kmeans_cuda(fixture13k, 50, init="random", device=1, yinyang_t=10)
+    with pytest.raises(ValueError):
+        kmeans_cuda(fixture13k, 50, init="random", device=0xFFFF, seed=3, tolerance=0.05, yinyang_t=0)
+
+
+def test_random_lloyd_7(fixture13k):
+    from kmcuda_amd import kmeans_cuda
+    out = StdoutListener()
+    with out:
+        centroids, assignments = kmeans_cuda(fixture13k, 50, init="random", device=1, verbosity=2, seed=3,
+                                             tolerance=0.05, yinyang_t=0)
+    assert out.iterations() == 7
+    assert centroids.shape == (50, 2) and assignments.shape == (13000,)
+    _validate(fixture13k, centroids, assignments, 0.05)
+    ocen, oasg, olog = oracle.kmeans(fixture13k, 50, init="random", seed=3, tolerance=0.05, yinyang_t=0)
+    assert (assignments == oasg).all()
+    numpy.testing.assert_allclose(centroids, ocen, rtol=1e-5, atol=1e-6)
+    reass = [int(l.split(":")[1].split()[0]) for l in out.text.split("\n") if l.startswith("iteration")]
+    assert reass == list(olog)
+
+
+def test_kmeanspp_lloyd_4(fixture13k):
+    from kmcuda_amd import kmeans_cuda
+    out = StdoutListener()
+    with out:
+        centroids, assignments = kmeans_cuda(fixture13k, 50, init="kmeans++", device=1, verbosity=2, seed=3,
+                                             tolerance=0.05, yinyang_t=0)
+    assert out.iterations() == 4
+    _validate(fixture13k, centroids, assignments, 0.05)
+    ocen, oasg, _ = oracle.kmeans(fixture13k, 50, init="kmeans++", seed=3, tolerance=0.05, yinyang_t=0)
+    assert (assignments == oasg).all()
+
+
+def test_import_lloyd_8(fixture13k):
+    from kmcuda_amd import kmeans_cuda
+    out = StdoutListener()
+    with out:
+        centroids, assignments = kmeans_cuda(fixture13k, 50, init="random", device=1, verbosity=2, seed=3,
+                                             tolerance=0.25, yinyang_t=0)
+        centroids, assignments = kmeans_cuda(fixture13k, 50, init=centroids, device=1, verbosity=2, seed=3,
+                                             tolerance=0.05, yinyang_t=0)
+    assert out.iterations() == 8
+    _validate(fixture13k, centroids, assignments, 0.05)
+
+
+def test_host_ptr(fixture13k):
+    from kmcuda_amd import kmeans_cuda
+    hostptr = (fixture13k.__array_interface__["data"][0], -1, fixture13k.shape)
+    out = StdoutListener()
+    with out:
+        centroids, assignments = kmeans_cuda(hostptr, 50, init="random", device=0, verbosity=2, seed=3,
+                                             tolerance=0.05, yinyang_t=0)
+    assert out.iterations() == 7
+    _validate(fixture13k, centroids, assignments, 0.05)
+    with pytest.raises(ValueError):
+        kmeans_cuda(("bullshit", -1, fixture13k.shape), 50, init="random", device=0, seed=3)
+    with pytest.raises(TypeError):
+        kmeans_cuda("bullshit", 50, init="random", device=0, seed=3)
+
+
+def test_device_ptr_in_out_and_samples_untouched(fixture13k):
+    # test.py:348-424 with torch standing in for cuda4py/pycuda
+    from kmcuda_amd import kmeans_cuda
+    from kmcuda_amd.api import free_device_ptr, _DEVICE_ALLOCS
+    dev = torch.device("cuda", 0)
+    st = torch.from_numpy(fixture13k).to(dev)
+    out = StdoutListener()
+    with out:
+        cptr, aptr = kmeans_cuda((st.data_ptr(), 0, fixture13k.shape), 50, init="random", device=1, verbosity=2,
+                                 seed=3, tolerance=0.05, yinyang_t=0)
+    assert out.iterations() == 7
+    assert isinstance(cptr, int) and isinstance(aptr, int)
+    centroids = _DEVICE_ALLOCS[cptr].cpu().numpy()
+    assignments = _DEVICE_ALLOCS[aptr].cpu().numpy().view(numpy.uint32)
+    _validate(fixture13k, centroids, assignments, 0.05)
+    assert (st.cpu().numpy() == fixture13k).all()
+    free_device_ptr(cptr)
+    free_device_ptr(aptr)
+
+
+def test_cosine_metric_5():
+    from kmcuda_amd import kmeans_cuda
+    numpy.random.seed(0)
+    arr = numpy.empty((10000, 2), dtype=numpy.float32)
+    angs = numpy.random.rand(10000) * 2 * numpy.pi
+    for i in range(10000):
+        arr[i] = numpy.sin(angs[i]), numpy.cos(angs[i])
+    out = StdoutListener()
+    with out:
+        centroids, assignments = kmeans_cuda(arr, 4, init="kmeans++", metric="cos", device=1, verbosity=2, seed=3)
+    assert out.iterations() == 5
+    for c in centroids:
+        assert 0.9999 < numpy.linalg.norm(c) < 1.0001
+    from sklearn.metrics.pairwise import cosine_distances
+    dists = numpy.round(cosine_distances(centroids)).astype(int)
+    assert (dists == [[0, 2, 1, 1], [2, 0, 1, 1], [1, 1, 0, 2], [1, 1, 2, 0]]).all()
+    assert assignments.min() == 0 and assignments.max() == 3
+
+
+def test_cosine_rejects_unnormalised():
+    from kmcuda_amd import kmeans_cuda
+    arr = numpy.random.RandomState(0).rand(1000, 8).astype(numpy.float32)
+    with pytest.raises(ValueError):
+        kmeans_cuda(arr, 4, metric="cos", seed=3)
+
+
+def test_average_distance(fixture13k):
+    from kmcuda_amd import kmeans_cuda
+    centroids, assignments, distance = kmeans_cuda(fixture13k, 50, init="kmeans++", device=1, seed=3,
+                                                   tolerance=0.05, yinyang_t=0, average_distance=True)
+    valid = numpy.linalg.norm(fixture13k - centroids[assignments], axis=1).astype(numpy.float64).mean()
+    assert abs(valid - distance) < 1e-6
+
+
+def test_virtual_shards_match_single(fixture13k, monkeypatch):
+    """Row-sharded path on one GPU (KMCUDA_AMD_VIRTUAL_SHARDS): same iterations, same
+    assignments, centroids within the update tolerance."""
+    from kmcuda_amd import kmeans_cuda
+    c1, a1 = kmeans_cuda(fixture13k, 50, init="kmeans++", device=1, seed=3, tolerance=0.02, yinyang_t=0)
+    monkeypatch.setenv("KMCUDA_AMD_VIRTUAL_SHARDS", "3")
+    c3, a3 = kmeans_cuda(fixture13k, 50, init="kmeans++", device=1, seed=3, tolerance=0.02, yinyang_t=0)
+    assert (a1 == a3).all()
+    numpy.testing.assert_allclose(c1, c3, rtol=1e-6, atol=1e-7)
+
+
+def test_256d_uniform_matches_oracle():
+    from kmcuda_amd import kmeans_cuda
+    rs = numpy.random.RandomState(0)
+    x = rs.rand(20000, 256).astype(numpy.float32)
+    cen, asg = kmeans_cuda(x, 64, init="random", seed=777, tolerance=0.01, yinyang_t=0, device=1)
+    ocen, oasg, _ = oracle.kmeans(x, 64, init="random", seed=777, tolerance=0.01, yinyang_t=0)
+    # centroids agree to ~1e-6, so an occasional near-tie row may flip; the bulk is identical
+    assert (asg != oasg).mean() < 1e-3
+    numpy.testing.assert_allclose(cen, ocen, rtol=1e-4, atol=1e-5)
