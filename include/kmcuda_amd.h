@@ -39,8 +39,8 @@ int kmamd_lloyd_assign_exact(kmamd_engine *e, const float *samples, const float 
                              uint32_t *assignments, uint32_t *assignments_prev);
 
 /* counters: [0] reassigned rows since the last reset (d_changed_number, kmeans.cu:31),
- * [1] rows the filter handed to the exact kernel, [2] Yinyang passed rows (d_passed_number),
- * [3] spare.  read = sync + copy to a host array; reset zeroes [0..3] (or one of them). */
+ * [1] rows the filter handed to the full exact scan, [2] Yinyang passed rows (d_passed_number),
+ * [3] rows the filter narrowed to two contenders (pair refine).  read = sync + copy to a host array; reset zeroes [0..3] (or one of them). */
 int kmamd_counters_read(kmamd_engine *e, uint32_t *host_out4);
 int kmamd_counters_reset(kmamd_engine *e, int which /* -1: all */);
 

@@ -3,6 +3,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/kmcuda_amd.h"
@@ -20,6 +21,7 @@ Engine::~Engine() {
 }
 
 int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric, int fp16x2, hipStream_t stream) {
+  if (getenv("KMCUDA_AMD_DEBUG")) g_verbosity = atoi(getenv("KMCUDA_AMD_DEBUG"));
   if (D == 0 || K < 2 || K >= 0x7FFFFFFFu) return kInvalidArguments;
   if (fp16x2) return kInvalidArguments;  // fp16x2 kernels are not built yet ("next")
   int ndev = 0;
@@ -51,13 +53,14 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if ((rc = alloc(&ct_, (size_t)D * Kt_))) return rc;
   if ((rc = alloc(&stats_, 4))) return rc;
   if ((rc = alloc(&flagged_, n_rows))) return rc;
+  if ((rc = alloc(&pairs_, 3 * (size_t)n_rows))) return rc;
   if ((rc = alloc(&counters_, 4))) return rc;
   if ((rc = alloc(&keys_tmp_, 2 * (size_t)n_rows))) return rc;
   if ((rc = alloc(&vals_tmp_, 2 * (size_t)n_rows))) return rc;
   if ((rc = alloc(&keys_sorted_, 2 * (size_t)n_rows))) return rc;
   if ((rc = alloc(&rows_sorted_, 2 * (size_t)n_rows))) return rc;
   if ((rc = alloc(&offsets2_, 2 * (size_t)K + 2))) return rc;
-  sort_temp_bytes_ = sort_temp_bytes(2 * n_rows, 2 * K);
+  sort_temp_bytes_ = sort_temp_bytes(2 * (size_t)n_rows, 2 * K);
   {
     const size_t b2 = sort_temp_bytes(n_rows, K);
     if (b2 > sort_temp_bytes_) sort_temp_bytes_ = b2;
@@ -116,7 +119,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   a.cfil = cfil_; a.bias = bias_; a.ct = ct_; a.csqr = csqr_; a.stats = stats_;
   a.eps = eps_; a.tie_slack = tie_slack_;
   a.assignments = assignments; a.assignments_prev = assignments_prev;
-  a.flagged = flagged_; a.counters = counters_;
+  a.flagged = flagged_; a.pairs = pairs_; a.counters = counters_;
   if (N_ == 0) return kSuccess;
   if (exact_only || DP_ == 0) {
     span_begin(1);
@@ -126,10 +129,13 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
     return kSuccess;
   }
   KMX_HIP(hipMemsetAsync(counters_ + 1, 0, sizeof(uint32_t), stream_), kRuntimeError);
+  KMX_HIP(hipMemsetAsync(counters_ + 3, 0, sizeof(uint32_t), stream_), kRuntimeError);
   span_begin(0);
   KMX_HIP(launch_lloyd_filter(a, stream_), kRuntimeError);
   span_end();
   span_begin(1);
+  KMX_HIP(launch_lloyd_pair(metric_, a, centroids, (N_ + 127) / 128 < 2048u ? (N_ + 127) / 128 : 2048u, stream_),
+          kRuntimeError);
   const uint32_t grid = N_ < 4096u ? N_ : 4096u;  // grid-strides over the device-side flagged count
   KMX_HIP(launch_lloyd_exact(metric_, a, flagged_, counters_ + 1, grid, stream_), kRuntimeError);
   span_end();

@@ -64,7 +64,7 @@ class Engine {
 
   // assignment workspace
   float *csqr_ = nullptr, *bias_ = nullptr, *cfil_ = nullptr, *ct_ = nullptr;
-  uint32_t *stats_ = nullptr, *flagged_ = nullptr, *counters_ = nullptr;
+  uint32_t *stats_ = nullptr, *flagged_ = nullptr, *pairs_ = nullptr, *counters_ = nullptr;
   // update workspace
   uint32_t *keys_tmp_ = nullptr, *vals_tmp_ = nullptr, *keys_sorted_ = nullptr, *rows_sorted_ = nullptr,
            *offsets2_ = nullptr;

@@ -19,8 +19,9 @@ struct LloydArgs {
   float eps;                 // relative error coefficient of the filter bound
   float tie_slack;           // absolute slack (angular: acos plateau width)
   uint32_t *assignments, *assignments_prev;
-  uint32_t *flagged;         // N: rows the filter could not decide
-  uint32_t *counters;        // [0] changed, [1] flagged, [2] passed (yinyang), [3] spare
+  uint32_t *flagged;         // N: rows with three or more contenders (full exact scan)
+  uint32_t *pairs;           // 3N: (row, i1, i2) rows with exactly two contenders
+  uint32_t *counters;        // [0] changed, [1] flagged, [2] passed (yinyang), [3] pairs
 };
 
 uint32_t filter_dp_for(uint32_t D);
@@ -28,12 +29,13 @@ hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, 
                                 uint32_t DP, uint32_t Kt, float *csqr, float *bias, float *cfil, float *ct,
                                 uint32_t *stats, hipStream_t st);
 hipError_t launch_lloyd_filter(const LloydArgs &a, hipStream_t st);
+hipError_t launch_lloyd_pair(int metric, const LloydArgs &a, const float *centroids, uint32_t grid, hipStream_t st);
 hipError_t launch_lloyd_exact(int metric, const LloydArgs &a, const uint32_t *rows, const uint32_t *nrows,
                               uint32_t grid, hipStream_t st);
 
 // update.hip -- centroid update (reference: kmeans.cu:366-429 kmeans_adjust)
 constexpr uint32_t kSumSplit = 8;
-size_t sort_temp_bytes(uint32_t n, uint32_t max_key);
+size_t sort_temp_bytes(size_t n, uint32_t max_key);
 hipError_t launch_inverse_assignments(const uint32_t *assignments, uint32_t N, uint32_t K, uint32_t *keys_tmp,
                                       uint32_t *vals_tmp, uint32_t *keys_sorted, uint32_t *inv,
                                       uint32_t *offsets, void *temp, size_t temp_bytes, hipStream_t st);

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_kernel(
     const float *__restrict__ samples, uint32_t N, uint32_t D, const float *__restrict__ cfil,
     const float *__restrict__ bias, uint32_t K_pad, uint32_t K, const uint32_t *__restrict__ stats,
     float eps, float tie_slack, uint32_t *__restrict__ assignments,
-    uint32_t *__restrict__ assignments_prev, uint32_t *__restrict__ flagged,
+    uint32_t *__restrict__ assignments_prev, uint32_t *__restrict__ flagged, uint32_t *__restrict__ pairs,
     uint32_t *__restrict__ counters) {
   constexpr int NK = DP / 2;           // k-steps (each MFMA consumes 2 features)
   constexpr int LDW = DP + 4;          // padded LDS row (floats): conflict-free ds_read_b128
@@ -183,8 +183,9 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_kernel(
   stage_store(0);
   __syncthreads();
 
-  float v1 = -INFINITY, v2 = -INFINITY;
-  uint32_t code1 = 0xFFFFFFFFu;
+  // running top-3 of my centroid rows: (v1,c1) best, (v2,c2) second, v3 third value
+  float v1 = -INFINITY, v2 = -INFINITY, v3 = -INFINITY;
+  uint32_t c1 = 0xFFFFFFFFu, c2 = 0xFFFFFFFFu;  // codes: tile*16 + accumulator register
 
   for (uint32_t t = 0; t < ntiles; t++) {
     const int buf = t & 1;
@@ -212,60 +213,118 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_kernel(
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, xb[4 * j + 2], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, xb[4 * j + 3], acc, 0, 0, 0);
     }
-    // running (max, argmax, second max) over my 16 rows; strict '>' keeps the first index,
-    // NaN scores compare false everywhere and are ignored (as in the reference).
+    // strict '>' keeps the earlier index on equal scores; NaN scores compare false everywhere
+    // and are ignored (as in the reference, where a NaN distance is never "less").
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const float v = acc[r];
-      const bool gt = v > v1;
-      const bool g2 = v > v2;
-      v2 = gt ? v1 : (g2 ? v : v2);
-      code1 = gt ? (t * 16u + r) : code1;
-      v1 = gt ? v : v1;
+      const uint32_t code = t * 16u + r;
+      const bool g1 = v > v1, g2 = v > v2, g3 = v > v3;
+      v3 = g2 ? v2 : (g3 ? v : v3);
+      c2 = g1 ? c1 : (g2 ? code : c2);
+      v2 = g1 ? v1 : (g2 ? v : v2);
+      c1 = g1 ? code : c1;
+      v1 = g1 ? v : v1;
     }
     if (t + 1 < ntiles) stage_store(buf ^ 1);
     __syncthreads();
   }
 
   // ---- merge the two half-waves (same sample, disjoint centroid rows) ----
-  uint32_t i1 = 0xFFFFFFFFu;
-  if (code1 != 0xFFFFFFFFu) {
-    const uint32_t r = code1 & 15u;
-    i1 = (code1 >> 4) * 32u + (r & 3u) + 8u * (r >> 2) + 4u * h;
-  }
+  auto decode = [&](uint32_t code, int half) -> uint32_t {
+    if (code == 0xFFFFFFFFu) return 0xFFFFFFFFu;
+    const uint32_t r = code & 15u;
+    return (code >> 4) * 32u + (r & 3u) + 8u * (r >> 2) + 4u * half;
+  };
+  uint32_t i1 = decode(c1, h), i2 = decode(c2, h);
   {
-    const float pv1 = __shfl_xor(v1, 32), pv2 = __shfl_xor(v2, 32);
-    const uint32_t pi1 = __shfl_xor(i1, 32);
-    const bool take = (pv1 > v1) || (pv1 == v1 && pi1 < i1);
-    const float lo = take ? v1 : pv1;  // the loser's best competes for second place
-    float nv2 = take ? pv2 : v2;
-    nv2 = (lo > nv2) ? lo : nv2;
-    if (take) { v1 = pv1; i1 = pi1; }
-    v2 = nv2;
+    const float pv1 = __shfl_xor(v1, 32), pv2 = __shfl_xor(v2, 32), pv3 = __shfl_xor(v3, 32);
+    const uint32_t pi1 = __shfl_xor(i1, 32), pi2 = __shfl_xor(i2, 32);
+    auto insert = [&](float v, uint32_t idx) {
+      const bool g1 = v > v1, g2 = v > v2, g3 = v > v3;
+      v3 = g2 ? v2 : (g3 ? v : v3);
+      i2 = g1 ? i1 : (g2 ? idx : i2);
+      v2 = g1 ? v1 : (g2 ? v : v2);
+      i1 = g1 ? idx : i1;
+      v1 = g1 ? v : v1;
+    };
+    insert(pv1, pi1);
+    insert(pv2, pi2);
+    insert(pv3, 0xFFFFFFFFu);  // can only land in third place
   }
 
   // ---- decide ----
   // |score_mfma - score_ref| <= E for every centroid, E = eps*(||x||*Cmax + Bmax)  (DESIGN.md).
-  // gap > 2E  =>  the reference's distance to i1 is strictly the smallest.
+  //   v1 - v2 > 2E : the reference's distance to i1 is strictly the smallest -> commit
+  //   v1 - v3 > 2E : the minimum is i1 or i2 -> two exact Kahan distances settle it (pair list)
+  //   otherwise    : three or more contenders -> full exact scan (flagged list)
   const float cmax = sqrtf(__uint_as_float(stats[0])) * 1.000001f;
   const float bmax = __uint_as_float(stats[1]);
   const float xn = sqrtf(xn2) * 1.0001f;
   const float thr = 2.0f * eps * (xn * cmax + bmax) * 1.001f + tie_slack;
-  const float gap = v1 - v2;
-  const bool certain = insane || (gap > thr);  // NaN gap / NaN thr => not certain
+  const bool certain = insane || ((v1 - v2) > thr);  // NaN gap / NaN thr => not certain
+  const bool two = !certain && ((v1 - v3) > thr) && i2 != 0xFFFFFFFFu;
   const bool mine = (h == 0) && (s < N);
   const bool commit_now = mine && certain;
-  const bool flag_now = mine && !certain;
+  const bool pair_now = mine && two;
+  const bool flag_now = mine && !certain && !two;
   bool changed = false;
   if (commit_now) changed = commit_row(s, insane ? K : i1, assignments, assignments_prev);
   const unsigned long long cm = __ballot(changed);
+  const unsigned long long pm = __ballot(pair_now);
   const unsigned long long fm = __ballot(flag_now);
   if (lane == 0 && cm) atomicAdd(&counters[0], (uint32_t)__popcll(cm));
+  if (pm) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&counters[3], (uint32_t)__popcll(pm));
+    base = __shfl(base, 0);
+    if (pair_now) {
+      const uint32_t slot = base + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+      pairs[3 * (size_t)slot + 0] = s;
+      pairs[3 * (size_t)slot + 1] = i1;
+      pairs[3 * (size_t)slot + 2] = i2;
+    }
+  }
   if (fm) {
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&counters[1], (uint32_t)__popcll(fm));
     base = __shfl(base, 0);
     if (flag_now) flagged[base + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// 2b. lloyd_pair: rows whose minimum is one of two centroids -- two exact Kahan chains per
+// thread (the reference's arithmetic), the smaller distance wins, the smaller index on a tie
+// (== the reference's ascending scan with strict '<').
+// ---------------------------------------------------------------------------------------
+template <int METRIC>
+__global__ __launch_bounds__(128) void lloyd_pair_kernel(
+    const float *__restrict__ samples, uint32_t D, const float *__restrict__ centroids,
+    const float *__restrict__ csqr, const uint32_t *__restrict__ pairs, const uint32_t *__restrict__ npairs,
+    uint32_t *__restrict__ assignments, uint32_t *__restrict__ assignments_prev, uint32_t *__restrict__ counters) {
+  const uint32_t total = *npairs;
+  for (uint32_t pi = blockIdx.x * blockDim.x + threadIdx.x; pi < total; pi += gridDim.x * blockDim.x) {
+    const uint32_t s = pairs[3 * (size_t)pi], ia = pairs[3 * (size_t)pi + 1], ib = pairs[3 * (size_t)pi + 2];
+    const uint32_t lo = ia < ib ? ia : ib, hi = ia < ib ? ib : ia;
+    const float *x = samples + (size_t)s * D;
+    const float *ca = centroids + (size_t)lo * D, *cb = centroids + (size_t)hi * D;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, corr[4] = {0.f, 0.f, 0.f, 0.f};
+    for (uint32_t f = 0; f < D; f++) {
+      const float cv[4] = {ca[f], cb[f], 0.f, 0.f};
+      float y[4];
+      fma_rd4(x[f], cv, corr, y);
+      kahan_fold(y[0], acc[0], corr[0]);
+      kahan_fold(y[1], acc[1], corr[1]);
+    }
+    const float da = lloyd_distance<METRIC>(csqr[lo], acc[0]);
+    const float db = lloyd_distance<METRIC>(csqr[hi], acc[1]);
+    // ascending scan, strict '<', starting from FLT_MAX
+    float min_dist = 3.402823466e+38f;
+    uint32_t nearest = 0xFFFFFFFFu;
+    if (da < min_dist) { min_dist = da; nearest = lo; }
+    if (db < min_dist) { min_dist = db; nearest = hi; }
+    if (nearest != 0xFFFFFFFFu && commit_row(s, nearest, assignments, assignments_prev)) atomicAdd(&counters[0], 1u);
   }
 }
 
@@ -352,11 +411,11 @@ static hipError_t launch_filter_dp(const LloydArgs &a, hipStream_t st) {
   if (fast) {
     hipLaunchKernelGGL((lloyd_filter_kernel<DP, true>), dim3(grid), dim3(256), lds_bytes, st, a.samples, a.N,
                        a.D, a.cfil, a.bias, a.K_pad, a.K, a.stats, a.eps, a.tie_slack, a.assignments,
-                       a.assignments_prev, a.flagged, a.counters);
+                       a.assignments_prev, a.flagged, a.pairs, a.counters);
   } else {
     hipLaunchKernelGGL((lloyd_filter_kernel<DP, false>), dim3(grid), dim3(256), lds_bytes, st, a.samples, a.N,
                        a.D, a.cfil, a.bias, a.K_pad, a.K, a.stats, a.eps, a.tie_slack, a.assignments,
-                       a.assignments_prev, a.flagged, a.counters);
+                       a.assignments_prev, a.flagged, a.pairs, a.counters);
   }
   return hipGetLastError();
 }
@@ -386,6 +445,17 @@ hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, 
   else
     hipLaunchKernelGGL((centroid_prep_kernel<1>), grid, block, 0, st, centroids, K, D, K_pad, DP, Kt, csqr, bias,
                        cfil, ct, stats);
+  return hipGetLastError();
+}
+
+hipError_t launch_lloyd_pair(int metric, const LloydArgs &a, const float *centroids, uint32_t grid, hipStream_t st) {
+  if (grid == 0) return hipSuccess;
+  if (metric == 0)
+    hipLaunchKernelGGL((lloyd_pair_kernel<0>), dim3(grid), dim3(128), 0, st, a.samples, a.D, centroids, a.csqr,
+                       a.pairs, a.counters + 3, a.assignments, a.assignments_prev, a.counters);
+  else
+    hipLaunchKernelGGL((lloyd_pair_kernel<1>), dim3(grid), dim3(128), 0, st, a.samples, a.D, centroids, a.csqr,
+                       a.pairs, a.counters + 3, a.assignments, a.assignments_prev, a.counters);
   return hipGetLastError();
 }
 

@@ -21,6 +21,8 @@
 // Centroids agree with the reference's fp32 Kahan chain to a few ulp (tests: 2e-6 relative);
 // they are bit-reproducible run to run and independent of kSumSplit.  An empty cluster yields
 // a non-finite row that is never chosen again, as in the reference (kmeans.cu:425-426).
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -36,10 +38,11 @@ static unsigned bits_for(uint64_t maxval) {
 }
 
 // ---- sorting helpers --------------------------------------------------------------------
-size_t sort_temp_bytes(uint32_t n, uint32_t max_key) {
+size_t sort_temp_bytes(size_t n, uint32_t max_key) {
   size_t bytes = 0;
   (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                                  (const uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, bits_for(max_key), 0);
+                                  (const uint32_t *)nullptr, (uint32_t *)nullptr, n, 0u, bits_for(max_key),
+                                  (hipStream_t)0);
   return bytes;
 }
 
@@ -72,7 +75,7 @@ hipError_t launch_inverse_assignments(const uint32_t *assignments, uint32_t N, u
   hipLaunchKernelGGL(cluster_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, st, assignments, N, K, keys_tmp,
                      vals_tmp);
   hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t *)keys_tmp, keys_sorted,
-                                           (const uint32_t *)vals_tmp, inv, N, 0, bits_for(K), st);
+                                           (const uint32_t *)vals_tmp, inv, (size_t)N, 0u, bits_for(K), st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(offsets_kernel, dim3((K + 1 + 255) / 256), dim3(256), 0, st, keys_sorted, N, K, offsets);
   return hipGetLastError();
@@ -135,15 +138,21 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
                               uint32_t *rows_sorted, uint32_t *offsets2, void *temp, size_t temp_bytes,
                               double *partial, double *delta, int32_t *dcount, hipStream_t st) {
   hipLaunchKernelGGL(move_events_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, keys_tmp, vals_tmp);
-  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t *)keys_tmp, keys_sorted,
-                                           (const uint32_t *)vals_tmp, rows_sorted, 2 * (size_t)N, 0,
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("move_events: %s\n", hipGetErrorString(e)); return e; }
+  e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t *)keys_tmp, keys_sorted,
+                                           (const uint32_t *)vals_tmp, rows_sorted, 2 * (size_t)N, 0u,
                                            bits_for(2ull * K), st);
-  if (e != hipSuccess) return e;
+  if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("radix_sort_pairs(%zu bytes temp): %s\n", temp_bytes, hipGetErrorString(e)); return e; }
   hipLaunchKernelGGL(offsets_kernel, dim3((2 * K + 1 + 255) / 256), dim3(256), 0, st, keys_sorted, 2 * N, 2 * K,
                      offsets2);
+  e = hipGetLastError();
+  if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("offsets: %s\n", hipGetErrorString(e)); return e; }
   const uint32_t bs = D >= 256 ? 256 : (D > 64 ? 128 : 64);
   hipLaunchKernelGGL(segment_sums_kernel, dim3(2 * K, kSumSplit), dim3(bs), 0, st, samples, D, rows_sorted, offsets2,
                      partial);
+  e = hipGetLastError();
+  if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("segment_sums: %s\n", hipGetErrorString(e)); return e; }
   const size_t n = (size_t)K * D;
   hipLaunchKernelGGL(fold_delta_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, partial, offsets2, K, D,
                      delta, dcount);
