@@ -59,6 +59,32 @@ int kmamd_move_deltas(kmamd_engine *e, const float *samples, const uint32_t *ass
 int kmamd_apply_delta(kmamd_engine *e, const double *delta, const int32_t *dcount,
                       float *centroids, uint32_t *ccounts);
 
+/* Strict-parity centroid update: kmeans_adjust (kmeans.cu:366-429) operation for operation --
+ * one serial fp32 Kahan chain per centroid over its move events in ascending row order with the
+ * reference's single shared compensation term, then normalize.  Centroids and ccounts are
+ * bit-identical to the reference's.  Needs ALL rows on this engine (the chain order is global),
+ * so it is the single-GPU verification mode (kmeans_cuda: env KMCUDA_AMD_EXACT_UPDATE=1). */
+int kmamd_adjust_exact(kmamd_engine *e, const float *samples, const uint32_t *assignments_prev,
+                       const uint32_t *assignments, float *centroids, uint32_t *ccounts);
+
+/* Yinyang steps (reference: kmeans.cu:431-672), all on the engine's n_rows local rows.
+ *   xt       D x n_rows feature-major copy of the rows (kmamd_transpose)
+ *   bounds   (G+1) x n_rows group-major: [0] upper bound, [1+g] lower bound to group g
+ *   groups   K: centroid -> group, >= G for a NaN centroid; cperm/gstart: the same relation as
+ *            centroid ids sorted by group + G+1 offsets (host-built)
+ *   drifts   K*D old centroids followed by K per-centroid drifts; gdrifts: G per-group maxima
+ * yy_init: kmeans_yy_init (:431-485).  yy_drifts: kmeans_yy_calc_drifts + _find_group_max_drifts
+ * (:487-538).  yy_filters: kmeans_yy_global_filter then _local_filter (:540-672); counters[2]
+ * (passed) must be reset by the caller, counters[0] accumulates reassignments.
+ * Bounds, drifts and assignments are bit-identical to the reference arithmetic. */
+int kmamd_yy_init(kmamd_engine *e, const float *xt, const float *centroids, const uint32_t *assignments,
+                  uint32_t G, const uint32_t *cperm, const uint32_t *gstart, float *bounds);
+int kmamd_yy_drifts(kmamd_engine *e, const float *centroids, uint32_t G, const uint32_t *groups,
+                    float *drifts, float *gdrifts);
+int kmamd_yy_filters(kmamd_engine *e, const float *samples, const float *xt, const float *centroids,
+                     uint32_t G, const uint32_t *groups, const float *drifts, const float *gdrifts,
+                     uint32_t *assignments, uint32_t *assignments_prev, float *bounds, uint32_t *passed);
+
 /* out[c][r] = in[r][c], 4-byte elements (reference: cuda_transpose, transpose.cu:83-117). */
 int kmamd_transpose(kmamd_engine *e, const float *in, uint32_t rows, uint32_t cols, float *out);
 

@@ -22,7 +22,7 @@ Engine::~Engine() {
 
 int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric, int fp16x2, hipStream_t stream) {
   if (getenv("KMCUDA_AMD_DEBUG")) g_verbosity = atoi(getenv("KMCUDA_AMD_DEBUG"));
-  if (D == 0 || K < 2 || K >= 0x7FFFFFFFu) return kInvalidArguments;
+  if (D == 0 || K < 1 || K >= 0x7FFFFFFFu) return kInvalidArguments;  // K == 1: Yinyang group clustering with one group
   if (fp16x2) return kInvalidArguments;  // fp16x2 kernels are not built yet ("next")
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return kNoSuchDevice;
@@ -161,6 +161,23 @@ int Engine::apply_delta(const double *delta, const int32_t *dcount, float *centr
   return kSuccess;
 }
 
+int Engine::adjust_exact(const float *samples, const uint32_t *prev, const uint32_t *cur, float *centroids,
+                         uint32_t *ccounts) {
+  KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  if (2ull * N_ >= 0xFFFFFFFFull) return kInvalidArguments;
+  if ((size_t)D_ * 64 * sizeof(float) > 128 * 1024 && !exact_work_) {
+    int rc = alloc(&exact_work_, (size_t)((K_ + 63) / 64) * 64 * D_);
+    if (rc) return rc;
+  }
+  span_begin(2);
+  KMX_HIP(launch_adjust_exact(metric_, samples, N_, D_, K_, prev, cur, keys_tmp_, vals_tmp_, keys_sorted_,
+                              rows_sorted_, offsets2_, sort_temp_, sort_temp_bytes_, exact_work_, centroids, ccounts,
+                              stream_),
+          kRuntimeError);
+  span_end();
+  return kSuccess;
+}
+
 int Engine::counters_read(uint32_t *host4) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   KMX_HIP(hipMemcpyAsync(host_counters_, counters_, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_),
@@ -230,6 +247,10 @@ int kmamd_apply_delta(kmamd_engine *e, const double *delta, const int32_t *dcoun
                       uint32_t *ccounts) {
   return e->e.apply_delta(delta, dcount, centroids, ccounts);
 }
+int kmamd_adjust_exact(kmamd_engine *e, const float *samples, const uint32_t *assignments_prev,
+                       const uint32_t *assignments, float *centroids, uint32_t *ccounts) {
+  return e->e.adjust_exact(samples, assignments_prev, assignments, centroids, ccounts);
+}
 int kmamd_pack_reduce_tail(kmamd_engine *e, const int32_t *dcount, double *dst) {
   if (hipSetDevice(e->e.device_) != hipSuccess) return kmx::kNoSuchDevice;
   return kmx::launch_pack_reduce_tail(dcount, e->e.counters_, e->e.K_, dst, e->e.stream_) == hipSuccess
@@ -243,6 +264,29 @@ int kmamd_unpack_dcount(kmamd_engine *e, const double *src, int32_t *dcount) {
 int kmamd_transpose(kmamd_engine *e, const float *in, uint32_t rows, uint32_t cols, float *out) {
   if (hipSetDevice(e->e.device_) != hipSuccess) return kmx::kNoSuchDevice;
   return kmx::launch_transpose(in, rows, cols, out, e->e.stream_) == hipSuccess ? kmx::kSuccess : kmx::kRuntimeError;
+}
+int kmamd_yy_init(kmamd_engine *e, const float *xt, const float *centroids, const uint32_t *assignments, uint32_t G,
+                  const uint32_t *cperm, const uint32_t *gstart, float *bounds) {
+  kmx::Engine &g = e->e;
+  if (hipSetDevice(g.device_) != hipSuccess) return kmx::kNoSuchDevice;
+  return kmx::launch_yy_init(g.metric_, xt, g.N_, g.D_, G, centroids, assignments, cperm, gstart, bounds,
+                             g.stream_) == hipSuccess ? kmx::kSuccess : kmx::kRuntimeError;
+}
+int kmamd_yy_drifts(kmamd_engine *e, const float *centroids, uint32_t G, const uint32_t *groups, float *drifts,
+                    float *gdrifts) {
+  kmx::Engine &g = e->e;
+  if (hipSetDevice(g.device_) != hipSuccess) return kmx::kNoSuchDevice;
+  return kmx::launch_yy_drifts(g.metric_, centroids, g.K_, g.D_, G, groups, drifts, gdrifts, g.stream_) == hipSuccess
+             ? kmx::kSuccess : kmx::kRuntimeError;
+}
+int kmamd_yy_filters(kmamd_engine *e, const float *samples, const float *xt, const float *centroids, uint32_t G,
+                     const uint32_t *groups, const float *drifts, const float *gdrifts, uint32_t *assignments,
+                     uint32_t *assignments_prev, float *bounds, uint32_t *passed) {
+  kmx::Engine &g = e->e;
+  if (hipSetDevice(g.device_) != hipSuccess) return kmx::kNoSuchDevice;
+  return kmx::launch_yy_filters(g.metric_, samples, xt, g.N_, g.D_, g.K_, G, centroids, groups, drifts, gdrifts,
+                                assignments, assignments_prev, bounds, passed, g.counters_, g.stream_) == hipSuccess
+             ? kmx::kSuccess : kmx::kRuntimeError;
 }
 int kmamd_profile_enable(kmamd_engine *e, int on) {
   e->e.profile_collect();

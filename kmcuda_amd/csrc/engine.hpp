@@ -42,6 +42,8 @@ class Engine {
                    uint32_t *assignments_prev, bool exact_only);
   int move_deltas(const float *samples, const uint32_t *prev, const uint32_t *cur, double *delta, int32_t *dcount);
   int apply_delta(const double *delta, const int32_t *dcount, float *centroids, uint32_t *ccounts);
+  int adjust_exact(const float *samples, const uint32_t *prev, const uint32_t *cur, float *centroids,
+                   uint32_t *ccounts);
   int counters_read(uint32_t *host4);
   int counters_reset(int which);
   int sync();
@@ -71,6 +73,7 @@ class Engine {
   void *sort_temp_ = nullptr;
   size_t sort_temp_bytes_ = 0;
   double *partial_ = nullptr;
+  float *exact_work_ = nullptr;  // adjust_exact scratch when 64 centroid rows exceed LDS (lazy)
   uint32_t *host_counters_ = nullptr;  // pinned
 
   // profiling of the step kernels with HIP events on stream_

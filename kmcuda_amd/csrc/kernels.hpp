@@ -43,6 +43,10 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
                               const uint32_t *cur, uint32_t *keys_tmp, uint32_t *vals_tmp, uint32_t *keys_sorted,
                               uint32_t *rows_sorted, uint32_t *offsets2, void *temp, size_t temp_bytes,
                               double *partial, double *delta, int32_t *dcount, hipStream_t st);
+hipError_t launch_adjust_exact(int metric, const float *samples, uint32_t N, uint32_t D, uint32_t K,
+                               const uint32_t *prev, const uint32_t *cur, uint32_t *keys_tmp, uint32_t *vals_tmp,
+                               uint32_t *keys_sorted, uint32_t *rows_sorted, uint32_t *offsets2, void *temp,
+                               size_t temp_bytes, float *work, float *centroids, uint32_t *ccounts, hipStream_t st);
 hipError_t launch_apply_delta(int metric, const double *delta, const int32_t *dcount, uint32_t K, uint32_t D,
                               float *centroids, uint32_t *ccounts, hipStream_t st);
 
@@ -59,6 +63,17 @@ hipError_t launch_kmpp_step(int metric, const float *samples, uint32_t N, uint32
 hipError_t launch_member_distances(int metric, const float *samples, uint32_t N, uint32_t D,
                                    const float *centroids, const uint32_t *assignments, uint32_t K,
                                    float *dists, hipStream_t st);
+
+// yinyang.hip (reference: kmeans.cu:431-672)
+hipError_t launch_yy_init(int metric, const float *xt, uint32_t len, uint32_t D, uint32_t G, const float *centroids,
+                          const uint32_t *assignments, const uint32_t *cperm, const uint32_t *gstart, float *bounds,
+                          hipStream_t st);
+hipError_t launch_yy_drifts(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t G,
+                            const uint32_t *groups, float *drifts, float *gdrifts, hipStream_t st);
+hipError_t launch_yy_filters(int metric, const float *samples, const float *xt, uint32_t len, uint32_t D, uint32_t K,
+                             uint32_t G, const float *centroids, const uint32_t *groups, const float *drifts,
+                             const float *gdrifts, uint32_t *assignments, uint32_t *assignments_prev, float *bounds,
+                             uint32_t *passed, uint32_t *counters, hipStream_t st);
 
 // transpose.hip (reference: transpose.cu:16-54)
 hipError_t launch_transpose(const float *in, uint32_t rows, uint32_t cols, float *out, hipStream_t st);

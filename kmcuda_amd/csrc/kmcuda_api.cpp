@@ -121,6 +121,14 @@ struct Shard {
   int32_t *dcount = nullptr;
   float *dists = nullptr;          // length floats (k-means++ / average distance)
   uint32_t *row_ids = nullptr;     // K uint32 staging for gathers
+  // Yinyang state (allocated when the Yinyang phase starts; reference: kmcuda.cc:448-470)
+  float *xt = nullptr;             // D x length feature-major copy of the rows
+  float *bounds = nullptr;         // (G+1) x length, group-major (kmeans.cu:431-485 layout)
+  float *drifts = nullptr;         // K*D old centroids + K per-centroid drifts
+  float *gdrifts = nullptr;        // G per-group max drifts
+  uint32_t *passed = nullptr;      // length
+  uint32_t *groups = nullptr;      // K: centroid -> group (assignments_yy)
+  uint32_t *cperm = nullptr, *gstart = nullptr;  // centroids sorted by group + G+1 offsets
   std::vector<void *> owned;
   ~Shard() {
     (void)hipSetDevice(dev);
@@ -422,7 +430,13 @@ class Job {
     return 0;
   }
 
+  bool exact_update = false;  // KMCUDA_AMD_EXACT_UPDATE=1: the reference's serial Kahan chain (single shard)
+
   int adjust() {  // reference: kmeans_adjust launch + peer exchange, kmeans.cu:1002-1024
+    if (exact_update) {
+      Shard &s = *shards[0];
+      return s.eng->adjust_exact(s.samples, s.prev, s.assignments, s.centroids, s.ccounts);
+    }
     for (auto &s : shards) RETERR(s->eng->move_deltas(s->samples, s->prev, s->assignments, s->delta, s->dcount));
     RETERR(allreduce_deltas());
     for (auto &s : shards) RETERR(s->eng->apply_delta(s->delta, s->dcount, s->centroids, s->ccounts));
@@ -461,6 +475,106 @@ class Job {
         }
       }
       RETERR(adjust());
+    }
+  }
+
+
+  // ---- Yinyang (reference: kmeans_cuda_yy, kmeans.cu:1028-1263) ----
+  // Clusters the K centroids into G groups: k-means++ (srand(0), kmeans.cu:1081-1084 passes seed 0)
+  // followed by Lloyd at YINYANG_GROUP_TOLERANCE on the centroids themselves (kmeans.cu:1062-1100).
+  // Runs as a nested single-GPU job whose "samples" are shard 0's centroid replica.
+  int cluster_groups(uint32_t G, std::vector<uint32_t> *groups) {
+    Shard &first = *shards[0];
+    RETERR(first.eng->sync());
+    Job gjob;
+    std::vector<int> one{first.dev};
+    RETERR(gjob.setup(one, 0, K, D, G, metric, verbosity, first.centroids, first.dev));
+    gjob.exact_update = exact_update;
+    RETERR(gjob.init_centroids(kmcudaInitMethodPlusPlus, 0, nullptr, first.dev));
+    RETERR(gjob.lloyd((float)kYinyangGroupTolerance, false, nullptr));
+    RETERR(gjob.sync_all());
+    groups->resize(K);
+    (void)hipSetDevice(first.dev);
+    if (hipMemcpy(groups->data(), gjob.shards[0]->assignments, K * sizeof(uint32_t), hipMemcpyDeviceToHost) !=
+        hipSuccess)
+      return kmcudaMemoryCopyError;
+    return 0;
+  }
+
+  int yinyang(float tolerance, uint32_t G, int iter) {
+    std::vector<uint32_t> groups;
+    RETERR(cluster_groups(G, &groups));
+    // centroids in group order for the bounds refresh; group >= G (a NaN centroid keeps the
+    // 0xFFFFFFFF "assignment" of its failed search, kmeans.cu:468-471) is left out
+    std::vector<uint32_t> cperm, gstart(G + 1, 0);
+    for (uint32_t c = 0; c < K; c++)
+      if (groups[c] < G) gstart[groups[c] + 1]++;
+    for (uint32_t g = 0; g < G; g++) gstart[g + 1] += gstart[g];
+    cperm.resize(gstart[G] ? gstart[G] : 1);
+    {
+      std::vector<uint32_t> fill(gstart.begin(), gstart.end() - 1);
+      for (uint32_t c = 0; c < K; c++)
+        if (groups[c] < G) cperm[fill[groups[c]]++] = c;
+    }
+    for (auto &s : shards) {
+      (void)hipSetDevice(s->dev);
+      int rc;
+      if ((rc = s->alloc(&s->xt, (size_t)s->length * D))) return rc;
+      if ((rc = s->alloc(&s->bounds, (size_t)s->length * (G + 1)))) return rc;
+      if ((rc = s->alloc(&s->drifts, (size_t)K * D + K))) return rc;
+      if ((rc = s->alloc(&s->gdrifts, G))) return rc;
+      if ((rc = s->alloc(&s->passed, s->length))) return rc;
+      if ((rc = s->alloc(&s->groups, K))) return rc;
+      if ((rc = s->alloc(&s->cperm, cperm.size()))) return rc;
+      if ((rc = s->alloc(&s->gstart, G + 1))) return rc;
+      hipStream_t st = s->eng->stream_;
+      if (hipMemcpyAsync(s->groups, groups.data(), K * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess ||
+          hipMemcpyAsync(s->cperm, cperm.data(), cperm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st) !=
+              hipSuccess ||
+          hipMemcpyAsync(s->gstart, gstart.data(), (G + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess)
+        return kmcudaMemoryCopyError;
+      if (launch_transpose(s->samples, s->length, D, s->xt, st) != hipSuccess) return kmcudaRuntimeError;
+    }
+    RETERR(sync_all());  // host vectors above go out of use
+    RETERR(prepare_mem(true));
+    bool refresh = true;
+    for (;; iter++) {
+      if (!refresh) {
+        uint32_t passed_total = 0;
+        const int status = check_changed(iter, tolerance, true, &passed_total);
+        if (status < 0) return -status;
+        if (status == 1) return 0;
+        DEBUG("passed number: %u\n", passed_total);
+        if (1.f - (passed_total + 0.f) / N < kYinyangRefreshEpsilon) refresh = true;  // kmeans.cu:1136-1138
+      }
+      if (refresh) {
+        INFO("refreshing Yinyang bounds...\n");
+        for (auto &s : shards) {
+          (void)hipSetDevice(s->dev);
+          if (launch_yy_init(metric, s->xt, s->length, D, G, s->centroids, s->assignments, s->cperm, s->gstart,
+                             s->bounds, s->eng->stream_) != hipSuccess)
+            return kmcudaRuntimeError;
+        }
+        refresh = false;
+      }
+      for (auto &s : shards) {  // kmeans.cu:1159: keep the old centroids for the drifts
+        (void)hipSetDevice(s->dev);
+        if (hipMemcpyAsync(s->drifts, s->centroids, (size_t)K * D * sizeof(float), hipMemcpyDeviceToDevice,
+                           s->eng->stream_) != hipSuccess)
+          return kmcudaMemoryCopyError;
+      }
+      RETERR(adjust());
+      for (auto &s : shards) {
+        (void)hipSetDevice(s->dev);
+        hipStream_t st = s->eng->stream_;
+        if (launch_yy_drifts(metric, s->centroids, K, D, G, s->groups, s->drifts, s->gdrifts, st) != hipSuccess)
+          return kmcudaRuntimeError;
+        RETERR(s->eng->counters_reset(2));  // d_passed_number = 0, kmeans.cu:1225-1229
+        if (launch_yy_filters(metric, s->samples, s->xt, s->length, D, K, G, s->centroids, s->groups, s->drifts,
+                              s->gdrifts, s->assignments, s->prev, s->bounds, s->passed, s->eng->counters_,
+                              st) != hipSuccess)
+          return kmcudaRuntimeError;
+      }
     }
   }
 
@@ -553,6 +667,11 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
   Job job;
   RETERR(job.setup(devs, virtual_shards(), samples_size, features_size, clusters_size, metric, verbosity, samples,
                    device_ptrs));
+  if (const char *v = getenv("KMCUDA_AMD_EXACT_UPDATE")) job.exact_update = atoi(v) != 0;
+  if (job.exact_update && job.shards.size() > 1) {
+    INFO("KMCUDA_AMD_EXACT_UPDATE needs all rows on one GPU (the reference's update order is global)\n");
+    return kmcudaInvalidArguments;
+  }
   RETERR(job.init_centroids(init, seed, centroids, device_ptrs));
 
   if (yy_groups_size == 0 || kYinyangDraftReassignments <= tolerance) {  // kmeans.cu:1037-1050
@@ -565,12 +684,7 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
     RETERR(job.lloyd((float)kYinyangDraftReassignments, false, &iter));
     const int st = job.check_changed(iter, tolerance, false);  // kmeans.cu:1058
     if (st < 0) return static_cast<KMCUDAResult>(-st);
-    if (st == 0) {
-      // TODO(yinyang): bound-based filtering kernels; until they land the remaining iterations
-      // run as plain Lloyd passes (identical assignments, no pruning).
-      RETERR(job.adjust());
-      RETERR(job.lloyd(tolerance, true, nullptr));
-    }
+    if (st == 0) RETERR(job.yinyang(tolerance, yy_groups_size, iter));
   }
   if (average_distance) RETERR(job.average_distance(average_distance));
   RETERR(job.gather_outputs(centroids, assignments, device_ptrs));

@@ -27,6 +27,7 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include "exact.hpp"
 #include "kernels.hpp"
 
 namespace kmx {
@@ -199,6 +200,117 @@ hipError_t launch_apply_delta(int metric, const double *delta, const int32_t *dc
     hipLaunchKernelGGL((apply_delta_kernel<0>), dim3(K), dim3(bs), 0, st, delta, dcount, D, centroids, ccounts);
   else
     hipLaunchKernelGGL((apply_delta_kernel<1>), dim3(K), dim3(bs), 0, st, delta, dcount, D, centroids, ccounts);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// adjust_exact: the reference's kmeans_adjust (kmeans.cu:366-429) restated operation for
+// operation -- c*count, then ONE serial Kahan chain per centroid over its move events in
+// ascending sample order with a single compensation term shared by all features and samples
+// (kmeans.cu:388, :410-419), then normalize (metric_abstraction.h:138-144, :255-272).  Centroids
+// come out BIT-IDENTICAL to the reference's.  The chain is inherently serial (one lane per
+// centroid, ~4 dependent VALU ops + a rounding-mode window per element), so this is the
+// verification / strict-parity mode (KMCUDA_AMD_EXACT_UPDATE=1, single shard); the default
+// update above is the fast one.
+//   rows / offsets : the (cluster, sign)-sorted move events of launch_move_events(): segment 2c =
+//                    rows that moved INTO c, 2c+1 = rows that moved OUT, each ascending; the lane
+//                    merges its two segments on the fly to recover the reference's scan order.
+//   work           : the 64 centroid rows of a wave, feature-major [f][lane] (LDS when it fits).
+// ---------------------------------------------------------------------------------------
+template <int METRIC, bool USE_LDS>
+__global__ __launch_bounds__(64) void adjust_exact_kernel(const float *__restrict__ samples, uint32_t D, uint32_t K,
+                                                          const uint32_t *__restrict__ rows,
+                                                          const uint32_t *__restrict__ offsets,
+                                                          float *__restrict__ centroids,
+                                                          uint32_t *__restrict__ ccounts, float *__restrict__ work_g) {
+  extern __shared__ float work_l[];
+  float *work = USE_LDS ? work_l : work_g + (size_t)blockIdx.x * D * 64;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t c = blockIdx.x * 64 + lane;
+  const bool live = c < K;
+  uint32_t my_count = live ? ccounts[c] : 0;
+  float *cen = centroids + (size_t)(live ? c : 0) * D;
+  {
+    const float fmy = (float)my_count;  // _const<F>(my_count), kmeans.cu:380
+    for (uint32_t f = 0; f < D; f++) work[f * 64 + lane] = live ? cen[f] * fmy : 0.f;
+  }
+  uint32_t ia = live ? offsets[2 * c] : 0, ea = live ? offsets[2 * c + 1] : 0;
+  uint32_t ib = ea, eb = live ? offsets[2 * c + 2] : 0;
+  float corr = 0.f;
+  while (ia < ea || ib < eb) {  // divergent per lane: lanes with fewer events idle
+    const uint32_t ra = ia < ea ? rows[ia] : 0xFFFFFFFFu;
+    const uint32_t rb = ib < eb ? rows[ib] : 0xFFFFFFFFu;
+    const bool in = ra < rb;  // a row is never in both lists of one centroid
+    const uint32_t row = in ? ra : rb;
+    const float fsign = in ? 1.f : -1.f;
+    if (in) { ia++; my_count++; } else { ib++; my_count--; }
+    const float *x = samples + (size_t)row * D;
+    uint32_t f = 0;
+    if ((D & 3u) == 0) {
+      for (; f < D; f += 4) {
+        const float4 xv = *reinterpret_cast<const float4 *>(x + f);
+        float c0 = work[(f + 0) * 64 + lane], c1 = work[(f + 1) * 64 + lane];
+        float c2 = work[(f + 2) * 64 + lane], c3 = work[(f + 3) * 64 + lane];
+        float y, t;
+        y = fma_rd(xv.x, fsign, corr); t = c0 + y; corr = y - (t - c0); c0 = t;
+        y = fma_rd(xv.y, fsign, corr); t = c1 + y; corr = y - (t - c1); c1 = t;
+        y = fma_rd(xv.z, fsign, corr); t = c2 + y; corr = y - (t - c2); c2 = t;
+        y = fma_rd(xv.w, fsign, corr); t = c3 + y; corr = y - (t - c3); c3 = t;
+        work[(f + 0) * 64 + lane] = c0; work[(f + 1) * 64 + lane] = c1;
+        work[(f + 2) * 64 + lane] = c2; work[(f + 3) * 64 + lane] = c3;
+      }
+    }
+    for (; f < D; f++) {
+      const float cv = work[f * 64 + lane];
+      const float y = fma_rd(x[f], fsign, corr);
+      const float t = cv + y;
+      corr = y - (t - cv);
+      work[f * 64 + lane] = t;
+    }
+  }
+  if (!live) return;
+  if (METRIC == 0) {  // metric_abstraction.h:138-144: count 0 => NaN/inf row, never chosen again
+    const float rc = 1.0f / (float)my_count;
+    for (uint32_t f = 0; f < D; f++) cen[f] = work[f * 64 + lane] * rc;
+  } else {            // metric_abstraction.h:255-272
+    float norm = 0.f, ncorr = 0.f;
+    for (uint32_t f = 0; f < D; f++) {
+      const float v = work[f * 64 + lane];
+      kahan_fold(fma_rd(v, v, ncorr), norm, ncorr);
+    }
+    norm = 1.0f / sqrtf(norm);
+    for (uint32_t f = 0; f < D; f++) cen[f] = work[f * 64 + lane] * norm;
+  }
+  ccounts[c] = my_count;
+}
+
+hipError_t launch_adjust_exact(int metric, const float *samples, uint32_t N, uint32_t D, uint32_t K,
+                               const uint32_t *prev, const uint32_t *cur, uint32_t *keys_tmp, uint32_t *vals_tmp,
+                               uint32_t *keys_sorted, uint32_t *rows_sorted, uint32_t *offsets2, void *temp,
+                               size_t temp_bytes, float *work, float *centroids, uint32_t *ccounts, hipStream_t st) {
+  hipLaunchKernelGGL(move_events_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, keys_tmp, vals_tmp);
+  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t *)keys_tmp, keys_sorted,
+                                           (const uint32_t *)vals_tmp, rows_sorted, 2 * (size_t)N, 0u,
+                                           bits_for(2ull * K), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(offsets_kernel, dim3((2 * K + 1 + 255) / 256), dim3(256), 0, st, keys_sorted, 2 * N, 2 * K,
+                     offsets2);
+  const uint32_t grid = (K + 63) / 64;
+  const size_t lds = (size_t)D * 64 * sizeof(float);
+  const bool use_lds = lds <= 128 * 1024;
+#define KMX_ADJ(M, L)                                                                                        \
+  hipLaunchKernelGGL((adjust_exact_kernel<M, L>), dim3(grid), dim3(64), (L) ? lds : 0, st, samples, D, K,    \
+                     rows_sorted, offsets2, centroids, ccounts, work)
+  if (use_lds) {
+    e = hipFuncSetAttribute(metric == 0 ? (const void *)adjust_exact_kernel<0, true>
+                                        : (const void *)adjust_exact_kernel<1, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (metric == 0) KMX_ADJ(0, true); else KMX_ADJ(1, true);
+  } else {
+    if (metric == 0) KMX_ADJ(0, false); else KMX_ADJ(1, false);
+  }
+#undef KMX_ADJ
   return hipGetLastError();
 }
 

@@ -72,6 +72,10 @@ class Engine:
         _lib.check(self.lib.kmamd_apply_delta(self.h, self._p(delta), self._p(dcount), self._p(centroids),
                                               self._p(ccounts)), "kmamd_apply_delta")
 
+    def adjust_exact(self, samples, prev, cur, centroids, ccounts):
+        _lib.check(self.lib.kmamd_adjust_exact(self.h, self._p(samples), self._p(prev), self._p(cur),
+                                               self._p(centroids), self._p(ccounts)), "kmamd_adjust_exact")
+
     def pack_reduce_tail(self, dcount, dst):
         _lib.check(self.lib.kmamd_pack_reduce_tail(self.h, self._p(dcount), self._p(dst)), "kmamd_pack_reduce_tail")
 
@@ -80,6 +84,21 @@ class Engine:
 
     def transpose(self, src, rows, cols, dst):
         _lib.check(self.lib.kmamd_transpose(self.h, self._p(src), rows, cols, self._p(dst)), "kmamd_transpose")
+
+    def yy_init(self, xt, centroids, assignments, groups_n, cperm, gstart, bounds):
+        _lib.check(self.lib.kmamd_yy_init(self.h, self._p(xt), self._p(centroids), self._p(assignments), groups_n,
+                                          self._p(cperm), self._p(gstart), self._p(bounds)), "kmamd_yy_init")
+
+    def yy_drifts(self, centroids, groups_n, groups, drifts, gdrifts):
+        _lib.check(self.lib.kmamd_yy_drifts(self.h, self._p(centroids), groups_n, self._p(groups), self._p(drifts),
+                                            self._p(gdrifts)), "kmamd_yy_drifts")
+
+    def yy_filters(self, samples, xt, centroids, groups_n, groups, drifts, gdrifts, assignments, assignments_prev,
+                   bounds, passed):
+        _lib.check(self.lib.kmamd_yy_filters(self.h, self._p(samples), self._p(xt), self._p(centroids), groups_n,
+                                             self._p(groups), self._p(drifts), self._p(gdrifts), self._p(assignments),
+                                             self._p(assignments_prev), self._p(bounds), self._p(passed)),
+                   "kmamd_yy_filters")
 
     def sync(self):
         _lib.check(self.lib.kmamd_engine_sync(self.h), "kmamd_engine_sync")

@@ -188,3 +188,47 @@ def knn(k, samples, centroids, assignments, metric="L2"):
     if rc:
         raise ValueError("kmo_knn failed: %d" % rc)
     return nb, calced.value
+
+
+def yy_init(samples, centroids, assignments, groups, n_groups, metric=L2):
+    """kmeans_yy_init.  Returns bounds, shape (G+1, N): [0] upper, [1+g] lower to group g."""
+    x, c = _c32(samples), _c32(centroids)
+    a = np.ascontiguousarray(assignments, dtype=np.uint32)
+    g = np.ascontiguousarray(groups, dtype=np.uint32)
+    bounds = np.empty((n_groups + 1, x.shape[0]), np.float32)
+    lib().kmo_yy_init(_metric(metric), x.shape[0], x.shape[1], c.shape[0], n_groups, _fp(x), _fp(c),
+                      _up(a), _up(g), _fp(bounds))
+    return bounds
+
+
+def yy_drifts(old_centroids, centroids, groups, n_groups, metric=L2):
+    """kmeans_yy_calc_drifts + kmeans_yy_find_group_max_drifts.  Returns the reference's drifts
+    buffer (K*D + K floats; [0, G) = group maxima overlaying the old centroids, [K*D, K*D+K) =
+    per-centroid drifts)."""
+    oc, c = _c32(old_centroids), _c32(centroids)
+    k, d = c.shape
+    drifts = np.empty(k * d + k, np.float32)
+    drifts[:k * d] = oc.ravel()
+    g = np.ascontiguousarray(groups, dtype=np.uint32)
+    lib().kmo_yy_calc_drifts(_metric(metric), d, k, _fp(c), _fp(drifts))
+    lib().kmo_yy_group_max_drifts(d, k, n_groups, _up(g), _fp(drifts))
+    return drifts
+
+
+def yy_filters(samples, centroids, groups, n_groups, drifts, assignments, bounds, metric=L2):
+    """kmeans_yy_global_filter + kmeans_yy_local_filter on copies.
+    Returns (assignments, assignments_prev, bounds, passed (sorted), changed)."""
+    x, c = _c32(samples), _c32(centroids)
+    n = x.shape[0]
+    g = np.ascontiguousarray(groups, dtype=np.uint32)
+    a = np.array(assignments, dtype=np.uint32, copy=True)
+    prev = np.empty(n, np.uint32)
+    b = np.array(bounds, dtype=np.float32, copy=True)
+    dr = np.ascontiguousarray(drifts, dtype=np.float32)
+    passed = np.empty(n, np.uint32)
+    m = _metric(metric)
+    npassed = lib().kmo_yy_global_filter(m, n, x.shape[1], c.shape[0], n_groups, _fp(x), _fp(c), _up(g),
+                                         _fp(dr), _up(a), _up(prev), _fp(b), _up(passed))
+    changed = lib().kmo_yy_local_filter(m, n, x.shape[1], c.shape[0], n_groups, _fp(x), _up(passed), npassed,
+                                        _fp(c), _up(g), _fp(dr), _up(a), _fp(b))
+    return a, prev, b, np.sort(passed[:npassed]), changed

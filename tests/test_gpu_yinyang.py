@@ -1,0 +1,128 @@
+"""GPU parity tests of the Yinyang path (reference: kmeans.cu:431-672, :1028-1263): the HIP
+kernels through the C ABI vs the CPU oracle.  Bar: bounds, drifts, the passed set, assignments
+and the reassignment counter are BIT-EXACT (all of them are produced by the reference's exact
+arithmetic); the end-to-end pins are the reference's own (test.py:228-234, :459-466)."""
+import numpy
+import pytest
+
+import oracle
+from test_gpu_kmeans import StdoutListener, _validate
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _t(a, dev):
+    if a.dtype == numpy.uint32:
+        a = a.view(numpy.int32)
+    return torch.from_numpy(numpy.ascontiguousarray(a)).to(dev)
+
+
+def _group_index(groups, G):
+    order = numpy.argsort(groups, kind="stable").astype(numpy.uint32)
+    order = order[groups[order] < G]
+    gstart = numpy.zeros(G + 1, numpy.uint32)
+    numpy.cumsum(numpy.bincount(groups[groups < G], minlength=G), out=gstart[1:])
+    return order, gstart
+
+
+@pytest.mark.parametrize("n,d,k,G,metric", [(3000, 2, 50, 5, "L2"), (2500, 33, 64, 6, "L2"),
+                                            (4000, 256, 128, 12, "L2"), (2000, 64, 40, 4, "cos")])
+def test_yinyang_steps_bit_exact(n, d, k, G, metric):
+    from kmcuda_amd.engine import Engine
+    dev = torch.device("cuda", 0)
+    rs = numpy.random.RandomState(n + d)
+    x = rs.rand(n, d).astype(numpy.float32)
+    if metric == "cos":
+        x /= numpy.linalg.norm(x, axis=1)[:, None]
+    m = oracle.COS if metric == "cos" else oracle.L2
+    c0 = x[rs.choice(n, k, replace=False)].copy()
+    a1, p1, _ = oracle.lloyd_assign(x, c0, metric=m)
+    c1, cc1 = oracle.adjust(x, p1, a1, c0, numpy.zeros(k, numpy.uint32), metric=m)
+    a2, p2, _ = oracle.lloyd_assign(x, c1, assignments=a1, metric=m)
+    groups = rs.randint(0, G, k).astype(numpy.uint32)
+    bounds = oracle.yy_init(x, c1, a2, groups, G, metric=m)
+    c2, cc2 = oracle.adjust(x, p2, a2, c1, cc1, metric=m)
+    drifts = oracle.yy_drifts(c1, c2, groups, G, metric=m)
+    ra, rprev, rb, rpassed, rchanged = oracle.yy_filters(x, c2, groups, G, drifts, a2, bounds, metric=m)
+
+    eng = Engine(n, d, k, metric, device=0)
+    xs = _t(x, dev)
+    xt = torch.empty(d * n, dtype=torch.float32, device=dev)
+    eng.transpose(xs, n, d, xt)
+    cperm, gstart = _group_index(groups, G)
+    gb = torch.empty((G + 1) * n, dtype=torch.float32, device=dev)
+    asg = _t(a2, dev)
+    eng.yy_init(xt, _t(c1, dev), asg, G, _t(cperm, dev), _t(gstart, dev), gb)
+    eng.sync()
+    got_b = gb.cpu().numpy().reshape(G + 1, n)
+    if metric == "cos":
+        # acosf: libm (oracle) vs ocml (GPU) differ in the last ulp -- the reference's CUDA acosf is
+        # a third implementation; angular parity is tolerance-only
+        numpy.testing.assert_allclose(got_b, bounds, rtol=0, atol=1e-6)
+        eng.close()
+        return
+    assert (got_b.view(numpy.uint32) == bounds.view(numpy.uint32)).all()
+
+    dr = torch.empty(k * d + k, dtype=torch.float32, device=dev)
+    dr[:k * d] = _t(c1, dev).ravel()
+    gdr = torch.empty(G, dtype=torch.float32, device=dev)
+    cen2 = _t(c2, dev)
+    eng.yy_drifts(cen2, G, _t(groups, dev), dr, gdr)
+    eng.sync()
+    assert (dr[k * d:].cpu().numpy().view(numpy.uint32) == drifts[k * d:].view(numpy.uint32)).all()
+    assert (gdr.cpu().numpy().view(numpy.uint32) == drifts[:G].view(numpy.uint32)).all()
+
+    prev = torch.empty(n, dtype=torch.int32, device=dev)
+    passed = torch.empty(n, dtype=torch.int32, device=dev)
+    eng.reset_counters(-1)
+    eng.yy_filters(xs, xt, cen2, G, _t(groups, dev), dr, gdr, asg, prev, gb, passed)
+    counters = eng.counters()
+    assert counters[2] == len(rpassed)
+    assert counters[0] == rchanged
+    got_passed = numpy.sort(passed.cpu().numpy().view(numpy.uint32)[:counters[2]])
+    assert (got_passed == rpassed).all()
+    assert (asg.cpu().numpy().view(numpy.uint32) == ra).all()
+    assert (prev.cpu().numpy().view(numpy.uint32) == rprev).all()
+    assert (gb.cpu().numpy().reshape(G + 1, n).view(numpy.uint32) == rb.view(numpy.uint32)).all()
+    eng.close()
+
+
+def test_kmeanspp_yinyang_15_3(fixture13k):
+    # test.py:228-234
+    from kmcuda_amd import kmeans_cuda
+    out = StdoutListener()
+    with out:
+        centroids, assignments = kmeans_cuda(fixture13k, 50, init="kmeans++", device=1, verbosity=2, seed=3,
+                                             tolerance=0.01, yinyang_t=0.1)
+    assert out.iterations() == 15 + 3
+    _validate(fixture13k, centroids, assignments, 0.01)
+    assert "refreshing Yinyang bounds" in out.text
+
+
+def test_256_features_cosine_yinyang_9():
+    # test.py:459-466
+    from kmcuda_amd import kmeans_cuda
+    numpy.random.seed(0)
+    arr = numpy.random.rand(1000, 256).astype(numpy.float32)
+    arr /= numpy.linalg.norm(arr, axis=1)[:, numpy.newaxis]
+    out = StdoutListener()
+    with out:
+        kmeans_cuda(arr, 10, init="kmeans++", metric="cos", device=1, verbosity=3, yinyang_t=0.1, seed=3)
+    assert out.iterations() == 9
+
+
+def test_yinyang_equals_lloyd_outcome(fixture13k):
+    from kmcuda_amd import kmeans_cuda
+    c1, a1 = kmeans_cuda(fixture13k, 50, init="kmeans++", device=1, seed=3, tolerance=0.01, yinyang_t=0)
+    c2, a2 = kmeans_cuda(fixture13k, 50, init="kmeans++", device=1, seed=3, tolerance=0.01, yinyang_t=0.1)
+    assert (a1 != a2).mean() < 0.01
+    numpy.testing.assert_allclose(c1, c2, rtol=1e-3, atol=1e-4)
+
+
+def test_yinyang_virtual_shards(fixture13k, monkeypatch):
+    from kmcuda_amd import kmeans_cuda
+    c1, a1 = kmeans_cuda(fixture13k, 50, init="kmeans++", device=1, seed=3, tolerance=0.01, yinyang_t=0.1)
+    monkeypatch.setenv("KMCUDA_AMD_VIRTUAL_SHARDS", "3")
+    c3, a3 = kmeans_cuda(fixture13k, 50, init="kmeans++", device=1, seed=3, tolerance=0.01, yinyang_t=0.1)
+    assert (a1 != a3).mean() < 0.002
