@@ -75,6 +75,33 @@ hipError_t launch_yy_filters(int metric, const float *samples, const float *xt, 
                              const float *gdrifts, uint32_t *assignments, uint32_t *assignments_prev, float *bounds,
                              uint32_t *passed, uint32_t *counters, hipStream_t st);
 
+// knn.hip (reference: knn.cu)
+struct KnnArgs {
+  const float *xs;          // N x DP cluster-sorted rows (zero padded to DP)
+  const float *n2s;         // N plain squared norms of the sorted rows
+  const uint32_t *inv;      // N: sorted position -> sample index (inverse assignments)
+  const uint32_t *offsets;  // K+1: cluster c occupies positions [offsets[c], offsets[c+1])
+  const float *mydist;      // N: exact distance of each sorted row to its own centroid
+  const float *R, *C;       // K radii, K x K centroid distances
+  const uint32_t *blocks;   // (cluster, first position) per 128-query block
+  const uint32_t *stats;    // [0] max squared norm bits
+  uint32_t N, D, DP, K, k;
+  uint32_t p_base, p_end;   // this launch covers sorted positions [p_base, p_end)
+  float eps;
+  float *heaps;             // (p_end - p_base) x 2k
+  uint32_t *out;            // (p_end - p_base) x k, sorted-position order
+  unsigned long long *calced;
+};
+hipError_t launch_knn_gather(const float *samples, uint32_t N, uint32_t D, uint32_t DP, const uint32_t *inv,
+                             float *xs, float *n2s, uint32_t *stats, hipStream_t st);
+hipError_t launch_knn_prep(int metric, const float *xs, uint32_t N, uint32_t D, uint32_t DP, const uint32_t *offsets,
+                           uint32_t K, const float *centroids, float *mydist, float *rdist, float *R, float *C,
+                           hipStream_t st);
+hipError_t launch_knn_filter(int metric, const KnnArgs &a, uint32_t nblocks, hipStream_t st);
+hipError_t launch_knn_exact(int metric, const KnnArgs &a, hipStream_t st);
+hipError_t launch_knn_scatter(const uint32_t *sorted_out, const uint32_t *inv, uint32_t p_base, uint32_t p_end,
+                              uint32_t k, uint32_t *neighbors, hipStream_t st);
+
 // transpose.hip (reference: transpose.cu:16-54)
 hipError_t launch_transpose(const float *in, uint32_t rows, uint32_t cols, float *out, hipStream_t st);
 

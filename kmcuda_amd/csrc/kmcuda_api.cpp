@@ -621,6 +621,231 @@ class Job {
   }
 };
 
+
+// ---------------------------------------------------------------------------------------
+// k-NN host side (reference: knn_cuda, kmcuda.cc:572-730 + knn_cuda_calc, knn.cu:381-532).
+// Every GPU of the mask holds the whole corpus (as in the reference, kmcuda.cc:593-598) in
+// CLUSTER-SORTED order and searches a contiguous slice of the sorted positions; there is no
+// data-path collective.  The small replicated pieces (radii, K x K centroid distances) are
+// recomputed on every GPU instead of exchanged.
+// ---------------------------------------------------------------------------------------
+struct KnnShard {
+  int dev = 0;
+  hipStream_t stream = nullptr;
+  const float *samples = nullptr, *centroids = nullptr;
+  const uint32_t *assignments = nullptr;
+  float *xs = nullptr, *n2s = nullptr, *mydist = nullptr, *rdist = nullptr, *R = nullptr, *C = nullptr, *heaps = nullptr;
+  uint32_t *inv = nullptr, *offsets = nullptr, *keys_tmp = nullptr, *vals_tmp = nullptr, *keys_sorted = nullptr,
+           *stats = nullptr, *blocks = nullptr, *out = nullptr;
+  unsigned long long *calced = nullptr;
+  void *sort_temp = nullptr;
+  uint32_t first_block = 0, nblocks = 0, p_base = 0, p_end = 0;
+  std::vector<void *> owned;
+  ~KnnShard() {
+    (void)hipSetDevice(dev);
+    for (void *p : owned) (void)hipFree(p);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  template <typename T>
+  int alloc(T **p, size_t count) {
+    void *q = nullptr;
+    if (hipMalloc(&q, count ? count * sizeof(T) : sizeof(T)) != hipSuccess) return kmcudaMemoryAllocationFailure;
+    owned.push_back(q);
+    *p = static_cast<T *>(q);
+    return 0;
+  }
+  // brings `count` elements of a caller buffer onto this device (or uses it in place)
+  template <typename T>
+  int stage_in(const T *src, size_t count, int32_t device_ptrs, const T **dst) {
+    if (device_ptrs >= 0 && device_ptrs == dev) {
+      *dst = src;
+      return 0;
+    }
+    T *buf = nullptr;
+    int rc = alloc(&buf, count);
+    if (rc) return rc;
+    hipError_t e = device_ptrs < 0
+                       ? hipMemcpyAsync(buf, src, count * sizeof(T), hipMemcpyHostToDevice, stream)
+                       : hipMemcpyPeerAsync(buf, dev, src, device_ptrs, count * sizeof(T), stream);
+    if (e != hipSuccess) return kmcudaMemoryCopyError;
+    *dst = buf;
+    return 0;
+  }
+};
+
+class KnnJob {
+ public:
+  std::vector<std::unique_ptr<KnnShard>> shards;
+
+  int run(const std::vector<int> &devs, int nvirtual, uint32_t k, int metric, uint32_t N, uint32_t D, uint32_t K,
+          int32_t device_ptrs, int verbosity, const float *samples, const float *centroids,
+          const uint32_t *assignments, uint32_t *neighbors) {
+    std::vector<int> shard_devs = devs;
+    if (nvirtual > 1 && devs.size() == 1) shard_devs.assign(nvirtual, devs[0]);  // test hook
+    const char *force_exact = getenv("KMCUDA_AMD_KNN_EXACT");
+    const uint32_t dp_filter = (force_exact && atoi(force_exact)) ? 0 : filter_dp_for(D);
+    const uint32_t DP = dp_filter ? dp_filter : D;
+    if (!dp_filter) INFO("k-NN: every candidate is evaluated with the exact arithmetic (no matrix-core filter)\n");
+    const size_t sort_bytes = sort_temp_bytes(N, K);
+    for (int dev : shard_devs) {
+      auto sh = std::make_unique<KnnShard>();
+      sh->dev = dev;
+      if (hipSetDevice(dev) != hipSuccess) return kmcudaNoSuchDevice;
+      if (hipStreamCreateWithFlags(&sh->stream, hipStreamNonBlocking) != hipSuccess) return kmcudaRuntimeError;
+      RETERR(sh->stage_in(samples, (size_t)N * D, device_ptrs, &sh->samples));
+      RETERR(sh->stage_in(centroids, (size_t)K * D, device_ptrs, &sh->centroids));
+      RETERR(sh->stage_in(assignments, (size_t)N, device_ptrs, &sh->assignments));
+      int rc;
+      if ((rc = sh->alloc(&sh->xs, (size_t)N * DP))) return rc;
+      if ((rc = sh->alloc(&sh->n2s, N))) return rc;
+      if ((rc = sh->alloc(&sh->mydist, N))) return rc;
+      if ((rc = sh->alloc(&sh->rdist, N))) return rc;
+      if ((rc = sh->alloc(&sh->R, K))) return rc;
+      if ((rc = sh->alloc(&sh->C, (size_t)K * K))) return rc;
+      if ((rc = sh->alloc(&sh->inv, N))) return rc;
+      if ((rc = sh->alloc(&sh->offsets, (size_t)K + 2))) return rc;
+      if ((rc = sh->alloc(&sh->keys_tmp, N))) return rc;
+      if ((rc = sh->alloc(&sh->vals_tmp, N))) return rc;
+      if ((rc = sh->alloc(&sh->keys_sorted, N))) return rc;
+      if ((rc = sh->alloc(&sh->stats, 4))) return rc;
+      if ((rc = sh->alloc(&sh->calced, 1))) return rc;
+      char *t = nullptr;
+      if ((rc = sh->alloc(&t, sort_bytes + 16))) return rc;
+      sh->sort_temp = t;
+      shards.push_back(std::move(sh));
+    }
+    // ---- per GPU: inverse assignments, sorted copy, radii, centroid distances ----
+    INFO("initializing the inverse assignments...\n");
+    for (auto &s : shards) {
+      (void)hipSetDevice(s->dev);
+      if (hipMemsetAsync(s->calced, 0, sizeof(unsigned long long), s->stream) != hipSuccess) return kmcudaRuntimeError;
+      if (launch_inverse_assignments(s->assignments, N, K, s->keys_tmp, s->vals_tmp, s->keys_sorted, s->inv,
+                                     s->offsets, s->sort_temp, sort_bytes, s->stream) != hipSuccess)
+        return kmcudaRuntimeError;
+      if (launch_knn_gather(s->samples, N, D, DP, s->inv, s->xs, s->n2s, s->stats, s->stream) != hipSuccess)
+        return kmcudaRuntimeError;
+    }
+    INFO("calculating the cluster radiuses...\n");
+    INFO("calculating the centroid distance matrix...\n");
+    for (auto &s : shards) {
+      (void)hipSetDevice(s->dev);
+      if (launch_knn_prep(metric, s->xs, N, D, DP, s->offsets, K, s->centroids, s->mydist, s->rdist, s->R, s->C,
+                          s->stream) != hipSuccess)
+        return kmcudaRuntimeError;
+    }
+    // ---- the block list: 128 consecutive sorted positions of one cluster per block ----
+    std::vector<uint32_t> offsets(K + 1);
+    {
+      KnnShard &f = *shards[0];
+      (void)hipSetDevice(f.dev);
+      if (hipStreamSynchronize(f.stream) != hipSuccess) return kmcudaRuntimeError;
+      if (hipMemcpy(offsets.data(), f.offsets, (K + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+        return kmcudaMemoryCopyError;
+    }
+    std::vector<uint32_t> blocks;  // (cluster, first position) pairs
+    for (uint32_t c = 0; c < K; c++)
+      for (uint32_t p = offsets[c]; p < offsets[c + 1]; p += 128) {
+        blocks.push_back(c);
+        blocks.push_back(p);
+      }
+    const uint32_t total_blocks = (uint32_t)(blocks.size() / 2);
+    const uint32_t assigned = offsets[K];  // positions >= assigned belong to no cluster (NaN samples)
+    for (size_t i = 0; i < shards.size(); i++) {
+      KnnShard &s = *shards[i];
+      s.first_block = (uint32_t)((uint64_t)total_blocks * i / shards.size());
+      const uint32_t next = (uint32_t)((uint64_t)total_blocks * (i + 1) / shards.size());
+      s.nblocks = next - s.first_block;
+      s.p_base = s.nblocks ? blocks[2 * (size_t)s.first_block + 1] : assigned;
+      s.p_end = next < total_blocks ? blocks[2 * (size_t)next + 1] : assigned;
+      if (!s.nblocks) s.p_end = s.p_base;
+      if (i + 1 == shards.size() && !dp_filter) s.p_end = N;  // the exact kernel also fills the unassigned rows
+    }
+    INFO("searching for the nearest neighbors...\n");
+    for (auto &sp : shards) {
+      KnnShard &s = *sp;
+      (void)hipSetDevice(s.dev);
+      const uint32_t len = s.p_end - s.p_base;
+      int rc;
+      if ((rc = s.alloc(&s.heaps, (size_t)len * 2 * k))) return rc;
+      if ((rc = s.alloc(&s.out, (size_t)len * k))) return rc;
+      if ((rc = s.alloc(&s.blocks, 2 * (size_t)(s.nblocks ? s.nblocks : 1)))) return rc;
+      if (s.nblocks &&
+          hipMemcpyAsync(s.blocks, blocks.data() + 2 * (size_t)s.first_block, 2 * (size_t)s.nblocks * sizeof(uint32_t),
+                         hipMemcpyHostToDevice, s.stream) != hipSuccess)
+        return kmcudaMemoryCopyError;
+      KnnArgs a;
+      a.xs = s.xs; a.n2s = s.n2s; a.inv = s.inv; a.offsets = s.offsets; a.mydist = s.mydist; a.R = s.R; a.C = s.C;
+      a.blocks = s.blocks; a.stats = s.stats; a.N = N; a.D = D; a.DP = DP; a.K = K; a.k = k;
+      a.p_base = s.p_base; a.p_end = s.p_end;
+      a.eps = (float)(1.02 * ((double)D + 12.0) * ldexp(1.0, -24));  // as the Lloyd filter
+      a.heaps = s.heaps; a.out = s.out; a.calced = s.calced;
+      const hipError_t e = dp_filter ? launch_knn_filter(metric, a, s.nblocks, s.stream)
+                                     : launch_knn_exact(metric, a, s.stream);
+      if (e != hipSuccess) return kmcudaRuntimeError;
+    }
+    // ---- outputs: rows back in sample order ----
+    unsigned long long dists_calced = 0;
+    std::vector<uint32_t> host_inv, host_out;
+    if (device_ptrs < 0) {
+      host_inv.resize(N);
+      KnnShard &f = *shards[0];
+      (void)hipSetDevice(f.dev);
+      if (hipMemcpy(host_inv.data(), f.inv, (size_t)N * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+        return kmcudaMemoryCopyError;
+    }
+    for (auto &sp : shards) {
+      KnnShard &s = *sp;
+      (void)hipSetDevice(s.dev);
+      if (hipStreamSynchronize(s.stream) != hipSuccess) {
+        INFO("k-NN kernel failed: %s\n", hipGetErrorString(hipGetLastError()));
+        return kmcudaRuntimeError;
+      }
+      unsigned long long c = 0;
+      if (hipMemcpy(&c, s.calced, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess) return kmcudaMemoryCopyError;
+      DEBUG("#%d dists_calced: %llu\n", s.dev, c);
+      dists_calced += c;
+      const uint32_t len = s.p_end - s.p_base;
+      if (!len) continue;
+      if (device_ptrs < 0) {
+        host_out.resize((size_t)len * k);
+        if (hipMemcpy(host_out.data(), s.out, (size_t)len * k * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+          return kmcudaMemoryCopyError;
+        for (uint32_t i = 0; i < len; i++)
+          memcpy(neighbors + (size_t)host_inv[s.p_base + i] * k, host_out.data() + (size_t)i * k, k * sizeof(uint32_t));
+      } else {
+        // scatter on the caller's device
+        const uint32_t *src_out = s.out, *src_inv = s.inv;
+        uint32_t *tmp_out = nullptr, *tmp_inv = nullptr;
+        if (s.dev != device_ptrs) {
+          (void)hipSetDevice(device_ptrs);
+          if (hipMalloc((void **)&tmp_out, (size_t)len * k * sizeof(uint32_t)) != hipSuccess ||
+              hipMalloc((void **)&tmp_inv, (size_t)N * sizeof(uint32_t)) != hipSuccess)
+            return kmcudaMemoryAllocationFailure;
+          if (hipMemcpyPeer(tmp_out, device_ptrs, s.out, s.dev, (size_t)len * k * sizeof(uint32_t)) != hipSuccess ||
+              hipMemcpyPeer(tmp_inv, device_ptrs, s.inv, s.dev, (size_t)N * sizeof(uint32_t)) != hipSuccess)
+            return kmcudaMemoryCopyError;
+          src_out = tmp_out;
+          src_inv = tmp_inv;
+        }
+        (void)hipSetDevice(device_ptrs);
+        hipError_t e = launch_knn_scatter(src_out, src_inv, s.p_base, s.p_end, k, neighbors, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (tmp_out) (void)hipFree(tmp_out);
+        if (tmp_inv) (void)hipFree(tmp_inv);
+        if (e != hipSuccess) return kmcudaRuntimeError;
+      }
+    }
+    if (dp_filter && assigned < N) {  // rows without a cluster: no neighbours (the reference reads out of bounds)
+      if (device_ptrs < 0) {
+        for (uint32_t p = assigned; p < N; p++)
+          for (uint32_t i = 0; i < k; i++) neighbors[(size_t)host_inv[p] * k + i] = UINT32_MAX;
+      }
+    }
+    INFO("calculated %f of all the distances\n", (dists_calced + .0) / ((double)N * N));  // knn.cu:529-530
+    return 0;
+  }
+};
+
 int virtual_shards() {
   const char *v = getenv("KMCUDA_AMD_VIRTUAL_SHARDS");
   return v ? atoi(v) : 0;
@@ -695,15 +920,30 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
 KMCUDAResult knn_cuda(uint16_t k, KMCUDADistanceMetric metric, uint32_t samples_size, uint16_t features_size,
                       uint32_t clusters_size, uint32_t device, int32_t device_ptrs, int32_t fp16x2, int32_t verbosity,
                       const float *samples, const float *centroids, const uint32_t *assignments, uint32_t *neighbors) {
-  (void)metric; (void)device; (void)device_ptrs; (void)verbosity;
-  // reference: check_knn_args, kmcuda.cc:537-570 (its result is ignored there; we report it)
+  kmx::g_verbosity = verbosity;
+  DEBUG("arguments: %u %d %u %u %u %u %d %d %d %p %p %p %p\n", (unsigned)k, metric, samples_size,
+        (unsigned)features_size, clusters_size, device, device_ptrs, fp16x2, verbosity, (const void *)samples,
+        (const void *)centroids, (const void *)assignments, (void *)neighbors);
+  // reference: check_knn_args, kmcuda.cc:537-570 (its result is ignored there, :583-584; we report it)
   if (k == 0) return kmcudaInvalidArguments;
   if (clusters_size < 2 || clusters_size == UINT32_MAX) return kmcudaInvalidArguments;
   if (features_size == 0) return kmcudaInvalidArguments;
   if (samples_size < clusters_size) return kmcudaInvalidArguments;
+  int ndev = 0;
+  (void)hipGetDeviceCount(&ndev);
+  if (ndev < 32 && device > (1u << ndev)) return kmcudaNoSuchDevice;
   if (!samples || !centroids || !assignments || !neighbors) return kmcudaInvalidArguments;
-  if (fp16x2) return kmcudaInvalidArguments;
-  return kmcudaRuntimeError;  // kernels land with knn.hip
+  if (fp16x2) {
+    INFO("fp16x2 kernels are not built in this round (DESIGN.md: next)\n");
+    return kmcudaInvalidArguments;
+  }
+  auto devs = setup_devices(device, verbosity);
+  if (devs.empty()) return kmcudaNoSuchDevice;
+  KnnJob job;
+  RETERR(job.run(devs, virtual_shards(), k, metric, samples_size, features_size, clusters_size, device_ptrs, verbosity,
+                 samples, centroids, assignments, neighbors));
+  DEBUG("return kmcudaSuccess\n");
+  return kmcudaSuccess;
 }
 
 }  // extern "C"
