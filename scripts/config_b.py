@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""BASELINE config B/A runs through the drop-in boundary with device-resident inputs:
+   python scripts/config_b.py [--samples N] [--yinyang T] [--tolerance X]
+Prints wall time of the whole kmeans_cuda() call and the iteration lines."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--samples", type=int, default=8000000)
+    ap.add_argument("--features", type=int, default=256)
+    ap.add_argument("--clusters", type=int, default=1024)
+    ap.add_argument("--yinyang", type=float, default=0.1)
+    ap.add_argument("--tolerance", type=float, default=0.01)
+    ap.add_argument("--init", default="random")
+    ap.add_argument("--verbosity", type=int, default=1)
+    args = ap.parse_args()
+    import torch
+    from kmcuda_amd import kmeans_cuda
+    from kmcuda_amd.api import _DEVICE_ALLOCS
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    x = torch.empty((args.samples, args.features), dtype=torch.float32, device=dev)
+    for s in range(0, args.samples, 1 << 20):
+        x[s:s + (1 << 20)].uniform_(0.0, 1.0, generator=gen)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cptr, aptr = kmeans_cuda((x.data_ptr(), 0, (args.samples, args.features)), args.clusters, init=args.init,
+                             seed=777, tolerance=args.tolerance, yinyang_t=args.yinyang, device=1,
+                             verbosity=args.verbosity)
+    dt = time.perf_counter() - t0
+    asg = _DEVICE_ALLOCS[aptr]
+    print("kmeans_cuda wall: %.3f s; clusters used: %d" % (dt, int(torch.unique(asg).numel())), flush=True)
+
+
+if __name__ == "__main__":
+    main()
