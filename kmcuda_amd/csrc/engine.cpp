@@ -52,6 +52,8 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if ((rc = alloc(&cfil_, (size_t)K_pad_ * dp))) return rc;
   if ((rc = alloc(&ct_, (size_t)D * Kt_))) return rc;
   if ((rc = alloc(&stats_, 4))) return rc;
+  if ((rc = alloc(&mu_, dp))) return rc;
+  if ((rc = alloc(&finite_, Kt_))) return rc;
   if ((rc = alloc(&flagged_, n_rows))) return rc;
   if ((rc = alloc(&pairs_, 3 * (size_t)n_rows))) return rc;
   if ((rc = alloc(&counters_, 4))) return rc;
@@ -112,11 +114,12 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
                          uint32_t *assignments_prev, bool exact_only) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   const uint32_t dp = DP_ ? DP_ : 8;
-  KMX_HIP(launch_centroid_prep(metric_, centroids, K_, D_, K_pad_, dp, Kt_, csqr_, bias_, cfil_, ct_, stats_, stream_),
+  KMX_HIP(launch_centroid_prep(metric_, centroids, K_, D_, K_pad_, dp, Kt_, csqr_, bias_, cfil_, ct_, mu_, finite_,
+                               stats_, stream_),
           kRuntimeError);
   LloydArgs a;
   a.samples = samples; a.N = N_; a.D = D_; a.K = K_; a.K_pad = K_pad_; a.DP = DP_; a.Kt = Kt_;
-  a.cfil = cfil_; a.bias = bias_; a.ct = ct_; a.csqr = csqr_; a.stats = stats_;
+  a.cfil = cfil_; a.bias = bias_; a.mu = mu_; a.ct = ct_; a.csqr = csqr_; a.stats = stats_;
   a.eps = eps_; a.tie_slack = tie_slack_;
   a.assignments = assignments; a.assignments_prev = assignments_prev;
   a.flagged = flagged_; a.pairs = pairs_; a.counters = counters_;

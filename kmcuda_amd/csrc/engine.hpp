@@ -65,7 +65,8 @@ class Engine {
   float eps_ = 0, tie_slack_ = 0;
 
   // assignment workspace
-  float *csqr_ = nullptr, *bias_ = nullptr, *cfil_ = nullptr, *ct_ = nullptr;
+  float *csqr_ = nullptr, *bias_ = nullptr, *cfil_ = nullptr, *ct_ = nullptr, *mu_ = nullptr;
+  uint32_t *finite_ = nullptr;
   uint32_t *stats_ = nullptr, *flagged_ = nullptr, *pairs_ = nullptr, *counters_ = nullptr;
   // update workspace
   uint32_t *keys_tmp_ = nullptr, *vals_tmp_ = nullptr, *keys_sorted_ = nullptr, *rows_sorted_ = nullptr,

@@ -415,13 +415,16 @@ class Job {
 
   // reference: check_changed, kmeans.cu:697-717.  Returns 1 to stop, 0 to go on, <0 error.
   int check_changed(int iter, float tolerance, bool print, uint32_t *passed_total = nullptr) {
-    uint32_t overall_changed = 0, overall_passed = 0;
+    uint32_t overall_changed = 0, overall_passed = 0, pair_rows = 0, scan_rows = 0;
     for (auto &s : shards) {
       uint32_t c[4];
       if (s->eng->counters_read(c) != 0) return -kmcudaMemoryCopyError;
       overall_changed += c[0];
       overall_passed += c[2];
+      scan_rows += c[1];
+      pair_rows += c[3];
     }
+    if (print) DEBUG("filter: %u rows settled by two exact chains, %u by a full exact scan\n", pair_rows, scan_rows);
     if (passed_total) *passed_total = overall_passed;
     if (print) INFO("iteration %d: %u reassignments\n", iter, overall_changed);
     if (overall_changed <= tolerance * N) return 1;  // counters are NOT zeroed on stop (kmeans.cu:707-709)

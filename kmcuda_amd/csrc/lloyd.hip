@@ -31,50 +31,92 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------
 // 1. centroid_prep
 // ---------------------------------------------------------------------------------------
-// One thread per centroid row.  csqr follows metric_abstraction.h:21-36 exactly (L2) or is
-// the constant 1 (:149-158, angular).
+// rows: one thread per centroid row.  csqr follows metric_abstraction.h:21-36 exactly (L2) or is
+// the constant 1 (:149-158, angular); finite[c] = 0 for a row holding a NaN or an inf (never
+// chosen by the reference: its distance is NaN or +inf and "dist < min_dist" is false).
 template <int METRIC>
-__global__ void centroid_prep_kernel(const float *__restrict__ centroids, uint32_t K, uint32_t D,
-                                     uint32_t K_pad, uint32_t DP, uint32_t Kt, float *__restrict__ csqr,
-                                     float *__restrict__ bias, float *__restrict__ cfil,
-                                     float *__restrict__ ct, uint32_t *__restrict__ stats) {
+__global__ void centroid_rows_kernel(const float *__restrict__ centroids, uint32_t K, uint32_t D, uint32_t Kt,
+                                     float *__restrict__ csqr, float *__restrict__ ct,
+                                     uint32_t *__restrict__ finite, uint32_t *__restrict__ stats) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= K_pad && c >= Kt) return;
-  float ssqr = 0.f, corr = 0.f, plain = 0.f;
-  bool finite = c < K;
+  if (c >= Kt) return;
   if (c < K) {
     const float *row = centroids + (size_t)c * D;
+    float ssqr = 0.f, corr = 0.f, plain = 0.f;
     for (uint32_t f = 0; f < D; f++) {
       const float v = row[f];
       kahan_fold(fma_rd(v, v, corr), ssqr, corr);
-      plain += v * v;  // only used for the finiteness test / angular bound
+      plain = fmaf(v, v, plain);
       if (ct) ct[(size_t)f * Kt + c] = v;
     }
-    finite = (plain - plain) == 0.f;  // false for NaN and inf
+    const bool fin = (plain - plain) == 0.f;  // false for NaN and inf
+    finite[c] = fin ? 1u : 0u;
     if (csqr) csqr[c] = (METRIC == 0) ? ssqr : 1.f;
-  } else if (ct && c < Kt) {
+    // uncentered max ||c||^2 for the bound on the REFERENCE's own rounding error
+    if (fin) atomicMax(&stats[2], __float_as_uint(plain * 1.0001f));
+  } else if (ct) {
     for (uint32_t f = 0; f < D; f++) ct[(size_t)f * Kt + c] = 0.f;
   }
-  if (c < K_pad) {
-    // A centroid with a non-finite norm is never chosen by the reference either: its distance
-    // is NaN or +inf and "dist < min_dist" (min_dist starts at FLT_MAX) is false.
-    float b;
-    if (METRIC == 0) b = finite ? -0.5f * ssqr : -INFINITY;
-    else b = finite ? 0.f : -INFINITY;
-    bias[c] = b;
-    float *dst = cfil + (size_t)c * DP;
-    if (finite) {
-      const float *row = centroids + (size_t)c * D;
-      for (uint32_t f = 0; f < D; f++) dst[f] = row[f];
-      for (uint32_t f = D; f < DP; f++) dst[f] = 0.f;
-      // magnitudes for the error bound: max ||c||^2 and max |bias| (non-negative floats
-      // order like their bit patterns)
-      const float n2 = (METRIC == 0) ? ssqr : plain;
-      atomicMax(&stats[0], __float_as_uint(n2));
-      atomicMax(&stats[1], __float_as_uint(fabsf(b)));
-    } else {
-      for (uint32_t f = 0; f < DP; f++) dst[f] = 0.f;
+}
+
+// mean of the finite centroid rows, one thread per (padded) feature.  Any vector would do: the
+// argmin is translation invariant, the mean just makes the centred norms (and so the filter's
+// error bound) small.
+__global__ void centroid_mean_kernel(const float *__restrict__ centroids, uint32_t K, uint32_t D, uint32_t DP,
+                                     const uint32_t *__restrict__ finite, float *__restrict__ mu) {
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= DP) return;
+  float sum = 0.f;
+  uint32_t n = 0;
+  if (f < D) {
+    for (uint32_t c = 0; c < K; c++) {
+      if (finite[c]) {
+        sum += centroids[(size_t)c * D + f];
+        n++;
+      }
     }
+  }
+  const float m = n ? sum / (float)n : 0.f;
+  mu[f] = ((m - m) == 0.f) ? m : 0.f;
+}
+
+// panel: one thread per padded centroid row: cfil = c - mu (zero row + bias -inf if not finite),
+// bias = -||c'||^2/2 (L2) or mu.c' (angular: x.c = x'.c' + mu.c' + terms constant in c), and the
+// two magnitudes of the centred bound.
+template <int METRIC>
+__global__ void centroid_panel_kernel(const float *__restrict__ centroids, uint32_t K, uint32_t D, uint32_t K_pad,
+                                      uint32_t DP, const uint32_t *__restrict__ finite,
+                                      const float *__restrict__ mu, float *__restrict__ bias,
+                                      float *__restrict__ cfil, uint32_t *__restrict__ stats) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= K_pad) return;
+  float *dst = cfil + (size_t)c * DP;
+  if (c < K && finite[c]) {
+    const float *row = centroids + (size_t)c * D;
+    float n2 = 0.f, mc = 0.f, m2 = 0.f;
+    for (uint32_t f = 0; f < D; f++) {
+      const float m = mu[f];
+      const float v = row[f] - m;
+      dst[f] = v;
+      n2 = fmaf(v, v, n2);
+      mc = fmaf(m, v, mc);
+      m2 = fmaf(m, m, m2);
+    }
+    for (uint32_t f = D; f < DP; f++) dst[f] = 0.f;
+    float b, bmag;
+    if (METRIC == 0) {
+      b = -0.5f * n2;
+      bmag = 0.5f * n2;
+    } else {
+      b = mc;
+      bmag = sqrtf(m2) * sqrtf(n2) * 1.0001f;  // >= sum |mu_f c'_f|
+    }
+    bias[c] = b;
+    atomicMax(&stats[0], __float_as_uint(n2 * 1.0001f));
+    atomicMax(&stats[1], __float_as_uint(bmag * 1.0001f));
+  } else {
+    bias[c] = -INFINITY;
+    for (uint32_t f = 0; f < DP; f++) dst[f] = 0.f;
   }
 }
 
@@ -104,8 +146,8 @@ __device__ __forceinline__ bool commit_row(uint32_t s, uint32_t nearest, uint32_
 template <int DP, bool FAST>
 __global__ __launch_bounds__(256, 2) void lloyd_filter_kernel(
     const float *__restrict__ samples, uint32_t N, uint32_t D, const float *__restrict__ cfil,
-    const float *__restrict__ bias, uint32_t K_pad, uint32_t K, const uint32_t *__restrict__ stats,
-    float eps, float tie_slack, uint32_t *__restrict__ assignments,
+    const float *__restrict__ bias, const float *__restrict__ mu, uint32_t K_pad, uint32_t K,
+    const uint32_t *__restrict__ stats, float eps, float tie_slack, uint32_t *__restrict__ assignments,
     uint32_t *__restrict__ assignments_prev, uint32_t *__restrict__ flagged, uint32_t *__restrict__ pairs,
     uint32_t *__restrict__ counters) {
   constexpr int NK = DP / 2;           // k-steps (each MFMA consumes 2 features)
@@ -123,35 +165,43 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_kernel(
   const int h = lane >> 5;    // which half of the features / which centroid rows
   const uint32_t s = blockIdx.x * 128u + wave * 32u + col;
 
-  // ---- B operand: my half row of my sample, resident for the whole kernel ----
+  // ---- B operand: my half row of my sample MINUS the centroid mean, resident for the whole
+  // kernel (the argmin is translation invariant; centring shrinks the norms in the error bound)
   float xb[NK];
+  float xo2 = 0.f;  // squared norm of the ORIGINAL half row (bound on the reference's own error)
   {
     const bool live = s < N;
     if (FAST) {
       const f32x4 *src = reinterpret_cast<const f32x4 *>(samples + (size_t)(live ? s : 0) * D + h * NK);
+      const f32x4 *msrc = reinterpret_cast<const f32x4 *>(mu + h * NK);
 #pragma unroll
       for (int j = 0; j < NK / 4; j++) {
-        f32x4 v = src[j];
-        xb[4 * j + 0] = live ? v.x : 0.f;
-        xb[4 * j + 1] = live ? v.y : 0.f;
-        xb[4 * j + 2] = live ? v.z : 0.f;
-        xb[4 * j + 3] = live ? v.w : 0.f;
+        const f32x4 v = src[j], m = msrc[j];
+        xo2 = fmaf(v.x, v.x, xo2); xo2 = fmaf(v.y, v.y, xo2); xo2 = fmaf(v.z, v.z, xo2); xo2 = fmaf(v.w, v.w, xo2);
+        xb[4 * j + 0] = live ? v.x - m.x : 0.f;
+        xb[4 * j + 1] = live ? v.y - m.y : 0.f;
+        xb[4 * j + 2] = live ? v.z - m.z : 0.f;
+        xb[4 * j + 3] = live ? v.w - m.w : 0.f;
       }
     } else {
       const float *src = samples + (size_t)(live ? s : 0) * D;
 #pragma unroll
       for (int j = 0; j < NK; j++) {
         const uint32_t f = h * NK + j;
-        xb[j] = (live && f < D) ? src[f] : 0.f;
+        const float v = (live && f < D) ? src[f] : 0.f;
+        xo2 = fmaf(v, v, xo2);
+        xb[j] = (live && f < D) ? v - mu[f] : 0.f;
       }
     }
+    if (!live) xo2 = 0.f;
   }
-  // squared norm of the sample (for the error bound) and the "insane" test of kmeans.cu:312
+  // squared norm of the centred sample (for the error bound) and the "insane" test of kmeans.cu:312
   float xn2 = 0.f;
 #pragma unroll
   for (int j = 0; j < NK; j++) xn2 = fmaf(xb[j], xb[j], xn2);
   xn2 += __shfl_xor(xn2, 32);
-  const float x0 = __shfl(xb[0], col);  // feature 0 lives in the lower half-wave
+  xo2 += __shfl_xor(xo2, 32);
+  const float x0 = __shfl(xb[0], col);  // feature 0 lives in the lower half-wave (NaN - mu = NaN)
   const bool insane = (x0 != x0);
 
   // ---- staging of centroid tiles: global -> registers -> LDS (double buffered) ----
@@ -254,14 +304,20 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_kernel(
   }
 
   // ---- decide ----
-  // |score_mfma - score_ref| <= E for every centroid, E = eps*(||x||*Cmax + Bmax)  (DESIGN.md).
+  // |score_filter - score_ref| <= E for every centroid, up to a term constant in c:
+  //   E_mfma = 2 eps (||x'|| C'max + B'max)   MFMA chain + centring roundings, centred magnitudes
+  //   E_ref  = u (12 ||x|| Cmax + 4 Cmax^2)    the reference's own Kahan / round-down rounding
   //   v1 - v2 > 2E : the reference's distance to i1 is strictly the smallest -> commit
   //   v1 - v3 > 2E : the minimum is i1 or i2 -> two exact Kahan distances settle it (pair list)
   //   otherwise    : three or more contenders -> full exact scan (flagged list)
-  const float cmax = sqrtf(__uint_as_float(stats[0])) * 1.000001f;
-  const float bmax = __uint_as_float(stats[1]);
-  const float xn = sqrtf(xn2) * 1.0001f;
-  const float thr = 2.0f * eps * (xn * cmax + bmax) * 1.001f + tie_slack;
+  const float cmaxc = sqrtf(__uint_as_float(stats[0])) * 1.000001f;
+  const float bmaxc = __uint_as_float(stats[1]);
+  const float cmaxo = sqrtf(__uint_as_float(stats[2])) * 1.000001f;
+  const float xn = sqrtf(xn2) * 1.0001f, xo = sqrtf(xo2) * 1.0001f;
+  const float u = 5.9604645e-8f;
+  const float e_mfma = 2.0f * eps * (xn * cmaxc + bmaxc);
+  const float e_ref = u * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
+  const float thr = 2.0f * (e_mfma + e_ref) * 1.001f + tie_slack;
   const bool certain = insane || ((v1 - v2) > thr);  // NaN gap / NaN thr => not certain
   const bool two = !certain && ((v1 - v3) > thr) && i2 != 0xFFFFFFFFu;
   const bool mine = (h == 0) && (s < N);
@@ -410,11 +466,11 @@ static hipError_t launch_filter_dp(const LloydArgs &a, hipStream_t st) {
   const uint32_t grid = (a.N + 127) / 128;
   if (fast) {
     hipLaunchKernelGGL((lloyd_filter_kernel<DP, true>), dim3(grid), dim3(256), lds_bytes, st, a.samples, a.N,
-                       a.D, a.cfil, a.bias, a.K_pad, a.K, a.stats, a.eps, a.tie_slack, a.assignments,
+                       a.D, a.cfil, a.bias, a.mu, a.K_pad, a.K, a.stats, a.eps, a.tie_slack, a.assignments,
                        a.assignments_prev, a.flagged, a.pairs, a.counters);
   } else {
     hipLaunchKernelGGL((lloyd_filter_kernel<DP, false>), dim3(grid), dim3(256), lds_bytes, st, a.samples, a.N,
-                       a.D, a.cfil, a.bias, a.K_pad, a.K, a.stats, a.eps, a.tie_slack, a.assignments,
+                       a.D, a.cfil, a.bias, a.mu, a.K_pad, a.K, a.stats, a.eps, a.tie_slack, a.assignments,
                        a.assignments_prev, a.flagged, a.pairs, a.counters);
   }
   return hipGetLastError();
@@ -433,18 +489,24 @@ hipError_t launch_lloyd_filter(const LloydArgs &a, hipStream_t st) {
 }
 
 hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad,
-                                uint32_t DP, uint32_t Kt, float *csqr, float *bias, float *cfil, float *ct,
-                                uint32_t *stats, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(stats, 0, 2 * sizeof(uint32_t), st);
+                                uint32_t DP, uint32_t Kt, float *csqr, float *bias, float *cfil, float *ct, float *mu,
+                                uint32_t *finite, uint32_t *stats, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(stats, 0, 4 * sizeof(uint32_t), st);
   if (e != hipSuccess) return e;
-  const uint32_t n = K_pad > Kt ? K_pad : Kt;
-  const dim3 grid((n + 63) / 64), block(64);
+  const dim3 block(64);
   if (metric == 0)
-    hipLaunchKernelGGL((centroid_prep_kernel<0>), grid, block, 0, st, centroids, K, D, K_pad, DP, Kt, csqr, bias,
-                       cfil, ct, stats);
+    hipLaunchKernelGGL((centroid_rows_kernel<0>), dim3((Kt + 63) / 64), block, 0, st, centroids, K, D, Kt, csqr, ct,
+                       finite, stats);
   else
-    hipLaunchKernelGGL((centroid_prep_kernel<1>), grid, block, 0, st, centroids, K, D, K_pad, DP, Kt, csqr, bias,
-                       cfil, ct, stats);
+    hipLaunchKernelGGL((centroid_rows_kernel<1>), dim3((Kt + 63) / 64), block, 0, st, centroids, K, D, Kt, csqr, ct,
+                       finite, stats);
+  hipLaunchKernelGGL(centroid_mean_kernel, dim3((DP + 63) / 64), block, 0, st, centroids, K, D, DP, finite, mu);
+  if (metric == 0)
+    hipLaunchKernelGGL((centroid_panel_kernel<0>), dim3((K_pad + 63) / 64), block, 0, st, centroids, K, D, K_pad, DP,
+                       finite, mu, bias, cfil, stats);
+  else
+    hipLaunchKernelGGL((centroid_panel_kernel<1>), dim3((K_pad + 63) / 64), block, 0, st, centroids, K, D, K_pad, DP,
+                       finite, mu, bias, cfil, stats);
   return hipGetLastError();
 }
 
