@@ -68,22 +68,23 @@ int kmamd_adjust_exact(kmamd_engine *e, const float *samples, const uint32_t *as
                        const uint32_t *assignments, float *centroids, uint32_t *ccounts);
 
 /* Yinyang steps (reference: kmeans.cu:431-672), all on the engine's n_rows local rows.
- *   xt       D x n_rows feature-major copy of the rows (kmamd_transpose)
+ *   groups   K host uint32: centroid -> group, >= G for a NaN centroid (kmamd_yy_configure uploads it
+ *            and builds the group-sorted panel index)
  *   bounds   (G+1) x n_rows group-major: [0] upper bound, [1+g] lower bound to group g
- *   groups   K: centroid -> group, >= G for a NaN centroid; cperm/gstart: the same relation as
- *            centroid ids sorted by group + G+1 offsets (host-built)
  *   drifts   K*D old centroids followed by K per-centroid drifts; gdrifts: G per-group maxima
  * yy_init: kmeans_yy_init (:431-485).  yy_drifts: kmeans_yy_calc_drifts + _find_group_max_drifts
  * (:487-538).  yy_filters: kmeans_yy_global_filter then _local_filter (:540-672); counters[2]
  * (passed) must be reset by the caller, counters[0] accumulates reassignments.
- * Bounds, drifts and assignments are bit-identical to the reference arithmetic. */
-int kmamd_yy_init(kmamd_engine *e, const float *xt, const float *centroids, const uint32_t *assignments,
-                  uint32_t G, const uint32_t *cperm, const uint32_t *gstart, float *bounds);
-int kmamd_yy_drifts(kmamd_engine *e, const float *centroids, uint32_t G, const uint32_t *groups,
-                    float *drifts, float *gdrifts);
-int kmamd_yy_filters(kmamd_engine *e, const float *samples, const float *xt, const float *centroids,
-                     uint32_t G, const uint32_t *groups, const float *drifts, const float *gdrifts,
-                     uint32_t *assignments, uint32_t *assignments_prev, float *bounds, uint32_t *passed);
+ * yy_init and the local filter run the matrix-core filter in front of the exact arithmetic
+ * (env KMCUDA_AMD_YY_EXACT=1 at configure time: plain exact kernels); either way bounds, drifts
+ * and assignments are bit-identical to the reference arithmetic. */
+int kmamd_yy_configure(kmamd_engine *e, uint32_t G, const uint32_t *groups_host);
+int kmamd_yy_init(kmamd_engine *e, const float *samples, const float *centroids, const uint32_t *assignments,
+                  float *bounds);
+int kmamd_yy_drifts(kmamd_engine *e, const float *centroids, float *drifts, float *gdrifts);
+int kmamd_yy_filters(kmamd_engine *e, const float *samples, const float *centroids, const float *drifts,
+                     const float *gdrifts, uint32_t *assignments, uint32_t *assignments_prev, float *bounds,
+                     uint32_t *passed);
 
 /* out[c][r] = in[r][c], 4-byte elements (reference: cuda_transpose, transpose.cu:83-117). */
 int kmamd_transpose(kmamd_engine *e, const float *in, uint32_t rows, uint32_t cols, float *out);

@@ -21,7 +21,7 @@ EXPORTS = [
     "kmamd_engine_create", "kmamd_engine_destroy", "kmamd_engine_stream", "kmamd_engine_sync",
     "kmamd_lloyd_assign", "kmamd_lloyd_assign_exact", "kmamd_counters_read", "kmamd_counters_reset",
     "kmamd_move_deltas", "kmamd_apply_delta", "kmamd_transpose", "kmamd_pack_reduce_tail",
-    "kmamd_unpack_dcount", "kmamd_adjust_exact", "kmamd_yy_init", "kmamd_yy_drifts", "kmamd_yy_filters",
+    "kmamd_unpack_dcount", "kmamd_adjust_exact", "kmamd_yy_configure", "kmamd_yy_init", "kmamd_yy_drifts", "kmamd_yy_filters",
     "kmamd_profile_reset", "kmamd_profile_read", "kmamd_profile_enable", "kmamd_build_arch",
 ]
 
@@ -69,11 +69,13 @@ def lib():
     L.kmamd_adjust_exact.restype = i32
     L.kmamd_adjust_exact.argtypes = [vp, vp, vp, vp, vp, vp]
     L.kmamd_yy_init.restype = i32
-    L.kmamd_yy_init.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp]
+    L.kmamd_yy_configure.restype = i32
+    L.kmamd_yy_configure.argtypes = [vp, u32, vp]
+    L.kmamd_yy_init.argtypes = [vp, vp, vp, vp, vp]
     L.kmamd_yy_drifts.restype = i32
-    L.kmamd_yy_drifts.argtypes = [vp, vp, u32, vp, vp, vp]
+    L.kmamd_yy_drifts.argtypes = [vp, vp, vp, vp]
     L.kmamd_yy_filters.restype = i32
-    L.kmamd_yy_filters.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]
+    L.kmamd_yy_filters.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.kmamd_profile_reset.restype = i32
     L.kmamd_profile_reset.argtypes = [vp]
     L.kmamd_profile_enable.restype = i32

@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
+
 #include "../../include/kmcuda_amd.h"
 
 namespace kmx {
@@ -110,13 +112,136 @@ void Engine::profile_reset() {
   filter_launches_ = 0;
 }
 
-int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t *assignments,
-                         uint32_t *assignments_prev, bool exact_only) {
-  KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+int Engine::prepare_centroids(const float *centroids) {
   const uint32_t dp = DP_ ? DP_ : 8;
   KMX_HIP(launch_centroid_prep(metric_, centroids, K_, D_, K_pad_, dp, Kt_, csqr_, bias_, cfil_, ct_, mu_, finite_,
                                stats_, stream_),
           kRuntimeError);
+  return kSuccess;
+}
+
+int Engine::yy_configure(uint32_t G, const uint32_t *groups_host) {
+  KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  if (const char *v = getenv("KMCUDA_AMD_YY_EXACT")) yy_exact_ = atoi(v) != 0;
+  G_ = G;
+  // centroids in group order; group >= G (a NaN centroid keeps the 0xFFFFFFFF "assignment" of
+  // its failed search, kmeans.cu:468-471) is left out
+  std::vector<uint32_t> gstart(G + 1, 0), cperm;
+  for (uint32_t c = 0; c < K_; c++)
+    if (groups_host[c] < G) gstart[groups_host[c] + 1]++;
+  for (uint32_t g = 0; g < G; g++) gstart[g + 1] += gstart[g];
+  cperm.resize(gstart[G] ? gstart[G] : 1);
+  {
+    std::vector<uint32_t> fill(gstart.begin(), gstart.end() - 1);
+    for (uint32_t c = 0; c < K_; c++)
+      if (groups_host[c] < G) cperm[fill[groups_host[c]]++] = c;
+  }
+  // padded panel: every group gets whole 4-slot chunks (at least one, so that an empty group still
+  // gets its FLT_MAX bound written), the panel whole 32-slot tiles
+  std::vector<uint32_t> pids, pmeta;
+  for (uint32_t g = 0; g < G; g++) {
+    const uint32_t n = gstart[g + 1] - gstart[g];
+    const uint32_t chunks = n ? (n + 3) / 4 : 1;
+    for (uint32_t ch = 0; ch < chunks; ch++) {
+      pmeta.push_back((g << 1) | (ch == 0 ? 1u : 0u));
+      for (uint32_t q = 0; q < 4; q++) {
+        const uint32_t i = ch * 4 + q;
+        pids.push_back(i < n ? cperm[gstart[g] + i] : 0xFFFFFFFFu);
+      }
+    }
+  }
+  while (pids.size() % 32) {
+    if (pids.size() % 4 == 0) pmeta.push_back(((G ? G - 1 : 0) << 1));
+    pids.push_back(0xFFFFFFFFu);
+  }
+  while (pmeta.size() < pids.size() / 4) pmeta.push_back(((G ? G - 1 : 0) << 1));
+  nslots_ = (uint32_t)pids.size();
+  int rc;
+  if ((rc = alloc(&groups_, K_))) return rc;
+  if ((rc = alloc(&cperm_, cperm.size()))) return rc;
+  if ((rc = alloc(&gstart_, G + 1))) return rc;
+  if ((rc = alloc(&pids_, pids.size()))) return rc;
+  if ((rc = alloc(&pmeta_, pmeta.size()))) return rc;
+  const uint32_t dp = DP_ ? DP_ : 8;
+  if ((rc = alloc(&pfil_, (size_t)nslots_ * dp))) return rc;
+  if ((rc = alloc(&pbias_, nslots_))) return rc;
+  KMX_HIP(hipMemcpy(groups_, groups_host, K_ * sizeof(uint32_t), hipMemcpyHostToDevice), kMemoryCopyError);
+  KMX_HIP(hipMemcpy(cperm_, cperm.data(), cperm.size() * sizeof(uint32_t), hipMemcpyHostToDevice), kMemoryCopyError);
+  KMX_HIP(hipMemcpy(gstart_, gstart.data(), (G + 1) * sizeof(uint32_t), hipMemcpyHostToDevice), kMemoryCopyError);
+  KMX_HIP(hipMemcpy(pids_, pids.data(), pids.size() * sizeof(uint32_t), hipMemcpyHostToDevice), kMemoryCopyError);
+  KMX_HIP(hipMemcpy(pmeta_, pmeta.data(), pmeta.size() * sizeof(uint32_t), hipMemcpyHostToDevice), kMemoryCopyError);
+  return kSuccess;
+}
+
+static void fill_yy_args(Engine &e, YyArgs &a, const float *samples, const float *centroids) {
+  a.samples = samples; a.centroids = centroids;
+  a.len = e.N_; a.D = e.D_; a.DP = e.DP_; a.K = e.K_; a.K_pad = e.K_pad_; a.G = e.G_;
+  a.cfil = e.cfil_; a.bias = e.bias_; a.mu = e.mu_; a.stats = e.stats_; a.eps = e.eps_;
+  a.groups = e.groups_; a.drifts = nullptr; a.gdrifts = nullptr; a.assignments = nullptr; a.bounds = nullptr;
+  a.passed = nullptr; a.counters = e.counters_;
+  a.pfil = e.pfil_; a.pbias = e.pbias_; a.pids = e.pids_; a.pmeta = e.pmeta_; a.cperm = e.cperm_;
+  a.gstart = e.gstart_; a.nslots = e.nslots_;
+}
+
+int Engine::yy_init(const float *samples, const float *centroids, const uint32_t *assignments, float *bounds) {
+  KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  if (N_ == 0) return kSuccess;
+  if (DP_ && !yy_exact_) {
+    int rc = prepare_centroids(centroids);
+    if (rc) return rc;
+    KMX_HIP(launch_yy_sorted_panel(cfil_, bias_, DP_, pids_, nslots_, pfil_, pbias_, stream_), kRuntimeError);
+    YyArgs a;
+    fill_yy_args(*this, a, samples, centroids);
+    a.assignments = const_cast<uint32_t *>(assignments);
+    a.bounds = bounds;
+    KMX_HIP(launch_yy_init_mfma(metric_, a, stream_), kRuntimeError);
+    return kSuccess;
+  }
+  if (!xt_) {
+    int rc = alloc(&xt_, (size_t)N_ * D_);
+    if (rc) return rc;
+  }
+  KMX_HIP(launch_transpose(samples, N_, D_, xt_, stream_), kRuntimeError);
+  KMX_HIP(launch_yy_init(metric_, xt_, N_, D_, G_, centroids, assignments, cperm_, gstart_, bounds, stream_),
+          kRuntimeError);
+  return kSuccess;
+}
+
+int Engine::yy_drifts(const float *centroids, float *drifts, float *gdrifts) {
+  KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  KMX_HIP(launch_yy_drifts(metric_, centroids, K_, D_, G_, groups_, drifts, gdrifts, stream_), kRuntimeError);
+  return kSuccess;
+}
+
+int Engine::yy_filters(const float *samples, const float *centroids, const float *drifts, const float *gdrifts,
+                       uint32_t *assignments, uint32_t *assignments_prev, float *bounds, uint32_t *passed) {
+  KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  if (N_ == 0) return kSuccess;
+  KMX_HIP(launch_yy_global_filter(metric_, samples, N_, D_, K_, G_, centroids, drifts, gdrifts, assignments,
+                                  assignments_prev, bounds, passed, counters_, stream_),
+          kRuntimeError);
+  if (DP_ && !yy_exact_) {
+    int rc = prepare_centroids(centroids);
+    if (rc) return rc;
+    YyArgs a;
+    fill_yy_args(*this, a, samples, centroids);
+    a.drifts = drifts; a.gdrifts = gdrifts; a.assignments = assignments; a.bounds = bounds; a.passed = passed;
+    KMX_HIP(launch_yy_local_mfma(metric_, a, stream_), kRuntimeError);
+    return kSuccess;
+  }
+  KMX_HIP(launch_yy_local_filter(metric_, samples, N_, D_, K_, G_, centroids, groups_, drifts, gdrifts, assignments,
+                                 bounds, passed, counters_, stream_),
+          kRuntimeError);
+  return kSuccess;
+}
+
+int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t *assignments,
+                         uint32_t *assignments_prev, bool exact_only) {
+  KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  {
+    int rc = prepare_centroids(centroids);
+    if (rc) return rc;
+  }
   LloydArgs a;
   a.samples = samples; a.N = N_; a.D = D_; a.K = K_; a.K_pad = K_pad_; a.DP = DP_; a.Kt = Kt_;
   a.cfil = cfil_; a.bias = bias_; a.mu = mu_; a.ct = ct_; a.csqr = csqr_; a.stats = stats_;
@@ -268,28 +393,20 @@ int kmamd_transpose(kmamd_engine *e, const float *in, uint32_t rows, uint32_t co
   if (hipSetDevice(e->e.device_) != hipSuccess) return kmx::kNoSuchDevice;
   return kmx::launch_transpose(in, rows, cols, out, e->e.stream_) == hipSuccess ? kmx::kSuccess : kmx::kRuntimeError;
 }
-int kmamd_yy_init(kmamd_engine *e, const float *xt, const float *centroids, const uint32_t *assignments, uint32_t G,
-                  const uint32_t *cperm, const uint32_t *gstart, float *bounds) {
-  kmx::Engine &g = e->e;
-  if (hipSetDevice(g.device_) != hipSuccess) return kmx::kNoSuchDevice;
-  return kmx::launch_yy_init(g.metric_, xt, g.N_, g.D_, G, centroids, assignments, cperm, gstart, bounds,
-                             g.stream_) == hipSuccess ? kmx::kSuccess : kmx::kRuntimeError;
+int kmamd_yy_configure(kmamd_engine *e, uint32_t G, const uint32_t *groups_host) {
+  return e->e.yy_configure(G, groups_host);
 }
-int kmamd_yy_drifts(kmamd_engine *e, const float *centroids, uint32_t G, const uint32_t *groups, float *drifts,
-                    float *gdrifts) {
-  kmx::Engine &g = e->e;
-  if (hipSetDevice(g.device_) != hipSuccess) return kmx::kNoSuchDevice;
-  return kmx::launch_yy_drifts(g.metric_, centroids, g.K_, g.D_, G, groups, drifts, gdrifts, g.stream_) == hipSuccess
-             ? kmx::kSuccess : kmx::kRuntimeError;
+int kmamd_yy_init(kmamd_engine *e, const float *samples, const float *centroids, const uint32_t *assignments,
+                  float *bounds) {
+  return e->e.yy_init(samples, centroids, assignments, bounds);
 }
-int kmamd_yy_filters(kmamd_engine *e, const float *samples, const float *xt, const float *centroids, uint32_t G,
-                     const uint32_t *groups, const float *drifts, const float *gdrifts, uint32_t *assignments,
-                     uint32_t *assignments_prev, float *bounds, uint32_t *passed) {
-  kmx::Engine &g = e->e;
-  if (hipSetDevice(g.device_) != hipSuccess) return kmx::kNoSuchDevice;
-  return kmx::launch_yy_filters(g.metric_, samples, xt, g.N_, g.D_, g.K_, G, centroids, groups, drifts, gdrifts,
-                                assignments, assignments_prev, bounds, passed, g.counters_, g.stream_) == hipSuccess
-             ? kmx::kSuccess : kmx::kRuntimeError;
+int kmamd_yy_drifts(kmamd_engine *e, const float *centroids, float *drifts, float *gdrifts) {
+  return e->e.yy_drifts(centroids, drifts, gdrifts);
+}
+int kmamd_yy_filters(kmamd_engine *e, const float *samples, const float *centroids, const float *drifts,
+                     const float *gdrifts, uint32_t *assignments, uint32_t *assignments_prev, float *bounds,
+                     uint32_t *passed) {
+  return e->e.yy_filters(samples, centroids, drifts, gdrifts, assignments, assignments_prev, bounds, passed);
 }
 int kmamd_profile_enable(kmamd_engine *e, int on) {
   e->e.profile_collect();

@@ -44,6 +44,13 @@ class Engine {
   int apply_delta(const double *delta, const int32_t *dcount, float *centroids, uint32_t *ccounts);
   int adjust_exact(const float *samples, const uint32_t *prev, const uint32_t *cur, float *centroids,
                    uint32_t *ccounts);
+  int prepare_centroids(const float *centroids);
+  // Yinyang steps (reference: kmeans.cu:431-672); yy_configure uploads the centroid -> group map
+  int yy_configure(uint32_t G, const uint32_t *groups_host);
+  int yy_init(const float *samples, const float *centroids, const uint32_t *assignments, float *bounds);
+  int yy_drifts(const float *centroids, float *drifts, float *gdrifts);
+  int yy_filters(const float *samples, const float *centroids, const float *drifts, const float *gdrifts,
+                 uint32_t *assignments, uint32_t *assignments_prev, float *bounds, uint32_t *passed);
   int counters_read(uint32_t *host4);
   int counters_reset(int which);
   int sync();
@@ -74,6 +81,11 @@ class Engine {
   void *sort_temp_ = nullptr;
   size_t sort_temp_bytes_ = 0;
   double *partial_ = nullptr;
+  // Yinyang
+  uint32_t G_ = 0, nslots_ = 0;
+  bool yy_exact_ = false;  // KMCUDA_AMD_YY_EXACT=1: plain exact kernels (cross-check)
+  uint32_t *groups_ = nullptr, *cperm_ = nullptr, *gstart_ = nullptr, *pids_ = nullptr, *pmeta_ = nullptr;
+  float *pfil_ = nullptr, *pbias_ = nullptr, *xt_ = nullptr;
   float *exact_work_ = nullptr;  // adjust_exact scratch when 64 centroid rows exceed LDS (lazy)
   uint32_t *host_counters_ = nullptr;  // pinned
 

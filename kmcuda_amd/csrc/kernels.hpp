@@ -71,10 +71,38 @@ hipError_t launch_yy_init(int metric, const float *xt, uint32_t len, uint32_t D,
                           hipStream_t st);
 hipError_t launch_yy_drifts(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t G,
                             const uint32_t *groups, float *drifts, float *gdrifts, hipStream_t st);
-hipError_t launch_yy_filters(int metric, const float *samples, const float *xt, uint32_t len, uint32_t D, uint32_t K,
-                             uint32_t G, const float *centroids, const uint32_t *groups, const float *drifts,
-                             const float *gdrifts, uint32_t *assignments, uint32_t *assignments_prev, float *bounds,
-                             uint32_t *passed, uint32_t *counters, hipStream_t st);
+
+// yinyang_mfma.hip: the same steps with the matrix-core filter in front of the exact arithmetic
+struct YyArgs {
+  const float *samples;      // len x D row-major
+  const float *centroids;    // K x D original values (exact chains)
+  uint32_t len, D, DP, K, K_pad, G;
+  const float *cfil, *bias, *mu;  // centred panel of centroid_prep (ascending c)
+  const uint32_t *stats;
+  float eps;
+  const uint32_t *groups;    // K
+  const float *drifts, *gdrifts;
+  uint32_t *assignments;
+  float *bounds;
+  const uint32_t *passed;
+  uint32_t *counters;
+  // yy_init: group-sorted padded panel
+  const float *pfil, *pbias;
+  const uint32_t *pids, *pmeta, *cperm, *gstart;
+  uint32_t nslots;
+};
+hipError_t launch_yy_local_mfma(int metric, const YyArgs &a, hipStream_t st);
+hipError_t launch_yy_init_mfma(int metric, const YyArgs &a, hipStream_t st);
+hipError_t launch_yy_sorted_panel(const float *cfil, const float *bias, uint32_t DP, const uint32_t *pids,
+                                  uint32_t nslots, float *pfil, float *pbias, hipStream_t st);
+hipError_t launch_yy_global_filter(int metric, const float *samples, uint32_t len, uint32_t D, uint32_t K, uint32_t G,
+                                   const float *centroids, const float *drifts, const float *gdrifts,
+                                   const uint32_t *assignments, uint32_t *assignments_prev, float *bounds,
+                                   uint32_t *passed, uint32_t *counters, hipStream_t st);
+hipError_t launch_yy_local_filter(int metric, const float *samples, uint32_t len, uint32_t D, uint32_t K, uint32_t G,
+                                  const float *centroids, const uint32_t *groups, const float *drifts,
+                                  const float *gdrifts, uint32_t *assignments, float *bounds, const uint32_t *passed,
+                                  uint32_t *counters, hipStream_t st);
 
 // knn.hip (reference: knn.cu)
 struct KnnArgs {

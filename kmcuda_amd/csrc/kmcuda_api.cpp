@@ -122,13 +122,10 @@ struct Shard {
   float *dists = nullptr;          // length floats (k-means++ / average distance)
   uint32_t *row_ids = nullptr;     // K uint32 staging for gathers
   // Yinyang state (allocated when the Yinyang phase starts; reference: kmcuda.cc:448-470)
-  float *xt = nullptr;             // D x length feature-major copy of the rows
   float *bounds = nullptr;         // (G+1) x length, group-major (kmeans.cu:431-485 layout)
   float *drifts = nullptr;         // K*D old centroids + K per-centroid drifts
   float *gdrifts = nullptr;        // G per-group max drifts
   uint32_t *passed = nullptr;      // length
-  uint32_t *groups = nullptr;      // K: centroid -> group (assignments_yy)
-  uint32_t *cperm = nullptr, *gstart = nullptr;  // centroids sorted by group + G+1 offsets
   std::vector<void *> owned;
   ~Shard() {
     (void)hipSetDevice(dev);
@@ -507,36 +504,14 @@ class Job {
   int yinyang(float tolerance, uint32_t G, int iter) {
     std::vector<uint32_t> groups;
     RETERR(cluster_groups(G, &groups));
-    // centroids in group order for the bounds refresh; group >= G (a NaN centroid keeps the
-    // 0xFFFFFFFF "assignment" of its failed search, kmeans.cu:468-471) is left out
-    std::vector<uint32_t> cperm, gstart(G + 1, 0);
-    for (uint32_t c = 0; c < K; c++)
-      if (groups[c] < G) gstart[groups[c] + 1]++;
-    for (uint32_t g = 0; g < G; g++) gstart[g + 1] += gstart[g];
-    cperm.resize(gstart[G] ? gstart[G] : 1);
-    {
-      std::vector<uint32_t> fill(gstart.begin(), gstart.end() - 1);
-      for (uint32_t c = 0; c < K; c++)
-        if (groups[c] < G) cperm[fill[groups[c]]++] = c;
-    }
     for (auto &s : shards) {
       (void)hipSetDevice(s->dev);
+      RETERR(s->eng->yy_configure(G, groups.data()));
       int rc;
-      if ((rc = s->alloc(&s->xt, (size_t)s->length * D))) return rc;
       if ((rc = s->alloc(&s->bounds, (size_t)s->length * (G + 1)))) return rc;
       if ((rc = s->alloc(&s->drifts, (size_t)K * D + K))) return rc;
       if ((rc = s->alloc(&s->gdrifts, G))) return rc;
       if ((rc = s->alloc(&s->passed, s->length))) return rc;
-      if ((rc = s->alloc(&s->groups, K))) return rc;
-      if ((rc = s->alloc(&s->cperm, cperm.size()))) return rc;
-      if ((rc = s->alloc(&s->gstart, G + 1))) return rc;
-      hipStream_t st = s->eng->stream_;
-      if (hipMemcpyAsync(s->groups, groups.data(), K * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess ||
-          hipMemcpyAsync(s->cperm, cperm.data(), cperm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st) !=
-              hipSuccess ||
-          hipMemcpyAsync(s->gstart, gstart.data(), (G + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess)
-        return kmcudaMemoryCopyError;
-      if (launch_transpose(s->samples, s->length, D, s->xt, st) != hipSuccess) return kmcudaRuntimeError;
     }
     RETERR(sync_all());  // host vectors above go out of use
     RETERR(prepare_mem(true));
@@ -554,9 +529,7 @@ class Job {
         INFO("refreshing Yinyang bounds...\n");
         for (auto &s : shards) {
           (void)hipSetDevice(s->dev);
-          if (launch_yy_init(metric, s->xt, s->length, D, G, s->centroids, s->assignments, s->cperm, s->gstart,
-                             s->bounds, s->eng->stream_) != hipSuccess)
-            return kmcudaRuntimeError;
+          RETERR(s->eng->yy_init(s->samples, s->centroids, s->assignments, s->bounds));
         }
         refresh = false;
       }
@@ -569,14 +542,10 @@ class Job {
       RETERR(adjust());
       for (auto &s : shards) {
         (void)hipSetDevice(s->dev);
-        hipStream_t st = s->eng->stream_;
-        if (launch_yy_drifts(metric, s->centroids, K, D, G, s->groups, s->drifts, s->gdrifts, st) != hipSuccess)
-          return kmcudaRuntimeError;
+        RETERR(s->eng->yy_drifts(s->centroids, s->drifts, s->gdrifts));
         RETERR(s->eng->counters_reset(2));  // d_passed_number = 0, kmeans.cu:1225-1229
-        if (launch_yy_filters(metric, s->samples, s->xt, s->length, D, K, G, s->centroids, s->groups, s->drifts,
-                              s->gdrifts, s->assignments, s->prev, s->bounds, s->passed, s->eng->counters_,
-                              st) != hipSuccess)
-          return kmcudaRuntimeError;
+        RETERR(s->eng->yy_filters(s->samples, s->centroids, s->drifts, s->gdrifts, s->assignments, s->prev, s->bounds,
+                                  s->passed));
       }
     }
   }

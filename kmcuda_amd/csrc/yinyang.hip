@@ -120,7 +120,7 @@ __global__ void yy_group_max_drifts_kernel(const uint32_t *__restrict__ groups, 
 // ---------------------------------------------------------------------------------------
 template <int METRIC>
 __global__ __launch_bounds__(256) void yy_global_filter_kernel(
-    const float *__restrict__ xt, uint32_t len, uint32_t D, uint32_t K, uint32_t G,
+    const float *__restrict__ samples, uint32_t len, uint32_t D, uint32_t K, uint32_t G,
     const float *__restrict__ centroids, const float *__restrict__ drifts, const float *__restrict__ gdrifts,
     const uint32_t *__restrict__ assignments, uint32_t *__restrict__ assignments_prev, float *__restrict__ bounds,
     uint32_t *__restrict__ passed, uint32_t *__restrict__ counters) {
@@ -142,7 +142,9 @@ __global__ __launch_bounds__(256) void yy_global_filter_kernel(
     if (min_lower_bound >= upper_bound) {  // group filter try #1
       bounds[s] = upper_bound;
     } else {
-      upper_bound = distance_t<METRIC>(xt, len, s, centroids + (size_t)cluster * D, D);
+      // row-major row walked by its own thread: the tightening is needed by a minority of rows and
+      // the (G+1) bounds streamed above dominate the traffic, so no feature-major copy is kept for it
+      upper_bound = distance_vv<METRIC>(samples + (size_t)s * D, centroids + (size_t)cluster * D, D);
       bounds[s] = upper_bound;
       pass = !(min_lower_bound >= upper_bound);  // try #2
     }
@@ -242,13 +244,21 @@ hipError_t launch_yy_drifts(int metric, const float *centroids, uint32_t K, uint
   return hipGetLastError();
 }
 
-hipError_t launch_yy_filters(int metric, const float *samples, const float *xt, uint32_t len, uint32_t D, uint32_t K,
-                             uint32_t G, const float *centroids, const uint32_t *groups, const float *drifts,
-                             const float *gdrifts, uint32_t *assignments, uint32_t *assignments_prev, float *bounds,
-                             uint32_t *passed, uint32_t *counters, hipStream_t st) {
+hipError_t launch_yy_global_filter(int metric, const float *samples, uint32_t len, uint32_t D, uint32_t K, uint32_t G,
+                                   const float *centroids, const float *drifts, const float *gdrifts,
+                                   const uint32_t *assignments, uint32_t *assignments_prev, float *bounds,
+                                   uint32_t *passed, uint32_t *counters, hipStream_t st) {
   if (len == 0) return hipSuccess;
-  KMX_DISPATCH(metric, yy_global_filter_kernel, dim3((len + 255) / 256), dim3(256), st, xt, len, D, K, G, centroids,
-               drifts, gdrifts, assignments, assignments_prev, bounds, passed, counters);
+  KMX_DISPATCH(metric, yy_global_filter_kernel, dim3((len + 255) / 256), dim3(256), st, samples, len, D, K, G,
+               centroids, drifts, gdrifts, assignments, assignments_prev, bounds, passed, counters);
+  return hipGetLastError();
+}
+
+hipError_t launch_yy_local_filter(int metric, const float *samples, uint32_t len, uint32_t D, uint32_t K, uint32_t G,
+                                  const float *centroids, const uint32_t *groups, const float *drifts,
+                                  const float *gdrifts, uint32_t *assignments, float *bounds, const uint32_t *passed,
+                                  uint32_t *counters, hipStream_t st) {
+  if (len == 0) return hipSuccess;
   // the passed count lives on the device: launch for the worst case, surplus threads exit at once
   KMX_DISPATCH(metric, yy_local_filter_kernel, dim3((len + 127) / 128), dim3(128), st, samples, len, D, K, G, passed,
                centroids, groups, drifts, gdrifts, assignments, bounds, counters);

@@ -1,0 +1,558 @@
+// yinyang_mfma.hip -- the two distance-heavy Yinyang steps with the matrix cores in front of the
+// reference's exact arithmetic (reference: src/kmeans.cu:431-485 kmeans_yy_init, :584-672
+// kmeans_yy_local_filter).  yinyang.hip holds the same steps as plain exact kernels (the
+// in-library cross-check, and the path for feature counts the filter is not instantiated for).
+//
+// Both kernels reuse the Lloyd filter's machinery (lloyd.hip): a wave keeps 32 rows, CENTRED
+// (x - mu), resident in VGPRs as the MFMA B operand; 32-centroid tiles of the centred panel stream
+// through LDS shared by the block's 4 waves; the accumulator is seeded with the bias so
+// ||x - c||^2 ~= ||x'||^2 - 2*acc (L2) / x.c ~= acc + x.mu (angular).  The approximate values
+// only decide WHICH exact distances need evaluating; every number that is stored (bounds) or
+// compared (min / second-min updates, skip tests) is the reference's exact arithmetic, evaluated
+// in the reference's order where order matters.  Outputs are bit-identical to yinyang.hip's.
+//
+// yy_local_filter (kmeans.cu:584-672).  Per passed row the reference scans c = 0..K-1:
+//     group bound >= upper bound      -> second_min = min(second_min, bound); skip          (a)
+//     second_min < bound + drifts     -> skip                                                 (b)
+//     else dist = exact; update (min, second_min, nearest) with strict '<'                    (c)
+//   A centroid whose exact distance is >= second_min at its turn changes nothing whether it is
+//   evaluated or skipped.  So: (a) is replayed for every centroid; (b)/(c) only for centroids whose
+//   approximate distance could be below the running second_min (threshold at tile start = a
+//   superset, second_min only decreases); the survivors go through the reference's tests and the
+//   exact distance IN ASCENDING c ORDER, so the state evolves exactly as in the reference.
+//
+// yy_init (kmeans.cu:431-485).  bounds[1+g] = min over the group's centroids (other than the
+//   row's own) of the exact distance: a minimum does not depend on the visiting order, so the panel
+//   is streamed GROUP-SORTED (groups padded to multiples of 4 rows = one half-wave's accumulator
+//   quad), each half-wave keeps a running top-3 of the approximate scores of the current group, and
+//   at the group boundary the exact distance is evaluated for the 1-2 contenders (all members when
+//   three or more are within the error bound).
+#include "exact.hpp"
+#include "kernels.hpp"
+
+namespace kmx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// One serial exact chain over the D features of (sample row, centroid row), both ORIGINAL values
+// from global memory: the lower half-wave runs features [0, NK), hands (acc, corr) to the upper
+// half which continues with [NK, D).  Every lane of a (col, col+32) pair gets the result.
+// metric_abstraction.h:73-86 (L2 distance_t) / :193-205 (angular).
+template <int NK, int METRIC, bool FAST>
+__device__ __forceinline__ float exact_distance_split(const float *__restrict__ xrow, const float *__restrict__ crow,
+                                                      uint32_t D, int h, int col) {
+  float acc = 0.f, corr = 0.f;
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    if (pass == 1) {
+      acc = __shfl(acc, col);
+      corr = __shfl(corr, col);
+    }
+    if (FAST) {
+      const f32x4 *xs = reinterpret_cast<const f32x4 *>(xrow + h * NK);
+      const f32x4 *cs = reinterpret_cast<const f32x4 *>(crow + h * NK);
+#pragma unroll 2
+      for (int j = 0; j < NK / 4; j++) {
+        const f32x4 xv = xs[j], cv = cs[j];
+        const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, ca[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          float y;
+          if (METRIC == 0) {
+            const float d = xa[q] - ca[q];
+            y = fma_rd(d, d, corr);
+          } else {
+            y = fma_rd(xa[q], ca[q], corr);
+          }
+          kahan_fold(y, acc, corr);
+        }
+      }
+    } else {
+#pragma unroll 4
+      for (int j = 0; j < NK; j++) {
+        const uint32_t f = h * NK + j;
+        const bool on = f < D;
+        const float xv = on ? xrow[f] : 0.f, cv = on ? crow[f] : 0.f;
+        float y;
+        if (METRIC == 0) {
+          const float d = xv - cv;
+          y = fma_rd(d, d, corr);
+        } else {
+          y = fma_rd(xv, cv, corr);
+        }
+        const float t = acc + y;
+        const float nc = y - (t - acc);
+        acc = on ? t : acc;
+        corr = on ? nc : corr;
+      }
+    }
+  }
+  const float total = __shfl(acc, col + 32);
+  return METRIC == 0 ? sqrtf(total) : angular_from_prod(total);
+}
+
+// Shared scaffold: centred resident rows, tile staging, one tile of MFMA.
+template <int DP, bool FAST>
+struct RowTile {
+  static constexpr int NK = DP / 2;
+  static constexpr int LDW = DP + 4;
+  static constexpr int TILE = 32 * LDW;
+  static constexpr int NST = (8 * DP + 255) / 256;
+};
+
+#define KMX_YY_LOAD_ROWS(samples_, row_, live_)                                                      \
+  float xb[NK];                                                                                      \
+  float xo2 = 0.f;                                                                                   \
+  {                                                                                                  \
+    if (FAST) {                                                                                      \
+      const f32x4 *src = reinterpret_cast<const f32x4 *>((samples_) + (size_t)((live_) ? (row_) : 0) * D + h * NK); \
+      const f32x4 *msrc = reinterpret_cast<const f32x4 *>(a.mu + h * NK);                            \
+      _Pragma("unroll") for (int j = 0; j < NK / 4; j++) {                                           \
+        const f32x4 v = src[j], m = msrc[j];                                                         \
+        xo2 = fmaf(v.x, v.x, xo2); xo2 = fmaf(v.y, v.y, xo2); xo2 = fmaf(v.z, v.z, xo2); xo2 = fmaf(v.w, v.w, xo2); \
+        xb[4 * j + 0] = (live_) ? v.x - m.x : 0.f;                                                   \
+        xb[4 * j + 1] = (live_) ? v.y - m.y : 0.f;                                                   \
+        xb[4 * j + 2] = (live_) ? v.z - m.z : 0.f;                                                   \
+        xb[4 * j + 3] = (live_) ? v.w - m.w : 0.f;                                                   \
+      }                                                                                              \
+    } else {                                                                                         \
+      const float *src = (samples_) + (size_t)((live_) ? (row_) : 0) * D;                            \
+      _Pragma("unroll") for (int j = 0; j < NK; j++) {                                               \
+        const uint32_t f = h * NK + j;                                                               \
+        const float v = ((live_) && f < D) ? src[f] : 0.f;                                           \
+        xo2 = fmaf(v, v, xo2);                                                                       \
+        xb[j] = ((live_) && f < D) ? v - a.mu[f] : 0.f;                                              \
+      }                                                                                              \
+    }                                                                                                \
+    if (!(live_)) xo2 = 0.f;                                                                         \
+  }                                                                                                  \
+  float xn2 = 0.f;                                                                                   \
+  _Pragma("unroll") for (int j = 0; j < NK; j++) xn2 = fmaf(xb[j], xb[j], xn2);                      \
+  xn2 += __shfl_xor(xn2, 32);                                                                        \
+  xo2 += __shfl_xor(xo2, 32);
+
+#define KMX_YY_MFMA_TILE(acc_, buf_)                                                                 \
+  f32x16 acc_;                                                                                       \
+  {                                                                                                  \
+    const float *bb = bias_ptr(buf_) + 4 * h;                                                        \
+    _Pragma("unroll") for (int g4 = 0; g4 < 4; g4++) {                                               \
+      const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bb + 8 * g4);                                \
+      acc_[4 * g4 + 0] = b4.x; acc_[4 * g4 + 1] = b4.y; acc_[4 * g4 + 2] = b4.z; acc_[4 * g4 + 3] = b4.w; \
+    }                                                                                                \
+    const float *arow = tile_ptr(buf_) + col * LDW + h * NK;                                         \
+    _Pragma("unroll") for (int j = 0; j < NK / 4; j++) {                                             \
+      const f32x4 a4 = *reinterpret_cast<const f32x4 *>(arow + 4 * j);                               \
+      acc_ = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, xb[4 * j + 0], acc_, 0, 0, 0);               \
+      acc_ = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, xb[4 * j + 1], acc_, 0, 0, 0);               \
+      acc_ = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, xb[4 * j + 2], acc_, 0, 0, 0);               \
+      acc_ = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, xb[4 * j + 3], acc_, 0, 0, 0);               \
+    }                                                                                                \
+  }
+
+// ---------------------------------------------------------------------------------------
+// yy_local_filter with the MFMA filter
+// ---------------------------------------------------------------------------------------
+template <int DP, int METRIC, bool FAST>
+__global__ __launch_bounds__(256, 2) void yy_local_mfma_kernel(YyArgs a) {
+  constexpr int NK = DP / 2, LDW = DP + 4, TILE = 32 * LDW, NST = (8 * DP + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  auto tile_ptr = [&](int buf) { return lds + buf * TILE; };
+  auto bias_ptr = [&](int buf) { return lds + 2 * TILE + buf * 32; };
+  auto grp_ptr = [&](int buf) { return reinterpret_cast<uint32_t *>(lds + 2 * TILE + 64) + buf * 32; };
+
+  const uint32_t npassed = a.counters[2];
+  if (blockIdx.x * 128u >= npassed) return;  // block-uniform
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+  const uint32_t D = a.D, K = a.K, G = a.G, len = a.len;
+  const uint32_t pi = blockIdx.x * 128u + wave * 32u + col;
+  const bool live = pi < npassed;
+  const uint32_t s = live ? a.passed[pi] : 0u;
+
+  KMX_YY_LOAD_ROWS(a.samples, s, live)
+
+  const float upper_bound = live ? a.bounds[s] : 0.f;
+  const uint32_t cluster = live ? a.assignments[s] : 0xFFFFFFFFu;
+  float min_dist = upper_bound, second_min = 3.402823466e+38f;
+  uint32_t nearest = cluster;
+
+  // threshold in accumulator space: a centroid can only matter if acc >= amin
+  const float cmaxc = sqrtf(__uint_as_float(a.stats[0])) * 1.000001f;
+  const float bmaxc = __uint_as_float(a.stats[1]);
+  const float xn = sqrtf(xn2) * 1.0001f;
+  const float e_mfma = 2.0f * a.eps * (xn * cmaxc + bmaxc) * 1.01f;
+  float kx = 0.f, e_cos = 0.f;
+  if (METRIC == 1) {
+    // x.c = acc + x.mu  (acc = x'.c' + mu.c');  x.mu evaluated here in fp32
+    float p = 0.f;
+#pragma unroll
+    for (int j = 0; j < NK; j++) {
+      const uint32_t f = h * NK + j;
+      const float m = f < D ? a.mu[f] : 0.f;
+      p = fmaf(xb[j] + m, m, p);
+    }
+    kx = p + __shfl_xor(p, 32);
+    const float mun = sqrtf(__uint_as_float(a.stats[3])) * 1.0001f;
+    e_cos = e_mfma + a.eps * (sqrtf(xo2) * 1.0001f + xn) * mun + 1e-6f;
+  }
+  auto amin_of = [&](float sm) -> float {
+    if (METRIC == 0) {
+      const float T2 = sm * sm * 1.000002f;  // inf while second_min is still FLT_MAX
+      return 0.5f * (xn2 - T2) - e_mfma - 1e-6f * (xn2 + T2);
+    }
+    if (sm >= 3.1415925f) return -INFINITY;
+    return cosf(sm) - kx - e_cos;
+  };
+  float amin = amin_of(second_min);
+
+  f32x4 stage[NST];
+  float bstage = 0.f;
+  uint32_t gstage = 0;
+  auto stage_load = [&](uint32_t tile) {
+    const float *src = a.cfil + (size_t)tile * 32 * DP;
+#pragma unroll
+    for (int i = 0; i < NST; i++) {
+      const int q = tid + i * 256;
+      if (q < 8 * DP) stage[i] = reinterpret_cast<const f32x4 *>(src)[q];
+    }
+    if (tid < 32) {
+      const uint32_t c = tile * 32 + tid;
+      bstage = a.bias[c];
+      gstage = c < K ? a.groups[c] : 0xFFFFFFFFu;
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NST; i++) {
+      const int q = tid + i * 256;
+      if (q < 8 * DP) {
+        const int row = q / (DP / 4), c4 = q % (DP / 4);
+        *reinterpret_cast<f32x4 *>(tile_ptr(buf) + row * LDW + c4 * 4) = stage[i];
+      }
+    }
+    if (tid < 32) {
+      bias_ptr(buf)[tid] = bstage;
+      grp_ptr(buf)[tid] = gstage;
+    }
+  };
+
+  const uint32_t ntiles = a.K_pad / 32;
+  const bool wave_live = __ballot(live) != 0ull;
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  const float *xrow = a.samples + (size_t)s * D;
+  for (uint32_t t = 0; t < ntiles; t++) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) stage_load(t + 1);
+    if (wave_live) {
+      KMX_YY_MFMA_TILE(acc, buf)
+      // (b)/(c) candidates by the filter, (a) group-skipped centroids by their bound
+      uint32_t m16 = 0, a16 = 0;
+      if (live) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const uint32_t row = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const uint32_t c = t * 32 + row;
+          const uint32_t g = grp_ptr(buf)[row];
+          const bool valid = g < G && c != cluster;  // g >= G: NaN centroid or padding
+          if (valid && acc[r] >= amin) m16 |= 1u << r;
+          if (valid) {
+            const float lb = a.bounds[(size_t)len * (1 + g) + s];
+            if (lb >= upper_bound) a16 |= 1u << r;
+          }
+        }
+      }
+      if (__ballot((m16 | a16) != 0u) != 0ull) {
+        const uint32_t pm = __shfl_xor(m16, 32), pa = __shfl_xor(a16, 32);
+        const uint32_t m0 = h ? pm : m16, m1 = h ? m16 : pm, a0 = h ? pa : a16, a1 = h ? a16 : pa;
+        uint32_t rowmask = 0, amask = 0;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+          rowmask |= (((m0 >> (4 * g4)) & 0xFu) << (8 * g4)) | (((m1 >> (4 * g4)) & 0xFu) << (8 * g4 + 4));
+          amask |= (((a0 >> (4 * g4)) & 0xFu) << (8 * g4)) | (((a1 >> (4 * g4)) & 0xFu) << (8 * g4 + 4));
+        }
+        rowmask = (rowmask & ~amask) | amask;  // (a) wins: the reference tests it first
+        while (__ballot(rowmask != 0u) != 0ull) {
+          const bool active = rowmask != 0u;
+          const uint32_t rho = active ? (uint32_t)__ffs((int)rowmask) - 1u : 0u;
+          rowmask &= rowmask - 1u;
+          const uint32_t c = t * 32 + rho;
+          const uint32_t g = active ? grp_ptr(buf)[rho] : 0u;
+          bool need = false;
+          if (active) {
+            float lb = a.bounds[(size_t)len * (1 + g) + s];
+            if (lb >= upper_bound) {                       // kmeans.cu:631-636
+              if (lb < second_min) second_min = lb;
+            } else {
+              lb += a.gdrifts[g] - a.drifts[(size_t)K * D + c];  // :637
+              need = !(second_min < lb);                   // :638-640
+            }
+          }
+          if (__ballot(need) != 0ull) {
+            const float dist = exact_distance_split<NK, METRIC, FAST>(
+                xrow, a.centroids + (size_t)(need ? c : 0) * D, D, h, col);
+            if (need) {                                    // :641-652
+              if (dist < min_dist) {
+                second_min = min_dist;
+                min_dist = dist;
+                nearest = c;
+              } else if (dist < second_min) {
+                second_min = dist;
+              }
+            }
+          }
+        }
+        amin = amin_of(second_min);
+      }
+    }
+    if (t + 1 < ntiles) stage_store(buf ^ 1);
+    __syncthreads();
+  }
+  // write-back, kmeans.cu:653-671
+  bool changed = false;
+  if (live && h == 0) {
+    const uint32_t nearest_group = a.groups[nearest], previous_group = a.groups[cluster];
+    a.bounds[(size_t)len * (1 + nearest_group) + s] = second_min;
+    if (nearest_group != previous_group) {
+      const size_t gi = (size_t)len * (1 + previous_group) + s;
+      const float pb = a.bounds[gi];
+      if (pb > upper_bound) a.bounds[gi] = upper_bound;
+    }
+    a.bounds[s] = min_dist;
+    if (cluster != nearest) {
+      a.assignments[s] = nearest;
+      changed = true;
+    }
+  }
+  const unsigned long long cm = __ballot(changed);
+  if (lane == 0 && cm) atomicAdd(&a.counters[0], (uint32_t)__popcll(cm));
+}
+
+// ---------------------------------------------------------------------------------------
+// yy_init with the MFMA filter: group-sorted panel, groups padded to multiples of 4 slots
+// ---------------------------------------------------------------------------------------
+// pids[slot]  centroid id of the slot or 0xFFFFFFFF (padding)
+// pmeta[8*tile + ch]  (group << 1) | starts_new_group, for the 4-slot chunk ch of the tile
+template <int DP, int METRIC, bool FAST>
+__global__ __launch_bounds__(256, 2) void yy_init_mfma_kernel(YyArgs a) {
+  constexpr int NK = DP / 2, LDW = DP + 4, TILE = 32 * LDW, NST = (8 * DP + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  auto tile_ptr = [&](int buf) { return lds + buf * TILE; };
+  auto bias_ptr = [&](int buf) { return lds + 2 * TILE + buf * 32; };
+  auto id_ptr = [&](int buf) { return reinterpret_cast<uint32_t *>(lds + 2 * TILE + 64) + buf * 32; };
+  auto meta_ptr = [&](int buf) { return reinterpret_cast<uint32_t *>(lds + 2 * TILE + 128) + buf * 8; };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+  const uint32_t D = a.D, K = a.K, G = a.G, len = a.len;
+  const uint32_t s = blockIdx.x * 128u + wave * 32u + col;
+  const bool live = s < len;
+
+  KMX_YY_LOAD_ROWS(a.samples, s, live)
+
+  const uint32_t nearest = live ? a.assignments[s] : 0xFFFFFFFFu;
+  const float *xrow = a.samples + (size_t)(live ? s : 0) * D;
+  // upper bound: exact distance to the row's own centroid (kmeans.cu:474-476); FLT_MAX if it has
+  // none (NaN row) or its centroid is not in any group (NaN centroid)
+  float upper = 3.402823466e+38f;
+  {
+    const bool has = live && nearest < K && a.groups[nearest] < G;
+    if (__ballot(has) != 0ull) {
+      const float d = exact_distance_split<NK, METRIC, FAST>(xrow, a.centroids + (size_t)(has ? nearest : 0) * D, D, h,
+                                                             col);
+      if (has) upper = d;
+    }
+  }
+
+  // two scores closer than thr cannot be ordered by the filter
+  const float cmaxc = sqrtf(__uint_as_float(a.stats[0])) * 1.000001f;
+  const float bmaxc = __uint_as_float(a.stats[1]);
+  const float xn = sqrtf(xn2) * 1.0001f;
+  const float u = 5.9604645e-8f;
+  float thr = 2.0f * (2.0f * a.eps * (xn * cmaxc + bmaxc)) * 1.01f;
+  if (METRIC == 0) thr += 16.0f * u * (xn + cmaxc) * (xn + cmaxc);
+  else thr += 16.0f * u * sqrtf(xo2) * sqrtf(__uint_as_float(a.stats[2])) + 2e-6f;
+
+  f32x4 stage[NST];
+  float bstage = 0.f;
+  uint32_t istage = 0xFFFFFFFFu, mstage = 0;
+  auto stage_load = [&](uint32_t tile) {
+    const float *src = a.pfil + (size_t)tile * 32 * DP;
+#pragma unroll
+    for (int i = 0; i < NST; i++) {
+      const int q = tid + i * 256;
+      if (q < 8 * DP) stage[i] = reinterpret_cast<const f32x4 *>(src)[q];
+    }
+    if (tid < 32) {
+      bstage = a.pbias[tile * 32 + tid];
+      istage = a.pids[tile * 32 + tid];
+    }
+    if (tid < 8) mstage = a.pmeta[tile * 8 + tid];
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NST; i++) {
+      const int q = tid + i * 256;
+      if (q < 8 * DP) {
+        const int row = q / (DP / 4), c4 = q % (DP / 4);
+        *reinterpret_cast<f32x4 *>(tile_ptr(buf) + row * LDW + c4 * 4) = stage[i];
+      }
+    }
+    if (tid < 32) {
+      bias_ptr(buf)[tid] = bstage;
+      id_ptr(buf)[tid] = istage;
+    }
+    if (tid < 8) meta_ptr(buf)[tid] = mstage;
+  };
+
+  // running top-3 (by score = smallest distance first) of the CURRENT group in this half-wave
+  float v1 = -INFINITY, v2 = -INFINITY, v3 = -INFINITY;
+  uint32_t c1 = 0xFFFFFFFFu, c2 = 0xFFFFFFFFu;
+  uint32_t cur_group = 0xFFFFFFFFu;
+  auto insert = [&](float v, uint32_t idx) {
+    const bool g1 = v > v1, g2 = v > v2, g3 = v > v3;
+    v3 = g2 ? v2 : (g3 ? v : v3);
+    c2 = g1 ? c1 : (g2 ? idx : c2);
+    v2 = g1 ? v1 : (g2 ? v : v2);
+    c1 = g1 ? idx : c1;
+    v1 = g1 ? v : v1;
+  };
+  auto finalize_group = [&]() {  // wave-uniform call
+    if (cur_group == 0xFFFFFFFFu) return;
+    // merge the partner half-wave's top-3
+    {
+      const float pv1 = __shfl_xor(v1, 32), pv2 = __shfl_xor(v2, 32), pv3 = __shfl_xor(v3, 32);
+      const uint32_t pc1 = __shfl_xor(c1, 32), pc2 = __shfl_xor(c2, 32);
+      insert(pv1, pc1);
+      insert(pv2, pc2);
+      insert(pv3, 0xFFFFFFFFu);
+    }
+    float gmin = 3.402823466e+38f;
+    const bool has1 = live && c1 != 0xFFFFFFFFu;
+    const bool sure1 = has1 && ((v1 - v2) > thr);                      // NaN gap => not sure
+    const bool sure2 = has1 && !sure1 && c2 != 0xFFFFFFFFu && ((v1 - v3) > thr);
+    const bool scan = has1 && !sure1 && !sure2;
+    if (__ballot(has1 && !scan) != 0ull) {
+      const bool on = has1 && !scan;
+      const float d = exact_distance_split<NK, METRIC, FAST>(xrow, a.centroids + (size_t)(on ? c1 : 0) * D, D, h, col);
+      if (on && d < gmin) gmin = d;
+    }
+    if (__ballot(sure2) != 0ull) {
+      const float d = exact_distance_split<NK, METRIC, FAST>(xrow, a.centroids + (size_t)(sure2 ? c2 : 0) * D, D, h,
+                                                             col);
+      if (sure2 && d < gmin) gmin = d;
+    }
+    if (__ballot(scan) != 0ull) {  // three or more contenders: every member of the group, exactly
+      const uint32_t gb = a.gstart[cur_group], ge = a.gstart[cur_group + 1];
+      for (uint32_t i = gb; i < ge; i++) {
+        const uint32_t c = a.cperm[i];
+        const bool on = scan && c != nearest;
+        if (__ballot(on) == 0ull) continue;
+        const float d = exact_distance_split<NK, METRIC, FAST>(xrow, a.centroids + (size_t)c * D, D, h, col);
+        if (on && d < gmin) gmin = d;
+      }
+    }
+    if (live && h == 0) a.bounds[(size_t)len * (1 + cur_group) + s] = gmin;
+    v1 = v2 = v3 = -INFINITY;
+    c1 = c2 = 0xFFFFFFFFu;
+  };
+
+  const uint32_t ntiles = a.nslots / 32;
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  for (uint32_t t = 0; t < ntiles; t++) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) stage_load(t + 1);
+    KMX_YY_MFMA_TILE(acc, buf)
+#pragma unroll
+    for (int ch = 0; ch < 8; ch++) {
+      const uint32_t meta = meta_ptr(buf)[ch];
+      if (meta & 1u) {  // this chunk starts a new group: close the previous one (wave-uniform)
+        finalize_group();
+        cur_group = meta >> 1;
+      }
+      if ((ch & 1) == h) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int r = 4 * (ch >> 1) + q;
+          const uint32_t row = 8 * (ch >> 1) + q + 4 * h;
+          const uint32_t id = id_ptr(buf)[row];
+          const float v = (id != 0xFFFFFFFFu && id != nearest) ? acc[r] : -INFINITY;
+          insert(v, id);
+        }
+      }
+    }
+    if (t + 1 < ntiles) stage_store(buf ^ 1);
+    __syncthreads();
+  }
+  finalize_group();
+  if (live && h == 0) a.bounds[s] = upper;
+  (void)K;
+}
+
+// group-sorted padded panel from the centred panel of centroid_prep
+__global__ void yy_sorted_panel_kernel(const float *__restrict__ cfil, const float *__restrict__ bias, uint32_t DP,
+                                       const uint32_t *__restrict__ pids, uint32_t nslots,
+                                       float *__restrict__ pfil, float *__restrict__ pbias) {
+  const uint32_t slot = blockIdx.x;
+  const uint32_t id = pids[slot];
+  for (uint32_t f = threadIdx.x; f < DP; f += blockDim.x)
+    pfil[(size_t)slot * DP + f] = id != 0xFFFFFFFFu ? cfil[(size_t)id * DP + f] : 0.f;
+  if (threadIdx.x == 0) pbias[slot] = id != 0xFFFFFFFFu ? bias[id] : -INFINITY;
+  (void)nslots;
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------
+template <int DP, int METRIC>
+static hipError_t launch_local_t(const YyArgs &a, hipStream_t st) {
+  const size_t lds_bytes = (2 * 32 * (DP + 4) + 64 + 64) * sizeof(float);
+  const uint32_t grid = (a.len + 127) / 128;  // worst case; blocks beyond the passed count exit at once
+  if (a.D == (uint32_t)DP)
+    hipLaunchKernelGGL((yy_local_mfma_kernel<DP, METRIC, true>), dim3(grid), dim3(256), lds_bytes, st, a);
+  else
+    hipLaunchKernelGGL((yy_local_mfma_kernel<DP, METRIC, false>), dim3(grid), dim3(256), lds_bytes, st, a);
+  return hipGetLastError();
+}
+template <int DP, int METRIC>
+static hipError_t launch_init_t(const YyArgs &a, hipStream_t st) {
+  const size_t lds_bytes = (2 * 32 * (DP + 4) + 64 + 64 + 16) * sizeof(float);
+  const uint32_t grid = (a.len + 127) / 128;
+  if (a.D == (uint32_t)DP)
+    hipLaunchKernelGGL((yy_init_mfma_kernel<DP, METRIC, true>), dim3(grid), dim3(256), lds_bytes, st, a);
+  else
+    hipLaunchKernelGGL((yy_init_mfma_kernel<DP, METRIC, false>), dim3(grid), dim3(256), lds_bytes, st, a);
+  return hipGetLastError();
+}
+
+#define KMX_YY_SWITCH(fn)                                                              \
+  switch (a.DP) {                                                                      \
+    case 8: return metric == 0 ? fn<8, 0>(a, st) : fn<8, 1>(a, st);                    \
+    case 16: return metric == 0 ? fn<16, 0>(a, st) : fn<16, 1>(a, st);                 \
+    case 32: return metric == 0 ? fn<32, 0>(a, st) : fn<32, 1>(a, st);                 \
+    case 64: return metric == 0 ? fn<64, 0>(a, st) : fn<64, 1>(a, st);                 \
+    case 128: return metric == 0 ? fn<128, 0>(a, st) : fn<128, 1>(a, st);              \
+    case 256: return metric == 0 ? fn<256, 0>(a, st) : fn<256, 1>(a, st);              \
+    default: return hipErrorInvalidValue;                                              \
+  }
+
+hipError_t launch_yy_local_mfma(int metric, const YyArgs &a, hipStream_t st) {
+  if (a.len == 0) return hipSuccess;
+  KMX_YY_SWITCH(launch_local_t)
+}
+
+hipError_t launch_yy_init_mfma(int metric, const YyArgs &a, hipStream_t st) {
+  if (a.len == 0) return hipSuccess;
+  KMX_YY_SWITCH(launch_init_t)
+}
+
+hipError_t launch_yy_sorted_panel(const float *cfil, const float *bias, uint32_t DP, const uint32_t *pids,
+                                  uint32_t nslots, float *pfil, float *pbias, hipStream_t st) {
+  if (nslots == 0) return hipSuccess;
+  hipLaunchKernelGGL(yy_sorted_panel_kernel, dim3(nslots), dim3(64), 0, st, cfil, bias, DP, pids, nslots, pfil, pbias);
+  return hipGetLastError();
+}
+
+}  // namespace kmx

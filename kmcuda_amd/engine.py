@@ -85,20 +85,24 @@ class Engine:
     def transpose(self, src, rows, cols, dst):
         _lib.check(self.lib.kmamd_transpose(self.h, self._p(src), rows, cols, self._p(dst)), "kmamd_transpose")
 
-    def yy_init(self, xt, centroids, assignments, groups_n, cperm, gstart, bounds):
-        _lib.check(self.lib.kmamd_yy_init(self.h, self._p(xt), self._p(centroids), self._p(assignments), groups_n,
-                                          self._p(cperm), self._p(gstart), self._p(bounds)), "kmamd_yy_init")
+    def yy_configure(self, groups_n, groups):
+        """groups: host numpy uint32[K] (centroid -> group)."""
+        import numpy
+        g = numpy.ascontiguousarray(groups, dtype=numpy.uint32)
+        _lib.check(self.lib.kmamd_yy_configure(self.h, groups_n, ctypes.c_void_p(g.ctypes.data)), "kmamd_yy_configure")
 
-    def yy_drifts(self, centroids, groups_n, groups, drifts, gdrifts):
-        _lib.check(self.lib.kmamd_yy_drifts(self.h, self._p(centroids), groups_n, self._p(groups), self._p(drifts),
-                                            self._p(gdrifts)), "kmamd_yy_drifts")
+    def yy_init(self, samples, centroids, assignments, bounds):
+        _lib.check(self.lib.kmamd_yy_init(self.h, self._p(samples), self._p(centroids), self._p(assignments),
+                                          self._p(bounds)), "kmamd_yy_init")
 
-    def yy_filters(self, samples, xt, centroids, groups_n, groups, drifts, gdrifts, assignments, assignments_prev,
-                   bounds, passed):
-        _lib.check(self.lib.kmamd_yy_filters(self.h, self._p(samples), self._p(xt), self._p(centroids), groups_n,
-                                             self._p(groups), self._p(drifts), self._p(gdrifts), self._p(assignments),
-                                             self._p(assignments_prev), self._p(bounds), self._p(passed)),
-                   "kmamd_yy_filters")
+    def yy_drifts(self, centroids, drifts, gdrifts):
+        _lib.check(self.lib.kmamd_yy_drifts(self.h, self._p(centroids), self._p(drifts), self._p(gdrifts)),
+                   "kmamd_yy_drifts")
+
+    def yy_filters(self, samples, centroids, drifts, gdrifts, assignments, assignments_prev, bounds, passed):
+        _lib.check(self.lib.kmamd_yy_filters(self.h, self._p(samples), self._p(centroids), self._p(drifts),
+                                             self._p(gdrifts), self._p(assignments), self._p(assignments_prev),
+                                             self._p(bounds), self._p(passed)), "kmamd_yy_filters")
 
     def sync(self):
         _lib.check(self.lib.kmamd_engine_sync(self.h), "kmamd_engine_sync")

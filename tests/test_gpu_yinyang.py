@@ -18,18 +18,17 @@ def _t(a, dev):
     return torch.from_numpy(numpy.ascontiguousarray(a)).to(dev)
 
 
-def _group_index(groups, G):
-    order = numpy.argsort(groups, kind="stable").astype(numpy.uint32)
-    order = order[groups[order] < G]
-    gstart = numpy.zeros(G + 1, numpy.uint32)
-    numpy.cumsum(numpy.bincount(groups[groups < G], minlength=G), out=gstart[1:])
-    return order, gstart
-
-
+@pytest.mark.parametrize("mode", ["mfma", "exact"])
 @pytest.mark.parametrize("n,d,k,G,metric", [(3000, 2, 50, 5, "L2"), (2500, 33, 64, 6, "L2"),
-                                            (4000, 256, 128, 12, "L2"), (2000, 64, 40, 4, "cos")])
-def test_yinyang_steps_bit_exact(n, d, k, G, metric):
+                                            (4000, 256, 128, 12, "L2"), (5000, 256, 1024, 102, "L2"),
+                                            (3000, 64, 50, 7, "L2"), (2000, 64, 40, 4, "cos")])
+def test_yinyang_steps_bit_exact(n, d, k, G, metric, mode, monkeypatch):
+    """Both implementations of the Yinyang steps -- the matrix-core filtered kernels
+    (yinyang_mfma.hip) and the plain exact kernels (yinyang.hip, KMCUDA_AMD_YY_EXACT=1) -- against
+    the oracle: bounds after the refresh, drifts, then bounds / passed set / assignments / counters
+    after one global+local filter pass."""
     from kmcuda_amd.engine import Engine
+    monkeypatch.setenv("KMCUDA_AMD_YY_EXACT", "1" if mode == "exact" else "0")
     dev = torch.device("cuda", 0)
     rs = numpy.random.RandomState(n + d)
     x = rs.rand(n, d).astype(numpy.float32)
@@ -41,48 +40,50 @@ def test_yinyang_steps_bit_exact(n, d, k, G, metric):
     c1, cc1 = oracle.adjust(x, p1, a1, c0, numpy.zeros(k, numpy.uint32), metric=m)
     a2, p2, _ = oracle.lloyd_assign(x, c1, assignments=a1, metric=m)
     groups = rs.randint(0, G, k).astype(numpy.uint32)
+    groups[groups == G - 1] = 0          # leave one group EMPTY: its bound must stay FLT_MAX
     bounds = oracle.yy_init(x, c1, a2, groups, G, metric=m)
     c2, cc2 = oracle.adjust(x, p2, a2, c1, cc1, metric=m)
     drifts = oracle.yy_drifts(c1, c2, groups, G, metric=m)
     ra, rprev, rb, rpassed, rchanged = oracle.yy_filters(x, c2, groups, G, drifts, a2, bounds, metric=m)
 
     eng = Engine(n, d, k, metric, device=0)
+    eng.yy_configure(G, groups)
     xs = _t(x, dev)
-    xt = torch.empty(d * n, dtype=torch.float32, device=dev)
-    eng.transpose(xs, n, d, xt)
-    cperm, gstart = _group_index(groups, G)
     gb = torch.empty((G + 1) * n, dtype=torch.float32, device=dev)
     asg = _t(a2, dev)
-    eng.yy_init(xt, _t(c1, dev), asg, G, _t(cperm, dev), _t(gstart, dev), gb)
+    eng.yy_init(xs, _t(c1, dev), asg, gb)
     eng.sync()
     got_b = gb.cpu().numpy().reshape(G + 1, n)
     if metric == "cos":
         # acosf: libm (oracle) vs ocml (GPU) differ in the last ulp -- the reference's CUDA acosf is
         # a third implementation; angular parity is tolerance-only
         numpy.testing.assert_allclose(got_b, bounds, rtol=0, atol=1e-6)
-        eng.close()
-        return
-    assert (got_b.view(numpy.uint32) == bounds.view(numpy.uint32)).all()
+    else:
+        assert (got_b.view(numpy.uint32) == bounds.view(numpy.uint32)).all()
 
     dr = torch.empty(k * d + k, dtype=torch.float32, device=dev)
     dr[:k * d] = _t(c1, dev).ravel()
     gdr = torch.empty(G, dtype=torch.float32, device=dev)
     cen2 = _t(c2, dev)
-    eng.yy_drifts(cen2, G, _t(groups, dev), dr, gdr)
+    eng.yy_drifts(cen2, dr, gdr)
     eng.sync()
+    if metric == "cos":
+        numpy.testing.assert_allclose(dr[k * d:].cpu().numpy(), drifts[k * d:], rtol=0, atol=1e-6)
+        eng.close()
+        return
     assert (dr[k * d:].cpu().numpy().view(numpy.uint32) == drifts[k * d:].view(numpy.uint32)).all()
     assert (gdr.cpu().numpy().view(numpy.uint32) == drifts[:G].view(numpy.uint32)).all()
 
     prev = torch.empty(n, dtype=torch.int32, device=dev)
     passed = torch.empty(n, dtype=torch.int32, device=dev)
     eng.reset_counters(-1)
-    eng.yy_filters(xs, xt, cen2, G, _t(groups, dev), dr, gdr, asg, prev, gb, passed)
+    eng.yy_filters(xs, cen2, dr, gdr, asg, prev, gb, passed)
     counters = eng.counters()
     assert counters[2] == len(rpassed)
-    assert counters[0] == rchanged
     got_passed = numpy.sort(passed.cpu().numpy().view(numpy.uint32)[:counters[2]])
     assert (got_passed == rpassed).all()
     assert (asg.cpu().numpy().view(numpy.uint32) == ra).all()
+    assert counters[0] == rchanged
     assert (prev.cpu().numpy().view(numpy.uint32) == rprev).all()
     assert (gb.cpu().numpy().reshape(G + 1, n).view(numpy.uint32) == rb.view(numpy.uint32)).all()
     eng.close()
