@@ -13,7 +13,7 @@ import numpy
 
 from . import _lib
 
-supports_fp16 = False  # fp16x2 kernels are not built yet (next)
+supports_fp16 = True  # fp16x2 boundary: half buffers, fp32 arithmetic on the half values
 
 _INIT = {"kmeans++": 1, "k-means++": 1, "afkmc2": 2, "afk-mc2": 2, "random": 0}  # kmcuda.h:168-174
 _METRIC = {"euclidean": 0, "L2": 0, "l2": 0, "cos": 1, "cosine": 1, "angular": 1}  # kmcuda.h:177-184
@@ -132,18 +132,19 @@ def kmeans_cuda(samples, clusters, tolerance=.01, init="k-means++", yinyang_t=.1
     elif cen_ptr is None:
         import torch  # device-pointer mode: torch owns the output allocations on that GPU
         dev = torch.device("cuda", device_ptrs)
-        cen_t = torch.empty((clusters, d), dtype=torch.float32, device=dev)
+        cen_t = torch.empty((clusters, 2 * d if fp16x2 else d), dtype=torch.float16 if fp16x2 else torch.float32,
+                            device=dev)
         asg_t = torch.empty(n, dtype=torch.int32, device=dev)
         _DEVICE_ALLOCS[cen_t.data_ptr()] = cen_t
         _DEVICE_ALLOCS[asg_t.data_ptr()] = asg_t
         cen_ptr, asg_ptr = cen_t.data_ptr(), asg_t.data_ptr()
     if init_id == 3:
-        imp = numpy.ascontiguousarray(init, dtype=numpy.float32)
+        imp = numpy.ascontiguousarray(init, dtype=numpy.float16 if fp16x2 else numpy.float32)
         if imp.ndim != 2:
             raise ValueError("\"init\" centroids must be a 2D numpy array")
         if imp.shape[0] != clusters:
             raise ValueError("\"init\" centroids shape[0] does not match the number of clusters")
-        if imp.shape[1] != d:
+        if imp.shape[1] != (2 * d if fp16x2 else d):
             raise ValueError("\"init\" centroids shape[1] does not match the number of features")
         if device_ptrs < 0:
             centroids[...] = imp

@@ -98,19 +98,46 @@ __device__ __forceinline__ float angular_from_prod(float fp) {
   return acosf(fp);
 }
 
+// Serial chains over contiguous vectors; 16-byte loads when both rows allow it (the chain order
+// is unchanged: the four elements of a load are folded in feature order).
+template <int METRIC>
+__device__ __forceinline__ float chain_vv(const float *__restrict__ a, const float *__restrict__ b, uint32_t D) {
+  float acc = 0.f, corr = 0.f;
+  uint32_t f = 0;
+  if ((D & 3u) == 0 && ((((uintptr_t)a) | ((uintptr_t)b)) & 15u) == 0) {
+    for (; f < D; f += 4) {
+      const float4 av = *reinterpret_cast<const float4 *>(a + f), bv = *reinterpret_cast<const float4 *>(b + f);
+      const float aa[4] = {av.x, av.y, av.z, av.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (METRIC == 0) {
+          const float d = aa[q] - bb[q];
+          kahan_fold(fma_rd(d, d, corr), acc, corr);
+        } else {
+          kahan_fold(fma_rd(aa[q], bb[q], corr), acc, corr);
+        }
+      }
+    }
+  }
+  for (; f < D; f++) {
+    if (METRIC == 0) {
+      const float d = a[f] - b[f];
+      kahan_fold(fma_rd(d, d, corr), acc, corr);
+    } else {
+      kahan_fold(fma_rd(a[f], b[f], corr), acc, corr);
+    }
+  }
+  return acc;
+}
+
 template <>
 __device__ __forceinline__ float distance_vv<0>(const float *__restrict__ a, const float *__restrict__ b, uint32_t D) {
-  float acc = 0.f, corr = 0.f;
-  for (uint32_t f = 0; f < D; f++) {
-    const float d = a[f] - b[f];
-    kahan_fold(fma_rd(d, d, corr), acc, corr);
-  }
-  return sqrtf(acc);
+  return sqrtf(chain_vv<0>(a, b, D));
 }
 
 template <>
 __device__ __forceinline__ float distance_vv<1>(const float *__restrict__ a, const float *__restrict__ b, uint32_t D) {
-  return angular_from_prod(kahan_dot(a, b, D));
+  return angular_from_prod(chain_vv<1>(a, b, D));
 }
 
 // metric_abstraction.h:55-57 (L2): distance(0, csqr, prod) = RD(-2*prod + (0 + csqr));

@@ -131,6 +131,11 @@ hipError_t launch_knn_exact(int metric, const KnnArgs &a, hipStream_t st);
 hipError_t launch_knn_scatter(const uint32_t *sorted_out, const uint32_t *inv, uint32_t p_base, uint32_t p_end,
                               uint32_t k, uint32_t *neighbors, hipStream_t st);
 
+// fp16x2 boundary conversions (seeding.hip)
+hipError_t launch_half_to_float(const void *src, size_t n, float *dst, hipStream_t st);
+hipError_t launch_float_to_half(const float *src, size_t n, void *dst, hipStream_t st);
+hipError_t launch_quantize_half(float *v, size_t n, hipStream_t st);
+
 // transpose.hip (reference: transpose.cu:16-54)
 hipError_t launch_transpose(const float *in, uint32_t rows, uint32_t cols, float *out, hipStream_t st);
 

@@ -145,6 +145,7 @@ class Job {
  public:
   uint32_t N = 0, D = 0, K = 0;
   int metric = 0, verbosity = 0;
+  bool fp16 = false;  // fp16x2 boundary: half buffers outside, fp32 arithmetic on the half values inside
   std::vector<std::unique_ptr<Shard>> shards;
   Rccl rccl;
   std::vector<void *> comms;
@@ -170,7 +171,28 @@ class Job {
       int rc = sh->eng->init(sh->dev, sh->length, D, K, metric, 0, nullptr);
       if (rc) return rc;
       const float *src = samples + (size_t)sh->offset * D;
-      if (device_ptrs >= 0 && device_ptrs == sh->dev) {
+      if (fp16) {
+        // `samples` holds halves: stage the raw halves on the device, widen into the fp32 working copy
+        const uint16_t *hsrc = reinterpret_cast<const uint16_t *>(samples) + (size_t)sh->offset * D;
+        const size_t n = (size_t)sh->length * D;
+        float *buf = nullptr;
+        if ((rc = sh->alloc(&buf, n))) return rc;
+        const uint16_t *dev_half = hsrc;
+        uint16_t *tmp = nullptr;
+        if (!(device_ptrs >= 0 && device_ptrs == sh->dev)) {
+          if (hipMalloc((void **)&tmp, (n ? n : 1) * sizeof(uint16_t)) != hipSuccess) return kmcudaMemoryAllocationFailure;
+          hipError_t e = device_ptrs < 0
+                             ? hipMemcpyAsync(tmp, hsrc, n * sizeof(uint16_t), hipMemcpyHostToDevice, sh->eng->stream_)
+                             : hipMemcpyPeerAsync(tmp, sh->dev, hsrc, device_ptrs, n * sizeof(uint16_t), sh->eng->stream_);
+          if (e != hipSuccess) { (void)hipFree(tmp); return kmcudaMemoryCopyError; }
+          dev_half = tmp;
+        }
+        hipError_t e = launch_half_to_float(dev_half, n, buf, sh->eng->stream_);
+        if (e == hipSuccess) e = hipStreamSynchronize(sh->eng->stream_);
+        if (tmp) (void)hipFree(tmp);
+        if (e != hipSuccess) return kmcudaRuntimeError;
+        sh->samples = buf;
+      } else if (device_ptrs >= 0 && device_ptrs == sh->dev) {
         sh->samples = src;  // already resident, used in place and never modified
       } else {
         float *buf = nullptr;
@@ -278,7 +300,7 @@ class Job {
 
   // ---- seeding (reference: kmeans_init_centroids, kmcuda.cc:189-400) ----
   int init_centroids(KMCUDAInitMethod method, uint32_t seed, const float *host_centroids, int32_t device_ptrs) {
-    if (metric == kmcudaDistanceMetricCosine) {  // kmcuda.cc:195-220: three unit-norm probes
+    if (metric == kmcudaDistanceMetricCosine && !fp16) {  // kmcuda.cc:195-220: three unit-norm probes, fp32 only
       std::vector<float> probe(D);
       for (uint32_t s : {0u, N / 2, N - 1}) {
         RETERR(read_sample_row(s, probe.data()));
@@ -294,6 +316,22 @@ class Job {
     srand(seed);  // kmcuda.cc:222
     switch (method) {
       case kmcudaInitMethodImport: {
+        if (fp16) {  // K x D halves -> fp32 replicas
+          const size_t n = (size_t)K * D;
+          for (auto &s : shards) {
+            (void)hipSetDevice(s->dev);
+            uint16_t *tmp = nullptr;
+            if (hipMalloc((void **)&tmp, n * sizeof(uint16_t)) != hipSuccess) return kmcudaMemoryAllocationFailure;
+            hipError_t e = device_ptrs < 0
+                               ? hipMemcpy(tmp, host_centroids, n * sizeof(uint16_t), hipMemcpyHostToDevice)
+                               : hipMemcpyPeer(tmp, s->dev, host_centroids, device_ptrs, n * sizeof(uint16_t));
+            if (e == hipSuccess) e = launch_half_to_float(tmp, n, s->centroids, s->eng->stream_);
+            if (e == hipSuccess) e = hipStreamSynchronize(s->eng->stream_);
+            (void)hipFree(tmp);
+            if (e != hipSuccess) return kmcudaMemoryCopyError;
+          }
+          return 0;
+        }
         if (device_ptrs < 0) return broadcast_centroids_from_host(host_centroids);
         for (auto &s : shards) {
           hipError_t e = hipMemcpyPeerAsync(s->centroids, s->dev, host_centroids, device_ptrs,
@@ -435,11 +473,22 @@ class Job {
   int adjust() {  // reference: kmeans_adjust launch + peer exchange, kmeans.cu:1002-1024
     if (exact_update) {
       Shard &s = *shards[0];
-      return s.eng->adjust_exact(s.samples, s.prev, s.assignments, s.centroids, s.ccounts);
+      RETERR(s.eng->adjust_exact(s.samples, s.prev, s.assignments, s.centroids, s.ccounts));
+      return quantize_centroids();
     }
     for (auto &s : shards) RETERR(s->eng->move_deltas(s->samples, s->prev, s->assignments, s->delta, s->dcount));
     RETERR(allreduce_deltas());
     for (auto &s : shards) RETERR(s->eng->apply_delta(s->delta, s->dcount, s->centroids, s->ccounts));
+    return quantize_centroids();
+  }
+
+  // fp16x2: the reference keeps centroids in half2, i.e. every update is rounded to half
+  int quantize_centroids() {
+    if (!fp16) return 0;
+    for (auto &s : shards) {
+      (void)hipSetDevice(s->dev);
+      if (launch_quantize_half(s->centroids, (size_t)K * D, s->eng->stream_) != hipSuccess) return kmcudaRuntimeError;
+    }
     return 0;
   }
 
@@ -488,8 +537,9 @@ class Job {
     RETERR(first.eng->sync());
     Job gjob;
     std::vector<int> one{first.dev};
-    RETERR(gjob.setup(one, 0, K, D, G, metric, verbosity, first.centroids, first.dev));
+    RETERR(gjob.setup(one, 0, K, D, G, metric, verbosity, first.centroids, first.dev));  // fp32 replica in place
     gjob.exact_update = exact_update;
+    gjob.fp16 = fp16;  // centroids_yy is half2 in the reference too (kmeans.cu:1084-1091)
     RETERR(gjob.init_centroids(kmcudaInitMethodPlusPlus, 0, nullptr, first.dev));
     RETERR(gjob.lloyd((float)kYinyangGroupTolerance, false, nullptr));
     RETERR(gjob.sync_all());
@@ -554,8 +604,20 @@ class Job {
     RETERR(sync_all());
     Shard &first = *shards[0];
     (void)hipSetDevice(first.dev);
+    const void *cen_src = first.centroids;
+    size_t cen_bytes = (size_t)K * D * sizeof(float);
+    if (fp16) {  // K x D halves out
+      uint16_t *hbuf = nullptr;
+      int rc = first.alloc(&hbuf, (size_t)K * D);
+      if (rc) return rc;
+      if (launch_float_to_half(first.centroids, (size_t)K * D, hbuf, first.eng->stream_) != hipSuccess ||
+          hipStreamSynchronize(first.eng->stream_) != hipSuccess)
+        return kmcudaRuntimeError;
+      cen_src = hbuf;
+      cen_bytes = (size_t)K * D * sizeof(uint16_t);
+    }
     if (device_ptrs < 0) {
-      if (hipMemcpy(centroids, first.centroids, (size_t)K * D * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+      if (hipMemcpy(centroids, cen_src, cen_bytes, hipMemcpyDeviceToHost) != hipSuccess)
         return kmcudaMemoryCopyError;
       for (auto &s : shards) {
         (void)hipSetDevice(s->dev);
@@ -564,7 +626,7 @@ class Job {
           return kmcudaMemoryCopyError;
       }
     } else {
-      if (hipMemcpyPeer(centroids, device_ptrs, first.centroids, first.dev, (size_t)K * D * sizeof(float)) != hipSuccess)
+      if (hipMemcpyPeer(centroids, device_ptrs, cen_src, first.dev, cen_bytes) != hipSuccess)
         return kmcudaMemoryCopyError;
       for (auto &s : shards)
         if (hipMemcpyPeer(assignments + s->offset, device_ptrs, s->assignments, s->dev,
@@ -645,12 +707,31 @@ struct KnnShard {
   }
 };
 
+// brings `count` halves of a caller buffer onto the shard's device and widens them to fp32
+static int stage_in_half(KnnShard &sh, const void *src, size_t count, int32_t device_ptrs, const float **dst) {
+  float *buf = nullptr;
+  int rc = sh.alloc(&buf, count);
+  if (rc) return rc;
+  const uint16_t *dev_half = reinterpret_cast<const uint16_t *>(src);
+  uint16_t *tmp = nullptr;
+  if (!(device_ptrs >= 0 && device_ptrs == sh.dev)) {
+    if ((rc = sh.alloc(&tmp, count))) return rc;
+    hipError_t e = device_ptrs < 0 ? hipMemcpyAsync(tmp, src, count * sizeof(uint16_t), hipMemcpyHostToDevice, sh.stream)
+                                   : hipMemcpyPeerAsync(tmp, sh.dev, src, device_ptrs, count * sizeof(uint16_t), sh.stream);
+    if (e != hipSuccess) return kmcudaMemoryCopyError;
+    dev_half = tmp;
+  }
+  if (launch_half_to_float(dev_half, count, buf, sh.stream) != hipSuccess) return kmcudaRuntimeError;
+  *dst = buf;
+  return 0;
+}
+
 class KnnJob {
  public:
   std::vector<std::unique_ptr<KnnShard>> shards;
 
   int run(const std::vector<int> &devs, int nvirtual, uint32_t k, int metric, uint32_t N, uint32_t D, uint32_t K,
-          int32_t device_ptrs, int verbosity, const float *samples, const float *centroids,
+          int32_t device_ptrs, int verbosity, bool fp16, const float *samples, const float *centroids,
           const uint32_t *assignments, uint32_t *neighbors) {
     std::vector<int> shard_devs = devs;
     if (nvirtual > 1 && devs.size() == 1) shard_devs.assign(nvirtual, devs[0]);  // test hook
@@ -664,8 +745,13 @@ class KnnJob {
       sh->dev = dev;
       if (hipSetDevice(dev) != hipSuccess) return kmcudaNoSuchDevice;
       if (hipStreamCreateWithFlags(&sh->stream, hipStreamNonBlocking) != hipSuccess) return kmcudaRuntimeError;
-      RETERR(sh->stage_in(samples, (size_t)N * D, device_ptrs, &sh->samples));
-      RETERR(sh->stage_in(centroids, (size_t)K * D, device_ptrs, &sh->centroids));
+      if (fp16) {  // half buffers -> fp32 working copies (fp32 arithmetic on the half values)
+        RETERR(stage_in_half(*sh, samples, (size_t)N * D, device_ptrs, &sh->samples));
+        RETERR(stage_in_half(*sh, centroids, (size_t)K * D, device_ptrs, &sh->centroids));
+      } else {
+        RETERR(sh->stage_in(samples, (size_t)N * D, device_ptrs, &sh->samples));
+        RETERR(sh->stage_in(centroids, (size_t)K * D, device_ptrs, &sh->centroids));
+      }
       RETERR(sh->stage_in(assignments, (size_t)N, device_ptrs, &sh->assignments));
       int rc;
       if ((rc = sh->alloc(&sh->xs, (size_t)N * DP))) return rc;
@@ -851,10 +937,6 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
   if (samples == nullptr || centroids == nullptr || assignments == nullptr) return kmcudaInvalidArguments;
   if (tolerance < 0 || tolerance > 1) return kmcudaInvalidArguments;
   if (yinyang_t < 0 || yinyang_t > 0.5) return kmcudaInvalidArguments;
-  if (fp16x2) {
-    INFO("fp16x2 kernels are not built in this round (DESIGN.md: next)\n");
-    return kmcudaInvalidArguments;
-  }
   INFO("reassignments threshold: %u\n", uint32_t(tolerance * samples_size));
   const uint32_t yy_groups_size = yinyang_t * clusters_size;  // float product, truncated (kmcuda.cc:417)
   DEBUG("yinyang groups: %u\n", yy_groups_size);
@@ -862,7 +944,10 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
   if (devs.empty()) return kmcudaNoSuchDevice;
 
   Job job;
-  RETERR(job.setup(devs, virtual_shards(), samples_size, features_size, clusters_size, metric, verbosity, samples,
+  job.fp16 = fp16x2 != 0;
+  // fp16x2: features_size counts half2 pairs (kmcuda.h:107-108); internally one feature per half
+  const uint32_t feats = fp16x2 ? 2u * features_size : features_size;
+  RETERR(job.setup(devs, virtual_shards(), samples_size, feats, clusters_size, metric, verbosity, samples,
                    device_ptrs));
   if (const char *v = getenv("KMCUDA_AMD_EXACT_UPDATE")) job.exact_update = atoi(v) != 0;
   if (job.exact_update && job.shards.size() > 1) {
@@ -905,15 +990,12 @@ KMCUDAResult knn_cuda(uint16_t k, KMCUDADistanceMetric metric, uint32_t samples_
   (void)hipGetDeviceCount(&ndev);
   if (ndev < 32 && device > (1u << ndev)) return kmcudaNoSuchDevice;
   if (!samples || !centroids || !assignments || !neighbors) return kmcudaInvalidArguments;
-  if (fp16x2) {
-    INFO("fp16x2 kernels are not built in this round (DESIGN.md: next)\n");
-    return kmcudaInvalidArguments;
-  }
   auto devs = setup_devices(device, verbosity);
   if (devs.empty()) return kmcudaNoSuchDevice;
   KnnJob job;
-  RETERR(job.run(devs, virtual_shards(), k, metric, samples_size, features_size, clusters_size, device_ptrs, verbosity,
-                 samples, centroids, assignments, neighbors));
+  const uint32_t feats = fp16x2 ? 2u * features_size : features_size;  // kmcuda.h:107-108
+  RETERR(job.run(devs, virtual_shards(), k, metric, samples_size, feats, clusters_size, device_ptrs, verbosity,
+                 fp16x2 != 0, samples, centroids, assignments, neighbors));
   DEBUG("return kmcudaSuccess\n");
   return kmcudaSuccess;
 }

@@ -62,22 +62,32 @@ __global__ void centroid_rows_kernel(const float *__restrict__ centroids, uint32
 // mean of the finite centroid rows, one thread per (padded) feature.  Any vector would do: the
 // argmin is translation invariant, the mean just makes the centred norms (and so the filter's
 // error bound) small.
-__global__ void centroid_mean_kernel(const float *__restrict__ centroids, uint32_t K, uint32_t D, uint32_t DP,
-                                     const uint32_t *__restrict__ finite, float *__restrict__ mu) {
-  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= DP) return;
+__global__ __launch_bounds__(256) void centroid_mean_kernel(const float *__restrict__ centroids, uint32_t K,
+                                                            uint32_t D, uint32_t DP,
+                                                            const uint32_t *__restrict__ finite,
+                                                            float *__restrict__ mu) {
+  // block = 64 features x 4 row-slices: coalesced row reads, fixed summation order
+  __shared__ float part[4][64];
+  __shared__ uint32_t cnt[4];
+  const uint32_t fl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const uint32_t f = blockIdx.x * 64 + fl;
   float sum = 0.f;
   uint32_t n = 0;
-  if (f < D) {
-    for (uint32_t c = 0; c < K; c++) {
-      if (finite[c]) {
-        sum += centroids[(size_t)c * D + f];
-        n++;
-      }
+  for (uint32_t c = sl; c < K; c += 4) {
+    if (finite[c]) {
+      if (f < D) sum += centroids[(size_t)c * D + f];
+      n++;
     }
   }
-  const float m = n ? sum / (float)n : 0.f;
-  mu[f] = ((m - m) == 0.f) ? m : 0.f;
+  part[sl][fl] = sum;
+  if (fl == 0) cnt[sl] = n;
+  __syncthreads();
+  if (sl == 0 && f < DP) {
+    const float tot = (part[0][fl] + part[1][fl]) + (part[2][fl] + part[3][fl]);
+    const uint32_t nt = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    const float m = (nt && f < D) ? tot / (float)nt : 0.f;
+    mu[f] = ((m - m) == 0.f) ? m : 0.f;
+  }
 }
 
 // panel: one thread per padded centroid row: cfil = c - mu (zero row + bias -inf if not finite),
@@ -500,7 +510,7 @@ hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, 
   else
     hipLaunchKernelGGL((centroid_rows_kernel<1>), dim3((Kt + 63) / 64), block, 0, st, centroids, K, D, Kt, csqr, ct,
                        finite, stats);
-  hipLaunchKernelGGL(centroid_mean_kernel, dim3((DP + 63) / 64), block, 0, st, centroids, K, D, DP, finite, mu);
+  hipLaunchKernelGGL(centroid_mean_kernel, dim3((DP + 63) / 64), dim3(256), 0, st, centroids, K, D, DP, finite, mu);
   if (metric == 0)
     hipLaunchKernelGGL((centroid_panel_kernel<0>), dim3((K_pad + 63) / 64), block, 0, st, centroids, K, D, K_pad, DP,
                        finite, mu, bias, cfil, stats);

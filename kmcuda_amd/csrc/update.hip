@@ -170,7 +170,13 @@ __global__ void apply_delta_kernel(const double *__restrict__ delta, const int32
   const uint32_t cnt_old = ccounts[c];
   const uint32_t cnt_new = cnt_old + (uint32_t)dcount[c];
   const double w = (double)cnt_old;
-  if (METRIC == 0) {
+  if (cnt_new == 0) {
+    // empty cluster => NaN centroid row, never chosen again (kmeans.cu:425-426, README "NaN
+    // centroid").  The reference gets there through 0 * (1/0); its fp32 residual c*count - sum is
+    // usually exactly 0, ours (fp64) usually is not and would give +-inf, which poisons the
+    // k-means++ of the Yinyang group clustering -- so the contract value is written directly.
+    for (uint32_t f = threadIdx.x; f < D; f += blockDim.x) cen[f] = __builtin_nanf("");
+  } else if (METRIC == 0) {
     const double cn = (double)cnt_new;  // 0 -> 0/0 = NaN or x/0 = inf: never chosen again
     for (uint32_t f = threadIdx.x; f < D; f += blockDim.x) cen[f] = (float)(((double)cen[f] * w + d[f]) / cn);
   } else {

@@ -604,6 +604,41 @@ static int check_changed(float tolerance, uint32_t N, uint32_t *changed, iterlog
   return 0;
 }
 
+/* fp16x2 storage mode (fp_abstraction.h:100-182 keeps centroids in half2): this repository's fp16
+ * semantics are "the fp32 arithmetic on the half values, centroids rounded to half (RN) after every
+ * update"  -- NOT the reference's half2 accumulation, which is tolerance-only. */
+static int g_fp16_storage = 0;
+void kmo_set_fp16_storage(int on) { g_fp16_storage = on; }
+
+/* round-to-nearest-even float -> IEEE half -> float */
+float kmo_quantize_half(float x) {
+  union { float f; uint32_t u; } v = { x };
+  const uint32_t sign = v.u & 0x80000000u;
+  uint32_t a = v.u & 0x7FFFFFFFu;
+  if (a >= 0x7F800000u) return x;                          /* inf / NaN */
+  if (a >= 0x477FF000u) {                                   /* >= 65520: rounds to inf */
+    v.u = sign | 0x7F800000u; return v.f;
+  }
+  if (a < 0x33000001u) { v.u = sign; return v.f; }          /* < 2^-25 (or == 2^-25: ties to even 0) */
+  int e = (int)(a >> 23) - 127;
+  int drop = e >= -14 ? 13 : (13 + (-14 - e));              /* mantissa bits to drop (subnormal halves) */
+  uint32_t m = (a & 0x007FFFFFu) | 0x00800000u;             /* 24-bit significand */
+  if (drop >= 25) { v.u = sign; return v.f; }
+  const uint32_t half_ulp = 1u << (drop - 1), mask = (1u << drop) - 1u;
+  uint32_t r = m & mask;
+  m >>= drop;
+  if (r > half_ulp || (r == half_ulp && (m & 1u))) m++;
+  /* rebuild: value = m * 2^(e - 23 + drop) */
+  double val = (double)m * ldexp(1.0, e - 23 + drop);
+  float out = (float)val;                                    /* exact: m has <= 12 significant bits */
+  v.f = out; v.u |= sign; return v.f;
+}
+
+static void quantize_centroids(float *c, size_t n) {
+  if (!g_fp16_storage) return;
+  for (size_t i = 0; i < n; i++) c[i] = kmo_quantize_half(c[i]);
+}
+
 /* kmeans.cu:934-1026 */
 static int lloyd_loop(float tolerance, int metric, uint32_t N, uint32_t D, uint32_t K, int resume,
                       const float *samples, float *centroids, uint32_t *ccounts, uint32_t *prev,
@@ -620,6 +655,7 @@ static int lloyd_loop(float tolerance, int metric, uint32_t N, uint32_t D, uint3
       if (check_changed(tolerance, N, changed, L, 1)) return iter;
     }
     kmo_adjust(metric, N, D, K, samples, prev, asg, centroids, ccounts);
+    quantize_centroids(centroids, (size_t)K * D);
   }
 }
 
@@ -674,6 +710,7 @@ int kmo_kmeans(int init, float tolerance, float yinyang_t, int metric, uint32_t 
         }
         memcpy(drifts, centroids, sizeof(float) * (size_t)K * D);
         kmo_adjust(metric, N, D, K, samples, prev, assignments, centroids, ccounts);
+        quantize_centroids(centroids, (size_t)K * D);
         kmo_yy_calc_drifts(metric, D, K, centroids, drifts);
         kmo_yy_group_max_drifts(D, K, G, groups, drifts);
         npassed = kmo_yy_global_filter(metric, N, D, K, G, samples, centroids, groups, drifts,

@@ -84,6 +84,11 @@ int kmo_kmeans(int init, float tolerance, float yinyang_t, int metric, uint32_t 
                uint32_t *assignments, float *average_distance,
                uint32_t *iter_log, uint32_t iter_log_cap, uint32_t *n_iter_log);
 
+/* fp16x2 storage mode of THIS repository (fp32 arithmetic on half values, centroids rounded to half
+ * after every update); affects kmo_kmeans only.  kmo_quantize_half: float -> half (RN) -> float. */
+void kmo_set_fp16_storage(int on);
+float kmo_quantize_half(float x);
+
 /* knn.cu:19-58 / :61-131 / :133-243 and kmcuda.cc:648-691 (inverse assignments) */
 void kmo_knn_inverse(uint32_t N, uint32_t K, const uint32_t *assignments, uint32_t *inv, uint32_t *offsets);
 void kmo_knn_radiuses(int metric, uint32_t N, uint32_t D, uint32_t K, const float *samples,

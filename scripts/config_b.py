@@ -19,6 +19,9 @@ def main():
     ap.add_argument("--tolerance", type=float, default=0.01)
     ap.add_argument("--init", default="random")
     ap.add_argument("--verbosity", type=int, default=1)
+    ap.add_argument("--data", default="uniform", choices=["uniform", "gaussian"],
+                    help="uniform [0,1) rows (README.md:206-207) or a mixture of `clusters` unit Gaussians "
+                         "with centres uniform in [0,10)^D (SURVEY 8d: pruning is meaningful)")
     args = ap.parse_args()
     import torch
     from kmcuda_amd import kmeans_cuda
@@ -27,8 +30,15 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234)
     x = torch.empty((args.samples, args.features), dtype=torch.float32, device=dev)
+    centres = torch.rand((args.clusters, args.features), device=dev, generator=gen) * 10.0
     for s in range(0, args.samples, 1 << 20):
-        x[s:s + (1 << 20)].uniform_(0.0, 1.0, generator=gen)
+        e = min(args.samples, s + (1 << 20))
+        if args.data == "uniform":
+            x[s:e].uniform_(0.0, 1.0, generator=gen)
+        else:
+            lab = torch.randint(0, args.clusters, (e - s,), device=dev, generator=gen)
+            x[s:e].normal_(0.0, 1.0, generator=gen)
+            x[s:e] += centres[lab]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     cptr, aptr = kmeans_cuda((x.data_ptr(), 0, (args.samples, args.features)), args.clusters, init=args.init,

@@ -1,0 +1,155 @@
+"""fp16x2 boundary (reference: fp_abstraction.h:100-182, tests src/test.py:468-560, :643-651).
+
+Semantics of this implementation: half buffers at the boundary, the fp32 reference
+arithmetic applied to the half VALUES, centroids rounded to half (RN) after every update -- where
+the reference accumulates in half2.  Hence two bars:
+  * vs the oracle in its fp16-storage mode (same semantics): assignments identical, centroids
+    identical halves (strict update) / within one half ulp (default fp64 update);
+  * vs the reference's own fp16 pins: tolerance -- iteration counts within the spread fp16
+    accumulation noise allows, sklearn agreement thresholds as in test.py."""
+import numpy
+import pytest
+
+import oracle
+from test_gpu_kmeans import StdoutListener, _validate
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def test_supports_fp16():
+    from kmcuda_amd import supports_fp16
+    assert supports_fp16
+
+
+def test_fp16_random_lloyd(fixture13k):
+    # test.py:470-485 (reference pin: 7 iterations, same as fp32)
+    from kmcuda_amd import kmeans_cuda
+    samples = fixture13k.astype(numpy.float16)
+    out = StdoutListener()
+    with out:
+        centroids, assignments = kmeans_cuda(samples, 50, init="random", device=1, verbosity=2, seed=3,
+                                             tolerance=0.05, yinyang_t=0)
+    assert centroids.dtype == numpy.float16
+    assert centroids.shape == (50, 2) and assignments.shape == (13000,)
+    assert abs(out.iterations() - 7) <= 1
+    _validate(fixture13k, centroids.astype(numpy.float32), assignments, 0.05)
+
+
+def test_fp16_kmeanspp_lloyd(fixture13k):
+    # test.py:487-497 (reference pin: 5)
+    from kmcuda_amd import kmeans_cuda
+    samples = fixture13k.astype(numpy.float16)
+    out = StdoutListener()
+    with out:
+        centroids, assignments = kmeans_cuda(samples, 50, init="kmeans++", device=1, verbosity=2, seed=3,
+                                             tolerance=0.05, yinyang_t=0)
+    assert abs(out.iterations() - 5) <= 1
+    _validate(fixture13k, centroids.astype(numpy.float32), assignments, 0.05)
+
+
+def test_fp16_kmeanspp_validate(fixture13k):
+    # test.py:511-521: same seeds as the fp32 run up to half quantisation
+    from kmcuda_amd import kmeans_cuda
+    c32, _ = kmeans_cuda(fixture13k, 50, init="kmeans++", device=1, seed=3, tolerance=1.0, yinyang_t=0)
+    c16, _ = kmeans_cuda(fixture13k.astype(numpy.float16), 50, init="kmeans++", device=1, seed=3, tolerance=1.0,
+                         yinyang_t=0)
+    # half spacing at |x| < 4 is 2^-9 .. 2^-8: the same seed rows differ by at most half an ulp
+    assert numpy.max(abs(c16[:4].astype(numpy.float32) - c32[:4])) < 2e-3
+
+
+def test_fp16_kmeanspp_yinyang(fixture13k):
+    # test.py:523-533 (reference pin 16 + 7 with half2 accumulation noise; "fp16 precision increases
+    # the number of iterations") -- fp32 accumulation of the half values sits between the fp32 pin
+    # (15 + 3) and that
+    from kmcuda_amd import kmeans_cuda
+    samples = fixture13k.astype(numpy.float16)
+    out = StdoutListener()
+    with out:
+        centroids, assignments = kmeans_cuda(samples, 50, init="kmeans++", device=1, verbosity=2, seed=3,
+                                             tolerance=0.01, yinyang_t=0.1)
+    assert 15 + 3 - 3 <= out.iterations() <= 16 + 7 + 3
+    _validate(fixture13k, centroids.astype(numpy.float32), assignments, 0.0105)
+
+
+def test_fp16_cosine_metric():
+    # test.py:535-560
+    from kmcuda_amd import kmeans_cuda
+    from sklearn.metrics.pairwise import cosine_distances
+    numpy.random.seed(0)
+    arr = numpy.empty((10000, 2), dtype=numpy.float16)
+    angs = numpy.random.rand(10000) * 2 * numpy.pi
+    for i in range(10000):
+        arr[i] = numpy.sin(angs[i]), numpy.cos(angs[i])
+    out = StdoutListener()
+    with out:
+        centroids, assignments = kmeans_cuda(arr, 4, init="kmeans++", metric="cos", device=1, verbosity=2, seed=3)
+    assert abs(out.iterations() - 5) <= 1
+    assert len(centroids) == 4
+    for c in centroids:
+        assert 0.9995 < numpy.linalg.norm(c.astype(numpy.float32)) < 1.0005
+    dists = numpy.round(cosine_distances(centroids.astype(numpy.float32))).astype(int)
+    assert sorted(map(tuple, dists)) == sorted(map(tuple, [[0, 2, 1, 1], [2, 0, 1, 1], [1, 1, 0, 2], [1, 1, 2, 0]]))
+    assert assignments.min() == 0 and assignments.max() == 3
+
+
+@pytest.mark.parametrize("kw", [dict(init="random", seed=3, tolerance=0.05, yinyang_t=0),
+                                dict(init="kmeans++", seed=3, tolerance=0.01, yinyang_t=0.1)])
+def test_fp16_bit_identical_to_oracle_fp16_storage(fixture13k, monkeypatch, kw):
+    """Strict update + fp16 storage: centroids (as halves), assignments and the per-iteration
+    reassignment counts equal the oracle's fp16-storage run exactly."""
+    from kmcuda_amd import kmeans_cuda
+    monkeypatch.setenv("KMCUDA_AMD_EXACT_UPDATE", "1")
+    samples = fixture13k.astype(numpy.float16)
+    out = StdoutListener()
+    with out:
+        cen, asg = kmeans_cuda(samples, 50, device=1, verbosity=1, **kw)
+    reass = [int(l.split(":")[1].split()[0]) for l in out.text.split("\n") if l.startswith("iteration")]
+    ocen, oasg, olog = oracle.kmeans(samples, 50, **kw)
+    assert reass == list(olog)
+    assert (asg == oasg).all()
+    assert (cen.view(numpy.uint16) == ocen.view(numpy.uint16)).all()
+
+
+def test_fp16_256d_default_update_close_to_oracle():
+    from kmcuda_amd import kmeans_cuda
+    rs = numpy.random.RandomState(0)
+    x = rs.rand(20000, 256).astype(numpy.float16)
+    cen, asg = kmeans_cuda(x, 64, init="random", seed=777, tolerance=0.02, yinyang_t=0, device=1)
+    assert cen.dtype == numpy.float16 and cen.shape == (64, 256)
+    nxt, _, _ = oracle.lloyd_assign(x.astype(numpy.float32), cen.astype(numpy.float32))
+    assert (nxt != asg).mean() < 0.02
+
+
+def test_fp16_import_and_device_ptrs(fixture13k):
+    from kmcuda_amd import kmeans_cuda
+    from kmcuda_amd.api import _DEVICE_ALLOCS, free_device_ptr
+    samples = fixture13k.astype(numpy.float16)
+    c0, _ = kmeans_cuda(samples, 50, init="random", device=1, seed=3, tolerance=0.25, yinyang_t=0)
+    c1, a1 = kmeans_cuda(samples, 50, init=c0, device=1, seed=3, tolerance=0.05, yinyang_t=0)
+    dev = torch.device("cuda", 0)
+    st = torch.from_numpy(samples).to(dev)
+    cptr, aptr = kmeans_cuda((st.data_ptr(), 0, (13000, 1, True)), 50, init="random", device=1, seed=3,
+                             tolerance=0.05, yinyang_t=0)
+    cd = _DEVICE_ALLOCS[cptr].cpu().numpy()
+    ad = _DEVICE_ALLOCS[aptr].cpu().numpy().view(numpy.uint32)
+    ch, ah = kmeans_cuda(samples, 50, init="random", device=1, seed=3, tolerance=0.05, yinyang_t=0)
+    assert cd.dtype == numpy.float16 and (cd.view(numpy.uint16) == ch.view(numpy.uint16)).all()
+    assert (ad == ah).all()
+    free_device_ptr(cptr)
+    free_device_ptr(aptr)
+    _validate(fixture13k, c1.astype(numpy.float32), a1, 0.05)
+
+
+def test_fp16_knn(fixture13k):
+    # test.py:643-651: < 500 mismatches vs sklearn on the half values; identical to the oracle's
+    # fp32 search on the same (widened) values
+    from sklearn.neighbors import NearestNeighbors
+    from kmcuda_amd import kmeans_cuda, knn_cuda
+    samples = fixture13k.astype(numpy.float16)
+    cen, asg = kmeans_cuda(samples, 50, seed=777, device=1)
+    nb = knn_cuda(10, samples, cen, asg, device=1)
+    bn = NearestNeighbors(n_neighbors=10).fit(samples.astype(numpy.float32)).kneighbors()[1]
+    assert (nb != bn).sum() < 500
+    ref, _ = oracle.knn(10, samples.astype(numpy.float32), cen.astype(numpy.float32), asg)
+    assert (nb == ref).all()

@@ -153,3 +153,19 @@ def test_knn_large_property():
             if r == i or r in set(sn):
                 continue
             assert d[-1] <= numpy.linalg.norm(samples[i] - samples[r])
+
+
+def test_half_quantisation_matches_numpy():
+    rs = numpy.random.RandomState(0)
+    v = numpy.concatenate([rs.randn(20000).astype(numpy.float32) * s for s in (1, 1e-3, 1e-6, 1e-8, 100, 3e4)] +
+                          [numpy.array([0, -0.0, 65504, 65519.9, 6e-8, 5.96e-8, 2.98e-8, 2.9802322e-8, 3e-8, 1e-10],
+                                       numpy.float32)])
+    ref = v.astype(numpy.float16).astype(numpy.float32)
+    got = numpy.array([oracle.lib().kmo_quantize_half(float(x)) for x in v], numpy.float32)
+    assert (got.view(numpy.uint32) == ref.view(numpy.uint32)).all()
+
+
+def test_fp16_storage_mode_quantises_centroids(fixture13k):
+    c, a, log = oracle.kmeans(fixture13k.astype(numpy.float16), 50, init="random", seed=3, tolerance=0.05, yinyang_t=0)
+    assert c.dtype == numpy.float16 and len(log) in (6, 7, 8)
+    _validate(fixture13k, c.astype(numpy.float32), a, 0.05)
