@@ -21,13 +21,27 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
+def pmc_traffic(rows_per_launch):
+    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
+    (profiles/*pmc_lloyd_filter.json: FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md, plus WRITE_SIZE), scaled by rows when the shard size differs.  PMC
+    counters cannot be collected from inside the bench process; None if no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_lloyd_filter.json")))
+    if not files:
+        return None
+    with open(files[-1]) as fin:
+        pmc = json.load(fin)
+    return pmc["traffic_bytes_per_launch"] * (rows_per_launch / float(pmc["rows_per_launch"]))
+
+
 def cpu_baseline(features, clusters, budget_s=12.0):
     """The oracle (plain-C port of the reference's Lloyd assignment) on this box's host cores,
     on a bounded sample of the same workload."""
     import numpy
     import oracle
     rs = numpy.random.RandomState(0)
-    cores = os.cpu_count() or 1
+    cores = int(oracle.lib().kmo_num_threads())   # OpenMP threads the port actually runs on
     cen = rs.rand(clusters, features).astype(numpy.float32)
     probe = rs.rand(2048, features).astype(numpy.float32)
     t0 = time.time()
@@ -136,7 +150,9 @@ def main():
                        "samples": N, "features": D, "clusters": K, "parallelism": "rows/%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": None, "kernel": "lloyd_filter_kernel<256,true>",
+                         "traffic": pmc_traffic(n_local), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+                         "algorithmic_bytes": n_local * (D * 4 + 4), "algorithmic_flop": flops,
+                         "kernel": "lloyd_filter_kernel<256,true>",
                          "kernel_ms": filter_ms, "rows_per_launch": n_local},
             "breakdown_ms_per_step": {"filter": filter_ms, "exact_refine": prof["exact_ms"] / launches,
                                       "update": prof["update_ms"] / launches},

@@ -265,13 +265,41 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_kernel(
       }
     }
     const float *arow = tile_ptr(buf) + col * LDW + h * NK;
+    // A fragments are read two 16-byte pieces (8 MFMAs = 512 cycles) AHEAD of their use and the
+    // order is pinned with sched_barrier, so the LDS latency never lands on the dependent MFMA chain
+    // (left alone, hipcc sinks each ds_read_b128 pair right in front of its first MFMA)
+    constexpr int NG = NK / 8 > 0 ? NK / 8 : 1;   // groups of 8 k-steps
+    if constexpr (NK >= 16) {
+      f32x4 c0 = *reinterpret_cast<const f32x4 *>(arow), c1 = *reinterpret_cast<const f32x4 *>(arow + 4);
 #pragma unroll
-    for (int j = 0; j < NK / 4; j++) {
-      const f32x4 a4 = *reinterpret_cast<const f32x4 *>(arow + 4 * j);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, xb[4 * j + 0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, xb[4 * j + 1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, xb[4 * j + 2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, xb[4 * j + 3], acc, 0, 0, 0);
+      for (int g = 0; g < NG; g++) {
+        f32x4 n0 = c0, n1 = c1;
+        if (g + 1 < NG) {
+          n0 = *reinterpret_cast<const f32x4 *>(arow + 8 * (g + 1));
+          n1 = *reinterpret_cast<const f32x4 *>(arow + 8 * (g + 1) + 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(c0.x, xb[8 * g + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(c0.y, xb[8 * g + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(c0.z, xb[8 * g + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(c0.w, xb[8 * g + 3], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(c1.x, xb[8 * g + 4], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(c1.y, xb[8 * g + 5], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(c1.z, xb[8 * g + 6], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(c1.w, xb[8 * g + 7], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        c0 = n0;
+        c1 = n1;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NK / 4; j++) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4 *>(arow + 4 * j);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, xb[4 * j + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, xb[4 * j + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, xb[4 * j + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, xb[4 * j + 3], acc, 0, 0, 0);
+      }
     }
     // strict '>' keeps the earlier index on equal scores; NaN scores compare false everywhere
     // and are ignored (as in the reference, where a NaN distance is never "less").

@@ -47,6 +47,7 @@ def lib():
         L.kmo_fma_rd_portable.restype = f32
         L.kmo_fma_rd_portable.argtypes = [f32, f32, f32]
         L.kmo_have_avx512.restype = i32
+        L.kmo_num_threads.restype = i32
         L.kmo_kahan_dot.restype = f32
         L.kmo_kahan_dot.argtypes = [_f32p, _f32p, u32]
         L.kmo_distance.restype = f32

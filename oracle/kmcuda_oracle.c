@@ -60,6 +60,18 @@ __attribute__((target("avx512f"))) static float fma_rd_avx512(float a, float b, 
 #endif
 
 static int g_avx512 = -1;
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* threads the OpenMP loops of this file run on (bench.py reports it as cpu_baseline.cores) */
+int kmo_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
 int kmo_have_avx512(void) {
   if (g_avx512 < 0) {
 #if defined(__x86_64__)

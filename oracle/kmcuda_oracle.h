@@ -30,6 +30,7 @@ enum { KMO_INIT_RANDOM = 0, KMO_INIT_PLUSPLUS = 1, KMO_INIT_AFKMC2 = 2, KMO_INIT
 float kmo_fma_rd(float a, float b, float c);
 float kmo_fma_rd_portable(float a, float b, float c);
 int   kmo_have_avx512(void);
+int   kmo_num_threads(void);
 
 /* metric_abstraction.h:21-36 (L2) / :149-158 (cos -> 1) */
 void kmo_sum_squares(int metric, uint32_t K, uint32_t D, const float *centroids, float *csqr);

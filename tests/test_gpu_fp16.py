@@ -32,7 +32,7 @@ def test_fp16_random_lloyd(fixture13k):
                                              tolerance=0.05, yinyang_t=0)
     assert centroids.dtype == numpy.float16
     assert centroids.shape == (50, 2) and assignments.shape == (13000,)
-    assert abs(out.iterations() - 7) <= 1
+    assert out.iterations() == 7
     _validate(fixture13k, centroids.astype(numpy.float32), assignments, 0.05)
 
 
@@ -44,7 +44,7 @@ def test_fp16_kmeanspp_lloyd(fixture13k):
     with out:
         centroids, assignments = kmeans_cuda(samples, 50, init="kmeans++", device=1, verbosity=2, seed=3,
                                              tolerance=0.05, yinyang_t=0)
-    assert abs(out.iterations() - 5) <= 1
+    assert out.iterations() == 5
     _validate(fixture13k, centroids.astype(numpy.float32), assignments, 0.05)
 
 
@@ -68,7 +68,7 @@ def test_fp16_kmeanspp_yinyang(fixture13k):
     with out:
         centroids, assignments = kmeans_cuda(samples, 50, init="kmeans++", device=1, verbosity=2, seed=3,
                                              tolerance=0.01, yinyang_t=0.1)
-    assert 15 + 3 - 3 <= out.iterations() <= 16 + 7 + 3
+    assert out.iterations() in (22, 23)   # measured: 22 (fp32 accumulation of the half values)
     _validate(fixture13k, centroids.astype(numpy.float32), assignments, 0.0105)
 
 
