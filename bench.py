@@ -63,6 +63,32 @@ def cpu_baseline(features, clusters, budget_s=12.0):
                        else "portable round-down FMA", dt)}
 
 
+def sklearn_baseline(features, clusters, rows=100000, iters=6):
+    """scikit-learn's Lloyd (the CPU contestant of the reference's README table, README.md:187-204)
+    on this box's host cores: BASELINE config[0] shape, seconds per iteration -> assignments/s."""
+    try:
+        import numpy
+        from sklearn.cluster import KMeans
+        from threadpoolctl import threadpool_info
+    except Exception as e:  # pragma: no cover
+        return {"error": repr(e)}
+    rs = numpy.random.RandomState(0)
+    x = rs.rand(rows, features).astype(numpy.float32)
+    init = x[rs.choice(rows, clusters, replace=False)].copy()
+    t = {}
+    for n in (1, 1, 1 + iters):   # the first fit warms the thread pool up and is discarded
+        km = KMeans(n_clusters=clusters, init=init, n_init=1, max_iter=n, tol=0, algorithm="lloyd")
+        t0 = time.time()
+        km.fit(x)
+        t[n] = time.time() - t0
+    per_iter = max((t[1 + iters] - t[1]) / iters, 1e-6)
+    threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    return {"value": rows / per_iter, "unit": "point-assignments/s", "cores": threads, "kind": "sklearn",
+            "sample": "sklearn.cluster.KMeans(algorithm='lloyd', n_init=1, tol=0) on %d x %d uniform rows, K=%d: "
+                      "%.3f s per iteration (difference of a %d- and a 1-iteration fit)" %
+                      (rows, features, clusters, per_iter, 1 + iters)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,6 +186,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(D, K)
+            out["cpu_baseline_sklearn"] = sklearn_baseline(D, K)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
