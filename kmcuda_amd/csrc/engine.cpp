@@ -51,9 +51,10 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   int rc;
   if ((rc = alloc(&csqr_, K))) return rc;
   if ((rc = alloc(&bias_, K_pad_))) return rc;
+  if ((rc = alloc(&bias2_, K_pad_))) return rc;
   if ((rc = alloc(&cfil_, (size_t)K_pad_ * dp))) return rc;
   if ((rc = alloc(&ct_, (size_t)D * Kt_))) return rc;
-  if ((rc = alloc(&stats_, 4))) return rc;
+  if ((rc = alloc(&stats_, 8))) return rc;
   if ((rc = alloc(&mu_, dp))) return rc;
   if ((rc = alloc(&finite_, Kt_))) return rc;
   if ((rc = alloc(&flagged_, n_rows))) return rc;
@@ -114,8 +115,8 @@ void Engine::profile_reset() {
 
 int Engine::prepare_centroids(const float *centroids) {
   const uint32_t dp = DP_ ? DP_ : 8;
-  KMX_HIP(launch_centroid_prep(metric_, centroids, K_, D_, K_pad_, dp, Kt_, csqr_, bias_, cfil_, ct_, mu_, finite_,
-                               stats_, stream_),
+  KMX_HIP(launch_centroid_prep(metric_, centroids, K_, D_, K_pad_, dp, Kt_, csqr_, bias_, bias2_, cfil_, ct_, mu_,
+                               finite_, stats_, stream_),
           kRuntimeError);
   return kSuccess;
 }

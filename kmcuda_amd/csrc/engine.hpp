@@ -72,7 +72,7 @@ class Engine {
   float eps_ = 0, tie_slack_ = 0;
 
   // assignment workspace
-  float *csqr_ = nullptr, *bias_ = nullptr, *cfil_ = nullptr, *ct_ = nullptr, *mu_ = nullptr;
+  float *csqr_ = nullptr, *bias_ = nullptr, *bias2_ = nullptr, *cfil_ = nullptr, *ct_ = nullptr, *mu_ = nullptr;
   uint32_t *finite_ = nullptr;
   uint32_t *stats_ = nullptr, *flagged_ = nullptr, *pairs_ = nullptr, *counters_ = nullptr;
   // update workspace

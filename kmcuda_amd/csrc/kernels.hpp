@@ -16,7 +16,8 @@ struct LloydArgs {
   const float *mu;           // DP: mean of the finite centroids (zero padded)
   const float *ct;           // D x Kt transposed centroids
   const float *csqr;         // K exact squared norms (reference's sum_squares)
-  const uint32_t *stats;     // bits of: [0] max ||c - mu||^2, [1] max bias magnitude, [2] max ||c||^2
+  const uint32_t *stats;     // bits of: [0] max ||c - mu||^2, [1] max bias magnitude, [2] max ||c||^2,
+                             //          [3] ||mu||^2, [4] max bias2 magnitude (original-row variant)
   float eps;                 // relative error coefficient of the filter bound
   float tie_slack;           // absolute slack (angular: acos plateau width)
   uint32_t *assignments, *assignments_prev;
@@ -27,8 +28,8 @@ struct LloydArgs {
 
 uint32_t filter_dp_for(uint32_t D);
 hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad,
-                                uint32_t DP, uint32_t Kt, float *csqr, float *bias, float *cfil, float *ct, float *mu,
-                                uint32_t *finite, uint32_t *stats, hipStream_t st);
+                                uint32_t DP, uint32_t Kt, float *csqr, float *bias, float *bias2, float *cfil,
+                                float *ct, float *mu, uint32_t *finite, uint32_t *stats, hipStream_t st);
 hipError_t launch_lloyd_filter(const LloydArgs &a, hipStream_t st);
 hipError_t launch_lloyd_pair(int metric, const LloydArgs &a, const float *centroids, uint32_t grid, hipStream_t st);
 hipError_t launch_lloyd_exact(int metric, const LloydArgs &a, const uint32_t *rows, const uint32_t *nrows,

@@ -459,7 +459,10 @@ class Job {
       scan_rows += c[1];
       pair_rows += c[3];
     }
-    if (print) DEBUG("filter: %u rows settled by two exact chains, %u by a full exact scan\n", pair_rows, scan_rows);
+    if (print && passed_total == nullptr)
+      DEBUG("filter: %u rows settled by two exact chains, %u by a full exact scan\n", pair_rows, scan_rows);
+    if (print && passed_total != nullptr)
+      DEBUG("local filter: %u exact distances queued, %u wave flushes\n", pair_rows, scan_rows);
     if (passed_total) *passed_total = overall_passed;
     if (print) INFO("iteration %d: %u reassignments\n", iter, overall_changed);
     if (overall_changed <= tolerance * N) return 1;  // counters are NOT zeroed on stop (kmeans.cu:707-709)
@@ -594,6 +597,8 @@ class Job {
         (void)hipSetDevice(s->dev);
         RETERR(s->eng->yy_drifts(s->centroids, s->drifts, s->gdrifts));
         RETERR(s->eng->counters_reset(2));  // d_passed_number = 0, kmeans.cu:1225-1229
+        RETERR(s->eng->counters_reset(1));  // statistics of the local filter (flushes, exact distances)
+        RETERR(s->eng->counters_reset(3));
         RETERR(s->eng->yy_filters(s->samples, s->centroids, s->drifts, s->gdrifts, s->assignments, s->prev, s->bounds,
                                   s->passed));
       }

@@ -97,7 +97,8 @@ template <int METRIC>
 __global__ void centroid_panel_kernel(const float *__restrict__ centroids, uint32_t K, uint32_t D, uint32_t K_pad,
                                       uint32_t DP, const uint32_t *__restrict__ finite,
                                       const float *__restrict__ mu, float *__restrict__ bias,
-                                      float *__restrict__ cfil, uint32_t *__restrict__ stats) {
+                                      float *__restrict__ bias2, float *__restrict__ cfil,
+                                      uint32_t *__restrict__ stats) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= K_pad) return;
   float *dst = cfil + (size_t)c * DP;
@@ -122,10 +123,17 @@ __global__ void centroid_panel_kernel(const float *__restrict__ centroids, uint3
       bmag = sqrtf(m2) * sqrtf(n2) * 1.0001f;  // >= sum |mu_f c'_f|
     }
     bias[c] = b;
+    // the variant for kernels that keep the ORIGINAL row resident (Yinyang: the exact chains need
+    // it): ||x - c||^2 = ||x - mu||^2 - 2 (x.c' - mu.c' - ||c'||^2/2)   /   x.c = x.c' + x.mu
+    const float mag2 = (METRIC == 0) ? sqrtf(m2) * sqrtf(n2) * 1.0001f + 0.5f * n2 : 0.f;
+    bias2[c] = (METRIC == 0) ? -mc - 0.5f * n2 : 0.f;
     atomicMax(&stats[0], __float_as_uint(n2 * 1.0001f));
     atomicMax(&stats[1], __float_as_uint(bmag * 1.0001f));
+    atomicMax(&stats[3], __float_as_uint(m2 * 1.0001f));
+    atomicMax(&stats[4], __float_as_uint(mag2 * 1.0001f));
   } else {
     bias[c] = -INFINITY;
+    bias2[c] = -INFINITY;
     for (uint32_t f = 0; f < DP; f++) dst[f] = 0.f;
   }
 }
@@ -527,9 +535,9 @@ hipError_t launch_lloyd_filter(const LloydArgs &a, hipStream_t st) {
 }
 
 hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad,
-                                uint32_t DP, uint32_t Kt, float *csqr, float *bias, float *cfil, float *ct, float *mu,
-                                uint32_t *finite, uint32_t *stats, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(stats, 0, 4 * sizeof(uint32_t), st);
+                                uint32_t DP, uint32_t Kt, float *csqr, float *bias, float *bias2, float *cfil,
+                                float *ct, float *mu, uint32_t *finite, uint32_t *stats, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(stats, 0, 8 * sizeof(uint32_t), st);
   if (e != hipSuccess) return e;
   const dim3 block(64);
   if (metric == 0)
@@ -541,10 +549,10 @@ hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, 
   hipLaunchKernelGGL(centroid_mean_kernel, dim3((DP + 63) / 64), dim3(256), 0, st, centroids, K, D, DP, finite, mu);
   if (metric == 0)
     hipLaunchKernelGGL((centroid_panel_kernel<0>), dim3((K_pad + 63) / 64), block, 0, st, centroids, K, D, K_pad, DP,
-                       finite, mu, bias, cfil, stats);
+                       finite, mu, bias, bias2, cfil, stats);
   else
     hipLaunchKernelGGL((centroid_panel_kernel<1>), dim3((K_pad + 63) / 64), block, 0, st, centroids, K, D, K_pad, DP,
-                       finite, mu, bias, cfil, stats);
+                       finite, mu, bias, bias2, cfil, stats);
   return hipGetLastError();
 }
 

@@ -4,29 +4,36 @@
 // in-library cross-check, and the path for feature counts the filter is not instantiated for).
 //
 // Both kernels reuse the Lloyd filter's machinery (lloyd.hip): a wave keeps 32 rows, CENTRED
-// (x - mu), resident in VGPRs as the MFMA B operand; 32-centroid tiles of the centred panel stream
-// through LDS shared by the block's 4 waves; the accumulator is seeded with the bias so
-// ||x - c||^2 ~= ||x'||^2 - 2*acc (L2) / x.c ~= acc + x.mu (angular).  The approximate values
-// only decide WHICH exact distances need evaluating; every number that is stored (bounds) or
-// compared (min / second-min updates, skip tests) is the reference's exact arithmetic, evaluated
-// in the reference's order where order matters.  Outputs are bit-identical to yinyang.hip's.
+// (x' = x - mu), resident in VGPRs as the MFMA B operand and 32-centroid tiles of the centred
+// panel (c' = c - mu) stream through LDS shared by the block's 4 waves.  With the accumulator
+// seeded by the panel's bias:
+//     ||x - c||^2 = ||x'||^2 - 2*acc          (L2)          x.c = acc + x.mu   (angular)
+// and |acc - exact| <= 2 eps (||x'|| C'max + B'max).  The exact chains read the ORIGINAL row and
+// centroid values from global memory (L1/L2 resident) in rolled loops.
+// The approximate values only decide WHICH exact distances need evaluating; every number that is
+// stored (bounds) or compared (min / second-min updates, skip tests) is the reference's exact
+// arithmetic, evaluated in the reference's order where order matters.  Outputs are bit-identical
+// to yinyang.hip's.
 //
 // yy_local_filter (kmeans.cu:584-672).  Per passed row the reference scans c = 0..K-1:
 //     group bound >= upper bound      -> second_min = min(second_min, bound); skip          (a)
 //     second_min < bound + drifts     -> skip                                                 (b)
 //     else dist = exact; update (min, second_min, nearest) with strict '<'                    (c)
 //   A centroid whose exact distance is >= second_min at its turn changes nothing whether it is
-//   evaluated or skipped.  So: (a) is replayed for every centroid; (b)/(c) only for centroids whose
-//   approximate distance could be below the running second_min (threshold at tile start = a
-//   superset, second_min only decreases); the survivors go through the reference's tests and the
-//   exact distance IN ASCENDING c ORDER, so the state evolves exactly as in the reference.
+//   evaluated or skipped.  So (a) is replayed for every centroid (folded into a running minimum
+//   between candidates: min is order free), and (b)/(c) only for centroids whose approximate
+//   distance could be below second_min (threshold as of the last flush = a superset, second_min
+//   only decreases).  Candidates are QUEUED per row, four deep; a flush evaluates the queued exact
+//   distances as four interleaved chains (a distance has no side effects, so evaluating one the
+//   reference would have skipped is harmless) and then replays the reference's tests and updates
+//   in ascending c order with the live state -- the state evolves exactly as in the reference.
 //
 // yy_init (kmeans.cu:431-485).  bounds[1+g] = min over the group's centroids (other than the
 //   row's own) of the exact distance: a minimum does not depend on the visiting order, so the panel
 //   is streamed GROUP-SORTED (groups padded to multiples of 4 rows = one half-wave's accumulator
 //   quad), each half-wave keeps a running top-3 of the approximate scores of the current group, and
-//   at the group boundary the exact distance is evaluated for the 1-2 contenders (all members when
-//   three or more are within the error bound).
+//   at the group boundary the 1-2 contenders are queued (all members, evaluated at once, when
+//   three or more are within the error bound); queued distances are evaluated four at a time.
 #include "exact.hpp"
 #include "kernels.hpp"
 
@@ -35,102 +42,117 @@ namespace kmx {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// One serial exact chain over the D features of (sample row, centroid row), both ORIGINAL values
+constexpr float kFltMax = 3.402823466e+38f;
+
+// Four exact chains at once over the D features of (original sample row, four centroid rows), all
 // from global memory: the lower half-wave runs features [0, NK), hands (acc, corr) to the upper
-// half which continues with [NK, D).  Every lane of a (col, col+32) pair gets the result.
+// half which continues with [NK, D).  Every lane of a (col, col+32) pair gets the results.  The
+// four round-down FMAs of a feature share one rounding-mode window (exact.hpp).  Rolled loops: the
+// function is instantiated at several call sites and must stay small.
 // metric_abstraction.h:73-86 (L2 distance_t) / :193-205 (angular).
 template <int NK, int METRIC, bool FAST>
-__device__ __forceinline__ float exact_distance_split(const float *__restrict__ xrow, const float *__restrict__ crow,
-                                                      uint32_t D, int h, int col) {
-  float acc = 0.f, corr = 0.f;
-#pragma unroll
+__device__ __forceinline__ void exact_distance4(const float *__restrict__ xrow, const float *const (&crow)[4],
+                                                uint32_t D, int h, int col, float (&dist)[4]) {
+  float acc[4] = {0.f, 0.f, 0.f, 0.f}, corr[4] = {0.f, 0.f, 0.f, 0.f};
+  const int nvalid = (int)D - h * NK < 0 ? 0 : ((int)D - h * NK > NK ? NK : (int)D - h * NK);
   for (int pass = 0; pass < 2; pass++) {
     if (pass == 1) {
-      acc = __shfl(acc, col);
-      corr = __shfl(corr, col);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        acc[i] = __shfl(acc[i], col);
+        corr[i] = __shfl(corr[i], col);
+      }
     }
-    if (FAST) {
-      const f32x4 *xs = reinterpret_cast<const f32x4 *>(xrow + h * NK);
-      const f32x4 *cs = reinterpret_cast<const f32x4 *>(crow + h * NK);
+    // only the half-wave whose features this pass covers loads and computes (the other half's
+    // lanes would gather 5 more scattered 16-byte pieces per step for nothing: the gathers, not the
+    // arithmetic, bound this path)
+    if (h == pass) {
 #pragma unroll 2
-      for (int j = 0; j < NK / 4; j++) {
-        const f32x4 xv = xs[j], cv = cs[j];
-        const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, ca[4] = {cv.x, cv.y, cv.z, cv.w};
+      for (int j = 0; j < NK; j += 4) {
+        float xv[4], cv[4][4];
+        if (FAST) {
+          const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xrow + h * NK + j);
+          xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(crow[i] + h * NK + j);
+            cv[i][0] = v.x; cv[i][1] = v.y; cv[i][2] = v.z; cv[i][3] = v.w;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const bool in = j + q < nvalid;
+            xv[q] = in ? xrow[h * NK + j + q] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) cv[i][q] = in ? crow[i][h * NK + j + q] : 0.f;
+          }
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          float y;
+          float y[4];
           if (METRIC == 0) {
-            const float d = xa[q] - ca[q];
-            y = fma_rd(d, d, corr);
+            float d[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) d[i] = xv[q] - cv[i][q];
+            sqfma_rd4(d, corr, y);
           } else {
-            y = fma_rd(xa[q], ca[q], corr);
+            const float b[4] = {cv[0][q], cv[1][q], cv[2][q], cv[3][q]};
+            fma_rd4(xv[q], b, corr, y);
           }
-          kahan_fold(y, acc, corr);
+          const bool on = FAST || (j + q < nvalid);
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const float t = acc[i] + y[i];
+            const float nc = y[i] - (t - acc[i]);
+            acc[i] = on ? t : acc[i];
+            corr[i] = on ? nc : corr[i];
+          }
         }
-      }
-    } else {
-#pragma unroll 4
-      for (int j = 0; j < NK; j++) {
-        const uint32_t f = h * NK + j;
-        const bool on = f < D;
-        const float xv = on ? xrow[f] : 0.f, cv = on ? crow[f] : 0.f;
-        float y;
-        if (METRIC == 0) {
-          const float d = xv - cv;
-          y = fma_rd(d, d, corr);
-        } else {
-          y = fma_rd(xv, cv, corr);
-        }
-        const float t = acc + y;
-        const float nc = y - (t - acc);
-        acc = on ? t : acc;
-        corr = on ? nc : corr;
       }
     }
   }
-  const float total = __shfl(acc, col + 32);
-  return METRIC == 0 ? sqrtf(total) : angular_from_prod(total);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float total = __shfl(acc[i], col + 32);
+    dist[i] = METRIC == 0 ? sqrtf(total) : angular_from_prod(total);
+  }
 }
 
-// Shared scaffold: centred resident rows, tile staging, one tile of MFMA.
-template <int DP, bool FAST>
-struct RowTile {
-  static constexpr int NK = DP / 2;
-  static constexpr int LDW = DP + 4;
-  static constexpr int TILE = 32 * LDW;
-  static constexpr int NST = (8 * DP + 255) / 256;
-};
-
+// rows of the wave, centred: xb = x - mu; squared norms of x and of x - mu; x.mu
 #define KMX_YY_LOAD_ROWS(samples_, row_, live_)                                                      \
   float xb[NK];                                                                                      \
-  float xo2 = 0.f;                                                                                   \
+  float xo2 = 0.f, xc2 = 0.f, xmu = 0.f;                                                             \
   {                                                                                                  \
-    if (FAST) {                                                                                      \
-      const f32x4 *src = reinterpret_cast<const f32x4 *>((samples_) + (size_t)((live_) ? (row_) : 0) * D + h * NK); \
-      const f32x4 *msrc = reinterpret_cast<const f32x4 *>(a.mu + h * NK);                            \
-      _Pragma("unroll") for (int j = 0; j < NK / 4; j++) {                                           \
-        const f32x4 v = src[j], m = msrc[j];                                                         \
-        xo2 = fmaf(v.x, v.x, xo2); xo2 = fmaf(v.y, v.y, xo2); xo2 = fmaf(v.z, v.z, xo2); xo2 = fmaf(v.w, v.w, xo2); \
-        xb[4 * j + 0] = (live_) ? v.x - m.x : 0.f;                                                   \
-        xb[4 * j + 1] = (live_) ? v.y - m.y : 0.f;                                                   \
-        xb[4 * j + 2] = (live_) ? v.z - m.z : 0.f;                                                   \
-        xb[4 * j + 3] = (live_) ? v.w - m.w : 0.f;                                                   \
+    const float *src = (samples_) + (size_t)((live_) ? (row_) : 0) * D;                              \
+    _Pragma("unroll") for (int j = 0; j < NK; j += 4) {                                              \
+      float v[4], m[4];                                                                              \
+      if (FAST) {                                                                                    \
+        const f32x4 vv = *reinterpret_cast<const f32x4 *>(src + h * NK + j);                         \
+        const f32x4 mm = *reinterpret_cast<const f32x4 *>(a.mu + h * NK + j);                        \
+        v[0] = vv.x; v[1] = vv.y; v[2] = vv.z; v[3] = vv.w;                                          \
+        m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;                                          \
+      } else {                                                                                       \
+        _Pragma("unroll") for (int q = 0; q < 4; q++) {                                              \
+          const uint32_t f = h * NK + j + q;                                                         \
+          v[q] = (f < D) ? src[f] : 0.f;                                                             \
+          m[q] = (f < D) ? a.mu[f] : 0.f;                                                            \
+        }                                                                                            \
       }                                                                                              \
-    } else {                                                                                         \
-      const float *src = (samples_) + (size_t)((live_) ? (row_) : 0) * D;                            \
-      _Pragma("unroll") for (int j = 0; j < NK; j++) {                                               \
-        const uint32_t f = h * NK + j;                                                               \
-        const float v = ((live_) && f < D) ? src[f] : 0.f;                                           \
-        xo2 = fmaf(v, v, xo2);                                                                       \
-        xb[j] = ((live_) && f < D) ? v - a.mu[f] : 0.f;                                              \
+      _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                \
+        if (j + q >= NK) break;                                                                      \
+        const float x = (live_) ? v[q] : 0.f;                                                        \
+        const float xc = (live_) ? v[q] - m[q] : 0.f;                                                \
+        xb[j + q] = xc;                                                                              \
+        xo2 = fmaf(x, x, xo2);                                                                       \
+        xc2 = fmaf(xc, xc, xc2);                                                                     \
+        xmu = fmaf(x, m[q], xmu);                                                                    \
       }                                                                                              \
     }                                                                                                \
-    if (!(live_)) xo2 = 0.f;                                                                         \
   }                                                                                                  \
-  float xn2 = 0.f;                                                                                   \
-  _Pragma("unroll") for (int j = 0; j < NK; j++) xn2 = fmaf(xb[j], xb[j], xn2);                      \
-  xn2 += __shfl_xor(xn2, 32);                                                                        \
-  xo2 += __shfl_xor(xo2, 32);
+  xo2 += __shfl_xor(xo2, 32);                                                                        \
+  xc2 += __shfl_xor(xc2, 32);                                                                        \
+  xmu += __shfl_xor(xmu, 32);                                                                        \
+  const float *xrow = (samples_) + (size_t)((live_) ? (row_) : 0) * D;
 
 #define KMX_YY_MFMA_TILE(acc_, buf_)                                                                 \
   f32x16 acc_;                                                                                       \
@@ -173,35 +195,23 @@ __global__ __launch_bounds__(256, 2) void yy_local_mfma_kernel(YyArgs a) {
 
   const float upper_bound = live ? a.bounds[s] : 0.f;
   const uint32_t cluster = live ? a.assignments[s] : 0xFFFFFFFFu;
-  float min_dist = upper_bound, second_min = 3.402823466e+38f;
+  float min_dist = upper_bound, second_min = kFltMax;
   uint32_t nearest = cluster;
 
   // threshold in accumulator space: a centroid can only matter if acc >= amin
   const float cmaxc = sqrtf(__uint_as_float(a.stats[0])) * 1.000001f;
   const float bmaxc = __uint_as_float(a.stats[1]);
-  const float xn = sqrtf(xn2) * 1.0001f;
-  const float e_mfma = 2.0f * a.eps * (xn * cmaxc + bmaxc) * 1.01f;
-  float kx = 0.f, e_cos = 0.f;
-  if (METRIC == 1) {
-    // x.c = acc + x.mu  (acc = x'.c' + mu.c');  x.mu evaluated here in fp32
-    float p = 0.f;
-#pragma unroll
-    for (int j = 0; j < NK; j++) {
-      const uint32_t f = h * NK + j;
-      const float m = f < D ? a.mu[f] : 0.f;
-      p = fmaf(xb[j] + m, m, p);
-    }
-    kx = p + __shfl_xor(p, 32);
-    const float mun = sqrtf(__uint_as_float(a.stats[3])) * 1.0001f;
-    e_cos = e_mfma + a.eps * (sqrtf(xo2) * 1.0001f + xn) * mun + 1e-6f;
-  }
+  const float xo = sqrtf(xo2) * 1.0001f, xc = sqrtf(xc2) * 1.0001f;
+  const float e_mfma = 2.0f * a.eps * (xc * cmaxc + bmaxc) * 1.01f;
+  // angular: x.c = acc + x.mu with x.mu evaluated in fp32 here
+  const float e_cos = e_mfma + a.eps * xo * sqrtf(__uint_as_float(a.stats[3])) * 1.01f + 1e-6f;
   auto amin_of = [&](float sm) -> float {
     if (METRIC == 0) {
       const float T2 = sm * sm * 1.000002f;  // inf while second_min is still FLT_MAX
-      return 0.5f * (xn2 - T2) - e_mfma - 1e-6f * (xn2 + T2);
+      return 0.5f * (xc2 - T2) - e_mfma - 1e-6f * (xc2 + T2);
     }
     if (sm >= 3.1415925f) return -INFINITY;
-    return cosf(sm) - kx - e_cos;
+    return cosf(sm) - xmu - e_cos;
   };
   float amin = amin_of(second_min);
 
@@ -236,12 +246,51 @@ __global__ __launch_bounds__(256, 2) void yy_local_mfma_kernel(YyArgs a) {
     }
   };
 
+  // queue of candidates (ascending c) + the minimum of the (a) bounds seen before each of them
+  uint32_t qc[4] = {0, 0, 0, 0};
+  float qpre[4] = {kFltMax, kFltMax, kFltMax, kFltMax};
+  float tail_a = kFltMax;
+  int qn = 0;
+  uint32_t n_flush = 0, n_cand = 0;  // statistics: counters[1] += flushes (per wave), [3] += candidates
+  auto flush = [&]() {  // wave-uniform call
+    n_flush++;
+    const float *crow[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) crow[i] = a.centroids + (size_t)(i < qn ? qc[i] : 0) * D;
+    float dist[4];
+    exact_distance4<NK, METRIC, FAST>(xrow, crow, D, h, col, dist);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (i < qn) {
+        if (qpre[i] < second_min) second_min = qpre[i];      // the (a) updates that preceded it
+        const uint32_t c = qc[i];
+        const uint32_t g = a.groups[c];
+        float lb = a.bounds[(size_t)len * (1 + g) + s];
+        lb += a.gdrifts[g] - a.drifts[(size_t)K * D + c];    // kmeans.cu:637
+        if (!(second_min < lb)) {                            // :638-640
+          const float d = dist[i];                           // :641-652
+          if (d < min_dist) {
+            second_min = min_dist;
+            min_dist = d;
+            nearest = c;
+          } else if (d < second_min) {
+            second_min = d;
+          }
+        }
+      }
+      qpre[i] = kFltMax;
+    }
+    if (tail_a < second_min) second_min = tail_a;
+    tail_a = kFltMax;
+    qn = 0;
+    amin = amin_of(second_min);
+  };
+
   const uint32_t ntiles = a.K_pad / 32;
   const bool wave_live = __ballot(live) != 0ull;
   stage_load(0);
   stage_store(0);
   __syncthreads();
-  const float *xrow = a.samples + (size_t)s * D;
   for (uint32_t t = 0; t < ntiles; t++) {
     const int buf = t & 1;
     if (t + 1 < ntiles) stage_load(t + 1);
@@ -256,59 +305,53 @@ __global__ __launch_bounds__(256, 2) void yy_local_mfma_kernel(YyArgs a) {
           const uint32_t c = t * 32 + row;
           const uint32_t g = grp_ptr(buf)[row];
           const bool valid = g < G && c != cluster;  // g >= G: NaN centroid or padding
-          if (valid && acc[r] >= amin) m16 |= 1u << r;
           if (valid) {
             const float lb = a.bounds[(size_t)len * (1 + g) + s];
-            if (lb >= upper_bound) a16 |= 1u << r;
+            if (lb >= upper_bound) a16 |= 1u << r;       // kmeans.cu:631-636
+            else if (acc[r] >= amin) m16 |= 1u << r;
           }
         }
       }
       if (__ballot((m16 | a16) != 0u) != 0ull) {
         const uint32_t pm = __shfl_xor(m16, 32), pa = __shfl_xor(a16, 32);
         const uint32_t m0 = h ? pm : m16, m1 = h ? m16 : pm, a0 = h ? pa : a16, a1 = h ? a16 : pa;
-        uint32_t rowmask = 0, amask = 0;
+        uint32_t bmask = 0, amask = 0;
 #pragma unroll
         for (int g4 = 0; g4 < 4; g4++) {
-          rowmask |= (((m0 >> (4 * g4)) & 0xFu) << (8 * g4)) | (((m1 >> (4 * g4)) & 0xFu) << (8 * g4 + 4));
+          bmask |= (((m0 >> (4 * g4)) & 0xFu) << (8 * g4)) | (((m1 >> (4 * g4)) & 0xFu) << (8 * g4 + 4));
           amask |= (((a0 >> (4 * g4)) & 0xFu) << (8 * g4)) | (((a1 >> (4 * g4)) & 0xFu) << (8 * g4 + 4));
         }
-        rowmask = (rowmask & ~amask) | amask;  // (a) wins: the reference tests it first
+        uint32_t rowmask = bmask | amask;
         while (__ballot(rowmask != 0u) != 0ull) {
+          if (__ballot(qn == 4) != 0ull) flush();  // some row's queue is full
           const bool active = rowmask != 0u;
           const uint32_t rho = active ? (uint32_t)__ffs((int)rowmask) - 1u : 0u;
           rowmask &= rowmask - 1u;
-          const uint32_t c = t * 32 + rho;
-          const uint32_t g = active ? grp_ptr(buf)[rho] : 0u;
-          bool need = false;
           if (active) {
-            float lb = a.bounds[(size_t)len * (1 + g) + s];
-            if (lb >= upper_bound) {                       // kmeans.cu:631-636
-              if (lb < second_min) second_min = lb;
+            if ((amask >> rho) & 1u) {
+              const uint32_t g = grp_ptr(buf)[rho];
+              const float lb = a.bounds[(size_t)len * (1 + g) + s];
+              if (lb < tail_a) tail_a = lb;
             } else {
-              lb += a.gdrifts[g] - a.drifts[(size_t)K * D + c];  // :637
-              need = !(second_min < lb);                   // :638-640
-            }
-          }
-          if (__ballot(need) != 0ull) {
-            const float dist = exact_distance_split<NK, METRIC, FAST>(
-                xrow, a.centroids + (size_t)(need ? c : 0) * D, D, h, col);
-            if (need) {                                    // :641-652
-              if (dist < min_dist) {
-                second_min = min_dist;
-                min_dist = dist;
-                nearest = c;
-              } else if (dist < second_min) {
-                second_min = dist;
-              }
+              const uint32_t c = t * 32 + rho;
+#pragma unroll
+              for (int i = 0; i < 4; i++)
+                if (i == qn) {
+                  qc[i] = c;
+                  qpre[i] = tail_a;
+                }
+              tail_a = kFltMax;
+              qn++;
+              n_cand++;
             }
           }
         }
-        amin = amin_of(second_min);
       }
     }
     if (t + 1 < ntiles) stage_store(buf ^ 1);
     __syncthreads();
   }
+  if (wave_live && __ballot(qn > 0 || tail_a < kFltMax) != 0ull) flush();
   // write-back, kmeans.cu:653-671
   bool changed = false;
   if (live && h == 0) {
@@ -327,6 +370,15 @@ __global__ __launch_bounds__(256, 2) void yy_local_mfma_kernel(YyArgs a) {
   }
   const unsigned long long cm = __ballot(changed);
   if (lane == 0 && cm) atomicAdd(&a.counters[0], (uint32_t)__popcll(cm));
+  {  // statistics (not part of the reference's state)
+    uint32_t nc = (live && h == 0) ? n_cand : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nc += __shfl_xor(nc, off);
+    if (lane == 0) {
+      atomicAdd(&a.counters[3], nc);
+      atomicAdd(&a.counters[1], n_flush);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -349,29 +401,18 @@ __global__ __launch_bounds__(256, 2) void yy_init_mfma_kernel(YyArgs a) {
   const bool live = s < len;
 
   KMX_YY_LOAD_ROWS(a.samples, s, live)
+  (void)xmu;
 
   const uint32_t nearest = live ? a.assignments[s] : 0xFFFFFFFFu;
-  const float *xrow = a.samples + (size_t)(live ? s : 0) * D;
-  // upper bound: exact distance to the row's own centroid (kmeans.cu:474-476); FLT_MAX if it has
-  // none (NaN row) or its centroid is not in any group (NaN centroid)
-  float upper = 3.402823466e+38f;
-  {
-    const bool has = live && nearest < K && a.groups[nearest] < G;
-    if (__ballot(has) != 0ull) {
-      const float d = exact_distance_split<NK, METRIC, FAST>(xrow, a.centroids + (size_t)(has ? nearest : 0) * D, D, h,
-                                                             col);
-      if (has) upper = d;
-    }
-  }
 
   // two scores closer than thr cannot be ordered by the filter
   const float cmaxc = sqrtf(__uint_as_float(a.stats[0])) * 1.000001f;
   const float bmaxc = __uint_as_float(a.stats[1]);
-  const float xn = sqrtf(xn2) * 1.0001f;
+  const float xo = sqrtf(xo2) * 1.0001f, xc = sqrtf(xc2) * 1.0001f;
   const float u = 5.9604645e-8f;
-  float thr = 2.0f * (2.0f * a.eps * (xn * cmaxc + bmaxc)) * 1.01f;
-  if (METRIC == 0) thr += 16.0f * u * (xn + cmaxc) * (xn + cmaxc);
-  else thr += 16.0f * u * sqrtf(xo2) * sqrtf(__uint_as_float(a.stats[2])) + 2e-6f;
+  float thr = 2.0f * (2.0f * a.eps * (xc * cmaxc + bmaxc)) * 1.01f;
+  if (METRIC == 0) thr += 16.0f * u * (xc + cmaxc) * (xc + cmaxc);
+  else thr += 16.0f * u * xo * sqrtf(__uint_as_float(a.stats[2])) + 2e-6f;
 
   f32x4 stage[NST];
   float bstage = 0.f;
@@ -405,6 +446,59 @@ __global__ __launch_bounds__(256, 2) void yy_init_mfma_kernel(YyArgs a) {
     if (tid < 8) meta_ptr(buf)[tid] = mstage;
   };
 
+  // queue of (group, centroid) distance evaluations; a group's entries are adjacent, its minimum
+  // is carried across flushes and stored when the next group's first entry is replayed (or at the end)
+  uint32_t qc[4] = {0, 0, 0, 0}, qg[4] = {0, 0, 0, 0};
+  int qn = 0;
+  uint32_t carry_g = 0xFFFFFFFFu;
+  float carry_min = kFltMax;
+  auto store_carry = [&]() {
+    if (carry_g != 0xFFFFFFFFu && live && h == 0) a.bounds[(size_t)len * (1 + carry_g) + s] = carry_min;
+  };
+  auto flush = [&]() {  // wave-uniform call
+    const float *crow[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) crow[i] = a.centroids + (size_t)(i < qn ? qc[i] : 0) * D;
+    float dist[4];
+    exact_distance4<NK, METRIC, FAST>(xrow, crow, D, h, col, dist);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (i < qn) {
+        if (qg[i] != carry_g) {
+          store_carry();
+          carry_g = qg[i];
+          carry_min = kFltMax;
+        }
+        if (dist[i] < carry_min) carry_min = dist[i];   // kmeans.cu:477-481 (NaN never "less")
+      }
+    }
+    qn = 0;
+  };
+  auto enqueue = [&](uint32_t g, uint32_t c, bool on) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (on && i == qn) {
+        qc[i] = c;
+        qg[i] = g;
+      }
+    if (on) qn++;
+  };
+
+  // upper bound: exact distance to the row's own centroid (kmeans.cu:474-476); stays FLT_MAX if the
+  // row has none (NaN row) or its centroid is in no group (NaN centroid)
+  float upper = kFltMax;
+  {
+    const bool has = live && nearest < K && a.groups[nearest] < G;
+    if (__ballot(has) != 0ull) {
+      const float *crow[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) crow[i] = a.centroids + (size_t)(has ? nearest : 0) * D;
+      float dist[4];
+      exact_distance4<NK, METRIC, FAST>(xrow, crow, D, h, col, dist);
+      if (has) upper = dist[0];
+    }
+  }
+
   // running top-3 (by score = smallest distance first) of the CURRENT group in this half-wave
   float v1 = -INFINITY, v2 = -INFINITY, v3 = -INFINITY;
   uint32_t c1 = 0xFFFFFFFFu, c2 = 0xFFFFFFFFu;
@@ -419,40 +513,53 @@ __global__ __launch_bounds__(256, 2) void yy_init_mfma_kernel(YyArgs a) {
   };
   auto finalize_group = [&]() {  // wave-uniform call
     if (cur_group == 0xFFFFFFFFu) return;
-    // merge the partner half-wave's top-3
-    {
+    {  // merge the partner half-wave's top-3
       const float pv1 = __shfl_xor(v1, 32), pv2 = __shfl_xor(v2, 32), pv3 = __shfl_xor(v3, 32);
       const uint32_t pc1 = __shfl_xor(c1, 32), pc2 = __shfl_xor(c2, 32);
       insert(pv1, pc1);
       insert(pv2, pc2);
       insert(pv3, 0xFFFFFFFFu);
     }
-    float gmin = 3.402823466e+38f;
     const bool has1 = live && c1 != 0xFFFFFFFFu;
     const bool sure1 = has1 && ((v1 - v2) > thr);                      // NaN gap => not sure
     const bool sure2 = has1 && !sure1 && c2 != 0xFFFFFFFFu && ((v1 - v3) > thr);
     const bool scan = has1 && !sure1 && !sure2;
-    if (__ballot(has1 && !scan) != 0ull) {
-      const bool on = has1 && !scan;
-      const float d = exact_distance_split<NK, METRIC, FAST>(xrow, a.centroids + (size_t)(on ? c1 : 0) * D, D, h, col);
-      if (on && d < gmin) gmin = d;
-    }
-    if (__ballot(sure2) != 0ull) {
-      const float d = exact_distance_split<NK, METRIC, FAST>(xrow, a.centroids + (size_t)(sure2 ? c2 : 0) * D, D, h,
-                                                             col);
-      if (sure2 && d < gmin) gmin = d;
-    }
-    if (__ballot(scan) != 0ull) {  // three or more contenders: every member of the group, exactly
-      const uint32_t gb = a.gstart[cur_group], ge = a.gstart[cur_group + 1];
-      for (uint32_t i = gb; i < ge; i++) {
-        const uint32_t c = a.cperm[i];
-        const bool on = scan && c != nearest;
-        if (__ballot(on) == 0ull) continue;
-        const float d = exact_distance_split<NK, METRIC, FAST>(xrow, a.centroids + (size_t)c * D, D, h, col);
-        if (on && d < gmin) gmin = d;
+    if (__ballot(qn > 2) != 0ull) flush();                              // room for two more everywhere
+    if (!has1) {
+      // no member other than the row's own centroid (or an empty group): the bound stays FLT_MAX.
+      // Replayed through the carry so that the store order stays one group at a time.
+      if (carry_g != cur_group) {
+        store_carry();
+        carry_g = cur_group;
+        carry_min = kFltMax;
       }
     }
-    if (live && h == 0) a.bounds[(size_t)len * (1 + cur_group) + s] = gmin;
+    enqueue(cur_group, c1, has1 && !scan);
+    enqueue(cur_group, c2, sure2);
+    if (__ballot(scan) != 0ull) {  // three or more contenders: every member of the group, exactly
+      flush();
+      if (scan && carry_g != cur_group) {
+        store_carry();
+        carry_g = cur_group;
+        carry_min = kFltMax;
+      }
+      const uint32_t gb = a.gstart[cur_group], ge = a.gstart[cur_group + 1];
+      for (uint32_t i0 = gb; i0 < ge; i0 += 4) {
+        const float *crow[4];
+        bool on[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const uint32_t c = (i0 + i < ge) ? a.cperm[i0 + i] : a.cperm[gb];
+          on[i] = scan && (i0 + i < ge) && c != nearest;
+          crow[i] = a.centroids + (size_t)c * D;
+        }
+        float dist[4];
+        exact_distance4<NK, METRIC, FAST>(xrow, crow, D, h, col, dist);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (on[i] && dist[i] < carry_min) carry_min = dist[i];
+      }
+    }
     v1 = v2 = v3 = -INFINITY;
     c1 = c2 = 0xFFFFFFFFu;
   };
@@ -487,8 +594,9 @@ __global__ __launch_bounds__(256, 2) void yy_init_mfma_kernel(YyArgs a) {
     __syncthreads();
   }
   finalize_group();
+  if (__ballot(qn > 0) != 0ull) flush();
+  store_carry();
   if (live && h == 0) a.bounds[s] = upper;
-  (void)K;
 }
 
 // group-sorted padded panel from the centred panel of centroid_prep
