@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--features", type=int, default=256)
     ap.add_argument("--clusters", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
+                    help="f32: the headline fp32 L2 path.  f16: the fp16x2 path (rows as halves, f16 matrix-core "
+                         "filter; same assignments as the fp32 path on the same values)")
     args = ap.parse_args()
 
     import torch
@@ -126,7 +129,11 @@ def main():
     for s in range(0, n_local, chunk):
         e = min(n_local, s + chunk)
         samples[s:e].uniform_(0.0, 1.0, generator=gen)
-    backend = HipBackend(samples, K, "L2", device_index=local_rank)
+    half = None
+    if args.dtype == "f16":
+        half = samples.to(torch.float16)
+        samples = half.to(torch.float32)
+    backend = HipBackend(samples, K, "L2", device_index=local_rank, half_rows=half)
     loop = ShardedLloyd(backend, N)
     # init="random": K sample rows of rank 0 (replicated by broadcast)
     perm = torch.randperm(n_local, generator=gen, device=dev)[:K]
@@ -166,19 +173,22 @@ def main():
         filter_ms = prof["filter_ms"] / launches
         flops = 2.0 * D * K * n_local                      # algorithmic flop of one filter launch
         achieved = flops / (filter_ms * 1e-3) / 1e12 if filter_ms > 0 else 0.0
+        f16 = args.dtype == "f16"
+        peak = 2500.0 if f16 else PEAK_FP32_MFMA_TFLOPS   # dense f16 MFMA / f32 MFMA (MI355X_MICROARCH.md)
         out = {
             "metric": "point-assignments/sec per Lloyd iter (8Mx256@1024)",
             "value": value, "unit": "point-assignments/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%dx%d fp32 L2 Lloyd iteration, K=%d, uniform[0,1) rows, init=random; "
-                                   "rows sharded %d-way" % (N, D, K, world),
+            "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "%dx%d %s L2 Lloyd iteration, K=%d, uniform[0,1) rows, init=random; "
+                                   "rows sharded %d-way" % (N, D, "fp16x2" if f16 else "fp32", K, world),
                        "samples": N, "features": D, "clusters": K, "parallelism": "rows/%d" % world},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": pmc_traffic(n_local), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
-                         "algorithmic_bytes": n_local * (D * 4 + 4), "algorithmic_flop": flops,
-                         "kernel": "lloyd_filter_kernel<256,true>",
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": None if f16 else pmc_traffic(n_local),
+                         "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+                         "algorithmic_bytes": n_local * (D * (2 if f16 else 4) + 4), "algorithmic_flop": flops,
+                         "kernel": "lloyd_filter_f16_kernel<256>" if f16 else "lloyd_filter_kernel<256,true>",
                          "kernel_ms": filter_ms, "rows_per_launch": n_local},
             "breakdown_ms_per_step": {"filter": filter_ms, "exact_refine": prof["exact_ms"] / launches,
                                       "update": prof["update_ms"] / launches},

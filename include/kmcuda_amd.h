@@ -38,6 +38,13 @@ int kmamd_lloyd_assign(kmamd_engine *e, const float *samples, const float *centr
 int kmamd_lloyd_assign_exact(kmamd_engine *e, const float *samples, const float *centroids,
                              uint32_t *assignments, uint32_t *assignments_prev);
 
+/* fp16x2 path: the engine's local rows as IEEE halves (n_rows x features halves, row-major, kept
+ * alive by the caller).  When set (and features is one of 16..256, power of two), kmamd_lloyd_assign
+ * runs its filter on the f16 matrix cores reading these rows; `samples` must still point to the
+ * same values widened to fp32 (the exact refine kernels read them).  Assignments are unchanged:
+ * bit-identical to the fp32 path on the widened values.  NULL switches back. */
+int kmamd_set_half_rows(kmamd_engine *e, const void *rows16);
+
 /* counters: [0] reassigned rows since the last reset (d_changed_number, kmeans.cu:31),
  * [1] rows the filter handed to the full exact scan, [2] Yinyang passed rows (d_passed_number),
  * [3] rows the filter narrowed to two contenders (pair refine).  read = sync + copy to a host array; reset zeroes [0..3] (or one of them). */

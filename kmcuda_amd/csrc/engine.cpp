@@ -260,7 +260,18 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   KMX_HIP(hipMemsetAsync(counters_ + 1, 0, sizeof(uint32_t), stream_), kRuntimeError);
   KMX_HIP(hipMemsetAsync(counters_ + 3, 0, sizeof(uint32_t), stream_), kRuntimeError);
   span_begin(0);
-  KMX_HIP(launch_lloyd_filter(a, stream_), kRuntimeError);
+  if (half_rows_ && lloyd_filter_f16_supported(D_, DP_)) {
+    if (!panel16_) {
+      uint16_t *p16 = nullptr;
+      int rc = alloc(&p16, (size_t)K_pad_ * 2 * DP_);
+      if (rc) return rc;
+      panel16_ = p16;
+    }
+    KMX_HIP(launch_centroid_panel16(centroids, K_, D_, K_pad_, DP_, finite_, mu_, panel16_, stream_), kRuntimeError);
+    KMX_HIP(launch_lloyd_filter_f16(a, half_rows_, panel16_, stream_), kRuntimeError);
+  } else {
+    KMX_HIP(launch_lloyd_filter(a, stream_), kRuntimeError);
+  }
   span_end();
   span_begin(1);
   KMX_HIP(launch_lloyd_pair(metric_, a, centroids, (N_ + 127) / 128 < 2048u ? (N_ + 127) / 128 : 2048u, stream_),
@@ -375,6 +386,10 @@ int kmamd_move_deltas(kmamd_engine *e, const float *samples, const uint32_t *ass
 int kmamd_apply_delta(kmamd_engine *e, const double *delta, const int32_t *dcount, float *centroids,
                       uint32_t *ccounts) {
   return e->e.apply_delta(delta, dcount, centroids, ccounts);
+}
+int kmamd_set_half_rows(kmamd_engine *e, const void *rows16) {
+  e->e.half_rows_ = rows16;
+  return kmx::kSuccess;
 }
 int kmamd_adjust_exact(kmamd_engine *e, const float *samples, const uint32_t *assignments_prev,
                        const uint32_t *assignments, float *centroids, uint32_t *ccounts) {

@@ -74,6 +74,9 @@ class Engine {
   // assignment workspace
   float *csqr_ = nullptr, *bias_ = nullptr, *bias2_ = nullptr, *cfil_ = nullptr, *ct_ = nullptr, *mu_ = nullptr;
   uint32_t *finite_ = nullptr;
+  // fp16x2 path: the local rows as halves (caller-owned) + the hi/lo-split centred centroid panel
+  const void *half_rows_ = nullptr;
+  void *panel16_ = nullptr;
   uint32_t *stats_ = nullptr, *flagged_ = nullptr, *pairs_ = nullptr, *counters_ = nullptr;
   // update workspace
   uint32_t *keys_tmp_ = nullptr, *vals_tmp_ = nullptr, *keys_sorted_ = nullptr, *rows_sorted_ = nullptr,

@@ -189,9 +189,10 @@ class Job {
         }
         hipError_t e = launch_half_to_float(dev_half, n, buf, sh->eng->stream_);
         if (e == hipSuccess) e = hipStreamSynchronize(sh->eng->stream_);
-        if (tmp) (void)hipFree(tmp);
+        if (tmp) sh->owned.push_back(tmp);  // kept: the f16 matrix-core filter reads the rows as halves
         if (e != hipSuccess) return kmcudaRuntimeError;
         sh->samples = buf;
+        sh->eng->half_rows_ = dev_half;
       } else if (device_ptrs >= 0 && device_ptrs == sh->dev) {
         sh->samples = src;  // already resident, used in place and never modified
       } else {

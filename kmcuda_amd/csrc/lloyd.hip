@@ -21,6 +21,7 @@
 // Assignments are therefore bit-identical to the reference's for ANY input; only the split of
 // work between 2 and 3 depends on the data.  See DESIGN.md for the bound's derivation.
 #include "exact.hpp"
+#include "filter_common.hpp"
 #include "kernels.hpp"
 
 namespace kmx {
@@ -136,20 +137,6 @@ __global__ void centroid_panel_kernel(const float *__restrict__ centroids, uint3
     bias2[c] = -INFINITY;
     for (uint32_t f = 0; f < DP; f++) dst[f] = 0.f;
   }
-}
-
-// ---------------------------------------------------------------------------------------
-// commit (kmeans.cu:358-363): prev[s] = old; if old != nearest { assign; ++changed }
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ bool commit_row(uint32_t s, uint32_t nearest, uint32_t *__restrict__ assignments,
-                                           uint32_t *__restrict__ assignments_prev) {
-  const uint32_t old = assignments[s];
-  assignments_prev[s] = old;
-  if (old != nearest) {
-    assignments[s] = nearest;
-    return true;
-  }
-  return false;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -326,73 +313,16 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_kernel(
     __syncthreads();
   }
 
-  // ---- merge the two half-waves (same sample, disjoint centroid rows) ----
-  auto decode = [&](uint32_t code, int half) -> uint32_t {
-    if (code == 0xFFFFFFFFu) return 0xFFFFFFFFu;
-    const uint32_t r = code & 15u;
-    return (code >> 4) * 32u + (r & 3u) + 8u * (r >> 2) + 4u * half;
-  };
-  uint32_t i1 = decode(c1, h), i2 = decode(c2, h);
-  {
-    const float pv1 = __shfl_xor(v1, 32), pv2 = __shfl_xor(v2, 32), pv3 = __shfl_xor(v3, 32);
-    const uint32_t pi1 = __shfl_xor(i1, 32), pi2 = __shfl_xor(i2, 32);
-    auto insert = [&](float v, uint32_t idx) {
-      const bool g1 = v > v1, g2 = v > v2, g3 = v > v3;
-      v3 = g2 ? v2 : (g3 ? v : v3);
-      i2 = g1 ? i1 : (g2 ? idx : i2);
-      v2 = g1 ? v1 : (g2 ? v : v2);
-      i1 = g1 ? idx : i1;
-      v1 = g1 ? v : v1;
-    };
-    insert(pv1, pi1);
-    insert(pv2, pi2);
-    insert(pv3, 0xFFFFFFFFu);  // can only land in third place
-  }
-
-  // ---- decide ----
-  // |score_filter - score_ref| <= E for every centroid, up to a term constant in c:
-  //   E_mfma = 2 eps (||x'|| C'max + B'max)   MFMA chain + centring roundings, centred magnitudes
-  //   E_ref  = u (12 ||x|| Cmax + 4 Cmax^2)    the reference's own Kahan / round-down rounding
-  //   v1 - v2 > 2E : the reference's distance to i1 is strictly the smallest -> commit
-  //   v1 - v3 > 2E : the minimum is i1 or i2 -> two exact Kahan distances settle it (pair list)
-  //   otherwise    : three or more contenders -> full exact scan (flagged list)
+  // ---- merge the half-waves, decide, commit / hand over (filter_common.hpp) ----
   const float cmaxc = sqrtf(__uint_as_float(stats[0])) * 1.000001f;
   const float bmaxc = __uint_as_float(stats[1]);
   const float cmaxo = sqrtf(__uint_as_float(stats[2])) * 1.000001f;
   const float xn = sqrtf(xn2) * 1.0001f, xo = sqrtf(xo2) * 1.0001f;
-  const float u = 5.9604645e-8f;
   const float e_mfma = 2.0f * eps * (xn * cmaxc + bmaxc);
-  const float e_ref = u * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
+  const float e_ref = 5.9604645e-8f * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
   const float thr = 2.0f * (e_mfma + e_ref) * 1.001f + tie_slack;
-  const bool certain = insane || ((v1 - v2) > thr);  // NaN gap / NaN thr => not certain
-  const bool two = !certain && ((v1 - v3) > thr) && i2 != 0xFFFFFFFFu;
-  const bool mine = (h == 0) && (s < N);
-  const bool commit_now = mine && certain;
-  const bool pair_now = mine && two;
-  const bool flag_now = mine && !certain && !two;
-  bool changed = false;
-  if (commit_now) changed = commit_row(s, insane ? K : i1, assignments, assignments_prev);
-  const unsigned long long cm = __ballot(changed);
-  const unsigned long long pm = __ballot(pair_now);
-  const unsigned long long fm = __ballot(flag_now);
-  if (lane == 0 && cm) atomicAdd(&counters[0], (uint32_t)__popcll(cm));
-  if (pm) {
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&counters[3], (uint32_t)__popcll(pm));
-    base = __shfl(base, 0);
-    if (pair_now) {
-      const uint32_t slot = base + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
-      pairs[3 * (size_t)slot + 0] = s;
-      pairs[3 * (size_t)slot + 1] = i1;
-      pairs[3 * (size_t)slot + 2] = i2;
-    }
-  }
-  if (fm) {
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&counters[1], (uint32_t)__popcll(fm));
-    base = __shfl(base, 0);
-    if (flag_now) flagged[base + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = s;
-  }
+  filter_finish(v1, v2, v3, c1, c2, h, lane, s, N, K, insane, thr, assignments, assignments_prev, flagged, pairs,
+                counters);
 }
 
 // ---------------------------------------------------------------------------------------

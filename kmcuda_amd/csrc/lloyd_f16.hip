@@ -1,0 +1,220 @@
+// lloyd_f16.hip -- the Lloyd assignment filter for the fp16x2 path (reference:
+// src/kmeans.cu:293-364 with F = half2, src/fp_abstraction.h:100-182) on the f16 matrix cores.
+//
+// fp16x2 semantics of this implementation: the fp32 reference arithmetic on the half
+// VALUES.  So the decision this filter has to reproduce is exactly the fp32 path's on the widened
+// rows -- and the same filter-and-refine contract holds: rows the filter cannot decide go to the
+// exact kernels of lloyd.hip (which read the widened fp32 copy), assignments are bit-identical to
+// the fp32 path's on the same values.  What changes is the matrix-core rate and the HBM bytes:
+//
+//   * rows are read as HALVES (512 B instead of 1 KB at D = 256);
+//   * operands are CENTRED in fp32 (x' = x - mu, c' = c - mu: the centred bound, lloyd.hip) and
+//     split into two halves each, a = a_hi + a_lo + r, |r| <= 2^-22 |a| + 2^-25, so that
+//         x'.c' ~= x_hi.c_hi + x_hi.c_lo + x_lo.c_hi
+//     with every product exact in the fp32 accumulator of v_mfma_f32_32x32x16_f16: three f16 MFMAs
+//     (16 features each, 32 cycles) replace eight f32 MFMAs (2 features each, 64 cycles) -- 5.3x
+//     fewer matrix-pipe cycles per (row, centroid) pair;
+//   * the dropped lo.lo term and the split residuals are part of the error bound E.
+//
+// Layout: identical to the f32 filter (4 waves x 32 rows per block, 32-centroid tiles double
+// buffered in LDS, the lower half-wave contracts features [0, DP/2), the upper [DP/2, DP)); a panel
+// row holds DP hi halves followed by DP lo halves = the same 4*DP bytes as an f32 row.
+#include <hip/hip_fp16.h>
+
+#include "exact.hpp"
+#include "filter_common.hpp"
+#include "kernels.hpp"
+
+namespace kmx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// c' = c - mu split into halves: panel16[c] = [hi(c'_0..DP-1) | lo(c'_0..DP-1)]; zero rows for
+// non-finite / padding centroids (their bias is -inf in the shared bias array).
+__global__ void centroid_panel16_kernel(const float *__restrict__ centroids, uint32_t K, uint32_t D, uint32_t K_pad,
+                                        uint32_t DP, const uint32_t *__restrict__ finite,
+                                        const float *__restrict__ mu, _Float16 *__restrict__ panel16) {
+  const uint32_t c = blockIdx.x;
+  if (c >= K_pad) return;
+  _Float16 *dst = panel16 + (size_t)c * 2 * DP;
+  const bool ok = c < K && finite[c];
+  for (uint32_t f = threadIdx.x; f < DP; f += blockDim.x) {
+    float v = 0.f;
+    if (ok && f < D) v = centroids[(size_t)c * D + f] - mu[f];
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    dst[f] = hi;
+    dst[DP + f] = lo;
+  }
+}
+
+template <int DP>
+__global__ __launch_bounds__(256, 2) void lloyd_filter_f16_kernel(
+    const _Float16 *__restrict__ rows16, uint32_t N, const float *__restrict__ panel16f,
+    const float *__restrict__ bias, const float *__restrict__ mu, uint32_t K_pad, uint32_t K,
+    const uint32_t *__restrict__ stats, float eps, float tie_slack, uint32_t *__restrict__ assignments,
+    uint32_t *__restrict__ assignments_prev, uint32_t *__restrict__ flagged, uint32_t *__restrict__ pairs,
+    uint32_t *__restrict__ counters) {
+  constexpr int NKH = DP / 2;          // features per half-wave
+  constexpr int KS = NKH / 8;          // k-steps (8 features per lane per MFMA)
+  constexpr int LDW = DP + 4;          // padded LDS row in 4-byte words (row = 2*DP halves)
+  constexpr int TILE = 32 * LDW;
+  constexpr int NST = (8 * DP + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  auto tile_ptr = [&](int buf) { return lds + buf * TILE; };
+  auto bias_ptr = [&](int buf) { return lds + 2 * TILE + buf * 32; };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+  const uint32_t s = blockIdx.x * 128u + wave * 32u + col;
+  const bool live = s < N;
+
+  // ---- B operand: my half row, centred in fp32, split into hi / lo halves ----
+  f16x8 xhi[KS], xlo[KS];
+  float xn2 = 0.f, xo2 = 0.f, x0 = 0.f;
+  {
+    const f16x8 *src = reinterpret_cast<const f16x8 *>(rows16 + (size_t)(live ? s : 0) * DP + h * NKH);
+    const float *m = mu + h * NKH;
+#pragma unroll
+    for (int j = 0; j < KS; j++) {
+      const f16x8 raw = src[j];
+      f16x8 hi, lo;
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const float x = live ? (float)raw[q] : 0.f;
+        const float xc = live ? x - m[8 * j + q] : 0.f;
+        const _Float16 a = (_Float16)xc;
+        hi[q] = a;
+        lo[q] = (_Float16)(xc - (float)a);
+        xo2 = fmaf(x, x, xo2);
+        xn2 = fmaf(xc, xc, xn2);
+        if (j == 0 && q == 0) x0 = x;
+      }
+      xhi[j] = hi;
+      xlo[j] = lo;
+    }
+  }
+  xn2 += __shfl_xor(xn2, 32);
+  xo2 += __shfl_xor(xo2, 32);
+  x0 = __shfl(x0, col);  // feature 0 lives in the lower half-wave
+  const bool insane = (x0 != x0);  // kmeans.cu:312
+
+  // ---- staging of panel tiles: byte-identical to the f32 filter's ----
+  f32x4 stage[NST];
+  float bstage = 0.f;
+  auto stage_load = [&](uint32_t tile) {
+    const float *src = panel16f + (size_t)tile * 32 * DP;
+#pragma unroll
+    for (int i = 0; i < NST; i++) {
+      const int q = tid + i * 256;
+      if (q < 8 * DP) stage[i] = reinterpret_cast<const f32x4 *>(src)[q];
+    }
+    if (tid < 32) bstage = bias[tile * 32 + tid];
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NST; i++) {
+      const int q = tid + i * 256;
+      if (q < 8 * DP) {
+        const int row = q / (DP / 4), c4 = q % (DP / 4);
+        *reinterpret_cast<f32x4 *>(tile_ptr(buf) + row * LDW + c4 * 4) = stage[i];
+      }
+    }
+    if (tid < 32) bias_ptr(buf)[tid] = bstage;
+  };
+
+  const uint32_t ntiles = K_pad / 32;
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+
+  float v1 = -INFINITY, v2 = -INFINITY, v3 = -INFINITY;
+  uint32_t c1 = 0xFFFFFFFFu, c2 = 0xFFFFFFFFu;
+  for (uint32_t t = 0; t < ntiles; t++) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) stage_load(t + 1);
+    f32x16 acc;
+    {
+      const float *bb = bias_ptr(buf) + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bb + 8 * g);
+        acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
+      }
+    }
+    // my centroid row of the tile: hi halves at [0, DP), lo halves at [DP, 2 DP)
+    const _Float16 *arow = reinterpret_cast<const _Float16 *>(tile_ptr(buf) + col * LDW) + h * NKH;
+#pragma unroll
+    for (int j = 0; j < KS; j++) {
+      const f16x8 ahi = *reinterpret_cast<const f16x8 *>(arow + 8 * j);
+      const f16x8 alo = *reinterpret_cast<const f16x8 *>(arow + DP + 8 * j);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, xhi[j], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, xhi[j], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, xlo[j], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float v = acc[r];
+      const uint32_t code = t * 16u + r;
+      const bool g1 = v > v1, g2 = v > v2, g3 = v > v3;
+      v3 = g2 ? v2 : (g3 ? v : v3);
+      c2 = g1 ? c1 : (g2 ? code : c2);
+      v2 = g1 ? v1 : (g2 ? v : v2);
+      c1 = g1 ? code : c1;
+      v1 = g1 ? v : v1;
+    }
+    if (t + 1 < ntiles) stage_store(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- decide: the f32 filter's bound plus the hi/lo split terms ----
+  //   accumulation of 3 DP exact products + bias in fp32:       gamma_{3DP+1} (||x'|| C'max + B'max)
+  //   dropped lo.lo and split residuals (|r| <= 2^-22|a| + 2^-25): 3 * 2^-22 ||x'|| C'max
+  //                                                              + 2^-25 sqrt(DP) (||x'|| + C'max)
+  const float cmaxc = sqrtf(__uint_as_float(stats[0])) * 1.000001f;
+  const float bmaxc = __uint_as_float(stats[1]);
+  const float cmaxo = sqrtf(__uint_as_float(stats[2])) * 1.000001f;
+  const float xn = sqrtf(xn2) * 1.0001f, xo = sqrtf(xo2) * 1.0001f;
+  const float u = 5.9604645e-8f;
+  const float e_mfma = 2.0f * (3.0f * eps) * (xn * cmaxc + bmaxc) + 12.0f * u * xn * cmaxc +
+                       2.9802322e-8f * sqrtf((float)DP) * (xn + cmaxc);
+  const float e_ref = u * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
+  const float thr = 2.0f * (e_mfma + e_ref) * 1.001f + tie_slack;
+  filter_finish(v1, v2, v3, c1, c2, h, lane, s, N, K, insane, thr, assignments, assignments_prev, flagged, pairs,
+                counters);
+}
+
+hipError_t launch_centroid_panel16(const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP,
+                                   const uint32_t *finite, const float *mu, void *panel16, hipStream_t st) {
+  hipLaunchKernelGGL(centroid_panel16_kernel, dim3(K_pad), dim3(DP >= 256 ? 256 : 64), 0, st, centroids, K, D, K_pad,
+                     DP, finite, mu, reinterpret_cast<_Float16 *>(panel16));
+  return hipGetLastError();
+}
+
+template <int DP>
+static hipError_t launch_f16_dp(const LloydArgs &a, const void *rows16, const void *panel16, hipStream_t st) {
+  const size_t lds_bytes = (2 * 32 * (DP + 4) + 64) * sizeof(float);
+  const uint32_t grid = (a.N + 127) / 128;
+  hipLaunchKernelGGL((lloyd_filter_f16_kernel<DP>), dim3(grid), dim3(256), lds_bytes, st,
+                     reinterpret_cast<const _Float16 *>(rows16), a.N, reinterpret_cast<const float *>(panel16), a.bias,
+                     a.mu, a.K_pad, a.K, a.stats, a.eps, a.tie_slack, a.assignments, a.assignments_prev, a.flagged,
+                     a.pairs, a.counters);
+  return hipGetLastError();
+}
+
+// only whole rows of halves with D == DP, DP >= 16 (one MFMA consumes 8 features per half-wave)
+bool lloyd_filter_f16_supported(uint32_t D, uint32_t DP) { return D == DP && DP >= 16; }
+
+hipError_t launch_lloyd_filter_f16(const LloydArgs &a, const void *rows16, const void *panel16, hipStream_t st) {
+  switch (a.DP) {
+    case 16: return launch_f16_dp<16>(a, rows16, panel16, st);
+    case 32: return launch_f16_dp<32>(a, rows16, panel16, st);
+    case 64: return launch_f16_dp<64>(a, rows16, panel16, st);
+    case 128: return launch_f16_dp<128>(a, rows16, panel16, st);
+    case 256: return launch_f16_dp<256>(a, rows16, panel16, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace kmx

@@ -24,7 +24,10 @@ def row_block(n_total, rank, world):
 class HipBackend:
     """This rank's rows on its GPU; all compute is libKMCUDA.so kernels."""
 
-    def __init__(self, samples, clusters, metric="L2", device_index=0):
+    def __init__(self, samples, clusters, metric="L2", device_index=0, half_rows=None):
+        """half_rows: the same rows as a float16 tensor (fp16x2 path): the assignment filter then runs
+        on the f16 matrix cores reading the halves; `samples` stays the widened fp32 copy the exact
+        refine / update kernels read."""
         from .engine import Engine
         assert samples.is_cuda and samples.dtype == torch.float32 and samples.is_contiguous()
         self.samples = samples
@@ -32,6 +35,10 @@ class HipBackend:
         self.clusters = clusters
         self.device = samples.device
         self.engine = Engine(self.n_local, self.features, clusters, metric, device=device_index)
+        if half_rows is not None:
+            assert half_rows.dtype == torch.float16 and half_rows.shape == samples.shape and half_rows.is_contiguous()
+            self.engine.set_half_rows(half_rows)
+        self.half = half_rows is not None
         i32 = dict(dtype=torch.int32, device=self.device)
         self.assignments = torch.full((self.n_local,), -1, **i32)   # 0xFFFFFFFF (prepare_mem)
         self.assignments_prev = torch.full((self.n_local,), -1, **i32)
@@ -58,6 +65,8 @@ class HipBackend:
         kd = self.clusters * self.features
         self.engine.unpack_dcount(buf[kd:], self.dcount)
         self.engine.apply_delta(buf, self.dcount, self.centroids, self.ccounts)
+        if self.half:   # fp16x2: centroids live in half2 in the reference -> rounded after every update
+            self.centroids.copy_(self.centroids.to(torch.float16).to(torch.float32))
 
     def synchronize(self):
         torch.cuda.synchronize(self.device)

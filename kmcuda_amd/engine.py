@@ -56,6 +56,12 @@ class Engine:
         _lib.check(fn(self.h, self._p(samples), self._p(centroids), self._p(assignments), self._p(assignments_prev)),
                    "kmamd_lloyd_assign")
 
+    def set_half_rows(self, rows16):
+        """rows16: float16 CUDA tensor with the same values as the fp32 rows (or None)."""
+        self._half_rows = rows16  # keep alive
+        _lib.check(self.lib.kmamd_set_half_rows(self.h, self._p(rows16) if rows16 is not None else None),
+                   "kmamd_set_half_rows")
+
     def counters(self):
         out = (ctypes.c_uint32 * 4)()
         _lib.check(self.lib.kmamd_counters_read(self.h, out), "kmamd_counters_read")

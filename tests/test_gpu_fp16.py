@@ -153,3 +153,43 @@ def test_fp16_knn(fixture13k):
     assert (nb != bn).sum() < 500
     ref, _ = oracle.knn(10, samples.astype(numpy.float32), cen.astype(numpy.float32), asg)
     assert (nb == ref).all()
+
+
+@pytest.mark.parametrize("n,d,k,metric", [(5000, 256, 1024, "L2"), (3000, 64, 100, "L2"), (2000, 16, 33, "L2"),
+                                          (4096, 128, 257, "L2"), (3000, 256, 64, "cos")])
+def test_f16_matrix_core_filter_bit_exact(n, d, k, metric):
+    """The f16-MFMA Lloyd filter (rows read as halves, centred hi/lo-split operands) + the shared
+    exact refine kernels: assignments bit-identical to the oracle on the widened values, and to the
+    f32-MFMA filter on the same values."""
+    from kmcuda_amd.engine import Engine
+    dev = torch.device("cuda", 0)
+    rs = numpy.random.RandomState(n + d + k)
+    x16 = rs.rand(n, d).astype(numpy.float16)
+    if metric == "cos":
+        x32n = x16.astype(numpy.float32)
+        x16 = (x32n / numpy.linalg.norm(x32n, axis=1)[:, None]).astype(numpy.float16)
+    x32 = x16.astype(numpy.float32)
+    c = x32[rs.choice(n, k, replace=False)].copy()
+    c[3] = c[1]                       # duplicate centroid: exact tie
+    m = oracle.COS if metric == "cos" else oracle.L2
+    ref, ref_prev, ref_changed = oracle.lloyd_assign(x32, c, metric=m)
+    xs32, xs16, cs = torch.from_numpy(x32).to(dev), torch.from_numpy(x16).to(dev), torch.from_numpy(c).to(dev)
+
+    def run(use_half):
+        asg = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        prev = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        eng = Engine(n, d, k, metric, device=0)
+        eng.set_half_rows(xs16 if use_half else None)
+        eng.lloyd_assign(xs32, cs, asg, prev)
+        counters = eng.counters()
+        eng.close()
+        return asg.cpu().numpy().view(numpy.uint32), counters
+
+    got16, c16 = run(True)
+    got32, c32 = run(False)
+    if metric == "cos":
+        assert (got16 != ref).mean() < 1e-3 and (got16 == got32).mean() > 0.999
+        return
+    assert (got16 == ref).all() and (got32 == ref).all()
+    assert c16[0] == ref_changed
+    assert c16[1] + c16[3] < 0.2 * n     # the filter itself decides the bulk of the rows
