@@ -98,6 +98,10 @@ def main():
     ap.add_argument("--features", type=int, default=256)
     ap.add_argument("--clusters", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--filter", default="f16", choices=["f16", "f32"],
+                    help="matrix-core instruction of the assignment filter: f16 = v_mfma_f32_32x32x16_f16 on centred "
+                         "hi/lo-split operands (default, fastest), f32 = v_mfma_f32_32x32x2_f32.  Assignments are "
+                         "bit-identical either way")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                     help="f32: the headline fp32 L2 path.  f16: the fp16x2 path (rows as halves, f16 matrix-core "
                          "filter; same assignments as the fp32 path on the same values)")
@@ -134,6 +138,7 @@ def main():
         half = samples.to(torch.float16)
         samples = half.to(torch.float32)
     backend = HipBackend(samples, K, "L2", device_index=local_rank, half_rows=half)
+    backend.engine.set_filter(args.filter)
     loop = ShardedLloyd(backend, N)
     # init="random": K sample rows of rank 0 (replicated by broadcast)
     perm = torch.randperm(n_local, generator=gen, device=dev)[:K]
@@ -155,6 +160,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = backend.engine.profile_read()
+    # outside the timed region: the OTHER filter on the same state, for the side-by-side roofline entry
+    other = "f32" if args.filter == "f16" else "f16"
+    backend.engine.set_filter(other)
+    backend.assign()
+    backend.engine.profile(True)
+    for _ in range(2):
+        backend.assign()
+    torch.cuda.synchronize(dev)
+    prof_other = backend.engine.profile_read()
+    backend.engine.set_filter(args.filter)
     backend.engine.profile(False)
     ctrs = backend.engine.counters()
     flagged = ctrs[1]
@@ -174,7 +189,19 @@ def main():
         flops = 2.0 * D * K * n_local                      # algorithmic flop of one filter launch
         achieved = flops / (filter_ms * 1e-3) / 1e12 if filter_ms > 0 else 0.0
         f16 = args.dtype == "f16"
-        peak = 2500.0 if f16 else PEAK_FP32_MFMA_TFLOPS   # dense f16 MFMA / f32 MFMA (MI355X_MICROARCH.md)
+
+        def roof(filt, ms):
+            # f32 filter: one v_mfma_f32_32x32x2_f32 MAC per algorithmic MAC -> the f32 MFMA peak.
+            # f16 filter: three f16 products per algorithmic MAC (hi.hi + hi.lo + lo.hi) -> the dense f16
+            # MFMA peak / 3 is the ceiling of the ALGORITHMIC rate (MI355X_MICROARCH.md: 157.3 / 2500 TFLOP/s)
+            pk = PEAK_FP32_MFMA_TFLOPS if filt == "f32" else 2500.0 / 3.0
+            ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            return pk, ach
+        peak, achieved = roof(args.filter, filter_ms)
+        other_ms = prof_other["filter_ms"] / max(prof_other["filter_launches"], 1)
+        opeak, oach = roof(other, other_ms)
+        kname = {"f16": "lloyd_filter_f16_kernel<256,%s,true>" % ("true" if f16 else "false"),
+                 "f32": "lloyd_filter_kernel<256,true>"}
         out = {
             "metric": "point-assignments/sec per Lloyd iter (8Mx256@1024)",
             "value": value, "unit": "point-assignments/s", "n_gpus": world, "steps": args.steps,
@@ -185,11 +212,16 @@ def main():
                        "samples": N, "features": D, "clusters": K, "parallelism": "rows/%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None if f16 else pmc_traffic(n_local),
+                         "traffic": pmc_traffic(n_local) if (args.filter == "f32" and not f16) else None,
                          "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
                          "algorithmic_bytes": n_local * (D * (2 if f16 else 4) + 4), "algorithmic_flop": flops,
-                         "kernel": "lloyd_filter_f16_kernel<256>" if f16 else "lloyd_filter_kernel<256,true>",
+                         "peak_note": "f32: dense f32 MFMA peak; f16: dense f16 MFMA peak / 3 (three half products "
+                                      "per algorithmic MAC of the hi/lo split)",
+                         "kernel": kname[args.filter],
                          "kernel_ms": filter_ms, "rows_per_launch": n_local},
+            "roofline_other_filter": {"filter": other, "kernel": kname[other], "kernel_ms": other_ms, "achieved": oach,
+                                      "peak": opeak, "unit": "TFLOP/s", "frac": oach / opeak,
+                                      "note": "same rows and centroids, timed outside the timed region"},
             "breakdown_ms_per_step": {"filter": filter_ms, "exact_refine": prof["exact_ms"] / launches,
                                       "update": prof["update_ms"] / launches},
             "rows_full_exact_scan_last_step": flagged, "rows_pair_refined_last_step": pair_rows, "reassigned_last_step": changed_last,

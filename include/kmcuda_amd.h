@@ -38,9 +38,15 @@ int kmamd_lloyd_assign(kmamd_engine *e, const float *samples, const float *centr
 int kmamd_lloyd_assign_exact(kmamd_engine *e, const float *samples, const float *centroids,
                              uint32_t *assignments, uint32_t *assignments_prev);
 
+/* Which matrix-core instruction the assignment filter runs on: 0 = f16 MFMA on centred hi/lo-split
+ * operands (default; 22 of 24 significand bits, rigorous bound, ~2.4x the f32 MFMA rate), 1 = f32
+ * MFMA.  Assignments are bit-identical either way (the exact kernels decide what the filter cannot);
+ * env KMCUDA_AMD_FILTER=f32 selects 1 at engine creation. */
+int kmamd_set_filter(kmamd_engine *e, int mode);
+
 /* fp16x2 path: the engine's local rows as IEEE halves (n_rows x features halves, row-major, kept
- * alive by the caller).  When set (and features is one of 16..256, power of two), kmamd_lloyd_assign
- * runs its filter on the f16 matrix cores reading these rows; `samples` must still point to the
+ * alive by the caller).  When set, the f16 matrix-core filter of kmamd_lloyd_assign reads these rows
+ * (half the HBM bytes) instead of the fp32 ones; `samples` must still point to the
  * same values widened to fp32 (the exact refine kernels read them).  Assignments are unchanged:
  * bit-identical to the fp32 path on the widened values.  NULL switches back. */
 int kmamd_set_half_rows(kmamd_engine *e, const void *rows16);

@@ -24,6 +24,7 @@ Engine::~Engine() {
 
 int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric, int fp16x2, hipStream_t stream) {
   if (getenv("KMCUDA_AMD_DEBUG")) g_verbosity = atoi(getenv("KMCUDA_AMD_DEBUG"));
+  if (const char *f = getenv("KMCUDA_AMD_FILTER")) filter_mode_ = (strcmp(f, "f32") == 0) ? 1 : 0;
   if (D == 0 || K < 1 || K >= 0x7FFFFFFFu) return kInvalidArguments;  // K == 1: Yinyang group clustering with one group
   if (fp16x2) return kInvalidArguments;  // fp16x2 kernels are not built yet ("next")
   int ndev = 0;
@@ -260,7 +261,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   KMX_HIP(hipMemsetAsync(counters_ + 1, 0, sizeof(uint32_t), stream_), kRuntimeError);
   KMX_HIP(hipMemsetAsync(counters_ + 3, 0, sizeof(uint32_t), stream_), kRuntimeError);
   span_begin(0);
-  if (half_rows_ && lloyd_filter_f16_supported(D_, DP_)) {
+  if (filter_mode_ == 0 && lloyd_filter_f16_supported(D_, DP_)) {
     if (!panel16_) {
       uint16_t *p16 = nullptr;
       int rc = alloc(&p16, (size_t)K_pad_ * 2 * DP_);
@@ -268,7 +269,9 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
       panel16_ = p16;
     }
     KMX_HIP(launch_centroid_panel16(centroids, K_, D_, K_pad_, DP_, finite_, mu_, panel16_, stream_), kRuntimeError);
-    KMX_HIP(launch_lloyd_filter_f16(a, half_rows_, panel16_, stream_), kRuntimeError);
+    KMX_HIP(launch_lloyd_filter_f16(a, half_rows_ ? half_rows_ : (const void *)samples, half_rows_ != nullptr,
+                                    panel16_, stream_),
+            kRuntimeError);
   } else {
     KMX_HIP(launch_lloyd_filter(a, stream_), kRuntimeError);
   }
@@ -386,6 +389,11 @@ int kmamd_move_deltas(kmamd_engine *e, const float *samples, const uint32_t *ass
 int kmamd_apply_delta(kmamd_engine *e, const double *delta, const int32_t *dcount, float *centroids,
                       uint32_t *ccounts) {
   return e->e.apply_delta(delta, dcount, centroids, ccounts);
+}
+int kmamd_set_filter(kmamd_engine *e, int mode) {
+  if (mode != 0 && mode != 1) return kmx::kInvalidArguments;
+  e->e.filter_mode_ = mode;
+  return kmx::kSuccess;
 }
 int kmamd_set_half_rows(kmamd_engine *e, const void *rows16) {
   e->e.half_rows_ = rows16;

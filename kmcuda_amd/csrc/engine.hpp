@@ -77,6 +77,7 @@ class Engine {
   // fp16x2 path: the local rows as halves (caller-owned) + the hi/lo-split centred centroid panel
   const void *half_rows_ = nullptr;
   void *panel16_ = nullptr;
+  int filter_mode_ = 0;  // 0: split-f16 matrix-core filter (default), 1: f32 matrix-core filter (KMCUDA_AMD_FILTER=f32)
   uint32_t *stats_ = nullptr, *flagged_ = nullptr, *pairs_ = nullptr, *counters_ = nullptr;
   // update workspace
   uint32_t *keys_tmp_ = nullptr, *vals_tmp_ = nullptr, *keys_sorted_ = nullptr, *rows_sorted_ = nullptr,

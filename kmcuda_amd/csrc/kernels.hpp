@@ -35,12 +35,13 @@ hipError_t launch_lloyd_pair(int metric, const LloydArgs &a, const float *centro
 hipError_t launch_lloyd_exact(int metric, const LloydArgs &a, const uint32_t *rows, const uint32_t *nrows,
                               uint32_t grid, hipStream_t st);
 
-// lloyd_f16.hip -- the same filter on the f16 matrix cores for the fp16x2 path (rows as halves,
-// centred hi/lo-split operands); decisions identical in kind, refine kernels shared
+// lloyd_f16.hip -- the same filter on the f16 matrix cores (centred hi/lo-split operands), for fp32
+// rows and for the fp16x2 path's half rows; decisions identical in kind, refine kernels shared
 bool lloyd_filter_f16_supported(uint32_t D, uint32_t DP);
 hipError_t launch_centroid_panel16(const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP,
                                    const uint32_t *finite, const float *mu, void *panel16, hipStream_t st);
-hipError_t launch_lloyd_filter_f16(const LloydArgs &a, const void *rows16, const void *panel16, hipStream_t st);
+hipError_t launch_lloyd_filter_f16(const LloydArgs &a, const void *rows, bool half_rows, const void *panel16,
+                                   hipStream_t st);
 
 // update.hip -- centroid update (reference: kmeans.cu:366-429 kmeans_adjust)
 constexpr uint32_t kSumSplit = 8;

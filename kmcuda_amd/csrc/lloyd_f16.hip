@@ -1,13 +1,16 @@
-// lloyd_f16.hip -- the Lloyd assignment filter for the fp16x2 path (reference:
-// src/kmeans.cu:293-364 with F = half2, src/fp_abstraction.h:100-182) on the f16 matrix cores.
+// lloyd_f16.hip -- the Lloyd assignment filter (reference: src/kmeans.cu:293-364) on the f16 matrix
+// cores, for fp32 rows AND for the fp16x2 path's half rows (src/fp_abstraction.h:100-182).
 //
-// fp16x2 semantics of this implementation: the fp32 reference arithmetic on the half
-// VALUES.  So the decision this filter has to reproduce is exactly the fp32 path's on the widened
-// rows -- and the same filter-and-refine contract holds: rows the filter cannot decide go to the
-// exact kernels of lloyd.hip (which read the widened fp32 copy), assignments are bit-identical to
-// the fp32 path's on the same values.  What changes is the matrix-core rate and the HBM bytes:
+// The filter only has to produce scores with a RIGOROUS error bound (lloyd.hip: rows it cannot
+// decide go to the exact kernels), so nothing forces it onto the f32 MFMA (64 FLOP/clk/SIMD, 1/16
+// of the f16 rate).  A centred fp32 operand split into two halves, a = a_hi + a_lo + r with
+// |r| <= 2^-22 |a| + 2^-25, keeps 22 of its 24 significand bits, the products of halves are exact
+// in the fp32 accumulator, and the residual is far below the bound the filter already carries.
+// fp16x2 semantics of this implementation are the fp32 reference arithmetic on the
+// half VALUES, so the half-row variant reproduces the fp32 path's decisions on the widened rows
+// (the exact kernels read the widened copy): same contract, half the HBM bytes.
 //
-//   * rows are read as HALVES (512 B instead of 1 KB at D = 256);
+//   * rows are read as fp32 (HALF_ROWS = false) or as HALVES (512 B instead of 1 KB at D = 256);
 //   * operands are CENTRED in fp32 (x' = x - mu, c' = c - mu: the centred bound, lloyd.hip) and
 //     split into two halves each, a = a_hi + a_lo + r, |r| <= 2^-22 |a| + 2^-25, so that
 //         x'.c' ~= x_hi.c_hi + x_hi.c_lo + x_lo.c_hi
@@ -50,9 +53,9 @@ __global__ void centroid_panel16_kernel(const float *__restrict__ centroids, uin
   }
 }
 
-template <int DP>
+template <int DP, bool HALF_ROWS, bool FAST>
 __global__ __launch_bounds__(256, 2) void lloyd_filter_f16_kernel(
-    const _Float16 *__restrict__ rows16, uint32_t N, const float *__restrict__ panel16f,
+    const void *__restrict__ rows, uint32_t N, uint32_t D, const float *__restrict__ panel16f,
     const float *__restrict__ bias, const float *__restrict__ mu, uint32_t K_pad, uint32_t K,
     const uint32_t *__restrict__ stats, float eps, float tie_slack, uint32_t *__restrict__ assignments,
     uint32_t *__restrict__ assignments_prev, uint32_t *__restrict__ flagged, uint32_t *__restrict__ pairs,
@@ -74,22 +77,42 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_f16_kernel(
   f16x8 xhi[KS], xlo[KS];
   float xn2 = 0.f, xo2 = 0.f, x0 = 0.f;
   {
-    const f16x8 *src = reinterpret_cast<const f16x8 *>(rows16 + (size_t)(live ? s : 0) * DP + h * NKH);
+    const size_t row = (size_t)(live ? s : 0);
     const float *m = mu + h * NKH;
 #pragma unroll
     for (int j = 0; j < KS; j++) {
-      const f16x8 raw = src[j];
+      float xv[8];
+      if (FAST && HALF_ROWS) {
+        const f16x8 raw = reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(rows) + row * DP + h * NKH)[j];
+#pragma unroll
+        for (int q = 0; q < 8; q++) xv[q] = (float)raw[q];
+      } else if (FAST) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(rows) + row * DP + h * NKH);
+        const f32x4 a = src[2 * j], b = src[2 * j + 1];
+        xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w;
+        xv[4] = b.x; xv[5] = b.y; xv[6] = b.z; xv[7] = b.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const uint32_t f = h * NKH + 8 * j + q;
+          float v = 0.f;
+          if (f < D) v = HALF_ROWS ? (float)reinterpret_cast<const _Float16 *>(rows)[row * D + f]
+                                   : reinterpret_cast<const float *>(rows)[row * D + f];
+          xv[q] = v;
+        }
+      }
       f16x8 hi, lo;
 #pragma unroll
       for (int q = 0; q < 8; q++) {
-        const float x = live ? (float)raw[q] : 0.f;
-        const float xc = live ? x - m[8 * j + q] : 0.f;
+        const bool on = live && (FAST || h * NKH + 8 * j + q < (int)D);
+        const float x = on ? xv[q] : 0.f;
+        const float xc = on ? x - m[8 * j + q] : 0.f;
         const _Float16 a = (_Float16)xc;
         hi[q] = a;
         lo[q] = (_Float16)(xc - (float)a);
         xo2 = fmaf(x, x, xo2);
         xn2 = fmaf(xc, xc, xn2);
-        if (j == 0 && q == 0) x0 = x;
+        if (j == 0 && q == 0) x0 = live ? xv[q] : 0.f;
       }
       xhi[j] = hi;
       xlo[j] = lo;
@@ -193,26 +216,35 @@ hipError_t launch_centroid_panel16(const float *centroids, uint32_t K, uint32_t 
 }
 
 template <int DP>
-static hipError_t launch_f16_dp(const LloydArgs &a, const void *rows16, const void *panel16, hipStream_t st) {
+static hipError_t launch_f16_dp(const LloydArgs &a, const void *rows, bool half_rows, const void *panel16,
+                                hipStream_t st) {
   const size_t lds_bytes = (2 * 32 * (DP + 4) + 64) * sizeof(float);
   const uint32_t grid = (a.N + 127) / 128;
-  hipLaunchKernelGGL((lloyd_filter_f16_kernel<DP>), dim3(grid), dim3(256), lds_bytes, st,
-                     reinterpret_cast<const _Float16 *>(rows16), a.N, reinterpret_cast<const float *>(panel16), a.bias,
-                     a.mu, a.K_pad, a.K, a.stats, a.eps, a.tie_slack, a.assignments, a.assignments_prev, a.flagged,
-                     a.pairs, a.counters);
+  const bool fast = a.D == (uint32_t)DP;
+#define KMX_F16_LAUNCH(H, F)                                                                                       \
+  hipLaunchKernelGGL((lloyd_filter_f16_kernel<DP, H, F>), dim3(grid), dim3(256), lds_bytes, st, rows, a.N, a.D,     \
+                     reinterpret_cast<const float *>(panel16), a.bias, a.mu, a.K_pad, a.K, a.stats, a.eps,           \
+                     a.tie_slack, a.assignments, a.assignments_prev, a.flagged, a.pairs, a.counters)
+  if (half_rows) {
+    if (fast) KMX_F16_LAUNCH(true, true); else KMX_F16_LAUNCH(true, false);
+  } else {
+    if (fast) KMX_F16_LAUNCH(false, true); else KMX_F16_LAUNCH(false, false);
+  }
+#undef KMX_F16_LAUNCH
   return hipGetLastError();
 }
 
-// only whole rows of halves with D == DP, DP >= 16 (one MFMA consumes 8 features per half-wave)
-bool lloyd_filter_f16_supported(uint32_t D, uint32_t DP) { return D == DP && DP >= 16; }
+// one MFMA consumes 8 features per half-wave: the padded width must be at least 16
+bool lloyd_filter_f16_supported(uint32_t D, uint32_t DP) { return DP >= 16 && D <= DP; }
 
-hipError_t launch_lloyd_filter_f16(const LloydArgs &a, const void *rows16, const void *panel16, hipStream_t st) {
+hipError_t launch_lloyd_filter_f16(const LloydArgs &a, const void *rows, bool half_rows, const void *panel16,
+                                   hipStream_t st) {
   switch (a.DP) {
-    case 16: return launch_f16_dp<16>(a, rows16, panel16, st);
-    case 32: return launch_f16_dp<32>(a, rows16, panel16, st);
-    case 64: return launch_f16_dp<64>(a, rows16, panel16, st);
-    case 128: return launch_f16_dp<128>(a, rows16, panel16, st);
-    case 256: return launch_f16_dp<256>(a, rows16, panel16, st);
+    case 16: return launch_f16_dp<16>(a, rows, half_rows, panel16, st);
+    case 32: return launch_f16_dp<32>(a, rows, half_rows, panel16, st);
+    case 64: return launch_f16_dp<64>(a, rows, half_rows, panel16, st);
+    case 128: return launch_f16_dp<128>(a, rows, half_rows, panel16, st);
+    case 256: return launch_f16_dp<256>(a, rows, half_rows, panel16, st);
     default: return hipErrorInvalidValue;
   }
 }

@@ -56,6 +56,10 @@ class Engine:
         _lib.check(fn(self.h, self._p(samples), self._p(centroids), self._p(assignments), self._p(assignments_prev)),
                    "kmamd_lloyd_assign")
 
+    def set_filter(self, mode):
+        """"f16" (default): f16 matrix cores on centred hi/lo-split operands; "f32": f32 matrix cores."""
+        _lib.check(self.lib.kmamd_set_filter(self.h, {"f16": 0, "f32": 1}[mode]), "kmamd_set_filter")
+
     def set_half_rows(self, rows16):
         """rows16: float16 CUDA tensor with the same values as the fp32 rows (or None)."""
         self._half_rows = rows16  # keep alive

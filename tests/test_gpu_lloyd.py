@@ -20,7 +20,7 @@ def _dev():
     return torch.device("cuda", 0)
 
 
-def _assign(x, c, metric="L2", exact=False, asg0=None):
+def _assign(x, c, metric="L2", exact=False, asg0=None, filt="f16"):
     from kmcuda_amd.engine import Engine
     dev = _dev()
     n, d = x.shape
@@ -30,6 +30,7 @@ def _assign(x, c, metric="L2", exact=False, asg0=None):
     asg = torch.from_numpy(init.view(numpy.int32).copy()).to(dev)
     prev = torch.full((n,), -1, dtype=torch.int32, device=dev)
     eng = Engine(n, d, k, metric, device=0)
+    eng.set_filter(filt)
     eng.lloyd_assign(xs, cs, asg, prev, exact=exact)
     counters = eng.counters()
     eng.close()
@@ -38,34 +39,38 @@ def _assign(x, c, metric="L2", exact=False, asg0=None):
 
 @pytest.mark.parametrize("n,d,k", [(3000, 2, 50), (1000, 7, 33), (2500, 16, 100), (2000, 64, 257),
                                    (4096, 128, 64), (5000, 256, 1024), (777, 300, 40)])
-@pytest.mark.parametrize("exact", [False, True])
-def test_assign_bit_exact(n, d, k, exact):
+@pytest.mark.parametrize("mode", ["f16", "f32", "exact"])
+def test_assign_bit_exact(n, d, k, mode):
+    """f16: split-operand f16 matrix-core filter (default), f32: f32 matrix-core filter, exact: the
+    reference arithmetic for every pair -- all three must reproduce the oracle bit for bit."""
     rs = numpy.random.RandomState(n + d + k)
     x = rs.rand(n, d).astype(numpy.float32)
     c = x[rs.choice(n, k, replace=False)].copy()
-    got, prev, counters = _assign(x, c, exact=exact)
+    got, prev, counters = _assign(x, c, exact=(mode == "exact"), filt="f32" if mode == "exact" else mode)
     ref, ref_prev, ref_changed = oracle.lloyd_assign(x, c)
     assert (got == ref).all()
     assert (prev == ref_prev).all()
     assert counters[0] == ref_changed
 
 
-def test_assign_gaussian_and_second_pass():
+@pytest.mark.parametrize("filt", ["f16", "f32"])
+def test_assign_gaussian_and_second_pass(filt):
     rs = numpy.random.RandomState(5)
     x = (rs.randn(6000, 256) * 3 + rs.randn(1, 256)).astype(numpy.float32)
     c = x[rs.choice(6000, 300, replace=False)].copy()
-    got, _, _ = _assign(x, c)
+    got, _, _ = _assign(x, c, filt=filt)
     ref, _, _ = oracle.lloyd_assign(x, c)
     assert (got == ref).all()
     # second pass from the previous assignments with perturbed centroids: counter = #changed
     c2 = (c + rs.randn(*c.shape).astype(numpy.float32) * 0.05).astype(numpy.float32)
-    got2, prev2, counters = _assign(x, c2, asg0=got)
+    got2, prev2, counters = _assign(x, c2, asg0=got, filt=filt)
     ref2, ref_prev2, ref_changed = oracle.lloyd_assign(x, c2, assignments=ref)
     assert (got2 == ref2).all() and (prev2 == ref_prev2).all()
     assert counters[0] == ref_changed
 
 
-def test_assign_ties_duplicates_nans():
+@pytest.mark.parametrize("filt", ["f16", "f32"])
+def test_assign_ties_duplicates_nans(filt):
     rs = numpy.random.RandomState(11)
     x = rs.rand(4000, 256).astype(numpy.float32)
     c = x[rs.choice(4000, 96, replace=False)].copy()
@@ -76,7 +81,9 @@ def test_assign_ties_duplicates_nans():
     x[5, 0] = numpy.nan   # "insane" sample -> assignment K (kmeans.cu:312, :349-356)
     x[6, 17] = numpy.nan  # NaN elsewhere: search fails, row left untouched
     x[7] = c[3]           # exact hit on a duplicated centroid
-    got, prev, counters = _assign(x, c)
+    x[8, 3] = numpy.inf   # inf feature: NaN / inf scores must end in the exact kernels
+    x[9, :] = 1e30        # centred halves overflow to inf in the split: same
+    got, prev, counters = _assign(x, c, filt=filt)
     ref, ref_prev, ref_changed = oracle.lloyd_assign(x, c)
     assert (got == ref).all()
     assert (prev == ref_prev).all()
@@ -85,13 +92,14 @@ def test_assign_ties_duplicates_nans():
     assert not numpy.isin(got, [10, 11, 40, 77]).any()
 
 
-def test_assign_all_rows_flagged_still_exact():
+@pytest.mark.parametrize("filt", ["f16", "f32"])
+def test_assign_all_rows_flagged_still_exact(filt):
     # every centroid duplicated: the filter can decide nothing, the exact kernel decides all
     rs = numpy.random.RandomState(13)
     x = rs.rand(1500, 64).astype(numpy.float32)
     base = x[rs.choice(1500, 20, replace=False)]
     c = numpy.concatenate([base, base]).astype(numpy.float32)
-    got, _, counters = _assign(x, c)
+    got, _, counters = _assign(x, c, filt=filt)
     ref, _, _ = oracle.lloyd_assign(x, c)
     assert (got == ref).all()
     assert counters[1] + counters[3] == 1500  # nothing decided by the filter itself
@@ -164,12 +172,13 @@ def test_transpose_roundtrip():
         eng.close()
 
 
-def test_config_a_100k_256_1024():
+@pytest.mark.parametrize("filt", ["f16", "f32"])
+def test_config_a_100k_256_1024(filt):
     """BASELINE config A shape: one assignment pass at 100000x256, K=1024, bit-exact."""
     rs = numpy.random.RandomState(0)
     x = rs.rand(100000, 256).astype(numpy.float32)
     c = x[rs.choice(100000, 1024, replace=False)].copy()
-    got, _, counters = _assign(x, c)
+    got, _, counters = _assign(x, c, filt=filt)
     ref, _, changed = oracle.lloyd_assign(x, c)
     assert (got == ref).all()
     assert counters[0] == changed == 100000
