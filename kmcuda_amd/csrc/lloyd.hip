@@ -302,12 +302,14 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_kernel(
     for (int r = 0; r < 16; r++) {
       const float v = acc[r];
       const uint32_t code = t * 16u + r;
-      const bool g1 = v > v1, g2 = v > v2, g3 = v > v3;
-      v3 = g2 ? v2 : (g3 ? v : v3);
+      // sorted insert with 3 value ops (v_med3 / v_max ignore a NaN operand, like the strict
+      // compares do) + the two index selects
+      const bool g1 = v > v1, g2 = v > v2;
+      v3 = __builtin_amdgcn_fmed3f(v2, v3, v);
       c2 = g1 ? c1 : (g2 ? code : c2);
-      v2 = g1 ? v1 : (g2 ? v : v2);
+      v2 = __builtin_amdgcn_fmed3f(v1, v2, v);
       c1 = g1 ? code : c1;
-      v1 = g1 ? v : v1;
+      v1 = fmaxf(v1, v);
     }
     if (t + 1 < ntiles) stage_store(buf ^ 1);
     __syncthreads();

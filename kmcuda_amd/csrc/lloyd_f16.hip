@@ -157,35 +157,54 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_f16_kernel(
   for (uint32_t t = 0; t < ntiles; t++) {
     const int buf = t & 1;
     if (t + 1 < ntiles) stage_load(t + 1);
-    f32x16 acc;
+    f32x16 acc0;
     {
       const float *bb = bias_ptr(buf) + 4 * h;
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bb + 8 * g);
-        acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
+        acc0[4 * g + 0] = b4.x; acc0[4 * g + 1] = b4.y; acc0[4 * g + 2] = b4.z; acc0[4 * g + 3] = b4.w;
       }
     }
-    // my centroid row of the tile: hi halves at [0, DP), lo halves at [DP, 2 DP)
+    // my centroid row of the tile: hi halves at [0, DP), lo halves at [DP, 2 DP).  Fragments are
+    // read TWO k-steps (6 MFMAs) ahead of their use and the order is pinned: left alone, hipcc sinks
+    // each ds_read_b128 right in front of its first MFMA and the LDS latency lands on the pipe
     const _Float16 *arow = reinterpret_cast<const _Float16 *>(tile_ptr(buf) + col * LDW) + h * NKH;
+    auto frag = [&](int j, int lo) { return *reinterpret_cast<const f16x8 *>(arow + lo * DP + 8 * j); };
+    if constexpr (KS >= 2) {
+      f16x8 h0 = frag(0, 0), l0 = frag(0, 1), h1 = frag(1, 0), l1 = frag(1, 1);
 #pragma unroll
-    for (int j = 0; j < KS; j++) {
-      const f16x8 ahi = *reinterpret_cast<const f16x8 *>(arow + 8 * j);
-      const f16x8 alo = *reinterpret_cast<const f16x8 *>(arow + DP + 8 * j);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, xhi[j], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, xhi[j], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, xlo[j], acc, 0, 0, 0);
+      for (int j = 0; j < KS; j++) {
+        f16x8 h2 = h1, l2 = l1;
+        if (j + 2 < KS) {
+          h2 = frag(j + 2, 0);
+          l2 = frag(j + 2, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, xhi[j], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(l0, xhi[j], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, xlo[j], acc0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        h0 = h1; l0 = l1;
+        h1 = h2; l1 = l2;
+      }
+    } else {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(0, 0), xhi[0], acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(0, 1), xhi[0], acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(0, 0), xlo[0], acc0, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      const float v = acc[r];
+      const float v = acc0[r];
       const uint32_t code = t * 16u + r;
-      const bool g1 = v > v1, g2 = v > v2, g3 = v > v3;
-      v3 = g2 ? v2 : (g3 ? v : v3);
+      // sorted insert with 3 value ops (v_med3 / v_max ignore a NaN operand, like the strict
+      // compares do) + the two index selects
+      const bool g1 = v > v1, g2 = v > v2;
+      v3 = __builtin_amdgcn_fmed3f(v2, v3, v);
       c2 = g1 ? c1 : (g2 ? code : c2);
-      v2 = g1 ? v1 : (g2 ? v : v2);
+      v2 = __builtin_amdgcn_fmed3f(v1, v2, v);
       c1 = g1 ? code : c1;
-      v1 = g1 ? v : v1;
+      v1 = fmaxf(v1, v);
     }
     if (t + 1 < ntiles) stage_store(buf ^ 1);
     __syncthreads();
