@@ -116,10 +116,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    # test hooks (a 1-GPU box cannot run RCCL across ranks): all ranks on GPU 0 over gloo
+    if os.environ.get("KMCUDA_AMD_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend_name = os.environ.get("KMCUDA_AMD_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm
+        if backend_name == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend_name)
 
     N, D, K = args.samples, args.features, args.clusters
     lo, hi = row_block(N, rank, world)

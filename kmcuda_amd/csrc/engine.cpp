@@ -117,7 +117,7 @@ void Engine::profile_reset() {
 int Engine::prepare_centroids(const float *centroids) {
   const uint32_t dp = DP_ ? DP_ : 8;
   KMX_HIP(launch_centroid_prep(metric_, centroids, K_, D_, K_pad_, dp, Kt_, csqr_, bias_, bias2_, cfil_, ct_, mu_,
-                               finite_, stats_, stream_),
+                               finite_, stats_, counters_ + 1, counters_ + 3, stream_),
           kRuntimeError);
   return kSuccess;
 }
@@ -258,8 +258,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
     span_end();
     return kSuccess;
   }
-  KMX_HIP(hipMemsetAsync(counters_ + 1, 0, sizeof(uint32_t), stream_), kRuntimeError);
-  KMX_HIP(hipMemsetAsync(counters_ + 3, 0, sizeof(uint32_t), stream_), kRuntimeError);
+  // counters_[1] / [3] (the filter's list lengths) were zeroed by centroid_prep
   span_begin(0);
   if (filter_mode_ == 0 && lloyd_filter_f16_supported(D_, DP_)) {
     if (!panel16_) {

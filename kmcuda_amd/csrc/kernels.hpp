@@ -29,7 +29,8 @@ struct LloydArgs {
 uint32_t filter_dp_for(uint32_t D);
 hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad,
                                 uint32_t DP, uint32_t Kt, float *csqr, float *bias, float *bias2, float *cfil,
-                                float *ct, float *mu, uint32_t *finite, uint32_t *stats, hipStream_t st);
+                                float *ct, float *mu, uint32_t *finite, uint32_t *stats, uint32_t *zero_a,
+                                uint32_t *zero_b, hipStream_t st);
 hipError_t launch_lloyd_filter(const LloydArgs &a, hipStream_t st);
 hipError_t launch_lloyd_pair(int metric, const LloydArgs &a, const float *centroids, uint32_t grid, hipStream_t st);
 hipError_t launch_lloyd_exact(int metric, const LloydArgs &a, const uint32_t *rows, const uint32_t *nrows,

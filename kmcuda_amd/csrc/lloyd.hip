@@ -44,9 +44,22 @@ __global__ void centroid_rows_kernel(const float *__restrict__ centroids, uint32
   if (c < K) {
     const float *row = centroids + (size_t)c * D;
     float ssqr = 0.f, corr = 0.f, plain = 0.f;
-    for (uint32_t f = 0; f < D; f++) {
+    uint32_t f = 0;
+    if ((D & 3u) == 0 && (((uintptr_t)row) & 15u) == 0) {
+      for (; f < D; f += 4) {  // 16-byte loads; the chain order is unchanged
+        const float4 v4 = *reinterpret_cast<const float4 *>(row + f);
+        const float vs[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if (METRIC == 0) kahan_fold(fma_rd(vs[q], vs[q], corr), ssqr, corr);
+          plain = fmaf(vs[q], vs[q], plain);
+          if (ct) ct[(size_t)(f + q) * Kt + c] = vs[q];
+        }
+      }
+    }
+    for (; f < D; f++) {
       const float v = row[f];
-      kahan_fold(fma_rd(v, v, corr), ssqr, corr);
+      if (METRIC == 0) kahan_fold(fma_rd(v, v, corr), ssqr, corr);
       plain = fmaf(v, v, plain);
       if (ct) ct[(size_t)f * Kt + c] = v;
     }
@@ -63,18 +76,24 @@ __global__ void centroid_rows_kernel(const float *__restrict__ centroids, uint32
 // mean of the finite centroid rows, one thread per (padded) feature.  Any vector would do: the
 // argmin is translation invariant, the mean just makes the centred norms (and so the filter's
 // error bound) small.
-__global__ __launch_bounds__(256) void centroid_mean_kernel(const float *__restrict__ centroids, uint32_t K,
-                                                            uint32_t D, uint32_t DP,
-                                                            const uint32_t *__restrict__ finite,
-                                                            float *__restrict__ mu) {
-  // block = 64 features x 4 row-slices: coalesced row reads, fixed summation order
-  __shared__ float part[4][64];
-  __shared__ uint32_t cnt[4];
+__global__ __launch_bounds__(1024) void centroid_mean_kernel(const float *__restrict__ centroids, uint32_t K,
+                                                             uint32_t D, uint32_t DP,
+                                                             const uint32_t *__restrict__ finite,
+                                                             float *__restrict__ mu, uint32_t *__restrict__ zero_a,
+                                                             uint32_t *__restrict__ zero_b) {
+  // block = 64 features x 16 row-slices: coalesced row reads, fixed summation order
+  constexpr int S = 16;
+  __shared__ float part[S][64];
+  __shared__ uint32_t cnt[S];
   const uint32_t fl = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const uint32_t f = blockIdx.x * 64 + fl;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // the filter's per-pass list counters (saves two memset launches)
+    if (zero_a) *zero_a = 0u;
+    if (zero_b) *zero_b = 0u;
+  }
   float sum = 0.f;
   uint32_t n = 0;
-  for (uint32_t c = sl; c < K; c += 4) {
+  for (uint32_t c = sl; c < K; c += S) {
     if (finite[c]) {
       if (f < D) sum += centroids[(size_t)c * D + f];
       n++;
@@ -84,8 +103,13 @@ __global__ __launch_bounds__(256) void centroid_mean_kernel(const float *__restr
   if (fl == 0) cnt[sl] = n;
   __syncthreads();
   if (sl == 0 && f < DP) {
-    const float tot = (part[0][fl] + part[1][fl]) + (part[2][fl] + part[3][fl]);
-    const uint32_t nt = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    float tot = 0.f;
+    uint32_t nt = 0;
+#pragma unroll
+    for (int i = 0; i < S; i++) {
+      tot += part[i][fl];
+      nt += cnt[i];
+    }
     const float m = (nt && f < D) ? tot / (float)nt : 0.f;
     mu[f] = ((m - m) == 0.f) ? m : 0.f;
   }
@@ -95,26 +119,38 @@ __global__ __launch_bounds__(256) void centroid_mean_kernel(const float *__restr
 // bias = -||c'||^2/2 (L2) or mu.c' (angular: x.c = x'.c' + mu.c' + terms constant in c), and the
 // two magnitudes of the centred bound.
 template <int METRIC>
-__global__ void centroid_panel_kernel(const float *__restrict__ centroids, uint32_t K, uint32_t D, uint32_t K_pad,
-                                      uint32_t DP, const uint32_t *__restrict__ finite,
-                                      const float *__restrict__ mu, float *__restrict__ bias,
-                                      float *__restrict__ bias2, float *__restrict__ cfil,
-                                      uint32_t *__restrict__ stats) {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void centroid_panel_kernel(const float *__restrict__ centroids, uint32_t K,
+                                                             uint32_t D, uint32_t K_pad, uint32_t DP,
+                                                             const uint32_t *__restrict__ finite,
+                                                             const float *__restrict__ mu, float *__restrict__ bias,
+                                                             float *__restrict__ bias2, float *__restrict__ cfil,
+                                                             uint32_t *__restrict__ stats) {
+  // one WAVE per padded centroid row: coalesced reads / writes, plain (order-free) sums by shuffles
+  const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
   if (c >= K_pad) return;
   float *dst = cfil + (size_t)c * DP;
-  if (c < K && finite[c]) {
-    const float *row = centroids + (size_t)c * D;
-    float n2 = 0.f, mc = 0.f, m2 = 0.f;
-    for (uint32_t f = 0; f < D; f++) {
-      const float m = mu[f];
-      const float v = row[f] - m;
-      dst[f] = v;
-      n2 = fmaf(v, v, n2);
-      mc = fmaf(m, v, mc);
-      m2 = fmaf(m, m, m2);
+  const bool ok = c < K && finite[c];
+  float n2 = 0.f, mc = 0.f, m2 = 0.f;
+  for (uint32_t f = lane; f < DP; f += 64) {
+    float v = 0.f, m = 0.f;
+    if (ok && f < D) {
+      m = mu[f];
+      v = centroids[(size_t)c * D + f] - m;
     }
-    for (uint32_t f = D; f < DP; f++) dst[f] = 0.f;
+    dst[f] = v;
+    n2 = fmaf(v, v, n2);
+    mc = fmaf(m, v, mc);
+    m2 = fmaf(m, m, m2);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n2 += __shfl_xor(n2, off);
+    mc += __shfl_xor(mc, off);
+    m2 += __shfl_xor(m2, off);
+  }
+  if (lane != 0) return;
+  if (ok) {
     float b, bmag;
     if (METRIC == 0) {
       b = -0.5f * n2;
@@ -124,8 +160,8 @@ __global__ void centroid_panel_kernel(const float *__restrict__ centroids, uint3
       bmag = sqrtf(m2) * sqrtf(n2) * 1.0001f;  // >= sum |mu_f c'_f|
     }
     bias[c] = b;
-    // the variant for kernels that keep the ORIGINAL row resident (Yinyang: the exact chains need
-    // it): ||x - c||^2 = ||x - mu||^2 - 2 (x.c' - mu.c' - ||c'||^2/2)   /   x.c = x.c' + x.mu
+    // the variant for kernels that keep the ORIGINAL row resident:
+    // ||x - c||^2 = ||x - mu||^2 - 2 (x.c' - mu.c' - ||c'||^2/2)   /   x.c = x.c' + x.mu
     const float mag2 = (METRIC == 0) ? sqrtf(m2) * sqrtf(n2) * 1.0001f + 0.5f * n2 : 0.f;
     bias2[c] = (METRIC == 0) ? -mc - 0.5f * n2 : 0.f;
     atomicMax(&stats[0], __float_as_uint(n2 * 1.0001f));
@@ -135,7 +171,6 @@ __global__ void centroid_panel_kernel(const float *__restrict__ centroids, uint3
   } else {
     bias[c] = -INFINITY;
     bias2[c] = -INFINITY;
-    for (uint32_t f = 0; f < DP; f++) dst[f] = 0.f;
   }
 }
 
@@ -344,7 +379,23 @@ __global__ __launch_bounds__(128) void lloyd_pair_kernel(
     const float *x = samples + (size_t)s * D;
     const float *ca = centroids + (size_t)lo * D, *cb = centroids + (size_t)hi * D;
     float acc[4] = {0.f, 0.f, 0.f, 0.f}, corr[4] = {0.f, 0.f, 0.f, 0.f};
-    for (uint32_t f = 0; f < D; f++) {
+    uint32_t f = 0;
+    if ((D & 3u) == 0 && ((((uintptr_t)x) | ((uintptr_t)ca) | ((uintptr_t)cb)) & 15u) == 0) {
+      for (; f < D; f += 4) {  // 16-byte loads; the chain order is unchanged
+        const float4 xv = *reinterpret_cast<const float4 *>(x + f);
+        const float4 av = *reinterpret_cast<const float4 *>(ca + f), bv = *reinterpret_cast<const float4 *>(cb + f);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, as[4] = {av.x, av.y, av.z, av.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float cv[4] = {as[q], bs[q], 0.f, 0.f};
+          float y[4];
+          fma_rd4(xs[q], cv, corr, y);
+          kahan_fold(y[0], acc[0], corr[0]);
+          kahan_fold(y[1], acc[1], corr[1]);
+        }
+      }
+    }
+    for (; f < D; f++) {
       const float cv[4] = {ca[f], cb[f], 0.f, 0.f};
       float y[4];
       fma_rd4(x[f], cv, corr, y);
@@ -370,32 +421,58 @@ __global__ __launch_bounds__(128) void lloyd_pair_kernel(
 // (coalesced).  Lane-local strict '<' in ascending c, then a wave argmin that prefers the
 // smaller index on equal distances == the reference's sequential first-minimum.
 template <int METRIC>
-__global__ __launch_bounds__(64) void lloyd_exact_kernel(
+__global__ __launch_bounds__(256) void lloyd_exact_kernel(
     const float *__restrict__ samples, uint32_t N, uint32_t D, const float *__restrict__ ct,
     const float *__restrict__ csqr, uint32_t K, uint32_t Kt, const uint32_t *__restrict__ rows,
     const uint32_t *__restrict__ nrows, uint32_t *__restrict__ assignments,
     uint32_t *__restrict__ assignments_prev, uint32_t *__restrict__ counters) {
-  constexpr int CH = 8;
-  const int lane = threadIdx.x;
+  // One BLOCK of 4 waves per row (the flagged rows are few, so the latency of a row matters, not the
+  // throughput): wave w takes the centroid chunks w, w+4, ... of 64*CH centroids, lane l runs CH
+  // independent chains per chunk; lane-local strict '<' in ascending c, then wave and block argmin
+  // preferring the smaller index on equal distances == the reference's sequential first minimum.
+  constexpr int CH = 4;
+  __shared__ float sh_dist[4];
+  __shared__ uint32_t sh_idx[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t total = rows ? *nrows : N;
   for (uint32_t ri = blockIdx.x; ri < total; ri += gridDim.x) {
     const uint32_t s = rows ? rows[ri] : ri;
-    const float *x = samples + (size_t)s * D;  // wave-uniform address: scalar loads
+    const float *x = samples + (size_t)s * D;  // block-uniform address: scalar loads
     const bool insane = (x[0] != x[0]);
     float min_dist = 3.402823466e+38f;
     uint32_t nearest = 0xFFFFFFFFu;
     if (!insane) {
-      for (uint32_t cbase = 0; cbase < K; cbase += 64 * CH) {
+      for (uint32_t cbase = wave * 64 * CH; cbase < K; cbase += 4 * 64 * CH) {
         float acc[CH], corr[CH];
 #pragma unroll
         for (int j = 0; j < CH; j++) { acc[j] = 0.f; corr[j] = 0.f; }
         const float *cp = ct + cbase + lane;
-        for (uint32_t f = 0; f < D; f++) {
+        bool in[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) in[j] = cbase + 64 * j + lane < Kt;
+        uint32_t f = 0;
+        for (; f + 4 <= D; f += 4) {  // 16 loads in flight per lane before the four dependent steps
+          float xf[4], cv[4][CH];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            xf[q] = x[f + q];
+#pragma unroll
+            for (int j = 0; j < CH; j++) cv[q][j] = in[j] ? cp[(size_t)(f + q) * Kt + 64 * j] : 0.f;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            float y[CH];
+            fma_rd4(xf[q], cv[q], corr, y);
+#pragma unroll
+            for (int j = 0; j < CH; j++) kahan_fold(y[j], acc[j], corr[j]);
+          }
+        }
+        for (; f < D; f++) {
           const float xf = x[f];
           float cv[CH], y[CH];
 #pragma unroll
-          for (int j = 0; j < CH; j++) cv[j] = (cbase + 64 * j + lane < Kt) ? cp[(size_t)f * Kt + 64 * j] : 0.f;
-          fma_rd8(xf, cv, corr, y);
+          for (int j = 0; j < CH; j++) cv[j] = in[j] ? cp[(size_t)f * Kt + 64 * j] : 0.f;
+          fma_rd4(xf, cv, corr, y);
 #pragma unroll
           for (int j = 0; j < CH; j++) kahan_fold(y[j], acc[j], corr[j]);
         }
@@ -419,11 +496,24 @@ __global__ __launch_bounds__(64) void lloyd_exact_kernel(
       }
     }
     if (lane == 0) {
+      sh_dist[wave] = min_dist;
+      sh_idx[wave] = nearest;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; w++) {
+        const float od = sh_dist[w];
+        const uint32_t oi = sh_idx[w];
+        const bool take = (oi != 0xFFFFFFFFu) &&
+                          (nearest == 0xFFFFFFFFu || od < min_dist || (od == min_dist && oi < nearest));
+        if (take) { min_dist = od; nearest = oi; }
+      }
       if (nearest == 0xFFFFFFFFu && insane) nearest = K;  // kmeans.cu:349-356
       if (nearest != 0xFFFFFFFFu) {                       // else: "search failed", row left untouched
         if (commit_row(s, nearest, assignments, assignments_prev)) atomicAdd(&counters[0], 1u);
       }
     }
+    __syncthreads();
   }
 }
 
@@ -468,7 +558,8 @@ hipError_t launch_lloyd_filter(const LloydArgs &a, hipStream_t st) {
 
 hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad,
                                 uint32_t DP, uint32_t Kt, float *csqr, float *bias, float *bias2, float *cfil,
-                                float *ct, float *mu, uint32_t *finite, uint32_t *stats, hipStream_t st) {
+                                float *ct, float *mu, uint32_t *finite, uint32_t *stats, uint32_t *zero_a,
+                                uint32_t *zero_b, hipStream_t st) {
   hipError_t e = hipMemsetAsync(stats, 0, 8 * sizeof(uint32_t), st);
   if (e != hipSuccess) return e;
   const dim3 block(64);
@@ -478,12 +569,13 @@ hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, 
   else
     hipLaunchKernelGGL((centroid_rows_kernel<1>), dim3((Kt + 63) / 64), block, 0, st, centroids, K, D, Kt, csqr, ct,
                        finite, stats);
-  hipLaunchKernelGGL(centroid_mean_kernel, dim3((DP + 63) / 64), dim3(256), 0, st, centroids, K, D, DP, finite, mu);
+  hipLaunchKernelGGL(centroid_mean_kernel, dim3((DP + 63) / 64), dim3(1024), 0, st, centroids, K, D, DP, finite, mu,
+                     zero_a, zero_b);
   if (metric == 0)
-    hipLaunchKernelGGL((centroid_panel_kernel<0>), dim3((K_pad + 63) / 64), block, 0, st, centroids, K, D, K_pad, DP,
+    hipLaunchKernelGGL((centroid_panel_kernel<0>), dim3((K_pad + 3) / 4), dim3(256), 0, st, centroids, K, D, K_pad, DP,
                        finite, mu, bias, bias2, cfil, stats);
   else
-    hipLaunchKernelGGL((centroid_panel_kernel<1>), dim3((K_pad + 63) / 64), block, 0, st, centroids, K, D, K_pad, DP,
+    hipLaunchKernelGGL((centroid_panel_kernel<1>), dim3((K_pad + 3) / 4), dim3(256), 0, st, centroids, K, D, K_pad, DP,
                        finite, mu, bias, bias2, cfil, stats);
   return hipGetLastError();
 }
@@ -503,10 +595,10 @@ hipError_t launch_lloyd_exact(int metric, const LloydArgs &a, const uint32_t *ro
                               uint32_t grid, hipStream_t st) {
   if (grid == 0) return hipSuccess;
   if (metric == 0)
-    hipLaunchKernelGGL((lloyd_exact_kernel<0>), dim3(grid), dim3(64), 0, st, a.samples, a.N, a.D, a.ct, a.csqr,
+    hipLaunchKernelGGL((lloyd_exact_kernel<0>), dim3(grid), dim3(256), 0, st, a.samples, a.N, a.D, a.ct, a.csqr,
                        a.K, a.Kt, rows, nrows, a.assignments, a.assignments_prev, a.counters);
   else
-    hipLaunchKernelGGL((lloyd_exact_kernel<1>), dim3(grid), dim3(64), 0, st, a.samples, a.N, a.D, a.ct, a.csqr,
+    hipLaunchKernelGGL((lloyd_exact_kernel<1>), dim3(grid), dim3(256), 0, st, a.samples, a.N, a.D, a.ct, a.csqr,
                        a.K, a.Kt, rows, nrows, a.assignments, a.assignments_prev, a.counters);
   return hipGetLastError();
 }
