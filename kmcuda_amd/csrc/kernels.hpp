@@ -127,6 +127,11 @@ struct KnnArgs {
   uint32_t N, D, DP, K, k;
   uint32_t p_base, p_end;   // this launch covers sorted positions [p_base, p_end)
   float eps;
+  // f16 matrix-core filter (knn_f16.hip): centred hi/lo-split rows; n2s then holds the CENTRED squared
+  // norms, mux[p] = mu.(x_p - mu), mu2 = ||mu||^2
+  const void *xs16;
+  const float *mux;
+  float mu2;
   float *heaps;             // (p_end - p_base) x 2k
   uint32_t *out;            // (p_end - p_base) x k, sorted-position order
   unsigned long long *calced;
@@ -138,6 +143,9 @@ hipError_t launch_knn_prep(int metric, const float *xs, uint32_t N, uint32_t D, 
                            hipStream_t st);
 hipError_t launch_knn_filter(int metric, const KnnArgs &a, uint32_t nblocks, hipStream_t st);
 hipError_t launch_knn_exact(int metric, const KnnArgs &a, hipStream_t st);
+hipError_t launch_knn_split(int metric, const float *xs, uint32_t N, uint32_t D, uint32_t DP, const float *mu,
+                            void *xs16, float *n2c, float *mux, uint32_t *stats, hipStream_t st);
+hipError_t launch_knn_filter_f16(int metric, const KnnArgs &a, uint32_t nblocks, hipStream_t st);
 hipError_t launch_knn_scatter(const uint32_t *sorted_out, const uint32_t *inv, uint32_t p_base, uint32_t p_end,
                               uint32_t k, uint32_t *neighbors, hipStream_t st);
 

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <memory>
 #include <vector>
 
@@ -675,6 +676,8 @@ struct KnnShard {
   const float *samples = nullptr, *centroids = nullptr;
   const uint32_t *assignments = nullptr;
   float *xs = nullptr, *n2s = nullptr, *mydist = nullptr, *rdist = nullptr, *R = nullptr, *C = nullptr, *heaps = nullptr;
+  float *mu = nullptr, *mux = nullptr;
+  uint16_t *xs16 = nullptr;
   uint32_t *inv = nullptr, *offsets = nullptr, *keys_tmp = nullptr, *vals_tmp = nullptr, *keys_sorted = nullptr,
            *stats = nullptr, *blocks = nullptr, *out = nullptr;
   unsigned long long *calced = nullptr;
@@ -745,6 +748,48 @@ class KnnJob {
     const uint32_t dp_filter = (force_exact && atoi(force_exact)) ? 0 : filter_dp_for(D);
     const uint32_t DP = dp_filter ? dp_filter : D;
     if (!dp_filter) INFO("k-NN: every candidate is evaluated with the exact arithmetic (no matrix-core filter)\n");
+    // which matrix-core instruction filters the candidates: f16 on centred hi/lo-split rows (default,
+    // needs DP >= 16) or f32 (KMCUDA_AMD_FILTER=f32)
+    const char *fenv = getenv("KMCUDA_AMD_FILTER");
+    const bool use_f16 = dp_filter >= 16 && !(fenv && strcmp(fenv, "f32") == 0);
+    // mu = mean of the finite centroid rows (any vector works: distances are translation invariant)
+    std::vector<float> mu_host(DP, 0.f);
+    float mu2 = 0.f;
+    if (use_f16) {
+      std::vector<float> cen((size_t)K * D);
+      if (fp16) {
+        std::vector<uint16_t> raw((size_t)K * D);
+        if (device_ptrs < 0) memcpy(raw.data(), centroids, raw.size() * sizeof(uint16_t));
+        else if (hipMemcpy(raw.data(), centroids, raw.size() * sizeof(uint16_t), hipMemcpyDeviceToHost) != hipSuccess)
+          return kmcudaMemoryCopyError;
+        for (size_t i = 0; i < raw.size(); i++) {  // half -> float on the host
+          const uint32_t hbits = raw[i], sign = (hbits & 0x8000u) << 16, ex = (hbits >> 10) & 0x1Fu, man = hbits & 0x3FFu;
+          float v;
+          if (ex == 0) v = ldexpf((float)man, -24);
+          else if (ex == 31) v = man ? NAN : INFINITY;
+          else v = ldexpf((float)(man | 0x400u), (int)ex - 25);
+          cen[i] = sign ? -v : v;
+        }
+      } else if (device_ptrs < 0) {
+        memcpy(cen.data(), centroids, cen.size() * sizeof(float));
+      } else if (hipMemcpy(cen.data(), centroids, cen.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+        return kmcudaMemoryCopyError;
+      }
+      std::vector<double> acc(D, 0.0);
+      uint32_t nfin = 0;
+      for (uint32_t c = 0; c < K; c++) {
+        bool fin = true;
+        for (uint32_t f = 0; f < D && fin; f++) fin = std::isfinite(cen[(size_t)c * D + f]);
+        if (!fin) continue;
+        for (uint32_t f = 0; f < D; f++) acc[f] += cen[(size_t)c * D + f];
+        nfin++;
+      }
+      for (uint32_t f = 0; f < D; f++) {
+        mu_host[f] = nfin ? (float)(acc[f] / nfin) : 0.f;
+        mu2 += mu_host[f] * mu_host[f];
+      }
+      mu2 *= 1.0001f;
+    }
     const size_t sort_bytes = sort_temp_bytes(N, K);
     for (int dev : shard_devs) {
       auto sh = std::make_unique<KnnShard>();
@@ -773,6 +818,13 @@ class KnnJob {
       if ((rc = sh->alloc(&sh->keys_sorted, N))) return rc;
       if ((rc = sh->alloc(&sh->stats, 4))) return rc;
       if ((rc = sh->alloc(&sh->calced, 1))) return rc;
+      if (use_f16) {
+        if ((rc = sh->alloc(&sh->xs16, (size_t)N * 2 * DP))) return rc;
+        if ((rc = sh->alloc(&sh->mu, DP))) return rc;
+        if ((rc = sh->alloc(&sh->mux, N))) return rc;
+        if (hipMemcpyAsync(sh->mu, mu_host.data(), DP * sizeof(float), hipMemcpyHostToDevice, sh->stream) != hipSuccess)
+          return kmcudaMemoryCopyError;
+      }
       char *t = nullptr;
       if ((rc = sh->alloc(&t, sort_bytes + 16))) return rc;
       sh->sort_temp = t;
@@ -824,6 +876,13 @@ class KnnJob {
       if (!s.nblocks) s.p_end = s.p_base;
       if (i + 1 == shards.size() && !dp_filter) s.p_end = N;  // the exact kernel also fills the unassigned rows
     }
+    if (use_f16) {  // after the radii / member distances, which read the plain norms' buffer no more
+      for (auto &s : shards) {
+        (void)hipSetDevice(s->dev);
+        if (launch_knn_split(metric, s->xs, N, D, DP, s->mu, s->xs16, s->n2s, s->mux, s->stats, s->stream) != hipSuccess)
+          return kmcudaRuntimeError;
+      }
+    }
     INFO("searching for the nearest neighbors...\n");
     for (auto &sp : shards) {
       KnnShard &s = *sp;
@@ -843,8 +902,10 @@ class KnnJob {
       a.p_base = s.p_base; a.p_end = s.p_end;
       a.eps = (float)(1.02 * ((double)D + 12.0) * ldexp(1.0, -24));  // as the Lloyd filter
       a.heaps = s.heaps; a.out = s.out; a.calced = s.calced;
-      const hipError_t e = dp_filter ? launch_knn_filter(metric, a, s.nblocks, s.stream)
-                                     : launch_knn_exact(metric, a, s.stream);
+      a.xs16 = s.xs16; a.mux = s.mux; a.mu2 = mu2;
+      const hipError_t e = !dp_filter ? launch_knn_exact(metric, a, s.stream)
+                           : use_f16 ? launch_knn_filter_f16(metric, a, s.nblocks, s.stream)
+                                     : launch_knn_filter(metric, a, s.nblocks, s.stream);
       if (e != hipSuccess) return kmcudaRuntimeError;
     }
     // ---- outputs: rows back in sample order ----

@@ -1,0 +1,351 @@
+// knn_f16.hip -- the cluster-pruned k-NN search (reference: src/knn.cu:177-243) with the candidate
+// filter on the f16 matrix cores.  Same contract as knn.hip's knn_filter_kernel (heap evolution,
+// prune decisions, neighbour indices and order identical to the reference's); what changes:
+//
+//   * the corpus is additionally stored CENTRED and split into two halves per value,
+//     xs16[p] = [hi(x_p - mu) | lo(x_p - mu)] (same bytes as an fp32 row; mu = mean of the centroids:
+//     distances are translation invariant, centring shrinks the norms in the error bound), so
+//     ||x - y||^2 ~= ||x'||^2 + ||y'||^2 - 2 (x_hi.y_hi + x_hi.y_lo + x_lo.y_hi) runs as three
+//     v_mfma_f32_32x32x16_f16 per 16 features (lloyd_f16.hip has the bound: products of halves are
+//     exact in the fp32 accumulator, |residual| <= 2^-22 |a| + 2^-25 per value);
+//     angular: x.y = x'.y' + mu.y' + (mu.x' + ||mu||^2): bias mu.y' per candidate, the rest per query;
+//   * survivors are QUEUED per query, four deep, and a flush evaluates the exact distances as four
+//     interleaved chains (exact_split.hpp; original fp32 rows from the cluster-sorted copy), then
+//     replays "distance <= kth => push" in the reference's visiting order.  Evaluating a candidate the
+//     reference would have rejected has no effect, and the filter threshold as of the last flush is
+//     a superset of the live one (kth only decreases).
+#include <hip/hip_fp16.h>
+
+#include "exact.hpp"
+#include "exact_split.hpp"
+#include "kernels.hpp"
+
+namespace kmx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr float kFltMaxK = 3.402823466e+38f;
+
+// one wave per sorted row: xs16 (centred, split), centred squared norm, mu.x', max norm
+template <int METRIC>
+__global__ __launch_bounds__(256) void knn_split_kernel(const float *__restrict__ xs, uint32_t N, uint32_t D,
+                                                        uint32_t DP, const float *__restrict__ mu,
+                                                        _Float16 *__restrict__ xs16, float *__restrict__ n2c,
+                                                        float *__restrict__ mux, uint32_t *__restrict__ stats) {
+  const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  if (p >= N) return;
+  const float *src = xs + (size_t)p * DP;
+  _Float16 *dst = xs16 + (size_t)p * 2 * DP;
+  float a = 0.f, b = 0.f;
+  for (uint32_t f = lane; f < DP; f += 64) {
+    const float m = f < D ? mu[f] : 0.f;
+    const float v = f < D ? src[f] - m : 0.f;
+    const _Float16 hi = (_Float16)v;
+    dst[f] = hi;
+    dst[DP + f] = (_Float16)(v - (float)hi);
+    a = fmaf(v, v, a);
+    b = fmaf(m, v, b);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_xor(a, off);
+    b += __shfl_xor(b, off);
+  }
+  if (lane == 0) {
+    n2c[p] = a;
+    mux[p] = b;
+    if ((a - a) == 0.f) atomicMax(&stats[0], __float_as_uint(a));
+  }
+  (void)METRIC;
+}
+
+__device__ __forceinline__ void knn_push_sample(uint32_t k, float dist, uint32_t index, float *heap) {
+  // knn.cu:133-175 (same as knn.hip's push_sample)
+  uint32_t pos = 0;
+  uint32_t *heapi = reinterpret_cast<uint32_t *>(heap);
+  while (true) {
+    float left = 0.f, right = 0.f;
+    bool left_le, right_le;
+    if ((2 * pos + 1) < k) { left = heap[4 * pos + 2]; left_le = dist >= left; } else left_le = true;
+    if ((2 * pos + 2) < k) { right = heap[4 * pos + 4]; right_le = dist >= right; } else right_le = true;
+    if (left_le && right_le) {
+      heap[2 * pos] = dist;
+      heapi[2 * pos + 1] = index;
+      break;
+    }
+    bool go_right;
+    if (!left_le && !right_le) go_right = left <= right;
+    else go_right = left_le;
+    if (go_right) {
+      heap[2 * pos] = right;
+      heapi[2 * pos + 1] = heapi[4 * pos + 5];
+      pos = 2 * pos + 2;
+    } else {
+      heap[2 * pos] = left;
+      heapi[2 * pos + 1] = heapi[4 * pos + 3];
+      pos = 2 * pos + 1;
+    }
+  }
+}
+
+template <int DP, int METRIC, bool FASTX>
+__global__ __launch_bounds__(256, 2) void knn_filter_f16_kernel(KnnArgs a) {
+  constexpr int NKH = DP / 2;   // features per half-wave
+  constexpr int KS = NKH / 8;   // k-steps
+  constexpr int LDW = DP + 4;   // padded LDS row (4-byte words; a row = 2*DP halves)
+  constexpr int TILE = 32 * LDW;
+  constexpr int NST = (8 * DP + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  auto tile_ptr = [&](int buf) { return lds + buf * TILE; };
+  auto bias_ptr = [&](int buf) { return lds + 2 * TILE + buf * 32; };
+  uint32_t *flags = reinterpret_cast<uint32_t *>(lds + 2 * TILE + 64);  // 2 x 4 words
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+  const uint32_t K = a.K, k = a.k, D = a.D;
+  const float *panel = reinterpret_cast<const float *>(a.xs16);
+
+  const uint32_t cls0 = a.blocks[2 * (size_t)blockIdx.x], p0 = a.blocks[2 * (size_t)blockIdx.x + 1];
+  const uint32_t own_end = a.offsets[cls0 + 1];
+  const uint32_t qp = p0 + wave * 32 + col;
+  const bool live = qp < own_end;
+
+  // B operand: my half of my query's split row
+  f16x8 xhi[KS], xlo[KS];
+  {
+    const _Float16 *src = reinterpret_cast<const _Float16 *>(a.xs16) + (size_t)(live ? qp : p0) * 2 * DP + h * NKH;
+#pragma unroll
+    for (int j = 0; j < KS; j++) {
+      xhi[j] = reinterpret_cast<const f16x8 *>(src)[j];
+      xlo[j] = reinterpret_cast<const f16x8 *>(src + DP)[j];
+      if (!live) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) { xhi[j][q] = (_Float16)0.f; xlo[j][q] = (_Float16)0.f; }
+      }
+    }
+  }
+  const float qn2 = live ? a.n2s[qp] : 0.f;      // centred squared norm
+  const float md = live ? a.mydist[qp] : 0.f;
+  const float *xrow = a.xs + (size_t)(live ? qp : p0) * DP;  // original values (exact chains)
+  float *heap = a.heaps + (size_t)((live ? qp : p0) - a.p_base) * 2 * k;
+  if (live && h == 0) {
+    for (uint32_t i = 0; i < k; i++) {
+      heap[2 * i] = kFltMaxK;
+      reinterpret_cast<uint32_t *>(heap)[2 * i + 1] = 0;
+    }
+  }
+  float mndist = kFltMaxK;
+
+  // a candidate can only be accepted by the reference if acc >= amin
+  const float nmax2 = __uint_as_float(a.stats[0]);
+  const float u = 5.9604645e-8f;
+  const float qn = sqrtf(qn2) * 1.0001f, nmx = sqrtf(nmax2) * 1.0001f;
+  float E, kq = 0.f;
+  if (METRIC == 0) {
+    E = 4.04f * (3.0f * a.eps + 16.0f * u) * (qn2 + nmax2) + 6e-8f * sqrtf((float)DP) * (qn + nmx);
+  } else {
+    const float mun = sqrtf(a.mu2) * 1.0001f;
+    kq = (live ? a.mux[qp] : 0.f) + a.mu2;      // x.y = acc + mu.x' + ||mu||^2
+    E = 2.02f * (3.0f * a.eps + 16.0f * u) * (qn * nmx + mun * nmx) + 3e-8f * sqrtf((float)DP) * (qn + nmx) +
+        a.eps * (mun * qn + a.mu2) + 1e-6f;
+  }
+  auto amin_of = [&](float mnd) -> float {
+    if (METRIC == 0) {
+      const float T2 = mnd * mnd * 1.000001f;  // inf when the heap is not full yet
+      return 0.5f * (qn2 - T2 - E) - 1e-6f * (qn2 + T2);
+    }
+    if (mnd >= 3.1415925f) return -INFINITY;
+    return cosf(mnd) - kq - E;
+  };
+  float amin = amin_of(mndist);
+
+  f32x4 stage[NST];
+  float bstage = 0.f;
+  auto stage_load = [&](uint32_t base, uint32_t end) {  // 32 sorted rows from `base`
+    const uint32_t last = a.N - 1;
+#pragma unroll
+    for (int i = 0; i < NST; i++) {
+      const int q = tid + i * 256;
+      if (q < 8 * DP) {
+        const uint32_t row = base + q / (DP / 4);
+        const uint32_t rr = row <= last ? row : last;
+        stage[i] = reinterpret_cast<const f32x4 *>(panel + (size_t)rr * DP)[q % (DP / 4)];
+      }
+    }
+    if (tid < 32) {
+      const uint32_t row = base + tid;
+      if (row < end) bstage = METRIC == 0 ? -0.5f * a.n2s[row] : a.mux[row];
+      else bstage = -INFINITY;  // rows past the cluster never pass the filter (and are re-checked)
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NST; i++) {
+      const int q = tid + i * 256;
+      if (q < 8 * DP) {
+        const int row = q / (DP / 4), c4 = q % (DP / 4);
+        *reinterpret_cast<f32x4 *>(tile_ptr(buf) + row * LDW + c4 * 4) = stage[i];
+      }
+    }
+    if (tid < 32) bias_ptr(buf)[tid] = bstage;
+  };
+
+  // queue of survivors (sorted positions, in visiting order)
+  uint32_t qc[4] = {0, 0, 0, 0};
+  int qn_ = 0;
+  auto flush = [&]() {  // wave-uniform call
+    const float *crow[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) crow[i] = a.xs + (size_t)(i < qn_ ? qc[i] : 0) * DP;
+    float dist[4];
+    exact_distance4<NKH, METRIC, FASTX>(xrow, crow, D, h, col, dist);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (h == 0 && i < qn_ && dist[i] <= mndist) {  // knn.cu:209-212
+        knn_push_sample(k, dist[i], a.inv[qc[i]], heap);
+        mndist = heap[0];
+      }
+    }
+    mndist = __shfl(mndist, col);
+    amin = amin_of(mndist);
+    qn_ = 0;
+  };
+
+  unsigned long long calced = 0;
+  int ph = 0;
+  for (uint32_t step = 0; step <= K; step++) {
+    const uint32_t cls = step == 0 ? cls0 : step - 1;
+    if (step > 0 && cls == cls0) continue;
+    const uint32_t beg = a.offsets[cls], end = a.offsets[cls + 1];
+    bool pruned = !live;
+    if (step > 0) {
+      const float cd = a.C[(size_t)cls * K + cls0];
+      if (cd != cd) continue;                     // knn.cu:219-221 (block-uniform)
+      // the prune test needs the LIVE kth distance: settle the queue first (wave-uniform)
+      if (__ballot(qn_ > 0) != 0ull) flush();
+      const float lim = cd - md - a.R[cls];
+      pruned = pruned || (lim > mndist);          // knn.cu:222-225
+    }
+    if (beg == end) continue;                     // nothing to visit (block-uniform)
+    const unsigned long long visiting = __ballot(!pruned);
+    const bool wave_need = visiting != 0ull;
+    if (lane == 0) flags[ph * 4 + wave] = wave_need ? 1u : 0u;
+    __syncthreads();
+    const bool need = (flags[ph * 4] | flags[ph * 4 + 1] | flags[ph * 4 + 2] | flags[ph * 4 + 3]) != 0u;
+    ph ^= 1;
+    if (!need) continue;
+    calced += (unsigned long long)__popcll(visiting & 0xFFFFFFFFull) * (end - beg);  // knn.cu:228 per query
+
+    const uint32_t ntiles = (end - beg + 31) / 32;
+    stage_load(beg, end);
+    stage_store(0);
+    __syncthreads();
+    for (uint32_t t = 0; t < ntiles; t++) {
+      const int buf = t & 1;
+      const uint32_t tile_base = beg + t * 32;
+      if (t + 1 < ntiles) stage_load(tile_base + 32, end);
+      if (wave_need) {
+        f32x16 acc;
+        {
+          const float *bb = bias_ptr(buf) + 4 * h;
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bb + 8 * g);
+            acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
+          }
+        }
+        const _Float16 *arow = reinterpret_cast<const _Float16 *>(tile_ptr(buf) + col * LDW) + h * NKH;
+#pragma unroll
+        for (int j = 0; j < KS; j++) {
+          const f16x8 ahi = *reinterpret_cast<const f16x8 *>(arow + 8 * j);
+          const f16x8 alo = *reinterpret_cast<const f16x8 *>(arow + DP + 8 * j);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, xhi[j], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, xhi[j], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, xlo[j], acc, 0, 0, 0);
+        }
+        uint32_t m16 = 0;
+        if (!pruned) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) m16 |= (acc[r] >= amin ? 1u : 0u) << r;  // NaN scores never pass
+        }
+        if (__ballot(m16 != 0u) != 0ull) {
+          const uint32_t pm = __shfl_xor(m16, 32);
+          const uint32_t m0 = h ? pm : m16, m1 = h ? m16 : pm;
+          uint32_t rowmask = 0;
+#pragma unroll
+          for (int g = 0; g < 4; g++)
+            rowmask |= (((m0 >> (4 * g)) & 0xFu) << (8 * g)) | (((m1 >> (4 * g)) & 0xFu) << (8 * g + 4));
+          while (__ballot(rowmask != 0u) != 0ull) {
+            if (__ballot(qn_ == 4) != 0ull) flush();
+            bool active = rowmask != 0u;
+            const uint32_t rho = active ? (uint32_t)__ffs((int)rowmask) - 1u : 0u;
+            rowmask &= rowmask - 1u;
+            const uint32_t cp = tile_base + rho;
+            if (step == 0 && cp == qp) active = false;  // knn.cu:204-206: not its own neighbour
+            if (cp >= end) active = false;              // tile padding passes while the heap is not full
+            if (active) {
+#pragma unroll
+              for (int i = 0; i < 4; i++)
+                if (i == qn_) qc[i] = cp;
+              qn_++;
+            }
+          }
+        }
+      }
+      if (t + 1 < ntiles) stage_store(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  if (__ballot(qn_ > 0) != 0ull) flush();
+  if (live && h == 0) {  // knn.cu:239-242
+    uint32_t *out = a.out + (size_t)(qp - a.p_base) * k;
+    for (int i = (int)k - 1; i >= 0; i--) {
+      out[i] = reinterpret_cast<uint32_t *>(heap)[1];
+      knn_push_sample(k, -1.f, 0xFFFFFFFFu, heap);
+    }
+  }
+  if (lane == 0 && calced) atomicAdd(a.calced, calced);
+}
+
+hipError_t launch_knn_split(int metric, const float *xs, uint32_t N, uint32_t D, uint32_t DP, const float *mu,
+                            void *xs16, float *n2c, float *mux, uint32_t *stats, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(stats, 0, sizeof(uint32_t), st);
+  if (e != hipSuccess) return e;
+  if (metric == 0)
+    hipLaunchKernelGGL((knn_split_kernel<0>), dim3((N + 3) / 4), dim3(256), 0, st, xs, N, D, DP, mu,
+                       reinterpret_cast<_Float16 *>(xs16), n2c, mux, stats);
+  else
+    hipLaunchKernelGGL((knn_split_kernel<1>), dim3((N + 3) / 4), dim3(256), 0, st, xs, N, D, DP, mu,
+                       reinterpret_cast<_Float16 *>(xs16), n2c, mux, stats);
+  return hipGetLastError();
+}
+
+template <int DP, int METRIC>
+static hipError_t launch_knn_f16_t(const KnnArgs &a, uint32_t nblocks, hipStream_t st) {
+  const size_t lds_bytes = (2 * 32 * (DP + 4) + 64 + 8) * sizeof(float);
+  if (a.D == (uint32_t)DP)
+    hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, true>), dim3(nblocks), dim3(256), lds_bytes, st, a);
+  else
+    hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, false>), dim3(nblocks), dim3(256), lds_bytes, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_knn_filter_f16(int metric, const KnnArgs &a, uint32_t nblocks, hipStream_t st) {
+  if (nblocks == 0) return hipSuccess;
+#define KMX_KNN16_CASE(dp)                                                           \
+  case dp:                                                                           \
+    return metric == 0 ? launch_knn_f16_t<dp, 0>(a, nblocks, st) : launch_knn_f16_t<dp, 1>(a, nblocks, st)
+  switch (a.DP) {
+    KMX_KNN16_CASE(16);
+    KMX_KNN16_CASE(32);
+    KMX_KNN16_CASE(64);
+    KMX_KNN16_CASE(128);
+    KMX_KNN16_CASE(256);
+    default: return hipErrorInvalidValue;
+  }
+#undef KMX_KNN16_CASE
+}
+
+}  // namespace kmx

@@ -35,6 +35,7 @@
 //   at the group boundary the 1-2 contenders are queued (all members, evaluated at once, when
 //   three or more are within the error bound); queued distances are evaluated four at a time.
 #include "exact.hpp"
+#include "exact_split.hpp"
 #include "kernels.hpp"
 
 namespace kmx {
@@ -43,80 +44,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float kFltMax = 3.402823466e+38f;
-
-// Four exact chains at once over the D features of (original sample row, four centroid rows), all
-// from global memory: the lower half-wave runs features [0, NK), hands (acc, corr) to the upper
-// half which continues with [NK, D).  Every lane of a (col, col+32) pair gets the results.  The
-// four round-down FMAs of a feature share one rounding-mode window (exact.hpp).  Rolled loops: the
-// function is instantiated at several call sites and must stay small.
-// metric_abstraction.h:73-86 (L2 distance_t) / :193-205 (angular).
-template <int NK, int METRIC, bool FAST>
-__device__ __forceinline__ void exact_distance4(const float *__restrict__ xrow, const float *const (&crow)[4],
-                                                uint32_t D, int h, int col, float (&dist)[4]) {
-  float acc[4] = {0.f, 0.f, 0.f, 0.f}, corr[4] = {0.f, 0.f, 0.f, 0.f};
-  const int nvalid = (int)D - h * NK < 0 ? 0 : ((int)D - h * NK > NK ? NK : (int)D - h * NK);
-  for (int pass = 0; pass < 2; pass++) {
-    if (pass == 1) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        acc[i] = __shfl(acc[i], col);
-        corr[i] = __shfl(corr[i], col);
-      }
-    }
-    // only the half-wave whose features this pass covers loads and computes (the other half's
-    // lanes would gather 5 more scattered 16-byte pieces per step for nothing: the gathers, not the
-    // arithmetic, bound this path)
-    if (h == pass) {
-#pragma unroll 2
-      for (int j = 0; j < NK; j += 4) {
-        float xv[4], cv[4][4];
-        if (FAST) {
-          const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xrow + h * NK + j);
-          xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(crow[i] + h * NK + j);
-            cv[i][0] = v.x; cv[i][1] = v.y; cv[i][2] = v.z; cv[i][3] = v.w;
-          }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const bool in = j + q < nvalid;
-            xv[q] = in ? xrow[h * NK + j + q] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; i++) cv[i][q] = in ? crow[i][h * NK + j + q] : 0.f;
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          float y[4];
-          if (METRIC == 0) {
-            float d[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) d[i] = xv[q] - cv[i][q];
-            sqfma_rd4(d, corr, y);
-          } else {
-            const float b[4] = {cv[0][q], cv[1][q], cv[2][q], cv[3][q]};
-            fma_rd4(xv[q], b, corr, y);
-          }
-          const bool on = FAST || (j + q < nvalid);
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const float t = acc[i] + y[i];
-            const float nc = y[i] - (t - acc[i]);
-            acc[i] = on ? t : acc[i];
-            corr[i] = on ? nc : corr[i];
-          }
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const float total = __shfl(acc[i], col + 32);
-    dist[i] = METRIC == 0 ? sqrtf(total) : angular_from_prod(total);
-  }
-}
 
 // rows of the wave, centred: xb = x - mu; squared norms of x and of x - mu; x.mu
 #define KMX_YY_LOAD_ROWS(samples_, row_, live_)                                                      \
