@@ -2,9 +2,8 @@
 
 Same functions, argument grammar, defaults, return shapes and exception mapping as
 libKMCUDA.kmeans_cuda / knn_cuda (python.cc:159-410, :412-632), implemented over the C ABI of
-include/kmcuda.h with ctypes.  A native CPython module with the same surface
-(PyInit_libKMCUDA) is built into libKMCUDA.so as well; this file is the toolchain-independent
-route and what the parity tests call.
+include/kmcuda.h with ctypes (the reference binds the same two C functions from a CPython
+extension; `import libKMCUDA` at the repo root re-exports this module under the reference's name).
 """
 import ctypes
 import time

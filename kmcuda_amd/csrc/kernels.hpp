@@ -67,8 +67,6 @@ hipError_t launch_unpack_dcount(const double *src, uint32_t K, int32_t *dcount, 
 
 // seeding.hip (reference: kmeans.cu:42-67 kmeans_plus_plus, transpose.cu:6-14 copy_sample_t,
 // kmeans.cu:674-691 kmeans_calc_average_distance)
-hipError_t launch_gather_rows(const float *samples, uint32_t D, const uint32_t *row_ids, uint32_t nrows,
-                              float *dst, hipStream_t st);
 hipError_t launch_kmpp_step(int metric, const float *samples, uint32_t N, uint32_t D, const float *centroid,
                             uint32_t cc, float *dists, hipStream_t st);
 hipError_t launch_member_distances(int metric, const float *samples, uint32_t N, uint32_t D,

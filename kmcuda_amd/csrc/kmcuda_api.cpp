@@ -121,7 +121,6 @@ struct Shard {
   double *delta = nullptr;
   int32_t *dcount = nullptr;
   float *dists = nullptr;          // length floats (k-means++ / average distance)
-  uint32_t *row_ids = nullptr;     // K uint32 staging for gathers
   // Yinyang state (allocated when the Yinyang phase starts; reference: kmcuda.cc:448-470)
   float *bounds = nullptr;         // (G+1) x length, group-major (kmeans.cu:431-485 layout)
   float *drifts = nullptr;         // K*D old centroids + K per-centroid drifts
@@ -215,7 +214,6 @@ class Job {
       if ((rc = sh->alloc(&sh->delta, (size_t)K * D))) return rc;
       if ((rc = sh->alloc(&sh->dcount, K))) return rc;
       if ((rc = sh->alloc(&sh->dists, sh->length))) return rc;
-      if ((rc = sh->alloc(&sh->row_ids, K))) return rc;
       shards.push_back(std::move(sh));
     }
     bool distinct = shards.size() > 1;

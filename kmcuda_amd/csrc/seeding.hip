@@ -1,6 +1,4 @@
 // seeding.hip -- exact-arithmetic helper kernels around the hot path:
-//   gather_rows        (reference: transpose.cu:6-14 copy_sample_t -- with row-major samples a
-//                       "sample copy" is a contiguous row copy)
 //   kmpp_step          (reference: kmeans.cu:42-67 kmeans_plus_plus): d[s] = min(d[s], dist(s, newest c))
 //   member_distances   (reference: kmeans.cu:674-691 kmeans_calc_average_distance, per-sample part)
 // Distances use the reference's exact arithmetic (exact.hpp) so that the host-side chooser sees
@@ -11,20 +9,6 @@
 #include "kernels.hpp"
 
 namespace kmx {
-
-__global__ void gather_rows_kernel(const float *__restrict__ samples, uint32_t D, const uint32_t *__restrict__ row_ids,
-                                   float *__restrict__ dst) {
-  const uint32_t r = blockIdx.x;
-  const float *src = samples + (size_t)row_ids[r] * D;
-  for (uint32_t f = threadIdx.x; f < D; f += blockDim.x) dst[(size_t)r * D + f] = src[f];
-}
-
-hipError_t launch_gather_rows(const float *samples, uint32_t D, const uint32_t *row_ids, uint32_t nrows,
-                              float *dst, hipStream_t st) {
-  if (nrows == 0) return hipSuccess;
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(nrows), dim3(D >= 256 ? 256 : 64), 0, st, samples, D, row_ids, dst);
-  return hipGetLastError();
-}
 
 template <int METRIC>
 __global__ void kmpp_step_kernel(const float *__restrict__ samples, uint32_t N, uint32_t D,

@@ -74,3 +74,11 @@ def test_c_abi_validation_codes_without_gpu():
     nb = numpy.zeros((100, 5), numpy.uint32)
     assert L.knn_cuda(0, 0, 100, 4, 10, 0, -1, 0, 0, x.ctypes.data, cen.ctypes.data, asg.ctypes.data,
                       nb.ctypes.data) == 1
+
+
+def test_reference_module_name():
+    """`from libKMCUDA import kmeans_cuda, knn_cuda, supports_fp16` (test.py:8) works."""
+    import libKMCUDA
+    from kmcuda_amd import api
+    assert libKMCUDA.kmeans_cuda is api.kmeans_cuda and libKMCUDA.knn_cuda is api.knn_cuda
+    assert libKMCUDA.supports_fp16 is True
