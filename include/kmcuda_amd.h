@@ -38,10 +38,11 @@ int kmamd_lloyd_assign(kmamd_engine *e, const float *samples, const float *centr
 int kmamd_lloyd_assign_exact(kmamd_engine *e, const float *samples, const float *centroids,
                              uint32_t *assignments, uint32_t *assignments_prev);
 
-/* Which matrix-core instruction the assignment filter runs on: 0 = f16 MFMA on centred hi/lo-split
- * operands (default; 22 of 24 significand bits, rigorous bound, ~2.4x the f32 MFMA rate), 1 = f32
- * MFMA.  Assignments are bit-identical either way (the exact kernels decide what the filter cannot);
- * env KMCUDA_AMD_FILTER=f32 selects 1 at engine creation. */
+/* Which matrix-core scheme the assignment filter runs: 0 = two-stage f16 MFMA (default): a coarse
+ * pass with the high halves of the centred operands decides most rows, the hi/lo-split pass (22 of 24
+ * significand bits) the rest; 1 = f32 MFMA; 2 = the single-stage hi/lo-split f16 pass for every row.
+ * Assignments are bit-identical in all three (every stage carries a rigorous bound and the exact
+ * kernels decide what is left); env KMCUDA_AMD_FILTER=f32 | f16x3 selects 1 | 2 at engine creation. */
 int kmamd_set_filter(kmamd_engine *e, int mode);
 
 /* fp16x2 path: the engine's local rows as IEEE halves (n_rows x features halves, row-major, kept

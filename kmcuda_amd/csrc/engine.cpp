@@ -24,7 +24,8 @@ Engine::~Engine() {
 
 int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric, int fp16x2, hipStream_t stream) {
   if (getenv("KMCUDA_AMD_DEBUG")) g_verbosity = atoi(getenv("KMCUDA_AMD_DEBUG"));
-  if (const char *f = getenv("KMCUDA_AMD_FILTER")) filter_mode_ = (strcmp(f, "f32") == 0) ? 1 : 0;
+  if (const char *f = getenv("KMCUDA_AMD_FILTER"))
+    filter_mode_ = strcmp(f, "f32") == 0 ? 1 : (strcmp(f, "f16x3") == 0 ? 2 : 0);
   if (D == 0 || K < 1 || K >= 0x7FFFFFFFu) return kInvalidArguments;  // K == 1: Yinyang group clustering with one group
   if (fp16x2) return kInvalidArguments;  // fp16x2 kernels are not built yet ("next")
   int ndev = 0;
@@ -60,7 +61,7 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if ((rc = alloc(&finite_, Kt_))) return rc;
   if ((rc = alloc(&flagged_, n_rows))) return rc;
   if ((rc = alloc(&pairs_, 3 * (size_t)n_rows))) return rc;
-  if ((rc = alloc(&counters_, 4))) return rc;
+  if ((rc = alloc(&counters_, 8))) return rc;
   if ((rc = alloc(&keys_tmp_, 2 * (size_t)n_rows))) return rc;
   if ((rc = alloc(&vals_tmp_, 2 * (size_t)n_rows))) return rc;
   if ((rc = alloc(&keys_sorted_, 2 * (size_t)n_rows))) return rc;
@@ -78,7 +79,7 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   }
   if ((rc = alloc(&partial_, (size_t)2 * K * kSumSplit * D))) return rc;
   KMX_HIP(hipHostMalloc((void **)&host_counters_, 4 * sizeof(uint32_t), hipHostMallocDefault), kMemoryAllocationFailure);
-  KMX_HIP(hipMemsetAsync(counters_, 0, 4 * sizeof(uint32_t), stream_), kRuntimeError);
+  KMX_HIP(hipMemsetAsync(counters_, 0, 8 * sizeof(uint32_t), stream_), kRuntimeError);
   return kSuccess;
 }
 
@@ -260,17 +261,26 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   }
   // counters_[1] / [3] (the filter's list lengths) were zeroed by centroid_prep
   span_begin(0);
-  if (filter_mode_ == 0 && lloyd_filter_f16_supported(D_, DP_)) {
+  if (filter_mode_ != 1 && lloyd_filter_f16_supported(D_, DP_)) {
     if (!panel16_) {
-      uint16_t *p16 = nullptr;
+      uint16_t *p16 = nullptr, *phi = nullptr;
       int rc = alloc(&p16, (size_t)K_pad_ * 2 * DP_);
       if (rc) return rc;
+      if ((rc = alloc(&phi, (size_t)K_pad_ * DP_))) return rc;
+      if ((rc = alloc(&undecided_, N_))) return rc;
       panel16_ = p16;
+      panelhi_ = phi;
     }
+    const void *rows = half_rows_ ? half_rows_ : (const void *)samples;
+    const bool half = half_rows_ != nullptr;
     KMX_HIP(launch_centroid_panel16(centroids, K_, D_, K_pad_, DP_, finite_, mu_, panel16_, stream_), kRuntimeError);
-    KMX_HIP(launch_lloyd_filter_f16(a, half_rows_ ? half_rows_ : (const void *)samples, half_rows_ != nullptr,
-                                    panel16_, stream_),
-            kRuntimeError);
+    if (filter_mode_ == 0) {
+      KMX_HIP(hipMemsetAsync(counters_ + 4, 0, sizeof(uint32_t), stream_), kRuntimeError);
+      KMX_HIP(launch_lloyd_coarse(a, rows, half, panel16_, panelhi_, undecided_, stream_), kRuntimeError);
+      KMX_HIP(launch_lloyd_filter_f16(a, rows, half, panel16_, undecided_, counters_ + 4, stream_), kRuntimeError);
+    } else {
+      KMX_HIP(launch_lloyd_filter_f16(a, rows, half, panel16_, nullptr, nullptr, stream_), kRuntimeError);
+    }
   } else {
     KMX_HIP(launch_lloyd_filter(a, stream_), kRuntimeError);
   }
@@ -390,7 +400,7 @@ int kmamd_apply_delta(kmamd_engine *e, const double *delta, const int32_t *dcoun
   return e->e.apply_delta(delta, dcount, centroids, ccounts);
 }
 int kmamd_set_filter(kmamd_engine *e, int mode) {
-  if (mode != 0 && mode != 1) return kmx::kInvalidArguments;
+  if (mode < 0 || mode > 2) return kmx::kInvalidArguments;
   e->e.filter_mode_ = mode;
   return kmx::kSuccess;
 }

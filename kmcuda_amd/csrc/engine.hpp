@@ -76,8 +76,11 @@ class Engine {
   uint32_t *finite_ = nullptr;
   // fp16x2 path: the local rows as halves (caller-owned) + the hi/lo-split centred centroid panel
   const void *half_rows_ = nullptr;
-  void *panel16_ = nullptr;
-  int filter_mode_ = 0;  // 0: split-f16 matrix-core filter (default), 1: f32 matrix-core filter (KMCUDA_AMD_FILTER=f32)
+  void *panel16_ = nullptr, *panelhi_ = nullptr;
+  uint32_t *undecided_ = nullptr;
+  // 0: two-stage f16 matrix-core filter (hi.hi, then hi/lo split for the undecided rows; default),
+  // 1: f32 matrix-core filter (KMCUDA_AMD_FILTER=f32), 2: single-stage hi/lo-split f16 filter (=f16x3)
+  int filter_mode_ = 0;
   uint32_t *stats_ = nullptr, *flagged_ = nullptr, *pairs_ = nullptr, *counters_ = nullptr;
   // update workspace
   uint32_t *keys_tmp_ = nullptr, *vals_tmp_ = nullptr, *keys_sorted_ = nullptr, *rows_sorted_ = nullptr,

@@ -23,7 +23,7 @@ struct LloydArgs {
   uint32_t *assignments, *assignments_prev;
   uint32_t *flagged;         // N: rows with three or more contenders (full exact scan)
   uint32_t *pairs;           // 3N: (row, i1, i2) rows with exactly two contenders
-  uint32_t *counters;        // [0] changed, [1] flagged, [2] passed (yinyang), [3] pairs
+  uint32_t *counters;        // [0] changed, [1] flagged, [2] passed (yinyang), [3] pairs, [4] undecided by stage 1
 };
 
 uint32_t filter_dp_for(uint32_t D);
@@ -42,7 +42,10 @@ bool lloyd_filter_f16_supported(uint32_t D, uint32_t DP);
 hipError_t launch_centroid_panel16(const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP,
                                    const uint32_t *finite, const float *mu, void *panel16, hipStream_t st);
 hipError_t launch_lloyd_filter_f16(const LloydArgs &a, const void *rows, bool half_rows, const void *panel16,
-                                   hipStream_t st);
+                                   const uint32_t *row_list, const uint32_t *n_list, hipStream_t st);
+// stage 1 of the default filter: hi.hi products only; rows it cannot decide -> undecided[counters[4]++]
+hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_rows, const void *panel16,
+                               void *panelhi, uint32_t *undecided, hipStream_t st);
 
 // update.hip -- centroid update (reference: kmeans.cu:366-429 kmeans_adjust)
 constexpr uint32_t kSumSplit = 8;

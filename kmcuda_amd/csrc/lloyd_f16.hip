@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_f16_kernel(
     const float *__restrict__ bias, const float *__restrict__ mu, uint32_t K_pad, uint32_t K,
     const uint32_t *__restrict__ stats, float eps, float tie_slack, uint32_t *__restrict__ assignments,
     uint32_t *__restrict__ assignments_prev, uint32_t *__restrict__ flagged, uint32_t *__restrict__ pairs,
-    uint32_t *__restrict__ counters) {
+    uint32_t *__restrict__ counters, const uint32_t *__restrict__ row_list, const uint32_t *__restrict__ n_list) {
   constexpr int NKH = DP / 2;          // features per half-wave
   constexpr int KS = NKH / 8;          // k-steps (8 features per lane per MFMA)
   constexpr int LDW = DP + 4;          // padded LDS row in 4-byte words (row = 2*DP halves)
@@ -70,8 +70,13 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_f16_kernel(
   auto bias_ptr = [&](int buf) { return lds + 2 * TILE + buf * 32; };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
-  const uint32_t s = blockIdx.x * 128u + wave * 32u + col;
-  const bool live = s < N;
+  // all rows (row_list == nullptr: one 128-row group per block) or the rows the coarse stage could not
+  // decide (a device-side list: the grid strides over its 128-row groups)
+  const uint32_t total = row_list ? *n_list : N;
+  for (uint32_t group = blockIdx.x; (size_t)group * 128u < total; group += gridDim.x) {
+  const uint32_t pi = group * 128u + wave * 32u + col;
+  const bool live = pi < total;
+  const uint32_t s = row_list ? (live ? row_list[pi] : 0u) : pi;
 
   // ---- B operand: my half row, centred in fp32, split into hi / lo halves ----
   f16x8 xhi[KS], xlo[KS];
@@ -226,8 +231,189 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_f16_kernel(
                        2.9802322e-8f * sqrtf((float)DP) * (xn + cmaxc);
   const float e_ref = u * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
   const float thr = 2.0f * (e_mfma + e_ref) * 1.001f + tie_slack;
-  filter_finish(v1, v2, v3, c1, c2, h, lane, s, N, K, insane, thr, assignments, assignments_prev, flagged, pairs,
-                counters);
+  // filter_finish treats a row as present iff s < N: present rows carry their index, absent ones N
+  filter_finish(v1, v2, v3, c1, c2, h, lane, live ? s : N, N, K, insane, thr, assignments, assignments_prev, flagged,
+                pairs, counters);
+  __syncthreads();  // the LDS tiles are reused by the next group
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Stage 1 of the default filter: ONE f16 MFMA per 16 features (hi.hi only).  Under the f16 matrix
+// load the chip is power limited (profiles/: 1.75 GHz), so the lever is fewer matrix operations:
+// the coarse scores carry |error| <= E_c ~ 2^-10 ||x'|| C'max, enough to decide the rows whose
+// best / second-best gap exceeds 2 E_c (the large majority); only the others go through the
+// three-product kernel above.  Half the registers (no lo halves) and half the LDS (hi panel only)
+// => 3 blocks per CU.
+// ---------------------------------------------------------------------------------------
+template <int DP, bool HALF_ROWS, bool FAST>
+__global__ __launch_bounds__(256, 3) void lloyd_coarse_kernel(
+    const void *__restrict__ rows, uint32_t N, uint32_t D, const float *__restrict__ panelhi,
+    const float *__restrict__ bias, const float *__restrict__ mu, uint32_t K_pad, uint32_t K,
+    const uint32_t *__restrict__ stats, float eps, float tie_slack, uint32_t *__restrict__ assignments,
+    uint32_t *__restrict__ assignments_prev, uint32_t *__restrict__ undecided, uint32_t *__restrict__ counters) {
+  constexpr int NKH = DP / 2;
+  constexpr int KS = NKH / 8;
+  constexpr int LDW = DP / 2 + 4;      // padded LDS row in 4-byte words (row = DP halves)
+  constexpr int TILE = 32 * LDW;
+  constexpr int NST = (4 * DP + 255) / 256;   // 16-byte pieces per thread per tile
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  auto tile_ptr = [&](int buf) { return lds + buf * TILE; };
+  auto bias_ptr = [&](int buf) { return lds + 2 * TILE + buf * 32; };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+  const uint32_t s = blockIdx.x * 128u + wave * 32u + col;
+  const bool live = s < N;
+
+  f16x8 xhi[KS];
+  float xn2 = 0.f, xo2 = 0.f, x0 = 0.f;
+  {
+    const size_t row = (size_t)(live ? s : 0);
+    const float *m = mu + h * NKH;
+#pragma unroll
+    for (int j = 0; j < KS; j++) {
+      float xv[8];
+      if (FAST && HALF_ROWS) {
+        const f16x8 raw = reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(rows) + row * DP + h * NKH)[j];
+#pragma unroll
+        for (int q = 0; q < 8; q++) xv[q] = (float)raw[q];
+      } else if (FAST) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(rows) + row * DP + h * NKH);
+        const f32x4 a = src[2 * j], b = src[2 * j + 1];
+        xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w;
+        xv[4] = b.x; xv[5] = b.y; xv[6] = b.z; xv[7] = b.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const uint32_t f = h * NKH + 8 * j + q;
+          float v = 0.f;
+          if (f < D) v = HALF_ROWS ? (float)reinterpret_cast<const _Float16 *>(rows)[row * D + f]
+                                   : reinterpret_cast<const float *>(rows)[row * D + f];
+          xv[q] = v;
+        }
+      }
+      f16x8 hi;
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const bool on = live && (FAST || h * NKH + 8 * j + q < (int)D);
+        const float x = on ? xv[q] : 0.f;
+        const float xc = on ? x - m[8 * j + q] : 0.f;
+        hi[q] = (_Float16)xc;
+        xo2 = fmaf(x, x, xo2);
+        xn2 = fmaf(xc, xc, xn2);
+        if (j == 0 && q == 0) x0 = live ? xv[q] : 0.f;
+      }
+      xhi[j] = hi;
+    }
+  }
+  xn2 += __shfl_xor(xn2, 32);
+  xo2 += __shfl_xor(xo2, 32);
+  x0 = __shfl(x0, col);
+  const bool insane = (x0 != x0);  // kmeans.cu:312
+
+  f32x4 stage[NST];
+  float bstage = 0.f;
+  auto stage_load = [&](uint32_t tile) {
+    const float *src = panelhi + (size_t)tile * 32 * (DP / 2);
+#pragma unroll
+    for (int i = 0; i < NST; i++) {
+      const int q = tid + i * 256;
+      if (q < 4 * DP) stage[i] = reinterpret_cast<const f32x4 *>(src)[q];
+    }
+    if (tid < 32) bstage = bias[tile * 32 + tid];
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NST; i++) {
+      const int q = tid + i * 256;
+      if (q < 4 * DP) {
+        const int row = q / (DP / 8), c4 = q % (DP / 8);
+        *reinterpret_cast<f32x4 *>(tile_ptr(buf) + row * LDW + c4 * 4) = stage[i];
+      }
+    }
+    if (tid < 32) bias_ptr(buf)[tid] = bstage;
+  };
+
+  const uint32_t ntiles = K_pad / 32;
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  float v1 = -INFINITY, v2 = -INFINITY;
+  uint32_t c1 = 0xFFFFFFFFu;
+  for (uint32_t t = 0; t < ntiles; t++) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) stage_load(t + 1);
+    f32x16 acc;
+    {
+      const float *bb = bias_ptr(buf) + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bb + 8 * g);
+        acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
+      }
+    }
+    const _Float16 *arow = reinterpret_cast<const _Float16 *>(tile_ptr(buf) + col * LDW) + h * NKH;
+#pragma unroll
+    for (int j = 0; j < KS; j++)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(arow + 8 * j), xhi[j], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float v = acc[r];
+      const bool g1 = v > v1;
+      v2 = __builtin_amdgcn_fmed3f(v1, v2, v);
+      c1 = g1 ? t * 16u + r : c1;
+      v1 = fmaxf(v1, v);
+    }
+    if (t + 1 < ntiles) stage_store(buf ^ 1);
+    __syncthreads();
+  }
+  // merge the half-waves (same sample, disjoint centroid rows)
+  uint32_t i1 = 0xFFFFFFFFu;
+  if (c1 != 0xFFFFFFFFu) {
+    const uint32_t r = c1 & 15u;
+    i1 = (c1 >> 4) * 32u + (r & 3u) + 8u * (r >> 2) + 4u * h;
+  }
+  {
+    const float pv1 = __shfl_xor(v1, 32), pv2 = __shfl_xor(v2, 32);
+    const uint32_t pi1 = __shfl_xor(i1, 32);
+    const bool g = pv1 > v1;
+    const float second = fmaxf(g ? v1 : pv1, fmaxf(v2, pv2));  // fmax ignores a NaN operand
+    i1 = g ? pi1 : i1;
+    v1 = g ? pv1 : v1;
+    v2 = second;
+  }
+  // |coarse score - reference score| <= E_c: the f32-accumulated hi.hi products (gamma_{DP+1}), the
+  // dropped lo terms (|a_lo| <= 2^-11 |a|: (2^-10 + 2^-22) ||x'|| C'max) and half underflow, + E_ref
+  const float cmaxc = sqrtf(__uint_as_float(stats[0])) * 1.000001f;
+  const float bmaxc = __uint_as_float(stats[1]);
+  const float cmaxo = sqrtf(__uint_as_float(stats[2])) * 1.000001f;
+  const float xn = sqrtf(xn2) * 1.0001f, xo = sqrtf(xo2) * 1.0001f;
+  const float u = 5.9604645e-8f;
+  const float e_c = 2.0f * eps * (xn * cmaxc + bmaxc) + 9.8e-4f * xn * cmaxc +
+                    6e-8f * sqrtf((float)DP) * (xn + cmaxc);
+  const float e_ref = u * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
+  const float thr = 2.0f * (e_c + e_ref) * 1.001f + tie_slack;
+  const bool certain = insane || ((v1 - v2) > thr);  // NaN gap / thr => not certain
+  const bool mine = (h == 0) && live;
+  bool changed = false;
+  if (mine && certain) changed = commit_row(s, insane ? K : i1, assignments, assignments_prev);
+  const bool und = mine && !certain;
+  const unsigned long long cm = __ballot(changed), um = __ballot(und);
+  if (lane == 0 && cm) atomicAdd(&counters[0], (uint32_t)__popcll(cm));
+  if (um) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&counters[4], (uint32_t)__popcll(um));
+    base = __shfl(base, 0);
+    if (und) undecided[base + (uint32_t)__popcll(um & ((1ull << lane) - 1ull))] = s;
+  }
+}
+
+// c' = c - mu, hi halves only: panelhi[c] = hi(c'_0..DP-1)
+__global__ void centroid_panelhi_kernel(const _Float16 *__restrict__ panel16, uint32_t K_pad, uint32_t DP,
+                                        _Float16 *__restrict__ panelhi) {
+  const uint32_t c = blockIdx.x;
+  if (c >= K_pad) return;
+  for (uint32_t f = threadIdx.x; f < DP; f += blockDim.x) panelhi[(size_t)c * DP + f] = panel16[(size_t)c * 2 * DP + f];
 }
 
 hipError_t launch_centroid_panel16(const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP,
@@ -239,14 +425,15 @@ hipError_t launch_centroid_panel16(const float *centroids, uint32_t K, uint32_t 
 
 template <int DP>
 static hipError_t launch_f16_dp(const LloydArgs &a, const void *rows, bool half_rows, const void *panel16,
-                                hipStream_t st) {
+                                const uint32_t *row_list, const uint32_t *n_list, hipStream_t st) {
   const size_t lds_bytes = (2 * 32 * (DP + 4) + 64) * sizeof(float);
-  const uint32_t grid = (a.N + 127) / 128;
+  uint32_t grid = (a.N + 127) / 128;
+  if (row_list && grid > 4096) grid = 4096;  // the list kernel strides over the device-side count
   const bool fast = a.D == (uint32_t)DP;
 #define KMX_F16_LAUNCH(H, F)                                                                                       \
   hipLaunchKernelGGL((lloyd_filter_f16_kernel<DP, H, F>), dim3(grid), dim3(256), lds_bytes, st, rows, a.N, a.D,     \
                      reinterpret_cast<const float *>(panel16), a.bias, a.mu, a.K_pad, a.K, a.stats, a.eps,           \
-                     a.tie_slack, a.assignments, a.assignments_prev, a.flagged, a.pairs, a.counters)
+                     a.tie_slack, a.assignments, a.assignments_prev, a.flagged, a.pairs, a.counters, row_list, n_list)
   if (half_rows) {
     if (fast) KMX_F16_LAUNCH(true, true); else KMX_F16_LAUNCH(true, false);
   } else {
@@ -256,17 +443,50 @@ static hipError_t launch_f16_dp(const LloydArgs &a, const void *rows, bool half_
   return hipGetLastError();
 }
 
+template <int DP>
+static hipError_t launch_coarse_dp(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
+                                   uint32_t *undecided, hipStream_t st) {
+  const size_t lds_bytes = (2 * 32 * (DP / 2 + 4) + 64) * sizeof(float);
+  const uint32_t grid = (a.N + 127) / 128;
+  const bool fast = a.D == (uint32_t)DP;
+#define KMX_CRS_LAUNCH(H, F)                                                                                       \
+  hipLaunchKernelGGL((lloyd_coarse_kernel<DP, H, F>), dim3(grid), dim3(256), lds_bytes, st, rows, a.N, a.D,         \
+                     reinterpret_cast<const float *>(panelhi), a.bias, a.mu, a.K_pad, a.K, a.stats, a.eps,           \
+                     a.tie_slack, a.assignments, a.assignments_prev, undecided, a.counters)
+  if (half_rows) {
+    if (fast) KMX_CRS_LAUNCH(true, true); else KMX_CRS_LAUNCH(true, false);
+  } else {
+    if (fast) KMX_CRS_LAUNCH(false, true); else KMX_CRS_LAUNCH(false, false);
+  }
+#undef KMX_CRS_LAUNCH
+  return hipGetLastError();
+}
+
 // one MFMA consumes 8 features per half-wave: the padded width must be at least 16
 bool lloyd_filter_f16_supported(uint32_t D, uint32_t DP) { return DP >= 16 && D <= DP; }
 
 hipError_t launch_lloyd_filter_f16(const LloydArgs &a, const void *rows, bool half_rows, const void *panel16,
-                                   hipStream_t st) {
+                                   const uint32_t *row_list, const uint32_t *n_list, hipStream_t st) {
   switch (a.DP) {
-    case 16: return launch_f16_dp<16>(a, rows, half_rows, panel16, st);
-    case 32: return launch_f16_dp<32>(a, rows, half_rows, panel16, st);
-    case 64: return launch_f16_dp<64>(a, rows, half_rows, panel16, st);
-    case 128: return launch_f16_dp<128>(a, rows, half_rows, panel16, st);
-    case 256: return launch_f16_dp<256>(a, rows, half_rows, panel16, st);
+    case 16: return launch_f16_dp<16>(a, rows, half_rows, panel16, row_list, n_list, st);
+    case 32: return launch_f16_dp<32>(a, rows, half_rows, panel16, row_list, n_list, st);
+    case 64: return launch_f16_dp<64>(a, rows, half_rows, panel16, row_list, n_list, st);
+    case 128: return launch_f16_dp<128>(a, rows, half_rows, panel16, row_list, n_list, st);
+    case 256: return launch_f16_dp<256>(a, rows, half_rows, panel16, row_list, n_list, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_rows, const void *panel16,
+                               void *panelhi, uint32_t *undecided, hipStream_t st) {
+  hipLaunchKernelGGL(centroid_panelhi_kernel, dim3(a.K_pad), dim3(a.DP >= 256 ? 256 : 64), 0, st,
+                     reinterpret_cast<const _Float16 *>(panel16), a.K_pad, a.DP, reinterpret_cast<_Float16 *>(panelhi));
+  switch (a.DP) {
+    case 16: return launch_coarse_dp<16>(a, rows, half_rows, panelhi, undecided, st);
+    case 32: return launch_coarse_dp<32>(a, rows, half_rows, panelhi, undecided, st);
+    case 64: return launch_coarse_dp<64>(a, rows, half_rows, panelhi, undecided, st);
+    case 128: return launch_coarse_dp<128>(a, rows, half_rows, panelhi, undecided, st);
+    case 256: return launch_coarse_dp<256>(a, rows, half_rows, panelhi, undecided, st);
     default: return hipErrorInvalidValue;
   }
 }

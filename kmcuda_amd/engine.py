@@ -57,8 +57,9 @@ class Engine:
                    "kmamd_lloyd_assign")
 
     def set_filter(self, mode):
-        """"f16" (default): f16 matrix cores on centred hi/lo-split operands; "f32": f32 matrix cores."""
-        _lib.check(self.lib.kmamd_set_filter(self.h, {"f16": 0, "f32": 1}[mode]), "kmamd_set_filter")
+        """"f16" (default): two-stage f16 matrix-core filter; "f32": f32 matrix cores; "f16x3": the
+        single-stage hi/lo-split f16 pass."""
+        _lib.check(self.lib.kmamd_set_filter(self.h, {"f16": 0, "f32": 1, "f16x3": 2}[mode]), "kmamd_set_filter")
 
     def set_half_rows(self, rows16):
         """rows16: float16 CUDA tensor with the same values as the fp32 rows (or None)."""
