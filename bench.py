@@ -98,10 +98,10 @@ def main():
     ap.add_argument("--features", type=int, default=256)
     ap.add_argument("--clusters", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--filter", default="f16", choices=["f16", "f32"],
-                    help="matrix-core instruction of the assignment filter: f16 = v_mfma_f32_32x32x16_f16 on centred "
-                         "hi/lo-split operands (default, fastest), f32 = v_mfma_f32_32x32x2_f32.  Assignments are "
-                         "bit-identical either way")
+    ap.add_argument("--filter", default="f16", choices=["f16", "f16x3", "f32"],
+                    help="matrix-core scheme of the assignment filter: f16 = two-stage v_mfma_f32_32x32x16_f16 (coarse "
+                         "hi.hi pass, then the hi/lo-split pass on the undecided rows; default, fastest), f16x3 = the "
+                         "hi/lo-split pass for every row, f32 = v_mfma_f32_32x32x2_f32.  Assignments are bit-identical")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                     help="f32: the headline fp32 L2 path.  f16: the fp16x2 path (rows as halves, f16 matrix-core "
                          "filter; same assignments as the fp32 path on the same values)")
@@ -168,7 +168,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = backend.engine.profile_read()
     # outside the timed region: the OTHER filter on the same state, for the side-by-side roofline entry
-    other = "f32" if args.filter == "f16" else "f16"
+    other = "f32" if args.filter != "f32" else "f16"
     backend.engine.set_filter(other)
     backend.assign()
     backend.engine.profile(True)
@@ -198,16 +198,20 @@ def main():
         f16 = args.dtype == "f16"
 
         def roof(filt, ms):
-            # f32 filter: one v_mfma_f32_32x32x2_f32 MAC per algorithmic MAC -> the f32 MFMA peak.
-            # f16 filter: three f16 products per algorithmic MAC (hi.hi + hi.lo + lo.hi) -> the dense f16
-            # MFMA peak / 3 is the ceiling of the ALGORITHMIC rate (MI355X_MICROARCH.md: 157.3 / 2500 TFLOP/s)
-            pk = PEAK_FP32_MFMA_TFLOPS if filt == "f32" else 2500.0 / 3.0
+            # ceilings of the ALGORITHMIC rate (2*D*K flop per row), MI355X_MICROARCH.md peaks:
+            #   f32   one v_mfma_f32_32x32x2_f32 MAC per algorithmic MAC        -> 157.3 TFLOP/s
+            #   f16x3 three half products per MAC (hi.hi + hi.lo + lo.hi)        -> 2500 / 3
+            #   f16   two-stage: the dominant (coarse) kernel does ONE half product per MAC -> 2500
+            pk = {"f32": PEAK_FP32_MFMA_TFLOPS, "f16x3": 2500.0 / 3.0, "f16": 2500.0}[filt]
             ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             return pk, ach
         peak, achieved = roof(args.filter, filter_ms)
         other_ms = prof_other["filter_ms"] / max(prof_other["filter_launches"], 1)
         opeak, oach = roof(other, other_ms)
-        kname = {"f16": "lloyd_filter_f16_kernel<256,%s,true>" % ("true" if f16 else "false"),
+        hr = "true" if f16 else "false"
+        kname = {"f16": "lloyd_coarse_kernel<256,%s,true> (+ lloyd_filter_f16_kernel<256,%s,true> on the rows it "
+                        "cannot decide; kernel_ms covers both)" % (hr, hr),
+                 "f16x3": "lloyd_filter_f16_kernel<256,%s,true>" % hr,
                  "f32": "lloyd_filter_kernel<256,true>"}
         out = {
             "metric": "point-assignments/sec per Lloyd iter (8Mx256@1024)",
@@ -222,8 +226,9 @@ def main():
                          "traffic": pmc_traffic(n_local) if (args.filter == "f32" and not f16) else None,
                          "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
                          "algorithmic_bytes": n_local * (D * (2 if f16 else 4) + 4), "algorithmic_flop": flops,
-                         "peak_note": "f32: dense f32 MFMA peak; f16: dense f16 MFMA peak / 3 (three half products "
-                                      "per algorithmic MAC of the hi/lo split)",
+                         "peak_note": "dense MFMA peak of the instruction the dominant kernel issues, per algorithmic "
+                                      "MAC: f32 157.3; f16 (two-stage, coarse pass = one half product per MAC) 2500; "
+                                      "f16x3 (three half products per MAC) 2500/3",
                          "kernel": kname[args.filter],
                          "kernel_ms": filter_ms, "rows_per_launch": n_local},
             "roofline_other_filter": {"filter": other, "kernel": kname[other], "kernel_ms": other_ms, "achieved": oach,

@@ -243,11 +243,11 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_f16_kernel(
 // load the chip is power limited (profiles/: 1.75 GHz), so the lever is fewer matrix operations:
 // the coarse scores carry |error| <= E_c ~ 2^-10 ||x'|| C'max, enough to decide the rows whose
 // best / second-best gap exceeds 2 E_c (the large majority); only the others go through the
-// three-product kernel above.  Half the registers (no lo halves) and half the LDS (hi panel only)
-// => 3 blocks per CU.
+// three-product kernel above.
 // ---------------------------------------------------------------------------------------
+constexpr int kCoarseThreads = 512;  // 8 waves share a super-tile: 2 blocks/CU = 4 waves per SIMD
 template <int DP, bool HALF_ROWS, bool FAST>
-__global__ __launch_bounds__(256, 3) void lloyd_coarse_kernel(
+__global__ __launch_bounds__(kCoarseThreads, 2) void lloyd_coarse_kernel(
     const void *__restrict__ rows, uint32_t N, uint32_t D, const float *__restrict__ panelhi,
     const float *__restrict__ bias, const float *__restrict__ mu, uint32_t K_pad, uint32_t K,
     const uint32_t *__restrict__ stats, float eps, float tie_slack, uint32_t *__restrict__ assignments,
@@ -256,13 +256,12 @@ __global__ __launch_bounds__(256, 3) void lloyd_coarse_kernel(
   constexpr int KS = NKH / 8;
   constexpr int LDW = DP / 2 + 4;      // padded LDS row in 4-byte words (row = DP halves)
   constexpr int TILE = 32 * LDW;
-  constexpr int NST = (4 * DP + 255) / 256;   // 16-byte pieces per thread per tile
+  constexpr int BT = kCoarseThreads;
+  constexpr int NST = (4 * DP + BT - 1) / BT;   // 16-byte pieces per thread per tile
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  auto tile_ptr = [&](int buf) { return lds + buf * TILE; };
-  auto bias_ptr = [&](int buf) { return lds + 2 * TILE + buf * 32; };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
-  const uint32_t s = blockIdx.x * 128u + wave * 32u + col;
+  const uint32_t s = blockIdx.x * (uint32_t)(BT / 2) + wave * 32u + col;
   const bool live = s < N;
 
   f16x8 xhi[KS];
@@ -311,48 +310,50 @@ __global__ __launch_bounds__(256, 3) void lloyd_coarse_kernel(
   x0 = __shfl(x0, col);
   const bool insane = (x0 != x0);  // kmeans.cu:312
 
-  f32x4 stage[NST];
+  // A tile's matrix work is only 16 MFMAs (512 cycles), so the barrier and the staging round trip
+  // weigh as much as the tile itself: stage SUPER-TILES of 64 centroids (two 32-row MFMA tiles) per
+  // barrier, double buffered (2 x 64 x (DP + 8) bytes of LDS, 2 blocks per CU).
+  constexpr int NSS = 2 * NST;  // 16-byte pieces per thread per super-tile
+  f32x4 stage[NSS];
   float bstage = 0.f;
-  auto stage_load = [&](uint32_t tile) {
-    const float *src = panelhi + (size_t)tile * 32 * (DP / 2);
+  const uint32_t ntiles = K_pad / 32, nsuper = (ntiles + 1) / 2;
+  auto sup_tile = [&](int buf, int sub) { return lds + (buf * 2 + sub) * TILE; };
+  auto sup_bias = [&](int buf) { return lds + 4 * TILE + buf * 64; };
+  auto stage_load = [&](uint32_t sp) {
+    const float *src = panelhi + (size_t)sp * 64 * (DP / 2);
+    const int limit = (2 * sp + 1 < ntiles) ? 8 * DP : 4 * DP;  // the last super-tile may hold one tile
 #pragma unroll
-    for (int i = 0; i < NST; i++) {
-      const int q = tid + i * 256;
-      if (q < 4 * DP) stage[i] = reinterpret_cast<const f32x4 *>(src)[q];
+    for (int i = 0; i < NSS; i++) {
+      const int q = tid + i * BT;
+      if (q < limit) stage[i] = reinterpret_cast<const f32x4 *>(src)[q];
     }
-    if (tid < 32) bstage = bias[tile * 32 + tid];
+    if (tid < 64) bstage = (sp * 64 + tid < K_pad) ? bias[sp * 64 + tid] : -INFINITY;
   };
   auto stage_store = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < NST; i++) {
-      const int q = tid + i * 256;
-      if (q < 4 * DP) {
-        const int row = q / (DP / 8), c4 = q % (DP / 8);
-        *reinterpret_cast<f32x4 *>(tile_ptr(buf) + row * LDW + c4 * 4) = stage[i];
+    for (int i = 0; i < NSS; i++) {
+      const int q = tid + i * BT;
+      if (q < 8 * DP) {
+        const int row = q / (DP / 8), c4 = q % (DP / 8);  // row 0..63
+        *reinterpret_cast<f32x4 *>(sup_tile(buf, row >> 5) + (row & 31) * LDW + c4 * 4) = stage[i];
       }
     }
-    if (tid < 32) bias_ptr(buf)[tid] = bstage;
+    if (tid < 64) sup_bias(buf)[tid] = bstage;
   };
 
-  const uint32_t ntiles = K_pad / 32;
-  stage_load(0);
-  stage_store(0);
-  __syncthreads();
   float v1 = -INFINITY, v2 = -INFINITY;
   uint32_t c1 = 0xFFFFFFFFu;
-  for (uint32_t t = 0; t < ntiles; t++) {
-    const int buf = t & 1;
-    if (t + 1 < ntiles) stage_load(t + 1);
+  auto compute_tile = [&](uint32_t t, int buf, int sub) {
     f32x16 acc;
     {
-      const float *bb = bias_ptr(buf) + 4 * h;
+      const float *bb = sup_bias(buf) + 32 * sub + 4 * h;
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bb + 8 * g);
         acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
       }
     }
-    const _Float16 *arow = reinterpret_cast<const _Float16 *>(tile_ptr(buf) + col * LDW) + h * NKH;
+    const _Float16 *arow = reinterpret_cast<const _Float16 *>(sup_tile(buf, sub) + col * LDW) + h * NKH;
 #pragma unroll
     for (int j = 0; j < KS; j++)
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(arow + 8 * j), xhi[j], acc, 0, 0, 0);
@@ -364,7 +365,17 @@ __global__ __launch_bounds__(256, 3) void lloyd_coarse_kernel(
       c1 = g1 ? t * 16u + r : c1;
       v1 = fmaxf(v1, v);
     }
-    if (t + 1 < ntiles) stage_store(buf ^ 1);
+  };
+
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  for (uint32_t sp = 0; sp < nsuper; sp++) {
+    const int buf = sp & 1;
+    if (sp + 1 < nsuper) stage_load(sp + 1);
+    compute_tile(2 * sp, buf, 0);
+    if (2 * sp + 1 < ntiles) compute_tile(2 * sp + 1, buf, 1);
+    if (sp + 1 < nsuper) stage_store(buf ^ 1);
     __syncthreads();
   }
   // merge the half-waves (same sample, disjoint centroid rows)
@@ -446,11 +457,12 @@ static hipError_t launch_f16_dp(const LloydArgs &a, const void *rows, bool half_
 template <int DP>
 static hipError_t launch_coarse_dp(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
                                    uint32_t *undecided, hipStream_t st) {
-  const size_t lds_bytes = (2 * 32 * (DP / 2 + 4) + 64) * sizeof(float);
-  const uint32_t grid = (a.N + 127) / 128;
+  const size_t lds_bytes = (4 * 32 * (DP / 2 + 4) + 128) * sizeof(float);
+  const uint32_t rows_per_block = kCoarseThreads / 2;
+  const uint32_t grid = (a.N + rows_per_block - 1) / rows_per_block;
   const bool fast = a.D == (uint32_t)DP;
 #define KMX_CRS_LAUNCH(H, F)                                                                                       \
-  hipLaunchKernelGGL((lloyd_coarse_kernel<DP, H, F>), dim3(grid), dim3(256), lds_bytes, st, rows, a.N, a.D,         \
+  hipLaunchKernelGGL((lloyd_coarse_kernel<DP, H, F>), dim3(grid), dim3(kCoarseThreads), lds_bytes, st, rows, a.N, a.D, \
                      reinterpret_cast<const float *>(panelhi), a.bias, a.mu, a.K_pad, a.K, a.stats, a.eps,           \
                      a.tie_slack, a.assignments, a.assignments_prev, undecided, a.counters)
   if (half_rows) {

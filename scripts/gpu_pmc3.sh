@@ -8,8 +8,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Kernel_Name"]
-    if "lloyd_filter" in n:
-        key = "f16" if "f16" in n else "f32"
+    if "lloyd_filter" in n or "lloyd_coarse" in n:
+        key = "coarse" if "coarse" in n else ("f16" if "f16" in n else "f32")
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
         dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 for k, v in agg.items():
