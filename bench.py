@@ -21,14 +21,28 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
-def pmc_traffic(rows_per_launch):
-    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
-    (profiles/*pmc_lloyd_filter.json: FETCH_SIZE doubled per the gfx950 note in
-    MI355X_MICROARCH.md, plus WRITE_SIZE), scaled by rows when the shard size differs.  PMC
-    counters cannot be collected from inside the bench process; None if no profile is committed."""
+def pmc_traffic(rows_per_launch, filt="f32"):
+    """HBM bytes per launch of the filter stage, from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_summary.json written by scripts/gpu_pmc_all.sh: FETCH_SIZE doubled per the gfx950
+    note in MI355X_MICROARCH.md, plus WRITE_SIZE), scaled by rows when the shard size differs.  The
+    two-stage default sums its two kernels.  PMC counters cannot be collected from inside the bench
+    process; None if no matching profile is committed."""
     import glob
+    want = {"f16": ("lloyd_coarse_kernel", "lloyd_filter_f16_kernel"), "f16x3": ("lloyd_filter_f16_kernel",),
+            "f32": ("lloyd_filter_kernel",)}[filt]
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if files and filt != "f16x3":   # the summaries are taken on the default run: f16x3 never sees all rows there
+        with open(files[-1]) as fin:
+            pmc = json.load(fin)
+        total = 0.0
+        for w in want:
+            hit = [v for k, v in pmc["kernels"].items() if k.startswith(w + "<") and "traffic_bytes_per_launch" in v]
+            if not hit:
+                return None
+            total += hit[0]["traffic_bytes_per_launch"]
+        return total * (rows_per_launch / float(pmc["rows_per_launch"]))
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_lloyd_filter.json")))
-    if not files:
+    if not files or filt != "f32":
         return None
     with open(files[-1]) as fin:
         pmc = json.load(fin)
@@ -223,7 +237,7 @@ def main():
                        "samples": N, "features": D, "clusters": K, "parallelism": "rows/%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": pmc_traffic(n_local) if (args.filter == "f32" and not f16) else None,
+                         "traffic": pmc_traffic(n_local, args.filter) if not f16 else None,
                          "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
                          "algorithmic_bytes": n_local * (D * (2 if f16 else 4) + 4), "algorithmic_flop": flops,
                          "peak_note": "dense MFMA peak of the instruction the dominant kernel issues, per algorithmic "

@@ -26,6 +26,7 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if (getenv("KMCUDA_AMD_DEBUG")) g_verbosity = atoi(getenv("KMCUDA_AMD_DEBUG"));
   if (const char *f = getenv("KMCUDA_AMD_FILTER"))
     filter_mode_ = strcmp(f, "f32") == 0 ? 1 : (strcmp(f, "f16x3") == 0 ? 2 : 0);
+  if (const char *g = getenv("KMCUDA_AMD_COARSE")) coarse_gen_ = atoi(g) == 1 ? 1 : 2;
   if (D == 0 || K < 1 || K >= 0x7FFFFFFFu) return kInvalidArguments;  // K == 1: Yinyang group clustering with one group
   if (fp16x2) return kInvalidArguments;  // fp16x2 kernels are not built yet ("next")
   int ndev = 0;
@@ -266,7 +267,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
       uint16_t *p16 = nullptr, *phi = nullptr;
       int rc = alloc(&p16, (size_t)K_pad_ * 2 * DP_);
       if (rc) return rc;
-      if ((rc = alloc(&phi, (size_t)K_pad_ * DP_))) return rc;
+      if ((rc = alloc(&phi, (size_t)((K_pad_ + 63u) / 64u * 64u) * (DP_ + 2)))) return rc;  // whole 64-row super-tiles + their biases
       if ((rc = alloc(&undecided_, N_))) return rc;
       panel16_ = p16;
       panelhi_ = phi;
@@ -276,7 +277,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
     KMX_HIP(launch_centroid_panel16(centroids, K_, D_, K_pad_, DP_, finite_, mu_, panel16_, stream_), kRuntimeError);
     if (filter_mode_ == 0) {
       KMX_HIP(hipMemsetAsync(counters_ + 4, 0, sizeof(uint32_t), stream_), kRuntimeError);
-      KMX_HIP(launch_lloyd_coarse(a, rows, half, panel16_, panelhi_, undecided_, stream_), kRuntimeError);
+      KMX_HIP(launch_lloyd_coarse(a, rows, half, panel16_, panelhi_, undecided_, coarse_gen_, stream_), kRuntimeError);
       KMX_HIP(launch_lloyd_filter_f16(a, rows, half, panel16_, undecided_, counters_ + 4, stream_), kRuntimeError);
     } else {
       KMX_HIP(launch_lloyd_filter_f16(a, rows, half, panel16_, nullptr, nullptr, stream_), kRuntimeError);

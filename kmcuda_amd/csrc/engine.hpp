@@ -81,6 +81,7 @@ class Engine {
   // 0: two-stage f16 matrix-core filter (hi.hi, then hi/lo split for the undecided rows; default),
   // 1: f32 matrix-core filter (KMCUDA_AMD_FILTER=f32), 2: single-stage hi/lo-split f16 filter (=f16x3)
   int filter_mode_ = 0;
+  int coarse_gen_ = 2;  // stage-1 kernel generation (KMCUDA_AMD_COARSE=1: the first one, for A/B runs)
   uint32_t *stats_ = nullptr, *flagged_ = nullptr, *pairs_ = nullptr, *counters_ = nullptr;
   // update workspace
   uint32_t *keys_tmp_ = nullptr, *vals_tmp_ = nullptr, *keys_sorted_ = nullptr, *rows_sorted_ = nullptr,

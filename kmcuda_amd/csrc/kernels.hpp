@@ -45,7 +45,7 @@ hipError_t launch_lloyd_filter_f16(const LloydArgs &a, const void *rows, bool ha
                                    const uint32_t *row_list, const uint32_t *n_list, hipStream_t st);
 // stage 1 of the default filter: hi.hi products only; rows it cannot decide -> undecided[counters[4]++]
 hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_rows, const void *panel16,
-                               void *panelhi, uint32_t *undecided, hipStream_t st);
+                               void *panelhi, uint32_t *undecided, int generation, hipStream_t st);
 
 // update.hip -- centroid update (reference: kmeans.cu:366-429 kmeans_adjust)
 constexpr uint32_t kSumSplit = 8;

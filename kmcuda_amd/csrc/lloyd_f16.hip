@@ -419,12 +419,266 @@ __global__ __launch_bounds__(kCoarseThreads, 2) void lloyd_coarse_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Stage 1, second generation.  PMC on the kernel above (profiles/r1e_pmc_summary.json): matrix pipe
+// busy 22-28 %, waves parked 65 % of their cycles.  Three structural causes, three changes:
+//   * every wave re-read the whole centroid panel from LDS for only 32 rows (1 KB of ds_read per
+//     MFMA = half the LDS bandwidth at full matrix rate): a wave now owns 64 rows (two B-operand
+//     sets), so each A fragment feeds two MFMAs;
+//   * the top-2 bookkeeping of a tile (VALU) ran after its MFMAs with the matrix pipe idle: the
+//     accumulators are double buffered and the bookkeeping of tile t-1 is interleaved with the MFMAs
+//     of tile t; it is 3 ops per score instead of 4 -- the accumulator register number travels in
+//     the low 4 mantissa bits of the score (<= 16 ulp, part of the bound), the tile index is noted
+//     once per tile;
+//   * staging went global -> 32 VGPRs -> ds_write_b128: tiles now arrive by LDS-DMA
+//     (global_load_lds_dwordx4, no registers, no LDS-write issue slots).  The DMA writes lane-linear,
+//     so the bank swizzle (16-byte chunk j of row r sits in slot j ^ (r & 15) of its half row) is
+//     applied to the SOURCE address and again by the fragment reads.
+// ---------------------------------------------------------------------------------------
+constexpr int kCoarse2Threads = 256;   // 4 waves x 64 rows; 2 blocks per CU (2 x 66 KB of LDS)
+template <int DP, bool HALF_ROWS, bool FAST>
+__global__ __launch_bounds__(kCoarse2Threads, 2) void lloyd_coarse2_kernel(
+    const void *__restrict__ rows, uint32_t N, uint32_t D, const float *__restrict__ panelhi,
+    const float *__restrict__ bias, const float *__restrict__ mu, uint32_t K_pad, uint32_t K,
+    const uint32_t *__restrict__ stats, float eps, float tie_slack, uint32_t *__restrict__ assignments,
+    uint32_t *__restrict__ assignments_prev, uint32_t *__restrict__ undecided, uint32_t *__restrict__ counters) {
+  constexpr int NKH = DP / 2;
+  constexpr int KS = NKH / 8;               // k-steps = 16-byte chunks per half row
+  constexpr int ROWB = DP * 2;              // bytes of one LDS row (DP hi halves)
+  constexpr int SUPB = 64 * ROWB;           // one super-tile: 64 centroids
+  constexpr int NP = SUPB / 1024;           // 1-KB LDS-DMA pieces per super-tile
+  constexpr int SWM = (KS < 16 ? KS : 16) - 1;
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds2[];
+  // raw LDS byte addresses (the fragment address is built with XOR: needs the 1-KB aligned base)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte *)lds2;
+  if (lds0 & 1023u) __builtin_trap();
+  const uint32_t bias0 = lds0 + 2 * SUPB;   // 2 x 64 floats
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 31, h = lane >> 5;
+  const uint32_t sA = blockIdx.x * 256u + wave * 64u + col, sB = sA + 32u;
+  const bool liveA = sA < N, liveB = sB < N;
+
+  f16x8 xa[KS], xb[KS];
+  float xn2a = 0.f, x0a = 0.f, xn2b = 0.f, x0b = 0.f;
+  // both rows of a lane per k-step, sharing the mean chunk.  Lanes without a row read row 0: an MFMA
+  // column only feeds its own outputs and theirs are never committed, so nothing is masked.
+  auto load_chunk = [&](uint32_t s, bool live, int j, float (&xv)[8]) {
+    const size_t row = (size_t)(live ? s : 0);
+    if (FAST && HALF_ROWS) {
+      const f16x8 raw = reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(rows) + row * DP + h * NKH)[j];
+#pragma unroll
+      for (int q = 0; q < 8; q++) xv[q] = (float)raw[q];
+    } else if (FAST) {
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(rows) + row * DP + h * NKH);
+      const f32x4 a = src[2 * j], b = src[2 * j + 1];
+      xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w;
+      xv[4] = b.x; xv[5] = b.y; xv[6] = b.z; xv[7] = b.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint32_t f = h * NKH + 8 * j + q;
+        float v = 0.f;
+        if (f < D) v = HALF_ROWS ? (float)reinterpret_cast<const _Float16 *>(rows)[row * D + f]
+                                 : reinterpret_cast<const float *>(rows)[row * D + f];
+        xv[q] = v;
+      }
+    }
+  };
+  auto centre = [&](const float (&xv)[8], const float (&mm)[8], f16x8 &hi, float &xn2) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const float xc = xv[q] - mm[q];
+      hi[q] = (_Float16)xc;
+      xn2 = fmaf(xc, xc, xn2);
+    }
+  };
+  auto load_rows = [&]() {
+    const f32x4 *mv = reinterpret_cast<const f32x4 *>(mu + h * NKH);  // DP floats, zero beyond D
+#pragma unroll
+    for (int j = 0; j < KS; j++) {
+      float va[8], vb[8], mm[8];
+      load_chunk(sA, liveA, j, va);
+      load_chunk(sB, liveB, j, vb);
+      const f32x4 m0 = mv[2 * j], m1 = mv[2 * j + 1];
+      mm[0] = m0.x; mm[1] = m0.y; mm[2] = m0.z; mm[3] = m0.w;
+      mm[4] = m1.x; mm[5] = m1.y; mm[6] = m1.z; mm[7] = m1.w;
+      centre(va, mm, xa[j], xn2a);
+      centre(vb, mm, xb[j], xn2b);
+      if (j == 0) { x0a = va[0]; x0b = vb[0]; }
+      asm volatile("" : "+v"(xa[j]), "+v"(xb[j]));  // convert NOW: hipcc parks the fp32 values in scratch otherwise
+      // keep the loads of later k-steps behind the conversions of this group: hoisted all at once
+      // they need far more registers than the kernel has
+      if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    xn2a += __shfl_xor(xn2a, 32); x0a = __shfl(x0a, col);
+    xn2b += __shfl_xor(xn2b, 32); x0b = __shfl(x0b, col);
+  };
+
+  // ---- LDS-DMA staging of super-tile sp into buffer buf ----
+  const uint32_t nsuper = (K_pad + 63) / 64;
+  const float *biashi = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(panelhi) + (size_t)nsuper * SUPB);
+  auto stage_issue = [&](uint32_t sp, int buf) {
+    // linear byte P of the super-tile image lands in LDS at P; it is fetched from source byte
+    // P ^ (((P / ROWB) & SWM) << 4): the 16-byte chunk index XORed with the row's low bits (inside a
+    // half row, SWM < KS).  Recomputed per call from one opaque register -- as loop invariants the
+    // per-piece addresses cost 30 VGPRs the MFMA loop needs.
+    uint32_t P0 = (uint32_t)lane * 16u;
+    asm volatile("" : "+v"(P0));
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(panelhi) + (size_t)sp * SUPB;
+#pragma unroll
+    for (int i = 0; i < (NP + 3) / 4; i++) {
+      const int p = i * 4 + wave;
+      if (NP % 4 == 0 || p < NP) {
+        const uint32_t P = (uint32_t)p * 1024u + P0;
+        const uint32_t from = P ^ (((P / ROWB) & SWM) << 4);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + from),
+                                         (__attribute__((address_space(3))) void *)(uintptr_t)(lds0 + buf * SUPB + p * 1024), 16, 0, 0);
+      }
+    }
+    // the 64 biases of the super-tile (clamped copy behind the panel): one 4-byte DMA by wave 0.  No
+    // ordinary global load lives in the loop: hipcc waits vmcnt(0) at its first use, draining the DMA
+    if (wave == 0)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(biashi + sp * 64u + lane),
+                                       (__attribute__((address_space(3))) void *)(uintptr_t)(bias0 + buf * 256), 4, 0, 0);
+  };
+
+  stage_issue(0, 0);
+  load_rows();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  float v1a = -INFINITY, v2a = -INFINITY, v1b = -INFINITY, v2b = -INFINITY;
+  uint32_t tba = 0, tbb = 0;
+  // fragment address of k-step j: rowbase ^ swizzle ^ (16 j); (row, half) part fixed per lane
+  const uint32_t fragbase = lds0 + (uint32_t)col * ROWB + (uint32_t)h * (KS * 16) + (uint32_t)((col & SWM) * 16);
+  auto frag = [&](uint32_t fb, int j) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) f16x8 *>((uintptr_t)(fb ^ (uint32_t)(j * 16)));
+  };
+  // max(v1, pk) as med3(v1, pk, +inf): fmaxf() costs a canonicalising v_max per operand on top
+  float pinf = INFINITY;
+  asm volatile("" : "+s"(pinf));
+  auto book = [&](float v, int r, float &v1, float &v2) {
+    const float pk = __uint_as_float((__float_as_uint(v) & 0xFFFFFFF0u) | (uint32_t)r);
+    v2 = __builtin_amdgcn_fmed3f(v1, v2, pk);
+    v1 = __builtin_amdgcn_fmed3f(v1, pk, pinf);
+  };
+  // One tile: 2 x KS MFMAs (each A fragment feeds both row sets), then the top-2 bookkeeping of its
+  // 2 x 16 scores on the VALU.  The two waves a SIMD holds belong to DIFFERENT blocks (4 waves per
+  // block, one per SIMD), so they are not in step: one's bookkeeping runs under the other's MFMAs.
+  // (Double-buffered accumulators with the bookkeeping interleaved in-wave need ~230 registers: the
+  // B operands spill, measured slower.)
+  auto tile_pass = [&](uint32_t ldsbase, uint32_t biasaddr, uint32_t t) {
+    f32x16 accA, accB;
+    {
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const f32x4 b4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>((uintptr_t)(biasaddr + (8 * g + 4 * h) * 4));
+        accA[4 * g + 0] = b4.x; accA[4 * g + 1] = b4.y; accA[4 * g + 2] = b4.z; accA[4 * g + 3] = b4.w;
+      }
+      accB = accA;
+    }
+    // (the 1-KB aligned tile base adds into bits the XOR never touches.)  Opaque on purpose: left
+    // visible, the KS addresses are hoisted out of the tile loop and the B operands spill instead
+    uint32_t fb = fragbase + ldsbase;
+    asm volatile("" : "+v"(fb));
+    f16x8 f0 = frag(fb, 0), f1 = frag(fb, KS > 1 ? 1 : 0);
+#pragma unroll
+    for (int j = 0; j < KS; j++) {
+      f16x8 f2 = f1;
+      if (j + 2 < KS) f2 = frag(fb, j + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0, xa[j], accA, 0, 0, 0);
+      accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0, xb[j], accB, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      f0 = f1;
+      f1 = f2;
+    }
+    const float v1a_in = v1a, v1b_in = v1b;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      book(accA[r], r, v1a, v2a);
+      book(accB[r], r, v1b, v2b);
+    }
+    tba = (v1a != v1a_in) ? t : tba;
+    tbb = (v1b != v1b_in) ? t : tbb;
+  };
+
+  for (uint32_t sp = 0; sp < nsuper; sp++) {
+    const int buf = sp & 1;
+    if (sp + 1 < nsuper) stage_issue(sp + 1, buf ^ 1);
+    const uint32_t base = buf * SUPB, bb = bias0 + buf * 256;
+    tile_pass(base, bb, 2 * sp);
+    tile_pass(base + 32 * ROWB, bb + 128, 2 * sp + 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // |coarse score - reference score| <= E_c as in lloyd_coarse_kernel, plus the 4 index bits packed
+  // into each score (<= 16 ulp of a score of magnitude <= ||x'|| C'max (1 + 2^-10) + B'max).  Rows or
+  // panels with a centred norm near the half range could hold inf halves: never decided here.
+  const float cmaxc = sqrtf(__uint_as_float(stats[0])) * 1.000001f;
+  const float bmaxc = __uint_as_float(stats[1]);
+  const float cmaxo = sqrtf(__uint_as_float(stats[2])) * 1.000001f;
+  const float u = 5.9604645e-8f;
+  uint32_t und_count = 0;
+  unsigned long long uma = 0, umb = 0;
+  bool unda = false, undb = false;
+  auto finish = [&](uint32_t s, bool live, float v1, float v2, uint32_t tb, float xn2, float x0, bool &und,
+                    unsigned long long &um) {
+    const bool insane = (x0 != x0);  // kmeans.cu:312
+    const uint32_t r = __float_as_uint(v1) & 15u;
+    uint32_t i1 = tb * 32u + (r & 3u) + 8u * (r >> 2) + 4u * h;
+    {
+      const float pv1 = __shfl_xor(v1, 32), pv2 = __shfl_xor(v2, 32);
+      const uint32_t pi1 = __shfl_xor(i1, 32);
+      const bool g = pv1 > v1;
+      const float second = fmaxf(g ? v1 : pv1, fmaxf(v2, pv2));
+      i1 = g ? pi1 : i1;
+      v1 = g ? pv1 : v1;
+      v2 = second;
+    }
+    // ||x|| <= ||x'|| + ||mu|| <= ||x'|| + Cmax (mu is a mean of centroids): saves a second norm
+    const float xn = sqrtf(xn2) * 1.0001f, xo = (xn + cmaxo) * 1.0001f;
+    const float e_c = 2.0f * eps * (xn * cmaxc + bmaxc) + 9.8e-4f * xn * cmaxc +
+                      6e-8f * sqrtf((float)DP) * (xn + cmaxc) + 2.0e-6f * (1.001f * xn * cmaxc + bmaxc);
+    const float e_ref = u * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
+    const float thr = 2.0f * (e_c + e_ref) * 1.001f + tie_slack;
+    const bool in_range = (xn < 6.0e4f) && (cmaxc < 6.0e4f) && (v1 > -1.0e38f) && (i1 < K);
+    const bool certain = insane || (in_range && ((v1 - v2) > thr));  // NaN gap / thr => not certain
+    const bool mine = (h == 0) && live;
+    bool changed = false;
+    if (mine && certain) changed = commit_row(s, insane ? K : i1, assignments, assignments_prev);
+    und = mine && !certain;
+    const unsigned long long cm = __ballot(changed);
+    um = __ballot(und);
+    if (lane == 0 && cm) atomicAdd(&counters[0], (uint32_t)__popcll(cm));
+    und_count += (uint32_t)__popcll(um);
+  };
+  finish(sA, liveA, v1a, v2a, tba, xn2a, x0a, unda, uma);
+  finish(sB, liveB, v1b, v2b, tbb, xn2b, x0b, undb, umb);
+  if (und_count) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&counters[4], und_count);
+    base = __shfl(base, 0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (unda) undecided[base + (uint32_t)__popcll(uma & below)] = sA;
+    if (undb) undecided[base + (uint32_t)__popcll(uma) + (uint32_t)__popcll(umb & below)] = sB;
+  }
+}
+
 // c' = c - mu, hi halves only: panelhi[c] = hi(c'_0..DP-1)
-__global__ void centroid_panelhi_kernel(const _Float16 *__restrict__ panel16, uint32_t K_pad, uint32_t DP,
-                                        _Float16 *__restrict__ panelhi) {
+__global__ void centroid_panelhi_kernel(const _Float16 *__restrict__ panel16, const float *__restrict__ bias,
+                                        uint32_t K_pad, uint32_t DP, _Float16 *__restrict__ panelhi) {
+  // grid = K_pad rounded up to 64 rows (the second-generation kernel stages whole 64-row super-tiles);
+  // behind the rows: the biases with -inf (padding / non-finite centroids) clamped to a finite floor
   const uint32_t c = blockIdx.x;
-  if (c >= K_pad) return;
-  for (uint32_t f = threadIdx.x; f < DP; f += blockDim.x) panelhi[(size_t)c * DP + f] = panel16[(size_t)c * 2 * DP + f];
+  for (uint32_t f = threadIdx.x; f < DP; f += blockDim.x)
+    panelhi[(size_t)c * DP + f] = c < K_pad ? panel16[(size_t)c * 2 * DP + f] : (_Float16)0.f;
+  if (threadIdx.x == 0) {
+    float *biashi = reinterpret_cast<float *>(panelhi + (size_t)gridDim.x * DP);
+    biashi[c] = c < K_pad ? fmaxf(bias[c], -3.0e38f) : -3.0e38f;
+  }
 }
 
 hipError_t launch_centroid_panel16(const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP,
@@ -489,10 +743,39 @@ hipError_t launch_lloyd_filter_f16(const LloydArgs &a, const void *rows, bool ha
   }
 }
 
+template <int DP>
+static hipError_t launch_coarse2_dp(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
+                                    uint32_t *undecided, hipStream_t st) {
+  const size_t lds_bytes = 2 * 64 * (size_t)(DP * 2) + 512;
+  const uint32_t grid = (a.N + 255u) / 256u;
+  const bool fast = a.D == (uint32_t)DP;
+#define KMX_CRS2_LAUNCH(H, F)                                                                                      \
+  hipLaunchKernelGGL((lloyd_coarse2_kernel<DP, H, F>), dim3(grid), dim3(kCoarse2Threads), lds_bytes, st, rows, a.N, \
+                     a.D, reinterpret_cast<const float *>(panelhi), a.bias, a.mu, a.K_pad, a.K, a.stats, a.eps,      \
+                     a.tie_slack, a.assignments, a.assignments_prev, undecided, a.counters)
+  if (half_rows) {
+    if (fast) KMX_CRS2_LAUNCH(true, true); else KMX_CRS2_LAUNCH(true, false);
+  } else {
+    if (fast) KMX_CRS2_LAUNCH(false, true); else KMX_CRS2_LAUNCH(false, false);
+  }
+#undef KMX_CRS2_LAUNCH
+  return hipGetLastError();
+}
+
 hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_rows, const void *panel16,
-                               void *panelhi, uint32_t *undecided, hipStream_t st) {
-  hipLaunchKernelGGL(centroid_panelhi_kernel, dim3(a.K_pad), dim3(a.DP >= 256 ? 256 : 64), 0, st,
-                     reinterpret_cast<const _Float16 *>(panel16), a.K_pad, a.DP, reinterpret_cast<_Float16 *>(panelhi));
+                               void *panelhi, uint32_t *undecided, int generation, hipStream_t st) {
+  hipLaunchKernelGGL(centroid_panelhi_kernel, dim3((a.K_pad + 63u) / 64u * 64u), dim3(a.DP >= 256 ? 256 : 64), 0, st,
+                     reinterpret_cast<const _Float16 *>(panel16), a.bias, a.K_pad, a.DP, reinterpret_cast<_Float16 *>(panelhi));
+  if (generation >= 2) {
+    switch (a.DP) {
+      case 16: return launch_coarse2_dp<16>(a, rows, half_rows, panelhi, undecided, st);
+      case 32: return launch_coarse2_dp<32>(a, rows, half_rows, panelhi, undecided, st);
+      case 64: return launch_coarse2_dp<64>(a, rows, half_rows, panelhi, undecided, st);
+      case 128: return launch_coarse2_dp<128>(a, rows, half_rows, panelhi, undecided, st);
+      case 256: return launch_coarse2_dp<256>(a, rows, half_rows, panelhi, undecided, st);
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (a.DP) {
     case 16: return launch_coarse_dp<16>(a, rows, half_rows, panelhi, undecided, st);
     case 32: return launch_coarse_dp<32>(a, rows, half_rows, panelhi, undecided, st);

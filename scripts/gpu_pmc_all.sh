@@ -1,0 +1,59 @@
+#!/bin/bash
+# PMC passes over the default bench (one rocprofv3 run per counter group, --kernel-trace only) and a
+# per-kernel summary -> gpurun_out/pmc_<tag>_summary.json (copy to profiles/<tag>_pmc_summary.json).
+set -u
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out
+TAG=${1:-r1}
+mkdir -p $OUT
+CMD=${PMC_CMD:-"python bench.py --steps 3 --warmup 1 --no-cpu-baseline"}
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+           "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
+  i=$((i+1))
+  rm -rf /tmp/pmc_$i
+  timeout 400 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmc_$i -o pmc -- $CMD > /tmp/pmc_$i.log 2>&1
+  echo "pmc pass $i ($grp) rc=$?"
+done
+python3 - "$OUT/pmc_${TAG}_summary.json" <<'PY'
+import csv, sys, glob, json, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+dur = collections.defaultdict(list)
+names = {}
+for f in glob.glob("/tmp/pmc_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"]
+        if "kmx::" not in n:
+            continue
+        key = n.split("kmx::")[1].split("(")[0]
+        agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if r["Counter_Name"] in ("GRBM_GUI_ACTIVE",):
+            dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+out = {"source": "scripts/gpu_pmc_all.sh: rocprofv3 --pmc <group> --kernel-trace, one run per group, "
+                 "python bench.py --steps 3 --warmup 1 --no-cpu-baseline; per-launch means",
+       "units": "FETCH_SIZE/WRITE_SIZE in KB as reported; fetch_bytes_corrected = 2 x FETCH_SIZE x 1024 (gfx950: "
+                "wide streaming reads are tallied at half, MI355X_MICROARCH.md HBM); SQ_* summed over SIMDs "
+                "(quad-cycles for *_CYCLES waits per the guide); GRBM_GUI_ACTIVE summed over 8 XCDs",
+       "rows_per_launch": 8000000, "kernels": {}}
+for k, v in sorted(agg.items()):
+    e = {c: sum(x) / len(x) for c, x in v.items()}
+    e["launches"] = max(len(x) for x in v.values())
+    if "FETCH_SIZE" in e:
+        e["fetch_bytes_corrected"] = 2.0 * e["FETCH_SIZE"] * 1024.0
+    if "WRITE_SIZE" in e:
+        e["write_bytes"] = e["WRITE_SIZE"] * 1024.0
+    if "fetch_bytes_corrected" in e and "write_bytes" in e:
+        e["traffic_bytes_per_launch"] = e["fetch_bytes_corrected"] + e["write_bytes"]
+    if dur[k] and "GRBM_GUI_ACTIVE" in e:
+        d = sum(dur[k]) / len(dur[k])
+        e["launch_ms_under_pmc"] = d / 1e6
+        e["effective_clock_GHz"] = e["GRBM_GUI_ACTIVE"] / 8.0 / d
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in e:
+            e["mfma_busy_fraction_of_active_cycles"] = (e["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (e["GRBM_GUI_ACTIVE"] / 8.0)
+    out["kernels"][k] = e
+json.dump(out, open(sys.argv[1], "w"), indent=1)
+for k in out["kernels"]:
+    if "lloyd" in k:
+        print(k, {a: (round(b, 4) if b < 100 else float("%.4g" % b)) for a, b in out["kernels"][k].items()})
+PY
