@@ -52,6 +52,18 @@ int kmamd_set_filter(kmamd_engine *e, int mode);
  * bit-identical to the fp32 path on the widened values.  NULL switches back. */
 int kmamd_set_half_rows(kmamd_engine *e, const void *rows16);
 
+/* Row cache of the two-stage filter's coarse pass.  on != 0: the caller promises that the rows given
+ * to kmamd_lloyd_assign (samples, or the half rows) are the SAME, UNMODIFIED buffer on every call
+ * from now on -- what the reference guarantees inside one kmeans_cuda() run, where the samples are
+ * transposed once and iterated over (kmcuda.cc:505-508).  The next kmamd_lloyd_assign then stores
+ * x - mu (mu = mean of that call's centroids, frozen from then on) as halves in the matrix-core
+ * operand order (2 * features bytes per row + 8) and later passes stream that copy: half the HBM
+ * bytes, whole 1-KB bursts, no conversion.  Assignments are unchanged (the bound is computed for the
+ * mu in use).  Calling it again (on or off) drops the copy; off (the default) converts from the rows
+ * on every pass.  If the copy cannot be allocated the engine silently stays uncached.
+ * Env KMCUDA_AMD_ROW_CACHE=0 vetoes it (A/B runs). */
+int kmamd_set_row_cache(kmamd_engine *e, int on);
+
 /* counters: [0] reassigned rows since the last reset (d_changed_number, kmeans.cu:31),
  * [1] rows the filter handed to the full exact scan, [2] Yinyang passed rows (d_passed_number),
  * [3] rows the filter narrowed to two contenders (pair refine).  read = sync + copy to a host array; reset zeroes [0..3] (or one of them). */

@@ -26,7 +26,7 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if (getenv("KMCUDA_AMD_DEBUG")) g_verbosity = atoi(getenv("KMCUDA_AMD_DEBUG"));
   if (const char *f = getenv("KMCUDA_AMD_FILTER"))
     filter_mode_ = strcmp(f, "f32") == 0 ? 1 : (strcmp(f, "f16x3") == 0 ? 2 : 0);
-  if (const char *g = getenv("KMCUDA_AMD_COARSE")) coarse_gen_ = atoi(g) == 1 ? 1 : 2;
+  if (const char *c = getenv("KMCUDA_AMD_ROW_CACHE")) row_cache_allowed_ = atoi(c) != 0;
   if (D == 0 || K < 1 || K >= 0x7FFFFFFFu) return kInvalidArguments;  // K == 1: Yinyang group clustering with one group
   if (fp16x2) return kInvalidArguments;  // fp16x2 kernels are not built yet ("next")
   int ndev = 0;
@@ -119,7 +119,7 @@ void Engine::profile_reset() {
 int Engine::prepare_centroids(const float *centroids) {
   const uint32_t dp = DP_ ? DP_ : 8;
   KMX_HIP(launch_centroid_prep(metric_, centroids, K_, D_, K_pad_, dp, Kt_, csqr_, bias_, bias2_, cfil_, ct_, mu_,
-                               finite_, stats_, counters_ + 1, counters_ + 3, stream_),
+                               mu_frozen_, finite_, stats_, counters_ + 1, counters_ + 3, stream_),
           kRuntimeError);
   return kSuccess;
 }
@@ -242,6 +242,12 @@ int Engine::yy_filters(const float *samples, const float *centroids, const float
 int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t *assignments,
                          uint32_t *assignments_prev, bool exact_only) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  // row cache (two-stage f16 filter only): x - mu as halves in operand order, built on the first pass
+  // after set_row_cache(1); mu is frozen from then on, so the copy stays valid for every later pass
+  const bool want_cache = row_cache_on_ && !exact_only && DP_ != 0 && filter_mode_ == 0 &&
+                          lloyd_filter_f16_supported(D_, DP_) && N_ != 0;
+  const bool build_cache = want_cache && !row_cache_valid_;
+  if (build_cache) mu_frozen_ = false;  // take the mean of THESE centroids
   {
     int rc = prepare_centroids(centroids);
     if (rc) return rc;
@@ -276,8 +282,31 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
     const bool half = half_rows_ != nullptr;
     KMX_HIP(launch_centroid_panel16(centroids, K_, D_, K_pad_, DP_, finite_, mu_, panel16_, stream_), kRuntimeError);
     if (filter_mode_ == 0) {
+      if (build_cache) {
+        const size_t npad = ((size_t)N_ + 255) / 256 * 256;
+        if (!xcache_) {
+          uint16_t *xc = nullptr;
+          float *xm = nullptr;
+          // no memory for the copy: not an error, the operands are converted from the rows every pass
+          if (alloc(&xc, npad * DP_) == kSuccess && alloc(&xm, npad * 2 + 2) == kSuccess) {
+            xcache_ = xc;
+            xmeta_ = xm;
+          } else {
+            (void)hipGetLastError();
+            row_cache_on_ = false;
+          }
+        }
+        if (xcache_) {
+          KMX_HIP(launch_row_cache(rows, half, N_, D_, DP_, mu_, xcache_, xmeta_, stream_), kRuntimeError);
+          row_cache_valid_ = true;
+          mu_frozen_ = true;
+        }
+      }
+      const bool cached = row_cache_on_ && row_cache_valid_;
       KMX_HIP(hipMemsetAsync(counters_ + 4, 0, sizeof(uint32_t), stream_), kRuntimeError);
-      KMX_HIP(launch_lloyd_coarse(a, rows, half, panel16_, panelhi_, undecided_, coarse_gen_, stream_), kRuntimeError);
+      KMX_HIP(launch_lloyd_coarse(a, rows, half, cached ? xcache_ : nullptr, xmeta_, panel16_, panelhi_, undecided_,
+                                  stream_),
+              kRuntimeError);
       KMX_HIP(launch_lloyd_filter_f16(a, rows, half, panel16_, undecided_, counters_ + 4, stream_), kRuntimeError);
     } else {
       KMX_HIP(launch_lloyd_filter_f16(a, rows, half, panel16_, nullptr, nullptr, stream_), kRuntimeError);
@@ -407,6 +436,13 @@ int kmamd_set_filter(kmamd_engine *e, int mode) {
 }
 int kmamd_set_half_rows(kmamd_engine *e, const void *rows16) {
   e->e.half_rows_ = rows16;
+  e->e.row_cache_valid_ = false;  // a cache built from other rows is stale
+  return kmx::kSuccess;
+}
+int kmamd_set_row_cache(kmamd_engine *e, int on) {
+  e->e.row_cache_on_ = on != 0 && e->e.row_cache_allowed_;
+  e->e.row_cache_valid_ = false;  // (re)built by the next kmamd_lloyd_assign
+  if (!e->e.row_cache_on_) e->e.mu_frozen_ = false;
   return kmx::kSuccess;
 }
 int kmamd_adjust_exact(kmamd_engine *e, const float *samples, const uint32_t *assignments_prev,

@@ -81,7 +81,11 @@ class Engine {
   // 0: two-stage f16 matrix-core filter (hi.hi, then hi/lo split for the undecided rows; default),
   // 1: f32 matrix-core filter (KMCUDA_AMD_FILTER=f32), 2: single-stage hi/lo-split f16 filter (=f16x3)
   int filter_mode_ = 0;
-  int coarse_gen_ = 2;  // stage-1 kernel generation (KMCUDA_AMD_COARSE=1: the first one, for A/B runs)
+  // row cache of the coarse filter stage (lloyd_f16.hip: row_cache_kernel); set_row_cache()
+  bool row_cache_allowed_ = true;   // KMCUDA_AMD_ROW_CACHE=0 vetoes it
+  bool row_cache_on_ = false, row_cache_valid_ = false, mu_frozen_ = false;
+  void *xcache_ = nullptr;
+  float *xmeta_ = nullptr;
   uint32_t *stats_ = nullptr, *flagged_ = nullptr, *pairs_ = nullptr, *counters_ = nullptr;
   // update workspace
   uint32_t *keys_tmp_ = nullptr, *vals_tmp_ = nullptr, *keys_sorted_ = nullptr, *rows_sorted_ = nullptr,

@@ -29,7 +29,7 @@ struct LloydArgs {
 uint32_t filter_dp_for(uint32_t D);
 hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad,
                                 uint32_t DP, uint32_t Kt, float *csqr, float *bias, float *bias2, float *cfil,
-                                float *ct, float *mu, uint32_t *finite, uint32_t *stats, uint32_t *zero_a,
+                                float *ct, float *mu, bool freeze_mu, uint32_t *finite, uint32_t *stats, uint32_t *zero_a,
                                 uint32_t *zero_b, hipStream_t st);
 hipError_t launch_lloyd_filter(const LloydArgs &a, hipStream_t st);
 hipError_t launch_lloyd_pair(int metric, const LloydArgs &a, const float *centroids, uint32_t grid, hipStream_t st);
@@ -43,9 +43,15 @@ hipError_t launch_centroid_panel16(const float *centroids, uint32_t K, uint32_t 
                                    const uint32_t *finite, const float *mu, void *panel16, hipStream_t st);
 hipError_t launch_lloyd_filter_f16(const LloydArgs &a, const void *rows, bool half_rows, const void *panel16,
                                    const uint32_t *row_list, const uint32_t *n_list, hipStream_t st);
-// stage 1 of the default filter: hi.hi products only; rows it cannot decide -> undecided[counters[4]++]
-hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_rows, const void *panel16,
-                               void *panelhi, uint32_t *undecided, int generation, hipStream_t st);
+// stage 1 of the default filter: hi.hi products only; rows it cannot decide -> undecided[counters[4]++].
+// xcache / xmeta: the engine's row cache (launch_row_cache) or nullptr (operands converted from rows)
+hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
+                               const float *xmeta, const void *panel16, void *panelhi, uint32_t *undecided,
+                               hipStream_t st);
+// x' = x - mu as halves in the coarse kernel's operand order (N rounded up to 256 rows: DP*2 bytes per
+// row) + (||x'||^2, x_0) per row (8 bytes); valid while mu is unchanged
+hipError_t launch_row_cache(const void *rows, bool half_rows, uint32_t N, uint32_t D, uint32_t DP, const float *mu,
+                            void *xcache, float *xmeta, hipStream_t st);
 
 // update.hip -- centroid update (reference: kmeans.cu:366-429 kmeans_adjust)
 constexpr uint32_t kSumSplit = 8;

@@ -515,6 +515,12 @@ class Job {
   // reference: kmeans_cuda_lloyd, kmeans.cu:934-1026
   int lloyd(float tolerance, bool resume, int *iterations) {
     RETERR(prepare_mem(resume));
+    // the samples do not change inside one kmeans_cuda() call: let the coarse filter stage keep its
+    // centred half copy of the rows across the iterations (kmamd_set_row_cache, include/kmcuda_amd.h)
+    for (auto &s : shards) {
+      s->eng->row_cache_on_ = s->eng->row_cache_allowed_;
+      s->eng->row_cache_valid_ = false;
+    }
     for (int iter = 1;; iter++) {
       if (!resume || iter > 1) {
         for (auto &s : shards)

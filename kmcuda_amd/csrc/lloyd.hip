@@ -79,7 +79,8 @@ __global__ void centroid_rows_kernel(const float *__restrict__ centroids, uint32
 __global__ __launch_bounds__(1024) void centroid_mean_kernel(const float *__restrict__ centroids, uint32_t K,
                                                              uint32_t D, uint32_t DP,
                                                              const uint32_t *__restrict__ finite,
-                                                             float *__restrict__ mu, uint32_t *__restrict__ zero_a,
+                                                             float *__restrict__ mu, bool freeze_mu,
+                                                             uint32_t *__restrict__ zero_a,
                                                              uint32_t *__restrict__ zero_b) {
   // block = 64 features x 16 row-slices: coalesced row reads, fixed summation order
   constexpr int S = 16;
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(1024) void centroid_mean_kernel(const float *__rest
     if (zero_a) *zero_a = 0u;
     if (zero_b) *zero_b = 0u;
   }
+  if (freeze_mu) return;  // the engine's row cache holds x - mu: mu stays what it was (any mu is valid)
   float sum = 0.f;
   uint32_t n = 0;
   for (uint32_t c = sl; c < K; c += S) {
@@ -558,8 +560,8 @@ hipError_t launch_lloyd_filter(const LloydArgs &a, hipStream_t st) {
 
 hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad,
                                 uint32_t DP, uint32_t Kt, float *csqr, float *bias, float *bias2, float *cfil,
-                                float *ct, float *mu, uint32_t *finite, uint32_t *stats, uint32_t *zero_a,
-                                uint32_t *zero_b, hipStream_t st) {
+                                float *ct, float *mu, bool freeze_mu, uint32_t *finite, uint32_t *stats,
+                                uint32_t *zero_a, uint32_t *zero_b, hipStream_t st) {
   hipError_t e = hipMemsetAsync(stats, 0, 8 * sizeof(uint32_t), st);
   if (e != hipSuccess) return e;
   const dim3 block(64);
@@ -570,7 +572,7 @@ hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, 
     hipLaunchKernelGGL((centroid_rows_kernel<1>), dim3((Kt + 63) / 64), block, 0, st, centroids, K, D, Kt, csqr, ct,
                        finite, stats);
   hipLaunchKernelGGL(centroid_mean_kernel, dim3((DP + 63) / 64), dim3(1024), 0, st, centroids, K, D, DP, finite, mu,
-                     zero_a, zero_b);
+                     freeze_mu, zero_a, zero_b);
   if (metric == 0)
     hipLaunchKernelGGL((centroid_panel_kernel<0>), dim3((K_pad + 3) / 4), dim3(256), 0, st, centroids, K, D, K_pad, DP,
                        finite, mu, bias, bias2, cfil, stats);

@@ -240,205 +240,47 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_f16_kernel(
 
 // ---------------------------------------------------------------------------------------
 // Stage 1 of the default filter: ONE f16 MFMA per 16 features (hi.hi only).  Under the f16 matrix
-// load the chip is power limited (profiles/: 1.75 GHz), so the lever is fewer matrix operations:
+// load the chip is power limited (profiles/: 1.7 GHz), so the lever is fewer matrix operations:
 // the coarse scores carry |error| <= E_c ~ 2^-10 ||x'|| C'max, enough to decide the rows whose
 // best / second-best gap exceeds 2 E_c (the large majority); only the others go through the
 // three-product kernel above.
-// ---------------------------------------------------------------------------------------
-constexpr int kCoarseThreads = 512;  // 8 waves share a super-tile: 2 blocks/CU = 4 waves per SIMD
-template <int DP, bool HALF_ROWS, bool FAST>
-__global__ __launch_bounds__(kCoarseThreads, 2) void lloyd_coarse_kernel(
-    const void *__restrict__ rows, uint32_t N, uint32_t D, const float *__restrict__ panelhi,
-    const float *__restrict__ bias, const float *__restrict__ mu, uint32_t K_pad, uint32_t K,
-    const uint32_t *__restrict__ stats, float eps, float tie_slack, uint32_t *__restrict__ assignments,
-    uint32_t *__restrict__ assignments_prev, uint32_t *__restrict__ undecided, uint32_t *__restrict__ counters) {
-  constexpr int NKH = DP / 2;
-  constexpr int KS = NKH / 8;
-  constexpr int LDW = DP / 2 + 4;      // padded LDS row in 4-byte words (row = DP halves)
-  constexpr int TILE = 32 * LDW;
-  constexpr int BT = kCoarseThreads;
-  constexpr int NST = (4 * DP + BT - 1) / BT;   // 16-byte pieces per thread per tile
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
-  const uint32_t s = blockIdx.x * (uint32_t)(BT / 2) + wave * 32u + col;
-  const bool live = s < N;
-
-  f16x8 xhi[KS];
-  float xn2 = 0.f, xo2 = 0.f, x0 = 0.f;
-  {
-    const size_t row = (size_t)(live ? s : 0);
-    const float *m = mu + h * NKH;
-#pragma unroll
-    for (int j = 0; j < KS; j++) {
-      float xv[8];
-      if (FAST && HALF_ROWS) {
-        const f16x8 raw = reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(rows) + row * DP + h * NKH)[j];
-#pragma unroll
-        for (int q = 0; q < 8; q++) xv[q] = (float)raw[q];
-      } else if (FAST) {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(rows) + row * DP + h * NKH);
-        const f32x4 a = src[2 * j], b = src[2 * j + 1];
-        xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w;
-        xv[4] = b.x; xv[5] = b.y; xv[6] = b.z; xv[7] = b.w;
-      } else {
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const uint32_t f = h * NKH + 8 * j + q;
-          float v = 0.f;
-          if (f < D) v = HALF_ROWS ? (float)reinterpret_cast<const _Float16 *>(rows)[row * D + f]
-                                   : reinterpret_cast<const float *>(rows)[row * D + f];
-          xv[q] = v;
-        }
-      }
-      f16x8 hi;
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const bool on = live && (FAST || h * NKH + 8 * j + q < (int)D);
-        const float x = on ? xv[q] : 0.f;
-        const float xc = on ? x - m[8 * j + q] : 0.f;
-        hi[q] = (_Float16)xc;
-        xo2 = fmaf(x, x, xo2);
-        xn2 = fmaf(xc, xc, xn2);
-        if (j == 0 && q == 0) x0 = live ? xv[q] : 0.f;
-      }
-      xhi[j] = hi;
-    }
-  }
-  xn2 += __shfl_xor(xn2, 32);
-  xo2 += __shfl_xor(xo2, 32);
-  x0 = __shfl(x0, col);
-  const bool insane = (x0 != x0);  // kmeans.cu:312
-
-  // A tile's matrix work is only 16 MFMAs (512 cycles), so the barrier and the staging round trip
-  // weigh as much as the tile itself: stage SUPER-TILES of 64 centroids (two 32-row MFMA tiles) per
-  // barrier, double buffered (2 x 64 x (DP + 8) bytes of LDS, 2 blocks per CU).
-  constexpr int NSS = 2 * NST;  // 16-byte pieces per thread per super-tile
-  f32x4 stage[NSS];
-  float bstage = 0.f;
-  const uint32_t ntiles = K_pad / 32, nsuper = (ntiles + 1) / 2;
-  auto sup_tile = [&](int buf, int sub) { return lds + (buf * 2 + sub) * TILE; };
-  auto sup_bias = [&](int buf) { return lds + 4 * TILE + buf * 64; };
-  auto stage_load = [&](uint32_t sp) {
-    const float *src = panelhi + (size_t)sp * 64 * (DP / 2);
-    const int limit = (2 * sp + 1 < ntiles) ? 8 * DP : 4 * DP;  // the last super-tile may hold one tile
-#pragma unroll
-    for (int i = 0; i < NSS; i++) {
-      const int q = tid + i * BT;
-      if (q < limit) stage[i] = reinterpret_cast<const f32x4 *>(src)[q];
-    }
-    if (tid < 64) bstage = (sp * 64 + tid < K_pad) ? bias[sp * 64 + tid] : -INFINITY;
-  };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NSS; i++) {
-      const int q = tid + i * BT;
-      if (q < 8 * DP) {
-        const int row = q / (DP / 8), c4 = q % (DP / 8);  // row 0..63
-        *reinterpret_cast<f32x4 *>(sup_tile(buf, row >> 5) + (row & 31) * LDW + c4 * 4) = stage[i];
-      }
-    }
-    if (tid < 64) sup_bias(buf)[tid] = bstage;
-  };
-
-  float v1 = -INFINITY, v2 = -INFINITY;
-  uint32_t c1 = 0xFFFFFFFFu;
-  auto compute_tile = [&](uint32_t t, int buf, int sub) {
-    f32x16 acc;
-    {
-      const float *bb = sup_bias(buf) + 32 * sub + 4 * h;
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bb + 8 * g);
-        acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
-      }
-    }
-    const _Float16 *arow = reinterpret_cast<const _Float16 *>(sup_tile(buf, sub) + col * LDW) + h * NKH;
-#pragma unroll
-    for (int j = 0; j < KS; j++)
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(arow + 8 * j), xhi[j], acc, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const float v = acc[r];
-      const bool g1 = v > v1;
-      v2 = __builtin_amdgcn_fmed3f(v1, v2, v);
-      c1 = g1 ? t * 16u + r : c1;
-      v1 = fmaxf(v1, v);
-    }
-  };
-
-  stage_load(0);
-  stage_store(0);
-  __syncthreads();
-  for (uint32_t sp = 0; sp < nsuper; sp++) {
-    const int buf = sp & 1;
-    if (sp + 1 < nsuper) stage_load(sp + 1);
-    compute_tile(2 * sp, buf, 0);
-    if (2 * sp + 1 < ntiles) compute_tile(2 * sp + 1, buf, 1);
-    if (sp + 1 < nsuper) stage_store(buf ^ 1);
-    __syncthreads();
-  }
-  // merge the half-waves (same sample, disjoint centroid rows)
-  uint32_t i1 = 0xFFFFFFFFu;
-  if (c1 != 0xFFFFFFFFu) {
-    const uint32_t r = c1 & 15u;
-    i1 = (c1 >> 4) * 32u + (r & 3u) + 8u * (r >> 2) + 4u * h;
-  }
-  {
-    const float pv1 = __shfl_xor(v1, 32), pv2 = __shfl_xor(v2, 32);
-    const uint32_t pi1 = __shfl_xor(i1, 32);
-    const bool g = pv1 > v1;
-    const float second = fmaxf(g ? v1 : pv1, fmaxf(v2, pv2));  // fmax ignores a NaN operand
-    i1 = g ? pi1 : i1;
-    v1 = g ? pv1 : v1;
-    v2 = second;
-  }
-  // |coarse score - reference score| <= E_c: the f32-accumulated hi.hi products (gamma_{DP+1}), the
-  // dropped lo terms (|a_lo| <= 2^-11 |a|: (2^-10 + 2^-22) ||x'|| C'max) and half underflow, + E_ref
-  const float cmaxc = sqrtf(__uint_as_float(stats[0])) * 1.000001f;
-  const float bmaxc = __uint_as_float(stats[1]);
-  const float cmaxo = sqrtf(__uint_as_float(stats[2])) * 1.000001f;
-  const float xn = sqrtf(xn2) * 1.0001f, xo = sqrtf(xo2) * 1.0001f;
-  const float u = 5.9604645e-8f;
-  const float e_c = 2.0f * eps * (xn * cmaxc + bmaxc) + 9.8e-4f * xn * cmaxc +
-                    6e-8f * sqrtf((float)DP) * (xn + cmaxc);
-  const float e_ref = u * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
-  const float thr = 2.0f * (e_c + e_ref) * 1.001f + tie_slack;
-  const bool certain = insane || ((v1 - v2) > thr);  // NaN gap / thr => not certain
-  const bool mine = (h == 0) && live;
-  bool changed = false;
-  if (mine && certain) changed = commit_row(s, insane ? K : i1, assignments, assignments_prev);
-  const bool und = mine && !certain;
-  const unsigned long long cm = __ballot(changed), um = __ballot(und);
-  if (lane == 0 && cm) atomicAdd(&counters[0], (uint32_t)__popcll(cm));
-  if (um) {
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&counters[4], (uint32_t)__popcll(um));
-    base = __shfl(base, 0);
-    if (und) undecided[base + (uint32_t)__popcll(um & ((1ull << lane) - 1ull))] = s;
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// Stage 1, second generation.  PMC on the kernel above (profiles/r1e_pmc_summary.json): matrix pipe
-// busy 22-28 %, waves parked 65 % of their cycles.  Three structural causes, three changes:
+//
+// History of this kernel (profiles/r1e_pmc_summary.json for the first generation: matrix pipe busy
+// 22-28 %, waves parked 65 % of their cycles).  Three structural causes, three changes:
 //   * every wave re-read the whole centroid panel from LDS for only 32 rows (1 KB of ds_read per
 //     MFMA = half the LDS bandwidth at full matrix rate): a wave now owns 64 rows (two B-operand
 //     sets), so each A fragment feeds two MFMAs;
-//   * the top-2 bookkeeping of a tile (VALU) ran after its MFMAs with the matrix pipe idle: the
-//     accumulators are double buffered and the bookkeeping of tile t-1 is interleaved with the MFMAs
-//     of tile t; it is 3 ops per score instead of 4 -- the accumulator register number travels in
-//     the low 4 mantissa bits of the score (<= 16 ulp, part of the bound), the tile index is noted
-//     once per tile;
+//   * 8-wave blocks put two waves of the SAME block on every SIMD, in step through the barriers, so
+//     the top-2 bookkeeping (VALU) of both ran with the matrix pipe idle: blocks are 4 waves, one per
+//     SIMD, two blocks per CU; the bookkeeping is 3 ops per score instead of 4 -- the accumulator
+//     register number travels in the low 4 mantissa bits of the score (<= 16 ulp, part of the
+//     bound), the tile index is noted once per tile;
 //   * staging went global -> 32 VGPRs -> ds_write_b128: tiles now arrive by LDS-DMA
 //     (global_load_lds_dwordx4, no registers, no LDS-write issue slots).  The DMA writes lane-linear,
 //     so the bank swizzle (16-byte chunk j of row r sits in slot j ^ (r & 15) of its half row) is
 //     applied to the SOURCE address and again by the fragment reads.
 // ---------------------------------------------------------------------------------------
-constexpr int kCoarse2Threads = 256;   // 4 waves x 64 rows; 2 blocks per CU (2 x 66 KB of LDS)
-template <int DP, bool HALF_ROWS, bool FAST>
-__global__ __launch_bounds__(kCoarse2Threads, 2) void lloyd_coarse2_kernel(
-    const void *__restrict__ rows, uint32_t N, uint32_t D, const float *__restrict__ panelhi,
+// hand-issued LDS fragment read + counted wait (see lloyd_coarse2_kernel)
+__device__ __forceinline__ f16x8 lds_frag_issue(uint32_t addr) {
+  f16x8 f;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(f) : "v"(addr) : "memory");
+  return f;
+}
+template <int N>
+__device__ __forceinline__ void lds_frag_wait(f16x8 &f) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N));
+}
+
+#ifndef KMX_ABL
+#define KMX_ABL 0  // timing ablations (scratch/abl_variants.sh): results are WRONG when non-zero
+#endif
+// 4 waves x 64 rows per block, 2 independent blocks per CU (2 x 67 KB of LDS).  (Tried and dropped:
+// one 8-wave block per CU run as a ping-pong -- the waves sharing a SIMD, read from HW_ID, alternate
+// MFMA and bookkeeping phases between workgroup barriers; 65 barriers per block made it 20 % slower.)
+// CACHED: the B operands come from the engine's row cache (row_cache_kernel below) instead of the rows.
+template <int DP, bool HALF_ROWS, bool FAST, bool CACHED>
+__global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
+    const void *__restrict__ rows, const float *__restrict__ xmeta, uint32_t N, uint32_t D, const float *__restrict__ panelhi,
     const float *__restrict__ bias, const float *__restrict__ mu, uint32_t K_pad, uint32_t K,
     const uint32_t *__restrict__ stats, float eps, float tie_slack, uint32_t *__restrict__ assignments,
     uint32_t *__restrict__ assignments_prev, uint32_t *__restrict__ undecided, uint32_t *__restrict__ counters) {
@@ -456,6 +298,7 @@ __global__ __launch_bounds__(kCoarse2Threads, 2) void lloyd_coarse2_kernel(
   const uint32_t bias0 = lds0 + 2 * SUPB;   // 2 x 64 floats
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 31, h = lane >> 5;
+  constexpr int WV = 4;
   const uint32_t sA = blockIdx.x * 256u + wave * 64u + col, sB = sA + 32u;
   const bool liveA = sA < N, liveB = sB < N;
 
@@ -464,7 +307,7 @@ __global__ __launch_bounds__(kCoarse2Threads, 2) void lloyd_coarse2_kernel(
   // both rows of a lane per k-step, sharing the mean chunk.  Lanes without a row read row 0: an MFMA
   // column only feeds its own outputs and theirs are never committed, so nothing is masked.
   auto load_chunk = [&](uint32_t s, bool live, int j, float (&xv)[8]) {
-    const size_t row = (size_t)(live ? s : 0);
+    const size_t row = (size_t)(live ? (KMX_ABL == 9 ? (s & 65535u) : s) : 0);  // ABL 9: rows from a 64-MB window
     if (FAST && HALF_ROWS) {
       const f16x8 raw = reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(rows) + row * DP + h * NKH)[j];
 #pragma unroll
@@ -493,23 +336,52 @@ __global__ __launch_bounds__(kCoarse2Threads, 2) void lloyd_coarse2_kernel(
       xn2 = fmaf(xc, xc, xn2);
     }
   };
+  // Rows arrive in at most two batches of 8 k-steps, every load of a batch issued before the first
+  // use: issued k-step by k-step the prologue is 8 dependent HBM round trips (~20 us of an 80-us
+  // block), and the other block's LDS-DMA pieces queue behind those misses in the in-order texture path.
+  // The mean comes from LDS (staged by DMA with super-tile 0): an ordinary global load would drain vmcnt.
+  constexpr int BJ = KS > 8 ? 8 : KS;
+  const uint32_t mu_lds = bias0 + 512 + 64;
   auto load_rows = [&]() {
-    const f32x4 *mv = reinterpret_cast<const f32x4 *>(mu + h * NKH);  // DP floats, zero beyond D
+    if constexpr (CACHED) {
+      // rows = the row cache: per 32-row block KS pieces of 64 lanes x 16 bytes, already centred halves
+      // in operand order -> 2 KS fully coalesced 1-KB loads per wave straight into the operand
+      // registers, no conversion; the norms wait in xmeta until the decision
+      const f16x8 *c = reinterpret_cast<const f16x8 *>(rows) + ((size_t)blockIdx.x * 8 + wave * 2) * (KS * 64) + lane;
 #pragma unroll
-    for (int j = 0; j < KS; j++) {
-      float va[8], vb[8], mm[8];
-      load_chunk(sA, liveA, j, va);
-      load_chunk(sB, liveB, j, vb);
-      const f32x4 m0 = mv[2 * j], m1 = mv[2 * j + 1];
-      mm[0] = m0.x; mm[1] = m0.y; mm[2] = m0.z; mm[3] = m0.w;
-      mm[4] = m1.x; mm[5] = m1.y; mm[6] = m1.z; mm[7] = m1.w;
-      centre(va, mm, xa[j], xn2a);
-      centre(vb, mm, xb[j], xn2b);
-      if (j == 0) { x0a = va[0]; x0b = vb[0]; }
-      asm volatile("" : "+v"(xa[j]), "+v"(xb[j]));  // convert NOW: hipcc parks the fp32 values in scratch otherwise
-      // keep the loads of later k-steps behind the conversions of this group: hoisted all at once
-      // they need far more registers than the kernel has
-      if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+      for (int j = 0; j < KS; j++) xa[j] = c[j * 64];
+#pragma unroll
+      for (int j = 0; j < KS; j++) xb[j] = c[(KS + j) * 64];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      return;
+    }
+#pragma unroll
+    for (int j0 = 0; j0 < KS; j0 += BJ) {
+      float va[BJ][8], vb[BJ][8];
+#pragma unroll
+      for (int jj = 0; jj < BJ; jj++) load_chunk(sA, liveA, j0 + jj, va[jj]);
+#pragma unroll
+      for (int jj = 0; jj < BJ; jj++) load_chunk(sB, liveB, j0 + jj, vb[jj]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j0 == 0) {  // the mean (and super-tile 0) landed, visible to every wave
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+#pragma unroll
+      for (int jj = 0; jj < BJ; jj++) {
+        const int j = j0 + jj;
+        float mm[8];
+        const f32x4 m0 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>((uintptr_t)(mu_lds + (h * NKH + 8 * j) * 4));
+        const f32x4 m1 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>((uintptr_t)(mu_lds + (h * NKH + 8 * j + 4) * 4));
+        mm[0] = m0.x; mm[1] = m0.y; mm[2] = m0.z; mm[3] = m0.w;
+        mm[4] = m1.x; mm[5] = m1.y; mm[6] = m1.z; mm[7] = m1.w;
+        centre(va[jj], mm, xa[j], xn2a);
+        centre(vb[jj], mm, xb[j], xn2b);
+        if (j == 0) { x0a = va[0][0]; x0b = vb[0][0]; }
+        asm volatile("" : "+v"(xa[j]), "+v"(xb[j]));  // convert NOW: hipcc parks the fp32 values in scratch otherwise
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     xn2a += __shfl_xor(xn2a, 32); x0a = __shfl(x0a, col);
     xn2b += __shfl_xor(xn2b, 32); x0b = __shfl(x0b, col);
@@ -518,43 +390,43 @@ __global__ __launch_bounds__(kCoarse2Threads, 2) void lloyd_coarse2_kernel(
   // ---- LDS-DMA staging of super-tile sp into buffer buf ----
   const uint32_t nsuper = (K_pad + 63) / 64;
   const float *biashi = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(panelhi) + (size_t)nsuper * SUPB);
-  auto stage_issue = [&](uint32_t sp, int buf) {
-    // linear byte P of the super-tile image lands in LDS at P; it is fetched from source byte
-    // P ^ (((P / ROWB) & SWM) << 4): the 16-byte chunk index XORed with the row's low bits (inside a
-    // half row, SWM < KS).  Recomputed per call from one opaque register -- as loop invariants the
-    // per-piece addresses cost 30 VGPRs the MFMA loop needs.
+  // linear byte P of the super-tile image lands in LDS at P; it is fetched from source byte
+  // P ^ (((P / ROWB) & SWM) << 4): the 16-byte chunk index XORed with the row's low bits (inside a
+  // half row, SWM < KS).  Recomputed per piece from one opaque register -- as loop invariants the
+  // per-piece addresses cost 30 VGPRs the MFMA loop needs.
+  auto stage_piece = [&](uint32_t sp, int buf, int p) {
     uint32_t P0 = (uint32_t)lane * 16u;
     asm volatile("" : "+v"(P0));
-    const unsigned char *src = reinterpret_cast<const unsigned char *>(panelhi) + (size_t)sp * SUPB;
-#pragma unroll
-    for (int i = 0; i < (NP + 3) / 4; i++) {
-      const int p = i * 4 + wave;
-      if (NP % 4 == 0 || p < NP) {
-        const uint32_t P = (uint32_t)p * 1024u + P0;
-        const uint32_t from = P ^ (((P / ROWB) & SWM) << 4);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + from),
-                                         (__attribute__((address_space(3))) void *)(uintptr_t)(lds0 + buf * SUPB + p * 1024), 16, 0, 0);
-      }
-    }
-    // the 64 biases of the super-tile (clamped copy behind the panel): one 4-byte DMA by wave 0.  No
-    // ordinary global load lives in the loop: hipcc waits vmcnt(0) at its first use, draining the DMA
-    if (wave == 0)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(biashi + sp * 64u + lane),
-                                       (__attribute__((address_space(3))) void *)(uintptr_t)(bias0 + buf * 256), 4, 0, 0);
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(panelhi) + (size_t)(KMX_ABL == 8 ? 0 : sp) * SUPB;  // ABL 8: always the same 32 KB
+    const uint32_t P = (uint32_t)p * 1024u + P0;
+    const uint32_t from = P ^ (((P / ROWB) & SWM) << 4);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + from),
+                                     (__attribute__((address_space(3))) void *)(uintptr_t)(lds0 + buf * SUPB + p * 1024), 16, 0, 0);
+  };
+  // the 64 biases of the super-tile (clamped copy behind the panel): one 4-byte DMA.  No ordinary
+  // global load lives in the loop: hipcc waits vmcnt(0) at its first use, draining the DMA
+  auto stage_bias = [&](uint32_t sp, int buf) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(biashi + sp * 64u + lane),
+                                     (__attribute__((address_space(3))) void *)(uintptr_t)(bias0 + buf * 256), 4, 0, 0);
+  };
+  auto stage_issue = [&](uint32_t sp, int buf, int nw, int me) {   // nw waves share the pieces, I am number me
+    for (int p = me; p < NP; p += nw) stage_piece(sp, buf, p);
+    if (me == 0) stage_bias(sp, buf);
   };
 
-  stage_issue(0, 0);
-  load_rows();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  {  // the mean -> LDS: DP floats = DP / 4 sixteen-byte lanes
+    constexpr int MUP = (DP * 4 + 1023) / 1024;   // 1-KB pieces
+    if (wave < MUP && lane * 16 < DP * 4 - wave * 1024)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(mu) + wave * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void *)(uintptr_t)(mu_lds + wave * 1024), 16, 0, 0);
+  }
+  stage_issue(0, 0, WV, wave);
+  load_rows();   // waits for the DMA above and closes with a barrier after its first batch
 
   float v1a = -INFINITY, v2a = -INFINITY, v1b = -INFINITY, v2b = -INFINITY;
   uint32_t tba = 0, tbb = 0;
   // fragment address of k-step j: rowbase ^ swizzle ^ (16 j); (row, half) part fixed per lane
   const uint32_t fragbase = lds0 + (uint32_t)col * ROWB + (uint32_t)h * (KS * 16) + (uint32_t)((col & SWM) * 16);
-  auto frag = [&](uint32_t fb, int j) {
-    return *reinterpret_cast<const __attribute__((address_space(3))) f16x8 *>((uintptr_t)(fb ^ (uint32_t)(j * 16)));
-  };
   // max(v1, pk) as med3(v1, pk, +inf): fmaxf() costs a canonicalising v_max per operand on top
   float pinf = INFINITY;
   asm volatile("" : "+s"(pinf));
@@ -568,7 +440,7 @@ __global__ __launch_bounds__(kCoarse2Threads, 2) void lloyd_coarse2_kernel(
   // block, one per SIMD), so they are not in step: one's bookkeeping runs under the other's MFMAs.
   // (Double-buffered accumulators with the bookkeeping interleaved in-wave need ~230 registers: the
   // B operands spill, measured slower.)
-  auto tile_pass = [&](uint32_t ldsbase, uint32_t biasaddr, uint32_t t) {
+  auto tile_pass = [&](uint32_t ldsbase, uint32_t biasaddr, uint32_t t, bool stage, uint32_t sp_next, int buf_next) {
     f32x16 accA, accB;
     {
 #pragma unroll
@@ -582,21 +454,42 @@ __global__ __launch_bounds__(kCoarse2Threads, 2) void lloyd_coarse2_kernel(
     // visible, the KS addresses are hoisted out of the tile loop and the B operands spill instead
     uint32_t fb = fragbase + ldsbase;
     asm volatile("" : "+v"(fb));
-    f16x8 f0 = frag(fb, 0), f1 = frag(fb, KS > 1 ? 1 : 0);
+    // Fragment reads are issued by hand, PD k-steps ahead, with counted waits: while an LDS-DMA is in
+    // flight hipcc turns every wait on a fragment into lgkmcnt(0), i.e. it waits for the read it
+    // has just issued.  (LDS returns in order: lgkmcnt(n) = all but the youngest n reads landed.)
+    constexpr int PD = KS < 4 ? KS - 1 : 3;
+    f16x8 fr[PD + 1];
+#pragma unroll
+    for (int j = 0; j < PD; j++) fr[j] = lds_frag_issue(fb ^ (uint32_t)(j * 16));
 #pragma unroll
     for (int j = 0; j < KS; j++) {
-      f16x8 f2 = f1;
-      if (j + 2 < KS) f2 = frag(fb, j + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0, xa[j], accA, 0, 0, 0);
-      accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0, xb[j], accB, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      f0 = f1;
-      f1 = f2;
+      if (j + PD < KS && KMX_ABL != 6) fr[(j + PD) % (PD + 1)] = lds_frag_issue(fb ^ (uint32_t)((j + PD) * 16));
+      constexpr int kMaxBehind = PD;
+      const int behind = (KS - 1 - j) < kMaxBehind ? (KS - 1 - j) : kMaxBehind;  // younger reads in flight
+      f16x8 &f = fr[j % (PD + 1)];
+      if (behind == 3) lds_frag_wait<3>(f);
+      else if (behind == 2) lds_frag_wait<2>(f);
+      else if (behind == 1) lds_frag_wait<1>(f);
+      else lds_frag_wait<0>(f);
+      if (KMX_ABL == 4 && j > 0) {  // no matrix work
+        accA[j] += (float)f[0];
+        continue;
+      }
+      accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, xa[j], accA, 0, 0, 0);
+      accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, xb[j], accB, 0, 0, 0);
+      // the next super-tile's LDS-DMA pieces, one at a time in the shadow of the MFMAs: issued
+      // back to back the four waves' 32 pieces queue up in the texture path and hold up the wave
+      // (all of them during the super-tile's FIRST tile: the second one's 32 MFMAs cover the flight)
+      constexpr int SPREAD = KS >= 8 ? KS / 8 : 1;            // a piece every SPREAD k-steps
+      if (stage && (j % SPREAD) == SPREAD / 2 && j / SPREAD < 8) {
+        const int slot = j / SPREAD;                           // 0..7
+        for (int p = slot * 4 + wave; p < NP; p += 32) stage_piece(sp_next, buf_next, p);
+        if (slot == 0 && wave == 0) stage_bias(sp_next, buf_next);
+      }
     }
     const float v1a_in = v1a, v1b_in = v1b;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
+    for (int r = 0; r < ((KMX_ABL == 1 || KMX_ABL >= 5) ? 1 : 16); r++) {
       book(accA[r], r, v1a, v2a);
       book(accB[r], r, v1b, v2b);
     }
@@ -604,22 +497,27 @@ __global__ __launch_bounds__(kCoarse2Threads, 2) void lloyd_coarse2_kernel(
     tbb = (v1b != v1b_in) ? t : tbb;
   };
 
-  for (uint32_t sp = 0; sp < nsuper; sp++) {
+  for (uint32_t sp = 0; sp < (KMX_ABL == 10 ? 1u : nsuper); sp++) {  // ABL 10: prologue + one super-tile
     const int buf = sp & 1;
-    if (sp + 1 < nsuper) stage_issue(sp + 1, buf ^ 1);
+    const bool stage = sp + 1 < nsuper && KMX_ABL != 2 && KMX_ABL < 5 && KMX_ABL != 7;  // ABL 7: barrier without DMA
     const uint32_t base = buf * SUPB, bb = bias0 + buf * 256;
-    tile_pass(base, bb, 2 * sp);
-    tile_pass(base + 32 * ROWB, bb + 128, 2 * sp + 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    tile_pass(base, bb, 2 * sp, stage, sp + 1, buf ^ 1);
+    tile_pass(base + 32 * ROWB, bb + 128, 2 * sp + 1, false, sp + 1, buf ^ 1);
+    if (KMX_ABL != 2 && KMX_ABL != 3 && KMX_ABL < 5) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   }
 
-  // |coarse score - reference score| <= E_c as in lloyd_coarse_kernel, plus the 4 index bits packed
-  // into each score (<= 16 ulp of a score of magnitude <= ||x'|| C'max (1 + 2^-10) + B'max).  Rows or
-  // panels with a centred norm near the half range could hold inf halves: never decided here.
+  // |coarse score - reference score| <= E_c: the f32-accumulated hi.hi products (gamma_{DP+1}), the
+  // dropped lo terms (|a_lo| <= 2^-11 |a|: (2^-10 + 2^-22) ||x'|| C'max), half underflow, the 4 index
+  // bits packed into each score (<= 16 ulp of a score of magnitude <= ||x'|| C'max (1 + 2^-10) +
+  // B'max), + E_ref.  Rows or panels with a centred norm near the half range could hold inf halves:
+  // never decided here.
   const float cmaxc = sqrtf(__uint_as_float(stats[0])) * 1.000001f;
   const float bmaxc = __uint_as_float(stats[1]);
   const float cmaxo = sqrtf(__uint_as_float(stats[2])) * 1.000001f;
+  const float mu_norm = CACHED ? xmeta[2 * (size_t)gridDim.x * 256] : cmaxo;
   const float u = 5.9604645e-8f;
   uint32_t und_count = 0;
   unsigned long long uma = 0, umb = 0;
@@ -638,8 +536,9 @@ __global__ __launch_bounds__(kCoarse2Threads, 2) void lloyd_coarse2_kernel(
       v1 = g ? pv1 : v1;
       v2 = second;
     }
-    // ||x|| <= ||x'|| + ||mu|| <= ||x'|| + Cmax (mu is a mean of centroids): saves a second norm
-    const float xn = sqrtf(xn2) * 1.0001f, xo = (xn + cmaxo) * 1.0001f;
+    // ||x|| <= ||x'|| + ||mu||, and ||mu|| <= Cmax while mu is the mean of the current centroids
+    // (with the row cache mu is frozen: its norm is stored behind the per-row records)
+    const float xn = sqrtf(xn2) * 1.0001f, xo = (xn + mu_norm) * 1.0001f;
     const float e_c = 2.0f * eps * (xn * cmaxc + bmaxc) + 9.8e-4f * xn * cmaxc +
                       6e-8f * sqrtf((float)DP) * (xn + cmaxc) + 2.0e-6f * (1.001f * xn * cmaxc + bmaxc);
     const float e_ref = u * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
@@ -655,6 +554,10 @@ __global__ __launch_bounds__(kCoarse2Threads, 2) void lloyd_coarse2_kernel(
     if (lane == 0 && cm) atomicAdd(&counters[0], (uint32_t)__popcll(cm));
     und_count += (uint32_t)__popcll(um);
   };
+  if constexpr (CACHED) {
+    const float2 ma = reinterpret_cast<const float2 *>(xmeta)[sA], mb = reinterpret_cast<const float2 *>(xmeta)[sB];
+    xn2a = ma.x; x0a = ma.y; xn2b = mb.x; x0b = mb.y;
+  }
   finish(sA, liveA, v1a, v2a, tba, xn2a, x0a, unda, uma);
   finish(sB, liveB, v1b, v2b, tbb, xn2b, x0b, undb, umb);
   if (und_count) {
@@ -708,26 +611,6 @@ static hipError_t launch_f16_dp(const LloydArgs &a, const void *rows, bool half_
   return hipGetLastError();
 }
 
-template <int DP>
-static hipError_t launch_coarse_dp(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
-                                   uint32_t *undecided, hipStream_t st) {
-  const size_t lds_bytes = (4 * 32 * (DP / 2 + 4) + 128) * sizeof(float);
-  const uint32_t rows_per_block = kCoarseThreads / 2;
-  const uint32_t grid = (a.N + rows_per_block - 1) / rows_per_block;
-  const bool fast = a.D == (uint32_t)DP;
-#define KMX_CRS_LAUNCH(H, F)                                                                                       \
-  hipLaunchKernelGGL((lloyd_coarse_kernel<DP, H, F>), dim3(grid), dim3(kCoarseThreads), lds_bytes, st, rows, a.N, a.D, \
-                     reinterpret_cast<const float *>(panelhi), a.bias, a.mu, a.K_pad, a.K, a.stats, a.eps,           \
-                     a.tie_slack, a.assignments, a.assignments_prev, undecided, a.counters)
-  if (half_rows) {
-    if (fast) KMX_CRS_LAUNCH(true, true); else KMX_CRS_LAUNCH(true, false);
-  } else {
-    if (fast) KMX_CRS_LAUNCH(false, true); else KMX_CRS_LAUNCH(false, false);
-  }
-#undef KMX_CRS_LAUNCH
-  return hipGetLastError();
-}
-
 // one MFMA consumes 8 features per half-wave: the padded width must be at least 16
 bool lloyd_filter_f16_supported(uint32_t D, uint32_t DP) { return DP >= 16 && D <= DP; }
 
@@ -744,44 +627,128 @@ hipError_t launch_lloyd_filter_f16(const LloydArgs &a, const void *rows, bool ha
 }
 
 template <int DP>
-static hipError_t launch_coarse2_dp(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
-                                    uint32_t *undecided, hipStream_t st) {
-  const size_t lds_bytes = 2 * 64 * (size_t)(DP * 2) + 512;
+static hipError_t launch_coarse2_dp(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
+                                    const float *xmeta, const void *panelhi, uint32_t *undecided, hipStream_t st) {
+  const size_t lds_bytes = 2 * 64 * (size_t)(DP * 2) + 512 + 64 + (size_t)DP * 4;
   const uint32_t grid = (a.N + 255u) / 256u;
   const bool fast = a.D == (uint32_t)DP;
-#define KMX_CRS2_LAUNCH(H, F)                                                                                      \
-  hipLaunchKernelGGL((lloyd_coarse2_kernel<DP, H, F>), dim3(grid), dim3(kCoarse2Threads), lds_bytes, st, rows, a.N, \
+#define KMX_CRS2_LAUNCH(H, F, C, SRC)                                                                              \
+  hipLaunchKernelGGL((lloyd_coarse2_kernel<DP, H, F, C>), dim3(grid), dim3(256), lds_bytes, st, SRC, xmeta, a.N,    \
                      a.D, reinterpret_cast<const float *>(panelhi), a.bias, a.mu, a.K_pad, a.K, a.stats, a.eps,      \
                      a.tie_slack, a.assignments, a.assignments_prev, undecided, a.counters)
-  if (half_rows) {
-    if (fast) KMX_CRS2_LAUNCH(true, true); else KMX_CRS2_LAUNCH(true, false);
+  if (xcache) {
+    KMX_CRS2_LAUNCH(false, true, true, xcache);
+  } else if (half_rows) {
+    if (fast) KMX_CRS2_LAUNCH(true, true, false, rows); else KMX_CRS2_LAUNCH(true, false, false, rows);
   } else {
-    if (fast) KMX_CRS2_LAUNCH(false, true); else KMX_CRS2_LAUNCH(false, false);
+    if (fast) KMX_CRS2_LAUNCH(false, true, false, rows); else KMX_CRS2_LAUNCH(false, false, false, rows);
   }
 #undef KMX_CRS2_LAUNCH
   return hipGetLastError();
 }
 
-hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_rows, const void *panel16,
-                               void *panelhi, uint32_t *undecided, int generation, hipStream_t st) {
+hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
+                               const float *xmeta, const void *panel16, void *panelhi, uint32_t *undecided,
+                               hipStream_t st) {
   hipLaunchKernelGGL(centroid_panelhi_kernel, dim3((a.K_pad + 63u) / 64u * 64u), dim3(a.DP >= 256 ? 256 : 64), 0, st,
                      reinterpret_cast<const _Float16 *>(panel16), a.bias, a.K_pad, a.DP, reinterpret_cast<_Float16 *>(panelhi));
-  if (generation >= 2) {
-    switch (a.DP) {
-      case 16: return launch_coarse2_dp<16>(a, rows, half_rows, panelhi, undecided, st);
-      case 32: return launch_coarse2_dp<32>(a, rows, half_rows, panelhi, undecided, st);
-      case 64: return launch_coarse2_dp<64>(a, rows, half_rows, panelhi, undecided, st);
-      case 128: return launch_coarse2_dp<128>(a, rows, half_rows, panelhi, undecided, st);
-      case 256: return launch_coarse2_dp<256>(a, rows, half_rows, panelhi, undecided, st);
-      default: return hipErrorInvalidValue;
-    }
-  }
   switch (a.DP) {
-    case 16: return launch_coarse_dp<16>(a, rows, half_rows, panelhi, undecided, st);
-    case 32: return launch_coarse_dp<32>(a, rows, half_rows, panelhi, undecided, st);
-    case 64: return launch_coarse_dp<64>(a, rows, half_rows, panelhi, undecided, st);
-    case 128: return launch_coarse_dp<128>(a, rows, half_rows, panelhi, undecided, st);
-    case 256: return launch_coarse_dp<256>(a, rows, half_rows, panelhi, undecided, st);
+    case 16: return launch_coarse2_dp<16>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, st);
+    case 32: return launch_coarse2_dp<32>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, st);
+    case 64: return launch_coarse2_dp<64>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, st);
+    case 128: return launch_coarse2_dp<128>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, st);
+    case 256: return launch_coarse2_dp<256>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Row cache: the coarse stage's B operands, x' = x - mu rounded to halves, in the operand order of
+// lloyd_coarse2_kernel -- per 32-row block, DP/16 pieces of 64 lanes x 16 bytes (lane = (row, half
+// of the features)) -- plus (||x'||^2, x_0) per row.  Built once per engine while mu stays frozen
+// (engine.cpp): afterwards an iteration streams 2 DP bytes per row in whole 1-KB bursts instead of
+// 4 DP bytes as 16-byte pieces of 64 different lines per load, and converts nothing.
+// ---------------------------------------------------------------------------------------
+template <int DP, bool HALF_ROWS, bool FAST>
+__global__ __launch_bounds__(256) void row_cache_kernel(const void *__restrict__ rows, uint32_t N, uint32_t D,
+                                                        const float *__restrict__ mu, f16x8 *__restrict__ xcache,
+                                                        float2 *__restrict__ xmeta, uint32_t nblocks32) {
+  constexpr int NKH = DP / 2, KS = NKH / 8;
+  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+  const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (b >= nblocks32) return;
+  if (b == 0) {  // ||mu|| behind the per-row records: ||x|| <= ||x'|| + ||mu|| in the coarse kernel's bound
+    float m2 = 0.f;
+    for (uint32_t f = lane; f < (uint32_t)DP; f += 64) m2 = fmaf(mu[f], mu[f], m2);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o);
+    if (lane == 0) xmeta[(size_t)nblocks32 * 32] = make_float2(sqrtf(m2) * 1.00001f, 0.f);
+  }
+  const uint32_t s = b * 32u + col;
+  const bool live = s < N;
+  const size_t row = (size_t)(live ? s : 0);
+  float xn2 = 0.f, x0 = 0.f;
+#pragma unroll
+  for (int j = 0; j < KS; j++) {
+    float xv[8];
+    if (FAST && HALF_ROWS) {
+      const f16x8 raw = reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(rows) + row * DP + h * NKH)[j];
+#pragma unroll
+      for (int q = 0; q < 8; q++) xv[q] = (float)raw[q];
+    } else if (FAST) {
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(rows) + row * DP + h * NKH);
+      const f32x4 a = src[2 * j], c = src[2 * j + 1];
+      xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w;
+      xv[4] = c.x; xv[5] = c.y; xv[6] = c.z; xv[7] = c.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint32_t f = h * NKH + 8 * j + q;
+        float v = 0.f;
+        if (f < D) v = HALF_ROWS ? (float)reinterpret_cast<const _Float16 *>(rows)[row * D + f]
+                                 : reinterpret_cast<const float *>(rows)[row * D + f];
+        xv[q] = v;
+      }
+    }
+    f16x8 hi;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const float xc = live ? xv[q] - mu[h * NKH + 8 * j + q] : 0.f;   // mu: DP floats, zero beyond D
+      hi[q] = (_Float16)xc;
+      xn2 = fmaf(xc, xc, xn2);
+    }
+    if (j == 0) x0 = live ? xv[0] : 0.f;
+    xcache[((size_t)b * KS + j) * 64 + lane] = hi;
+  }
+  xn2 += __shfl_xor(xn2, 32);
+  if (h == 0) xmeta[s] = make_float2(xn2, x0);   // xmeta covers the padded row count
+}
+
+template <int DP>
+static hipError_t launch_row_cache_dp(const void *rows, bool half_rows, uint32_t N, uint32_t D, const float *mu,
+                                      void *xcache, float *xmeta, hipStream_t st) {
+  const uint32_t nblocks32 = (N + 255u) / 256u * 8u;
+  const bool fast = D == (uint32_t)DP;
+#define KMX_RC_LAUNCH(H, F)                                                                                       \
+  hipLaunchKernelGGL((row_cache_kernel<DP, H, F>), dim3(nblocks32 / 4), dim3(256), 0, st, rows, N, D, mu,          \
+                     reinterpret_cast<f16x8 *>(xcache), reinterpret_cast<float2 *>(xmeta), nblocks32)
+  if (half_rows) {
+    if (fast) KMX_RC_LAUNCH(true, true); else KMX_RC_LAUNCH(true, false);
+  } else {
+    if (fast) KMX_RC_LAUNCH(false, true); else KMX_RC_LAUNCH(false, false);
+  }
+#undef KMX_RC_LAUNCH
+  return hipGetLastError();
+}
+
+hipError_t launch_row_cache(const void *rows, bool half_rows, uint32_t N, uint32_t D, uint32_t DP, const float *mu,
+                            void *xcache, float *xmeta, hipStream_t st) {
+  switch (DP) {
+    case 16: return launch_row_cache_dp<16>(rows, half_rows, N, D, mu, xcache, xmeta, st);
+    case 32: return launch_row_cache_dp<32>(rows, half_rows, N, D, mu, xcache, xmeta, st);
+    case 64: return launch_row_cache_dp<64>(rows, half_rows, N, D, mu, xcache, xmeta, st);
+    case 128: return launch_row_cache_dp<128>(rows, half_rows, N, D, mu, xcache, xmeta, st);
+    case 256: return launch_row_cache_dp<256>(rows, half_rows, N, D, mu, xcache, xmeta, st);
     default: return hipErrorInvalidValue;
   }
 }

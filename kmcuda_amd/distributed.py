@@ -24,10 +24,11 @@ def row_block(n_total, rank, world):
 class HipBackend:
     """This rank's rows on its GPU; all compute is libKMCUDA.so kernels."""
 
-    def __init__(self, samples, clusters, metric="L2", device_index=0, half_rows=None):
+    def __init__(self, samples, clusters, metric="L2", device_index=0, half_rows=None, row_cache=True):
         """half_rows: the same rows as a float16 tensor (fp16x2 path): the assignment filter then runs
         on the f16 matrix cores reading the halves; `samples` stays the widened fp32 copy the exact
-        refine / update kernels read."""
+        refine / update kernels read.  row_cache: this backend's rows never change, so the coarse filter
+        stage may keep its centred half copy of them across iterations (Engine.set_row_cache)."""
         from .engine import Engine
         assert samples.is_cuda and samples.dtype == torch.float32 and samples.is_contiguous()
         self.samples = samples
@@ -39,6 +40,8 @@ class HipBackend:
             assert half_rows.dtype == torch.float16 and half_rows.shape == samples.shape and half_rows.is_contiguous()
             self.engine.set_half_rows(half_rows)
         self.half = half_rows is not None
+        if row_cache:
+            self.engine.set_row_cache(True)
         i32 = dict(dtype=torch.int32, device=self.device)
         self.assignments = torch.full((self.n_local,), -1, **i32)   # 0xFFFFFFFF (prepare_mem)
         self.assignments_prev = torch.full((self.n_local,), -1, **i32)

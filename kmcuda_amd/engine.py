@@ -67,6 +67,13 @@ class Engine:
         _lib.check(self.lib.kmamd_set_half_rows(self.h, self._p(rows16) if rows16 is not None else None),
                    "kmamd_set_half_rows")
 
+    def set_row_cache(self, on=True):
+        """Promise that lloyd_assign() gets the same, unmodified rows from now on: the coarse filter
+        stage then keeps x - mean as halves in matrix-core operand order (built by the next
+        lloyd_assign, mean frozen) and streams that copy instead of converting the rows every pass.
+        Assignments are unchanged.  Calling it again drops the copy."""
+        _lib.check(self.lib.kmamd_set_row_cache(self.h, 1 if on else 0), "kmamd_set_row_cache")
+
     def counters(self):
         out = (ctypes.c_uint32 * 4)()
         _lib.check(self.lib.kmamd_counters_read(self.h, out), "kmamd_counters_read")
