@@ -280,7 +280,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
     }
     const void *rows = half_rows_ ? half_rows_ : (const void *)samples;
     const bool half = half_rows_ != nullptr;
-    KMX_HIP(launch_centroid_panel16(centroids, K_, D_, K_pad_, DP_, finite_, mu_, panel16_, stream_), kRuntimeError);
+    KMX_HIP(launch_centroid_panel16(centroids, K_, D_, K_pad_, DP_, finite_, mu_, panel16_, stats_, stream_), kRuntimeError);
     if (filter_mode_ == 0) {
       if (build_cache) {
         const size_t npad = ((size_t)N_ + 255) / 256 * 256;

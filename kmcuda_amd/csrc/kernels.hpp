@@ -40,7 +40,8 @@ hipError_t launch_lloyd_exact(int metric, const LloydArgs &a, const uint32_t *ro
 // rows and for the fp16x2 path's half rows; decisions identical in kind, refine kernels shared
 bool lloyd_filter_f16_supported(uint32_t D, uint32_t DP);
 hipError_t launch_centroid_panel16(const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP,
-                                   const uint32_t *finite, const float *mu, void *panel16, hipStream_t st);
+                                   const uint32_t *finite, const float *mu, void *panel16, uint32_t *stats,
+                                   hipStream_t st);
 hipError_t launch_lloyd_filter_f16(const LloydArgs &a, const void *rows, bool half_rows, const void *panel16,
                                    const uint32_t *row_list, const uint32_t *n_list, hipStream_t st);
 // stage 1 of the default filter: hi.hi products only; rows it cannot decide -> undecided[counters[4]++].

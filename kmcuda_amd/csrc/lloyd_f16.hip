@@ -38,18 +38,34 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // non-finite / padding centroids (their bias is -inf in the shared bias array).
 __global__ void centroid_panel16_kernel(const float *__restrict__ centroids, uint32_t K, uint32_t D, uint32_t K_pad,
                                         uint32_t DP, const uint32_t *__restrict__ finite,
-                                        const float *__restrict__ mu, _Float16 *__restrict__ panel16) {
+                                        const float *__restrict__ mu, _Float16 *__restrict__ panel16,
+                                        uint32_t *__restrict__ stats) {
   const uint32_t c = blockIdx.x;
   if (c >= K_pad) return;
   _Float16 *dst = panel16 + (size_t)c * 2 * DP;
   const bool ok = c < K && finite[c];
+  float res2 = 0.f;  // ||c' - hi(c')||^2: what the coarse stage's hi.hi products drop on this side
   for (uint32_t f = threadIdx.x; f < DP; f += blockDim.x) {
     float v = 0.f;
     if (ok && f < D) v = centroids[(size_t)c * D + f] - mu[f];
     const _Float16 hi = (_Float16)v;
-    const _Float16 lo = (_Float16)(v - (float)hi);
+    const float r = v - (float)hi;  // exact: hi keeps the leading 11 bits of v
+    const _Float16 lo = (_Float16)r;
     dst[f] = hi;
     dst[DP + f] = lo;
+    res2 = fmaf(r, r, res2);
+  }
+  // stats[5] = max over centroids (block = 1 or 4 waves)
+  __shared__ float part[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) res2 += __shfl_xor(res2, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = res2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (uint32_t w = 0; w < (blockDim.x + 63) / 64; w++) t += part[w];
+    if ((t - t) == 0.f) atomicMax(&stats[5], __float_as_uint(t * 1.0001f));  // an overflowed half leaves inf - inf
+    else atomicMax(&stats[5], 0x7F800000u);                                   // = "no bound": nothing decided
   }
 }
 
@@ -518,11 +534,12 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   const float bmaxc = __uint_as_float(stats[1]);
   const float cmaxo = sqrtf(__uint_as_float(stats[2])) * 1.000001f;
   const float mu_norm = CACHED ? xmeta[2 * (size_t)gridDim.x * 256] : cmaxo;
+  const float dcmax = sqrtf(__uint_as_float(stats[5])) * 1.000001f;   // max ||c' - hi(c')||; inf = no bound
   const float u = 5.9604645e-8f;
   uint32_t und_count = 0;
   unsigned long long uma = 0, umb = 0;
   bool unda = false, undb = false;
-  auto finish = [&](uint32_t s, bool live, float v1, float v2, uint32_t tb, float xn2, float x0, bool &und,
+  auto finish = [&](uint32_t s, bool live, float v1, float v2, uint32_t tb, float xn2, float x0, float dx2, bool &und,
                     unsigned long long &um) {
     const bool insane = (x0 != x0);  // kmeans.cu:312
     const uint32_t r = __float_as_uint(v1) & 15u;
@@ -539,7 +556,11 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     // ||x|| <= ||x'|| + ||mu||, and ||mu|| <= Cmax while mu is the mean of the current centroids
     // (with the row cache mu is frozen: its norm is stored behind the per-row records)
     const float xn = sqrtf(xn2) * 1.0001f, xo = (xn + mu_norm) * 1.0001f;
-    const float e_c = 2.0f * eps * (xn * cmaxc + bmaxc) + 9.8e-4f * xn * cmaxc +
+    // operand rounding: x'.c' - hi(x').hi(c') = x'.dc + dx.c' - dx.dc with dx = x' - hi(x'), dc likewise,
+    // bounded by Cauchy-Schwarz on MEASURED residual norms (row cache / centroid_panel16_kernel; about
+    // half the worst case 2^-11 ||.||, which the uncached path uses for its rows)
+    const float dx = dx2 >= 0.f ? sqrtf(dx2) * 1.0001f : 4.8829e-4f * xn;
+    const float e_c = 2.0f * eps * (xn * cmaxc + bmaxc) + (xn * dcmax + dx * cmaxc + dx * dcmax) * 1.001f +
                       6e-8f * sqrtf((float)DP) * (xn + cmaxc) + 2.0e-6f * (1.001f * xn * cmaxc + bmaxc);
     const float e_ref = u * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
     const float thr = 2.0f * (e_c + e_ref) * 1.001f + tie_slack;
@@ -554,12 +575,15 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     if (lane == 0 && cm) atomicAdd(&counters[0], (uint32_t)__popcll(cm));
     und_count += (uint32_t)__popcll(um);
   };
+  float dx2a = -2.f, dx2b = -2.f;   // -2: not measured (no row cache) -> the worst case 2^-11 ||x'||
   if constexpr (CACHED) {
     const float2 ma = reinterpret_cast<const float2 *>(xmeta)[sA], mb = reinterpret_cast<const float2 *>(xmeta)[sB];
-    xn2a = ma.x; x0a = ma.y; xn2b = mb.x; x0b = mb.y;
+    xn2a = ma.x; dx2a = ma.y; xn2b = mb.x; dx2b = mb.y;
+    x0a = (ma.y == -1.f) ? __builtin_nanf("") : 0.f;
+    x0b = (mb.y == -1.f) ? __builtin_nanf("") : 0.f;
   }
-  finish(sA, liveA, v1a, v2a, tba, xn2a, x0a, unda, uma);
-  finish(sB, liveB, v1b, v2b, tbb, xn2b, x0b, undb, umb);
+  finish(sA, liveA, v1a, v2a, tba, xn2a, x0a, dx2a, unda, uma);
+  finish(sB, liveB, v1b, v2b, tbb, xn2b, x0b, dx2b, undb, umb);
   if (und_count) {
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&counters[4], und_count);
@@ -585,9 +609,10 @@ __global__ void centroid_panelhi_kernel(const _Float16 *__restrict__ panel16, co
 }
 
 hipError_t launch_centroid_panel16(const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP,
-                                   const uint32_t *finite, const float *mu, void *panel16, hipStream_t st) {
+                                   const uint32_t *finite, const float *mu, void *panel16, uint32_t *stats,
+                                   hipStream_t st) {
   hipLaunchKernelGGL(centroid_panel16_kernel, dim3(K_pad), dim3(DP >= 256 ? 256 : 64), 0, st, centroids, K, D, K_pad,
-                     DP, finite, mu, reinterpret_cast<_Float16 *>(panel16));
+                     DP, finite, mu, reinterpret_cast<_Float16 *>(panel16), stats);
   return hipGetLastError();
 }
 
@@ -687,7 +712,7 @@ __global__ __launch_bounds__(256) void row_cache_kernel(const void *__restrict__
   const uint32_t s = b * 32u + col;
   const bool live = s < N;
   const size_t row = (size_t)(live ? s : 0);
-  float xn2 = 0.f, x0 = 0.f;
+  float xn2 = 0.f, dx2 = 0.f, x0 = 0.f;
 #pragma unroll
   for (int j = 0; j < KS; j++) {
     float xv[8];
@@ -714,14 +739,19 @@ __global__ __launch_bounds__(256) void row_cache_kernel(const void *__restrict__
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       const float xc = live ? xv[q] - mu[h * NKH + 8 * j + q] : 0.f;   // mu: DP floats, zero beyond D
-      hi[q] = (_Float16)xc;
+      const _Float16 a = (_Float16)xc;
+      const float r = xc - (float)a;   // exact; what the hi.hi products drop on this side
+      hi[q] = a;
       xn2 = fmaf(xc, xc, xn2);
+      dx2 = fmaf(r, r, dx2);
     }
     if (j == 0) x0 = live ? xv[0] : 0.f;
     xcache[((size_t)b * KS + j) * 64 + lane] = hi;
   }
   xn2 += __shfl_xor(xn2, 32);
-  if (h == 0) xmeta[s] = make_float2(xn2, x0);   // xmeta covers the padded row count
+  dx2 += __shfl_xor(dx2, 32);
+  // record = (||x'||^2, ||x' - hi(x')||^2); a NaN first feature (kmeans.cu:312) is flagged by -1
+  if (h == 0) xmeta[s] = make_float2(xn2, (x0 != x0) ? -1.f : dx2 * 1.0001f);   // xmeta covers the padded row count
 }
 
 template <int DP>
