@@ -119,7 +119,7 @@ void Engine::profile_reset() {
 int Engine::prepare_centroids(const float *centroids) {
   const uint32_t dp = DP_ ? DP_ : 8;
   KMX_HIP(launch_centroid_prep(metric_, centroids, K_, D_, K_pad_, dp, Kt_, csqr_, bias_, bias2_, cfil_, ct_, mu_,
-                               mu_frozen_, finite_, stats_, counters_ + 1, counters_ + 3, stream_),
+                               mu_frozen_, finite_, stats_, counters_ + 1, counters_ + 3, counters_ + 4, stream_),
           kRuntimeError);
   return kSuccess;
 }
@@ -280,7 +280,9 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
     }
     const void *rows = half_rows_ ? half_rows_ : (const void *)samples;
     const bool half = half_rows_ != nullptr;
-    KMX_HIP(launch_centroid_panel16(centroids, K_, D_, K_pad_, DP_, finite_, mu_, panel16_, stats_, stream_), kRuntimeError);
+    KMX_HIP(launch_centroid_panel16(centroids, K_, D_, K_pad_, DP_, finite_, mu_, bias_, panel16_,
+                                    filter_mode_ == 0 ? panelhi_ : nullptr, stats_, stream_),
+            kRuntimeError);
     if (filter_mode_ == 0) {
       if (build_cache) {
         const size_t npad = ((size_t)N_ + 255) / 256 * 256;
@@ -303,9 +305,8 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
         }
       }
       const bool cached = row_cache_on_ && row_cache_valid_;
-      KMX_HIP(hipMemsetAsync(counters_ + 4, 0, sizeof(uint32_t), stream_), kRuntimeError);
-      KMX_HIP(launch_lloyd_coarse(a, rows, half, cached ? xcache_ : nullptr, xmeta_, panel16_, panelhi_, undecided_,
-                                  stream_),
+      // counters_[4] (the undecided list's length) was zeroed by centroid_prep
+      KMX_HIP(launch_lloyd_coarse(a, rows, half, cached ? xcache_ : nullptr, xmeta_, panelhi_, undecided_, stream_),
               kRuntimeError);
       KMX_HIP(launch_lloyd_filter_f16(a, rows, half, panel16_, undecided_, counters_ + 4, stream_), kRuntimeError);
     } else {

@@ -30,7 +30,7 @@ uint32_t filter_dp_for(uint32_t D);
 hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad,
                                 uint32_t DP, uint32_t Kt, float *csqr, float *bias, float *bias2, float *cfil,
                                 float *ct, float *mu, bool freeze_mu, uint32_t *finite, uint32_t *stats, uint32_t *zero_a,
-                                uint32_t *zero_b, hipStream_t st);
+                                uint32_t *zero_b, uint32_t *zero_c, hipStream_t st);
 hipError_t launch_lloyd_filter(const LloydArgs &a, hipStream_t st);
 hipError_t launch_lloyd_pair(int metric, const LloydArgs &a, const float *centroids, uint32_t grid, hipStream_t st);
 hipError_t launch_lloyd_exact(int metric, const LloydArgs &a, const uint32_t *rows, const uint32_t *nrows,
@@ -39,16 +39,17 @@ hipError_t launch_lloyd_exact(int metric, const LloydArgs &a, const uint32_t *ro
 // lloyd_f16.hip -- the same filter on the f16 matrix cores (centred hi/lo-split operands), for fp32
 // rows and for the fp16x2 path's half rows; decisions identical in kind, refine kernels shared
 bool lloyd_filter_f16_supported(uint32_t D, uint32_t DP);
+// panel16 = [hi | lo] rows for the split pass; panelhi (may be null) = hi rows + clamped biases for the
+// coarse pass, K_pad rounded up to 64 rows, (DP + 2) * 2 bytes per row; stats[5] = max ||c' - hi(c')||^2
 hipError_t launch_centroid_panel16(const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP,
-                                   const uint32_t *finite, const float *mu, void *panel16, uint32_t *stats,
-                                   hipStream_t st);
+                                   const uint32_t *finite, const float *mu, const float *bias, void *panel16,
+                                   void *panelhi, uint32_t *stats, hipStream_t st);
 hipError_t launch_lloyd_filter_f16(const LloydArgs &a, const void *rows, bool half_rows, const void *panel16,
                                    const uint32_t *row_list, const uint32_t *n_list, hipStream_t st);
 // stage 1 of the default filter: hi.hi products only; rows it cannot decide -> undecided[counters[4]++].
 // xcache / xmeta: the engine's row cache (launch_row_cache) or nullptr (operands converted from rows)
 hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
-                               const float *xmeta, const void *panel16, void *panelhi, uint32_t *undecided,
-                               hipStream_t st);
+                               const float *xmeta, const void *panelhi, uint32_t *undecided, hipStream_t st);
 // x' = x - mu as halves in the coarse kernel's operand order (N rounded up to 256 rows: DP*2 bytes per
 // row) + (||x'||^2, x_0) per row (8 bytes); valid while mu is unchanged
 hipError_t launch_row_cache(const void *rows, bool half_rows, uint32_t N, uint32_t D, uint32_t DP, const float *mu,

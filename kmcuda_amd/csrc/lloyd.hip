@@ -40,8 +40,8 @@ __global__ void centroid_rows_kernel(const float *__restrict__ centroids, uint32
                                      float *__restrict__ csqr, float *__restrict__ ct,
                                      uint32_t *__restrict__ finite, uint32_t *__restrict__ stats) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= Kt) return;
-  if (c < K) {
+  float plain_max = 0.f;  // this lane's contribution to stats[2]
+  if (c < Kt && c < K) {
     const float *row = centroids + (size_t)c * D;
     float ssqr = 0.f, corr = 0.f, plain = 0.f;
     uint32_t f = 0;
@@ -67,10 +67,14 @@ __global__ void centroid_rows_kernel(const float *__restrict__ centroids, uint32
     finite[c] = fin ? 1u : 0u;
     if (csqr) csqr[c] = (METRIC == 0) ? ssqr : 1.f;
     // uncentered max ||c||^2 for the bound on the REFERENCE's own rounding error
-    if (fin) atomicMax(&stats[2], __float_as_uint(plain * 1.0001f));
-  } else if (ct) {
+    if (fin) plain_max = plain * 1.0001f;
+  } else if (c < Kt && ct) {
     for (uint32_t f = 0; f < D; f++) ct[(size_t)f * Kt + c] = 0.f;
   }
+  // one atomic per wave, not per centroid (K same-address atomics cost more than the kernel)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) plain_max = fmaxf(plain_max, __shfl_xor(plain_max, off));
+  if ((threadIdx.x & 63) == 0 && plain_max > 0.f) atomicMax(&stats[2], __float_as_uint(plain_max));
 }
 
 // mean of the finite centroid rows, one thread per (padded) feature.  Any vector would do: the
@@ -81,7 +85,8 @@ __global__ __launch_bounds__(1024) void centroid_mean_kernel(const float *__rest
                                                              const uint32_t *__restrict__ finite,
                                                              float *__restrict__ mu, bool freeze_mu,
                                                              uint32_t *__restrict__ zero_a,
-                                                             uint32_t *__restrict__ zero_b) {
+                                                             uint32_t *__restrict__ zero_b,
+                                                             uint32_t *__restrict__ zero_c) {
   // block = 64 features x 16 row-slices: coalesced row reads, fixed summation order
   constexpr int S = 16;
   __shared__ float part[S][64];
@@ -91,6 +96,7 @@ __global__ __launch_bounds__(1024) void centroid_mean_kernel(const float *__rest
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // the filter's per-pass list counters (saves two memset launches)
     if (zero_a) *zero_a = 0u;
     if (zero_b) *zero_b = 0u;
+    if (zero_c) *zero_c = 0u;
   }
   if (freeze_mu) return;  // the engine's row cache holds x - mu: mu stays what it was (any mu is valid)
   float sum = 0.f;
@@ -127,52 +133,68 @@ __global__ __launch_bounds__(256) void centroid_panel_kernel(const float *__rest
                                                              const float *__restrict__ mu, float *__restrict__ bias,
                                                              float *__restrict__ bias2, float *__restrict__ cfil,
                                                              uint32_t *__restrict__ stats) {
-  // one WAVE per padded centroid row: coalesced reads / writes, plain (order-free) sums by shuffles
-  const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const uint32_t lane = threadIdx.x & 63;
-  if (c >= K_pad) return;
-  float *dst = cfil + (size_t)c * DP;
-  const bool ok = c < K && finite[c];
-  float n2 = 0.f, mc = 0.f, m2 = 0.f;
-  for (uint32_t f = lane; f < DP; f += 64) {
-    float v = 0.f, m = 0.f;
-    if (ok && f < D) {
-      m = mu[f];
-      v = centroids[(size_t)c * D + f] - m;
+  // one WAVE per padded centroid row (4 rows per wave, 16 per block): coalesced reads / writes, plain
+  // (order-free) sums by shuffles; the four maxima go out once per block -- per-row same-address
+  // atomics used to be most of this kernel's 49 us
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // maxima as BITS: the values are non-negative, so bits order like values, and a NaN (0 * inf in a
+  // bound term) sorts above inf and poisons the bound -- as the per-row atomicMax on bits did
+  uint32_t s0 = 0, s1 = 0, s3 = 0, s4 = 0;
+  for (uint32_t i = 0; i < 4; i++) {
+    const uint32_t c = blockIdx.x * 16 + wave * 4 + i;
+    if (c >= K_pad) break;
+    float *dst = cfil + (size_t)c * DP;
+    const bool ok = c < K && finite[c];
+    float n2 = 0.f, mc = 0.f, m2 = 0.f;
+    for (uint32_t f = lane; f < DP; f += 64) {
+      float v = 0.f, m = 0.f;
+      if (ok && f < D) {
+        m = mu[f];
+        v = centroids[(size_t)c * D + f] - m;
+      }
+      dst[f] = v;
+      n2 = fmaf(v, v, n2);
+      mc = fmaf(m, v, mc);
+      m2 = fmaf(m, m, m2);
     }
-    dst[f] = v;
-    n2 = fmaf(v, v, n2);
-    mc = fmaf(m, v, mc);
-    m2 = fmaf(m, m, m2);
-  }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    n2 += __shfl_xor(n2, off);
-    mc += __shfl_xor(mc, off);
-    m2 += __shfl_xor(m2, off);
-  }
-  if (lane != 0) return;
-  if (ok) {
-    float b, bmag;
-    if (METRIC == 0) {
-      b = -0.5f * n2;
-      bmag = 0.5f * n2;
-    } else {
-      b = mc;
-      bmag = sqrtf(m2) * sqrtf(n2) * 1.0001f;  // >= sum |mu_f c'_f|
+    for (int off = 32; off > 0; off >>= 1) {
+      n2 += __shfl_xor(n2, off);
+      mc += __shfl_xor(mc, off);
+      m2 += __shfl_xor(m2, off);
     }
-    bias[c] = b;
-    // the variant for kernels that keep the ORIGINAL row resident:
-    // ||x - c||^2 = ||x - mu||^2 - 2 (x.c' - mu.c' - ||c'||^2/2)   /   x.c = x.c' + x.mu
-    const float mag2 = (METRIC == 0) ? sqrtf(m2) * sqrtf(n2) * 1.0001f + 0.5f * n2 : 0.f;
-    bias2[c] = (METRIC == 0) ? -mc - 0.5f * n2 : 0.f;
-    atomicMax(&stats[0], __float_as_uint(n2 * 1.0001f));
-    atomicMax(&stats[1], __float_as_uint(bmag * 1.0001f));
-    atomicMax(&stats[3], __float_as_uint(m2 * 1.0001f));
-    atomicMax(&stats[4], __float_as_uint(mag2 * 1.0001f));
-  } else {
-    bias[c] = -INFINITY;
-    bias2[c] = -INFINITY;
+    if (ok) {
+      float b, bmag;
+      if (METRIC == 0) {
+        b = -0.5f * n2;
+        bmag = 0.5f * n2;
+      } else {
+        b = mc;
+        bmag = sqrtf(m2) * sqrtf(n2) * 1.0001f;  // >= sum |mu_f c'_f|
+      }
+      // the variant for kernels that keep the ORIGINAL row resident:
+      // ||x - c||^2 = ||x - mu||^2 - 2 (x.c' - mu.c' - ||c'||^2/2)   /   x.c = x.c' + x.mu
+      const float mag2 = (METRIC == 0) ? sqrtf(m2) * sqrtf(n2) * 1.0001f + 0.5f * n2 : 0.f;
+      if (lane == 0) {
+        bias[c] = b;
+        bias2[c] = (METRIC == 0) ? -mc - 0.5f * n2 : 0.f;
+      }
+      s0 = max(s0, __float_as_uint(n2 * 1.0001f));
+      s1 = max(s1, __float_as_uint(bmag * 1.0001f));
+      s3 = max(s3, __float_as_uint(m2 * 1.0001f));
+      s4 = max(s4, __float_as_uint(mag2 * 1.0001f));
+    } else if (lane == 0) {
+      bias[c] = -INFINITY;
+      bias2[c] = -INFINITY;
+    }
+  }
+  __shared__ uint32_t red[4][4];
+  if (lane == 0) { red[wave][0] = s0; red[wave][1] = s1; red[wave][2] = s3; red[wave][3] = s4; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const uint32_t m = max(max(red[0][threadIdx.x], red[1][threadIdx.x]), max(red[2][threadIdx.x], red[3][threadIdx.x]));
+    const uint32_t slot = threadIdx.x < 2 ? threadIdx.x : threadIdx.x + 1;  // stats[0], [1], [3], [4]
+    atomicMax(&stats[slot], m);
   }
 }
 
@@ -561,7 +583,7 @@ hipError_t launch_lloyd_filter(const LloydArgs &a, hipStream_t st) {
 hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad,
                                 uint32_t DP, uint32_t Kt, float *csqr, float *bias, float *bias2, float *cfil,
                                 float *ct, float *mu, bool freeze_mu, uint32_t *finite, uint32_t *stats,
-                                uint32_t *zero_a, uint32_t *zero_b, hipStream_t st) {
+                                uint32_t *zero_a, uint32_t *zero_b, uint32_t *zero_c, hipStream_t st) {
   hipError_t e = hipMemsetAsync(stats, 0, 8 * sizeof(uint32_t), st);
   if (e != hipSuccess) return e;
   const dim3 block(64);
@@ -572,12 +594,12 @@ hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, 
     hipLaunchKernelGGL((centroid_rows_kernel<1>), dim3((Kt + 63) / 64), block, 0, st, centroids, K, D, Kt, csqr, ct,
                        finite, stats);
   hipLaunchKernelGGL(centroid_mean_kernel, dim3((DP + 63) / 64), dim3(1024), 0, st, centroids, K, D, DP, finite, mu,
-                     freeze_mu, zero_a, zero_b);
+                     freeze_mu, zero_a, zero_b, zero_c);
   if (metric == 0)
-    hipLaunchKernelGGL((centroid_panel_kernel<0>), dim3((K_pad + 3) / 4), dim3(256), 0, st, centroids, K, D, K_pad, DP,
+    hipLaunchKernelGGL((centroid_panel_kernel<0>), dim3((K_pad + 15) / 16), dim3(256), 0, st, centroids, K, D, K_pad, DP,
                        finite, mu, bias, bias2, cfil, stats);
   else
-    hipLaunchKernelGGL((centroid_panel_kernel<1>), dim3((K_pad + 3) / 4), dim3(256), 0, st, centroids, K, D, K_pad, DP,
+    hipLaunchKernelGGL((centroid_panel_kernel<1>), dim3((K_pad + 15) / 16), dim3(256), 0, st, centroids, K, D, K_pad, DP,
                        finite, mu, bias, bias2, cfil, stats);
   return hipGetLastError();
 }

@@ -35,38 +35,45 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // c' = c - mu split into halves: panel16[c] = [hi(c'_0..DP-1) | lo(c'_0..DP-1)]; zero rows for
-// non-finite / padding centroids (their bias is -inf in the shared bias array).
-__global__ void centroid_panel16_kernel(const float *__restrict__ centroids, uint32_t K, uint32_t D, uint32_t K_pad,
-                                        uint32_t DP, const uint32_t *__restrict__ finite,
-                                        const float *__restrict__ mu, _Float16 *__restrict__ panel16,
-                                        uint32_t *__restrict__ stats) {
-  const uint32_t c = blockIdx.x;
-  if (c >= K_pad) return;
-  _Float16 *dst = panel16 + (size_t)c * 2 * DP;
-  const bool ok = c < K && finite[c];
-  float res2 = 0.f;  // ||c' - hi(c')||^2: what the coarse stage's hi.hi products drop on this side
-  for (uint32_t f = threadIdx.x; f < DP; f += blockDim.x) {
-    float v = 0.f;
-    if (ok && f < D) v = centroids[(size_t)c * D + f] - mu[f];
-    const _Float16 hi = (_Float16)v;
-    const float r = v - (float)hi;  // exact: hi keeps the leading 11 bits of v
-    const _Float16 lo = (_Float16)r;
-    dst[f] = hi;
-    dst[DP + f] = lo;
-    res2 = fmaf(r, r, res2);
-  }
-  // stats[5] = max over centroids (block = 1 or 4 waves)
-  __shared__ float part[4];
+// non-finite / padding centroids (their bias is -inf in the shared bias array).  One wave per centroid.
+// For the coarse stage the same pass writes the hi halves alone (panelhi: K_pad rounded up to whole
+// 64-row super-tiles, zero rows beyond K_pad) and, behind them, the biases with -inf clamped to a
+// finite floor; stats[5] = max ||c' - hi(c')||^2, the rounding residual the coarse bound needs.
+__global__ __launch_bounds__(256) void centroid_panel16_kernel(
+    const float *__restrict__ centroids, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP,
+    const uint32_t *__restrict__ finite, const float *__restrict__ mu, const float *__restrict__ bias,
+    _Float16 *__restrict__ panel16, _Float16 *__restrict__ panelhi, uint32_t K_pad64,
+    uint32_t *__restrict__ stats) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t c = blockIdx.x * 4 + wave;
+  uint32_t res_bits = 0;
+  if (c < K_pad64) {
+    const bool real = c < K_pad;
+    const bool ok = c < K && finite[c];
+    float res2 = 0.f;  // ||c' - hi(c')||^2: what the coarse stage's hi.hi products drop on this side
+    for (uint32_t f = lane; f < DP; f += 64) {
+      float v = 0.f;
+      if (ok && f < D) v = centroids[(size_t)c * D + f] - mu[f];
+      const _Float16 hi = (_Float16)v;
+      const float r = v - (float)hi;  // exact: hi keeps the leading 11 bits of v
+      if (real) {
+        panel16[(size_t)c * 2 * DP + f] = hi;
+        panel16[(size_t)c * 2 * DP + DP + f] = (_Float16)r;
+      }
+      if (panelhi) panelhi[(size_t)c * DP + f] = hi;
+      res2 = fmaf(r, r, res2);
+    }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) res2 += __shfl_xor(res2, o);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = res2;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (uint32_t w = 0; w < (blockDim.x + 63) / 64; w++) t += part[w];
-    if ((t - t) == 0.f) atomicMax(&stats[5], __float_as_uint(t * 1.0001f));  // an overflowed half leaves inf - inf
-    else atomicMax(&stats[5], 0x7F800000u);                                   // = "no bound": nothing decided
+    for (int o = 32; o > 0; o >>= 1) res2 += __shfl_xor(res2, o);
+    // an overflowed half leaves inf - inf = NaN: "no bound", the coarse stage decides nothing
+    res_bits = ((res2 - res2) == 0.f) ? __float_as_uint(res2 * 1.0001f) : 0x7F800000u;
+    if (panelhi && lane == 0)
+      reinterpret_cast<float *>(panelhi + (size_t)K_pad64 * DP)[c] = real ? fmaxf(bias[c], -3.0e38f) : -3.0e38f;
   }
+  __shared__ uint32_t part[4];
+  if (lane == 0) part[wave] = res_bits;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(&stats[5], max(max(part[0], part[1]), max(part[2], part[3])));
 }
 
 template <int DP, bool HALF_ROWS, bool FAST>
@@ -477,6 +484,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     f16x8 fr[PD + 1];
 #pragma unroll
     for (int j = 0; j < PD; j++) fr[j] = lds_frag_issue(fb ^ (uint32_t)(j * 16));
+    if (KMX_ABL == 12) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int j = 0; j < KS; j++) {
       if (j + PD < KS && KMX_ABL != 6) fr[(j + PD) % (PD + 1)] = lds_frag_issue(fb ^ (uint32_t)((j + PD) * 16));
@@ -503,9 +511,10 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
         if (slot == 0 && wave == 0) stage_bias(sp_next, buf_next);
       }
     }
+    if (KMX_ABL == 12) __builtin_amdgcn_s_setprio(0);
     const float v1a_in = v1a, v1b_in = v1b;
 #pragma unroll
-    for (int r = 0; r < ((KMX_ABL == 1 || KMX_ABL >= 5) ? 1 : 16); r++) {
+    for (int r = 0; r < ((KMX_ABL == 1 || (KMX_ABL >= 5 && KMX_ABL <= 11)) ? 1 : 16); r++) {
       book(accA[r], r, v1a, v2a);
       book(accB[r], r, v1b, v2b);
     }
@@ -515,11 +524,11 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
 
   for (uint32_t sp = 0; sp < (KMX_ABL == 10 ? 1u : nsuper); sp++) {  // ABL 10: prologue + one super-tile
     const int buf = sp & 1;
-    const bool stage = sp + 1 < nsuper && KMX_ABL != 2 && KMX_ABL < 5 && KMX_ABL != 7;  // ABL 7: barrier without DMA
+    const bool stage = sp + 1 < nsuper && !(KMX_ABL == 2 || KMX_ABL == 5 || KMX_ABL == 6 || KMX_ABL == 7);  // ABL 7: barrier without DMA
     const uint32_t base = buf * SUPB, bb = bias0 + buf * 256;
     tile_pass(base, bb, 2 * sp, stage, sp + 1, buf ^ 1);
     tile_pass(base + 32 * ROWB, bb + 128, 2 * sp + 1, false, sp + 1, buf ^ 1);
-    if (KMX_ABL != 2 && KMX_ABL != 3 && KMX_ABL < 5) {
+    if (!(KMX_ABL == 2 || KMX_ABL == 3 || KMX_ABL == 5 || KMX_ABL == 6)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
@@ -594,25 +603,13 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   }
 }
 
-// c' = c - mu, hi halves only: panelhi[c] = hi(c'_0..DP-1)
-__global__ void centroid_panelhi_kernel(const _Float16 *__restrict__ panel16, const float *__restrict__ bias,
-                                        uint32_t K_pad, uint32_t DP, _Float16 *__restrict__ panelhi) {
-  // grid = K_pad rounded up to 64 rows (the second-generation kernel stages whole 64-row super-tiles);
-  // behind the rows: the biases with -inf (padding / non-finite centroids) clamped to a finite floor
-  const uint32_t c = blockIdx.x;
-  for (uint32_t f = threadIdx.x; f < DP; f += blockDim.x)
-    panelhi[(size_t)c * DP + f] = c < K_pad ? panel16[(size_t)c * 2 * DP + f] : (_Float16)0.f;
-  if (threadIdx.x == 0) {
-    float *biashi = reinterpret_cast<float *>(panelhi + (size_t)gridDim.x * DP);
-    biashi[c] = c < K_pad ? fmaxf(bias[c], -3.0e38f) : -3.0e38f;
-  }
-}
-
 hipError_t launch_centroid_panel16(const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP,
-                                   const uint32_t *finite, const float *mu, void *panel16, uint32_t *stats,
-                                   hipStream_t st) {
-  hipLaunchKernelGGL(centroid_panel16_kernel, dim3(K_pad), dim3(DP >= 256 ? 256 : 64), 0, st, centroids, K, D, K_pad,
-                     DP, finite, mu, reinterpret_cast<_Float16 *>(panel16), stats);
+                                   const uint32_t *finite, const float *mu, const float *bias, void *panel16,
+                                   void *panelhi, uint32_t *stats, hipStream_t st) {
+  const uint32_t K_pad64 = (K_pad + 63u) / 64u * 64u;
+  hipLaunchKernelGGL(centroid_panel16_kernel, dim3(K_pad64 / 4), dim3(256), 0, st, centroids, K, D, K_pad, DP, finite,
+                     mu, bias, reinterpret_cast<_Float16 *>(panel16), reinterpret_cast<_Float16 *>(panelhi), K_pad64,
+                     stats);
   return hipGetLastError();
 }
 
@@ -673,10 +670,7 @@ static hipError_t launch_coarse2_dp(const LloydArgs &a, const void *rows, bool h
 }
 
 hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
-                               const float *xmeta, const void *panel16, void *panelhi, uint32_t *undecided,
-                               hipStream_t st) {
-  hipLaunchKernelGGL(centroid_panelhi_kernel, dim3((a.K_pad + 63u) / 64u * 64u), dim3(a.DP >= 256 ? 256 : 64), 0, st,
-                     reinterpret_cast<const _Float16 *>(panel16), a.bias, a.K_pad, a.DP, reinterpret_cast<_Float16 *>(panelhi));
+                               const float *xmeta, const void *panelhi, uint32_t *undecided, hipStream_t st) {
   switch (a.DP) {
     case 16: return launch_coarse2_dp<16>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, st);
     case 32: return launch_coarse2_dp<32>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, st);
