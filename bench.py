@@ -24,11 +24,11 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 def pmc_traffic(rows_per_launch, filt="f32"):
     """HBM bytes per launch of the filter stage, from the committed rocprofv3 PMC passes
     (profiles/*_pmc_summary.json written by scripts/gpu_pmc_all.sh: FETCH_SIZE doubled per the gfx950
-    note in MI355X_MICROARCH.md, plus WRITE_SIZE), scaled by rows when the shard size differs.  The
-    two-stage default sums its two kernels.  PMC counters cannot be collected from inside the bench
+    note in MI355X_MICROARCH.md, plus WRITE_SIZE), scaled by rows when the shard size differs.  For the
+    two-stage default: its dominant (coarse) kernel.  PMC counters cannot be collected from inside the bench
     process; None if no matching profile is committed."""
     import glob
-    want = {"f16": ("lloyd_coarse_kernel", "lloyd_filter_f16_kernel"), "f16x3": ("lloyd_filter_f16_kernel",),
+    want = {"f16": ("lloyd_coarse2_kernel",), "f16x3": ("lloyd_filter_f16_kernel",),
             "f32": ("lloyd_filter_kernel",)}[filt]
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
     if files and filt != "f16x3":   # the summaries are taken on the default run: f16x3 never sees all rows there
@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--features", type=int, default=256)
     ap.add_argument("--clusters", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-row-cache", action="store_true",
+                    help="convert the coarse stage's operands from the rows on every pass instead of streaming the "
+                         "engine's centred half copy (kmamd_set_row_cache); assignments are identical")
     ap.add_argument("--filter", default="f16", choices=["f16", "f16x3", "f32"],
                     help="matrix-core scheme of the assignment filter: f16 = two-stage v_mfma_f32_32x32x16_f16 (coarse "
                          "hi.hi pass, then the hi/lo-split pass on the undecided rows; default, fastest), f16x3 = the "
@@ -158,7 +161,7 @@ def main():
     if args.dtype == "f16":
         half = samples.to(torch.float16)
         samples = half.to(torch.float32)
-    backend = HipBackend(samples, K, "L2", device_index=local_rank, half_rows=half)
+    backend = HipBackend(samples, K, "L2", device_index=local_rank, half_rows=half, row_cache=not args.no_row_cache)
     backend.engine.set_filter(args.filter)
     loop = ShardedLloyd(backend, N)
     # init="random": K sample rows of rank 0 (replicated by broadcast)
@@ -206,7 +209,10 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = N / (elapsed / args.steps)
         launches = max(prof["filter_launches"], 1)
-        filter_ms = prof["filter_ms"] / launches
+        filter_ms = prof["filter_ms"] / launches          # both stages of the two-stage filter
+        coarse_ms = prof["coarse_ms"] / launches          # its dominant kernel alone (0 for the other filters)
+        cached = args.filter == "f16" and not args.no_row_cache and os.environ.get("KMCUDA_AMD_ROW_CACHE", "1") != "0"
+        dom_ms = coarse_ms if (args.filter == "f16" and coarse_ms > 0) else filter_ms
         flops = 2.0 * D * K * n_local                      # algorithmic flop of one filter launch
         achieved = flops / (filter_ms * 1e-3) / 1e12 if filter_ms > 0 else 0.0
         f16 = args.dtype == "f16"
@@ -219,14 +225,16 @@ def main():
             pk = {"f32": PEAK_FP32_MFMA_TFLOPS, "f16x3": 2500.0 / 3.0, "f16": 2500.0}[filt]
             ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             return pk, ach
-        peak, achieved = roof(args.filter, filter_ms)
+        peak, achieved = roof(args.filter, dom_ms)
         other_ms = prof_other["filter_ms"] / max(prof_other["filter_launches"], 1)
         opeak, oach = roof(other, other_ms)
         hr = "true" if f16 else "false"
-        kname = {"f16": "lloyd_coarse_kernel<256,%s,true> (+ lloyd_filter_f16_kernel<256,%s,true> on the rows it "
-                        "cannot decide; kernel_ms covers both)" % (hr, hr),
+        kname = {"f16": "lloyd_coarse2_kernel<256,%s,true,%s>" % (("false", "true") if cached else (hr, "false")),
                  "f16x3": "lloyd_filter_f16_kernel<256,%s,true>" % hr,
                  "f32": "lloyd_filter_kernel<256,true>"}
+        # HBM bytes the dominant kernel has to move: the row cache (2 D + 8 bytes per row) or the rows
+        row_bytes = (2 * D + 8) if cached else (D * (2 if f16 else 4))
+        alg_bytes = n_local * (row_bytes + 4)
         out = {
             "metric": "point-assignments/sec per Lloyd iter (8Mx256@1024)",
             "value": value, "unit": "point-assignments/s", "n_gpus": world, "steps": args.steps,
@@ -234,21 +242,26 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%dx%d %s L2 Lloyd iteration, K=%d, uniform[0,1) rows, init=random; "
                                    "rows sharded %d-way" % (N, D, "fp16x2" if f16 else "fp32", K, world),
-                       "samples": N, "features": D, "clusters": K, "parallelism": "rows/%d" % world},
+                       "samples": N, "features": D, "clusters": K, "parallelism": "rows/%d" % world,
+                       "filter": args.filter, "row_cache": bool(cached)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": pmc_traffic(n_local, args.filter) if not f16 else None,
                          "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
-                         "algorithmic_bytes": n_local * (D * (2 if f16 else 4) + 4), "algorithmic_flop": flops,
+                         "algorithmic_bytes": alg_bytes, "algorithmic_flop": flops,
+                         "hbm": {"achieved": alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0, "peak": 8000.0,
+                                 "unit": "GB/s", "frac": alg_bytes / (dom_ms * 1e-3) / 1e9 / 8000.0 if dom_ms > 0 else 0.0},
                          "peak_note": "dense MFMA peak of the instruction the dominant kernel issues, per algorithmic "
                                       "MAC: f32 157.3; f16 (two-stage, coarse pass = one half product per MAC) 2500; "
-                                      "f16x3 (three half products per MAC) 2500/3",
+                                      "f16x3 (three half products per MAC) 2500/3.  The chip runs the f16 kernels "
+                                      "at ~1.7 GHz (power), where the same pipe peaks at ~1770",
                          "kernel": kname[args.filter],
-                         "kernel_ms": filter_ms, "rows_per_launch": n_local},
+                         "kernel_ms": dom_ms, "filter_stage_ms": filter_ms, "rows_per_launch": n_local},
             "roofline_other_filter": {"filter": other, "kernel": kname[other], "kernel_ms": other_ms, "achieved": oach,
                                       "peak": opeak, "unit": "TFLOP/s", "frac": oach / opeak,
                                       "note": "same rows and centroids, timed outside the timed region"},
-            "breakdown_ms_per_step": {"filter": filter_ms, "exact_refine": prof["exact_ms"] / launches,
+            "breakdown_ms_per_step": {"filter": filter_ms, "filter_coarse_kernel": coarse_ms,
+                                      "exact_refine": prof["exact_ms"] / launches,
                                       "update": prof["update_ms"] / launches},
             "rows_full_exact_scan_last_step": flagged, "rows_pair_refined_last_step": pair_rows, "reassigned_last_step": changed_last,
         }

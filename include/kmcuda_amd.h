@@ -120,6 +120,8 @@ int kmamd_transpose(kmamd_engine *e, const float *in, uint32_t rows, uint32_t co
 int kmamd_profile_reset(kmamd_engine *e);
 int kmamd_profile_read(kmamd_engine *e, double *filter_ms, uint32_t *filter_launches,
                        double *exact_ms, double *update_ms);
+/* stage 1 of the two-stage filter on its own (HIP events around that one launch, inside the filter span) */
+int kmamd_profile_read_coarse(kmamd_engine *e, double *coarse_ms);
 int kmamd_profile_enable(kmamd_engine *e, int on);
 
 /* Library identification: returns the gfx arch string this library was compiled for. */

@@ -91,11 +91,13 @@ void Engine::span_begin(int kind) {
   (void)hipEventCreate(&s.b);
   s.kind = kind;
   (void)hipEventRecord(s.a, stream_);
+  open_spans_.push_back(spans_.size());
   spans_.push_back(s);
 }
-void Engine::span_end() {
-  if (!profile_) return;
-  (void)hipEventRecord(spans_.back().b, stream_);
+void Engine::span_end() {  // closes the innermost open span (spans nest: the coarse kernel inside the filter)
+  if (!profile_ || open_spans_.empty()) return;
+  (void)hipEventRecord(spans_[open_spans_.back()].b, stream_);
+  open_spans_.pop_back();
 }
 void Engine::profile_collect() {
   for (auto &s : spans_) {
@@ -104,15 +106,17 @@ void Engine::profile_collect() {
     (void)hipEventElapsedTime(&ms, s.a, s.b);
     if (s.kind == 0) { filter_ms_ += ms; filter_launches_++; }
     else if (s.kind == 1) exact_ms_ += ms;
+    else if (s.kind == 3) coarse_ms_ += ms;
     else update_ms_ += ms;
     (void)hipEventDestroy(s.a);
     (void)hipEventDestroy(s.b);
   }
   spans_.clear();
+  open_spans_.clear();
 }
 void Engine::profile_reset() {
   profile_collect();
-  filter_ms_ = exact_ms_ = update_ms_ = 0;
+  filter_ms_ = exact_ms_ = update_ms_ = coarse_ms_ = 0;
   filter_launches_ = 0;
 }
 
@@ -306,8 +310,10 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
       }
       const bool cached = row_cache_on_ && row_cache_valid_;
       // counters_[4] (the undecided list's length) was zeroed by centroid_prep
+      span_begin(3);  // the dominant kernel on its own, inside the filter span
       KMX_HIP(launch_lloyd_coarse(a, rows, half, cached ? xcache_ : nullptr, xmeta_, panelhi_, undecided_, stream_),
               kRuntimeError);
+      span_end();
       KMX_HIP(launch_lloyd_filter_f16(a, rows, half, panel16_, undecided_, counters_ + 4, stream_), kRuntimeError);
     } else {
       KMX_HIP(launch_lloyd_filter_f16(a, rows, half, panel16_, nullptr, nullptr, stream_), kRuntimeError);
@@ -495,6 +501,11 @@ int kmamd_profile_read(kmamd_engine *e, double *filter_ms, uint32_t *filter_laun
   if (filter_launches) *filter_launches = e->e.filter_launches_;
   if (exact_ms) *exact_ms = e->e.exact_ms_;
   if (update_ms) *update_ms = e->e.update_ms_;
+  return kmx::kSuccess;
+}
+int kmamd_profile_read_coarse(kmamd_engine *e, double *coarse_ms) {
+  e->e.profile_collect();
+  if (coarse_ms) *coarse_ms = e->e.coarse_ms_;
   return kmx::kSuccess;
 }
 const char *kmamd_build_arch(void) { return "gfx950"; }

@@ -103,10 +103,11 @@ class Engine {
 
   // profiling of the step kernels with HIP events on stream_
   bool profile_ = false;
-  double filter_ms_ = 0, exact_ms_ = 0, update_ms_ = 0;
+  double filter_ms_ = 0, exact_ms_ = 0, update_ms_ = 0, coarse_ms_ = 0;
   uint32_t filter_launches_ = 0;
   struct Span { hipEvent_t a, b; int kind; };
   std::vector<Span> spans_;
+  std::vector<size_t> open_spans_;
   void span_begin(int kind);
   void span_end();
   void profile_collect();

@@ -133,4 +133,7 @@ class Engine:
         f, e, u = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         n = ctypes.c_uint32()
         self.lib.kmamd_profile_read(self.h, ctypes.byref(f), ctypes.byref(n), ctypes.byref(e), ctypes.byref(u))
-        return {"filter_ms": f.value, "filter_launches": n.value, "exact_ms": e.value, "update_ms": u.value}
+        c = ctypes.c_double()
+        self.lib.kmamd_profile_read_coarse(self.h, ctypes.byref(c))
+        return {"filter_ms": f.value, "filter_launches": n.value, "exact_ms": e.value, "update_ms": u.value,
+                "coarse_ms": c.value}
