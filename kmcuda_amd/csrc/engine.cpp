@@ -19,6 +19,12 @@ Engine::~Engine() {
   for (auto &s : spans_) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (void *p : owned_) (void)hipFree(p);
   if (host_counters_) (void)hipHostFree(host_counters_);
+  if (host_move_count_) (void)hipHostFree(host_move_count_);
+  if (side_stream_) {
+    (void)hipStreamDestroy(side_stream_);
+    (void)hipEventDestroy(ev_fork_);
+    (void)hipEventDestroy(ev_join_);
+  }
   if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -68,6 +74,8 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if ((rc = alloc(&keys_sorted_, 2 * (size_t)n_rows))) return rc;
   if ((rc = alloc(&rows_sorted_, 2 * (size_t)n_rows))) return rc;
   if ((rc = alloc(&offsets2_, 2 * (size_t)K + 2))) return rc;
+  if ((rc = alloc(&move_blocks_, (size_t)n_rows / 1024 + 4))) return rc;
+  KMX_HIP(hipHostMalloc(reinterpret_cast<void **>(&host_move_count_), sizeof(uint32_t), hipHostMallocDefault), kMemoryAllocationFailure);
   sort_temp_bytes_ = sort_temp_bytes(2 * (size_t)n_rows, 2 * K);
   {
     const size_t b2 = sort_temp_bytes(n_rows, K);
@@ -323,10 +331,21 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   }
   span_end();
   span_begin(1);
+  // the two refine kernels work on disjoint row lists and are latency bound (one 256-step exact
+  // chain per contender): the full-scan kernel runs on a side stream beside the pair kernel
+  if (!side_stream_) {
+    KMX_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking), kRuntimeError);
+    KMX_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming), kRuntimeError);
+    KMX_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming), kRuntimeError);
+  }
+  KMX_HIP(hipEventRecord(ev_fork_, stream_), kRuntimeError);
+  KMX_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0), kRuntimeError);
+  const uint32_t grid = N_ < 4096u ? N_ : 4096u;  // grid-strides over the device-side flagged count
+  KMX_HIP(launch_lloyd_exact(metric_, a, flagged_, counters_ + 1, grid, side_stream_), kRuntimeError);
+  KMX_HIP(hipEventRecord(ev_join_, side_stream_), kRuntimeError);
   KMX_HIP(launch_lloyd_pair(metric_, a, centroids, (N_ + 127) / 128 < 2048u ? (N_ + 127) / 128 : 2048u, stream_),
           kRuntimeError);
-  const uint32_t grid = N_ < 4096u ? N_ : 4096u;  // grid-strides over the device-side flagged count
-  KMX_HIP(launch_lloyd_exact(metric_, a, flagged_, counters_ + 1, grid, stream_), kRuntimeError);
+  KMX_HIP(hipStreamWaitEvent(stream_, ev_join_, 0), kRuntimeError);
   span_end();
   return kSuccess;
 }
@@ -336,7 +355,8 @@ int Engine::move_deltas(const float *samples, const uint32_t *prev, const uint32
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   span_begin(2);
   KMX_HIP(launch_move_deltas(samples, N_, D_, K_, prev, cur, keys_tmp_, vals_tmp_, keys_sorted_, rows_sorted_,
-                             offsets2_, sort_temp_, sort_temp_bytes_, partial_, delta, dcount, stream_),
+                             offsets2_, sort_temp_, sort_temp_bytes_, partial_, delta, dcount, move_blocks_,
+                             host_move_count_, stream_),
           kRuntimeError);
   span_end();
   return kSuccess;

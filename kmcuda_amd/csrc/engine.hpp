@@ -67,6 +67,8 @@ class Engine {
   int device_ = -1;
   hipStream_t stream_ = nullptr;
   bool own_stream_ = false;
+  hipStream_t side_stream_ = nullptr;   // the full-scan refine kernel beside the pair kernel
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   uint32_t N_ = 0, D_ = 0, K_ = 0, K_pad_ = 0, Kt_ = 0, DP_ = 0;
   int metric_ = 0, fp16x2_ = 0;
   float eps_ = 0, tie_slack_ = 0;
@@ -89,7 +91,8 @@ class Engine {
   uint32_t *stats_ = nullptr, *flagged_ = nullptr, *pairs_ = nullptr, *counters_ = nullptr;
   // update workspace
   uint32_t *keys_tmp_ = nullptr, *vals_tmp_ = nullptr, *keys_sorted_ = nullptr, *rows_sorted_ = nullptr,
-           *offsets2_ = nullptr;
+           *offsets2_ = nullptr, *move_blocks_ = nullptr;
+  uint32_t *host_move_count_ = nullptr;  // pinned: the event count the update's sort is sized by
   void *sort_temp_ = nullptr;
   size_t sort_temp_bytes_ = 0;
   double *partial_ = nullptr;

@@ -10,9 +10,11 @@
 //
 // Reference mechanics (discarded): one thread per centroid scanning all N (assignment, prev)
 // pairs with a serial fp32 Kahan chain.  Here:
-//   move_events      two slots per row: (2*cur, row) if the row moved in, (2*prev+1, row) if it
-//                    moved out, a sentinel key otherwise -- no atomics, so the order is fixed
-//   radix sort       stable, by key -> per (cluster, sign) segments with rows ascending
+//   move events      (2*cur, row) if the row moved in, (2*prev+1, row) if it moved out, COMPACTED in
+//                    row order (count per 1024-row block, scan, write: no atomics, the order is fixed);
+//                    the host reads the event count M -- late iterations move a few percent of the
+//                    rows, and sorting 2N slots that are mostly sentinels cost more than the sums
+//   radix sort       stable, by key, M events -> per (cluster, sign) segments with rows ascending
 //   segment_sums     grid (2K, kSumSplit): fp64 column sums of each segment slice, rows read as
 //                    whole coalesced rows (only MOVED rows are touched: late iterations are cheap)
 //   fold_delta       delta[c] = sum_in - sum_out (fixed order), dcount[c] = n_in - n_out
@@ -83,6 +85,7 @@ hipError_t launch_inverse_assignments(const uint32_t *assignments, uint32_t N, u
 }
 
 // ---- move events --------------------------------------------------------------------------
+// uncompacted form (two slots per row, sentinel keys): the strict-parity update sorts all of them
 __global__ void move_events_kernel(const uint32_t *__restrict__ prev, const uint32_t *__restrict__ cur, uint32_t N,
                                    uint32_t K, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -94,6 +97,109 @@ __global__ void move_events_kernel(const uint32_t *__restrict__ prev, const uint
   keys[2 * (size_t)s + 1] = (moved && p < K) ? 2u * p + 1u : sentinel;
   vals[2 * (size_t)s] = s;
   vals[2 * (size_t)s + 1] = s;
+}
+
+constexpr uint32_t kMoveRows = 1024;  // rows per block of the event compaction (256 threads x 4)
+
+__device__ __forceinline__ void move_flags(const uint32_t *__restrict__ prev, const uint32_t *__restrict__ cur,
+                                           uint32_t s, uint32_t N, uint32_t K, uint32_t &p, uint32_t &a, bool &ein,
+                                           bool &eout) {
+  p = a = 0;
+  ein = eout = false;
+  if (s < N) {
+    p = prev[s];
+    a = cur[s];
+    const bool moved = p != a;
+    ein = moved && a < K;    // joins cluster a
+    eout = moved && p < K;   // leaves cluster p (p >= K: it had no cluster, kmeans.cu:395-403)
+  }
+}
+
+__global__ __launch_bounds__(256) void move_count_kernel(const uint32_t *__restrict__ prev,
+                                                         const uint32_t *__restrict__ cur, uint32_t N, uint32_t K,
+                                                         uint32_t *__restrict__ blockcnt) {
+  uint32_t cnt = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < kMoveRows / 256; i++) {
+    uint32_t p, a;
+    bool ein, eout;
+    move_flags(prev, cur, blockIdx.x * kMoveRows + i * 256 + threadIdx.x, N, K, p, a, ein, eout);
+    cnt += (uint32_t)ein + (uint32_t)eout;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  __shared__ uint32_t w[4];
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) blockcnt[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+}
+
+// counts -> exclusive offsets in place, total -> total[0]; one block (nb = N / 1024 entries)
+__global__ __launch_bounds__(1024) void move_scan_kernel(uint32_t *__restrict__ blockcnt, uint32_t nb,
+                                                         uint32_t *__restrict__ total) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry_s;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nb; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < nb ? blockcnt[i] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(inc, o);
+      if ((int)lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, all = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) {
+      const uint32_t t = wsum[k];
+      if (k < wave) wbase += t;
+      all += t;
+    }
+    const uint32_t carry = carry_s;
+    if (i < nb) blockcnt[i] = carry + wbase + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + all;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) total[0] = carry_s;
+}
+
+// events in row order, per row (in, out): exactly the order the stable sort needs
+__global__ __launch_bounds__(256) void move_write_kernel(const uint32_t *__restrict__ prev,
+                                                         const uint32_t *__restrict__ cur, uint32_t N, uint32_t K,
+                                                         const uint32_t *__restrict__ blockoff,
+                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  __shared__ uint32_t wcnt[4];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t off = blockoff[blockIdx.x];
+#pragma unroll
+  for (uint32_t i = 0; i < kMoveRows / 256; i++) {
+    const uint32_t s = blockIdx.x * kMoveRows + i * 256 + threadIdx.x;
+    uint32_t p, a;
+    bool ein, eout;
+    move_flags(prev, cur, s, N, K, p, a, ein, eout);
+    const unsigned long long min = __ballot(ein), mout = __ballot(eout);
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    const uint32_t rank = (uint32_t)__popcll(min & lower) + (uint32_t)__popcll(mout & lower);
+    if (lane == 0) wcnt[wave] = (uint32_t)__popcll(min) + (uint32_t)__popcll(mout);
+    __syncthreads();
+    uint32_t wbase = 0, all = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      if (k < wave) wbase += wcnt[k];
+      all += wcnt[k];
+    }
+    const size_t at = (size_t)off + wbase + rank;
+    if (ein) { keys[at] = 2u * a; vals[at] = s; }
+    if (eout) { keys[at + (ein ? 1 : 0)] = 2u * p + 1u; vals[at + (ein ? 1 : 0)] = s; }
+    off += all;
+    __syncthreads();
+  }
 }
 
 // grid (2K, kSumSplit); thread t owns features t, t+blockDim, ...
@@ -137,16 +243,30 @@ __global__ void fold_delta_kernel(const double *__restrict__ partial, const uint
 hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint32_t K, const uint32_t *prev,
                               const uint32_t *cur, uint32_t *keys_tmp, uint32_t *vals_tmp, uint32_t *keys_sorted,
                               uint32_t *rows_sorted, uint32_t *offsets2, void *temp, size_t temp_bytes,
-                              double *partial, double *delta, int32_t *dcount, hipStream_t st) {
-  hipLaunchKernelGGL(move_events_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, keys_tmp, vals_tmp);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("move_events: %s\n", hipGetErrorString(e)); return e; }
-  e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t *)keys_tmp, keys_sorted,
-                                           (const uint32_t *)vals_tmp, rows_sorted, 2 * (size_t)N, 0u,
-                                           bits_for(2ull * K), st);
-  if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("radix_sort_pairs(%zu bytes temp): %s\n", temp_bytes, hipGetErrorString(e)); return e; }
-  hipLaunchKernelGGL(offsets_kernel, dim3((2 * K + 1 + 255) / 256), dim3(256), 0, st, keys_sorted, 2 * N, 2 * K,
-                     offsets2);
+                              double *partial, double *delta, int32_t *dcount, uint32_t *blockoff,
+                              uint32_t *host_count, hipStream_t st) {
+  // blockoff: N / 1024 + 2 words (the last one receives the event count); host_count: pinned
+  const uint32_t nb = (N + kMoveRows - 1) / kMoveRows;
+  uint32_t m = 0;
+  hipError_t e = hipSuccess;
+  if (nb) {
+    hipLaunchKernelGGL(move_count_kernel, dim3(nb), dim3(256), 0, st, prev, cur, N, K, blockoff);
+    hipLaunchKernelGGL(move_scan_kernel, dim3(1), dim3(1024), 0, st, blockoff, nb, blockoff + nb + 1);
+    hipLaunchKernelGGL(move_write_kernel, dim3(nb), dim3(256), 0, st, prev, cur, N, K, blockoff, keys_tmp, vals_tmp);
+    e = hipGetLastError();
+    if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("move events: %s\n", hipGetErrorString(e)); return e; }
+    // the one host round trip of the update: the sort below is sized by it
+    e = hipMemcpyAsync(host_count, blockoff + nb + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    m = *host_count;
+  }
+  if (m) {
+    e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t *)keys_tmp, keys_sorted,
+                                  (const uint32_t *)vals_tmp, rows_sorted, (size_t)m, 0u, bits_for(2ull * K), st);
+    if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("radix_sort_pairs(%zu bytes temp): %s\n", temp_bytes, hipGetErrorString(e)); return e; }
+  }
+  hipLaunchKernelGGL(offsets_kernel, dim3((2 * K + 1 + 255) / 256), dim3(256), 0, st, keys_sorted, m, 2 * K, offsets2);
   e = hipGetLastError();
   if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("offsets: %s\n", hipGetErrorString(e)); return e; }
   const uint32_t bs = D >= 256 ? 256 : (D > 64 ? 128 : 64);
