@@ -475,20 +475,37 @@ __global__ __launch_bounds__(256) void lloyd_exact_kernel(
 #pragma unroll
         for (int j = 0; j < CH; j++) in[j] = cbase + 64 * j + lane < Kt;
         uint32_t f = 0;
-        for (; f + 4 <= D; f += 4) {  // 16 loads in flight per lane before the four dependent steps
-          float xf[4], cv[4][CH];
+        // groups of 4 features, the NEXT group's 16 + 4 loads issued before the current group's four
+        // dependent steps: the panel is L2 resident (~1 us away), a row is latency, not throughput
+        auto load_group = [&](uint32_t f0, float (&xf)[4], float (&cv)[4][CH]) {
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            xf[q] = x[f + q];
+            xf[q] = x[f0 + q];
 #pragma unroll
-            for (int j = 0; j < CH; j++) cv[q][j] = in[j] ? cp[(size_t)(f + q) * Kt + 64 * j] : 0.f;
+            for (int j = 0; j < CH; j++) cv[q][j] = in[j] ? cp[(size_t)(f0 + q) * Kt + 64 * j] : 0.f;
           }
+        };
+        auto fold_group = [&](const float (&xf)[4], float (&cv)[4][CH]) {
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             float y[CH];
             fma_rd4(xf[q], cv[q], corr, y);
 #pragma unroll
             for (int j = 0; j < CH; j++) kahan_fold(y[j], acc[j], corr[j]);
+          }
+        };
+        if (D >= 4) {
+          float xa[4], ca[4][CH], xb[4], cb[4][CH];
+          load_group(0, xa, ca);
+          for (; f + 8 <= D; f += 8) {
+            load_group(f + 4, xb, cb);
+            fold_group(xa, ca);
+            if (f + 12 <= D) load_group(f + 8, xa, ca);
+            fold_group(xb, cb);
+          }
+          if (f + 4 <= D) {  // an odd number of groups: the last one is already loaded
+            fold_group(xa, ca);
+            f += 4;
           }
         }
         for (; f < D; f++) {
