@@ -22,8 +22,12 @@ extern "C" {
 typedef struct kmamd_engine kmamd_engine;
 
 /* Creates the per-GPU workspace for n_rows local rows (reference: the allocations of
- * kmcuda.cc:423-470 + kmeans_cuda_setup kmeans.cu:750-772).  hip_stream may be NULL (the
- * engine then creates its own); pass torch's current stream to order with framework work. */
+ * kmcuda.cc:423-470 + kmeans_cuda_setup kmeans.cu:750-772).  hip_stream: the stream every step is
+ * enqueued on -- pass the framework's current stream to order with its work.  NULL: the engine
+ * creates its own non-blocking stream (nothing else may touch its buffers without
+ * kmamd_engine_sync).  (hipStream_t)-1: the caller works on the legacy default stream (handle 0,
+ * torch's default): the engine creates an own BLOCKING stream, which the default stream orders
+ * with implicitly in both directions. */
 int kmamd_engine_create(kmamd_engine **out, int device, uint32_t n_rows, uint32_t features,
                         uint32_t clusters, int metric, int fp16x2, void *hip_stream);
 void kmamd_engine_destroy(kmamd_engine *e);

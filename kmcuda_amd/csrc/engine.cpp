@@ -39,7 +39,13 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return kNoSuchDevice;
   KMX_HIP(hipSetDevice(device), kNoSuchDevice);
   device_ = device;
-  if (stream) {
+  if (stream == (hipStream_t)(intptr_t)-1) {
+    // the caller works on the legacy default (NULL) stream -- torch's default: an own BLOCKING stream
+    // orders with it implicitly in both directions (a non-blocking one would race with that work)
+    KMX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamDefault), kRuntimeError);
+    own_stream_ = true;
+    blocking_stream_ = true;
+  } else if (stream) {
     stream_ = stream;
   } else {
     KMX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), kRuntimeError);
@@ -334,6 +340,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   // the two refine kernels work on disjoint row lists and are latency bound (one 256-step exact
   // chain per contender): the full-scan kernel runs on a side stream beside the pair kernel
   if (!side_stream_) {
+    // (non-blocking even beside a blocking main stream: fork / join events order it completely)
     KMX_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking), kRuntimeError);
     KMX_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming), kRuntimeError);
     KMX_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming), kRuntimeError);

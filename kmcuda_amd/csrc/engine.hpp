@@ -66,7 +66,7 @@ class Engine {
 
   int device_ = -1;
   hipStream_t stream_ = nullptr;
-  bool own_stream_ = false;
+  bool own_stream_ = false, blocking_stream_ = false;
   hipStream_t side_stream_ = nullptr;   // the full-scan refine kernel beside the pair kernel
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   uint32_t N_ = 0, D_ = 0, K_ = 0, K_pad_ = 0, Kt_ = 0, DP_ = 0;

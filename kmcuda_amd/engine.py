@@ -29,7 +29,11 @@ class Engine:
         self.device = torch.device("cuda", device)
         stream = None
         if use_torch_stream:
-            stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            # torch's default stream is the legacy NULL stream (handle 0): ask for an own BLOCKING
+            # stream then (-1), which orders with it implicitly; a NULL argument would mean an own
+            # NON-blocking stream, racing with every torch op (copies, NCCL) on these buffers
+            handle = torch.cuda.current_stream(self.device).cuda_stream
+            stream = ctypes.c_void_p(handle if handle else ctypes.c_void_p(-1).value)
         h = ctypes.c_void_p()
         rc = self.lib.kmamd_engine_create(ctypes.byref(h), device, self.n_rows, self.features, self.clusters,
                                           self.metric, 0, stream)

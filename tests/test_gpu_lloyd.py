@@ -184,3 +184,30 @@ def test_config_a_100k_256_1024(filt):
     assert (got == ref).all()
     assert counters[0] == changed == 100000
     assert counters[1] + counters[3] < 20000  # the filter decides the bulk of the rows
+
+
+def test_orders_with_torch_default_stream():
+    """Engine steps and torch ops on the same buffers without any explicit synchronisation: torch's
+    default stream is the legacy NULL stream, the engine's own stream must order with it (it once was a
+    non-blocking stream: .cpu() read assignments the kernels had not written yet, and an NCCL
+    all-reduce would have read the deltas early)."""
+    from kmcuda_amd.engine import Engine
+    dev = _dev()
+    rs = numpy.random.RandomState(77)
+    n, d, k = 200000, 256, 1024
+    x = rs.rand(n, d).astype(numpy.float32)
+    xs = torch.from_numpy(x).to(dev)
+    eng = Engine(n, d, k, "L2", device=0)
+    asg = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    prev = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    cbuf = torch.empty((k, d), dtype=torch.float32, device=dev)
+    ref_asg = None
+    for it in range(4):
+        c = x[rs.choice(n, k, replace=False)].copy()
+        cbuf.copy_(torch.from_numpy(c))          # torch op, then the engine reads cbuf
+        eng.lloyd_assign(xs, cbuf, asg, prev)
+        got = asg.cpu().numpy().view(numpy.uint32).copy()   # torch op right behind the engine's kernels
+        ref, _, _ = oracle.lloyd_assign(x, c, assignments=ref_asg)
+        assert (got == ref).all(), "pass %d" % it
+        ref_asg = ref
+    eng.close()
