@@ -1014,6 +1014,10 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
   auto devs = setup_devices(device, verbosity);
   if (devs.empty()) return kmcudaNoSuchDevice;
 
+  // device-pointer inputs: whatever the caller still has in flight on that GPU (any stream) must have
+  // landed before our own non-blocking streams read it -- the reference got this from the legacy
+  // default stream's implicit synchronisation
+  if (device_ptrs >= 0 && hipSetDevice(device_ptrs) == hipSuccess) (void)hipDeviceSynchronize();
   Job job;
   job.fp16 = fp16x2 != 0;
   // fp16x2: features_size counts half2 pairs (kmcuda.h:107-108); internally one feature per half
@@ -1063,6 +1067,7 @@ KMCUDAResult knn_cuda(uint16_t k, KMCUDADistanceMetric metric, uint32_t samples_
   if (!samples || !centroids || !assignments || !neighbors) return kmcudaInvalidArguments;
   auto devs = setup_devices(device, verbosity);
   if (devs.empty()) return kmcudaNoSuchDevice;
+  if (device_ptrs >= 0 && hipSetDevice(device_ptrs) == hipSuccess) (void)hipDeviceSynchronize();  // as kmeans_cuda
   KnnJob job;
   const uint32_t feats = fp16x2 ? 2u * features_size : features_size;  // kmcuda.h:107-108
   RETERR(job.run(devs, virtual_shards(), k, metric, samples_size, feats, clusters_size, device_ptrs, verbosity,
