@@ -81,7 +81,9 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if ((rc = alloc(&rows_sorted_, 2 * (size_t)n_rows))) return rc;
   if ((rc = alloc(&offsets2_, 2 * (size_t)K + 2))) return rc;
   if ((rc = alloc(&move_blocks_, (size_t)n_rows / 1024 + 4))) return rc;
-  KMX_HIP(hipHostMalloc(reinterpret_cast<void **>(&host_move_count_), sizeof(uint32_t), hipHostMallocDefault), kMemoryAllocationFailure);
+  if ((rc = alloc(&bucket_work_, move_bucket_words(K)))) return rc;
+  KMX_HIP(hipMemset(bucket_work_, 0, move_bucket_words(K) * sizeof(uint32_t)), kRuntimeError);
+  KMX_HIP(hipHostMalloc(reinterpret_cast<void **>(&host_move_count_), 2 * sizeof(uint32_t), hipHostMallocDefault), kMemoryAllocationFailure);
   sort_temp_bytes_ = sort_temp_bytes(2 * (size_t)n_rows, 2 * K);
   {
     const size_t b2 = sort_temp_bytes(n_rows, K);
@@ -363,7 +365,7 @@ int Engine::move_deltas(const float *samples, const uint32_t *prev, const uint32
   span_begin(2);
   KMX_HIP(launch_move_deltas(samples, N_, D_, K_, prev, cur, keys_tmp_, vals_tmp_, keys_sorted_, rows_sorted_,
                              offsets2_, sort_temp_, sort_temp_bytes_, partial_, delta, dcount, move_blocks_,
-                             host_move_count_, stream_),
+                             bucket_work_, host_move_count_, stream_),
           kRuntimeError);
   span_end();
   return kSuccess;

@@ -58,6 +58,8 @@ hipError_t launch_row_cache(const void *rows, bool half_rows, uint32_t N, uint32
 // update.hip -- centroid update (reference: kmeans.cu:366-429 kmeans_adjust)
 constexpr uint32_t kSumSplit = 8;
 size_t sort_temp_bytes(size_t n, uint32_t max_key);
+uint32_t move_bucket_stride(uint32_t K);
+size_t move_bucket_words(uint32_t K);   // launch_move_deltas' bucket_work, zero-initialised by the owner
 hipError_t launch_inverse_assignments(const uint32_t *assignments, uint32_t N, uint32_t K, uint32_t *keys_tmp,
                                       uint32_t *vals_tmp, uint32_t *keys_sorted, uint32_t *inv,
                                       uint32_t *offsets, void *temp, size_t temp_bytes, hipStream_t st);
@@ -65,7 +67,7 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
                               const uint32_t *cur, uint32_t *keys_tmp, uint32_t *vals_tmp, uint32_t *keys_sorted,
                               uint32_t *rows_sorted, uint32_t *offsets2, void *temp, size_t temp_bytes,
                               double *partial, double *delta, int32_t *dcount, uint32_t *blockoff,
-                              uint32_t *host_count, hipStream_t st);
+                              uint32_t *bucket_work, uint32_t *host_count, hipStream_t st);
 hipError_t launch_adjust_exact(int metric, const float *samples, uint32_t N, uint32_t D, uint32_t K,
                                const uint32_t *prev, const uint32_t *cur, uint32_t *keys_tmp, uint32_t *vals_tmp,
                                uint32_t *keys_sorted, uint32_t *rows_sorted, uint32_t *offsets2, void *temp,

@@ -10,11 +10,15 @@
 //
 // Reference mechanics (discarded): one thread per centroid scanning all N (assignment, prev)
 // pairs with a serial fp32 Kahan chain.  Here:
-//   move events      (2*cur, row) if the row moved in, (2*prev+1, row) if it moved out, COMPACTED in
-//                    row order (count per 1024-row block, scan, write: no atomics, the order is fixed);
-//                    the host reads the event count M -- late iterations move a few percent of the
-//                    rows, and sorting 2N slots that are mostly sentinels cost more than the sums
-//   radix sort       stable, by key, M events -> per (cluster, sign) segments with rows ascending
+//   move events      key 2*cur if the row moved in, 2*prev+1 if it moved out.  Late iterations move a
+//                    few percent of the rows, so nothing here is sized by N except one read of
+//                    (prev, cur): histogram of the keys (integer atomics: exact) -> scan -> the host
+//                    reads (event count, largest bucket), then either
+//     buckets        (largest bucket <= 8192) rows scattered to their key's bucket through atomic
+//                    cursors, each bucket sorted ascending in LDS: the set is exact, the order fixed
+//     radix sort     (else) events compacted in row order (count per 1024-row block, scan, write)
+//                    and sorted stably by key (rocprim)
+//                    -- both give per (cluster, sign) segments with rows ascending, bit-identical sums
 //   segment_sums     grid (2K, kSumSplit): fp64 column sums of each segment slice, rows read as
 //                    whole coalesced rows (only MOVED rows are touched: late iterations are cheap)
 //   fold_delta       delta[c] = sum_in - sum_out (fixed order), dcount[c] = n_in - n_out
@@ -240,35 +244,165 @@ __global__ void fold_delta_kernel(const double *__restrict__ partial, const uint
     dcount[c] = (int32_t)(offsets[2 * c + 1] - offsets[2 * c]) - (int32_t)(offsets[2 * c + 2] - offsets[2 * c + 1]);
 }
 
+// ---- bucket path: histogram / scan / scatter / per-bucket LDS sort ----------------------------
+// counters one cache line apart while that stays under ~1 MB per array
+uint32_t move_bucket_stride(uint32_t K) {
+  uint32_t s = 32;
+  while (s > 1 && 2ull * K * s > 262144ull) s >>= 1;
+  return s;
+}
+size_t move_bucket_words(uint32_t K) { return 4 * (size_t)K * move_bucket_stride(K) + 4; }
+
+__global__ __launch_bounds__(256) void move_hist_kernel(const uint32_t *__restrict__ prev,
+                                                        const uint32_t *__restrict__ cur, uint32_t N, uint32_t K,
+                                                        uint32_t *__restrict__ hist, uint32_t stride) {
+  // counters `stride` words apart: packed, the 2K counters of K = 1024 share 64 cache lines and the
+  // L2 serialises the atomics per line (measured 118 us for 6e5 events; one line each: ~20 us)
+  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+  uint32_t p, a;
+  bool ein, eout;
+  move_flags(prev, cur, s, N, K, p, a, ein, eout);
+  if (ein) atomicAdd(&hist[(size_t)(2u * a) * stride], 1u);
+  if (eout) atomicAdd(&hist[(size_t)(2u * p + 1u) * stride], 1u);
+}
+
+// hist[0..nkeys) -> offsets[0..nkeys] (exclusive), cursors = offsets, hist zeroed for the next call;
+// out[0] = events, out[1] = largest bucket.  One block.
+__global__ __launch_bounds__(1024) void move_bucket_scan_kernel(uint32_t *__restrict__ hist, uint32_t nkeys,
+                                                                uint32_t stride, uint32_t *__restrict__ offsets,
+                                                                uint32_t *__restrict__ cursors,
+                                                                uint32_t *__restrict__ out) {
+  __shared__ uint32_t wsum[16], wmax[16];
+  __shared__ uint32_t carry_s, max_s;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) { carry_s = 0; max_s = 0; }
+  __syncthreads();
+  for (uint32_t base = 0; base < nkeys; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < nkeys ? hist[(size_t)i * stride] : 0u;
+    if (i < nkeys) hist[(size_t)i * stride] = 0u;
+    uint32_t inc = v, mx = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(inc, o);
+      if ((int)lane >= o) inc += t;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    if (lane == 63) wsum[wave] = inc;
+    if (lane == 0) wmax[wave] = mx;
+    __syncthreads();
+    uint32_t wbase = 0, all = 0, m = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) {
+      const uint32_t t = wsum[k];
+      if (k < wave) wbase += t;
+      all += t;
+      m = max(m, wmax[k]);
+    }
+    const uint32_t carry = carry_s;
+    if (i < nkeys) {
+      const uint32_t ex = carry + wbase + inc - v;
+      offsets[i] = ex;
+      cursors[(size_t)i * stride] = ex;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { carry_s = carry + all; max_s = max(max_s, m); }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    offsets[nkeys] = carry_s;
+    out[0] = carry_s;
+    out[1] = max_s;
+  }
+}
+
+__global__ __launch_bounds__(256) void move_scatter_kernel(const uint32_t *__restrict__ prev,
+                                                           const uint32_t *__restrict__ cur, uint32_t N, uint32_t K,
+                                                           uint32_t *__restrict__ cursors, uint32_t stride,
+                                                           uint32_t *__restrict__ rows_out) {
+  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+  uint32_t p, a;
+  bool ein, eout;
+  move_flags(prev, cur, s, N, K, p, a, ein, eout);
+  if (ein) rows_out[atomicAdd(&cursors[(size_t)(2u * a) * stride], 1u)] = s;
+  if (eout) rows_out[atomicAdd(&cursors[(size_t)(2u * p + 1u) * stride], 1u)] = s;
+}
+
+// one block per bucket: ascending row order (bitonic in LDS; the scatter order above is arbitrary)
+constexpr uint32_t kBucketCap = 8192;
+__global__ __launch_bounds__(256) void bucket_sort_kernel(const uint32_t *__restrict__ offsets,
+                                                          uint32_t *__restrict__ rows) {
+  __shared__ uint32_t v[kBucketCap];
+  const uint32_t beg = offsets[blockIdx.x], n = offsets[blockIdx.x + 1] - beg;
+  if (n < 2) return;
+  uint32_t m = 2;
+  while (m < n) m <<= 1;
+  for (uint32_t i = threadIdx.x; i < m; i += 256) v[i] = i < n ? rows[beg + i] : 0xFFFFFFFFu;
+  __syncthreads();
+  for (uint32_t k = 2; k <= m; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = threadIdx.x; i < m; i += 256) {
+        const uint32_t l = i ^ j;
+        if (l > i) {
+          const uint32_t a = v[i], b = v[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) { v[i] = b; v[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t i = threadIdx.x; i < n; i += 256) rows[beg + i] = v[i];
+}
+
 hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint32_t K, const uint32_t *prev,
                               const uint32_t *cur, uint32_t *keys_tmp, uint32_t *vals_tmp, uint32_t *keys_sorted,
                               uint32_t *rows_sorted, uint32_t *offsets2, void *temp, size_t temp_bytes,
                               double *partial, double *delta, int32_t *dcount, uint32_t *blockoff,
-                              uint32_t *host_count, hipStream_t st) {
-  // blockoff: N / 1024 + 2 words (the last one receives the event count); host_count: pinned
-  const uint32_t nb = (N + kMoveRows - 1) / kMoveRows;
-  uint32_t m = 0;
+                              uint32_t *bucket_work, uint32_t *host_count, hipStream_t st) {
+  // blockoff: N / 1024 + 2 words; bucket_work: move_bucket_words(K) words = histogram | cursors (both
+  // 2 K counters, move_bucket_stride(K) words apart) | 2 results; the histogram is zero on entry (engine:
+  // zeroed at creation, left zero by the scan); host_count: 2 pinned words
+  const uint32_t stride = move_bucket_stride(K);
+  uint32_t *hist = bucket_work, *cursors = bucket_work + 2 * (size_t)K * stride,
+           *res = bucket_work + 4 * (size_t)K * stride;
   hipError_t e = hipSuccess;
-  if (nb) {
+  uint32_t m = 0, maxb = 0;
+  if (N) {
+    hipLaunchKernelGGL(move_hist_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, hist, stride);
+    hipLaunchKernelGGL(move_bucket_scan_kernel, dim3(1), dim3(1024), 0, st, hist, 2 * K, stride, offsets2, cursors, res);
+    e = hipGetLastError();
+    if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("move events: %s\n", hipGetErrorString(e)); return e; }
+    // the one host round trip of the update: which path, and (radix path) the sort's size
+    e = hipMemcpyAsync(host_count, res, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    m = host_count[0];
+    maxb = host_count[1];
+  } else {
+    e = hipMemsetAsync(offsets2, 0, (2 * (size_t)K + 1) * sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+  }
+  const bool force_radix = getenv("KMCUDA_AMD_UPDATE_RADIX") != nullptr;  // A/B and tests
+  if (m && maxb <= kBucketCap && !force_radix) {
+    hipLaunchKernelGGL(move_scatter_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, cursors,
+                       stride, rows_sorted);
+    hipLaunchKernelGGL(bucket_sort_kernel, dim3(2 * K), dim3(256), 0, st, offsets2, rows_sorted);
+    e = hipGetLastError();
+    if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("bucket path: %s\n", hipGetErrorString(e)); return e; }
+  } else if (m) {
+    const uint32_t nb = (N + kMoveRows - 1) / kMoveRows;
     hipLaunchKernelGGL(move_count_kernel, dim3(nb), dim3(256), 0, st, prev, cur, N, K, blockoff);
     hipLaunchKernelGGL(move_scan_kernel, dim3(1), dim3(1024), 0, st, blockoff, nb, blockoff + nb + 1);
     hipLaunchKernelGGL(move_write_kernel, dim3(nb), dim3(256), 0, st, prev, cur, N, K, blockoff, keys_tmp, vals_tmp);
     e = hipGetLastError();
     if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("move events: %s\n", hipGetErrorString(e)); return e; }
-    // the one host round trip of the update: the sort below is sized by it
-    e = hipMemcpyAsync(host_count, blockoff + nb + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) return e;
-    m = *host_count;
-  }
-  if (m) {
     e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t *)keys_tmp, keys_sorted,
                                   (const uint32_t *)vals_tmp, rows_sorted, (size_t)m, 0u, bits_for(2ull * K), st);
     if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("radix_sort_pairs(%zu bytes temp): %s\n", temp_bytes, hipGetErrorString(e)); return e; }
   }
-  hipLaunchKernelGGL(offsets_kernel, dim3((2 * K + 1 + 255) / 256), dim3(256), 0, st, keys_sorted, m, 2 * K, offsets2);
-  e = hipGetLastError();
-  if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("offsets: %s\n", hipGetErrorString(e)); return e; }
+  // offsets2 (segment starts per key) came out of the histogram scan in both paths
   const uint32_t bs = D >= 256 ? 256 : (D > 64 ? 128 : 64);
   hipLaunchKernelGGL(segment_sums_kernel, dim3(2 * K, kSumSplit), dim3(bs), 0, st, samples, D, rows_sorted, offsets2,
                      partial);

@@ -201,3 +201,24 @@ def test_256d_uniform_matches_oracle():
     # trajectories of an unstructured data set are chaotic in the low bits of the centroids: the
     # bit-for-bit end-to-end comparison is test_gpu_exact_update.py (strict-parity update mode)
     numpy.testing.assert_allclose(cen, ocen, atol=0.05)
+
+
+@pytest.mark.parametrize("k", [3, 64, 1024])
+def test_update_paths_bit_identical(monkeypatch, k):
+    """The centroid update sorts the move events by (cluster, sign) either in per-key buckets (LDS sort,
+    when no bucket exceeds 8192 rows) or with a stable radix sort: both give rows ascending per
+    segment, so whole runs must agree bit for bit -- including k = 3, whose first buckets are far
+    beyond the bucket path's capacity and take the radix path either way."""
+    from kmcuda_amd import kmeans_cuda
+    rs = numpy.random.RandomState(k)
+    x = rs.rand(40000, 32).astype(numpy.float32)
+    res = []
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("KMCUDA_AMD_UPDATE_RADIX", "1")
+        else:
+            monkeypatch.delenv("KMCUDA_AMD_UPDATE_RADIX", raising=False)
+        c, a = kmeans_cuda(x, k, tolerance=0.001, init="random", seed=3, yinyang_t=0, verbosity=0)
+        res.append((c.copy(), a.copy()))
+    assert (res[0][1] == res[1][1]).all()
+    assert numpy.array_equal(res[0][0], res[1][0], equal_nan=True)
