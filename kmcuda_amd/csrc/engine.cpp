@@ -33,6 +33,7 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if (const char *f = getenv("KMCUDA_AMD_FILTER"))
     filter_mode_ = strcmp(f, "f32") == 0 ? 1 : (strcmp(f, "f16x3") == 0 ? 2 : 0);
   if (const char *c = getenv("KMCUDA_AMD_ROW_CACHE")) row_cache_allowed_ = atoi(c) != 0;
+  if (const char *r = getenv("KMCUDA_AMD_REFINE")) refine_split_ = strcmp(r, "split") == 0;
   if (D == 0 || K < 1 || K >= 0x7FFFFFFFu) return kInvalidArguments;  // K == 1: Yinyang group clustering with one group
   if (fp16x2) return kInvalidArguments;  // fp16x2 kernels are not built yet ("next")
   int ndev = 0;
@@ -295,6 +296,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
       if (rc) return rc;
       if ((rc = alloc(&phi, (size_t)((K_pad_ + 63u) / 64u * 64u) * (DP_ + 2)))) return rc;  // whole 64-row super-tiles + their biases
       if ((rc = alloc(&undecided_, N_))) return rc;
+      if ((rc = alloc(&und_thr_, N_))) return rc;
       panel16_ = p16;
       panelhi_ = phi;
     }
@@ -327,10 +329,15 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
       const bool cached = row_cache_on_ && row_cache_valid_;
       // counters_[4] (the undecided list's length) was zeroed by centroid_prep
       span_begin(3);  // the dominant kernel on its own, inside the filter span
-      KMX_HIP(launch_lloyd_coarse(a, rows, half, cached ? xcache_ : nullptr, xmeta_, panelhi_, undecided_, stream_),
+      KMX_HIP(launch_lloyd_coarse(a, rows, half, cached ? xcache_ : nullptr, xmeta_, panelhi_, undecided_, und_thr_,
+                                  stream_),
               kRuntimeError);
       span_end();
-      KMX_HIP(launch_lloyd_filter_f16(a, rows, half, panel16_, undecided_, counters_ + 4, stream_), kRuntimeError);
+      if (refine_split_)  // KMCUDA_AMD_REFINE=split: the three-product pass over all K for the undecided rows
+        KMX_HIP(launch_lloyd_filter_f16(a, rows, half, panel16_, undecided_, counters_ + 4, stream_), kRuntimeError);
+      else
+        KMX_HIP(launch_lloyd_refine(a, rows, half, panelhi_, undecided_, und_thr_, counters_ + 4, stream_),
+                kRuntimeError);
     } else {
       KMX_HIP(launch_lloyd_filter_f16(a, rows, half, panel16_, nullptr, nullptr, stream_), kRuntimeError);
     }

@@ -80,6 +80,8 @@ class Engine {
   const void *half_rows_ = nullptr;
   void *panel16_ = nullptr, *panelhi_ = nullptr;
   uint32_t *undecided_ = nullptr;
+  float *und_thr_ = nullptr;      // per undecided row: coarse scores below it are ruled out
+  bool refine_split_ = false;     // KMCUDA_AMD_REFINE=split (A/B, cross-check)
   // 0: two-stage f16 matrix-core filter (hi.hi, then hi/lo split for the undecided rows; default),
   // 1: f32 matrix-core filter (KMCUDA_AMD_FILTER=f32), 2: single-stage hi/lo-split f16 filter (=f16x3)
   int filter_mode_ = 0;

@@ -211,3 +211,28 @@ def test_orders_with_torch_default_stream():
         assert (got == ref).all(), "pass %d" % it
         ref_asg = ref
     eng.close()
+
+
+@pytest.mark.parametrize("refine", ["contenders", "split"])
+def test_stage2_variants_on_a_converged_state(monkeypatch, refine):
+    """Stage 2 of the default filter -- contenders scored in fp32 (default) or the three-product f16
+    pass over all centroids (KMCUDA_AMD_REFINE=split) -- on centroids that have converged onto
+    unstructured data (small best/second gaps: the state that sends most rows past stage 1)."""
+    if refine == "split":
+        monkeypatch.setenv("KMCUDA_AMD_REFINE", "split")
+    else:
+        monkeypatch.delenv("KMCUDA_AMD_REFINE", raising=False)
+    rs = numpy.random.RandomState(123)
+    n, d, k = 20000, 256, 300
+    x = rs.rand(n, d).astype(numpy.float32)
+    c = x[rs.choice(n, k, replace=False)].copy()
+    asg = None
+    for _ in range(6):   # a few oracle Lloyd steps: centroids drift toward the data mean
+        asg, _, _ = oracle.lloyd_assign(x, c, assignments=asg)
+        for j in range(k):
+            m = asg == j
+            if m.any():
+                c[j] = x[m].mean(axis=0)
+    got, prev, counters = _assign(x, c, asg0=asg)
+    ref, ref_prev, ref_changed = oracle.lloyd_assign(x, c, assignments=asg)
+    assert (got == ref).all() and (prev == ref_prev).all() and counters[0] == ref_changed
