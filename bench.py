@@ -106,8 +106,8 @@ def sklearn_baseline(features, clusters, rows=100000, iters=6):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--samples", type=int, default=8000000)
     ap.add_argument("--features", type=int, default=256)
     ap.add_argument("--clusters", type=int, default=1024)

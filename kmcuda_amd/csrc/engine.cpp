@@ -372,7 +372,7 @@ int Engine::move_deltas(const float *samples, const uint32_t *prev, const uint32
   span_begin(2);
   KMX_HIP(launch_move_deltas(samples, N_, D_, K_, prev, cur, keys_tmp_, vals_tmp_, keys_sorted_, rows_sorted_,
                              offsets2_, sort_temp_, sort_temp_bytes_, partial_, delta, dcount, move_blocks_,
-                             bucket_work_, host_move_count_, stream_),
+                             bucket_work_, host_move_count_, &last_move_events_, stream_),
           kRuntimeError);
   span_end();
   return kSuccess;

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void move_scatter_kernel(const uint32_t *__res
 }
 
 // one block per bucket: ascending row order (bitonic in LDS; the scatter order above is arbitrary)
-constexpr uint32_t kBucketCap = 8192;
+constexpr uint32_t kBucketCap = 1024;   // larger buckets: the radix path (a bitonic pass costs n log^2 n per block)
 __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint32_t *__restrict__ offsets,
                                                           uint32_t *__restrict__ rows) {
   __shared__ uint32_t v[kBucketCap];
@@ -360,7 +360,7 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
                               const uint32_t *cur, uint32_t *keys_tmp, uint32_t *vals_tmp, uint32_t *keys_sorted,
                               uint32_t *rows_sorted, uint32_t *offsets2, void *temp, size_t temp_bytes,
                               double *partial, double *delta, int32_t *dcount, uint32_t *blockoff,
-                              uint32_t *bucket_work, uint32_t *host_count, hipStream_t st) {
+                              uint32_t *bucket_work, uint32_t *host_count, uint32_t *last_events, hipStream_t st) {
   // blockoff: N / 1024 + 2 words; bucket_work: move_bucket_words(K) words = histogram | cursors (both
   // 2 K counters, move_bucket_stride(K) words apart) | 2 results; the histogram is zero on entry (engine:
   // zeroed at creation, left zero by the scan); host_count: 2 pinned words
@@ -369,7 +369,14 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
            *res = bucket_work + 4 * (size_t)K * stride;
   hipError_t e = hipSuccess;
   uint32_t m = 0, maxb = 0;
-  if (N) {
+  const bool force_radix = getenv("KMCUDA_AMD_UPDATE_RADIX") != nullptr;  // A/B and tests
+  // *last_events: the previous call's event count (2 N before the first one).  While most rows still
+  // move (the first iterations) the histogram's atomics alone cost more than the whole radix path
+  const bool direct_radix = force_radix || *last_events > N / 2;
+  if (N == 0) {
+    e = hipMemsetAsync(offsets2, 0, (2 * (size_t)K + 1) * sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+  } else if (!direct_radix) {
     hipLaunchKernelGGL(move_hist_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, hist, stride);
     hipLaunchKernelGGL(move_bucket_scan_kernel, dim3(1), dim3(1024), 0, st, hist, 2 * K, stride, offsets2, cursors, res);
     e = hipGetLastError();
@@ -380,28 +387,38 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
     if (e != hipSuccess) return e;
     m = host_count[0];
     maxb = host_count[1];
-  } else {
-    e = hipMemsetAsync(offsets2, 0, (2 * (size_t)K + 1) * sizeof(uint32_t), st);
-    if (e != hipSuccess) return e;
   }
-  const bool force_radix = getenv("KMCUDA_AMD_UPDATE_RADIX") != nullptr;  // A/B and tests
-  if (m && maxb <= kBucketCap && !force_radix) {
+  if (N && !direct_radix && m && maxb <= kBucketCap) {
     hipLaunchKernelGGL(move_scatter_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, cursors,
                        stride, rows_sorted);
     hipLaunchKernelGGL(bucket_sort_kernel, dim3(2 * K), dim3(256), 0, st, offsets2, rows_sorted);
     e = hipGetLastError();
     if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("bucket path: %s\n", hipGetErrorString(e)); return e; }
-  } else if (m) {
+  } else if (N && (direct_radix || m)) {
     const uint32_t nb = (N + kMoveRows - 1) / kMoveRows;
     hipLaunchKernelGGL(move_count_kernel, dim3(nb), dim3(256), 0, st, prev, cur, N, K, blockoff);
     hipLaunchKernelGGL(move_scan_kernel, dim3(1), dim3(1024), 0, st, blockoff, nb, blockoff + nb + 1);
     hipLaunchKernelGGL(move_write_kernel, dim3(nb), dim3(256), 0, st, prev, cur, N, K, blockoff, keys_tmp, vals_tmp);
     e = hipGetLastError();
     if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("move events: %s\n", hipGetErrorString(e)); return e; }
-    e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t *)keys_tmp, keys_sorted,
-                                  (const uint32_t *)vals_tmp, rows_sorted, (size_t)m, 0u, bits_for(2ull * K), st);
-    if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("radix_sort_pairs(%zu bytes temp): %s\n", temp_bytes, hipGetErrorString(e)); return e; }
+    if (direct_radix) {   // the event count was not read yet
+      e = hipMemcpyAsync(host_count, blockoff + nb + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e != hipSuccess) return e;
+      m = host_count[0];
+    }
+    if (m) {
+      e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t *)keys_tmp, keys_sorted,
+                                    (const uint32_t *)vals_tmp, rows_sorted, (size_t)m, 0u, bits_for(2ull * K), st);
+      if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("radix_sort_pairs(%zu bytes temp): %s\n", temp_bytes, hipGetErrorString(e)); return e; }
+    }
+    if (direct_radix) {   // no histogram ran: segment starts by binary search in the sorted keys
+      hipLaunchKernelGGL(offsets_kernel, dim3((2 * K + 1 + 255) / 256), dim3(256), 0, st, keys_sorted, m, 2 * K, offsets2);
+      e = hipGetLastError();
+      if (e != hipSuccess) return e;
+    }
   }
+  *last_events = m;
   // offsets2 (segment starts per key) came out of the histogram scan in both paths
   const uint32_t bs = D >= 256 ? 256 : (D > 64 ? 128 : 64);
   hipLaunchKernelGGL(segment_sums_kernel, dim3(2 * K, kSumSplit), dim3(bs), 0, st, samples, D, rows_sorted, offsets2,
