@@ -55,7 +55,7 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   N_ = n_rows; D_ = D; K_ = K; metric_ = metric; fp16x2_ = fp16x2;
   K_pad_ = (K + 31) / 32 * 32;
   Kt_ = (K + 63) / 64 * 64;
-  DP_ = filter_dp_for(D);
+  DP_ = lloyd_dp_for(D);   // > 256: only the two-stage f16 Lloyd filter is instantiated that wide
   // Filter error bound coefficient (DESIGN.md "error bound"): gamma_D + (kappa + 3) u with
   // u = 2^-24, gamma_D <= 1.01 D u, kappa = 8 for the reference's Kahan chain; +2% margin.
   eps_ = (float)(1.02 * ((double)D + 12.0) * ldexp(1.0, -24));
@@ -211,7 +211,7 @@ static void fill_yy_args(Engine &e, YyArgs &a, const float *samples, const float
 int Engine::yy_init(const float *samples, const float *centroids, const uint32_t *assignments, float *bounds) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   if (N_ == 0) return kSuccess;
-  if (DP_ && !yy_exact_) {
+  if (DP_ && DP_ <= 256 && !yy_exact_) {
     int rc = prepare_centroids(centroids);
     if (rc) return rc;
     KMX_HIP(launch_yy_sorted_panel(cfil_, bias_, DP_, pids_, nslots_, pfil_, pbias_, stream_), kRuntimeError);
@@ -245,7 +245,7 @@ int Engine::yy_filters(const float *samples, const float *centroids, const float
   KMX_HIP(launch_yy_global_filter(metric_, samples, N_, D_, K_, G_, centroids, drifts, gdrifts, assignments,
                                   assignments_prev, bounds, passed, counters_, stream_),
           kRuntimeError);
-  if (DP_ && !yy_exact_) {
+  if (DP_ && DP_ <= 256 && !yy_exact_) {
     int rc = prepare_centroids(centroids);
     if (rc) return rc;
     YyArgs a;
@@ -280,7 +280,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   a.assignments = assignments; a.assignments_prev = assignments_prev;
   a.flagged = flagged_; a.pairs = pairs_; a.counters = counters_;
   if (N_ == 0) return kSuccess;
-  if (exact_only || DP_ == 0) {
+  if (exact_only || DP_ == 0 || (DP_ > 256 && filter_mode_ != 0)) {
     span_begin(1);
     const uint32_t grid = N_ < 8192u ? N_ : 8192u;
     KMX_HIP(launch_lloyd_exact(metric_, a, nullptr, nullptr, grid, stream_), kRuntimeError);

@@ -27,6 +27,7 @@ struct LloydArgs {
 };
 
 uint32_t filter_dp_for(uint32_t D);
+uint32_t lloyd_dp_for(uint32_t D);   // + 512 for 256 < D <= 512: two-stage f16 Lloyd filter only
 hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad,
                                 uint32_t DP, uint32_t Kt, float *csqr, float *bias, float *bias2, float *cfil,
                                 float *ct, float *mu, bool freeze_mu, uint32_t *finite, uint32_t *stats, uint32_t *zero_a,

@@ -561,6 +561,10 @@ __global__ __launch_bounds__(256) void lloyd_exact_kernel(
 // ---------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------
+// the Lloyd two-stage f16 filter also has a 512-wide instantiation (one operand set per wave)
+uint32_t filter_dp_for(uint32_t D);
+uint32_t lloyd_dp_for(uint32_t D) { return (D > 256 && D <= 512) ? 512u : filter_dp_for(D); }
+
 uint32_t filter_dp_for(uint32_t D) {
   static const uint32_t sizes[] = {8, 16, 32, 64, 128, 256};
   for (uint32_t v : sizes)

@@ -301,7 +301,9 @@ __device__ __forceinline__ void lds_frag_wait(f16x8 &f) {
 // one 8-wave block per CU run as a ping-pong -- the waves sharing a SIMD, read from HW_ID, alternate
 // MFMA and bookkeeping phases between workgroup barriers; 65 barriers per block made it 20 % slower.)
 // CACHED: the B operands come from the engine's row cache (row_cache_kernel below) instead of the rows.
-template <int DP, bool HALF_ROWS, bool FAST, bool CACHED>
+// NSET: 32-row operand sets per wave -- 2 up to 256 features; 1 for 512 (the halves of 64 rows x 512
+// features would be the whole register file), with each A fragment feeding one MFMA again.
+template <int DP, bool HALF_ROWS, bool FAST, bool CACHED, int NSET>
 __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     const void *__restrict__ rows, const float *__restrict__ xmeta, uint32_t N, uint32_t D, const float *__restrict__ panelhi,
     const float *__restrict__ bias, const float *__restrict__ mu, uint32_t K_pad, uint32_t K,
@@ -323,10 +325,11 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 31, h = lane >> 5;
   constexpr int WV = 4;
-  const uint32_t sA = blockIdx.x * 256u + wave * 64u + col, sB = sA + 32u;
-  const bool liveA = sA < N, liveB = sB < N;
+  constexpr bool TWO = NSET == 2;
+  const uint32_t sA = blockIdx.x * (128u * NSET) + wave * (32u * NSET) + col, sB = sA + 32u;
+  const bool liveA = sA < N, liveB = TWO && sB < N;
 
-  f16x8 xa[KS], xb[KS];
+  f16x8 xa[KS], xb[TWO ? KS : 1];
   float xn2a = 0.f, x0a = 0.f, xn2b = 0.f, x0b = 0.f;
   // both rows of a lane per k-step, sharing the mean chunk.  Lanes without a row read row 0: an MFMA
   // column only feeds its own outputs and theirs are never committed, so nothing is masked.
@@ -371,22 +374,22 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
       // rows = the row cache: per 32-row block KS pieces of 64 lanes x 16 bytes, already centred halves
       // in operand order -> 2 KS fully coalesced 1-KB loads per wave straight into the operand
       // registers, no conversion; the norms wait in xmeta until the decision
-      const f16x8 *c = reinterpret_cast<const f16x8 *>(rows) + ((size_t)blockIdx.x * 8 + wave * 2) * (KS * 64) + lane;
+      const f16x8 *c = reinterpret_cast<const f16x8 *>(rows) + ((size_t)blockIdx.x * (4 * NSET) + wave * NSET) * (KS * 64) + lane;
 #pragma unroll
       for (int j = 0; j < KS; j++) xa[j] = c[j * 64];
 #pragma unroll
-      for (int j = 0; j < KS; j++) xb[j] = c[(KS + j) * 64];
+      for (int j = 0; j < (TWO ? KS : 0); j++) xb[j] = c[(KS + j) * 64];
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       return;
     }
 #pragma unroll
     for (int j0 = 0; j0 < KS; j0 += BJ) {
-      float va[BJ][8], vb[BJ][8];
+      float va[BJ][8], vb[TWO ? BJ : 1][8];
 #pragma unroll
       for (int jj = 0; jj < BJ; jj++) load_chunk(sA, liveA, j0 + jj, va[jj]);
 #pragma unroll
-      for (int jj = 0; jj < BJ; jj++) load_chunk(sB, liveB, j0 + jj, vb[jj]);
+      for (int jj = 0; jj < (TWO ? BJ : 0); jj++) load_chunk(sB, liveB, j0 + jj, vb[jj]);
       __builtin_amdgcn_sched_barrier(0);
       if (j0 == 0) {  // the mean (and super-tile 0) landed, visible to every wave
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -401,9 +404,10 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
         mm[0] = m0.x; mm[1] = m0.y; mm[2] = m0.z; mm[3] = m0.w;
         mm[4] = m1.x; mm[5] = m1.y; mm[6] = m1.z; mm[7] = m1.w;
         centre(va[jj], mm, xa[j], xn2a);
-        centre(vb[jj], mm, xb[j], xn2b);
-        if (j == 0) { x0a = va[0][0]; x0b = vb[0][0]; }
-        asm volatile("" : "+v"(xa[j]), "+v"(xb[j]));  // convert NOW: hipcc parks the fp32 values in scratch otherwise
+        if constexpr (TWO) centre(vb[jj], mm, xb[j], xn2b);
+        if (j == 0) { x0a = va[0][0]; if constexpr (TWO) x0b = vb[0][0]; }
+        asm volatile("" : "+v"(xa[j]));  // convert NOW: hipcc parks the fp32 values in scratch otherwise
+        if constexpr (TWO) asm volatile("" : "+v"(xb[j]));
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
         continue;
       }
       accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, xa[j], accA, 0, 0, 0);
-      accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, xb[j], accB, 0, 0, 0);
+      if constexpr (TWO) accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, xb[j], accB, 0, 0, 0);
       // the next super-tile's LDS-DMA pieces, one at a time in the shadow of the MFMAs: issued
       // back to back the four waves' 32 pieces queue up in the texture path and hold up the wave
       // (all of them during the super-tile's FIRST tile: the second one's 32 MFMAs cover the flight)
@@ -524,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
 #pragma unroll
     for (int r = 0; r < ((KMX_ABL == 1 || (KMX_ABL >= 5 && KMX_ABL <= 11)) ? 1 : 16); r++) {
       book(accA[r], r, v1a, v2a);
-      book(accB[r], r, v1b, v2b);
+      if constexpr (TWO) book(accB[r], r, v1b, v2b);
     }
     tba = (v1a != v1a_in) ? t : tba;
     tbb = (v1b != v1b_in) ? t : tbb;
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   const float cmaxc = sqrtf(__uint_as_float(stats[0])) * 1.000001f;
   const float bmaxc = __uint_as_float(stats[1]);
   const float cmaxo = sqrtf(__uint_as_float(stats[2])) * 1.000001f;
-  const float mu_norm = CACHED ? xmeta[2 * (size_t)gridDim.x * 256] : cmaxo;
+  const float mu_norm = CACHED ? xmeta[2 * (((size_t)N + 255) / 256 * 256)] : cmaxo;
   const float dcmax = sqrtf(__uint_as_float(stats[5])) * 1.000001f;   // max ||c' - hi(c')||; inf = no bound
   const float u = 5.9604645e-8f;
   uint32_t und_count = 0;
@@ -597,14 +601,15 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   };
   float dx2a = -2.f, dx2b = -2.f;   // -2: not measured (no row cache) -> the worst case 2^-11 ||x'||
   if constexpr (CACHED) {
-    const float2 ma = reinterpret_cast<const float2 *>(xmeta)[sA], mb = reinterpret_cast<const float2 *>(xmeta)[sB];
+    const float2 ma = reinterpret_cast<const float2 *>(xmeta)[sA], mb = reinterpret_cast<const float2 *>(xmeta)[TWO ? sB : sA];
     xn2a = ma.x; dx2a = ma.y; xn2b = mb.x; dx2b = mb.y;
     x0a = (ma.y == -1.f) ? __builtin_nanf("") : 0.f;
     x0b = (mb.y == -1.f) ? __builtin_nanf("") : 0.f;
   }
   float cuta, cutb;
   finish(sA, liveA, v1a, v2a, tba, xn2a, x0a, dx2a, unda, uma, cuta);
-  finish(sB, liveB, v1b, v2b, tbb, xn2b, x0b, dx2b, undb, umb, cutb);
+  cutb = 0.f;
+  if constexpr (TWO) finish(sB, liveB, v1b, v2b, tbb, xn2b, x0b, dx2b, undb, umb, cutb);
   if (und_count) {
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&counters[4], und_count);
@@ -672,13 +677,15 @@ template <int DP>
 static hipError_t launch_coarse2_dp(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
                                     const float *xmeta, const void *panelhi, uint32_t *undecided, float *und_thr,
                                     hipStream_t st) {
+  constexpr int NSET = DP <= 256 ? 2 : 1;
   const size_t lds_bytes = 2 * 64 * (size_t)(DP * 2) + 512 + 64 + (size_t)DP * 4;
-  const uint32_t grid = (a.N + 255u) / 256u;
+  const uint32_t rows_per_block = 128u * NSET;
+  const uint32_t grid = (a.N + rows_per_block - 1) / rows_per_block;
   const bool fast = a.D == (uint32_t)DP;
 #define KMX_CRS2_LAUNCH(H, F, C, SRC)                                                                              \
-  hipLaunchKernelGGL((lloyd_coarse2_kernel<DP, H, F, C>), dim3(grid), dim3(256), lds_bytes, st, SRC, xmeta, a.N,    \
-                     a.D, reinterpret_cast<const float *>(panelhi), a.bias, a.mu, a.K_pad, a.K, a.stats, a.eps,      \
-                     a.tie_slack, a.assignments, a.assignments_prev, undecided, und_thr, a.counters)
+  hipLaunchKernelGGL((lloyd_coarse2_kernel<DP, H, F, C, NSET>), dim3(grid), dim3(256), lds_bytes, st, SRC, xmeta,   \
+                     a.N, a.D, reinterpret_cast<const float *>(panelhi), a.bias, a.mu, a.K_pad, a.K, a.stats,       \
+                     a.eps, a.tie_slack, a.assignments, a.assignments_prev, undecided, und_thr, a.counters)
   if (xcache) {
     KMX_CRS2_LAUNCH(false, true, true, xcache);
   } else if (half_rows) {
@@ -699,6 +706,7 @@ hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_r
     case 64: return launch_coarse2_dp<64>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, und_thr, st);
     case 128: return launch_coarse2_dp<128>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, und_thr, st);
     case 256: return launch_coarse2_dp<256>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, und_thr, st);
+    case 512: return launch_coarse2_dp<512>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, und_thr, st);
     default: return hipErrorInvalidValue;
   }
 }
@@ -720,7 +728,7 @@ hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_r
 //      cut-off, operands near the half range) goes to the full exact scan.
 // ---------------------------------------------------------------------------------------
 constexpr int kRefineCap = 8;   // contenders kept per row
-template <int DP, bool HALF_ROWS, bool FAST>
+template <int DP, bool HALF_ROWS, bool FAST, int NSET>
 __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
     const void *__restrict__ rows, const float *__restrict__ samples, uint32_t N, uint32_t D,
     const float *__restrict__ panelhi, const float *__restrict__ cfil, const float *__restrict__ bias,
@@ -735,7 +743,8 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
   constexpr int NP = SUPB / 1024;
   constexpr int SWM = (KS < 16 ? KS : 16) - 1;
   const uint32_t total = *n_list;
-  if (blockIdx.x * 256u >= total) return;   // the grid is sized for N rows, the list is usually 5-10 % of it
+  constexpr bool TWO = NSET == 2;
+  if (blockIdx.x * (128u * NSET) >= total) return;   // the grid is sized for N rows, the list is usually 5-10 % of it
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds2[];
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte *)lds2;
@@ -747,17 +756,17 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
   auto lds_u32 = [](uint32_t addr) { return reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uintptr_t)addr); };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 31, h = lane >> 5;
-  const uint32_t posA = blockIdx.x * 256u + wave * 64u + col, posB = posA + 32u;
-  const bool liveA = posA < total, liveB = posB < total;
+  const uint32_t posA = blockIdx.x * (128u * NSET) + wave * (32u * NSET) + col, posB = posA + 32u;
+  const bool liveA = posA < total, liveB = TWO && posB < total;
   const uint32_t sA = liveA ? row_list[posA] : 0u, sB = liveB ? row_list[posB] : 0u;
   // a lane without a row gets a cut-off nothing reaches; NaN (no usable cut-off) behaves the same and is
   // caught below by "no contender"
   const float cutA = liveA ? thr_list[posA] : INFINITY, cutB = liveB ? thr_list[posB] : INFINITY;
-  const uint32_t rlA = wave * 64u + col, rlB = rlA + 32u;   // row slots of the block's contender lists
+  const uint32_t rlA = wave * (32u * NSET) + col, rlB = rlA + 32u;   // row slots of the block's contender lists
   *lds_u32(cnt_lds + tid * 4) = 0u;
 
   // ---- operands: as lloyd_coarse2_kernel without the row cache (gathered rows) ----
-  f16x8 xa[KS], xb[KS];
+  f16x8 xa[KS], xb[TWO ? KS : 1];
   auto load_chunk = [&](uint32_t s, int j, float (&xv)[8]) {
     const size_t row = (size_t)s;
     if (FAST && HALF_ROWS) {
@@ -807,11 +816,11 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
     constexpr int BJ = KS > 8 ? 8 : KS;
 #pragma unroll
     for (int j0 = 0; j0 < KS; j0 += BJ) {
-      float va[BJ][8], vb[BJ][8];
+      float va[BJ][8], vb[TWO ? BJ : 1][8];
 #pragma unroll
       for (int jj = 0; jj < BJ; jj++) load_chunk(sA, j0 + jj, va[jj]);
 #pragma unroll
-      for (int jj = 0; jj < BJ; jj++) load_chunk(sB, j0 + jj, vb[jj]);
+      for (int jj = 0; jj < (TWO ? BJ : 0); jj++) load_chunk(sB, j0 + jj, vb[jj]);
       __builtin_amdgcn_sched_barrier(0);
       if (j0 == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -823,15 +832,18 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
         const f32x4 m0 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>((uintptr_t)(mu_lds + (h * NKH + 8 * j) * 4));
         const f32x4 m1 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>((uintptr_t)(mu_lds + (h * NKH + 8 * j + 4) * 4));
         const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
-        f16x8 ha, hb;
+        f16x8 ha;
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-          ha[q] = (_Float16)(va[jj][q] - mm[q]);
-          hb[q] = (_Float16)(vb[jj][q] - mm[q]);
-        }
+        for (int q = 0; q < 8; q++) ha[q] = (_Float16)(va[jj][q] - mm[q]);
         xa[j] = ha;
-        xb[j] = hb;
-        asm volatile("" : "+v"(xa[j]), "+v"(xb[j]));
+        asm volatile("" : "+v"(xa[j]));
+        if constexpr (TWO) {
+          f16x8 hb;
+#pragma unroll
+          for (int q = 0; q < 8; q++) hb[q] = (_Float16)(vb[jj][q] - mm[q]);
+          xb[j] = hb;
+          asm volatile("" : "+v"(xb[j]));
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -868,7 +880,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
       else if (behind == 1) lds_frag_wait<1>(f);
       else lds_frag_wait<0>(f);
       accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, xa[j], accA, 0, 0, 0);
-      accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, xb[j], accB, 0, 0, 0);
+      if constexpr (TWO) accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, xb[j], accB, 0, 0, 0);
       constexpr int SPREAD = KS >= 8 ? KS / 8 : 1;
       if (stage && (j % SPREAD) == SPREAD / 2 && j / SPREAD < 8) {
         const int slot = j / SPREAD;
@@ -890,13 +902,13 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
       m2 = __builtin_amdgcn_fmed3f(m2, m3, pinf);
       return __builtin_amdgcn_fmed3f(m0, m2, pinf);
     };
-    const bool hitA = max16(accA) >= cutA, hitB = max16(accB) >= cutB;
+    const bool hitA = max16(accA) >= cutA, hitB = TWO && max16(accB) >= cutB;
     if (__ballot(hitA || hitB)) {
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const uint32_t c = t * 32u + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * h;
         if (accA[r] >= cutA) append(rlA, c);
-        if (accB[r] >= cutB) append(rlB, c);
+        if (TWO && accB[r] >= cutB) append(rlB, c);
       }
     }
   };
@@ -916,14 +928,24 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
   const float cmaxo = sqrtf(__uint_as_float(stats[2])) * 1.000001f;
   const float u = 5.9604645e-8f;
   auto settle = [&](uint32_t s, bool live, uint32_t rl) {
-    // my half of the centred fp32 row (the MFMA operands are dead: their registers hold it now)
-    float xv[NKH];
-    float xn2 = 0.f, xo2 = 0.f;
-    {
-      const float *xr = samples + (size_t)s * D + h * NKH;
-      const float *m = mu + h * NKH;
+    // my half of the centred fp32 row, FC <= 128 features at a time (the MFMA operands are dead: their
+    // registers hold it now), against every contender of the row.  One chunk (DP <= 256): the dot
+    // product of a contender lives in registers; more: its partial sums wait in LDS between chunks.
+    constexpr int FC = NKH < 128 ? NKH : 128, NCHUNK = NKH / FC;
+    const uint32_t part_lds = list_lds + 256 * kRefineCap * 4;   // NCHUNK > 1 only: 256 x 2 x kRefineCap floats
+    float xn2 = 0.f, xo2 = 0.f, x0 = 0.f;
+    float v1 = -INFINITY, v2 = -INFINITY, v3 = -INFINITY;
+    uint32_t i1 = 0xFFFFFFFFu, i2 = 0xFFFFFFFFu;
+    uint32_t n = 0;
+    bool usable = false;
 #pragma unroll
-      for (int f = 0; f < NKH; f += 4) {
+    for (int ch = 0; ch < NCHUNK; ch++) {
+      const int f0 = ch * FC;
+      float xv[FC];
+      const float *xr = samples + (size_t)s * D + h * NKH + f0;
+      const float *m = mu + h * NKH + f0;
+#pragma unroll
+      for (int f = 0; f < FC; f += 4) {
         float x4[4], m4[4];
         if (FAST) {
           const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + f), b = *reinterpret_cast<const f32x4 *>(m + f);
@@ -932,7 +954,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
         } else {
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            const uint32_t ff = h * NKH + f + q;
+            const uint32_t ff = h * NKH + f0 + f + q;
             x4[q] = ff < D ? xr[f + q] : 0.f;
             m4[q] = m[f + q];   // DP floats, zero beyond D
           }
@@ -944,45 +966,53 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
           xn2 = fmaf(xc, xc, xn2);
           xo2 = fmaf(x4[q], x4[q], xo2);
         }
+        if (f == 0 && ch == 0) x0 = x4[0];
+      }
+      // (read here, after the row chunk is in registers: earlier, hipcc spills around the loads)
+      n = *lds_u32(cnt_lds + rl * 4);
+      usable = n >= 1 && n <= (uint32_t)kRefineCap;
+      uint32_t nmax = usable ? n : 0u;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off));
+      for (uint32_t i = 0; i < nmax; i++) {
+        const bool on = usable && i < n;
+        const uint32_t c = on ? *lds_u32(list_lds + (rl * kRefineCap + i) * 4) : 0u;
+        const float *cr = cfil + (size_t)c * DP + h * NKH + f0;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int f = 0; f < FC; f += 4) {
+          const f32x4 c4 = *reinterpret_cast<const f32x4 *>(cr + f);
+          a0 = fmaf(xv[f + 0], c4.x, a0);
+          a1 = fmaf(xv[f + 1], c4.y, a1);
+          a2 = fmaf(xv[f + 2], c4.z, a2);
+          a3 = fmaf(xv[f + 3], c4.w, a3);
+        }
+        float part = (a0 + a1) + (a2 + a3);
+        if constexpr (NCHUNK > 1) {
+          __attribute__((address_space(3))) float *slot =
+              reinterpret_cast<__attribute__((address_space(3))) float *>((uintptr_t)(part_lds + ((rl * 2 + h) * kRefineCap + i) * 4));
+          if (ch > 0) part += *slot;
+          if (ch + 1 < NCHUNK) {
+            *slot = part;   // my own slot: no other lane touches it
+            continue;
+          }
+        }
+        part += __shfl_xor(part, 32);
+        const float v = part + bias[c];
+        if (on) {
+          const bool g1 = v > v1, g2 = v > v2, g3 = v > v3;
+          v3 = g2 ? v2 : (g3 ? v : v3);
+          i2 = g1 ? i1 : (g2 ? c : i2);
+          v2 = g1 ? v1 : (g2 ? v : v2);
+          i1 = g1 ? c : i1;
+          v1 = g1 ? v : v1;
+        }
       }
     }
     xn2 += __shfl_xor(xn2, 32);
     xo2 += __shfl_xor(xo2, 32);
-    float x0 = (h == 0) ? xv[0] + mu[0] : 0.f;   // only its NaN-ness matters (kmeans.cu:312)
-    x0 = __shfl(x0, col);
+    x0 = __shfl(x0, col);   // feature 0 lives in the lower half-wave; only its NaN-ness matters (kmeans.cu:312)
     const bool insane = (x0 != x0);
-    const uint32_t n = *lds_u32(cnt_lds + rl * 4);
-    const bool usable = n >= 1 && n <= (uint32_t)kRefineCap;
-    float v1 = -INFINITY, v2 = -INFINITY, v3 = -INFINITY;
-    uint32_t i1 = 0xFFFFFFFFu, i2 = 0xFFFFFFFFu;
-    uint32_t nmax = usable ? n : 0u;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off));
-    for (uint32_t i = 0; i < nmax; i++) {
-      const bool on = usable && i < n;
-      const uint32_t c = on ? *lds_u32(list_lds + (rl * kRefineCap + i) * 4) : 0u;
-      const float *cr = cfil + (size_t)c * DP + h * NKH;
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-      for (int f = 0; f < NKH; f += 4) {
-        const f32x4 c4 = *reinterpret_cast<const f32x4 *>(cr + f);
-        a0 = fmaf(xv[f + 0], c4.x, a0);
-        a1 = fmaf(xv[f + 1], c4.y, a1);
-        a2 = fmaf(xv[f + 2], c4.z, a2);
-        a3 = fmaf(xv[f + 3], c4.w, a3);
-      }
-      float part = (a0 + a1) + (a2 + a3);
-      part += __shfl_xor(part, 32);
-      const float v = part + bias[c];
-      if (on) {
-        const bool g1 = v > v1, g2 = v > v2, g3 = v > v3;
-        v3 = g2 ? v2 : (g3 ? v : v3);
-        i2 = g1 ? i1 : (g2 ? c : i2);
-        v2 = g1 ? v1 : (g2 ? v : v2);
-        i1 = g1 ? c : i1;
-        v1 = g1 ? v : v1;
-      }
-    }
     const float xn = sqrtf(xn2) * 1.0001f, xo = sqrtf(xo2) * 1.0001f;
     const float e_mfma = 2.0f * eps * (xn * cmaxc + bmaxc);
     const float e_ref = u * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
@@ -1016,21 +1046,24 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
     }
   };
   settle(sA, liveA, rlA);
-  settle(sB, liveB, rlB);
+  if constexpr (TWO) settle(sB, liveB, rlB);
 }
 
 template <int DP>
 static hipError_t launch_refine_dp(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
                                    const uint32_t *row_list, const float *thr_list, const uint32_t *n_list,
                                    hipStream_t st) {
-  const size_t lds_bytes = 2 * 64 * (size_t)(DP * 2) + 512 + 64 + (size_t)DP * 4 + 1024 + 256 * kRefineCap * 4;
-  const uint32_t grid = (a.N + 255u) / 256u;   // blocks beyond the device-side list length leave at once
+  constexpr int NSET = DP <= 256 ? 2 : 1;
+  const size_t lds_bytes = 2 * 64 * (size_t)(DP * 2) + 512 + 64 + (size_t)DP * 4 + 1024 + 256 * kRefineCap * 4 +
+                           (DP > 256 ? 256 * 2 * kRefineCap * 4 : 0);   // partial dot products between feature chunks
+  const uint32_t rows_per_block = 128u * NSET;
+  const uint32_t grid = (a.N + rows_per_block - 1) / rows_per_block;   // blocks beyond the device-side list length leave at once
   const bool fast = a.D == (uint32_t)DP;
 #define KMX_RFN_LAUNCH(H, F)                                                                                       \
-  hipLaunchKernelGGL((lloyd_refine_kernel<DP, H, F>), dim3(grid), dim3(256), lds_bytes, st, rows, a.samples, a.N,   \
-                     a.D, reinterpret_cast<const float *>(panelhi), a.cfil, a.bias, a.mu, a.K_pad, a.K, a.stats,    \
-                     a.eps, a.tie_slack, a.assignments, a.assignments_prev, row_list, thr_list, n_list, a.flagged,  \
-                     a.pairs, a.counters)
+  hipLaunchKernelGGL((lloyd_refine_kernel<DP, H, F, NSET>), dim3(grid), dim3(256), lds_bytes, st, rows, a.samples,  \
+                     a.N, a.D, reinterpret_cast<const float *>(panelhi), a.cfil, a.bias, a.mu, a.K_pad, a.K,        \
+                     a.stats, a.eps, a.tie_slack, a.assignments, a.assignments_prev, row_list, thr_list, n_list,    \
+                     a.flagged, a.pairs, a.counters)
   if (half_rows) {
     if (fast) KMX_RFN_LAUNCH(true, true); else KMX_RFN_LAUNCH(true, false);
   } else {
@@ -1049,6 +1082,7 @@ hipError_t launch_lloyd_refine(const LloydArgs &a, const void *rows, bool half_r
     case 64: return launch_refine_dp<64>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, st);
     case 128: return launch_refine_dp<128>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, st);
     case 256: return launch_refine_dp<256>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, st);
+    case 512: return launch_refine_dp<512>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, st);
     default: return hipErrorInvalidValue;
   }
 }
@@ -1145,6 +1179,7 @@ hipError_t launch_row_cache(const void *rows, bool half_rows, uint32_t N, uint32
     case 64: return launch_row_cache_dp<64>(rows, half_rows, N, D, mu, xcache, xmeta, st);
     case 128: return launch_row_cache_dp<128>(rows, half_rows, N, D, mu, xcache, xmeta, st);
     case 256: return launch_row_cache_dp<256>(rows, half_rows, N, D, mu, xcache, xmeta, st);
+    case 512: return launch_row_cache_dp<512>(rows, half_rows, N, D, mu, xcache, xmeta, st);
     default: return hipErrorInvalidValue;
   }
 }

@@ -38,7 +38,8 @@ def _assign(x, c, metric="L2", exact=False, asg0=None, filt="f16"):
 
 
 @pytest.mark.parametrize("n,d,k", [(3000, 2, 50), (1000, 7, 33), (2500, 16, 100), (2000, 64, 257),
-                                   (4096, 128, 64), (5000, 256, 1024), (777, 300, 40)])
+                                   (4096, 128, 64), (5000, 256, 1024), (777, 300, 40), (3000, 384, 500),
+                                   (2500, 512, 1024), (1500, 600, 64)])
 @pytest.mark.parametrize("mode", ["f16", "f16x3", "f32", "exact"])
 def test_assign_bit_exact(n, d, k, mode):
     """f16: two-stage f16 matrix-core filter (default), f16x3: its hi/lo-split stage alone, f32: f32

@@ -41,7 +41,8 @@ def _run_passes(x, cs, cached, rebuild_at=None):
     return out
 
 
-@pytest.mark.parametrize("n,d,k", [(5000, 256, 1024), (3001, 64, 100), (2000, 16, 33), (4100, 100, 257), (300, 256, 64)])
+@pytest.mark.parametrize("n,d,k", [(5000, 256, 1024), (3001, 64, 100), (2000, 16, 33), (4100, 100, 257), (300, 256, 64),
+                                   (2600, 512, 300), (1900, 300, 70)])
 def test_cached_passes_match_oracle(n, d, k):
     rs = numpy.random.RandomState(n + k)
     x = rs.rand(n, d).astype(numpy.float32)
