@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cmath>
 #include <memory>
+#include <thread>
 #include <vector>
 
 #include "../../include/kmcuda.h"
@@ -96,15 +97,37 @@ std::vector<std::pair<uint32_t, uint32_t>> row_plan(uint32_t N, size_t nshards) 
 
 // sum of `n` floats the way the reference forms it on device (kmeans.cu:63-66, :687-690):
 // float butterfly over each aligned group of 32, then a double accumulation
+static float butterfly_group(const float *v, uint32_t base, uint32_t n) {
+  float lane[32];
+  for (int l = 0; l < 32; l++) lane[l] = (base + l < n) ? v[base + l] : 0.f;
+  for (int off = 16; off > 0; off /= 2)
+    for (int l = 0; l < 32; l++) lane[l] = lane[l] + ((l + off < 32) ? lane[l + off] : lane[l]);
+  return lane[0];
+}
+
 double butterfly_sum(const float *v, uint32_t n) {
-  double sum = 0.0;
-  for (uint32_t base = 0; base < n; base += 32) {
-    float lane[32];
-    for (int l = 0; l < 32; l++) lane[l] = (base + l < n) ? v[base + l] : 0.f;
-    for (int off = 16; off > 0; off /= 2)
-      for (int l = 0; l < 32; l++) lane[l] = lane[l] + ((l + off < 32) ? lane[l + off] : lane[l]);
-    sum += (double)lane[0];
+  const uint32_t groups = (n + 31) / 32;
+  if (groups < 4096) {
+    double sum = 0.0;
+    for (uint32_t g = 0; g < groups; g++) sum += (double)butterfly_group(v, g * 32, n);
+    return sum;
   }
+  // the group sums are independent (threads), the double accumulation keeps its sequential order
+  std::vector<float> gs(groups);
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = nt == 0 ? 4 : (nt > 16 ? 16 : nt);
+  std::vector<std::thread> pool;
+  const uint32_t per = (groups + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; t++) {
+    const uint32_t g0 = t * per, g1 = std::min(groups, g0 + per);
+    if (g0 >= g1) break;
+    pool.emplace_back([&gs, v, n, g0, g1]() {
+      for (uint32_t g = g0; g < g1; g++) gs[g] = butterfly_group(v, g * 32, n);
+    });
+  }
+  for (auto &th : pool) th.join();
+  double sum = 0.0;
+  for (uint32_t g = 0; g < groups; g++) sum += (double)gs[g];
   return sum;
 }
 
@@ -359,7 +382,11 @@ class Job {
         }
         RETERR(copy_sample_to_centroid(first_index, 0));
         INFO("performing kmeans++...\n");
-        std::vector<float> host_dists(N);
+        // pinned: 4 N bytes come back from the GPUs at every one of the K - 1 steps
+        float *host_dists = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void **>(&host_dists), (size_t)N * sizeof(float), hipHostMallocDefault) != hipSuccess)
+          return kmcudaMemoryAllocationFailure;
+        struct HostFree { float *p; ~HostFree() { (void)hipHostFree(p); } } host_dists_guard{host_dists};
         for (uint32_t i = 1; i < K; i++) {
           if (verbosity > 1 || (verbosity > 0 && (K < 100 || i % (K / 100) == 0))) {
             printf("\rstep %d", i);
@@ -370,12 +397,12 @@ class Job {
             if (launch_kmpp_step(metric, s->samples, s->length, D, s->centroids + (size_t)(i - 1) * D, i, s->dists,
                                  s->eng->stream_) != hipSuccess)
               return kmcudaRuntimeError;
-            if (hipMemcpyAsync(host_dists.data() + s->offset, s->dists, (size_t)s->length * sizeof(float),
+            if (hipMemcpyAsync(host_dists + s->offset, s->dists, (size_t)s->length * sizeof(float),
                                hipMemcpyDeviceToHost, s->eng->stream_) != hipSuccess)
               return kmcudaMemoryCopyError;
           }
           RETERR(sync_all());
-          const double dist_sum = butterfly_sum(host_dists.data(), N);
+          const double dist_sum = butterfly_sum(host_dists, N);
           // the reference's chooser, kmcuda.cc:300-326
           const double choice = ((rand() + .0) / RAND_MAX);
           const uint32_t choice_approx = choice * N;
