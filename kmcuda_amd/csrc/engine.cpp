@@ -84,7 +84,7 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if ((rc = alloc(&move_blocks_, (size_t)n_rows / 1024 + 4))) return rc;
   if ((rc = alloc(&bucket_work_, move_bucket_words(K)))) return rc;
   KMX_HIP(hipMemset(bucket_work_, 0, move_bucket_words(K) * sizeof(uint32_t)), kRuntimeError);
-  KMX_HIP(hipHostMalloc(reinterpret_cast<void **>(&host_move_count_), 2 * sizeof(uint32_t), hipHostMallocDefault), kMemoryAllocationFailure);
+  KMX_HIP(hipHostMalloc(reinterpret_cast<void **>(&host_move_count_), 4 * sizeof(uint32_t), hipHostMallocDefault), kMemoryAllocationFailure);
   sort_temp_bytes_ = sort_temp_bytes(2 * (size_t)n_rows, 2 * K);
   {
     const size_t b2 = sort_temp_bytes(n_rows, K);
@@ -336,7 +336,8 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
       if (refine_split_)  // KMCUDA_AMD_REFINE=split: the three-product pass over all K for the undecided rows
         KMX_HIP(launch_lloyd_filter_f16(a, rows, half, panel16_, undecided_, counters_ + 4, stream_), kRuntimeError);
       else
-        KMX_HIP(launch_lloyd_refine(a, rows, half, panelhi_, undecided_, und_thr_, counters_ + 4, stream_),
+        KMX_HIP(launch_lloyd_refine(a, rows, half, panelhi_, undecided_, und_thr_, counters_ + 4, last_undecided_,
+                                    stream_),
                 kRuntimeError);
     } else {
       KMX_HIP(launch_lloyd_filter_f16(a, rows, half, panel16_, nullptr, nullptr, stream_), kRuntimeError);
@@ -370,10 +371,15 @@ int Engine::move_deltas(const float *samples, const uint32_t *prev, const uint32
                         int32_t *dcount) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   span_begin(2);
+  // rides on the update's host round trip: the length of this pass's undecided list sizes the next
+  // pass's stage-2 grid
+  KMX_HIP(hipMemcpyAsync(host_move_count_ + 2, counters_ + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_),
+          kMemoryCopyError);
   KMX_HIP(launch_move_deltas(samples, N_, D_, K_, prev, cur, keys_tmp_, vals_tmp_, keys_sorted_, rows_sorted_,
                              offsets2_, sort_temp_, sort_temp_bytes_, partial_, delta, dcount, move_blocks_,
                              bucket_work_, host_move_count_, &last_move_events_, stream_),
           kRuntimeError);
+  if (N_) last_undecided_ = host_move_count_[2];   // launch_move_deltas synchronised the stream
   span_end();
   return kSuccess;
 }

@@ -94,6 +94,7 @@ class Engine {
   // update workspace
   uint32_t *keys_tmp_ = nullptr, *vals_tmp_ = nullptr, *keys_sorted_ = nullptr, *rows_sorted_ = nullptr,
            *offsets2_ = nullptr, *move_blocks_ = nullptr, *bucket_work_ = nullptr;
+  uint32_t last_undecided_ = 0xFFFFFFFFu;     // previous pass's undecided rows (sizes stage 2's grid)
   uint32_t last_move_events_ = 0xFFFFFFFFu;   // previous update's event count (predicts the cheaper path)
   uint32_t *host_move_count_ = nullptr;  // pinned: the event count the update's sort is sized by
   void *sort_temp_ = nullptr;

@@ -55,7 +55,7 @@ hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_r
 // stage 2 of the default filter: the undecided rows' contenders (coarse score >= und_thr) scored in fp32
 hipError_t launch_lloyd_refine(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
                                const uint32_t *row_list, const float *thr_list, const uint32_t *n_list,
-                               hipStream_t st);
+                               uint32_t rows_hint /* expected list length, 0xFFFFFFFF = unknown */, hipStream_t st);
 // x' = x - mu as halves in the coarse kernel's operand order (N rounded up to 256 rows: DP*2 bytes per
 // row) + (||x'||^2, x_0) per row (8 bytes); valid while mu is unchanged
 hipError_t launch_row_cache(const void *rows, bool half_rows, uint32_t N, uint32_t D, uint32_t DP, const float *mu,

@@ -744,7 +744,6 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
   constexpr int SWM = (KS < 16 ? KS : 16) - 1;
   const uint32_t total = *n_list;
   constexpr bool TWO = NSET == 2;
-  if (blockIdx.x * (128u * NSET) >= total) return;   // the grid is sized for N rows, the list is usually 5-10 % of it
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds2[];
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte *)lds2;
@@ -754,9 +753,11 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
   const uint32_t cnt_lds = mu_lds + DP * 4;          // 256 contender counts
   const uint32_t list_lds = cnt_lds + 1024;          // 256 x kRefineCap centroid indices
   auto lds_u32 = [](uint32_t addr) { return reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uintptr_t)addr); };
+  // the grid follows the previous pass's list length (engine.cpp); a longer list is strided over
+  for (uint32_t blk = blockIdx.x; (size_t)blk * (128u * NSET) < total; blk += gridDim.x) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 31, h = lane >> 5;
-  const uint32_t posA = blockIdx.x * (128u * NSET) + wave * (32u * NSET) + col, posB = posA + 32u;
+  const uint32_t posA = blk * (128u * NSET) + wave * (32u * NSET) + col, posB = posA + 32u;
   const bool liveA = posA < total, liveB = TWO && posB < total;
   const uint32_t sA = liveA ? row_list[posA] : 0u, sB = liveB ? row_list[posB] : 0u;
   // a lane without a row gets a cut-off nothing reaches; NaN (no usable cut-off) behaves the same and is
@@ -1047,17 +1048,25 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
   };
   settle(sA, liveA, rlA);
   if constexpr (TWO) settle(sB, liveB, rlB);
+  __syncthreads();   // the lists and tile buffers are reused by the next group
+  }
 }
 
 template <int DP>
 static hipError_t launch_refine_dp(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
                                    const uint32_t *row_list, const float *thr_list, const uint32_t *n_list,
-                                   hipStream_t st) {
+                                   uint32_t rows_hint, hipStream_t st) {
   constexpr int NSET = DP <= 256 ? 2 : 1;
   const size_t lds_bytes = 2 * 64 * (size_t)(DP * 2) + 512 + 64 + (size_t)DP * 4 + 1024 + 256 * kRefineCap * 4 +
                            (DP > 256 ? 256 * 2 * kRefineCap * 4 : 0);   // partial dot products between feature chunks
   const uint32_t rows_per_block = 128u * NSET;
-  const uint32_t grid = (a.N + rows_per_block - 1) / rows_per_block;   // blocks beyond the device-side list length leave at once
+  // blocks beyond the device-side list length leave at once, but dispatching 31k of them for a list
+  // 2k long is not free: the grid follows the caller's estimate of the list (the kernel strides)
+  uint32_t grid = (a.N + rows_per_block - 1) / rows_per_block;
+  if (rows_hint != 0xFFFFFFFFu) {
+    const uint32_t want = rows_hint / rows_per_block + rows_hint / (4 * rows_per_block) + 64;
+    if (want < grid) grid = want;
+  }
   const bool fast = a.D == (uint32_t)DP;
 #define KMX_RFN_LAUNCH(H, F)                                                                                       \
   hipLaunchKernelGGL((lloyd_refine_kernel<DP, H, F, NSET>), dim3(grid), dim3(256), lds_bytes, st, rows, a.samples,  \
@@ -1075,14 +1084,14 @@ static hipError_t launch_refine_dp(const LloydArgs &a, const void *rows, bool ha
 
 hipError_t launch_lloyd_refine(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
                                const uint32_t *row_list, const float *thr_list, const uint32_t *n_list,
-                               hipStream_t st) {
+                               uint32_t rows_hint, hipStream_t st) {
   switch (a.DP) {
-    case 16: return launch_refine_dp<16>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, st);
-    case 32: return launch_refine_dp<32>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, st);
-    case 64: return launch_refine_dp<64>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, st);
-    case 128: return launch_refine_dp<128>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, st);
-    case 256: return launch_refine_dp<256>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, st);
-    case 512: return launch_refine_dp<512>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, st);
+    case 16: return launch_refine_dp<16>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, rows_hint, st);
+    case 32: return launch_refine_dp<32>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, rows_hint, st);
+    case 64: return launch_refine_dp<64>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, rows_hint, st);
+    case 128: return launch_refine_dp<128>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, rows_hint, st);
+    case 256: return launch_refine_dp<256>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, rows_hint, st);
+    case 512: return launch_refine_dp<512>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, rows_hint, st);
     default: return hipErrorInvalidValue;
   }
 }
