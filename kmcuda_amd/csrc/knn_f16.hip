@@ -15,6 +15,7 @@
 //     reference would have rejected has no effect, and the filter threshold as of the last flush is
 //     a superset of the live one (kth only decreases).
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 #include "exact.hpp"
 #include "exact_split.hpp"
@@ -91,7 +92,13 @@ __device__ __forceinline__ void knn_push_sample(uint32_t k, float dist, uint32_t
   }
 }
 
-template <int DP, int METRIC, bool FASTX>
+// COARSE (default): hi.hi products only, ONE MFMA per 16 features.  The candidate test only has to
+// never drop a candidate the reference would accept; the operand rounding it then carries,
+// |x'.y' - hi(x').hi(y')| <= (2^-10 + 2^-22) ||x'|| ||y'||, widens the acceptance band by ~0.1 % of a
+// typical squared distance, i.e. lets through about one more candidate per query for the exact chain,
+// and saves two of three MFMAs and half the LDS fragment traffic.  (KMCUDA_AMD_KNN_SPLIT=1: the
+// three-product filter.)
+template <int DP, int METRIC, bool FASTX, bool COARSE>
 __global__ __launch_bounds__(256, 2) void knn_filter_f16_kernel(KnnArgs a) {
   constexpr int NKH = DP / 2;   // features per half-wave
   constexpr int KS = NKH / 8;   // k-steps
@@ -113,16 +120,19 @@ __global__ __launch_bounds__(256, 2) void knn_filter_f16_kernel(KnnArgs a) {
   const bool live = qp < own_end;
 
   // B operand: my half of my query's split row
-  f16x8 xhi[KS], xlo[KS];
+  f16x8 xhi[KS], xlo[COARSE ? 1 : KS];
   {
     const _Float16 *src = reinterpret_cast<const _Float16 *>(a.xs16) + (size_t)(live ? qp : p0) * 2 * DP + h * NKH;
 #pragma unroll
     for (int j = 0; j < KS; j++) {
       xhi[j] = reinterpret_cast<const f16x8 *>(src)[j];
-      xlo[j] = reinterpret_cast<const f16x8 *>(src + DP)[j];
+      if (!COARSE) xlo[j] = reinterpret_cast<const f16x8 *>(src + DP)[j];
       if (!live) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) { xhi[j][q] = (_Float16)0.f; xlo[j][q] = (_Float16)0.f; }
+        for (int q = 0; q < 8; q++) {
+          xhi[j][q] = (_Float16)0.f;
+          if (!COARSE) xlo[j][q] = (_Float16)0.f;
+        }
       }
     }
   }
@@ -143,13 +153,15 @@ __global__ __launch_bounds__(256, 2) void knn_filter_f16_kernel(KnnArgs a) {
   const float u = 5.9604645e-8f;
   const float qn = sqrtf(qn2) * 1.0001f, nmx = sqrtf(nmax2) * 1.0001f;
   float E, kq = 0.f;
+  // operand rounding of the hi.hi-only score, in the units of the respective test
+  const float e_round = COARSE ? 9.78e-4f * qn * nmx : 0.f;
   if (METRIC == 0) {
-    E = 4.04f * (3.0f * a.eps + 16.0f * u) * (qn2 + nmax2) + 6e-8f * sqrtf((float)DP) * (qn + nmx);
+    E = 4.04f * (3.0f * a.eps + 16.0f * u) * (qn2 + nmax2) + 6e-8f * sqrtf((float)DP) * (qn + nmx) + 2.0f * e_round;
   } else {
     const float mun = sqrtf(a.mu2) * 1.0001f;
     kq = (live ? a.mux[qp] : 0.f) + a.mu2;      // x.y = acc + mu.x' + ||mu||^2
     E = 2.02f * (3.0f * a.eps + 16.0f * u) * (qn * nmx + mun * nmx) + 3e-8f * sqrtf((float)DP) * (qn + nmx) +
-        a.eps * (mun * qn + a.mu2) + 1e-6f;
+        a.eps * (mun * qn + a.mu2) + 1e-6f + e_round;
   }
   auto amin_of = [&](float mnd) -> float {
     if (METRIC == 0) {
@@ -260,10 +272,12 @@ __global__ __launch_bounds__(256, 2) void knn_filter_f16_kernel(KnnArgs a) {
 #pragma unroll
         for (int j = 0; j < KS; j++) {
           const f16x8 ahi = *reinterpret_cast<const f16x8 *>(arow + 8 * j);
-          const f16x8 alo = *reinterpret_cast<const f16x8 *>(arow + DP + 8 * j);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, xhi[j], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, xhi[j], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, xlo[j], acc, 0, 0, 0);
+          if constexpr (!COARSE) {
+            const f16x8 alo = *reinterpret_cast<const f16x8 *>(arow + DP + 8 * j);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, xhi[j], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, xlo[j], acc, 0, 0, 0);
+          }
         }
         uint32_t m16 = 0;
         if (!pruned) {
@@ -325,10 +339,14 @@ hipError_t launch_knn_split(int metric, const float *xs, uint32_t N, uint32_t D,
 template <int DP, int METRIC>
 static hipError_t launch_knn_f16_t(const KnnArgs &a, uint32_t nblocks, hipStream_t st) {
   const size_t lds_bytes = (2 * 32 * (DP + 4) + 64 + 8) * sizeof(float);
-  if (a.D == (uint32_t)DP)
-    hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, true>), dim3(nblocks), dim3(256), lds_bytes, st, a);
-  else
-    hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, false>), dim3(nblocks), dim3(256), lds_bytes, st, a);
+  const bool split = getenv("KMCUDA_AMD_KNN_SPLIT") != nullptr;
+  if (a.D == (uint32_t)DP) {
+    if (split) hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, true, false>), dim3(nblocks), dim3(256), lds_bytes, st, a);
+    else hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, true, true>), dim3(nblocks), dim3(256), lds_bytes, st, a);
+  } else {
+    if (split) hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, false, false>), dim3(nblocks), dim3(256), lds_bytes, st, a);
+    else hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, false, true>), dim3(nblocks), dim3(256), lds_bytes, st, a);
+  }
   return hipGetLastError();
 }
 
