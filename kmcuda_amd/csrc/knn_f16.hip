@@ -173,17 +173,21 @@ __global__ __launch_bounds__(256, 2) void knn_filter_f16_kernel(KnnArgs a) {
   };
   float amin = amin_of(mndist);
 
-  f32x4 stage[NST];
+  // pieces of 16 bytes per staged row: the whole [hi | lo] row, or (COARSE) its hi half only
+  constexpr int RP = COARSE ? DP / 8 : DP / 4;
+  constexpr int NSTG = (32 * RP + 255) / 256;
+  static_assert(NSTG <= NST, "staging registers");
+  f32x4 stage[NSTG];
   float bstage = 0.f;
   auto stage_load = [&](uint32_t base, uint32_t end) {  // 32 sorted rows from `base`
     const uint32_t last = a.N - 1;
 #pragma unroll
-    for (int i = 0; i < NST; i++) {
+    for (int i = 0; i < NSTG; i++) {
       const int q = tid + i * 256;
-      if (q < 8 * DP) {
-        const uint32_t row = base + q / (DP / 4);
+      if (q < 32 * RP) {
+        const uint32_t row = base + q / RP;
         const uint32_t rr = row <= last ? row : last;
-        stage[i] = reinterpret_cast<const f32x4 *>(panel + (size_t)rr * DP)[q % (DP / 4)];
+        stage[i] = reinterpret_cast<const f32x4 *>(panel + (size_t)rr * DP)[q % RP];
       }
     }
     if (tid < 32) {
@@ -194,10 +198,10 @@ __global__ __launch_bounds__(256, 2) void knn_filter_f16_kernel(KnnArgs a) {
   };
   auto stage_store = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < NST; i++) {
+    for (int i = 0; i < NSTG; i++) {
       const int q = tid + i * 256;
-      if (q < 8 * DP) {
-        const int row = q / (DP / 4), c4 = q % (DP / 4);
+      if (q < 32 * RP) {
+        const int row = q / RP, c4 = q % RP;
         *reinterpret_cast<f32x4 *>(tile_ptr(buf) + row * LDW + c4 * 4) = stage[i];
       }
     }
