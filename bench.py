@@ -263,6 +263,13 @@ def main():
             "breakdown_ms_per_step": {"filter": filter_ms, "filter_coarse_kernel": coarse_ms,
                                       "exact_refine": prof["exact_ms"] / launches,
                                       "update": prof["update_ms"] / launches},
+            "assignment_step_only": {"ms": filter_ms + prof["exact_ms"] / launches,
+                                     "value": n_local * world / ((filter_ms + prof["exact_ms"] / launches) * 1e-3)
+                                     if filter_ms > 0 else 0.0,
+                                     "note": "SURVEY 8(d) also names N / (time of the assignment step alone): both "
+                                             "filter stages + pair / exact refine of rank 0's shard, by HIP events; "
+                                             "`value` above divides by the FULL iteration (prep, assignment, update, "
+                                             "all-reduce)"},
             "rows_full_exact_scan_last_step": flagged, "rows_pair_refined_last_step": pair_rows, "reassigned_last_step": changed_last,
         }
         if world == 1 and not args.no_cpu_baseline:
