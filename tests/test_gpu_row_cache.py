@@ -105,3 +105,21 @@ def test_kmeans_cuda_iterations_unchanged_by_cache(monkeypatch):
         res.append((c.copy(), a.copy()))
     assert (res[0][1] == res[1][1]).all()
     assert numpy.array_equal(res[0][0], res[1][0], equal_nan=True)
+
+
+@pytest.mark.parametrize("n,d,k", [(1, 256, 1), (31, 256, 2), (33, 64, 3), (129, 512, 5), (257, 16, 2), (1000, 256, 1000),
+                                   (65, 300, 65)])
+@pytest.mark.parametrize("cached", [False, True])
+def test_tiny_and_ragged_shapes(n, d, k, cached):
+    """row counts around the 32 / 64 / 128 / 256-row tiling steps, K around the 32 / 64-centroid tiles,
+    K == N, a single row; with and without the row cache."""
+    rs = numpy.random.RandomState(n * 7 + d + k)
+    x = rs.rand(n, d).astype(numpy.float32)
+    c0 = x[rs.choice(n, k, replace=False)].copy()
+    cs = [c0, (c0 + rs.randn(k, d).astype(numpy.float32) * 0.01).astype(numpy.float32)]
+    got = _run_passes(x, cs, cached=cached)
+    ref_asg = None
+    for (asg, prev, changed), c in zip(got, cs):
+        ref, ref_prev, ref_changed = oracle.lloyd_assign(x, c, assignments=ref_asg)
+        assert (asg == ref).all() and (prev == ref_prev).all() and changed == ref_changed
+        ref_asg = ref
