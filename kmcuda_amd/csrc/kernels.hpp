@@ -89,6 +89,15 @@ hipError_t launch_unpack_dcount(const double *src, uint32_t K, int32_t *dcount, 
 // kmeans.cu:674-691 kmeans_calc_average_distance)
 hipError_t launch_kmpp_step(int metric, const float *samples, uint32_t N, uint32_t D, const float *centroid,
                             uint32_t cc, float *dists, hipStream_t st);
+// k-means++ with the chooser on the device (seeding.hip): step = distances + exact block sums + exponent
+// range; totals_host = pinned { double sum_g, sum_d; uint32 emin, emax, bad, chosen } (32 bytes)
+hipError_t launch_kmpp_step2(int metric, const float *samples, uint32_t N, uint32_t D, const float *centroid,
+                             uint32_t cc, float *dists, void *block_stats, double *bpre, void *totals_host,
+                             hipStream_t st);
+hipError_t launch_kmpp_choose(const float *dists, uint32_t N, const double *bpre, uint32_t choice_approx,
+                              double choice_sum, void *totals_host, hipStream_t st);
+size_t kmpp_block_stat_bytes(uint32_t N);
+size_t kmpp_blocks(uint32_t N);
 hipError_t launch_member_distances(int metric, const float *samples, uint32_t N, uint32_t D,
                                    const float *centroids, const uint32_t *assignments, uint32_t K,
                                    float *dists, hipStream_t st);

@@ -382,43 +382,107 @@ class Job {
         }
         RETERR(copy_sample_to_centroid(first_index, 0));
         INFO("performing kmeans++...\n");
-        // pinned: 4 N bytes come back from the GPUs at every one of the K - 1 steps
+        // Two ways to the reference's choice (kmcuda.cc:286-326).  HOST: all N distances come back
+        // (pinned, 4 N bytes per step), butterfly sum and sequential double prefix sums as the
+        // reference.  DEVICE (one shard; seeding.hip): sums of floats in double are exact -- order free
+        // -- while the distances' exponent range is narrow enough, so the step kernel's exact block
+        // sums give the same choice from 32 bytes per step; a step whose range is too wide (or that
+        // holds a NaN / inf distance) takes the host way.
         float *host_dists = nullptr;
-        if (hipHostMalloc(reinterpret_cast<void **>(&host_dists), (size_t)N * sizeof(float), hipHostMallocDefault) != hipSuccess)
-          return kmcudaMemoryAllocationFailure;
-        struct HostFree { float *p; ~HostFree() { (void)hipHostFree(p); } } host_dists_guard{host_dists};
+        struct HostFree { float **p; ~HostFree() { if (*p) (void)hipHostFree(*p); } } host_dists_guard{&host_dists};
+        const bool device_chooser = shards.size() == 1 && getenv("KMCUDA_AMD_KMPP_HOST") == nullptr;
+        struct Totals { double sum_g, sum_d; uint32_t emin, emax, bad, chosen; };
+        Totals *totals_host = nullptr;
+        struct TotalsFree { Totals **p; ~TotalsFree() { if (*p) (void)hipHostFree(*p); } } totals_guard{&totals_host};
+        void *block_stats = nullptr, *totals_dev = nullptr;
+        double *bpre = nullptr;
+        if (device_chooser) {
+          Shard &s = *shards[0];
+          (void)hipSetDevice(s.dev);
+          unsigned char *bs = nullptr, *td = nullptr;
+          int rc;
+          if ((rc = s.alloc(&bs, kmpp_block_stat_bytes(N)))) return rc;
+          if ((rc = s.alloc(&td, sizeof(Totals)))) return rc;
+          if ((rc = s.alloc(&bpre, kmpp_blocks(N) + 1))) return rc;
+          block_stats = bs;
+          totals_dev = td;
+          if (hipHostMalloc(reinterpret_cast<void **>(&totals_host), sizeof(Totals), hipHostMallocDefault) != hipSuccess)
+            return kmcudaMemoryAllocationFailure;
+        }
+        uint32_t log2n = 0;
+        while ((1ull << log2n) < (uint64_t)N) log2n++;
+        uint32_t host_steps = 0;
         for (uint32_t i = 1; i < K; i++) {
           if (verbosity > 1 || (verbosity > 0 && (K < 100 || i % (K / 100) == 0))) {
             printf("\rstep %d", i);
             fflush(stdout);
           }
-          for (auto &s : shards) {
-            (void)hipSetDevice(s->dev);
-            if (launch_kmpp_step(metric, s->samples, s->length, D, s->centroids + (size_t)(i - 1) * D, i, s->dists,
-                                 s->eng->stream_) != hipSuccess)
+          uint32_t j = 0;
+          bool chosen = false;
+          if (device_chooser) {
+            Shard &s = *shards[0];
+            (void)hipSetDevice(s.dev);
+            hipStream_t st = s.eng->stream_;
+            if (launch_kmpp_step2(metric, s.samples, N, D, s.centroids + (size_t)(i - 1) * D, i, s.dists, block_stats,
+                                  bpre, totals_dev, st) != hipSuccess)
               return kmcudaRuntimeError;
-            if (hipMemcpyAsync(host_dists + s->offset, s->dists, (size_t)s->length * sizeof(float),
-                               hipMemcpyDeviceToHost, s->eng->stream_) != hipSuccess)
+            if (hipMemcpyAsync(totals_host, totals_dev, sizeof(Totals), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess)
               return kmcudaMemoryCopyError;
-          }
-          RETERR(sync_all());
-          const double dist_sum = butterfly_sum(host_dists, N);
-          // the reference's chooser, kmcuda.cc:300-326
-          const double choice = ((rand() + .0) / RAND_MAX);
-          const uint32_t choice_approx = choice * N;
-          const double choice_sum = choice * dist_sum;
-          uint32_t j;
-          if (choice_approx < 100) {
-            double dist_sum2 = 0;
-            for (j = 0; j < N && dist_sum2 < choice_sum; j++) dist_sum2 += host_dists[j];
+            // every partial sum of the distances (and of their butterfly sums) is exact in double iff
+            // (emax + 1 + log2 N) - (emin - 23) <= 53
+            const bool none = totals_host->emin > totals_host->emax;
+            const bool exact = !totals_host->bad && (none || totals_host->emax - totals_host->emin + log2n <= 29u);
+            if (exact) {
+              const double dist_sum = totals_host->sum_g;
+              const double choice = ((rand() + .0) / RAND_MAX);   // kmcuda.cc:300-302
+              const uint32_t choice_approx = choice * N;
+              const double choice_sum = choice * dist_sum;
+              if (launch_kmpp_choose(s.dists, N, bpre, choice_approx, choice_sum, totals_dev, st) != hipSuccess)
+                return kmcudaRuntimeError;
+              if (hipMemcpyAsync(totals_host, totals_dev, sizeof(Totals), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                  hipStreamSynchronize(st) != hipSuccess)
+                return kmcudaMemoryCopyError;
+              j = totals_host->chosen;
+              chosen = true;
+            }
           } else {
-            double dist_sum2 = 0;
-            for (uint32_t t = 0; t < choice_approx; t++) dist_sum2 += host_dists[t];
-            if (dist_sum2 < choice_sum) {
-              for (j = choice_approx; j < N && dist_sum2 < choice_sum; j++) dist_sum2 += host_dists[j];
+            for (auto &s : shards) {
+              (void)hipSetDevice(s->dev);
+              if (launch_kmpp_step(metric, s->samples, s->length, D, s->centroids + (size_t)(i - 1) * D, i, s->dists,
+                                   s->eng->stream_) != hipSuccess)
+                return kmcudaRuntimeError;
+            }
+          }
+          if (!chosen) {   // the reference's way, on the host
+            host_steps++;
+            if (!host_dists &&
+                hipHostMalloc(reinterpret_cast<void **>(&host_dists), (size_t)N * sizeof(float), hipHostMallocDefault) != hipSuccess)
+              return kmcudaMemoryAllocationFailure;
+            for (auto &s : shards) {
+              (void)hipSetDevice(s->dev);
+              if (hipMemcpyAsync(host_dists + s->offset, s->dists, (size_t)s->length * sizeof(float),
+                                 hipMemcpyDeviceToHost, s->eng->stream_) != hipSuccess)
+                return kmcudaMemoryCopyError;
+            }
+            RETERR(sync_all());
+            const double dist_sum = butterfly_sum(host_dists, N);
+            // the reference's chooser, kmcuda.cc:300-326
+            const double choice = ((rand() + .0) / RAND_MAX);
+            const uint32_t choice_approx = choice * N;
+            const double choice_sum = choice * dist_sum;
+            if (choice_approx < 100) {
+              double dist_sum2 = 0;
+              for (j = 0; j < N && dist_sum2 < choice_sum; j++) dist_sum2 += host_dists[j];
             } else {
-              for (j = choice_approx; j > 1 && dist_sum2 >= choice_sum; j--) dist_sum2 -= host_dists[j];
-              j++;
+              double dist_sum2 = 0;
+              for (uint32_t t = 0; t < choice_approx; t++) dist_sum2 += host_dists[t];
+              if (dist_sum2 < choice_sum) {
+                for (j = choice_approx; j < N && dist_sum2 < choice_sum; j++) dist_sum2 += host_dists[j];
+              } else {
+                for (j = choice_approx; j > 1 && dist_sum2 >= choice_sum; j--) dist_sum2 -= host_dists[j];
+                j++;
+              }
             }
           }
           if (j == 0 || j > N) {
@@ -427,6 +491,7 @@ class Job {
           }
           RETERR(copy_sample_to_centroid(j - 1, i));
         }
+        if (device_chooser) DEBUG("k-means++: %u of %u steps took the host chooser\n", host_steps, K - 1);
         RETERR(sync_all());
         break;
       }

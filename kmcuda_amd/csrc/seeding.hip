@@ -31,6 +31,286 @@ hipError_t launch_kmpp_step(int metric, const float *samples, uint32_t N, uint32
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// k-means++ chooser on the device.  The reference picks the next seed on the HOST from
+// the N distances (kmcuda.cc:286-326): dist_sum = warp-butterfly float sums of 32 accumulated in
+// double, then sequential double prefix sums from a guessed start.  Sums of floats in double are EXACT
+// -- hence order free, hence parallel -- as long as every partial sum fits 53 bits:
+// (max exponent + 1 + ceil(log2 N)) - (min nonzero exponent - 23) <= 53.  The step kernel reports the
+// exponent range; when it fits (distances of one data set rarely span more than a few binades) the
+// device reproduces the host's choice bit for bit from exact block sums, otherwise (or with a NaN /
+// inf distance) the caller falls back to the host path.
+// ---------------------------------------------------------------------------------------
+constexpr int kKmppBlock = 256;   // rows per block of the step kernel = granularity of the exact prefix sums
+
+struct KmppBlockStat {   // one per block of kKmppBlock rows
+  double sum_d;          // exact sum of the block's distances
+  double sum_g;          // exact sum of its per-32 butterfly float sums
+  uint32_t emin, emax;   // biased exponent range of its finite non-zero distances (emin > emax: none)
+  uint32_t bad;          // a NaN or inf distance
+  uint32_t pad;
+};
+
+template <int METRIC>
+__global__ __launch_bounds__(kKmppBlock) void kmpp_step2_kernel(const float *__restrict__ samples, uint32_t N,
+                                                                uint32_t D, const float *__restrict__ centroid,
+                                                                uint32_t cc, float *__restrict__ dists,
+                                                                KmppBlockStat *__restrict__ stats) {
+  const uint32_t s = blockIdx.x * kKmppBlock + threadIdx.x;
+  float v = 0.f;   // rows past N count as 0, like the host emulation of the butterfly
+  if ((D & 3u) == 0 && ((uintptr_t)samples & 15u) == 0) {
+    // One serial chain per row, but the rows come in through LDS: a thread walking its own row makes
+    // every 16-byte load of a wave touch 64 different lines (1.1 TB/s measured).  Chunks of 32
+    // features: 8 lanes fetch a row's 128-byte line, the tile is stored with a 36-float row stride
+    // (conflict-free b128 reads by 16 consecutive rows), the next chunk's loads fly during the chain.
+    __shared__ __attribute__((aligned(16))) float tile[kKmppBlock * 36];
+    const uint32_t nchunk = (D + 31) / 32;
+    float4 stage[8];
+    auto fetch = [&](uint32_t ch) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint32_t p = threadIdx.x + kKmppBlock * q, r = p >> 3, c4 = p & 7u;
+        const uint32_t row = blockIdx.x * kKmppBlock + r, f = ch * 32 + c4 * 4;
+        stage[q] = (row < N && f < D) ? *reinterpret_cast<const float4 *>(samples + (size_t)row * D + f)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    float acc = 0.f, corr = 0.f, x0 = 0.f;
+    fetch(0);
+    for (uint32_t ch = 0; ch < nchunk; ch++) {
+      __syncthreads();   // the previous chunk has been consumed
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint32_t p = threadIdx.x + kKmppBlock * q, r = p >> 3, c4 = p & 7u;
+        *reinterpret_cast<float4 *>(&tile[r * 36 + c4 * 4]) = stage[q];
+      }
+      __syncthreads();
+      if (ch + 1 < nchunk) fetch(ch + 1);
+      const uint32_t fmax = D - ch * 32 < 32u ? D - ch * 32 : 32u;   // multiple of 4
+      for (uint32_t c4 = 0; c4 * 4 < fmax; c4++) {
+        const float4 xv = *reinterpret_cast<const float4 *>(&tile[threadIdx.x * 36 + c4 * 4]);
+        const float4 cv = *reinterpret_cast<const float4 *>(centroid + ch * 32 + c4 * 4);
+        const float aa[4] = {xv.x, xv.y, xv.z, xv.w}, bb[4] = {cv.x, cv.y, cv.z, cv.w};
+        if (ch == 0 && c4 == 0) x0 = aa[0];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if (METRIC == 0) {
+            const float d = aa[q] - bb[q];
+            kahan_fold(fma_rd(d, d, corr), acc, corr);
+          } else {
+            kahan_fold(fma_rd(aa[q], bb[q], corr), acc, corr);
+          }
+        }
+      }
+    }
+    if (s < N) {
+      float dist = 0.f;
+      if (x0 == x0) dist = METRIC == 0 ? sqrtf(acc) : angular_from_prod(acc);   // kmeans.cu:53-56
+      if (cc == 1 || dist < dists[s]) dists[s] = dist; else dist = dists[s];     // :57-62
+      v = dist;
+    }
+  } else if (s < N) {
+    const float *x = samples + (size_t)s * D;
+    float dist = 0.f;
+    if (x[0] == x[0]) dist = distance_vv<METRIC>(x, centroid, D);  // kmeans.cu:53-56
+    if (cc == 1 || dist < dists[s]) dists[s] = dist; else dist = dists[s];   // :57-62
+    v = dist;
+  }
+  // the reference's warpReduceSum over 32 lanes (kmeans.cu:63-66): a lane past the group reads itself
+  float g = v;
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) g = g + __shfl_down(g, off, 32);
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double sd = (double)v, sg = ((threadIdx.x & 31) == 0) ? (double)g : 0.0;
+  const uint32_t bits = __float_as_uint(v), ex = (bits >> 23) & 0xFFu;
+  const bool finite = ex != 0xFFu, nz = (bits & 0x7FFFFFFFu) != 0u;
+  uint32_t emin = (finite && nz) ? (ex ? ex : 1u) : 0xFFFFu, emax = (finite && nz) ? (ex ? ex : 1u) : 0u;
+  uint32_t bad = finite ? 0u : 1u;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    sd += __shfl_xor(sd, off);
+    sg += __shfl_xor(sg, off);
+    emin = min(emin, (uint32_t)__shfl_xor((int)emin, off));
+    emax = max(emax, (uint32_t)__shfl_xor((int)emax, off));
+    bad |= (uint32_t)__shfl_xor((int)bad, off);
+  }
+  __shared__ double wd[4], wg[4];
+  __shared__ uint32_t wmin[4], wmax[4], wbad[4];
+  if (lane == 0) { wd[wave] = sd; wg[wave] = sg; wmin[wave] = emin; wmax[wave] = emax; wbad[wave] = bad; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    KmppBlockStat st;
+    st.sum_d = (wd[0] + wd[1]) + (wd[2] + wd[3]);
+    st.sum_g = (wg[0] + wg[1]) + (wg[2] + wg[3]);
+    st.emin = min(min(wmin[0], wmin[1]), min(wmin[2], wmin[3]));
+    st.emax = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    st.bad = wbad[0] | wbad[1] | wbad[2] | wbad[3];
+    st.pad = 0;
+    stats[blockIdx.x] = st;
+  }
+}
+
+struct KmppTotals {   // pinned host memory
+  double sum_g, sum_d;
+  uint32_t emin, emax, bad, chosen;
+};
+
+// one block: totals + exclusive prefix of the block sums (bpre[nb] = total)
+__global__ __launch_bounds__(1024) void kmpp_reduce_kernel(const KmppBlockStat *__restrict__ stats, uint32_t nb,
+                                                           double *__restrict__ bpre, KmppTotals *__restrict__ out) {
+  __shared__ double wsum[16], wsg[16];
+  __shared__ uint32_t wmin[16], wmax[16], wbad[16];
+  __shared__ double carry_s, sg_s;
+  __shared__ uint32_t min_s, max_s, bad_s;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) { carry_s = 0.0; sg_s = 0.0; min_s = 0xFFFFu; max_s = 0u; bad_s = 0u; }
+  __syncthreads();
+  for (uint32_t base = 0; base < nb; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const bool in = i < nb;
+    const double v = in ? stats[i].sum_d : 0.0;
+    double sg = in ? stats[i].sum_g : 0.0;
+    uint32_t emin = in ? stats[i].emin : 0xFFFFu, emax = in ? stats[i].emax : 0u, bad = in ? stats[i].bad : 0u;
+    double inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double t = __shfl_up(inc, o);
+      if ((int)lane >= o) inc += t;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      sg += __shfl_xor(sg, o);
+      emin = min(emin, (uint32_t)__shfl_xor((int)emin, o));
+      emax = max(emax, (uint32_t)__shfl_xor((int)emax, o));
+      bad |= (uint32_t)__shfl_xor((int)bad, o);
+    }
+    if (lane == 63) wsum[wave] = inc;
+    if (lane == 0) { wsg[wave] = sg; wmin[wave] = emin; wmax[wave] = emax; wbad[wave] = bad; }
+    __syncthreads();
+    double wbase = 0.0, all = 0.0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) {
+      const double t = wsum[k];
+      if (k < wave) wbase += t;
+      all += t;
+    }
+    const double carry = carry_s;
+    if (in) bpre[i] = carry + wbase + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      carry_s = carry + all;
+      double g = sg_s;
+      uint32_t mn = min_s, mx = max_s, bd = bad_s;
+      for (uint32_t k = 0; k < 16; k++) { g += wsg[k]; mn = min(mn, wmin[k]); mx = max(mx, wmax[k]); bd |= wbad[k]; }
+      sg_s = g; min_s = mn; max_s = mx; bad_s = bd;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    bpre[nb] = carry_s;
+    out->sum_g = sg_s;
+    out->sum_d = carry_s;
+    out->emin = min_s;
+    out->emax = max_s;
+    out->bad = bad_s;
+  }
+}
+
+// The host chooser (kmcuda.cc:300-326) on exact prefix sums.  prefix(m) = sum of d[0..m).
+//   forward search  m0(dca) = min { m in [0, N] : prefix(m) - dca >= cs }  (N when there is none)
+//   choice_approx < 100, or prefix(ca) < cs :  j = m0(0)
+//   else (backward loop, which subtracts d[ca] first):  j = max(2, min(m0(d[ca]) - 1, ca + 1))
+__global__ __launch_bounds__(kKmppBlock) void kmpp_choose_kernel(const float *__restrict__ dists, uint32_t N,
+                                                                 const double *__restrict__ bpre, uint32_t nb,
+                                                                 uint32_t ca, double cs, KmppTotals *__restrict__ out) {
+  __shared__ double incl[kKmppBlock];
+  __shared__ uint32_t best;
+  __shared__ double pca_s;
+  const uint32_t tid = threadIdx.x;
+  // inclusive exact prefix of block bi into incl[] (Hillis-Steele; any order is exact)
+  auto scan_block = [&](uint32_t bi) {
+    const uint32_t s = bi * kKmppBlock + tid;
+    incl[tid] = s < N ? (double)dists[s] : 0.0;
+    __syncthreads();
+    for (int o = 1; o < kKmppBlock; o <<= 1) {
+      const double t = tid >= (uint32_t)o ? incl[tid - o] : 0.0;
+      __syncthreads();
+      incl[tid] += t;
+      __syncthreads();
+    }
+  };
+  auto first_m = [&](double dca) -> uint32_t {   // block-uniform result
+    if (tid == 0) best = 0xFFFFFFFFu;
+    __syncthreads();
+    if (0.0 - dca >= cs) return 0u;                               // prefix(0) = 0
+    for (uint32_t bi = tid; bi < nb; bi += kKmppBlock)            // smallest block whose END prefix qualifies
+      if (bpre[bi + 1] - dca >= cs) { atomicMin(&best, bi); break; }
+    __syncthreads();
+    const uint32_t bi = best;
+    __syncthreads();
+    if (bi == 0xFFFFFFFFu) return N;
+    scan_block(bi);
+    if (tid == 0) best = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint32_t m = bi * kKmppBlock + tid + 1;                  // prefix(m) = bpre[bi] + incl[tid]
+    if (m <= N && (bpre[bi] + incl[tid]) - dca >= cs) atomicMin(&best, m);
+    __syncthreads();
+    const uint32_t r = best;
+    __syncthreads();
+    return r == 0xFFFFFFFFu ? N : r;
+  };
+  uint32_t j;
+  bool forward = ca < 100u;
+  if (!forward) {   // prefix(ca), exact
+    const uint32_t bi = ca / kKmppBlock, r = ca % kKmppBlock;
+    double pca;
+    if (bi >= nb) pca = bpre[nb];
+    else {
+      scan_block(bi);
+      pca = bpre[bi] + (r ? incl[r - 1] : 0.0);
+    }
+    if (tid == 0) pca_s = pca;
+    __syncthreads();
+    forward = pca_s < cs;
+    __syncthreads();
+  }
+  if (forward) {
+    j = first_m(0.0);
+  } else {
+    const double dca = ca < N ? (double)dists[ca] : 0.0;
+    const uint32_t m0 = first_m(dca);
+    const uint32_t mp = m0 == 0u ? 0u : min(m0 - 1u, ca + 1u);
+    j = max(2u, mp);
+  }
+  if (tid == 0) out->chosen = j;
+}
+
+hipError_t launch_kmpp_step2(int metric, const float *samples, uint32_t N, uint32_t D, const float *centroid,
+                             uint32_t cc, float *dists, void *block_stats, double *bpre, void *totals_host,
+                             hipStream_t st) {
+  const uint32_t nb = (N + kKmppBlock - 1) / kKmppBlock;
+  if (metric == 0)
+    hipLaunchKernelGGL((kmpp_step2_kernel<0>), dim3(nb), dim3(kKmppBlock), 0, st, samples, N, D, centroid, cc, dists,
+                       reinterpret_cast<KmppBlockStat *>(block_stats));
+  else
+    hipLaunchKernelGGL((kmpp_step2_kernel<1>), dim3(nb), dim3(kKmppBlock), 0, st, samples, N, D, centroid, cc, dists,
+                       reinterpret_cast<KmppBlockStat *>(block_stats));
+  hipLaunchKernelGGL(kmpp_reduce_kernel, dim3(1), dim3(1024), 0, st, reinterpret_cast<const KmppBlockStat *>(block_stats),
+                     nb, bpre, reinterpret_cast<KmppTotals *>(totals_host));
+  return hipGetLastError();
+}
+
+hipError_t launch_kmpp_choose(const float *dists, uint32_t N, const double *bpre, uint32_t choice_approx,
+                              double choice_sum, void *totals_host, hipStream_t st) {
+  const uint32_t nb = (N + kKmppBlock - 1) / kKmppBlock;
+  hipLaunchKernelGGL(kmpp_choose_kernel, dim3(1), dim3(kKmppBlock), 0, st, dists, N, bpre, nb, choice_approx, choice_sum,
+                     reinterpret_cast<KmppTotals *>(totals_host));
+  return hipGetLastError();
+}
+
+size_t kmpp_block_stat_bytes(uint32_t N) { return (size_t)((N + kKmppBlock - 1) / kKmppBlock) * sizeof(KmppBlockStat); }
+size_t kmpp_blocks(uint32_t N) { return (N + kKmppBlock - 1) / kKmppBlock; }
+
 template <int METRIC>
 __global__ void member_distances_kernel(const float *__restrict__ samples, uint32_t N, uint32_t D,
                                         const float *__restrict__ centroids, const uint32_t *__restrict__ assignments,

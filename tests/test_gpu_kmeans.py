@@ -222,3 +222,42 @@ def test_update_paths_bit_identical(monkeypatch, k):
         res.append((c.copy(), a.copy()))
     assert (res[0][1] == res[1][1]).all()
     assert numpy.array_equal(res[0][0], res[1][0], equal_nan=True)
+
+
+@pytest.mark.parametrize("case", ["uniform", "blobs", "duplicates", "wide", "tiny", "ragged"])
+def test_kmeanspp_device_chooser_equals_host(monkeypatch, case):
+    """k-means++ with the chooser on the device (exact block sums; seeding.hip) against the reference's
+    host chooser (KMCUDA_AMD_KMPP_HOST=1): the same seeds, hence identical runs.  'wide' spans so many
+    binades that the device path must hand every step to the host way; 'duplicates' has zero distances."""
+    from kmcuda_amd import kmeans_cuda
+    rs = numpy.random.RandomState(hash(case) % 1000)
+    if case == "uniform":
+        x = rs.rand(30000, 64).astype(numpy.float32)
+        k = 200
+    elif case == "blobs":
+        cen = rs.rand(40, 32) * 20
+        x = (cen[rs.randint(0, 40, 25000)] + rs.randn(25000, 32)).astype(numpy.float32)
+        k = 64
+    elif case == "duplicates":
+        base = rs.rand(500, 16).astype(numpy.float32)
+        x = base[rs.randint(0, 500, 20000)].copy()
+        k = 100
+    elif case == "wide":
+        x = (rs.rand(20000, 8) * numpy.exp(rs.uniform(-12, 12, (20000, 1)))).astype(numpy.float32)
+        k = 50
+    elif case == "tiny":
+        x = rs.rand(300, 5).astype(numpy.float32)
+        k = 120
+    else:
+        x = rs.rand(10007, 33).astype(numpy.float32)
+        k = 257
+    res = []
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("KMCUDA_AMD_KMPP_HOST", "1")
+        else:
+            monkeypatch.delenv("KMCUDA_AMD_KMPP_HOST", raising=False)
+        c, a = kmeans_cuda(x, k, tolerance=0.5, init="k-means++", seed=11, yinyang_t=0, verbosity=0)
+        res.append((c.copy(), a.copy()))
+    assert numpy.array_equal(res[0][0], res[1][0], equal_nan=True)   # after one update: same seeds
+    assert (res[0][1] == res[1][1]).all()
