@@ -98,6 +98,14 @@ hipError_t launch_kmpp_choose(const float *dists, uint32_t N, const double *bpre
                               double choice_sum, void *totals_host, hipStream_t st);
 size_t kmpp_block_stat_bytes(uint32_t N);
 size_t kmpp_blocks(uint32_t N);
+// AFK-MC2 seeding (seeding.hip; reference kmeans.cu:69-212)
+hipError_t launch_afk_qdist(int metric, const float *samples, uint32_t N, uint32_t D, const float *c1, float *dists,
+                            hipStream_t st);
+hipError_t launch_afk_q(float *q, uint32_t N, float dsum, hipStream_t st);
+hipError_t launch_afk_random_step(uint32_t m, uint64_t seed, uint64_t seq, const float *q, uint32_t N,
+                                  uint32_t *choices, float *rand_a, hipStream_t st);
+hipError_t launch_afk_min_dist(int metric, uint32_t m, uint32_t k, const float *samples, uint32_t D,
+                               const uint32_t *choices, const float *centroids, float *min_dists, hipStream_t st);
 hipError_t launch_member_distances(int metric, const float *samples, uint32_t N, uint32_t D,
                                    const float *centroids, const uint32_t *assignments, uint32_t K,
                                    float *dists, hipStream_t st);

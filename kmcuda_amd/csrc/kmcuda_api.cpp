@@ -322,7 +322,8 @@ class Job {
   }
 
   // ---- seeding (reference: kmeans_init_centroids, kmcuda.cc:189-400) ----
-  int init_centroids(KMCUDAInitMethod method, uint32_t seed, const float *host_centroids, int32_t device_ptrs) {
+  int init_centroids(KMCUDAInitMethod method, uint32_t seed, const float *host_centroids, int32_t device_ptrs,
+                     uint32_t afk_m = 0) {
     if (metric == kmcudaDistanceMetricCosine && !fp16) {  // kmcuda.cc:195-220: three unit-norm probes, fp32 only
       std::vector<float> probe(D);
       for (uint32_t s : {0u, N / 2, N - 1}) {
@@ -495,9 +496,93 @@ class Job {
         RETERR(sync_all());
         break;
       }
-      case kmcudaInitMethodAFKMC2:
-        INFO("afkmc2 seeding is not built in this tier (SURVEY 8f.3)\n");
-        return kmcudaInvalidArguments;
+      case kmcudaInitMethodAFKMC2: {   // kmcuda.cc:337-396
+        uint32_t m = afk_m;
+        if (m == 0) {
+          m = 200;
+        } else if (m > N / 2) {
+          INFO("afkmc2: m > %u is not supported (got %u)\n", N / 2, m);
+          return kmcudaInvalidArguments;
+        }
+        float smoke = NAN;
+        uint32_t first_index = 0;
+        while (smoke != smoke) {
+          first_index = rand() % N;
+          RETERR(read_sample_value(first_index, 0, &smoke));
+        }
+        INFO("afkmc2: calculating q (c0 = %u)... ", first_index / D);
+        RETERR(copy_sample_to_centroid(first_index, 0));
+        // the candidate kernels index rows globally: with several shards the rows are gathered on the first
+        Shard &s0 = *shards[0];
+        (void)hipSetDevice(s0.dev);
+        hipStream_t st = s0.eng->stream_;
+        const float *all = s0.samples;
+        if (shards.size() > 1) {
+          float *gathered = nullptr;
+          int rc = s0.alloc(&gathered, (size_t)N * D);
+          if (rc) return rc;
+          RETERR(sync_all());
+          for (auto &s : shards) {
+            const hipError_t e = s->dev == s0.dev
+                ? hipMemcpy(gathered + (size_t)s->offset * D, s->samples, (size_t)s->length * D * sizeof(float), hipMemcpyDeviceToDevice)
+                : hipMemcpyPeer(gathered + (size_t)s->offset * D, s0.dev, s->samples, s->dev, (size_t)s->length * D * sizeof(float));
+            if (e != hipSuccess) return kmcudaMemoryCopyError;
+          }
+          all = gathered;
+        }
+        float *qdev = nullptr, *rand_dev = nullptr, *mind_dev = nullptr;
+        uint32_t *choice_dev = nullptr;
+        {
+          int rc;
+          if ((rc = s0.alloc(&qdev, N))) return rc;
+          if ((rc = s0.alloc(&rand_dev, m))) return rc;
+          if ((rc = s0.alloc(&mind_dev, m))) return rc;
+          if ((rc = s0.alloc(&choice_dev, m))) return rc;
+        }
+        if (hipMemsetAsync(choice_dev, 0, m * sizeof(uint32_t), st) != hipSuccess) return kmcudaRuntimeError;
+        std::vector<float> q(N), rand_a(m), p_cand(m);
+        std::vector<uint32_t> cand_ind(m);
+        // q(x) = 1 / 2N + d(x, c1)^2 / (2 sum d^2), with c1 = sample (first_index / D): the reference
+        // seeds q from THAT sample while centroid 0 is sample first_index (kmcuda.cc:356-362)
+        if (launch_afk_qdist(metric, all, N, D, all + (size_t)(first_index / D) * D, qdev, st) != hipSuccess)
+          return kmcudaRuntimeError;
+        if (hipMemcpyAsync(q.data(), qdev, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+          return kmcudaMemoryCopyError;
+        const double dsum = butterfly_sum(q.data(), N);   // kmeans.cu:92-95 (warp sums, double accumulation)
+        if (launch_afk_q(qdev, N, (float)dsum, st) != hipSuccess) return kmcudaRuntimeError;
+        if (hipMemcpyAsync(q.data(), qdev, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+          return kmcudaMemoryCopyError;
+        INFO("done\n");
+        for (uint32_t k = 1; k < K; k++) {
+          if (verbosity > 1 || (verbosity > 0 && (K < 100 || k % (K / 100) == 0))) {
+            printf("\rstep %d", k);
+            fflush(stdout);
+          }
+          (void)hipSetDevice(s0.dev);
+          if (launch_afk_random_step(m, seed, k, qdev, N, choice_dev, rand_dev, st) != hipSuccess ||
+              launch_afk_min_dist(metric, m, k, all, D, choice_dev, s0.centroids, mind_dev, st) != hipSuccess)
+            return kmcudaRuntimeError;
+          if (hipMemcpyAsync(cand_ind.data(), choice_dev, m * sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+              hipMemcpyAsync(rand_a.data(), rand_dev, m * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess ||
+              hipMemcpyAsync(p_cand.data(), mind_dev, m * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess ||
+              hipStreamSynchronize(st) != hipSuccess)
+            return kmcudaMemoryCopyError;
+          float curr_prob = 0;   // the Metropolis-Hastings chain, kmcuda.cc:381-388
+          uint32_t curr_ind = 0;
+          for (uint32_t j = 0; j < m; j++) {
+            const float cand_prob = p_cand[j] / q[cand_ind[j]];
+            if (curr_prob == 0 || cand_prob / curr_prob > rand_a[j]) {
+              curr_ind = j;
+              curr_prob = cand_prob;
+            }
+          }
+          RETERR(copy_sample_to_centroid(cand_ind[curr_ind], k));
+        }
+        RETERR(sync_all());
+        break;
+      }
     }
     INFO("\rdone            \n");
     return 0;
@@ -1085,7 +1170,6 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
                          uint32_t clusters_size, uint32_t seed, uint32_t device, int32_t device_ptrs, int32_t fp16x2,
                          int32_t verbosity, const float *samples, float *centroids, uint32_t *assignments,
                          float *average_distance) {
-  (void)init_params;
   kmx::g_verbosity = verbosity;
   DEBUG("arguments: %d %p %.3f %.2f %d %u %u %u %u %u %d %d %p %p %p %p\n", init, init_params, tolerance, yinyang_t,
         metric, samples_size, (unsigned)features_size, clusters_size, seed, device, fp16x2, verbosity,
@@ -1121,7 +1205,8 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
     INFO("KMCUDA_AMD_EXACT_UPDATE needs all rows on one GPU (the reference's update order is global)\n");
     return kmcudaInvalidArguments;
   }
-  RETERR(job.init_centroids(init, seed, centroids, device_ptrs));
+  const uint32_t afk_m = (init == kmcudaInitMethodAFKMC2 && init_params) ? *reinterpret_cast<const uint32_t *>(init_params) : 0;
+  RETERR(job.init_centroids(init, seed, centroids, device_ptrs, afk_m));
 
   if (yy_groups_size == 0 || kYinyangDraftReassignments <= tolerance) {  // kmeans.cu:1037-1050
     if (yy_groups_size == 0) INFO("too few clusters for this yinyang_t => Lloyd\n");

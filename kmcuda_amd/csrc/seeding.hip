@@ -4,6 +4,7 @@
 // Distances use the reference's exact arithmetic (exact.hpp) so that the host-side chooser sees
 // the very same floats as the reference's and picks the same seeds.
 #include <hip/hip_fp16.h>
+#include <rocrand/rocrand_xorwow.h>
 
 #include "exact.hpp"
 #include "kernels.hpp"
@@ -310,6 +311,95 @@ hipError_t launch_kmpp_choose(const float *dists, uint32_t N, const double *bpre
 
 size_t kmpp_block_stat_bytes(uint32_t N) { return (size_t)((N + kKmppBlock - 1) / kKmppBlock) * sizeof(KmppBlockStat); }
 size_t kmpp_blocks(uint32_t N) { return (N + kKmppBlock - 1) / kKmppBlock; }
+
+// ---------------------------------------------------------------------------------------
+// AFK-MC2 seeding (reference: kmeans.cu:69-212, host chain kmcuda.cc:337-396).
+// The reference draws from cuRAND's XORWOW (curand_init(seed, thread, step), two curand_uniform per
+// thread).  Here: the same generator as published (Marsaglia xorwow + Weyl sequence, state seeded and
+// jumped as rocRAND's xorwow_engine does -- subsequence = thread, offset = step) and cuRAND's
+// documented uint -> (0, 1] mapping x * 2^-32 + 2^-33.  Bit-compatibility of the SEQUENCE with CUDA's
+// cannot be checked without CUDA: the reference's pins for this init (4 / 4 / 4 iterations,
+// test.py:248-289) are met, nothing stronger is claimed.
+// ---------------------------------------------------------------------------------------
+template <int METRIC>
+__global__ void afk_qdist_kernel(const float *__restrict__ samples, uint32_t N, uint32_t D,
+                                 const float *__restrict__ c1, float *__restrict__ dists) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= N) return;
+  const float d = distance_vv<METRIC>(samples + (size_t)s * D, c1, D);   // kmeans.cu:88-90 (no NaN test here)
+  dists[s] = d * d;
+}
+
+__global__ void afk_q_kernel(float *__restrict__ q, uint32_t N, float dsum) {   // kmeans.cu:98-109
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= N) return;
+  q[s] = 1 / (2.f * N) + q[s] / (2 * dsum);
+}
+
+__device__ __forceinline__ float afk_uniform(unsigned int x) { return fmaf((float)x, 2.3283064e-10f, 2.3283064e-10f / 2.0f); }
+
+// one thread per candidate: two uniforms, then the first index whose Kahan prefix sum of q reaches the
+// first one (kmeans.cu:111-164; a thread whose sum never gets there leaves its choice as it was)
+__global__ void afk_random_step_kernel(uint32_t m, unsigned long long seed, unsigned long long seq,
+                                       const float *__restrict__ q, uint32_t N, uint32_t *__restrict__ choices,
+                                       float *__restrict__ rand_a) {
+  const uint32_t ti = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ti >= m) return;
+  rocrand_device::xorwow_engine eng(seed, ti, seq);
+  const float part = afk_uniform(eng.next());
+  rand_a[ti] = afk_uniform(eng.next());
+  float accum = 0.f, corr = 0.f;
+  uint32_t i = 0;
+  for (; i < N && accum < part; i++) {   // Kahan summation with inverted c
+    const float y = corr + q[i];
+    const float t = accum + y;
+    corr = y - (t - accum);
+    accum = t;
+  }
+  if (accum >= part) choices[ti] = i - 1;
+}
+
+template <int METRIC>
+__global__ void afk_min_dist_kernel(uint32_t m, uint32_t k, const float *__restrict__ samples, uint32_t D,
+                                    const uint32_t *__restrict__ choices, const float *__restrict__ centroids,
+                                    float *__restrict__ min_dists) {   // kmeans.cu:166-183
+  const uint32_t chi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (chi >= m) return;
+  const float *x = samples + (size_t)choices[chi] * D;
+  float min_dist = 3.402823466e+38f;
+  for (uint32_t c = 0; c < k; c++) {
+    const float dist = distance_vv<METRIC>(x, centroids + (size_t)c * D, D);
+    if (dist < min_dist) min_dist = dist;
+  }
+  min_dists[chi] = min_dist * min_dist;
+}
+
+hipError_t launch_afk_qdist(int metric, const float *samples, uint32_t N, uint32_t D, const float *c1, float *dists,
+                            hipStream_t st) {
+  const dim3 grid((N + 127) / 128), block(128);
+  if (metric == 0) hipLaunchKernelGGL((afk_qdist_kernel<0>), grid, block, 0, st, samples, N, D, c1, dists);
+  else hipLaunchKernelGGL((afk_qdist_kernel<1>), grid, block, 0, st, samples, N, D, c1, dists);
+  return hipGetLastError();
+}
+hipError_t launch_afk_q(float *q, uint32_t N, float dsum, hipStream_t st) {
+  hipLaunchKernelGGL(afk_q_kernel, dim3((N + 255) / 256), dim3(256), 0, st, q, N, dsum);
+  return hipGetLastError();
+}
+hipError_t launch_afk_random_step(uint32_t m, uint64_t seed, uint64_t seq, const float *q, uint32_t N,
+                                  uint32_t *choices, float *rand_a, hipStream_t st) {
+  hipLaunchKernelGGL(afk_random_step_kernel, dim3((m + 63) / 64), dim3(64), 0, st, m, (unsigned long long)seed,
+                     (unsigned long long)seq, q, N, choices, rand_a);
+  return hipGetLastError();
+}
+hipError_t launch_afk_min_dist(int metric, uint32_t m, uint32_t k, const float *samples, uint32_t D,
+                               const uint32_t *choices, const float *centroids, float *min_dists, hipStream_t st) {
+  const dim3 grid((m + 63) / 64), block(64);
+  if (metric == 0)
+    hipLaunchKernelGGL((afk_min_dist_kernel<0>), grid, block, 0, st, m, k, samples, D, choices, centroids, min_dists);
+  else
+    hipLaunchKernelGGL((afk_min_dist_kernel<1>), grid, block, 0, st, m, k, samples, D, choices, centroids, min_dists);
+  return hipGetLastError();
+}
 
 template <int METRIC>
 __global__ void member_distances_kernel(const float *__restrict__ samples, uint32_t N, uint32_t D,

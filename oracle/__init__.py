@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(_HERE, "libkmcuda_oracle.so")
 
 L2, COS = 0, 1
 INIT_RANDOM, INIT_PLUSPLUS, INIT_AFKMC2, INIT_IMPORT = 0, 1, 2, 3
-_INITS = {"random": INIT_RANDOM, "kmeans++": INIT_PLUSPLUS, "k-means++": INIT_PLUSPLUS}
+_INITS = {"random": INIT_RANDOM, "kmeans++": INIT_PLUSPLUS, "k-means++": INIT_PLUSPLUS, "afkmc2": INIT_AFKMC2, "afk-mc2": INIT_AFKMC2}
 _METRICS = {"L2": L2, "l2": L2, "euclidean": L2, "cos": COS, "cosine": COS, "angular": COS}
 
 
@@ -179,7 +179,12 @@ def _kmeans(samples, clusters, tolerance, init, yinyang_t, metric, average_dista
         method = INIT_IMPORT
     else:
         cen = np.empty((clusters, d), np.float32)
+        afk_m = 0
+        if isinstance(init, tuple):   # ("afkmc2", m), kmcuda.h:168-174
+            init, afk_m = init[0], int(init[1])
         method = _INITS[init]
+        lib().kmo_set_afkmc2_m.argtypes = [u32]
+        lib().kmo_set_afkmc2_m(afk_m)
     asg = np.empty(n, np.uint32)
     log = np.zeros(4096, np.uint32)
     nlog = u32(0)

@@ -522,6 +522,137 @@ static double kmpp_step(int metric, uint32_t N, uint32_t D, uint32_t cc, const f
   return sum;
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* AFK-MC2 seeding: kmeans.cu:69-212 (kernels), kmcuda.cc:337-396 (host chain).            */
+/* Third-party arithmetic: the reference draws from cuRAND's XORWOW (CUDA toolkit 8.0,    */
+/* curand_init(seed, thread, step) + curand_uniform), which is not in /root/reference.    */
+/* Restated from the published algorithm: Marsaglia's xorwow (5 x 32-bit xorshift + a     */
+/* Weyl sequence, increment 362437), state seeded and advanced as rocRAND 7.2's           */
+/* xorwow_engine documents it (rocrand_xorwow.h: seed scrambling constants; subsequence   */
+/* = 2^67 draws via precomputed jump matrices, taken from the system header               */
+/* rocrand_xorwow_precomputed.h), and cuRAND's uint -> (0,1] map x*2^-32 + 2^-33.          */
+/* Whether CUDA's sequence is bit-identical cannot be checked here: PARITY UNPINNED       */
+/* beyond the reference's 4 / 4 / 4 iteration pins (test.py:248-289).                     */
+/* ------------------------------------------------------------------------------------ */
+#define __device__
+#include <rocrand/rocrand_xorwow_precomputed.h>
+#undef __device__
+
+typedef struct { uint32_t x[5]; uint32_t d; } xorwow_t;
+
+static void xorwow_mul(const unsigned int *m, uint32_t *v) {
+  uint32_t r[XORWOW_N] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < XORWOW_N; i++)
+    for (int j = 0; j < XORWOW_M; j++)
+      if (v[i] & (1u << j))
+        for (int k = 0; k < XORWOW_N; k++) r[k] ^= m[i * XORWOW_M * XORWOW_N + j * XORWOW_N + k];
+  for (int k = 0; k < XORWOW_N; k++) v[k] = r[k];
+}
+
+static void xorwow_jump(xorwow_t *st, unsigned long long v, const unsigned int mats[XORWOW_JUMP_MATRICES][XORWOW_SIZE]) {
+  unsigned mi = 0;
+  while (v > 0) {
+    const unsigned is = (unsigned)v & ((1u << XORWOW_JUMP_LOG2) - 1u);
+    for (unsigned i = 0; i < is; i++) xorwow_mul(mats[mi], st->x);
+    mi++;
+    v >>= XORWOW_JUMP_LOG2;
+  }
+}
+
+static void xorwow_init(xorwow_t *st, unsigned long long seed, unsigned long long subsequence, unsigned long long offset) {
+  st->x[0] = 123456789u; st->x[1] = 362436069u; st->x[2] = 521288629u; st->x[3] = 88675123u; st->x[4] = 5783321u;
+  st->d = 6615241u;
+  const uint32_t s0 = (uint32_t)seed ^ 0x2c7f967fu, s1 = (uint32_t)(seed >> 32) ^ 0xa03697cbu;
+  const uint32_t t0 = 1228688033u * s0, t1 = 2073658381u * s1;
+  st->x[0] += t0; st->x[1] ^= t0; st->x[2] += t1; st->x[3] ^= t1; st->x[4] += t0;
+  st->d += t1 + t0;
+  xorwow_jump(st, subsequence, h_xorwow_sequence_jump_matrices);
+  xorwow_jump(st, offset, h_xorwow_jump_matrices);
+  st->d += (uint32_t)offset * 362437u;
+}
+
+static uint32_t xorwow_next(xorwow_t *st) {
+  const uint32_t t = st->x[0] ^ (st->x[0] >> 2);
+  st->x[0] = st->x[1]; st->x[1] = st->x[2]; st->x[2] = st->x[3]; st->x[3] = st->x[4];
+  st->x[4] = (st->x[4] ^ (st->x[4] << 4)) ^ (t ^ (t << 1));
+  st->d += 362437u;
+  return st->d + st->x[4];
+}
+
+static float afk_uniform(uint32_t x) { return fmaf((float)x, 2.3283064e-10f, 2.3283064e-10f / 2.0f); }
+
+static uint32_t g_afk_m = 0;
+void kmo_set_afkmc2_m(uint32_t m) { g_afk_m = m; }
+
+static int afkmc2_init(int metric, uint32_t N, uint32_t D, uint32_t K, uint32_t seed, uint32_t m,
+                       const float *samples, float *centroids) {
+  if (m == 0) m = 200;
+  else if (m > N / 2) return 1;
+  uint32_t first_index;
+  float smoke = NAN;
+  while (smoke != smoke) {
+    first_index = (uint32_t)(rand() % (long)N);
+    smoke = samples[(size_t)first_index * D];
+  }
+  memcpy(centroids, samples + (size_t)first_index * D, sizeof(float) * D);
+  /* q relative to sample (first_index / D) -- the reference's quirk, kmcuda.cc:356-362 */
+  const float *c1 = samples + (size_t)(first_index / D) * D;
+  float *q = (float *)malloc(sizeof(float) * N);
+  for (uint32_t s = 0; s < N; s++) {
+    const float d = kmo_distance(metric, samples + (size_t)s * D, c1, D);
+    q[s] = d * d;
+  }
+  double dsum = 0.0;                                   /* warp butterfly sums of 32, double accumulation */
+  for (uint32_t base = 0; base < N; base += 32) {
+    float lane[32];
+    for (int l = 0; l < 32; l++) lane[l] = (base + l < N) ? q[base + l] : 0.f;
+    for (int off = 16; off > 0; off /= 2)
+      for (int l = 0; l < 32; l++) lane[l] = lane[l] + ((l + off < 32) ? lane[l + off] : lane[l]);
+    dsum += (double)lane[0];
+  }
+  const float dsumf = (float)dsum;
+  for (uint32_t s = 0; s < N; s++) q[s] = 1 / (2.f * N) + q[s] / (2 * dsumf);     /* kmeans.cu:108 */
+  uint32_t *cand = (uint32_t *)calloc(m, sizeof(uint32_t));
+  float *rand_a = (float *)malloc(sizeof(float) * m), *p_cand = (float *)malloc(sizeof(float) * m);
+  for (uint32_t k = 1; k < K; k++) {
+    for (uint32_t ti = 0; ti < m; ti++) {                                            /* kmeans.cu:111-164 */
+      xorwow_t st;
+      xorwow_init(&st, seed, ti, k);
+      const float part = afk_uniform(xorwow_next(&st));
+      rand_a[ti] = afk_uniform(xorwow_next(&st));
+      float accum = 0.f, corr = 0.f;
+      uint32_t i = 0;
+      for (; i < N && accum < part; i++) {
+        const float y = corr + q[i];
+        const float t = accum + y;
+        corr = y - (t - accum);
+        accum = t;
+      }
+      if (accum >= part) cand[ti] = i - 1;
+    }
+    for (uint32_t chi = 0; chi < m; chi++) {                                         /* kmeans.cu:166-183 */
+      float min_dist = FLT_MAX;
+      for (uint32_t c = 0; c < k; c++) {
+        const float dist = kmo_distance(metric, samples + (size_t)cand[chi] * D, centroids + (size_t)c * D, D);
+        if (dist < min_dist) min_dist = dist;
+      }
+      p_cand[chi] = min_dist * min_dist;
+    }
+    float curr_prob = 0;                                                             /* kmcuda.cc:381-388 */
+    uint32_t curr_ind = 0;
+    for (uint32_t j = 0; j < m; j++) {
+      const float cand_prob = p_cand[j] / q[cand[j]];
+      if (curr_prob == 0 || cand_prob / curr_prob > rand_a[j]) {
+        curr_ind = j;
+        curr_prob = cand_prob;
+      }
+    }
+    memcpy(centroids + (size_t)k * D, samples + (size_t)cand[curr_ind] * D, sizeof(float) * D);
+  }
+  free(q); free(cand); free(rand_a); free(p_cand);
+  return 0;
+}
+
 int kmo_init_centroids(int method, int metric, uint32_t N, uint32_t D, uint32_t K, uint32_t seed,
                        const float *samples, float *centroids) {
   srand(seed);                                               /* kmcuda.cc:222 */
@@ -573,7 +704,8 @@ int kmo_init_centroids(int method, int metric, uint32_t N, uint32_t D, uint32_t 
     free(host_dists);
     return 0;
   }
-  return 3; /* AFK-MC2 is out of scope (cuRAND-bound) */
+  if (method == KMO_INIT_AFKMC2) return afkmc2_init(metric, N, D, K, seed, g_afk_m, samples, centroids);
+  return 3;
 }
 
 /* kmeans.cu:674-691: float warp butterfly sums, double accumulation, / N */

@@ -88,6 +88,8 @@ int kmo_kmeans(int init, float tolerance, float yinyang_t, int metric, uint32_t 
 /* fp16x2 storage mode of THIS repository (fp32 arithmetic on half values, centroids rounded to half
  * after every update); affects kmo_kmeans only.  kmo_quantize_half: float -> half (RN) -> float. */
 void kmo_set_fp16_storage(int on);
+/* m of init = KMO_INIT_AFKMC2 (0 => 200), kmcuda.h:89-92 */
+void kmo_set_afkmc2_m(uint32_t m);
 float kmo_quantize_half(float x);
 
 /* knn.cu:19-58 / :61-131 / :133-243 and kmcuda.cc:648-691 (inverse assignments) */

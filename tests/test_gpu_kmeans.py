@@ -88,6 +88,40 @@ def test_kmeanspp_lloyd_4(fixture13k):
     assert (assignments == oasg).all()
 
 
+@pytest.mark.parametrize("init,k", [(("afkmc2", 200), 50), ("afkmc2", 50), (("afkmc2", 100), 200)])
+def test_afkmc2_lloyd_4(fixture13k, init, k):
+    """test.py:248-289 through the boundary, and seed-for-seed equality with the oracle's AFK-MC2."""
+    from kmcuda_amd import kmeans_cuda
+    out = StdoutListener()
+    with out:
+        centroids, assignments = kmeans_cuda(fixture13k, k, init=init, device=1, verbosity=2, seed=3,
+                                             tolerance=0.05, yinyang_t=0)
+    assert out.iterations() == 4
+    if k == 50:
+        _validate(fixture13k, centroids, assignments, 0.05)
+    ocen, oasg, _ = oracle.kmeans(fixture13k, k, init=init, seed=3, tolerance=0.05, yinyang_t=0)
+    assert (assignments == oasg).all()
+
+
+def test_afkmc2_256d_seeds_equal_oracle():
+    """wider rows, angular metric too: after one iteration (tolerance 0.5) the assignments are a function
+    of the seeds alone"""
+    from kmcuda_amd import kmeans_cuda
+    rs = numpy.random.RandomState(4)
+    x = rs.rand(6000, 256).astype(numpy.float32)
+    for metric in ("L2", "cos"):
+        xs = x if metric == "L2" else (x / numpy.linalg.norm(x, axis=1, keepdims=True)).astype(numpy.float32)
+        c, a = kmeans_cuda(xs, 40, init=("afkmc2", 64), seed=9, tolerance=0.5, yinyang_t=0, metric=metric)
+        oc, oa, _ = oracle.kmeans(xs, 40, init=("afkmc2", 64), seed=9, tolerance=0.5, yinyang_t=0, metric=metric)
+        assert (a == oa).mean() > (0.999 if metric == "cos" else 0.99999)
+
+
+def test_afkmc2_rejects_large_m(fixture13k):
+    from kmcuda_amd import kmeans_cuda
+    with pytest.raises(ValueError):
+        kmeans_cuda(fixture13k, 50, init=("afkmc2", 7000), seed=3, yinyang_t=0)   # m > N / 2, kmcuda.cc:341-345
+
+
 def test_import_lloyd_8(fixture13k):
     from kmcuda_amd import kmeans_cuda
     out = StdoutListener()

@@ -65,6 +65,17 @@ def test_kmeanspp_lloyd_4(fixture13k):
     _validate(fixture13k, c, a, 0.05)
 
 
+@pytest.mark.parametrize("init,k", [(("afkmc2", 200), 50), ("afkmc2", 50), (("afkmc2", 100), 200)])
+def test_afkmc2_lloyd_4(fixture13k, init, k):
+    """test.py:248-289: AFK-MC2 seeding (m = 200, the default m, and 200 clusters with m = 100), 4 Lloyd
+    iterations each.  The random draws are a restatement of XORWOW, not cuRAND itself (oracle header):
+    an iteration count is all the reference pins for this init."""
+    c, a, log = oracle.kmeans(fixture13k, k, init=init, seed=3, tolerance=0.05, yinyang_t=0)
+    assert len(log) == 4
+    if k == 50:
+        _validate(fixture13k, c, a, 0.05)
+
+
 def test_kmeanspp_yinyang_15_3(fixture13k):
     # test.py:228-234
     c, a, log = oracle.kmeans(fixture13k, 50, init="kmeans++", seed=3, tolerance=0.01, yinyang_t=0.1)
