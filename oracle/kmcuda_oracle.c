@@ -11,7 +11,9 @@
  * Parity pinning: reference is CUDA-only => no oracle/_ref; pinned on the reference's own
  * known-answer tests (src/test.py iteration counts + sklearn agreement).  The angular
  * metric goes through libm acosf, which is not bit-identical to CUDA's acosf
- * ("parity unpinned" for angular beyond the reference's own loose thresholds).
+ * ("parity unpinned" for angular beyond the reference's own loose thresholds).  The AFK-MC2
+ * seeding draws from a restatement of XORWOW, not from cuRAND: "parity unpinned" beyond the
+ * reference's iteration-count pins for that init (see the section comment below).
  */
 #include "kmcuda_oracle.h"
 
