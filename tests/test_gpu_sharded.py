@@ -1,0 +1,106 @@
+"""The row-sharded Lloyd loop with the PRODUCT backend (HipBackend: HIP kernels through the C ABI)
+under torch.distributed, world_size 2.  A test box has one GPU, and RCCL refuses two ranks on one
+device, so both ranks sit on GPU 0 and the all-reduce goes over gloo (device tensors); what is
+covered is everything else the N > 1 path of bench.py runs: shard bookkeeping, the fused fp64
+reduce buffer, ordering between the engine's stream and torch's collectives, the stop rule.
+
+Bar: identical per-iteration reassignment counts and assignments as ONE process over all rows
+(the deltas are exact fp64 sums of fp32 values for these sizes, so the split does not change
+them), and the first assignment pass bit-exact against the oracle."""
+import datetime
+import os
+import socket
+import sys
+
+import numpy
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _data():
+    rs = numpy.random.RandomState(11)
+    x = numpy.concatenate([rs.randn(1500, 64) + 3 * rs.randn(1, 64) for _ in range(8)]).astype(numpy.float32)
+    x = x[rs.permutation(len(x))]
+    init = x[rs.choice(len(x), 40, replace=False)].copy()
+    return x, init
+
+
+def _worker(rank, world, port, out):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from kmcuda_amd.distributed import HipBackend, ShardedLloyd, row_block
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    x, init = _data()
+    lo, hi = row_block(len(x), rank, world)
+    xs = torch.from_numpy(x[lo:hi]).to(dev)
+    try:
+        probe = torch.ones(4, dtype=torch.float64, device=dev)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize(dev)
+        assert float(probe[0].item()) == world
+    except (RuntimeError, AssertionError) as e:   # a gloo build without device-tensor support
+        if rank == 0:
+            numpy.savez(out, skipped=numpy.array([1]), why=numpy.array([str(e)[:200]]))
+        dist.destroy_process_group()
+        return
+    loop = ShardedLloyd(HipBackend(xs, len(init), "L2", device_index=0), len(x))
+    c0 = torch.from_numpy(init).to(dev) if rank == 0 else torch.zeros((len(init), x.shape[1]), device=dev)
+    loop.set_centroids(c0)
+    first = None
+    log = []
+    for it in range(60):
+        changed = loop.step(0.002)
+        log.append(changed)
+        if it == 0:
+            torch.cuda.synchronize(dev)
+            first = loop.b.assignments.cpu().numpy().view(numpy.uint32).copy()
+        if changed <= 0.002 * len(x):
+            break
+    torch.cuda.synchronize(dev)
+    mine = loop.b.assignments.cpu().numpy().view(numpy.uint32).copy()
+    gathered, firsts = [None] * world, [None] * world
+    dist.all_gather_object(gathered, mine)
+    dist.all_gather_object(firsts, first)
+    if rank == 0:
+        numpy.savez(out, skipped=numpy.array([0]), log=numpy.array(log), asg=numpy.concatenate(gathered),
+                    first=numpy.concatenate(firsts), cen=loop.b.centroids.cpu().numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_hip_backend_world2_matches_single(tmp_path):
+    import torch.multiprocessing as mp
+    from kmcuda_amd.distributed import HipBackend, ShardedLloyd
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "w2.npz")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = numpy.load(out)
+    if int(got["skipped"][0]):
+        pytest.skip("gloo cannot reduce device tensors here: %s" % got["why"][0])
+    x, init = _data()
+    dev = torch.device("cuda", 0)
+    loop = ShardedLloyd(HipBackend(torch.from_numpy(x).to(dev), len(init), "L2", device_index=0), len(x))
+    loop.set_centroids(torch.from_numpy(init).to(dev))
+    log = loop.run(tolerance=0.002, max_iter=60)
+    torch.cuda.synchronize(dev)
+    single = loop.b.assignments.cpu().numpy().view(numpy.uint32)
+    assert list(got["log"]) == log
+    assert len(log) > 3 and log[-1] <= 0.002 * len(x)
+    assert (got["asg"] == single).all()
+    numpy.testing.assert_allclose(got["cen"], loop.b.centroids.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    ref, _, _ = oracle.lloyd_assign(x, init)
+    assert (got["first"] == ref).all()
