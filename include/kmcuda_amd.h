@@ -73,6 +73,12 @@ int kmamd_set_row_cache(kmamd_engine *e, int on);
  * [3] rows the filter narrowed to two contenders (pair refine).  read = sync + copy to a host array; reset zeroes [0..3] (or one of them). */
 int kmamd_counters_read(kmamd_engine *e, uint32_t *host_out4);
 int kmamd_counters_reset(kmamd_engine *e, int which /* -1: all */);
+/* Yinyang local filter with the second-best estimate (yinyang_hint.hip; KMCUDA_AMD_YY_HINT=0 turns it
+ * off): running totals since the engine was created -- [0] rows it processed, [1] rows it handed to the
+ * plain kernel (results are the reference's either way; the ratio is a performance figure), [2..5] the
+ * hand-overs by first reason: no estimate, a skipped candidate whose bound does not hold, an evaluated
+ * candidate whose bound exceeds the estimate, a final second minimum above the estimate. */
+int kmamd_yy_hint_stats(kmamd_engine *e, uint32_t *host_out6);
 
 /* Device-side export for a FUSED all-reduce buffer: dst[0..K) = (double)dcount[c],
  * dst[K + i] = (double)counters[i], i = 0..3.  Lets a row-sharded driver reduce

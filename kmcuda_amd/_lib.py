@@ -19,7 +19,7 @@ _lib = None
 EXPORTS = [
     "kmeans_cuda", "knn_cuda",
     "kmamd_engine_create", "kmamd_engine_destroy", "kmamd_engine_stream", "kmamd_engine_sync",
-    "kmamd_lloyd_assign", "kmamd_lloyd_assign_exact", "kmamd_set_half_rows", "kmamd_set_row_cache", "kmamd_profile_read_coarse", "kmamd_set_filter", "kmamd_counters_read", "kmamd_counters_reset",
+    "kmamd_lloyd_assign", "kmamd_lloyd_assign_exact", "kmamd_set_half_rows", "kmamd_set_row_cache", "kmamd_profile_read_coarse", "kmamd_set_filter", "kmamd_counters_read", "kmamd_counters_reset", "kmamd_yy_hint_stats",
     "kmamd_move_deltas", "kmamd_apply_delta", "kmamd_transpose", "kmamd_pack_reduce_tail",
     "kmamd_unpack_dcount", "kmamd_adjust_exact", "kmamd_yy_configure", "kmamd_yy_init", "kmamd_yy_drifts", "kmamd_yy_filters",
     "kmamd_profile_reset", "kmamd_profile_read", "kmamd_profile_enable", "kmamd_build_arch",
@@ -62,6 +62,8 @@ def lib():
     L.kmamd_counters_read.argtypes = [vp, ctypes.POINTER(u32)]
     L.kmamd_counters_reset.restype = i32
     L.kmamd_counters_reset.argtypes = [vp, i32]
+    L.kmamd_yy_hint_stats.restype = i32
+    L.kmamd_yy_hint_stats.argtypes = [vp, vp]
     L.kmamd_move_deltas.restype = i32
     L.kmamd_move_deltas.argtypes = [vp, vp, vp, vp, vp, vp]
     L.kmamd_apply_delta.restype = i32

@@ -75,7 +75,7 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if ((rc = alloc(&finite_, Kt_))) return rc;
   if ((rc = alloc(&flagged_, n_rows))) return rc;
   if ((rc = alloc(&pairs_, 3 * (size_t)n_rows))) return rc;
-  if ((rc = alloc(&counters_, 8))) return rc;
+  if ((rc = alloc(&counters_, 16))) return rc;
   if ((rc = alloc(&keys_tmp_, 2 * (size_t)n_rows))) return rc;
   if ((rc = alloc(&vals_tmp_, 2 * (size_t)n_rows))) return rc;
   if ((rc = alloc(&keys_sorted_, 2 * (size_t)n_rows))) return rc;
@@ -96,8 +96,8 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
     sort_temp_ = t;
   }
   if ((rc = alloc(&partial_, (size_t)2 * K * kSumSplit * D))) return rc;
-  KMX_HIP(hipHostMalloc((void **)&host_counters_, 4 * sizeof(uint32_t), hipHostMallocDefault), kMemoryAllocationFailure);
-  KMX_HIP(hipMemsetAsync(counters_, 0, 8 * sizeof(uint32_t), stream_), kRuntimeError);
+  KMX_HIP(hipHostMalloc((void **)&host_counters_, 8 * sizeof(uint32_t), hipHostMallocDefault), kMemoryAllocationFailure);
+  KMX_HIP(hipMemsetAsync(counters_, 0, 16 * sizeof(uint32_t), stream_), kRuntimeError);
   return kSuccess;
 }
 
@@ -148,6 +148,7 @@ int Engine::prepare_centroids(const float *centroids) {
 int Engine::yy_configure(uint32_t G, const uint32_t *groups_host) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   if (const char *v = getenv("KMCUDA_AMD_YY_EXACT")) yy_exact_ = atoi(v) != 0;
+  if (const char *v = getenv("KMCUDA_AMD_YY_HINT")) yy_hint_ = atoi(v) != 0;
   G_ = G;
   // centroids in group order; group >= G (a NaN centroid keeps the 0xFFFFFFFF "assignment" of
   // its failed search, kmeans.cu:468-471) is left out
@@ -181,7 +182,17 @@ int Engine::yy_configure(uint32_t G, const uint32_t *groups_host) {
   }
   while (pmeta.size() < pids.size() / 4) pmeta.push_back(((G ? G - 1 : 0) << 1));
   nslots_ = (uint32_t)pids.size();
+  // the two smallest member indices of every group: where the reference's ascending scan first meets it
+  std::vector<uint32_t> gfirst(G ? G : 1, 0xFFFFFFFFu), gsecond(G ? G : 1, 0xFFFFFFFFu);
+  for (uint32_t g = 0; g < G; g++) {
+    if (gstart[g + 1] - gstart[g] >= 1) gfirst[g] = cperm[gstart[g]];       // cperm is ascending inside a group
+    if (gstart[g + 1] - gstart[g] >= 2) gsecond[g] = cperm[gstart[g] + 1];
+  }
   int rc;
+  if ((rc = alloc(&gfirst_, gfirst.size()))) return rc;
+  if ((rc = alloc(&gsecond_, gsecond.size()))) return rc;
+  KMX_HIP(hipMemcpy(gfirst_, gfirst.data(), gfirst.size() * sizeof(uint32_t), hipMemcpyHostToDevice), kMemoryCopyError);
+  KMX_HIP(hipMemcpy(gsecond_, gsecond.data(), gsecond.size() * sizeof(uint32_t), hipMemcpyHostToDevice), kMemoryCopyError);
   if ((rc = alloc(&groups_, K_))) return rc;
   if ((rc = alloc(&cperm_, cperm.size()))) return rc;
   if ((rc = alloc(&gstart_, G + 1))) return rc;
@@ -203,7 +214,8 @@ static void fill_yy_args(Engine &e, YyArgs &a, const float *samples, const float
   a.len = e.N_; a.D = e.D_; a.DP = e.DP_; a.K = e.K_; a.K_pad = e.K_pad_; a.G = e.G_;
   a.cfil = e.cfil_; a.bias = e.bias_; a.mu = e.mu_; a.stats = e.stats_; a.eps = e.eps_;
   a.groups = e.groups_; a.drifts = nullptr; a.gdrifts = nullptr; a.assignments = nullptr; a.bounds = nullptr;
-  a.passed = nullptr; a.counters = e.counters_;
+  a.passed = nullptr; a.counters = e.counters_; a.count_ptr = e.counters_ + 2;
+  a.panelhi = nullptr; a.hint = nullptr; a.flag_rows = nullptr; a.gfirst = e.gfirst_; a.gsecond = e.gsecond_;
   a.pfil = e.pfil_; a.pbias = e.pbias_; a.pids = e.pids_; a.pmeta = e.pmeta_; a.cperm = e.cperm_;
   a.gstart = e.gstart_; a.nslots = e.nslots_;
 }
@@ -251,6 +263,27 @@ int Engine::yy_filters(const float *samples, const float *centroids, const float
     YyArgs a;
     fill_yy_args(*this, a, samples, centroids);
     a.drifts = drifts; a.gdrifts = gdrifts; a.assignments = assignments; a.bounds = bounds; a.passed = passed;
+    if (yy_hint_ && yy_hint_supported(DP_)) {
+      // second-best estimate per passed row, the local filter against it, the plain kernel for the rest
+      if (!yy_hint_buf_) {
+        uint16_t *p16 = nullptr, *phi = nullptr;
+        if ((rc = alloc(&p16, (size_t)K_pad_ * 2 * DP_))) return rc;
+        if ((rc = alloc(&phi, (size_t)((K_pad_ + 63u) / 64u * 64u) * (DP_ + 2)))) return rc;
+        if ((rc = alloc(&yy_flag_rows_, N_))) return rc;
+        if ((rc = alloc(&yy_hint_buf_, N_))) return rc;
+        yy_panel16_ = p16;
+        yy_panelhi_ = phi;
+      }
+      KMX_HIP(launch_centroid_panel16(centroids, K_, D_, K_pad_, DP_, finite_, mu_, bias_, yy_panel16_, yy_panelhi_,
+                                      stats_, stream_),
+              kRuntimeError);
+      KMX_HIP(hipMemsetAsync(counters_ + 5, 0, sizeof(uint32_t), stream_), kRuntimeError);
+      a.panelhi = yy_panelhi_; a.hint = yy_hint_buf_; a.flag_rows = yy_flag_rows_;
+      KMX_HIP(launch_yy_hint(metric_, a, stream_), kRuntimeError);
+      KMX_HIP(launch_yy_local_hint(metric_, a, stream_), kRuntimeError);
+      a.passed = yy_flag_rows_;
+      a.count_ptr = counters_ + 5;
+    }
     KMX_HIP(launch_yy_local_mfma(metric_, a, stream_), kRuntimeError);
     return kSuccess;
   }
@@ -418,6 +451,15 @@ int Engine::counters_read(uint32_t *host4) {
   return kSuccess;
 }
 
+int Engine::yy_hint_stats(uint32_t *host6) {
+  KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  KMX_HIP(hipMemcpyAsync(host_counters_, counters_ + 6, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_),
+          kMemoryCopyError);
+  KMX_HIP(hipStreamSynchronize(stream_), kRuntimeError);
+  memcpy(host6, host_counters_, 6 * sizeof(uint32_t));
+  return kSuccess;
+}
+
 int Engine::counters_reset(int which) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   if (which < 0) KMX_HIP(hipMemsetAsync(counters_, 0, 4 * sizeof(uint32_t), stream_), kRuntimeError);
@@ -470,6 +512,7 @@ int kmamd_lloyd_assign_exact(kmamd_engine *e, const float *samples, const float 
 }
 int kmamd_counters_read(kmamd_engine *e, uint32_t *host_out4) { return e->e.counters_read(host_out4); }
 int kmamd_counters_reset(kmamd_engine *e, int which) { return e->e.counters_reset(which); }
+int kmamd_yy_hint_stats(kmamd_engine *e, uint32_t *host_out6) { return e->e.yy_hint_stats(host_out6); }
 int kmamd_move_deltas(kmamd_engine *e, const float *samples, const uint32_t *assignments_prev,
                       const uint32_t *assignments, double *delta, int32_t *dcount) {
   return e->e.move_deltas(samples, assignments_prev, assignments, delta, dcount);

@@ -103,6 +103,11 @@ class Engine {
   // Yinyang
   uint32_t G_ = 0, nslots_ = 0;
   bool yy_exact_ = false;  // KMCUDA_AMD_YY_EXACT=1: plain exact kernels (cross-check)
+  bool yy_hint_ = true;    // KMCUDA_AMD_YY_HINT=0: local filter without the second-best estimate (yinyang_hint.hip)
+  uint32_t *gfirst_ = nullptr, *gsecond_ = nullptr, *yy_flag_rows_ = nullptr;
+  float *yy_hint_buf_ = nullptr;
+  void *yy_panel16_ = nullptr, *yy_panelhi_ = nullptr;
+  int yy_hint_stats(uint32_t *host6);
   uint32_t *groups_ = nullptr, *cperm_ = nullptr, *gstart_ = nullptr, *pids_ = nullptr, *pmeta_ = nullptr;
   float *pfil_ = nullptr, *pbias_ = nullptr, *xt_ = nullptr;
   float *exact_work_ = nullptr;  // adjust_exact scratch when 64 centroid rows exceed LDS (lazy)

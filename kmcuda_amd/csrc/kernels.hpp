@@ -130,7 +130,13 @@ struct YyArgs {
   uint32_t *assignments;
   float *bounds;
   const uint32_t *passed;
-  uint32_t *counters;
+  const uint32_t *count_ptr; // length of `passed` (counters + 2, or counters + 5 for the fall-back list)
+  uint32_t *counters;        // + [5] rows of the hinted kernel handed to the plain one, [6] / [7] running totals
+  // hinted local filter (yinyang_hint.hip)
+  const void *panelhi;       // hi halves of the centred panel (centroid_panel16_kernel), DP halves per row
+  float *hint;               // per passed row: S' >= upper bound (or +inf: no hint)
+  uint32_t *flag_rows;       // rows the hinted kernel could not settle
+  const uint32_t *gfirst, *gsecond;  // G: the two smallest member indices of every group (0xFFFFFFFF: none)
   // yy_init: group-sorted padded panel
   const float *pfil, *pbias;
   const uint32_t *pids, *pmeta, *cperm, *gstart;
@@ -138,6 +144,11 @@ struct YyArgs {
 };
 hipError_t launch_yy_local_mfma(int metric, const YyArgs &a, hipStream_t st);
 hipError_t launch_yy_init_mfma(int metric, const YyArgs &a, hipStream_t st);
+// yinyang_hint.hip: coarse second-best estimate per passed row (f16 matrix cores), then the local filter
+// with that estimate as its candidate threshold; rows it cannot settle go to flag_rows (counters[5])
+bool yy_hint_supported(uint32_t DP);
+hipError_t launch_yy_hint(int metric, const YyArgs &a, hipStream_t st);
+hipError_t launch_yy_local_hint(int metric, const YyArgs &a, hipStream_t st);
 hipError_t launch_yy_sorted_panel(const float *cfil, const float *bias, uint32_t DP, const uint32_t *pids,
                                   uint32_t nslots, float *pfil, float *pbias, hipStream_t st);
 hipError_t launch_yy_global_filter(int metric, const float *samples, uint32_t len, uint32_t D, uint32_t K, uint32_t G,

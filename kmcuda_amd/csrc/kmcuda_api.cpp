@@ -757,7 +757,19 @@ class Job {
         uint32_t passed_total = 0;
         const int status = check_changed(iter, tolerance, true, &passed_total);
         if (status < 0) return -status;
-        if (status == 1) return 0;
+        if (status == 1) {
+          if (verbosity > 1) {
+            for (auto &s : shards) {
+              uint32_t hs[6] = {0, 0, 0, 0, 0, 0};
+              (void)hipSetDevice(s->dev);
+              if (s->eng->yy_hint_stats(hs) == 0 && hs[0])
+                printf("local filter with the second-best estimate: %u rows, %u of them handed to the plain kernel "
+                       "(no estimate %u, bound not holding %u, candidate bound %u, second minimum %u)\n",
+                       hs[0], hs[1], hs[2], hs[3], hs[4], hs[5]);
+            }
+          }
+          return 0;
+        }
         DEBUG("passed number: %u\n", passed_total);
         if (1.f - (passed_total + 0.f) / N < kYinyangRefreshEpsilon) refresh = true;  // kmeans.cu:1136-1138
       }

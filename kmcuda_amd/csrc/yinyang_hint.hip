@@ -1,0 +1,472 @@
+// yinyang_hint.hip -- kmeans_yy_local_filter (reference: src/kmeans.cu:584-672) with a per-row
+// estimate of the FINAL second-best distance as the candidate threshold.
+//
+// yy_local_mfma_kernel (yinyang_mfma.hip) evaluates the reference's exact distance for every
+// centroid whose approximate distance could be below the LIVE second minimum of the reference's
+// scan.  The live value starts at FLT_MAX and falls as the scan meets closer centroids, so on data
+// without cluster structure a row pays ~40 exact distances where 2 matter.  Here a first kernel
+// (yy_hint_kernel: one f16 matrix-core product per 16 features, hi halves only, a best-two
+// bookkeeping of 3 VALU operations per score) estimates the row's second-best centroid and the
+// local filter takes candidates against  S' = max(upper bound, that estimate)  instead.
+//
+// S' is only a number: nothing below relies on its quality, only on  S' >= upper bound.  Write R
+// for the reference's scan of the row and O for ours.  Both keep (min, nearest, second) where
+// second is the second smallest of a multiset: {upper bound} + the exact distances evaluated so
+// far + the group bounds folded by the (a) rule (group bound >= upper bound: second = min(second,
+// bound), never evaluated).  O differs from R in three ways:
+//   (1) it never looks at a centroid whose f32 matrix-core score rules out d <= min(second_O, S')
+//       (rigorous bound, as in yinyang_mfma.hip);
+//   (2) it folds the (a) bounds that are <= S' all at once, before the scan, and ignores the larger ones;
+//   (3) it therefore applies the (b) test "second < bound + drifts -> skip" with its own second.
+// Call X the values above S' that R's second has absorbed and O never saw (centroids of (1), bounds of
+// (2)).  Claim: second_O <= second_R whenever second_R is not one of X, and min / nearest agree.
+//   * What (1) drops cannot lower R's minimum (d > min(second_O, S') >= min) and lowers R's second only
+//     with a value above S': an X.
+//   * R skips, O evaluates: second_R < bound <= second_O, so second_R is an X and bound > S' -- FLAGGED (F1).
+//   * O skips, R evaluates: second_O < bound <= second_R, so second_O is an early-folded group bound b
+//     (everything else in O's multiset is in R's).  O has the exact distance anyway (a flush evaluates
+//     its whole queue first): if d < bound the row is FLAGGED (F3); else d >= bound > b >= upper bound
+//     >= min, so in R this centroid never becomes the minimum and stops mattering for the second
+//     once R folds b itself -- until then second_O <= b < d keeps the claim.
+//   * Both evaluate: the same exact distance and the same update on both sides.
+//   * At the end R has folded every group bound, so second_R = min(second_O, X): equal to second_O iff
+//     second_O <= S', else FLAGGED (F2).
+// Flagged rows (also: no estimate) are left untouched and appended to flag_rows; the engine runs
+// yy_local_mfma_kernel -- the reference's scan replayed state for state -- over that list.  Every
+// row's outcome is therefore the reference's, bit for bit, whatever the estimate was.
+#include "yinyang_tiles.hpp"
+
+namespace kmx {
+
+typedef _Float16 f16x8h __attribute__((ext_vector_type(8)));
+
+// ---------------------------------------------------------------------------------------
+// the estimate: best two coarse scores of every passed row
+// ---------------------------------------------------------------------------------------
+template <int DP, int METRIC, bool FAST>
+__global__ __launch_bounds__(256, 2) void yy_hint_kernel(YyArgs a) {
+  constexpr int NK = DP / 2, KS = NK / 8, LDWH = DP / 2 + 4, TILE = 32 * LDWH, NSTH = (4 * DP + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  auto tile_ptr = [&](int buf) { return lds + buf * TILE; };
+  auto bias_ptr = [&](int buf) { return lds + 2 * TILE + buf * 32; };
+
+  const uint32_t npassed = *a.count_ptr;
+  if (blockIdx.x * 128u >= npassed) return;  // block-uniform
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+  const uint32_t D = a.D, K = a.K, G = a.G, len = a.len;
+  const uint32_t pi = blockIdx.x * 128u + wave * 32u + col;
+  const bool live = pi < npassed;
+  const uint32_t s = live ? a.passed[pi] : 0u;
+
+  f16x8h xh[KS];
+  float xc2h, xmuh;
+  {
+    KMX_YY_LOAD_ROWS(a.samples, s, live)
+    (void)xo2; (void)xrow;
+#pragma unroll
+    for (int j = 0; j < KS; j++) {
+      f16x8h v;
+#pragma unroll
+      for (int q = 0; q < 8; q++) v[q] = (_Float16)xb[8 * j + q];
+      xh[j] = v;
+    }
+    xc2h = xc2;
+    xmuh = xmu;
+  }
+  const float xc2 = xc2h, xmu = xmuh;
+
+  f32x4 stage[NSTH];
+  float bstage = 0.f;
+  auto stage_load = [&](uint32_t tile) {
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(reinterpret_cast<const _Float16 *>(a.panelhi) + (size_t)tile * 32 * DP);
+#pragma unroll
+    for (int i = 0; i < NSTH; i++) {
+      const int q = tid + i * 256;
+      if (q < 4 * DP) stage[i] = src[q];
+    }
+    if (tid < 32) bstage = a.bias[tile * 32 + tid];
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NSTH; i++) {
+      const int q = tid + i * 256;
+      if (q < 4 * DP) {
+        const int row = q / (DP / 8), c8 = q % (DP / 8);
+        *reinterpret_cast<f32x4 *>(tile_ptr(buf) + row * LDWH + c8 * 4) = stage[i];
+      }
+    }
+    if (tid < 32) bias_ptr(buf)[tid] = bstage;
+  };
+
+  // best two scores of my 16 accumulator rows per tile; the register number rides in the low 4
+  // mantissa bits, the tile index is noted once per tile
+  float v1 = -INFINITY, v2 = -INFINITY;
+  uint32_t t1 = 0, t2 = 0;
+  const uint32_t ntiles = a.K_pad / 32;
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  for (uint32_t t = 0; t < ntiles; t++) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) stage_load(t + 1);
+    f32x16 acc;
+    {
+      const float *bb = bias_ptr(buf) + 4 * h;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bb + 8 * g4);
+        acc[4 * g4 + 0] = b4.x; acc[4 * g4 + 1] = b4.y; acc[4 * g4 + 2] = b4.z; acc[4 * g4 + 3] = b4.w;
+      }
+      const _Float16 *arow = reinterpret_cast<const _Float16 *>(tile_ptr(buf) + col * LDWH) + h * NK;
+#pragma unroll
+      for (int j = 0; j < KS; j++) {
+        const f16x8h af = *reinterpret_cast<const f16x8h *>(arow + 8 * j);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xh[j], acc, 0, 0, 0);
+      }
+    }
+    const float o1 = v1, o2 = v2;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float v = __uint_as_float((__float_as_uint(acc[r]) & ~15u) | (uint32_t)r);
+      v2 = __builtin_amdgcn_fmed3f(v1, v2, v);
+      v1 = fmaxf(v1, v);
+    }
+    const uint32_t n1 = (v1 == o1) ? t1 : ((v1 == o2) ? t2 : t);
+    const uint32_t n2 = (v2 == o1) ? t1 : ((v2 == o2) ? t2 : t);
+    t1 = n1;
+    t2 = n2;
+    if (t + 1 < ntiles) stage_store(buf ^ 1);
+    __syncthreads();
+  }
+
+  // the better of the (up to four) noted centroids that is neither the row's own nor groupless
+  const float pv1 = __shfl_xor(v1, 32), pv2 = __shfl_xor(v2, 32);
+  const uint32_t pt1 = __shfl_xor(t1, 32), pt2 = __shfl_xor(t2, 32);
+  if (!live || h != 0) return;
+  const float upper_bound = a.bounds[s];
+  const uint32_t cluster = a.assignments[s];
+  const float cv[4] = {v1, v2, pv1, pv2};
+  const uint32_t ct[4] = {t1, t2, pt1, pt2};
+  float best = -INFINITY;
+  uint32_t best_g = 0xFFFFFFFFu;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint32_t r = __float_as_uint(cv[i]) & 15u;
+    const uint32_t c = ct[i] * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (i >= 2 ? 1u : 0u);
+    if (c < K && c != cluster && cv[i] > best) {
+      const uint32_t g = a.groups[c];
+      if (g < G) {
+        best = cv[i];
+        best_g = g;
+      }
+    }
+  }
+  float hint = INFINITY;
+  if (best_g < G) {
+    const float lbg = a.bounds[(size_t)len * (1 + best_g) + s];
+    float y;
+    if (lbg >= upper_bound) {
+      y = lbg;  // an (a) group: its bound itself enters the second minimum
+    } else {
+      // typical rounding of the hi.hi products (a fraction of the worst case 2^-10 ||x'|| C'max; the
+      // fraction only trades candidates against flagged rows), 16 ulp for the register number
+      const float cmaxc = sqrtf(__uint_as_float(a.stats[0]));
+      const float xc = sqrtf(xc2);
+      const float frac = fminf(1.0f, 4.0f / sqrtf((float)DP));
+      const float e_h = 9.8e-4f * frac * xc * cmaxc + 4e-6f * fabsf(best) + 1e-6f * xc2;
+      if (METRIC == 0) {
+        y = sqrtf(fmaxf(xc2 - 2.0f * (best - e_h), 0.f)) * 1.00001f;
+      } else {
+        const float dot = best + xmu - e_h;
+        y = (dot >= 1.f ? 0.f : (dot <= -1.f ? 3.1415927f : acosf(dot))) * 1.00001f + 1e-6f;
+      }
+    }
+    hint = fmaxf(upper_bound, y);  // a NaN y leaves the upper bound
+    if (!(hint >= upper_bound)) hint = INFINITY;
+  }
+  a.hint[pi] = hint;
+}
+
+// ---------------------------------------------------------------------------------------
+// the local filter against the estimate
+// ---------------------------------------------------------------------------------------
+template <int DP, int METRIC, bool FAST>
+__global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
+  constexpr int NK = DP / 2, LDW = DP + 4, TILE = 32 * LDW, NST = (8 * DP + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  auto tile_ptr = [&](int buf) { return lds + buf * TILE; };
+  auto bias_ptr = [&](int buf) { return lds + 2 * TILE + buf * 32; };
+  auto grp_ptr = [&](int buf) { return reinterpret_cast<uint32_t *>(lds + 2 * TILE + 64) + buf * 32; };
+
+  const uint32_t npassed = *a.count_ptr;
+  if (blockIdx.x * 128u >= npassed) return;  // block-uniform
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+  const uint32_t D = a.D, K = a.K, G = a.G, len = a.len;
+  const uint32_t pi = blockIdx.x * 128u + wave * 32u + col;
+  const bool live = pi < npassed;
+  const uint32_t s = live ? a.passed[pi] : 0u;
+
+  KMX_YY_LOAD_ROWS(a.samples, s, live)
+
+  const float upper_bound = live ? a.bounds[s] : 0.f;
+  const uint32_t cluster = live ? a.assignments[s] : 0xFFFFFFFFu;
+  const float hint = live ? a.hint[pi] : INFINITY;
+  float min_dist = upper_bound, second_min = kFltMax;
+  uint32_t nearest = cluster;
+  bool bad = !(hint < INFINITY);  // no estimate (or a dead lane): the plain kernel's row
+  uint32_t why = bad ? 1u : 0u;   // statistics: first reason the row was handed over
+
+  // (a) groups (bound >= upper bound) whose bound can still matter (<= S'): folded up front
+  {
+    float alow = kFltMax;
+    if (!bad) {
+      for (uint32_t g = h; g < G; g += 2) {
+        const float lb = a.bounds[(size_t)len * (1 + g) + s];
+        if (lb >= upper_bound && lb <= hint && lb < alow) {
+          uint32_t p = a.gfirst[g];
+          if (p == cluster) p = a.gsecond[g];
+          if (p != 0xFFFFFFFFu) alow = lb;  // the group has a member the reference's scan meets
+        }
+      }
+    }
+    const float other = __shfl_xor(alow, 32);
+    second_min = other < alow ? other : alow;
+  }
+
+  // threshold in accumulator space (yinyang_mfma.hip): a centroid can only matter if acc >= amin
+  const float cmaxc = sqrtf(__uint_as_float(a.stats[0])) * 1.000001f;
+  const float bmaxc = __uint_as_float(a.stats[1]);
+  const float xo = sqrtf(xo2) * 1.0001f, xc = sqrtf(xc2) * 1.0001f;
+  const float e_mfma = 2.0f * a.eps * (xc * cmaxc + bmaxc) * 1.01f;
+  const float e_cos = e_mfma + a.eps * xo * sqrtf(__uint_as_float(a.stats[3])) * 1.01f + 1e-6f;
+  auto amin_of = [&](float sm) -> float {
+    if (METRIC == 0) {
+      const float T2 = sm * sm * 1.000002f;
+      return 0.5f * (xc2 - T2) - e_mfma - 1e-6f * (xc2 + T2);
+    }
+    if (sm >= 3.1415925f) return -INFINITY;
+    return cosf(sm) - xmu - e_cos;
+  };
+  float amin = amin_of(fminf(second_min, hint));
+
+  f32x4 stage[NST];
+  float bstage = 0.f;
+  uint32_t gstage = 0;
+  auto stage_load = [&](uint32_t tile) {
+    const float *src = a.cfil + (size_t)tile * 32 * DP;
+#pragma unroll
+    for (int i = 0; i < NST; i++) {
+      const int q = tid + i * 256;
+      if (q < 8 * DP) stage[i] = reinterpret_cast<const f32x4 *>(src)[q];
+    }
+    if (tid < 32) {
+      const uint32_t c = tile * 32 + tid;
+      bstage = a.bias[c];
+      gstage = c < K ? a.groups[c] : 0xFFFFFFFFu;
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NST; i++) {
+      const int q = tid + i * 256;
+      if (q < 8 * DP) {
+        const int row = q / (DP / 4), c4 = q % (DP / 4);
+        *reinterpret_cast<f32x4 *>(tile_ptr(buf) + row * LDW + c4 * 4) = stage[i];
+      }
+    }
+    if (tid < 32) {
+      bias_ptr(buf)[tid] = bstage;
+      grp_ptr(buf)[tid] = gstage;
+    }
+  };
+
+  // queue of candidates (ascending c)
+  uint32_t qc[4] = {0, 0, 0, 0};
+  int qn = 0;
+  uint32_t n_flush = 0, n_cand = 0;
+  auto flush = [&]() {  // wave-uniform call
+    n_flush++;
+    const float *crow[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) crow[i] = a.centroids + (size_t)(i < qn ? qc[i] : 0) * D;
+    float dist[4];
+    exact_distance4<NK, METRIC, FAST>(xrow, crow, D, h, col, dist);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (i < qn) {
+        const uint32_t c = qc[i];
+        const uint32_t g = a.groups[c];
+        float lb = a.bounds[(size_t)len * (1 + g) + s];
+        lb += a.gdrifts[g] - a.drifts[(size_t)K * D + c];    // kmeans.cu:637
+        if (!(second_min < lb)) {                            // :638-640
+          if (lb > hint) {                                   // F1: the reference may have skipped it
+            bad = true;
+            if (!why) why = 3u;
+          }
+          const float d = dist[i];                           // :641-652
+          if (d < min_dist) {
+            second_min = min_dist;
+            min_dist = d;
+            nearest = c;
+          } else if (d < second_min) {
+            second_min = d;
+          }
+        } else if (dist[i] < lb) {                           // F3: skipped here on the strength of a bound
+          bad = true;                                        // that does not hold; the reference may not have
+          if (!why) why = 2u;                                // skipped it (its second minimum lags ours)
+        }
+      }
+    }
+    qn = 0;
+    amin = amin_of(fminf(second_min, hint));
+  };
+
+  const uint32_t ntiles = a.K_pad / 32;
+  const bool wave_live = __ballot(live && !bad) != 0ull;
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  for (uint32_t t = 0; t < ntiles; t++) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) stage_load(t + 1);
+    if (wave_live) {
+      KMX_YY_MFMA_TILE(acc, buf)
+      uint32_t m16 = 0;
+      if (live && !bad) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          if (acc[r] >= amin) m16 |= 1u << r;
+      }
+      if (__ballot(m16 != 0u) != 0ull) {
+        const uint32_t pm = __shfl_xor(m16, 32);
+        const uint32_t m0 = h ? pm : m16, m1 = h ? m16 : pm;
+        uint32_t rowmask = 0;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++)
+          rowmask |= (((m0 >> (4 * g4)) & 0xFu) << (8 * g4)) | (((m1 >> (4 * g4)) & 0xFu) << (8 * g4 + 4));
+        while (__ballot(rowmask != 0u) != 0ull) {
+          if (__ballot(qn == 4) != 0ull) flush();  // some row's queue is full
+          const bool active = rowmask != 0u;
+          const uint32_t rho = active ? (uint32_t)__ffs((int)rowmask) - 1u : 0u;
+          rowmask &= rowmask - 1u;
+          if (active) {
+            const uint32_t c = t * 32 + rho;
+            const uint32_t g = grp_ptr(buf)[rho];
+            if (g < G && c != cluster) {  // g >= G: NaN centroid or padding
+              const float lbg = a.bounds[(size_t)len * (1 + g) + s];
+              if (!(lbg >= upper_bound)) {  // else an (a) centroid: an event if its bound is <= S'
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                  if (i == qn) qc[i] = c;
+                qn++;
+                n_cand++;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (t + 1 < ntiles) stage_store(buf ^ 1);
+    __syncthreads();
+  }
+  if (wave_live && __ballot(qn > 0) != 0ull) flush();
+  if (!(second_min <= hint)) {  // F2: the reference's second minimum may be a value we never saw
+    bad = true;
+    if (!why) why = 4u;
+  }
+
+  // write-back, kmeans.cu:653-671 -- or hand the row to the plain kernel, untouched
+  bool changed = false;
+  const bool mine = live && h == 0;
+  if (mine && !bad) {
+    const uint32_t nearest_group = a.groups[nearest], previous_group = a.groups[cluster];
+    a.bounds[(size_t)len * (1 + nearest_group) + s] = second_min;
+    if (nearest_group != previous_group) {
+      const size_t gi = (size_t)len * (1 + previous_group) + s;
+      const float pb = a.bounds[gi];
+      if (pb > upper_bound) a.bounds[gi] = upper_bound;
+    }
+    a.bounds[s] = min_dist;
+    if (cluster != nearest) {
+      a.assignments[s] = nearest;
+      changed = true;
+    }
+  }
+  const unsigned long long cm = __ballot(changed);
+  if (lane == 0 && cm) atomicAdd(&a.counters[0], (uint32_t)__popcll(cm));
+  const unsigned long long fm = __ballot(mine && bad);
+  if (fm) {
+    uint32_t base = 0;
+    if (lane == 0) {
+      base = atomicAdd(&a.counters[5], (uint32_t)__popcll(fm));
+      atomicAdd(&a.counters[7], (uint32_t)__popcll(fm));
+    }
+    base = __shfl(base, 0);
+    if (mine && bad) a.flag_rows[base + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = s;
+  }
+  {  // statistics (not part of the reference's state)
+    uint32_t nc = (mine && !bad) ? n_cand : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nc += __shfl_xor(nc, off);
+    const uint32_t nmine = (uint32_t)__popcll(__ballot(mine));
+    uint32_t nwhy[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) nwhy[w] = (uint32_t)__popcll(__ballot(mine && why == (uint32_t)(w + 1)));
+    if (lane == 0) {
+      atomicAdd(&a.counters[3], nc);
+      atomicAdd(&a.counters[1], n_flush);
+      atomicAdd(&a.counters[6], nmine);
+#pragma unroll
+      for (int w = 0; w < 4; w++)
+        if (nwhy[w]) atomicAdd(&a.counters[8 + w], nwhy[w]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------
+bool yy_hint_supported(uint32_t DP) { return DP >= 16 && DP <= 256; }
+
+template <int DP, int METRIC>
+static hipError_t launch_hint_t(const YyArgs &a, hipStream_t st) {
+  const size_t lds_bytes = (2 * 32 * (DP / 2 + 4) + 64) * sizeof(float);
+  const uint32_t grid = (a.len + 127) / 128;  // worst case; blocks beyond the passed count exit at once
+  if (a.D == (uint32_t)DP)
+    hipLaunchKernelGGL((yy_hint_kernel<DP, METRIC, true>), dim3(grid), dim3(256), lds_bytes, st, a);
+  else
+    hipLaunchKernelGGL((yy_hint_kernel<DP, METRIC, false>), dim3(grid), dim3(256), lds_bytes, st, a);
+  return hipGetLastError();
+}
+template <int DP, int METRIC>
+static hipError_t launch_local_hint_t(const YyArgs &a, hipStream_t st) {
+  const size_t lds_bytes = (2 * 32 * (DP + 4) + 64 + 64) * sizeof(float);
+  const uint32_t grid = (a.len + 127) / 128;
+  if (a.D == (uint32_t)DP)
+    hipLaunchKernelGGL((yy_local_hint_kernel<DP, METRIC, true>), dim3(grid), dim3(256), lds_bytes, st, a);
+  else
+    hipLaunchKernelGGL((yy_local_hint_kernel<DP, METRIC, false>), dim3(grid), dim3(256), lds_bytes, st, a);
+  return hipGetLastError();
+}
+
+#define KMX_YYH_SWITCH(fn)                                                             \
+  switch (a.DP) {                                                                      \
+    case 16: return metric == 0 ? fn<16, 0>(a, st) : fn<16, 1>(a, st);                 \
+    case 32: return metric == 0 ? fn<32, 0>(a, st) : fn<32, 1>(a, st);                 \
+    case 64: return metric == 0 ? fn<64, 0>(a, st) : fn<64, 1>(a, st);                 \
+    case 128: return metric == 0 ? fn<128, 0>(a, st) : fn<128, 1>(a, st);              \
+    case 256: return metric == 0 ? fn<256, 0>(a, st) : fn<256, 1>(a, st);              \
+    default: return hipErrorInvalidValue;                                              \
+  }
+
+hipError_t launch_yy_hint(int metric, const YyArgs &a, hipStream_t st) {
+  if (a.len == 0) return hipSuccess;
+  KMX_YYH_SWITCH(launch_hint_t)
+}
+
+hipError_t launch_yy_local_hint(int metric, const YyArgs &a, hipStream_t st) {
+  if (a.len == 0) return hipSuccess;
+  KMX_YYH_SWITCH(launch_local_hint_t)
+}
+
+}  // namespace kmx

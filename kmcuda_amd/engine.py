@@ -126,6 +126,14 @@ class Engine:
                                              self._p(gdrifts), self._p(assignments), self._p(assignments_prev),
                                              self._p(bounds), self._p(passed)), "kmamd_yy_filters")
 
+    def yy_hint_stats(self):
+        """[rows the hinted local filter processed, rows it handed to the plain kernel, then the hand-overs
+        by first reason: no estimate, skipped candidate below its bound, candidate bound above the estimate, final second
+        minimum above the estimate] since creation."""
+        out = (ctypes.c_uint32 * 6)()
+        _lib.check(self.lib.kmamd_yy_hint_stats(self.h, out), "kmamd_yy_hint_stats")
+        return list(out)
+
     def sync(self):
         _lib.check(self.lib.kmamd_engine_sync(self.h), "kmamd_engine_sync")
 

@@ -18,7 +18,7 @@ def _t(a, dev):
     return torch.from_numpy(numpy.ascontiguousarray(a)).to(dev)
 
 
-@pytest.mark.parametrize("mode", ["mfma", "exact"])
+@pytest.mark.parametrize("mode", ["mfma", "nohint", "exact"])
 @pytest.mark.parametrize("n,d,k,G,metric", [(3000, 2, 50, 5, "L2"), (2500, 33, 64, 6, "L2"),
                                             (4000, 256, 128, 12, "L2"), (5000, 256, 1024, 102, "L2"),
                                             (3000, 64, 50, 7, "L2"), (2000, 64, 40, 4, "cos")])
@@ -29,6 +29,7 @@ def test_yinyang_steps_bit_exact(n, d, k, G, metric, mode, monkeypatch):
     after one global+local filter pass."""
     from kmcuda_amd.engine import Engine
     monkeypatch.setenv("KMCUDA_AMD_YY_EXACT", "1" if mode == "exact" else "0")
+    monkeypatch.setenv("KMCUDA_AMD_YY_HINT", "0" if mode == "nohint" else "1")
     dev = torch.device("cuda", 0)
     rs = numpy.random.RandomState(n + d)
     x = rs.rand(n, d).astype(numpy.float32)
@@ -86,6 +87,70 @@ def test_yinyang_steps_bit_exact(n, d, k, G, metric, mode, monkeypatch):
     assert counters[0] == rchanged
     assert (prev.cpu().numpy().view(numpy.uint32) == rprev).all()
     assert (gb.cpu().numpy().reshape(G + 1, n).view(numpy.uint32) == rb.view(numpy.uint32)).all()
+    eng.close()
+
+
+@pytest.mark.parametrize("hint", [True, False])
+@pytest.mark.parametrize("n,d,k,G,data", [(6000, 256, 256, 25, "uniform"), (8000, 64, 100, 10, "uniform"),
+                                          (5000, 16, 64, 6, "uniform"), (6000, 256, 128, 12, "blobs"),
+                                          (4000, 100, 60, 6, "blobs"), (3000, 24, 200, 20, "uniform")])
+def test_yinyang_many_passes_bit_exact(n, d, k, G, data, hint, monkeypatch):
+    """Six consecutive update + drift + filter passes against the oracle: bounds, assignments and
+    the passed set stay BIT-EXACT from pass to pass, with the local filter's second-best estimate
+    (yinyang_hint.hip: estimate kernel, hinted kernel, plain kernel for the rows it hands over) and
+    without it (KMCUDA_AMD_YY_HINT=0)."""
+    from kmcuda_amd.engine import Engine
+    monkeypatch.setenv("KMCUDA_AMD_YY_EXACT", "0")
+    monkeypatch.setenv("KMCUDA_AMD_YY_HINT", "1" if hint else "0")
+    dev = torch.device("cuda", 0)
+    rs = numpy.random.RandomState(n + d + k)
+    if data == "uniform":
+        x = rs.rand(n, d).astype(numpy.float32)
+    else:
+        x = numpy.concatenate([rs.randn(n // 10, d) + 3 * rs.randn(1, d) for _ in range(10)]).astype(numpy.float32)
+        x = x[rs.permutation(len(x))]
+    n = len(x)
+    c0 = x[rs.choice(n, k, replace=False)].copy()
+    a_prev, p_prev, _ = oracle.lloyd_assign(x, c0)
+    cen, cc = oracle.adjust(x, p_prev, a_prev, c0, numpy.zeros(k, numpy.uint32))
+    asg, prv, _ = oracle.lloyd_assign(x, cen, assignments=a_prev)
+    groups = (rs.permutation(k) % G).astype(numpy.uint32)
+    bounds = oracle.yy_init(x, cen, asg, groups, G)
+
+    eng = Engine(n, d, k, "L2", device=0)
+    eng.yy_configure(G, groups)
+    xs = _t(x, dev)
+    gb = _t(bounds.ravel().copy(), dev)
+    gasg = _t(asg, dev)
+    gprev = torch.empty(n, dtype=torch.int32, device=dev)
+    passed = torch.empty(n, dtype=torch.int32, device=dev)
+    dr = torch.empty(k * d + k, dtype=torch.float32, device=dev)
+    gdr = torch.empty(G, dtype=torch.float32, device=dev)
+    total_passed = 0
+    for it in range(6):
+        new_cen, cc = oracle.adjust(x, prv, asg, cen, cc)
+        drifts = oracle.yy_drifts(cen, new_cen, groups, G)
+        asg, prv, bounds, rpassed, rchanged = oracle.yy_filters(x, new_cen, groups, G, drifts, asg, bounds)
+        dr[:k * d] = _t(cen, dev).ravel()
+        gcen = _t(new_cen, dev)
+        eng.yy_drifts(gcen, dr, gdr)
+        eng.reset_counters(-1)
+        eng.yy_filters(xs, gcen, dr, gdr, gasg, gprev, gb, passed)
+        counters = eng.counters()
+        assert counters[2] == len(rpassed), "pass %d" % it
+        assert counters[0] == rchanged, "pass %d" % it
+        assert (gasg.cpu().numpy().view(numpy.uint32) == asg).all(), "pass %d" % it
+        assert (gb.cpu().numpy().reshape(G + 1, n).view(numpy.uint32) == bounds.view(numpy.uint32)).all(), "pass %d" % it
+        total_passed += len(rpassed)
+        cen = new_cen
+    stats = eng.yy_hint_stats()
+    if hint and d >= 16:
+        assert stats[0] == total_passed
+        assert stats[1] == sum(stats[2:])
+        print("hinted rows %d, handed over %d (no estimate %d, bound not holding %d, candidate bound %d, second minimum %d)"
+              % tuple(stats))
+    else:
+        assert stats == [0] * 6
     eng.close()
 
 
