@@ -148,7 +148,10 @@ int Engine::prepare_centroids(const float *centroids) {
 int Engine::yy_configure(uint32_t G, const uint32_t *groups_host) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   if (const char *v = getenv("KMCUDA_AMD_YY_EXACT")) yy_exact_ = atoi(v) != 0;
-  if (const char *v = getenv("KMCUDA_AMD_YY_HINT")) yy_hint_ = atoi(v) != 0;
+  if (const char *v = getenv("KMCUDA_AMD_YY_HINT")) {
+    yy_hint_ = atoi(v) != 0;
+    yy_hint_f32_ = atoi(v) == 2;
+  }
   G_ = G;
   // centroids in group order; group >= G (a NaN centroid keeps the 0xFFFFFFFF "assignment" of
   // its failed search, kmeans.cu:468-471) is left out
@@ -216,6 +219,7 @@ static void fill_yy_args(Engine &e, YyArgs &a, const float *samples, const float
   a.groups = e.groups_; a.drifts = nullptr; a.gdrifts = nullptr; a.assignments = nullptr; a.bounds = nullptr;
   a.passed = nullptr; a.counters = e.counters_; a.count_ptr = e.counters_ + 2;
   a.panelhi = nullptr; a.hint = nullptr; a.flag_rows = nullptr; a.gfirst = e.gfirst_; a.gsecond = e.gsecond_;
+  a.hint_f32_sweep = e.yy_hint_f32_ ? 1 : 0;
   a.pfil = e.pfil_; a.pbias = e.pbias_; a.pids = e.pids_; a.pmeta = e.pmeta_; a.cperm = e.cperm_;
   a.gstart = e.gstart_; a.nslots = e.nslots_;
 }

@@ -190,9 +190,16 @@ __global__ __launch_bounds__(256, 2) void yy_hint_kernel(YyArgs a) {
 // ---------------------------------------------------------------------------------------
 // the local filter against the estimate
 // ---------------------------------------------------------------------------------------
-template <int DP, int METRIC, bool FAST>
+// F16: the candidate sweep on the f16 matrix cores (hi halves only, like the estimate) with the
+// coarse Lloyd stage's rigorous bound on the dropped parts (lloyd_f16.hip): the
+// measured ||x' - hi(x')|| of the row and max ||c' - hi(c')|| of the panel (stats[5]).  !F16: the f32
+// matrix cores of yinyang_mfma.hip (KMCUDA_AMD_YY_HINT=2, cross-check).
+template <int DP, int METRIC, bool FAST, bool F16>
 __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
-  constexpr int NK = DP / 2, LDW = DP + 4, TILE = 32 * LDW, NST = (8 * DP + 255) / 256;
+  constexpr int NK = DP / 2, KS = NK / 8;
+  constexpr int LDW = F16 ? DP / 2 + 4 : DP + 4;          // LDS row in 4-byte words
+  constexpr int TILE = 32 * LDW;
+  constexpr int NST = ((F16 ? 4 : 8) * DP + 255) / 256;    // 16-byte pieces of a tile per thread
   extern __shared__ __attribute__((aligned(16))) float lds[];
   auto tile_ptr = [&](int buf) { return lds + buf * TILE; };
   auto bias_ptr = [&](int buf) { return lds + 2 * TILE + buf * 32; };
@@ -207,6 +214,23 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
   const uint32_t s = live ? a.passed[pi] : 0u;
 
   KMX_YY_LOAD_ROWS(a.samples, s, live)
+  f16x8h xh[F16 ? KS : 1];
+  float dx2 = 0.f;  // ||x' - hi(x')||^2, measured
+  if constexpr (F16) {
+#pragma unroll
+    for (int j = 0; j < KS; j++) {
+      f16x8h v;
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const _Float16 hi = (_Float16)xb[8 * j + q];
+        const float r = xb[8 * j + q] - (float)hi;  // exact
+        dx2 = fmaf(r, r, dx2);
+        v[q] = hi;
+      }
+      xh[j] = v;
+    }
+    dx2 += __shfl_xor(dx2, 32);
+  }
 
   const float upper_bound = live ? a.bounds[s] : 0.f;
   const uint32_t cluster = live ? a.assignments[s] : 0xFFFFFFFFu;
@@ -237,7 +261,18 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
   const float cmaxc = sqrtf(__uint_as_float(a.stats[0])) * 1.000001f;
   const float bmaxc = __uint_as_float(a.stats[1]);
   const float xo = sqrtf(xo2) * 1.0001f, xc = sqrtf(xc2) * 1.0001f;
-  const float e_mfma = 2.0f * a.eps * (xc * cmaxc + bmaxc) * 1.01f;
+  float e_mfma = 2.0f * a.eps * (xc * cmaxc + bmaxc) * 1.01f;
+  if constexpr (F16) {
+    // x'.c' - hi(x').hi(c') = x'.dc + dx.c' - dx.dc, Cauchy-Schwarz on the measured residual norms; the
+    // last term covers the absolute rounding of halves below the normal range
+    const float dcmax = sqrtf(__uint_as_float(a.stats[5])) * 1.0001f;
+    const float dx = sqrtf(dx2) * 1.0001f;
+    e_mfma += (xc * dcmax + dx * cmaxc + dx * dcmax) * 1.001f + 6e-8f * sqrtf((float)DP) * (xc + cmaxc);
+    if (!(xc < 6.0e4f && cmaxc < 6.0e4f && e_mfma < INFINITY) && !bad) {  // a half overflowed: no statement
+      bad = true;
+      why = 1u;
+    }
+  }
   const float e_cos = e_mfma + a.eps * xo * sqrtf(__uint_as_float(a.stats[3])) * 1.01f + 1e-6f;
   auto amin_of = [&](float sm) -> float {
     if (METRIC == 0) {
@@ -252,12 +287,15 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
   f32x4 stage[NST];
   float bstage = 0.f;
   uint32_t gstage = 0;
+  constexpr int PIECES = (F16 ? 4 : 8) * DP;   // 16-byte pieces per tile
+  constexpr int PPR = F16 ? DP / 8 : DP / 4;    // ... per centroid row
   auto stage_load = [&](uint32_t tile) {
-    const float *src = a.cfil + (size_t)tile * 32 * DP;
+    const f32x4 *src = F16 ? reinterpret_cast<const f32x4 *>(reinterpret_cast<const _Float16 *>(a.panelhi) + (size_t)tile * 32 * DP)
+                           : reinterpret_cast<const f32x4 *>(a.cfil + (size_t)tile * 32 * DP);
 #pragma unroll
     for (int i = 0; i < NST; i++) {
       const int q = tid + i * 256;
-      if (q < 8 * DP) stage[i] = reinterpret_cast<const f32x4 *>(src)[q];
+      if (q < PIECES) stage[i] = src[q];
     }
     if (tid < 32) {
       const uint32_t c = tile * 32 + tid;
@@ -269,8 +307,8 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
 #pragma unroll
     for (int i = 0; i < NST; i++) {
       const int q = tid + i * 256;
-      if (q < 8 * DP) {
-        const int row = q / (DP / 4), c4 = q % (DP / 4);
+      if (q < PIECES) {
+        const int row = q / PPR, c4 = q % PPR;
         *reinterpret_cast<f32x4 *>(tile_ptr(buf) + row * LDW + c4 * 4) = stage[i];
       }
     }
@@ -330,7 +368,24 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
     const int buf = t & 1;
     if (t + 1 < ntiles) stage_load(t + 1);
     if (wave_live) {
-      KMX_YY_MFMA_TILE(acc, buf)
+      f32x16 acc;
+      if constexpr (F16) {
+        const float *bb = bias_ptr(buf) + 4 * h;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bb + 8 * g4);
+          acc[4 * g4 + 0] = b4.x; acc[4 * g4 + 1] = b4.y; acc[4 * g4 + 2] = b4.z; acc[4 * g4 + 3] = b4.w;
+        }
+        const _Float16 *arow = reinterpret_cast<const _Float16 *>(tile_ptr(buf) + col * LDW) + h * NK;
+#pragma unroll
+        for (int j = 0; j < KS; j++) {
+          const f16x8h af = *reinterpret_cast<const f16x8h *>(arow + 8 * j);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xh[j], acc, 0, 0, 0);
+        }
+      } else {
+        KMX_YY_MFMA_TILE(acc32, buf)
+        acc = acc32;
+      }
       uint32_t m16 = 0;
       if (live && !bad) {
 #pragma unroll
@@ -440,12 +495,20 @@ static hipError_t launch_hint_t(const YyArgs &a, hipStream_t st) {
 }
 template <int DP, int METRIC>
 static hipError_t launch_local_hint_t(const YyArgs &a, hipStream_t st) {
-  const size_t lds_bytes = (2 * 32 * (DP + 4) + 64 + 64) * sizeof(float);
   const uint32_t grid = (a.len + 127) / 128;
-  if (a.D == (uint32_t)DP)
-    hipLaunchKernelGGL((yy_local_hint_kernel<DP, METRIC, true>), dim3(grid), dim3(256), lds_bytes, st, a);
-  else
-    hipLaunchKernelGGL((yy_local_hint_kernel<DP, METRIC, false>), dim3(grid), dim3(256), lds_bytes, st, a);
+  if (a.hint_f32_sweep) {
+    const size_t lds_bytes = (2 * 32 * (DP + 4) + 64 + 64) * sizeof(float);
+    if (a.D == (uint32_t)DP)
+      hipLaunchKernelGGL((yy_local_hint_kernel<DP, METRIC, true, false>), dim3(grid), dim3(256), lds_bytes, st, a);
+    else
+      hipLaunchKernelGGL((yy_local_hint_kernel<DP, METRIC, false, false>), dim3(grid), dim3(256), lds_bytes, st, a);
+  } else {
+    const size_t lds_bytes = (2 * 32 * (DP / 2 + 4) + 64 + 64) * sizeof(float);
+    if (a.D == (uint32_t)DP)
+      hipLaunchKernelGGL((yy_local_hint_kernel<DP, METRIC, true, true>), dim3(grid), dim3(256), lds_bytes, st, a);
+    else
+      hipLaunchKernelGGL((yy_local_hint_kernel<DP, METRIC, false, true>), dim3(grid), dim3(256), lds_bytes, st, a);
+  }
   return hipGetLastError();
 }
 
