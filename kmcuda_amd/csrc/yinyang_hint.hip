@@ -240,16 +240,27 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
   bool bad = !(hint < INFINITY);  // no estimate (or a dead lane): the plain kernel's row
   uint32_t why = bad ? 1u : 0u;   // statistics: first reason the row was handed over
 
-  // (a) groups (bound >= upper bound) whose bound can still matter (<= S'): folded up front
+  // (a) groups (bound >= upper bound) whose bound can still matter (<= S'): folded up front.  Each half
+  // wave takes every other group, eight loads in flight at a time (a row's G bounds are G cache lines)
   {
     float alow = kFltMax;
     if (!bad) {
-      for (uint32_t g = h; g < G; g += 2) {
-        const float lb = a.bounds[(size_t)len * (1 + g) + s];
-        if (lb >= upper_bound && lb <= hint && lb < alow) {
-          uint32_t p = a.gfirst[g];
-          if (p == cluster) p = a.gsecond[g];
-          if (p != 0xFFFFFFFFu) alow = lb;  // the group has a member the reference's scan meets
+      for (uint32_t g0 = h; g0 < G; g0 += 16) {
+        float lb8[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const uint32_t g = g0 + 2 * q;
+          lb8[q] = g < G ? a.bounds[(size_t)len * (1 + g) + s] : -INFINITY;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const float lb = lb8[q];
+          if (lb >= upper_bound && lb <= hint && lb < alow) {
+            const uint32_t g = g0 + 2 * q;
+            uint32_t p = a.gfirst[g];
+            if (p == cluster) p = a.gsecond[g];
+            if (p != 0xFFFFFFFFu) alow = lb;  // the group has a member the reference's scan meets
+          }
         }
       }
     }
