@@ -318,29 +318,41 @@ __global__ __launch_bounds__(256, 2) void yy_init_mfma_kernel(YyArgs a) {
   int qn = 0;
   uint32_t carry_g = 0xFFFFFFFFu;
   float carry_min = kFltMax;
-  auto store_carry = [&]() {
+  auto store_carry = [&]() __attribute__((always_inline)) {
     if (carry_g != 0xFFFFFFFFu && live && h == 0) a.bounds[(size_t)len * (1 + carry_g) + s] = carry_min;
   };
-  auto flush = [&]() {  // wave-uniform call
-    const float *crow[4];
+  // the exact chains run as a two-batch pipeline (exact_split.hpp): a flush starts the queued batch and
+  // completes -- and replays -- the one before it
+  uint32_t pqc[4] = {0, 0, 0, 0}, pqg[4] = {0, 0, 0, 0};
+  int pqn = 0;
+  ExactPipe4 pipe;
+  auto flush = [&]() __attribute__((always_inline)) {  // wave-uniform call
+    uint32_t cidx[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) crow[i] = a.centroids + (size_t)(i < qn ? qc[i] : 0) * D;
+    for (int i = 0; i < 4; i++) cidx[i] = h ? (i < pqn ? pqc[i] : 0u) : (i < qn ? qc[i] : 0u);
     float dist[4];
-    exact_distance4<NK, METRIC, FAST>(xrow, crow, D, h, col, dist);
+    exact_distance4_pipe<NK, METRIC, FAST>(xrow, a.centroids, cidx, D, h, col, pipe, dist);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      if (i < qn) {
-        if (qg[i] != carry_g) {
+      if (i < pqn) {
+        if (pqg[i] != carry_g) {
           store_carry();
-          carry_g = qg[i];
+          carry_g = pqg[i];
           carry_min = kFltMax;
         }
         if (dist[i] < carry_min) carry_min = dist[i];   // kmeans.cu:477-481 (NaN never "less")
       }
+      pqc[i] = qc[i];
+      pqg[i] = qg[i];
     }
+    pqn = qn;
     qn = 0;
   };
-  auto enqueue = [&](uint32_t g, uint32_t c, bool on) {
+  auto drain = [&]() __attribute__((always_inline)) {  // wave-uniform call: nothing queued, nothing pending afterwards
+    if (__ballot(qn > 0) != 0ull) flush();
+    if (__ballot(pqn > 0) != 0ull) flush();
+  };
+  auto enqueue = [&](uint32_t g, uint32_t c, bool on) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; i++)
       if (on && i == qn) {
@@ -377,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void yy_init_mfma_kernel(YyArgs a) {
     c1 = g1 ? idx : c1;
     v1 = g1 ? v : v1;
   };
-  auto finalize_group = [&]() {  // wave-uniform call
+  auto finalize_group = [&]() __attribute__((always_inline)) {  // wave-uniform call
     if (cur_group == 0xFFFFFFFFu) return;
     {  // merge the partner half-wave's top-3
       const float pv1 = __shfl_xor(v1, 32), pv2 = __shfl_xor(v2, 32), pv3 = __shfl_xor(v3, 32);
@@ -403,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void yy_init_mfma_kernel(YyArgs a) {
     enqueue(cur_group, c1, has1 && !scan);
     enqueue(cur_group, c2, sure2);
     if (__ballot(scan) != 0ull) {  // three or more contenders: every member of the group, exactly
-      flush();
+      drain();
       if (scan && carry_g != cur_group) {
         store_carry();
         carry_g = cur_group;
@@ -460,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void yy_init_mfma_kernel(YyArgs a) {
     __syncthreads();
   }
   finalize_group();
-  if (__ballot(qn > 0) != 0ull) flush();
+  drain();
   store_carry();
   if (live && h == 0) a.bounds[s] = upper;
 }
