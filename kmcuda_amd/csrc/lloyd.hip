@@ -404,7 +404,46 @@ __global__ __launch_bounds__(128) void lloyd_pair_kernel(
     const float *ca = centroids + (size_t)lo * D, *cb = centroids + (size_t)hi * D;
     float acc[4] = {0.f, 0.f, 0.f, 0.f}, corr[4] = {0.f, 0.f, 0.f, 0.f};
     uint32_t f = 0;
-    if ((D & 3u) == 0 && ((((uintptr_t)x) | ((uintptr_t)ca) | ((uintptr_t)cb)) & 15u) == 0) {
+    const bool aligned16 = ((((uintptr_t)x) | ((uintptr_t)ca) | ((uintptr_t)cb)) & 15u) == 0;
+    if ((D & 7u) == 0 && aligned16) {
+      // 8 features per group, the next group's six 16-byte loads issued before the current group's
+      // dependent steps (the three rows are scattered: every group is a round trip to L2 / HBM)
+      auto load8 = [&](uint32_t f0, float4 (&xv)[2], float4 (&av)[2], float4 (&bv)[2]) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          xv[t] = *reinterpret_cast<const float4 *>(x + f0 + 4 * t);
+          av[t] = *reinterpret_cast<const float4 *>(ca + f0 + 4 * t);
+          bv[t] = *reinterpret_cast<const float4 *>(cb + f0 + 4 * t);
+        }
+      };
+      auto fold8 = [&](const float4 (&xv)[2], const float4 (&av)[2], const float4 (&bv)[2]) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          const float xs[4] = {xv[t].x, xv[t].y, xv[t].z, xv[t].w}, as[4] = {av[t].x, av[t].y, av[t].z, av[t].w},
+                      bs[4] = {bv[t].x, bv[t].y, bv[t].z, bv[t].w};
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const float cv[4] = {as[q], bs[q], 0.f, 0.f};
+            float y[4];
+            fma_rd4(xs[q], cv, corr, y);
+            kahan_fold(y[0], acc[0], corr[0]);
+            kahan_fold(y[1], acc[1], corr[1]);
+          }
+        }
+      };
+      float4 x0[2], a0[2], b0[2], x1[2], a1[2], b1[2];
+      load8(0, x0, a0, b0);
+      for (; f + 16 <= D; f += 16) {
+        load8(f + 8, x1, a1, b1);
+        fold8(x0, a0, b0);
+        if (f + 24 <= D) load8(f + 16, x0, a0, b0);
+        fold8(x1, a1, b1);
+      }
+      if (f + 8 <= D) {  // an odd number of groups: the last one is already loaded
+        fold8(x0, a0, b0);
+        f += 8;
+      }
+    } else if ((D & 3u) == 0 && aligned16) {
       for (; f < D; f += 4) {  // 16-byte loads; the chain order is unchanged
         const float4 xv = *reinterpret_cast<const float4 *>(x + f);
         const float4 av = *reinterpret_cast<const float4 *>(ca + f), bv = *reinterpret_cast<const float4 *>(cb + f);
@@ -475,37 +514,40 @@ __global__ __launch_bounds__(256) void lloyd_exact_kernel(
 #pragma unroll
         for (int j = 0; j < CH; j++) in[j] = cbase + 64 * j + lane < Kt;
         uint32_t f = 0;
-        // groups of 4 features, the NEXT group's 16 + 4 loads issued before the current group's four
-        // dependent steps: the panel is L2 resident (~1 us away), a row is latency, not throughput
-        auto load_group = [&](uint32_t f0, float (&xf)[4], float (&cv)[4][CH]) {
+        // groups of GF features, the NEXT group's GF * (CH + 1) loads issued before the current group's
+        // dependent steps: the panel is L2 resident (~1 us away) and a flagged row is latency, not
+        // throughput -- one group in flight covers GF steps of arithmetic (GF = 4 measured 68 us per row
+        // at D = 256: 64 round trips)
+        constexpr int GF = 8;
+        auto load_group = [&](uint32_t f0, float (&xf)[GF], float (&cv)[GF][CH]) {
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
+          for (int q = 0; q < GF; q++) {
             xf[q] = x[f0 + q];
 #pragma unroll
             for (int j = 0; j < CH; j++) cv[q][j] = in[j] ? cp[(size_t)(f0 + q) * Kt + 64 * j] : 0.f;
           }
         };
-        auto fold_group = [&](const float (&xf)[4], float (&cv)[4][CH]) {
+        auto fold_group = [&](const float (&xf)[GF], float (&cv)[GF][CH]) {
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
+          for (int q = 0; q < GF; q++) {
             float y[CH];
             fma_rd4(xf[q], cv[q], corr, y);
 #pragma unroll
             for (int j = 0; j < CH; j++) kahan_fold(y[j], acc[j], corr[j]);
           }
         };
-        if (D >= 4) {
-          float xa[4], ca[4][CH], xb[4], cb[4][CH];
+        if (D >= GF) {
+          float xa[GF], ca[GF][CH], xb[GF], cb[GF][CH];
           load_group(0, xa, ca);
-          for (; f + 8 <= D; f += 8) {
-            load_group(f + 4, xb, cb);
+          for (; f + 2 * GF <= D; f += 2 * GF) {
+            load_group(f + GF, xb, cb);
             fold_group(xa, ca);
-            if (f + 12 <= D) load_group(f + 8, xa, ca);
+            if (f + 3 * GF <= D) load_group(f + 2 * GF, xa, ca);
             fold_group(xb, cb);
           }
-          if (f + 4 <= D) {  // an odd number of groups: the last one is already loaded
+          if (f + GF <= D) {  // an odd number of groups: the last one is already loaded
             fold_group(xa, ca);
-            f += 4;
+            f += GF;
           }
         }
         for (; f < D; f++) {

@@ -1052,11 +1052,10 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
   }
 }
 
-template <int DP>
-static hipError_t launch_refine_dp(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
-                                   const uint32_t *row_list, const float *thr_list, const uint32_t *n_list,
-                                   uint32_t rows_hint, hipStream_t st) {
-  constexpr int NSET = DP <= 256 ? 2 : 1;
+template <int DP, int NSET>
+static hipError_t launch_refine_dp_n(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
+                                     const uint32_t *row_list, const float *thr_list, const uint32_t *n_list,
+                                     uint32_t rows_hint, hipStream_t st) {
   const size_t lds_bytes = 2 * 64 * (size_t)(DP * 2) + 512 + 64 + (size_t)DP * 4 + 1024 + 256 * kRefineCap * 4 +
                            (DP > 256 ? 256 * 2 * kRefineCap * 4 : 0);   // partial dot products between feature chunks
   const uint32_t rows_per_block = 128u * NSET;
@@ -1080,6 +1079,23 @@ static hipError_t launch_refine_dp(const LloydArgs &a, const void *rows, bool ha
   }
 #undef KMX_RFN_LAUNCH
   return hipGetLastError();
+}
+
+template <int DP>
+static hipError_t launch_refine_dp(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
+                                   const uint32_t *row_list, const float *thr_list, const uint32_t *n_list,
+                                   uint32_t rows_hint, hipStream_t st) {
+  if constexpr (DP > 256) {
+    return launch_refine_dp_n<DP, 1>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, rows_hint, st);
+  } else if constexpr (DP >= 64) {
+    // a short list (an 8-GPU shard's: ~70k rows) in 256-row blocks is one block per CU, one wave per SIMD,
+    // and the kernel's gather / contender phases are latency: 128-row blocks put two on every CU
+    if (rows_hint != 0xFFFFFFFFu && rows_hint < 256u * 512u)
+      return launch_refine_dp_n<DP, 1>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, rows_hint, st);
+    return launch_refine_dp_n<DP, 2>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, rows_hint, st);
+  } else {
+    return launch_refine_dp_n<DP, 2>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, rows_hint, st);
+  }
 }
 
 hipError_t launch_lloyd_refine(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
