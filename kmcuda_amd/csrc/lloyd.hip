@@ -509,10 +509,12 @@ __global__ __launch_bounds__(256) void lloyd_exact_kernel(
         float acc[CH], corr[CH];
 #pragma unroll
         for (int j = 0; j < CH; j++) { acc[j] = 0.f; corr[j] = 0.f; }
-        const float *cp = ct + cbase + lane;
-        bool in[CH];
+        // chain j reads column cbase + 64 j + lane of the panel; a column beyond the panel reads column
+        // `lane` instead (unconditional loads: a predicated load costs a branch each) and its result is
+        // dropped below (c < K)
+        const float *cp[CH];
 #pragma unroll
-        for (int j = 0; j < CH; j++) in[j] = cbase + 64 * j + lane < Kt;
+        for (int j = 0; j < CH; j++) cp[j] = ct + ((cbase + 64 * j + lane < Kt) ? cbase + 64 * j + lane : (uint32_t)lane);
         uint32_t f = 0;
         // groups of GF features, the NEXT group's GF * (CH + 1) loads issued before the current group's
         // dependent steps: the panel is L2 resident (~1 us away) and a flagged row is latency, not
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(256) void lloyd_exact_kernel(
           for (int q = 0; q < GF; q++) {
             xf[q] = x[f0 + q];
 #pragma unroll
-            for (int j = 0; j < CH; j++) cv[q][j] = in[j] ? cp[(size_t)(f0 + q) * Kt + 64 * j] : 0.f;
+            for (int j = 0; j < CH; j++) cv[q][j] = cp[j][(size_t)(f0 + q) * Kt];
           }
         };
         auto fold_group = [&](const float (&xf)[GF], float (&cv)[GF][CH]) {
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(256) void lloyd_exact_kernel(
           const float xf = x[f];
           float cv[CH], y[CH];
 #pragma unroll
-          for (int j = 0; j < CH; j++) cv[j] = in[j] ? cp[(size_t)f * Kt + 64 * j] : 0.f;
+          for (int j = 0; j < CH; j++) cv[j] = cp[j][(size_t)f * Kt];
           fma_rd4(xf, cv, corr, y);
 #pragma unroll
           for (int j = 0; j < CH; j++) kahan_fold(y[j], acc[j], corr[j]);
