@@ -104,7 +104,45 @@ template <int METRIC>
 __device__ __forceinline__ float chain_vv(const float *__restrict__ a, const float *__restrict__ b, uint32_t D) {
   float acc = 0.f, corr = 0.f;
   uint32_t f = 0;
-  if ((D & 3u) == 0 && ((((uintptr_t)a) | ((uintptr_t)b)) & 15u) == 0) {
+  const bool aligned16 = ((((uintptr_t)a) | ((uintptr_t)b)) & 15u) == 0;
+  if ((D & 7u) == 0 && aligned16) {
+    // 8 features per group, the next group's four 16-byte loads issued before the current group's
+    // dependent steps: both rows are one thread's own (scattered) lines, every group a round trip
+    auto load8 = [&](uint32_t f0, float4 (&av)[2], float4 (&bv)[2]) {
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        av[t] = *reinterpret_cast<const float4 *>(a + f0 + 4 * t);
+        bv[t] = *reinterpret_cast<const float4 *>(b + f0 + 4 * t);
+      }
+    };
+    auto fold8 = [&](const float4 (&av)[2], const float4 (&bv)[2]) {
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const float aa[4] = {av[t].x, av[t].y, av[t].z, av[t].w}, bb[4] = {bv[t].x, bv[t].y, bv[t].z, bv[t].w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if (METRIC == 0) {
+            const float d = aa[q] - bb[q];
+            kahan_fold(fma_rd(d, d, corr), acc, corr);
+          } else {
+            kahan_fold(fma_rd(aa[q], bb[q], corr), acc, corr);
+          }
+        }
+      }
+    };
+    float4 a0[2], b0[2], a1[2], b1[2];
+    load8(0, a0, b0);
+    for (; f + 16 <= D; f += 16) {
+      load8(f + 8, a1, b1);
+      fold8(a0, b0);
+      if (f + 24 <= D) load8(f + 16, a0, b0);
+      fold8(a1, b1);
+    }
+    if (f + 8 <= D) {  // an odd number of groups: the last one is already loaded
+      fold8(a0, b0);
+      f += 8;
+    }
+  } else if ((D & 3u) == 0 && aligned16) {
     for (; f < D; f += 4) {
       const float4 av = *reinterpret_cast<const float4 *>(a + f), bv = *reinterpret_cast<const float4 *>(b + f);
       const float aa[4] = {av.x, av.y, av.z, av.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
