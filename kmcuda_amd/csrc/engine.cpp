@@ -25,6 +25,7 @@ Engine::~Engine() {
     (void)hipEventDestroy(ev_fork_);
     (void)hipEventDestroy(ev_join_);
   }
+  if (ev_move_) (void)hipEventDestroy(ev_move_);
   if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -85,6 +86,8 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if ((rc = alloc(&bucket_work_, move_bucket_words(K)))) return rc;
   KMX_HIP(hipMemset(bucket_work_, 0, move_bucket_words(K) * sizeof(uint32_t)), kRuntimeError);
   KMX_HIP(hipHostMalloc(reinterpret_cast<void **>(&host_move_count_), 4 * sizeof(uint32_t), hipHostMallocDefault), kMemoryAllocationFailure);
+  memset(host_move_count_, 0, 4 * sizeof(uint32_t));
+  KMX_HIP(hipEventCreateWithFlags(&ev_move_, hipEventDisableTiming), kRuntimeError);
   sort_temp_bytes_ = sort_temp_bytes(2 * (size_t)n_rows, 2 * K);
   {
     const size_t b2 = sort_temp_bytes(n_rows, K);
@@ -414,7 +417,7 @@ int Engine::move_deltas(const float *samples, const uint32_t *prev, const uint32
           kMemoryCopyError);
   KMX_HIP(launch_move_deltas(samples, N_, D_, K_, prev, cur, keys_tmp_, vals_tmp_, keys_sorted_, rows_sorted_,
                              offsets2_, sort_temp_, sort_temp_bytes_, partial_, delta, dcount, move_blocks_,
-                             bucket_work_, host_move_count_, &last_move_events_, stream_),
+                             bucket_work_, host_move_count_, &last_move_events_, ev_move_, stream_),
           kRuntimeError);
   if (N_) last_undecided_ = host_move_count_[2];   // launch_move_deltas synchronised the stream
   span_end();

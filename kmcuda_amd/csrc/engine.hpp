@@ -69,6 +69,7 @@ class Engine {
   bool own_stream_ = false, blocking_stream_ = false;
   hipStream_t side_stream_ = nullptr;   // the full-scan refine kernel beside the pair kernel
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+  hipEvent_t ev_move_ = nullptr;        // the update's count copy (launch_move_deltas waits for it alone)
   uint32_t N_ = 0, D_ = 0, K_ = 0, K_pad_ = 0, Kt_ = 0, DP_ = 0;
   int metric_ = 0, fp16x2_ = 0;
   float eps_ = 0, tie_slack_ = 0;

@@ -73,7 +73,8 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
                               const uint32_t *cur, uint32_t *keys_tmp, uint32_t *vals_tmp, uint32_t *keys_sorted,
                               uint32_t *rows_sorted, uint32_t *offsets2, void *temp, size_t temp_bytes,
                               double *partial, double *delta, int32_t *dcount, uint32_t *blockoff,
-                              uint32_t *bucket_work, uint32_t *host_count, uint32_t *last_events, hipStream_t st);
+                              uint32_t *bucket_work, uint32_t *host_count /* 4 pinned words, zeroed by the owner */,
+                              uint32_t *last_events, hipEvent_t copied /* may be null */, hipStream_t st);
 hipError_t launch_adjust_exact(int metric, const float *samples, uint32_t N, uint32_t D, uint32_t K,
                                const uint32_t *prev, const uint32_t *cur, uint32_t *keys_tmp, uint32_t *vals_tmp,
                                uint32_t *keys_sorted, uint32_t *rows_sorted, uint32_t *offsets2, void *temp,

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint32_t *__rest
                                                           uint32_t *__restrict__ rows) {
   __shared__ uint32_t v[kBucketCap];
   const uint32_t beg = offsets[blockIdx.x], n = offsets[blockIdx.x + 1] - beg;
-  if (n < 2) return;
+  if (n < 2 || n > kBucketCap) return;  // n > cap: a speculative launch (below); the radix path redoes the list
   uint32_t m = 2;
   while (m < n) m <<= 1;
   for (uint32_t i = threadIdx.x; i < m; i += 256) v[i] = i < n ? rows[beg + i] : 0xFFFFFFFFu;
@@ -360,7 +360,8 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
                               const uint32_t *cur, uint32_t *keys_tmp, uint32_t *vals_tmp, uint32_t *keys_sorted,
                               uint32_t *rows_sorted, uint32_t *offsets2, void *temp, size_t temp_bytes,
                               double *partial, double *delta, int32_t *dcount, uint32_t *blockoff,
-                              uint32_t *bucket_work, uint32_t *host_count, uint32_t *last_events, hipStream_t st) {
+                              uint32_t *bucket_work, uint32_t *host_count, uint32_t *last_events, hipEvent_t copied,
+                              hipStream_t st) {
   // blockoff: N / 1024 + 2 words; bucket_work: move_bucket_words(K) words = histogram | cursors (both
   // 2 K counters, move_bucket_stride(K) words apart) | 2 results; the histogram is zero on entry (engine:
   // zeroed at creation, left zero by the scan); host_count: 2 pinned words
@@ -369,6 +370,7 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
            *res = bucket_work + 4 * (size_t)K * stride;
   hipError_t e = hipSuccess;
   uint32_t m = 0, maxb = 0;
+  bool speculated = false;
   const bool force_radix = getenv("KMCUDA_AMD_UPDATE_RADIX") != nullptr;  // A/B and tests
   // *last_events: the previous call's event count (2 N before the first one).  While most rows still
   // move (the first iterations) the histogram's atomics alone cost more than the whole radix path
@@ -381,17 +383,33 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
     hipLaunchKernelGGL(move_bucket_scan_kernel, dim3(1), dim3(1024), 0, st, hist, 2 * K, stride, offsets2, cursors, res);
     e = hipGetLastError();
     if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("move events: %s\n", hipGetErrorString(e)); return e; }
-    // the one host round trip of the update: which path, and (radix path) the sort's size
+    // the one host round trip of the update: which path, and (radix path) the sort's size.  While the
+    // previous call took the bucket path (host_count[3], the owner's pinned word) its two kernels are
+    // launched BEFORE the host waits for the counts -- the GPU runs them instead of idling through the
+    // round trip; if the counts say otherwise the radix path below simply redoes rows_sorted
     e = hipMemcpyAsync(host_count, res, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && copied) e = hipEventRecord(copied, st);
+    if (e != hipSuccess) return e;
+    const bool speculate = copied && host_count[3] == 1u;
+    if (speculate) {
+      hipLaunchKernelGGL(move_scatter_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, cursors,
+                         stride, rows_sorted);
+      hipLaunchKernelGGL(bucket_sort_kernel, dim3(2 * K), dim3(256), 0, st, offsets2, rows_sorted);
+    }
+    e = copied ? hipEventSynchronize(copied) : hipStreamSynchronize(st);   // the copy, not what was queued behind it
     if (e != hipSuccess) return e;
     m = host_count[0];
     maxb = host_count[1];
+    speculated = speculate;
   }
+  host_count[3] = 0u;
   if (N && !direct_radix && m && maxb <= kBucketCap) {
-    hipLaunchKernelGGL(move_scatter_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, cursors,
-                       stride, rows_sorted);
-    hipLaunchKernelGGL(bucket_sort_kernel, dim3(2 * K), dim3(256), 0, st, offsets2, rows_sorted);
+    host_count[3] = 1u;
+    if (!speculated) {
+      hipLaunchKernelGGL(move_scatter_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, cursors,
+                         stride, rows_sorted);
+      hipLaunchKernelGGL(bucket_sort_kernel, dim3(2 * K), dim3(256), 0, st, offsets2, rows_sorted);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("bucket path: %s\n", hipGetErrorString(e)); return e; }
   } else if (N && (direct_radix || m)) {

@@ -258,6 +258,58 @@ def test_update_paths_bit_identical(monkeypatch, k):
     assert numpy.array_equal(res[0][0], res[1][0], equal_nan=True)
 
 
+def test_update_bucket_speculation_falls_back():
+    """The update launches the bucket path's scatter + sort BEFORE it has read the move counts while the
+    previous call took that path; when the counts then demand the radix path (a bucket beyond the LDS
+    sort's capacity, fewer than N / 2 events in all) the list is redone.  Engine.move_deltas directly:
+    few moves (bucket path), one huge bucket (speculation wrong), few moves again; every delta against
+    numpy in fp64."""
+    from kmcuda_amd.engine import Engine
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    n, d, k = 20000, 24, 16
+    rs = numpy.random.RandomState(5)
+    x = rs.rand(n, d).astype(numpy.float32)
+    base = rs.randint(0, k, n).astype(numpy.int32)
+    eng = Engine(n, d, k, "L2", device=0)
+    xs = torch.from_numpy(x).to(dev)
+    delta = torch.zeros(k * d, dtype=torch.float64, device=dev)
+    dcount = torch.zeros(k, dtype=torch.int32, device=dev)
+
+    def step(prev, cur):
+        eng.move_deltas(xs, torch.from_numpy(prev).to(dev), torch.from_numpy(cur).to(dev), delta, dcount)
+        eng.sync()
+        want = numpy.zeros((k, d), numpy.float64)
+        wc = numpy.zeros(k, numpy.int64)
+        moved = numpy.nonzero(prev != cur)[0]
+        numpy.add.at(want, cur[moved], x[moved].astype(numpy.float64))
+        numpy.subtract.at(want, prev[moved], x[moved].astype(numpy.float64))
+        numpy.add.at(wc, cur[moved], 1)
+        numpy.subtract.at(wc, prev[moved], 1)
+        numpy.testing.assert_allclose(delta.cpu().numpy().reshape(k, d), want, rtol=1e-12, atol=1e-9)
+        assert (dcount.cpu().numpy() == wc).all()
+
+    a0 = base.copy()
+    a1 = a0.copy()
+    a1[:300] = (a1[:300] + 1) % k                    # 600 events: bucket path, first of its kind
+    step(a0, a1)
+    a2 = a1.copy()
+    a2[rs.choice(n, 50, replace=False)] = 3          # still the bucket path, now launched speculatively
+    step(a1, a2)
+    a3 = a2.copy()
+    src = numpy.nonzero(a2 == 5)[0]
+    a3[src] = 7                                      # one bucket of ~1250 rows (> 1024): radix path after all
+    assert len(src) > 1024 and 2 * len(src) < n // 2
+    step(a2, a3)
+    a4 = a3.copy()
+    a4[:100] = (a4[:100] + 2) % k
+    step(a3, a4)                                     # not speculative (the previous call was radix), bucket again
+    a5 = a4.copy()
+    a5[200:260] = 0
+    step(a4, a5)                                     # speculative again
+    eng.close()
+
+
 @pytest.mark.parametrize("case", ["uniform", "blobs", "duplicates", "wide", "tiny", "ragged"])
 def test_kmeanspp_device_chooser_equals_host(monkeypatch, case):
     """k-means++ with the chooser on the device (exact block sums; seeding.hip) against the reference's
