@@ -43,6 +43,8 @@ typedef _Float16 f16x8h __attribute__((ext_vector_type(8)));
 // ---------------------------------------------------------------------------------------
 // the estimate: best two coarse scores of every passed row
 // ---------------------------------------------------------------------------------------
+// A wave owns 64 rows as two 32-row operand sets, so every centroid fragment read from LDS feeds two
+// matrix products (with one set the LDS reads alone are half the LDS bandwidth at full matrix rate).
 template <int DP, int METRIC, bool FAST>
 __global__ __launch_bounds__(256, 2) void yy_hint_kernel(YyArgs a) {
   constexpr int NK = DP / 2, KS = NK / 8, LDWH = DP / 2 + 4, TILE = 32 * LDWH, NSTH = (4 * DP + 255) / 256;
@@ -51,29 +53,43 @@ __global__ __launch_bounds__(256, 2) void yy_hint_kernel(YyArgs a) {
   auto bias_ptr = [&](int buf) { return lds + 2 * TILE + buf * 32; };
 
   const uint32_t npassed = *a.count_ptr;
-  if (blockIdx.x * 128u >= npassed) return;  // block-uniform
+  if (blockIdx.x * 256u >= npassed) return;  // block-uniform
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
   const uint32_t D = a.D, K = a.K, G = a.G, len = a.len;
-  const uint32_t pi = blockIdx.x * 128u + wave * 32u + col;
-  const bool live = pi < npassed;
-  const uint32_t s = live ? a.passed[pi] : 0u;
-
-  f16x8h xh[KS];
-  float xc2h, xmuh;
-  {
-    KMX_YY_LOAD_ROWS(a.samples, s, live)
-    (void)xo2; (void)xrow;
+  uint32_t pi[2], s[2];
+  bool live[2];
 #pragma unroll
-    for (int j = 0; j < KS; j++) {
-      f16x8h v;
-#pragma unroll
-      for (int q = 0; q < 8; q++) v[q] = (_Float16)xb[8 * j + q];
-      xh[j] = v;
-    }
-    xc2h = xc2;
-    xmuh = xmu;
+  for (int e = 0; e < 2; e++) {
+    pi[e] = blockIdx.x * 256u + wave * 64u + 32u * e + col;
+    live[e] = pi[e] < npassed;
+    s[e] = live[e] ? a.passed[pi[e]] : 0u;
   }
-  const float xc2 = xc2h, xmu = xmuh;
+
+  f16x8h xh[2][KS];
+  float xc2[2], xmu[2];
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    float xc2e, xmue;
+    {
+      KMX_YY_LOAD_ROWS(a.samples, s[e], live[e])
+      (void)xo2; (void)xrow;
+#pragma unroll
+      for (int j = 0; j < KS; j++) {
+        f16x8h v;
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = (_Float16)xb[8 * j + q];
+        xh[e][j] = v;
+      }
+      xc2e = xc2;
+      xmue = xmu;
+    }
+    xc2[e] = xc2e;
+    xmu[e] = xmue;
+    // one set at a time: both sets' fp32 rows in flight at once would not fit the register file
+#pragma unroll
+    for (int j = 0; j < KS; j++) asm volatile("" : "+v"(xh[e][j]));
+    __builtin_amdgcn_sched_barrier(0);
+  }
 
   f32x4 stage[NSTH];
   float bstage = 0.f;
@@ -100,8 +116,8 @@ __global__ __launch_bounds__(256, 2) void yy_hint_kernel(YyArgs a) {
 
   // best two scores of my 16 accumulator rows per tile; the register number rides in the low 4
   // mantissa bits, the tile index is noted once per tile
-  float v1 = -INFINITY, v2 = -INFINITY;
-  uint32_t t1 = 0, t2 = 0;
+  float v1[2] = {-INFINITY, -INFINITY}, v2[2] = {-INFINITY, -INFINITY};
+  uint32_t t1[2] = {0, 0}, t2[2] = {0, 0};
   const uint32_t ntiles = a.K_pad / 32;
   stage_load(0);
   stage_store(0);
@@ -109,82 +125,93 @@ __global__ __launch_bounds__(256, 2) void yy_hint_kernel(YyArgs a) {
   for (uint32_t t = 0; t < ntiles; t++) {
     const int buf = t & 1;
     if (t + 1 < ntiles) stage_load(t + 1);
-    f32x16 acc;
+    f32x16 acc[2];
     {
       const float *bb = bias_ptr(buf) + 4 * h;
 #pragma unroll
       for (int g4 = 0; g4 < 4; g4++) {
         const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bb + 8 * g4);
-        acc[4 * g4 + 0] = b4.x; acc[4 * g4 + 1] = b4.y; acc[4 * g4 + 2] = b4.z; acc[4 * g4 + 3] = b4.w;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          acc[e][4 * g4 + 0] = b4.x; acc[e][4 * g4 + 1] = b4.y; acc[e][4 * g4 + 2] = b4.z; acc[e][4 * g4 + 3] = b4.w;
+        }
       }
       const _Float16 *arow = reinterpret_cast<const _Float16 *>(tile_ptr(buf) + col * LDWH) + h * NK;
 #pragma unroll
       for (int j = 0; j < KS; j++) {
         const f16x8h af = *reinterpret_cast<const f16x8h *>(arow + 8 * j);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xh[j], acc, 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xh[0][j], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xh[1][j], acc[1], 0, 0, 0);
       }
     }
-    const float o1 = v1, o2 = v2;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const float v = __uint_as_float((__float_as_uint(acc[r]) & ~15u) | (uint32_t)r);
-      v2 = __builtin_amdgcn_fmed3f(v1, v2, v);
-      v1 = fmaxf(v1, v);
+    for (int e = 0; e < 2; e++) {
+      const float o1 = v1[e], o2 = v2[e];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float v = __uint_as_float((__float_as_uint(acc[e][r]) & ~15u) | (uint32_t)r);
+        v2[e] = __builtin_amdgcn_fmed3f(v1[e], v2[e], v);
+        v1[e] = fmaxf(v1[e], v);
+      }
+      const uint32_t n1 = (v1[e] == o1) ? t1[e] : ((v1[e] == o2) ? t2[e] : t);
+      const uint32_t n2 = (v2[e] == o1) ? t1[e] : ((v2[e] == o2) ? t2[e] : t);
+      t1[e] = n1;
+      t2[e] = n2;
     }
-    const uint32_t n1 = (v1 == o1) ? t1 : ((v1 == o2) ? t2 : t);
-    const uint32_t n2 = (v2 == o1) ? t1 : ((v2 == o2) ? t2 : t);
-    t1 = n1;
-    t2 = n2;
     if (t + 1 < ntiles) stage_store(buf ^ 1);
     __syncthreads();
   }
 
-  // the better of the (up to four) noted centroids that is neither the row's own nor groupless
-  const float pv1 = __shfl_xor(v1, 32), pv2 = __shfl_xor(v2, 32);
-  const uint32_t pt1 = __shfl_xor(t1, 32), pt2 = __shfl_xor(t2, 32);
-  if (!live || h != 0) return;
-  const float upper_bound = a.bounds[s];
-  const uint32_t cluster = a.assignments[s];
-  const float cv[4] = {v1, v2, pv1, pv2};
-  const uint32_t ct[4] = {t1, t2, pt1, pt2};
-  float best = -INFINITY;
-  uint32_t best_g = 0xFFFFFFFFu;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const uint32_t r = __float_as_uint(cv[i]) & 15u;
-    const uint32_t c = ct[i] * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (i >= 2 ? 1u : 0u);
-    if (c < K && c != cluster && cv[i] > best) {
-      const uint32_t g = a.groups[c];
-      if (g < G) {
-        best = cv[i];
-        best_g = g;
+  for (int e = 0; e < 2; e++) {
+    // the better of the (up to four) noted centroids that is neither the row's own nor groupless
+    const float pv1 = __shfl_xor(v1[e], 32), pv2 = __shfl_xor(v2[e], 32);
+    const uint32_t pt1 = __shfl_xor(t1[e], 32), pt2 = __shfl_xor(t2[e], 32);
+    if (!live[e] || h != 0) continue;
+    const uint32_t row = s[e];
+    const float upper_bound = a.bounds[row];
+    const uint32_t cluster = a.assignments[row];
+    const float cv[4] = {v1[e], v2[e], pv1, pv2};
+    const uint32_t ct[4] = {t1[e], t2[e], pt1, pt2};
+    float best = -INFINITY;
+    uint32_t best_g = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint32_t r = __float_as_uint(cv[i]) & 15u;
+      const uint32_t c = ct[i] * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (i >= 2 ? 1u : 0u);
+      if (c < K && c != cluster && cv[i] > best) {
+        const uint32_t g = a.groups[c];
+        if (g < G) {
+          best = cv[i];
+          best_g = g;
+        }
       }
     }
-  }
-  float hint = INFINITY;
-  if (best_g < G) {
-    const float lbg = a.bounds[(size_t)len * (1 + best_g) + s];
-    float y;
-    if (lbg >= upper_bound) {
-      y = lbg;  // an (a) group: its bound itself enters the second minimum
-    } else {
-      // typical rounding of the hi.hi products (a fraction of the worst case 2^-10 ||x'|| C'max; the
-      // fraction only trades candidates against flagged rows), 16 ulp for the register number
-      const float cmaxc = sqrtf(__uint_as_float(a.stats[0]));
-      const float xc = sqrtf(xc2);
-      const float frac = fminf(1.0f, 4.0f / sqrtf((float)DP));
-      const float e_h = 9.8e-4f * frac * xc * cmaxc + 4e-6f * fabsf(best) + 1e-6f * xc2;
-      if (METRIC == 0) {
-        y = sqrtf(fmaxf(xc2 - 2.0f * (best - e_h), 0.f)) * 1.00001f;
+    float hint = INFINITY;
+    if (best_g < G) {
+      const float lbg = a.bounds[(size_t)len * (1 + best_g) + row];
+      float y;
+      if (lbg >= upper_bound) {
+        y = lbg;  // an (a) group: its bound itself enters the second minimum
       } else {
-        const float dot = best + xmu - e_h;
-        y = (dot >= 1.f ? 0.f : (dot <= -1.f ? 3.1415927f : acosf(dot))) * 1.00001f + 1e-6f;
+        // typical rounding of the hi.hi products (a fraction of the worst case 2^-10 ||x'|| C'max; the
+        // fraction only trades candidates against handed-over rows), 16 ulp for the register number
+        const float cmaxc = sqrtf(__uint_as_float(a.stats[0]));
+        const float xc = sqrtf(xc2[e]);
+        const float frac = fminf(1.0f, 4.0f / sqrtf((float)DP));
+        const float e_h = 9.8e-4f * frac * xc * cmaxc + 4e-6f * fabsf(best) + 1e-6f * xc2[e];
+        if (METRIC == 0) {
+          y = sqrtf(fmaxf(xc2[e] - 2.0f * (best - e_h), 0.f)) * 1.00001f;
+        } else {
+          const float dot = best + xmu[e] - e_h;
+          y = (dot >= 1.f ? 0.f : (dot <= -1.f ? 3.1415927f : acosf(dot))) * 1.00001f + 1e-6f;
+        }
       }
+      hint = fmaxf(upper_bound, y);  // a NaN y leaves the upper bound
+      if (!(hint >= upper_bound)) hint = INFINITY;
     }
-    hint = fmaxf(upper_bound, y);  // a NaN y leaves the upper bound
-    if (!(hint >= upper_bound)) hint = INFINITY;
+    a.hint[pi[e]] = hint;
   }
-  a.hint[pi] = hint;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -497,7 +524,7 @@ bool yy_hint_supported(uint32_t DP) { return DP >= 16 && DP <= 256; }
 template <int DP, int METRIC>
 static hipError_t launch_hint_t(const YyArgs &a, hipStream_t st) {
   const size_t lds_bytes = (2 * 32 * (DP / 2 + 4) + 64) * sizeof(float);
-  const uint32_t grid = (a.len + 127) / 128;  // worst case; blocks beyond the passed count exit at once
+  const uint32_t grid = (a.len + 255) / 256;  // worst case; blocks beyond the passed count exit at once
   if (a.D == (uint32_t)DP)
     hipLaunchKernelGGL((yy_hint_kernel<DP, METRIC, true>), dim3(grid), dim3(256), lds_bytes, st, a);
   else
