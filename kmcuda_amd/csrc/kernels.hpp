@@ -139,6 +139,9 @@ struct YyArgs {
   uint32_t *flag_rows;       // rows the hinted kernel could not settle
   const uint32_t *gfirst, *gsecond;  // G: the two smallest member indices of every group (0xFFFFFFFF: none)
   int hint_f32_sweep;        // candidate sweep of the hinted kernel on the f32 matrix cores (cross-check)
+  // candidate lists from the estimate kernel (KMCUDA_AMD_YY_HINT=3): 8 centroid indices per row, their
+  // number (0xFFFFFFFF: not certified complete), and the rows that keep the sweep (counters[12])
+  uint32_t *cand, *cand_n, *sweep_rows;
   // yy_init: group-sorted padded panel
   const float *pfil, *pbias;
   const uint32_t *pids, *pmeta, *cperm, *gstart;
@@ -151,6 +154,8 @@ hipError_t launch_yy_init_mfma(int metric, const YyArgs &a, hipStream_t st);
 bool yy_hint_supported(uint32_t DP);
 hipError_t launch_yy_hint(int metric, const YyArgs &a, hipStream_t st);
 hipError_t launch_yy_local_hint(int metric, const YyArgs &a, hipStream_t st);
+hipError_t launch_yy_hint_list(int metric, const YyArgs &a, hipStream_t st);
+hipError_t launch_yy_local_list(int metric, const YyArgs &a, hipStream_t st);
 hipError_t launch_yy_sorted_panel(const float *cfil, const float *bias, uint32_t DP, const uint32_t *pids,
                                   uint32_t nslots, float *pfil, float *pbias, hipStream_t st);
 hipError_t launch_yy_global_filter(int metric, const float *samples, uint32_t len, uint32_t D, uint32_t K, uint32_t G,

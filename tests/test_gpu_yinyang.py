@@ -90,7 +90,7 @@ def test_yinyang_steps_bit_exact(n, d, k, G, metric, mode, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("hint", ["f16", "f32", "off"])
+@pytest.mark.parametrize("hint", ["f16", "lists", "f32", "off"])
 @pytest.mark.parametrize("n,d,k,G,data", [(6000, 256, 256, 25, "uniform"), (8000, 64, 100, 10, "uniform"),
                                           (5000, 16, 64, 6, "uniform"), (6000, 256, 128, 12, "blobs"),
                                           (4000, 100, 60, 6, "blobs"), (3000, 24, 200, 20, "uniform")])
@@ -102,7 +102,7 @@ def test_yinyang_many_passes_bit_exact(n, d, k, G, data, hint, monkeypatch):
     f32 matrix cores (KMCUDA_AMD_YY_HINT=2)."""
     from kmcuda_amd.engine import Engine
     monkeypatch.setenv("KMCUDA_AMD_YY_EXACT", "0")
-    monkeypatch.setenv("KMCUDA_AMD_YY_HINT", {"f16": "1", "f32": "2", "off": "0"}[hint])
+    monkeypatch.setenv("KMCUDA_AMD_YY_HINT", {"f16": "1", "f32": "2", "lists": "3", "off": "0"}[hint])
     dev = torch.device("cuda", 0)
     rs = numpy.random.RandomState(n + d + k)
     if data == "uniform":
