@@ -142,6 +142,9 @@ struct YyArgs {
   // candidate lists from the estimate kernel (KMCUDA_AMD_YY_HINT=3): 8 centroid indices per row, their
   // number (0xFFFFFFFF: not certified complete), and the rows that keep the sweep (counters[12])
   uint32_t *cand, *cand_n, *sweep_rows;
+  // per row: its four smallest group bounds (ascending) and their groups, noted by yy_global_filter (or null)
+  const float *rec_lb;
+  const uint32_t *rec_g;
   // yy_init: group-sorted padded panel
   const float *pfil, *pbias;
   const uint32_t *pids, *pmeta, *cperm, *gstart;
@@ -161,7 +164,8 @@ hipError_t launch_yy_sorted_panel(const float *cfil, const float *bias, uint32_t
 hipError_t launch_yy_global_filter(int metric, const float *samples, uint32_t len, uint32_t D, uint32_t K, uint32_t G,
                                    const float *centroids, const float *drifts, const float *gdrifts,
                                    const uint32_t *assignments, uint32_t *assignments_prev, float *bounds,
-                                   uint32_t *passed, uint32_t *counters, hipStream_t st);
+                                   uint32_t *passed, uint32_t *counters, float *rec_lb /* 4 N, or null */,
+                                   uint32_t *rec_g /* 4 N, or null */, hipStream_t st);
 hipError_t launch_yy_local_filter(int metric, const float *samples, uint32_t len, uint32_t D, uint32_t K, uint32_t G,
                                   const float *centroids, const uint32_t *groups, const float *drifts,
                                   const float *gdrifts, uint32_t *assignments, float *bounds, const uint32_t *passed,

@@ -118,12 +118,16 @@ __global__ void yy_group_max_drifts_kernel(const uint32_t *__restrict__ groups, 
 // yy_global_filter (kmeans.cu:540-582): streams the bounds matrix; rows that survive both
 // group-filter tries are appended to `passed` (order irrelevant: each is handled independently)
 // ---------------------------------------------------------------------------------------
-template <int METRIC>
+// REC: also note the row's four smallest (updated) group bounds and their groups: all the hinted local
+// filter needs from the bounds matrix (yinyang_hint.hip: low_bound_fold), which this kernel streams anyway
+// while the local filter would walk it a second time, G lines 4 N bytes apart per row.
+template <int METRIC, bool REC>
 __global__ __launch_bounds__(256) void yy_global_filter_kernel(
     const float *__restrict__ samples, uint32_t len, uint32_t D, uint32_t K, uint32_t G,
     const float *__restrict__ centroids, const float *__restrict__ drifts, const float *__restrict__ gdrifts,
     const uint32_t *__restrict__ assignments, uint32_t *__restrict__ assignments_prev, float *__restrict__ bounds,
-    uint32_t *__restrict__ passed, uint32_t *__restrict__ counters) {
+    uint32_t *__restrict__ passed, uint32_t *__restrict__ counters, float *__restrict__ rec_lb,
+    uint32_t *__restrict__ rec_g) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   bool pass = false;
   if (s < len) {
@@ -133,11 +137,25 @@ __global__ __launch_bounds__(256) void yy_global_filter_kernel(
     const float cluster_drift = drifts[(size_t)K * D + cluster];
     upper_bound += cluster_drift;
     float min_lower_bound = 3.402823466e+38f;
+    float l0 = INFINITY, l1 = INFINITY, l2 = INFINITY, l3 = INFINITY;   // ascending; a NaN bound is never noted
+    uint32_t g0 = 0xFFFFFFFFu, g1 = 0xFFFFFFFFu, g2 = 0xFFFFFFFFu, g3 = 0xFFFFFFFFu;
     for (uint32_t g = 0; g < G; g++) {
       const size_t gi = (size_t)len * (1 + g) + s;
       const float lower_bound = bounds[gi] - gdrifts[g];
       bounds[gi] = lower_bound;
       if (lower_bound < min_lower_bound) min_lower_bound = lower_bound;
+      if (REC) {
+        const float v = lower_bound;
+        const bool c0 = v < l0, c1 = v < l1, c2 = v < l2, c3 = v < l3;
+        l3 = c2 ? l2 : (c3 ? v : l3); g3 = c2 ? g2 : (c3 ? g : g3);
+        l2 = c1 ? l1 : (c2 ? v : l2); g2 = c1 ? g1 : (c2 ? g : g2);
+        l1 = c0 ? l0 : (c1 ? v : l1); g1 = c0 ? g0 : (c1 ? g : g1);
+        l0 = c0 ? v : l0;             g0 = c0 ? g : g0;
+      }
+    }
+    if (REC) {  // (rows that do not pass never read theirs)
+      reinterpret_cast<float4 *>(rec_lb)[s] = make_float4(l0, l1, l2, l3);
+      reinterpret_cast<uint4 *>(rec_g)[s] = make_uint4(g0, g1, g2, g3);
     }
     if (min_lower_bound >= upper_bound) {  // group filter try #1
       bounds[s] = upper_bound;
@@ -247,10 +265,19 @@ hipError_t launch_yy_drifts(int metric, const float *centroids, uint32_t K, uint
 hipError_t launch_yy_global_filter(int metric, const float *samples, uint32_t len, uint32_t D, uint32_t K, uint32_t G,
                                    const float *centroids, const float *drifts, const float *gdrifts,
                                    const uint32_t *assignments, uint32_t *assignments_prev, float *bounds,
-                                   uint32_t *passed, uint32_t *counters, hipStream_t st) {
+                                   uint32_t *passed, uint32_t *counters, float *rec_lb, uint32_t *rec_g,
+                                   hipStream_t st) {
   if (len == 0) return hipSuccess;
-  KMX_DISPATCH(metric, yy_global_filter_kernel, dim3((len + 255) / 256), dim3(256), st, samples, len, D, K, G,
-               centroids, drifts, gdrifts, assignments, assignments_prev, bounds, passed, counters);
+  const dim3 grid((len + 255) / 256), block(256);
+#define KMX_GF_LAUNCH(M, R)                                                                                         \
+  hipLaunchKernelGGL((yy_global_filter_kernel<M, R>), grid, block, 0, st, samples, len, D, K, G, centroids, drifts, \
+                     gdrifts, assignments, assignments_prev, bounds, passed, counters, rec_lb, rec_g)
+  if (rec_lb && rec_g) {
+    if (metric == 0) KMX_GF_LAUNCH(0, true); else KMX_GF_LAUNCH(1, true);
+  } else {
+    if (metric == 0) KMX_GF_LAUNCH(0, false); else KMX_GF_LAUNCH(1, false);
+  }
+#undef KMX_GF_LAUNCH
   return hipGetLastError();
 }
 

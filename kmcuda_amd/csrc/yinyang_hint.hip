@@ -40,6 +40,66 @@ namespace kmx {
 
 typedef _Float16 f16x8h __attribute__((ext_vector_type(8)));
 
+// The (a) rule's share of the second minimum, folded up front (header): the smallest group bound that is
+// >= the upper bound, belongs to a group the reference's scan meets (a member other than the row's own
+// centroid), and is <= S'.  From the global filter's record of the row's four smallest bounds when there is
+// one -- scanning them in ascending order finds it unless all four are below the upper bound (or memberless)
+// while the fourth is still <= S' -- else by walking all G bounds (G lines, 4 N bytes apart per row: this
+// walk, not the matrix sweep, was most of the local filter's time).  Both half-waves return the same value.
+__device__ __forceinline__ float low_bound_fold(const YyArgs &a, uint32_t s, int h, uint32_t cluster, float upper_bound,
+                                                float hint, bool on) {
+  const uint32_t G = a.G, len = a.len;
+  bool walk = on;
+  float alow = kFltMax;
+  if (on && a.rec_lb) {
+    const float4 l4 = reinterpret_cast<const float4 *>(a.rec_lb)[s];
+    const uint4 g4 = reinterpret_cast<const uint4 *>(a.rec_g)[s];
+    const float l[4] = {l4.x, l4.y, l4.z, l4.w};
+    const uint32_t g[4] = {g4.x, g4.y, g4.z, g4.w};
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (!found && g[i] < G && l[i] >= upper_bound) {
+        uint32_t p = a.gfirst[g[i]];
+        if (p == cluster) p = a.gsecond[g[i]];
+        if (p != 0xFFFFFFFFu) {
+          found = true;
+          if (l[i] <= hint) alow = l[i];
+        }
+      }
+    }
+    // not found: every bound that is not recorded is >= the fourth (+inf when fewer than four exist)
+    walk = !found && !(l[3] > hint);
+  }
+  if (__ballot(walk) != 0ull) {
+    float mine = kFltMax;
+    if (walk) {
+      for (uint32_t g0 = h; g0 < G; g0 += 16) {
+        float lb8[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const uint32_t g = g0 + 2 * q;
+          lb8[q] = g < G ? a.bounds[(size_t)len * (1 + g) + s] : -INFINITY;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const float lb = lb8[q];
+          if (lb >= upper_bound && lb <= hint && lb < mine) {
+            const uint32_t g = g0 + 2 * q;
+            uint32_t p = a.gfirst[g];
+            if (p == cluster) p = a.gsecond[g];
+            if (p != 0xFFFFFFFFu) mine = lb;  // the group has a member the reference's scan meets
+          }
+        }
+      }
+    }
+    const float other = __shfl_xor(mine, 32);
+    const float both = other < mine ? other : mine;
+    if (walk) alow = both;
+  }
+  return alow;
+}
+
 // ---------------------------------------------------------------------------------------
 // the estimate: best two coarse scores of every passed row
 // ---------------------------------------------------------------------------------------
@@ -478,31 +538,7 @@ __global__ __launch_bounds__(256) void yy_local_list_kernel(YyArgs a) {
   bool bad = false;
   uint32_t why = 0u;
 
-  {  // (a) groups whose bound can still matter (<= S'), as in yy_local_hint_kernel
-    float alow = kFltMax;
-    if (work) {
-      for (uint32_t g0 = h; g0 < G; g0 += 16) {
-        float lb8[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const uint32_t g = g0 + 2 * q;
-          lb8[q] = g < G ? a.bounds[(size_t)len * (1 + g) + s] : -INFINITY;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const float lb = lb8[q];
-          if (lb >= upper_bound && lb <= hint && lb < alow) {
-            const uint32_t g = g0 + 2 * q;
-            uint32_t p = a.gfirst[g];
-            if (p == cluster) p = a.gsecond[g];
-            if (p != 0xFFFFFFFFu) alow = lb;
-          }
-        }
-      }
-    }
-    const float other = __shfl_xor(alow, 32);
-    second_min = other < alow ? other : alow;
-  }
+  second_min = low_bound_fold(a, s, h, cluster, upper_bound, hint, work);
 
   // the kept candidates that the reference's scan would look at, ascending
   uint32_t cs[8];
@@ -689,33 +725,8 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
   bool bad = !(hint < INFINITY);  // no estimate (or a dead lane): the plain kernel's row
   uint32_t why = bad ? 1u : 0u;   // statistics: first reason the row was handed over
 
-  // (a) groups (bound >= upper bound) whose bound can still matter (<= S'): folded up front.  Each half
-  // wave takes every other group, eight loads in flight at a time (a row's G bounds are G cache lines)
-  {
-    float alow = kFltMax;
-    if (!bad) {
-      for (uint32_t g0 = h; g0 < G; g0 += 16) {
-        float lb8[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const uint32_t g = g0 + 2 * q;
-          lb8[q] = g < G ? a.bounds[(size_t)len * (1 + g) + s] : -INFINITY;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const float lb = lb8[q];
-          if (lb >= upper_bound && lb <= hint && lb < alow) {
-            const uint32_t g = g0 + 2 * q;
-            uint32_t p = a.gfirst[g];
-            if (p == cluster) p = a.gsecond[g];
-            if (p != 0xFFFFFFFFu) alow = lb;  // the group has a member the reference's scan meets
-          }
-        }
-      }
-    }
-    const float other = __shfl_xor(alow, 32);
-    second_min = other < alow ? other : alow;
-  }
+  // (a) groups (bound >= upper bound) whose bound can still matter (<= S'): folded up front
+  second_min = low_bound_fold(a, s, h, cluster, upper_bound, hint, !bad);
 
   // threshold in accumulator space (yinyang_mfma.hip): a centroid can only matter if acc >= amin
   const float cmaxc = sqrtf(__uint_as_float(a.stats[0])) * 1.000001f;
