@@ -1,13 +1,17 @@
 #!/usr/bin/env python
 """bench.py -- point-assignments/sec per Lloyd iteration, 8M x 256 fp32 L2 @ K=1024.
 
-  python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks, one per GPU, RCCL)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (same ranks, launched for it)
+  python bench.py --gpus N --api                          (whole kmeans_cuda() calls through the C ABI, ONE process
+                                                           driving the N GPUs of the device mask, ncclCommInitAll)
 
 A "step" is one full Lloyd iteration over the (row-sharded) synthetic batch: centroid prep,
 MFMA filter + exact refinement (bit-identical assignments), move-delta reduction, the fused
 all-reduce (N > 1) and the centroid update.  Inputs are resident in HBM before timing starts.
 STRONG scaling: the 8M rows are split over the N ranks.  Rank 0 prints ONE JSON line.
+After the timed region (never inside it) rank 0 checks >= 1M rows of the state it has just timed
+against the CPU oracle ("verify" in the line; --no-verify skips it).
 """
 import argparse
 import json
@@ -28,10 +32,9 @@ def pmc_traffic(rows_per_launch, filt="f32"):
     two-stage default: its dominant (coarse) kernel.  PMC counters cannot be collected from inside the bench
     process; None if no matching profile is committed."""
     import glob
-    want = {"f16": ("lloyd_coarse2_kernel",), "f16x3": ("lloyd_filter_f16_kernel",),
-            "f32": ("lloyd_filter_kernel",)}[filt]
+    want = {"f16": ("lloyd_coarse2_kernel",), "f32": ("lloyd_filter_kernel",)}[filt]
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
-    if files and filt != "f16x3":   # the summaries are taken on the default run: f16x3 never sees all rows there
+    if files:
         with open(files[-1]) as fin:
             pmc = json.load(fin)
         total = 0.0
@@ -103,6 +106,106 @@ def sklearn_baseline(features, clusters, rows=100000, iters=6):
                       (rows, features, clusters, per_iter, 1 + iters)}
 
 
+def verify_state(backend, want_rows):
+    """Outside the timed region: one more assignment pass on the state the bench has just timed (the
+    centroids after the last update, the previous assignments), then >= want_rows of its rows -- whole
+    128-row blocks spread over the shard plus a random sample -- are recomputed by the CPU oracle
+    (oracle.lloyd_assign = the reference's kmeans_assign_lloyd arithmetic) and compared bit for bit;
+    the device's reassignment counter is checked against a count of (new != previous) over all rows."""
+    import numpy
+    import torch
+    import oracle
+    n = backend.n_local
+    prev = backend.assignments.clone()
+    backend.reset_changed()
+    backend.assign()
+    backend.synchronize()
+    changed_dev = backend.engine.counters()[0]
+    changed_cnt = int((backend.assignments != prev).sum().item())
+    want = min(int(want_rows), n)
+    rs = numpy.random.RandomState(99)
+    nblk = max(want // 2 // 128, 1)
+    starts = numpy.unique((rs.randint(0, max(n // 128, 1), size=nblk) * 128).astype(numpy.int64))
+    blocks = (starts[:, None] + numpy.arange(128)[None, :]).reshape(-1)
+    blocks = blocks[blocks < n]
+    rest = rs.choice(n, size=max(want - blocks.size, 0), replace=False) if n > want else numpy.arange(0)
+    sel = numpy.unique(numpy.concatenate([blocks, rest.astype(numpy.int64)]))
+    idx = torch.from_numpy(sel).to(backend.device)
+    x = backend.samples.index_select(0, idx).cpu().numpy()
+    cen = backend.centroids.cpu().numpy()
+    got = backend.assignments.index_select(0, idx).cpu().numpy().view(numpy.uint32)
+    prv = prev.index_select(0, idx).cpu().numpy().view(numpy.uint32)
+    t0 = time.time()
+    ref, _, ref_changed = oracle.lloyd_assign(x, cen, assignments=prv)
+    dt = time.time() - t0
+    mism = int((ref != got).sum())
+    return {"rows_checked": int(sel.size), "assignment_mismatches": mism,
+            "reassigned_in_sample_oracle": int(ref_changed), "reassigned_in_sample_device": int((got != prv).sum()),
+            "changed_counter_device": int(changed_dev), "changed_recount_all_rows": changed_cnt,
+            "ok": bool(mism == 0 and changed_dev == changed_cnt and int(ref_changed) == int((got != prv).sum())),
+            "oracle_seconds": round(dt, 2),
+            "what": "assignment pass after the timed steps vs oracle.lloyd_assign on whole 128-row blocks + a random "
+                    "sample of this rank's rows (outside the timed region)"}
+
+
+def api_bench(args):
+    """Whole kmeans_cuda() calls through the drop-in C ABI: ONE process, device mask = the first
+    --gpus GPUs (row shards + ncclCommInitAll inside the library), samples resident on GPU 0
+    (device_ptrs = 0), init=random, Lloyd (yinyang_t = 0).  value = N x iterations / the library's own
+    clock around its iteration loop (kmamd_last_run_stats); the call's wall time is reported beside it."""
+    import ctypes
+    import torch
+    from kmcuda_amd import _lib
+    L = _lib.lib()
+    N, D, K = args.samples, args.features, args.clusters
+    ngpu = args.gpus
+    if torch.cuda.device_count() < ngpu and not os.environ.get("KMCUDA_AMD_VIRTUAL_SHARDS"):
+        raise SystemExit("--gpus %d but only %d GPU(s) visible" % (ngpu, torch.cuda.device_count()))
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    samples = torch.empty((N, D), dtype=torch.float32, device=dev)
+    for s in range(0, N, 1 << 20):
+        samples[s:min(N, s + (1 << 20))].uniform_(0.0, 1.0, generator=gen)
+    cen = torch.empty((K, D), dtype=torch.float32, device=dev)
+    asg = torch.empty(N, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+    mask = (1 << ngpu) - 1 if not os.environ.get("KMCUDA_AMD_VIRTUAL_SHARDS") else 1
+    runs = []
+    calls = max(args.warmup > 0, 0) + max(args.steps // 10, 1)   # one warm-up call, then ~steps/10 timed calls
+    for i in range(calls):
+        t0 = time.perf_counter()
+        rc = L.kmeans_cuda(0, None, args.tolerance, 0.0, 0, N, D, K, 777, mask, 0, 0, 0,
+                           ctypes.c_void_p(samples.data_ptr()), ctypes.c_void_p(cen.data_ptr()),
+                           ctypes.c_void_p(asg.data_ptr()), None)
+        wall = time.perf_counter() - t0
+        if rc != 0:
+            raise SystemExit("kmeans_cuda failed: %s" % _lib.STATUS.get(rc, rc))
+        it, shards, rccl = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        loop_s, setup_s = ctypes.c_double(), ctypes.c_double()
+        L.kmamd_last_run_stats(ctypes.byref(it), ctypes.byref(loop_s), ctypes.byref(setup_s), ctypes.byref(shards),
+                               ctypes.byref(rccl))
+        runs.append({"wall_s": wall, "loop_s": loop_s.value, "setup_s": setup_s.value, "iterations": it.value,
+                     "shards": shards.value, "rccl_ranks": rccl.value})
+    timed = runs[1:] if len(runs) > 1 else runs
+    iters = sum(r["iterations"] for r in timed)
+    loop = sum(r["loop_s"] for r in timed)
+    out = {"metric": "point-assignments/sec per Lloyd iter (8Mx256@1024)", "value": N * iters / loop,
+           "unit": "point-assignments/s", "n_gpus": ngpu, "steps": iters, "warmup": runs[0]["iterations"] if len(runs) > 1 else 0,
+           "ms_per_step": loop / iters * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "whole kmeans_cuda() calls (C ABI, one process, device mask 0x%x): %dx%d fp32 L2 Lloyd, "
+                                  "K=%d, uniform[0,1) rows on GPU 0 (device_ptrs=0), init=random seed 777, tolerance %g, "
+                                  "yinyang_t=0" % (mask, N, D, K, args.tolerance),
+                      "samples": N, "features": D, "clusters": K, "parallelism": "rows/%d" % timed[0]["shards"],
+                      "rccl_ranks_in_library": timed[0]["rccl_ranks"]},
+           "calls": runs,
+           "note": "value = N x iterations / seconds the library spent in its iteration loop (after upload and "
+                   "seeding); wall_s is the whole call incl. the peer copies of the row shards, std::random_shuffle "
+                   "over N indices for init=random and the output gather"}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,10 +218,17 @@ def main():
     ap.add_argument("--no-row-cache", action="store_true",
                     help="convert the coarse stage's operands from the rows on every pass instead of streaming the "
                          "engine's centred half copy (kmamd_set_row_cache); assignments are identical")
-    ap.add_argument("--filter", default="f16", choices=["f16", "f16x3", "f32"],
+    ap.add_argument("--filter", default="f16", choices=["f16", "f32"],
                     help="matrix-core scheme of the assignment filter: f16 = two-stage v_mfma_f32_32x32x16_f16 (coarse "
-                         "hi.hi pass, then the hi/lo-split pass on the undecided rows; default, fastest), f16x3 = the "
-                         "hi/lo-split pass for every row, f32 = v_mfma_f32_32x32x2_f32.  Assignments are bit-identical")
+                         "hi.hi pass, then the contenders of the undecided rows in fp32; default), f32 = "
+                         "v_mfma_f32_32x32x2_f32.  Assignments are bit-identical")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the oracle check of the timed state (outside the timed region)")
+    ap.add_argument("--verify-rows", type=int, default=1000000)
+    ap.add_argument("--api", action="store_true",
+                    help="time whole kmeans_cuda() calls through the drop-in C ABI (device mask = the first --gpus "
+                         "GPUs, ONE process, device-resident input) instead of the one-process-per-GPU step loop")
+    ap.add_argument("--tolerance", type=float, default=0.01, help="--api: kmeans_cuda's stop tolerance")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                     help="f32: the headline fp32 L2 path.  f16: the fp16x2 path (rows as halves, f16 matrix-core "
                          "filter; same assignments as the fp32 path on the same values)")
@@ -127,12 +237,25 @@ def main():
     import torch
     import torch.distributed as dist
     from kmcuda_amd.distributed import HipBackend, ShardedLloyd, row_block
-
+    ranks_seen = 1
+    if args.api:
+        return api_bench(args)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # started as `python bench.py --gpus N`: become the launcher of N ranks of this same script, one per
+        # GPU (RCCL over xGMI between them); the ranks print the line
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # test hooks (a 1-GPU box cannot run RCCL across ranks): all ranks on GPU 0 over gloo
     if os.environ.get("KMCUDA_AMD_BENCH_SINGLE_DEVICE"):
         local_rank = 0
@@ -144,6 +267,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend_name)
+        ranks_seen = dist.get_world_size()
+        if not os.environ.get("KMCUDA_AMD_BENCH_SINGLE_DEVICE") and torch.cuda.device_count() < world:
+            raise SystemExit("--gpus %d but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
 
     N, D, K = args.samples, args.features, args.clusters
     lo, hi = row_block(N, rank, world)
@@ -204,6 +330,9 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    verify = None
+    if rank == 0 and not args.no_verify:
+        verify = verify_state(backend, args.verify_rows)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -220,9 +349,8 @@ def main():
         def roof(filt, ms):
             # ceilings of the ALGORITHMIC rate (2*D*K flop per row), MI355X_MICROARCH.md peaks:
             #   f32   one v_mfma_f32_32x32x2_f32 MAC per algorithmic MAC        -> 157.3 TFLOP/s
-            #   f16x3 three half products per MAC (hi.hi + hi.lo + lo.hi)        -> 2500 / 3
             #   f16   two-stage: the dominant (coarse) kernel does ONE half product per MAC -> 2500
-            pk = {"f32": PEAK_FP32_MFMA_TFLOPS, "f16x3": 2500.0 / 3.0, "f16": 2500.0}[filt]
+            pk = {"f32": PEAK_FP32_MFMA_TFLOPS, "f16": 2500.0}[filt]
             ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             return pk, ach
         peak, achieved = roof(args.filter, dom_ms)
@@ -230,7 +358,6 @@ def main():
         opeak, oach = roof(other, other_ms)
         hr = "true" if f16 else "false"
         kname = {"f16": "lloyd_coarse2_kernel<256,%s,true,%s>" % (("false", "true") if cached else (hr, "false")),
-                 "f16x3": "lloyd_filter_f16_kernel<256,%s,true>" % hr,
                  "f32": "lloyd_filter_kernel<256,true>"}
         # HBM bytes the dominant kernel has to move: the row cache (2 D + 8 bytes per row) or the rows
         row_bytes = (2 * D + 8) if cached else (D * (2 if f16 else 4))
@@ -243,6 +370,10 @@ def main():
             "config": {"workload": "%dx%d %s L2 Lloyd iteration, K=%d, uniform[0,1) rows, init=random; "
                                    "rows sharded %d-way" % (N, D, "fp16x2" if f16 else "fp32", K, world),
                        "samples": N, "features": D, "clusters": K, "parallelism": "rows/%d" % world,
+                       "ranks_seen_by_communicator": ranks_seen,
+                       "collective": ("one all-reduce of %d doubles per iteration (%s)" %
+                                      (K * D + K + 4, os.environ.get("KMCUDA_AMD_BENCH_BACKEND", "nccl = RCCL")))
+                       if world > 1 else "none",
                        "filter": args.filter, "row_cache": bool(cached)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak,
@@ -252,8 +383,8 @@ def main():
                          "hbm": {"achieved": alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0, "peak": 8000.0,
                                  "unit": "GB/s", "frac": alg_bytes / (dom_ms * 1e-3) / 1e9 / 8000.0 if dom_ms > 0 else 0.0},
                          "peak_note": "dense MFMA peak of the instruction the dominant kernel issues, per algorithmic "
-                                      "MAC: f32 157.3; f16 (two-stage, coarse pass = one half product per MAC) 2500; "
-                                      "f16x3 (three half products per MAC) 2500/3.  The chip runs the f16 kernels "
+                                      "MAC: f32 157.3; f16 (two-stage, coarse pass = one half product per MAC) 2500.  "
+                                      "The chip runs the f16 kernels "
                                       "at ~1.7 GHz (power), where the same pipe peaks at ~1770",
                          "kernel": kname[args.filter],
                          "kernel_ms": dom_ms, "filter_stage_ms": filter_ms, "rows_per_launch": n_local},
@@ -272,6 +403,8 @@ def main():
                                              "all-reduce)"},
             "rows_full_exact_scan_last_step": flagged, "rows_pair_refined_last_step": pair_rows, "reassigned_last_step": changed_last,
         }
+        if verify is not None:
+            out["verify"] = verify
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(D, K)
             out["cpu_baseline_sklearn"] = sklearn_baseline(D, K)

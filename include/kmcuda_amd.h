@@ -43,10 +43,10 @@ int kmamd_lloyd_assign_exact(kmamd_engine *e, const float *samples, const float 
                              uint32_t *assignments, uint32_t *assignments_prev);
 
 /* Which matrix-core scheme the assignment filter runs: 0 = two-stage f16 MFMA (default): a coarse
- * pass with the high halves of the centred operands decides most rows, the hi/lo-split pass (22 of 24
- * significand bits) the rest; 1 = f32 MFMA; 2 = the single-stage hi/lo-split f16 pass for every row.
- * Assignments are bit-identical in all three (every stage carries a rigorous bound and the exact
- * kernels decide what is left); env KMCUDA_AMD_FILTER=f32 | f16x3 selects 1 | 2 at engine creation. */
+ * pass with the high halves of the centred operands decides most rows, a contender pass in fp32 the
+ * rest; 1 = f32 MFMA (cross-check).  Assignments are bit-identical in both (every stage carries a
+ * rigorous bound and the exact kernels decide what is left); env KMCUDA_AMD_FILTER=f32 selects 1 at
+ * engine creation. */
 int kmamd_set_filter(kmamd_engine *e, int mode);
 
 /* fp16x2 path: the engine's local rows as IEEE halves (n_rows x features halves, row-major, kept
@@ -80,13 +80,6 @@ int kmamd_counters_reset(kmamd_engine *e, int which /* -1: all */);
  * candidate whose bound exceeds the estimate, a final second minimum above the estimate. */
 int kmamd_yy_hint_stats(kmamd_engine *e, uint32_t *host_out6);
 
-/* Device-side export for a FUSED all-reduce buffer: dst[0..K) = (double)dcount[c],
- * dst[K + i] = (double)counters[i], i = 0..3.  Lets a row-sharded driver reduce
- * [delta | dcount | changed] in ONE collective per iteration (dcount/counters are exact in fp64). */
-int kmamd_pack_reduce_tail(kmamd_engine *e, const int32_t *dcount, double *dst);
-/* inverse: dcount[c] = (int32) src[c] */
-int kmamd_unpack_dcount(kmamd_engine *e, const double *src, int32_t *dcount);
-
 /* Centroid update, split for the all-reduce (reference: kmeans_adjust, kmeans.cu:366-429):
  * move_deltas: delta[K*D] (fp64) = sum(moved-in rows) - sum(moved-out rows), dcount[K];
  * apply_delta: centroids = normalize(centroids*ccounts + delta), ccounts += dcount. */
@@ -94,6 +87,21 @@ int kmamd_move_deltas(kmamd_engine *e, const float *samples, const uint32_t *ass
                       const uint32_t *assignments, double *delta, int32_t *dcount);
 int kmamd_apply_delta(kmamd_engine *e, const double *delta, const int32_t *dcount,
                       float *centroids, uint32_t *ccounts);
+/* The same two steps around ONE collective: buf is kmamd_reduce_len(e) = K*D + K + 4 doubles,
+ *   [ delta (K*D) | dcount (K) | counters 0..3 ]
+ * (counts and counters are exact in fp64), written by reduce_fill with no separate pack step, summed
+ * over the row shards by the caller (one all-reduce per iteration, the exchange of SURVEY 8e), and
+ * consumed by reduce_apply; buf[K*D + K] then holds the GLOBAL number of reassigned rows.  In steady
+ * state reduce_fill enqueues without any host read (update.hip: launch_move_deltas). */
+size_t kmamd_reduce_len(kmamd_engine *e);
+int kmamd_reduce_fill(kmamd_engine *e, const float *samples, const uint32_t *assignments_prev,
+                      const uint32_t *assignments, double *buf);
+int kmamd_reduce_apply(kmamd_engine *e, const double *buf, float *centroids, uint32_t *ccounts);
+/* Test / A-B hook for the update's host logic: 0 default, 1 radix path always, 2 always read the
+ * counts before choosing (the pre-round-2 behaviour), 3 bucket path always without reading (exercises
+ * the device-side fallback of oversized buckets).  Env KMCUDA_AMD_UPDATE=radix|sync|bucket sets it at
+ * engine creation.  Sums are bit-identical on every path. */
+int kmamd_set_update_mode(kmamd_engine *e, int mode);
 
 /* Strict-parity centroid update: kmeans_adjust (kmeans.cu:366-429) operation for operation --
  * one serial fp32 Kahan chain per centroid over its move events in ascending row order with the
@@ -133,6 +141,13 @@ int kmamd_profile_read(kmamd_engine *e, double *filter_ms, uint32_t *filter_laun
 /* stage 1 of the two-stage filter on its own (HIP events around that one launch, inside the filter span) */
 int kmamd_profile_read_coarse(kmamd_engine *e, double *coarse_ms);
 int kmamd_profile_enable(kmamd_engine *e, int on);
+
+/* What the last kmeans_cuda() call of this process did: iterations of its Lloyd / Yinyang loops, the
+ * wall-clock seconds spent in them (after upload + seeding, before the outputs are gathered), the
+ * seconds before (upload, seeding), the number of row shards and of RCCL ranks (0: single GPU or the
+ * one-device test hook).  Lets a driver time the drop-in entry point itself (bench.py --api). */
+int kmamd_last_run_stats(uint32_t *iterations, double *loop_seconds, double *setup_seconds, uint32_t *shards,
+                         uint32_t *rccl_ranks);
 
 /* Library identification: returns the gfx arch string this library was compiled for. */
 const char *kmamd_build_arch(void);

@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libKMCUDA.so")
+# KMCUDA_AMD_LIB: another build of the same library (A/B runs of kernel variants, scripts/coarse_variants.sh)
+LIB_PATH = os.environ.get("KMCUDA_AMD_LIB") or os.path.join(_HERE, "libKMCUDA.so")
 
 u32, i32, f32 = ctypes.c_uint32, ctypes.c_int32, ctypes.c_float
 vp = ctypes.c_void_p
@@ -20,8 +21,8 @@ EXPORTS = [
     "kmeans_cuda", "knn_cuda",
     "kmamd_engine_create", "kmamd_engine_destroy", "kmamd_engine_stream", "kmamd_engine_sync",
     "kmamd_lloyd_assign", "kmamd_lloyd_assign_exact", "kmamd_set_half_rows", "kmamd_set_row_cache", "kmamd_profile_read_coarse", "kmamd_set_filter", "kmamd_counters_read", "kmamd_counters_reset", "kmamd_yy_hint_stats",
-    "kmamd_move_deltas", "kmamd_apply_delta", "kmamd_transpose", "kmamd_pack_reduce_tail",
-    "kmamd_unpack_dcount", "kmamd_adjust_exact", "kmamd_yy_configure", "kmamd_yy_init", "kmamd_yy_drifts", "kmamd_yy_filters",
+    "kmamd_move_deltas", "kmamd_apply_delta", "kmamd_transpose", "kmamd_reduce_len", "kmamd_reduce_fill",
+    "kmamd_reduce_apply", "kmamd_set_update_mode", "kmamd_last_run_stats", "kmamd_adjust_exact", "kmamd_yy_configure", "kmamd_yy_init", "kmamd_yy_drifts", "kmamd_yy_filters",
     "kmamd_profile_reset", "kmamd_profile_read", "kmamd_profile_enable", "kmamd_build_arch",
 ]
 
@@ -68,10 +69,17 @@ def lib():
     L.kmamd_move_deltas.argtypes = [vp, vp, vp, vp, vp, vp]
     L.kmamd_apply_delta.restype = i32
     L.kmamd_apply_delta.argtypes = [vp, vp, vp, vp, vp]
-    L.kmamd_pack_reduce_tail.restype = i32
-    L.kmamd_pack_reduce_tail.argtypes = [vp, vp, vp]
-    L.kmamd_unpack_dcount.restype = i32
-    L.kmamd_unpack_dcount.argtypes = [vp, vp, vp]
+    L.kmamd_reduce_len.restype = ctypes.c_size_t
+    L.kmamd_reduce_len.argtypes = [vp]
+    L.kmamd_reduce_fill.restype = i32
+    L.kmamd_reduce_fill.argtypes = [vp, vp, vp, vp, vp]
+    L.kmamd_reduce_apply.restype = i32
+    L.kmamd_reduce_apply.argtypes = [vp, vp, vp, vp]
+    L.kmamd_set_update_mode.restype = i32
+    L.kmamd_set_update_mode.argtypes = [vp, i32]
+    L.kmamd_last_run_stats.restype = i32
+    L.kmamd_last_run_stats.argtypes = [ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_double),
+                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u32), ctypes.POINTER(u32)]
     L.kmamd_transpose.restype = i32
     L.kmamd_transpose.argtypes = [vp, vp, u32, u32, vp]
     L.kmamd_adjust_exact.restype = i32

@@ -26,15 +26,16 @@ Engine::~Engine() {
     (void)hipEventDestroy(ev_join_);
   }
   if (ev_move_) (void)hipEventDestroy(ev_move_);
+  if (ev_rows_) (void)hipEventDestroy(ev_rows_);
   if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 
 int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric, int fp16x2, hipStream_t stream) {
   if (getenv("KMCUDA_AMD_DEBUG")) g_verbosity = atoi(getenv("KMCUDA_AMD_DEBUG"));
-  if (const char *f = getenv("KMCUDA_AMD_FILTER"))
-    filter_mode_ = strcmp(f, "f32") == 0 ? 1 : (strcmp(f, "f16x3") == 0 ? 2 : 0);
+  if (const char *f = getenv("KMCUDA_AMD_FILTER")) filter_mode_ = strcmp(f, "f32") == 0 ? 1 : 0;
   if (const char *c = getenv("KMCUDA_AMD_ROW_CACHE")) row_cache_allowed_ = atoi(c) != 0;
-  if (const char *r = getenv("KMCUDA_AMD_REFINE")) refine_split_ = strcmp(r, "split") == 0;
+  if (const char *u = getenv("KMCUDA_AMD_UPDATE"))
+    ms_.force = strcmp(u, "radix") == 0 ? 1 : (strcmp(u, "sync") == 0 ? 2 : (strcmp(u, "bucket") == 0 ? 3 : 0));
   if (D == 0 || K < 1 || K >= 0x7FFFFFFFu) return kInvalidArguments;  // K == 1: Yinyang group clustering with one group
   if (fp16x2) return kInvalidArguments;  // fp16x2 kernels are not built yet ("next")
   int ndev = 0;
@@ -71,7 +72,8 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if ((rc = alloc(&bias2_, K_pad_))) return rc;
   if ((rc = alloc(&cfil_, (size_t)K_pad_ * dp))) return rc;
   if ((rc = alloc(&ct_, (size_t)D * Kt_))) return rc;
-  if ((rc = alloc(&stats_, 8))) return rc;
+  if ((rc = alloc(&stats_base_, 16))) return rc;
+  stats_ = stats_base_;
   if ((rc = alloc(&mu_, dp))) return rc;
   if ((rc = alloc(&finite_, Kt_))) return rc;
   if ((rc = alloc(&flagged_, n_rows))) return rc;
@@ -84,10 +86,14 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if ((rc = alloc(&offsets2_, 2 * (size_t)K + 2))) return rc;
   if ((rc = alloc(&move_blocks_, (size_t)n_rows / 1024 + 4))) return rc;
   if ((rc = alloc(&bucket_work_, move_bucket_words(K)))) return rc;
-  KMX_HIP(hipMemset(bucket_work_, 0, move_bucket_words(K) * sizeof(uint32_t)), kRuntimeError);
+  KMX_HIP(hipMemsetAsync(bucket_work_, 0, move_bucket_words(K) * sizeof(uint32_t), stream_), kRuntimeError);
+  KMX_HIP(hipMemsetAsync(stats_base_, 0, 16 * sizeof(uint32_t), stream_), kRuntimeError);
   KMX_HIP(hipHostMalloc(reinterpret_cast<void **>(&host_move_count_), 4 * sizeof(uint32_t), hipHostMallocDefault), kMemoryAllocationFailure);
   memset(host_move_count_, 0, 4 * sizeof(uint32_t));
+  host_move_count_[2] = 0xFFFFFFFFu;   // undecided rows: not known yet
+  ms_.host = host_move_count_;
   KMX_HIP(hipEventCreateWithFlags(&ev_move_, hipEventDisableTiming), kRuntimeError);
+  KMX_HIP(hipEventCreateWithFlags(&ev_rows_, hipEventDisableTiming), kRuntimeError);
   sort_temp_bytes_ = sort_temp_bytes(2 * (size_t)n_rows, 2 * K);
   {
     const size_t b2 = sort_temp_bytes(n_rows, K);
@@ -142,6 +148,10 @@ void Engine::profile_reset() {
 
 int Engine::prepare_centroids(const float *centroids) {
   const uint32_t dp = DP_ ? DP_ : 8;
+  // this preparation's statistics go to the other half; both halves are zeroed here, which also leaves
+  // the half after this one zero (the invariant centroid_prep_frozen_kernel relies on)
+  stats_ = stats_ == stats_base_ ? stats_base_ + 8 : stats_base_;
+  KMX_HIP(hipMemsetAsync(stats_base_, 0, 16 * sizeof(uint32_t), stream_), kRuntimeError);
   KMX_HIP(launch_centroid_prep(metric_, centroids, K_, D_, K_pad_, dp, Kt_, csqr_, bias_, bias2_, cfil_, ct_, mu_,
                                mu_frozen_, finite_, stats_, counters_ + 1, counters_ + 3, counters_ + 4, stream_),
           kRuntimeError);
@@ -287,16 +297,14 @@ int Engine::yy_filters(const float *samples, const float *centroids, const float
     if (yy_hint_ && yy_hint_supported(DP_)) {
       // second-best estimate per passed row, the local filter against it, the plain kernel for the rest
       if (!yy_hint_buf_) {
-        uint16_t *p16 = nullptr, *phi = nullptr;
-        if ((rc = alloc(&p16, (size_t)K_pad_ * 2 * DP_))) return rc;
+        uint16_t *phi = nullptr;
         if ((rc = alloc(&phi, (size_t)((K_pad_ + 63u) / 64u * 64u) * (DP_ + 2)))) return rc;
         if ((rc = alloc(&yy_flag_rows_, N_))) return rc;
         if ((rc = alloc(&yy_hint_buf_, N_))) return rc;
-        yy_panel16_ = p16;
         yy_panelhi_ = phi;
       }
-      KMX_HIP(launch_centroid_panel16(centroids, K_, D_, K_pad_, DP_, finite_, mu_, bias_, yy_panel16_, yy_panelhi_,
-                                      stats_, stream_),
+      KMX_HIP(launch_centroid_panelhi(centroids, K_, D_, K_pad_, DP_, finite_, mu_, bias_, yy_panelhi_, stats_,
+                                      stream_),
               kRuntimeError);
       KMX_HIP(hipMemsetAsync(counters_ + 5, 0, sizeof(uint32_t), stream_), kRuntimeError);
       a.panelhi = yy_panelhi_; a.hint = yy_hint_buf_; a.flag_rows = yy_flag_rows_;
@@ -336,11 +344,41 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   // row cache (two-stage f16 filter only): x - mu as halves in operand order, built on the first pass
   // after set_row_cache(1); mu is frozen from then on, so the copy stays valid for every later pass
-  const bool want_cache = row_cache_on_ && !exact_only && DP_ != 0 && filter_mode_ == 0 &&
-                          lloyd_filter_f16_supported(D_, DP_) && N_ != 0;
+  const bool two_stage = !exact_only && DP_ != 0 && filter_mode_ == 0 && lloyd_filter_f16_supported(D_, DP_);
+  const bool want_cache = row_cache_on_ && two_stage && N_ != 0;
   const bool build_cache = want_cache && !row_cache_valid_;
   if (build_cache) mu_frozen_ = false;  // take the mean of THESE centroids
-  {
+  if (!side_stream_) {
+    // (non-blocking even beside a blocking main stream: fork / join events order it completely)
+    KMX_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking), kRuntimeError);
+    KMX_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming), kRuntimeError);
+    KMX_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming), kRuntimeError);
+  }
+  if (two_stage && !panelhi_) {
+    uint16_t *phi = nullptr;
+    int rc = alloc(&phi, (size_t)((K_pad_ + 63u) / 64u * 64u) * (DP_ + 2));  // whole 64-row super-tiles + their biases
+    if (rc) return rc;
+    if ((rc = alloc(&undecided_, N_))) return rc;
+    if ((rc = alloc(&und_thr_, N_))) return rc;
+    panelhi_ = phi;
+  }
+  // Steady state of the two-stage filter (mean frozen, cache valid): ONE preparation kernel in front of
+  // stage 1; the reference's serial sum_squares chain and the transposed panel, which only the pair /
+  // exact kernels read, are computed beside stage 1 on the side stream.
+  const bool steady = two_stage && mu_frozen_ && row_cache_on_ && row_cache_valid_ && N_ != 0;
+  bool rows_on_side = false;
+  if (steady) {
+    uint32_t *next = stats_;
+    stats_ = stats_ == stats_base_ ? stats_base_ + 8 : stats_base_;
+    KMX_HIP(hipEventRecord(ev_fork_, stream_), kRuntimeError);   // the centroids are final here
+    KMX_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0), kRuntimeError);
+    KMX_HIP(launch_centroid_rows(metric_, centroids, K_, D_, Kt_, csqr_, ct_, side_stream_), kRuntimeError);
+    KMX_HIP(hipEventRecord(ev_rows_, side_stream_), kRuntimeError);
+    rows_on_side = true;
+    KMX_HIP(launch_centroid_prep_frozen(metric_, centroids, K_, D_, K_pad_, DP_, mu_, finite_, bias_, bias2_, cfil_,
+                                        panelhi_, stats_, next, counters_ + 1, counters_ + 3, counters_ + 4, stream_),
+            kRuntimeError);
+  } else {
     int rc = prepare_centroids(centroids);
     if (rc) return rc;
   }
@@ -358,61 +396,47 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
     span_end();
     return kSuccess;
   }
-  // counters_[1] / [3] (the filter's list lengths) were zeroed by centroid_prep
+  // counters_[1] / [3] / [4] (the filter's list lengths) were zeroed by the preparation
   span_begin(0);
-  if (filter_mode_ != 1 && lloyd_filter_f16_supported(D_, DP_)) {
-    if (!panel16_) {
-      uint16_t *p16 = nullptr, *phi = nullptr;
-      int rc = alloc(&p16, (size_t)K_pad_ * 2 * DP_);
-      if (rc) return rc;
-      if ((rc = alloc(&phi, (size_t)((K_pad_ + 63u) / 64u * 64u) * (DP_ + 2)))) return rc;  // whole 64-row super-tiles + their biases
-      if ((rc = alloc(&undecided_, N_))) return rc;
-      if ((rc = alloc(&und_thr_, N_))) return rc;
-      panel16_ = p16;
-      panelhi_ = phi;
-    }
+  if (two_stage) {
     const void *rows = half_rows_ ? half_rows_ : (const void *)samples;
     const bool half = half_rows_ != nullptr;
-    KMX_HIP(launch_centroid_panel16(centroids, K_, D_, K_pad_, DP_, finite_, mu_, bias_, panel16_,
-                                    filter_mode_ == 0 ? panelhi_ : nullptr, stats_, stream_),
-            kRuntimeError);
-    if (filter_mode_ == 0) {
-      if (build_cache) {
-        const size_t npad = ((size_t)N_ + 255) / 256 * 256;
-        if (!xcache_) {
-          uint16_t *xc = nullptr;
-          float *xm = nullptr;
-          // no memory for the copy: not an error, the operands are converted from the rows every pass
-          if (alloc(&xc, npad * DP_) == kSuccess && alloc(&xm, npad * 2 + 2) == kSuccess) {
-            xcache_ = xc;
-            xmeta_ = xm;
-          } else {
-            (void)hipGetLastError();
-            row_cache_on_ = false;
-          }
-        }
-        if (xcache_) {
-          KMX_HIP(launch_row_cache(rows, half, N_, D_, DP_, mu_, xcache_, xmeta_, stream_), kRuntimeError);
-          row_cache_valid_ = true;
-          mu_frozen_ = true;
+    if (!steady)
+      KMX_HIP(launch_centroid_panelhi(centroids, K_, D_, K_pad_, DP_, finite_, mu_, bias_, panelhi_, stats_, stream_),
+              kRuntimeError);
+    if (build_cache) {
+      const size_t npad = ((size_t)N_ + 255) / 256 * 256;
+      if (!xcache_) {
+        uint16_t *xc = nullptr;
+        float *xm = nullptr;
+        // no memory for the copy: not an error, the operands are converted from the rows every pass
+        if (alloc(&xc, npad * DP_) == kSuccess && alloc(&xm, npad * 2 + 2) == kSuccess) {
+          xcache_ = xc;
+          xmeta_ = xm;
+        } else {
+          (void)hipGetLastError();
+          row_cache_on_ = false;
         }
       }
-      const bool cached = row_cache_on_ && row_cache_valid_;
-      // counters_[4] (the undecided list's length) was zeroed by centroid_prep
-      span_begin(3);  // the dominant kernel on its own, inside the filter span
-      KMX_HIP(launch_lloyd_coarse(a, rows, half, cached ? xcache_ : nullptr, xmeta_, panelhi_, undecided_, und_thr_,
-                                  stream_),
-              kRuntimeError);
-      span_end();
-      if (refine_split_)  // KMCUDA_AMD_REFINE=split: the three-product pass over all K for the undecided rows
-        KMX_HIP(launch_lloyd_filter_f16(a, rows, half, panel16_, undecided_, counters_ + 4, stream_), kRuntimeError);
-      else
-        KMX_HIP(launch_lloyd_refine(a, rows, half, panelhi_, undecided_, und_thr_, counters_ + 4, last_undecided_,
-                                    stream_),
-                kRuntimeError);
-    } else {
-      KMX_HIP(launch_lloyd_filter_f16(a, rows, half, panel16_, nullptr, nullptr, stream_), kRuntimeError);
+      if (xcache_) {
+        KMX_HIP(launch_row_cache(rows, half, N_, D_, DP_, mu_, xcache_, xmeta_, stream_), kRuntimeError);
+        row_cache_valid_ = true;
+        mu_frozen_ = true;
+      }
     }
+    const bool cached = row_cache_on_ && row_cache_valid_;
+    span_begin(3);  // the dominant kernel on its own, inside the filter span
+    KMX_HIP(launch_lloyd_coarse(a, rows, half, cached ? xcache_ : nullptr, xmeta_, panelhi_, undecided_, und_thr_,
+                                stream_),
+            kRuntimeError);
+    span_end();
+    // stage 2's grid follows an EARLIER pass's list length (whatever the update's async copy has
+    // delivered to the pinned word; the kernel strides over the device-side count, so only speed
+    // depends on it)
+    last_undecided_ = host_move_count_[2];
+    KMX_HIP(launch_lloyd_refine(a, rows, half, panelhi_, undecided_, und_thr_, counters_ + 4, last_undecided_,
+                                stream_),
+            kRuntimeError);
   } else {
     KMX_HIP(launch_lloyd_filter(a, stream_), kRuntimeError);
   }
@@ -420,17 +444,12 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   span_begin(1);
   // the two refine kernels work on disjoint row lists and are latency bound (one 256-step exact
   // chain per contender): the full-scan kernel runs on a side stream beside the pair kernel
-  if (!side_stream_) {
-    // (non-blocking even beside a blocking main stream: fork / join events order it completely)
-    KMX_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking), kRuntimeError);
-    KMX_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming), kRuntimeError);
-    KMX_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming), kRuntimeError);
-  }
   KMX_HIP(hipEventRecord(ev_fork_, stream_), kRuntimeError);
   KMX_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0), kRuntimeError);
   const uint32_t grid = N_ < 4096u ? N_ : 4096u;  // grid-strides over the device-side flagged count
   KMX_HIP(launch_lloyd_exact(metric_, a, flagged_, counters_ + 1, grid, side_stream_), kRuntimeError);
   KMX_HIP(hipEventRecord(ev_join_, side_stream_), kRuntimeError);
+  if (rows_on_side) KMX_HIP(hipStreamWaitEvent(stream_, ev_rows_, 0), kRuntimeError);   // csqr for the pair kernel
   KMX_HIP(launch_lloyd_pair(metric_, a, centroids, (N_ + 127) / 128 < 2048u ? (N_ + 127) / 128 : 2048u, stream_),
           kRuntimeError);
   KMX_HIP(hipStreamWaitEvent(stream_, ev_join_, 0), kRuntimeError);
@@ -439,26 +458,25 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
 }
 
 int Engine::move_deltas(const float *samples, const uint32_t *prev, const uint32_t *cur, double *delta,
-                        int32_t *dcount) {
+                        int32_t *dcount, double *tail) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   span_begin(2);
-  // rides on the update's host round trip: the length of this pass's undecided list sizes the next
-  // pass's stage-2 grid
+  // the length of this pass's undecided list, for a LATER pass's stage-2 grid (async: nobody waits)
   KMX_HIP(hipMemcpyAsync(host_move_count_ + 2, counters_ + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_),
           kMemoryCopyError);
   KMX_HIP(launch_move_deltas(samples, N_, D_, K_, prev, cur, keys_tmp_, vals_tmp_, keys_sorted_, rows_sorted_,
-                             offsets2_, sort_temp_, sort_temp_bytes_, partial_, delta, dcount, move_blocks_,
-                             bucket_work_, host_move_count_, &last_move_events_, ev_move_, stream_),
+                             offsets2_, sort_temp_, sort_temp_bytes_, partial_, delta, dcount, tail, counters_,
+                             move_blocks_, bucket_work_, &ms_, ev_move_, stream_),
           kRuntimeError);
-  if (N_) last_undecided_ = host_move_count_[2];   // launch_move_deltas synchronised the stream
   span_end();
   return kSuccess;
 }
 
-int Engine::apply_delta(const double *delta, const int32_t *dcount, float *centroids, uint32_t *ccounts) {
+int Engine::apply_delta(const double *delta, const int32_t *dcount, const double *dcount_d, float *centroids,
+                        uint32_t *ccounts) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   span_begin(2);
-  KMX_HIP(launch_apply_delta(metric_, delta, dcount, K_, D_, centroids, ccounts, stream_), kRuntimeError);
+  KMX_HIP(launch_apply_delta(metric_, delta, dcount, dcount_d, K_, D_, centroids, ccounts, stream_), kRuntimeError);
   span_end();
   return kSuccess;
 }
@@ -553,14 +571,28 @@ int kmamd_counters_reset(kmamd_engine *e, int which) { return e->e.counters_rese
 int kmamd_yy_hint_stats(kmamd_engine *e, uint32_t *host_out6) { return e->e.yy_hint_stats(host_out6); }
 int kmamd_move_deltas(kmamd_engine *e, const float *samples, const uint32_t *assignments_prev,
                       const uint32_t *assignments, double *delta, int32_t *dcount) {
-  return e->e.move_deltas(samples, assignments_prev, assignments, delta, dcount);
+  return e->e.move_deltas(samples, assignments_prev, assignments, delta, dcount, nullptr);
 }
 int kmamd_apply_delta(kmamd_engine *e, const double *delta, const int32_t *dcount, float *centroids,
                       uint32_t *ccounts) {
-  return e->e.apply_delta(delta, dcount, centroids, ccounts);
+  return e->e.apply_delta(delta, dcount, nullptr, centroids, ccounts);
+}
+size_t kmamd_reduce_len(kmamd_engine *e) { return (size_t)e->e.K_ * e->e.D_ + e->e.K_ + 4; }
+int kmamd_reduce_fill(kmamd_engine *e, const float *samples, const uint32_t *assignments_prev,
+                      const uint32_t *assignments, double *buf) {
+  return e->e.move_deltas(samples, assignments_prev, assignments, buf, nullptr, buf + (size_t)e->e.K_ * e->e.D_);
+}
+int kmamd_reduce_apply(kmamd_engine *e, const double *buf, float *centroids, uint32_t *ccounts) {
+  return e->e.apply_delta(buf, nullptr, buf + (size_t)e->e.K_ * e->e.D_, centroids, ccounts);
+}
+int kmamd_set_update_mode(kmamd_engine *e, int mode) {
+  if (mode < 0 || mode > 3) return kmx::kInvalidArguments;
+  e->e.ms_.force = mode;
+  e->e.ms_.async_ok = false;
+  return kmx::kSuccess;
 }
 int kmamd_set_filter(kmamd_engine *e, int mode) {
-  if (mode < 0 || mode > 2) return kmx::kInvalidArguments;
+  if (mode < 0 || mode > 1) return kmx::kInvalidArguments;
   e->e.filter_mode_ = mode;
   return kmx::kSuccess;
 }
@@ -578,16 +610,6 @@ int kmamd_set_row_cache(kmamd_engine *e, int on) {
 int kmamd_adjust_exact(kmamd_engine *e, const float *samples, const uint32_t *assignments_prev,
                        const uint32_t *assignments, float *centroids, uint32_t *ccounts) {
   return e->e.adjust_exact(samples, assignments_prev, assignments, centroids, ccounts);
-}
-int kmamd_pack_reduce_tail(kmamd_engine *e, const int32_t *dcount, double *dst) {
-  if (hipSetDevice(e->e.device_) != hipSuccess) return kmx::kNoSuchDevice;
-  return kmx::launch_pack_reduce_tail(dcount, e->e.counters_, e->e.K_, dst, e->e.stream_) == hipSuccess
-             ? kmx::kSuccess : kmx::kRuntimeError;
-}
-int kmamd_unpack_dcount(kmamd_engine *e, const double *src, int32_t *dcount) {
-  if (hipSetDevice(e->e.device_) != hipSuccess) return kmx::kNoSuchDevice;
-  return kmx::launch_unpack_dcount(src, e->e.K_, dcount, e->e.stream_) == hipSuccess ? kmx::kSuccess
-                                                                                      : kmx::kRuntimeError;
 }
 int kmamd_transpose(kmamd_engine *e, const float *in, uint32_t rows, uint32_t cols, float *out) {
   if (hipSetDevice(e->e.device_) != hipSuccess) return kmx::kNoSuchDevice;

@@ -40,8 +40,11 @@ class Engine {
   // steps (all async on stream_)
   int lloyd_assign(const float *samples, const float *centroids, uint32_t *assignments,
                    uint32_t *assignments_prev, bool exact_only);
-  int move_deltas(const float *samples, const uint32_t *prev, const uint32_t *cur, double *delta, int32_t *dcount);
-  int apply_delta(const double *delta, const int32_t *dcount, float *centroids, uint32_t *ccounts);
+  // tail: the fused reduce buffer's [dcount | counters] behind delta (or null); dcount may be null then
+  int move_deltas(const float *samples, const uint32_t *prev, const uint32_t *cur, double *delta, int32_t *dcount,
+                  double *tail);
+  int apply_delta(const double *delta, const int32_t *dcount, const double *dcount_d, float *centroids,
+                  uint32_t *ccounts);
   int adjust_exact(const float *samples, const uint32_t *prev, const uint32_t *cur, float *centroids,
                    uint32_t *ccounts);
   int prepare_centroids(const float *centroids);
@@ -70,6 +73,7 @@ class Engine {
   hipStream_t side_stream_ = nullptr;   // the full-scan refine kernel beside the pair kernel
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   hipEvent_t ev_move_ = nullptr;        // the update's count copy (launch_move_deltas waits for it alone)
+  hipEvent_t ev_rows_ = nullptr;        // csqr / ct ready on the side stream (steady-state preparation)
   uint32_t N_ = 0, D_ = 0, K_ = 0, K_pad_ = 0, Kt_ = 0, DP_ = 0;
   int metric_ = 0, fp16x2_ = 0;
   float eps_ = 0, tie_slack_ = 0;
@@ -79,25 +83,26 @@ class Engine {
   uint32_t *finite_ = nullptr;
   // fp16x2 path: the local rows as halves (caller-owned) + the hi/lo-split centred centroid panel
   const void *half_rows_ = nullptr;
-  void *panel16_ = nullptr, *panelhi_ = nullptr;
+  void *panelhi_ = nullptr;
   uint32_t *undecided_ = nullptr;
   float *und_thr_ = nullptr;      // per undecided row: coarse scores below it are ruled out
-  bool refine_split_ = false;     // KMCUDA_AMD_REFINE=split (A/B, cross-check)
-  // 0: two-stage f16 matrix-core filter (hi.hi, then hi/lo split for the undecided rows; default),
-  // 1: f32 matrix-core filter (KMCUDA_AMD_FILTER=f32), 2: single-stage hi/lo-split f16 filter (=f16x3)
+  // 0: two-stage f16 matrix-core filter (hi.hi, then the contenders in fp32; default),
+  // 1: f32 matrix-core filter (KMCUDA_AMD_FILTER=f32; cross-check)
   int filter_mode_ = 0;
   // row cache of the coarse filter stage (lloyd_f16.hip: row_cache_kernel); set_row_cache()
   bool row_cache_allowed_ = true;   // KMCUDA_AMD_ROW_CACHE=0 vetoes it
   bool row_cache_on_ = false, row_cache_valid_ = false, mu_frozen_ = false;
   void *xcache_ = nullptr;
   float *xmeta_ = nullptr;
-  uint32_t *stats_ = nullptr, *flagged_ = nullptr, *pairs_ = nullptr, *counters_ = nullptr;
+  // stats_: the ACTIVE half of a double-buffered 2 x 8 words (stats_base_): every preparation flips to
+  // the other half, which the invariant keeps zero (memset, or zeroed by centroid_prep_frozen_kernel)
+  uint32_t *stats_base_ = nullptr, *stats_ = nullptr, *flagged_ = nullptr, *pairs_ = nullptr, *counters_ = nullptr;
   // update workspace
   uint32_t *keys_tmp_ = nullptr, *vals_tmp_ = nullptr, *keys_sorted_ = nullptr, *rows_sorted_ = nullptr,
            *offsets2_ = nullptr, *move_blocks_ = nullptr, *bucket_work_ = nullptr;
-  uint32_t last_undecided_ = 0xFFFFFFFFu;     // previous pass's undecided rows (sizes stage 2's grid)
-  uint32_t last_move_events_ = 0xFFFFFFFFu;   // previous update's event count (predicts the cheaper path)
-  uint32_t *host_move_count_ = nullptr;  // pinned: the event count the update's sort is sized by
+  uint32_t last_undecided_ = 0xFFFFFFFFu;     // an earlier pass's undecided rows (sizes stage 2's grid)
+  MoveState ms_;                          // the update's host-side state (update.hip: launch_move_deltas)
+  uint32_t *host_move_count_ = nullptr;   // 4 pinned words: [0] events [1] largest bucket [2] undecided rows
   void *sort_temp_ = nullptr;
   size_t sort_temp_bytes_ = 0;
   double *partial_ = nullptr;
@@ -113,7 +118,7 @@ class Engine {
   uint32_t *yy_rec_g_ = nullptr;
   uint32_t *gfirst_ = nullptr, *gsecond_ = nullptr, *yy_flag_rows_ = nullptr;
   float *yy_hint_buf_ = nullptr;
-  void *yy_panel16_ = nullptr, *yy_panelhi_ = nullptr;
+  void *yy_panelhi_ = nullptr;
   int yy_hint_stats(uint32_t *host6);
   uint32_t *groups_ = nullptr, *cperm_ = nullptr, *gstart_ = nullptr, *pids_ = nullptr, *pmeta_ = nullptr;
   float *pfil_ = nullptr, *pbias_ = nullptr, *xt_ = nullptr;

@@ -37,16 +37,23 @@ hipError_t launch_lloyd_pair(int metric, const LloydArgs &a, const float *centro
 hipError_t launch_lloyd_exact(int metric, const LloydArgs &a, const uint32_t *rows, const uint32_t *nrows,
                               uint32_t grid, hipStream_t st);
 
-// lloyd_f16.hip -- the same filter on the f16 matrix cores (centred hi/lo-split operands), for fp32
+// lloyd_f16.hip -- the two-stage filter on the f16 matrix cores (centred operands), for fp32
 // rows and for the fp16x2 path's half rows; decisions identical in kind, refine kernels shared
 bool lloyd_filter_f16_supported(uint32_t D, uint32_t DP);
-// panel16 = [hi | lo] rows for the split pass; panelhi (may be null) = hi rows + clamped biases for the
-// coarse pass, K_pad rounded up to 64 rows, (DP + 2) * 2 bytes per row; stats[5] = max ||c' - hi(c')||^2
-hipError_t launch_centroid_panel16(const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP,
-                                   const uint32_t *finite, const float *mu, const float *bias, void *panel16,
-                                   void *panelhi, uint32_t *stats, hipStream_t st);
-hipError_t launch_lloyd_filter_f16(const LloydArgs &a, const void *rows, bool half_rows, const void *panel16,
-                                   const uint32_t *row_list, const uint32_t *n_list, hipStream_t st);
+// panelhi = hi(c - mu) rows + clamped biases for the coarse pass, K_pad rounded up to 64 rows,
+// (DP + 2) * 2 bytes per row; stats[5] = max ||c' - hi(c')||^2
+hipError_t launch_centroid_panelhi(const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP,
+                                   const uint32_t *finite, const float *mu, const float *bias, void *panelhi,
+                                   uint32_t *stats, hipStream_t st);
+// the steady-state preparation of the two-stage filter in one kernel (mean frozen); zeroes stats_next
+// and the three list counters.  csqr / ct come from launch_centroid_rows on another stream
+hipError_t launch_centroid_prep_frozen(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad,
+                                       uint32_t DP, const float *mu, uint32_t *finite, float *bias, float *bias2,
+                                       float *cfil, void *panelhi, uint32_t *stats, uint32_t *stats_next,
+                                       uint32_t *zero_a, uint32_t *zero_b, uint32_t *zero_c, hipStream_t st);
+// the reference's exact sum_squares (csqr) + the transposed panel (ct) alone: what the pair / exact kernels read
+hipError_t launch_centroid_rows(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t Kt, float *csqr,
+                                float *ct, hipStream_t st);
 // stage 1 of the default filter: hi.hi products only; rows it cannot decide -> undecided[counters[4]++].
 // xcache / xmeta: the engine's row cache (launch_row_cache) or nullptr (operands converted from rows)
 hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
@@ -69,22 +76,28 @@ size_t move_bucket_words(uint32_t K);   // launch_move_deltas' bucket_work, zero
 hipError_t launch_inverse_assignments(const uint32_t *assignments, uint32_t N, uint32_t K, uint32_t *keys_tmp,
                                       uint32_t *vals_tmp, uint32_t *keys_sorted, uint32_t *inv,
                                       uint32_t *offsets, void *temp, size_t temp_bytes, hipStream_t st);
+// host-side state of the update across calls (engine-owned)
+struct MoveState {
+  uint32_t *host = nullptr;            // 4 pinned words: [0] events, [1] largest bucket (async copies land here)
+  uint32_t last_events = 0xFFFFFFFFu;  // newest event count the host knows
+  bool async_ok = false;               // bucket path without reading the counts first
+  bool bucket_last = false;            // the last CHECKED call took the bucket path (speculation)
+  int force = 0;                       // kmamd_set_update_mode
+};
 hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint32_t K, const uint32_t *prev,
                               const uint32_t *cur, uint32_t *keys_tmp, uint32_t *vals_tmp, uint32_t *keys_sorted,
                               uint32_t *rows_sorted, uint32_t *offsets2, void *temp, size_t temp_bytes,
-                              double *partial, double *delta, int32_t *dcount, uint32_t *blockoff,
-                              uint32_t *bucket_work, uint32_t *host_count /* 4 pinned words, zeroed by the owner */,
-                              uint32_t *last_events, hipEvent_t copied /* may be null */, hipStream_t st);
+                              double *partial, double *delta, int32_t *dcount /* may be null */,
+                              double *tail /* fused buffer's [dcount | counters], may be null */,
+                              const uint32_t *counters, uint32_t *blockoff, uint32_t *bucket_work, MoveState *ms,
+                              hipEvent_t copied /* may be null */, hipStream_t st);
 hipError_t launch_adjust_exact(int metric, const float *samples, uint32_t N, uint32_t D, uint32_t K,
                                const uint32_t *prev, const uint32_t *cur, uint32_t *keys_tmp, uint32_t *vals_tmp,
                                uint32_t *keys_sorted, uint32_t *rows_sorted, uint32_t *offsets2, void *temp,
                                size_t temp_bytes, float *work, float *centroids, uint32_t *ccounts, hipStream_t st);
-hipError_t launch_apply_delta(int metric, const double *delta, const int32_t *dcount, uint32_t K, uint32_t D,
+hipError_t launch_apply_delta(int metric, const double *delta, const int32_t *dcount /* or */,
+                              const double *dcount_d /* the fused buffer's tail */, uint32_t K, uint32_t D,
                               float *centroids, uint32_t *ccounts, hipStream_t st);
-
-hipError_t launch_pack_reduce_tail(const int32_t *dcount, const uint32_t *counters, uint32_t K, double *dst,
-                                   hipStream_t st);
-hipError_t launch_unpack_dcount(const double *src, uint32_t K, int32_t *dcount, hipStream_t st);
 
 // seeding.hip (reference: kmeans.cu:42-67 kmeans_plus_plus, transpose.cu:6-14 copy_sample_t,
 // kmeans.cu:674-691 kmeans_calc_average_distance)

@@ -16,12 +16,15 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <functional>
 #include <memory>
 #include <thread>
 #include <vector>
 
 #include "../../include/kmcuda.h"
+#include "../../include/kmcuda_amd.h"
 #include "engine.hpp"
 
 using namespace kmx;
@@ -61,7 +64,7 @@ struct Rccl {
     return CommInitAll && CommDestroy && GroupStart && GroupEnd && AllReduce;
   }
 };
-constexpr int kNcclInt32 = 2, kNcclFloat64 = 8, kNcclSum = 0;  // rccl.h ncclDataType_t / ncclRedOp_t
+constexpr int kNcclFloat64 = 8, kNcclSum = 0;  // rccl.h ncclDataType_t / ncclRedOp_t
 
 // ---------------------------------------------------------------------------------------
 // device list from the mask (reference: setup_devices, kmcuda.cc:63-137)
@@ -141,8 +144,7 @@ struct Shard {
   const float *samples = nullptr;  // length x D on this device
   float *centroids = nullptr;      // K x D (replicated)
   uint32_t *assignments = nullptr, *prev = nullptr, *ccounts = nullptr;
-  double *delta = nullptr;
-  int32_t *dcount = nullptr;
+  double *reduce = nullptr;        // the iteration's ONE exchange: [delta K*D | dcount K | counters 4] (kmcuda_amd.h)
   float *dists = nullptr;          // length floats (k-means++ / average distance)
   // Yinyang state (allocated when the Yinyang phase starts; reference: kmcuda.cc:448-470)
   float *bounds = nullptr;         // (G+1) x length, group-major (kmeans.cu:431-485 layout)
@@ -163,6 +165,11 @@ struct Shard {
     return 0;
   }
 };
+
+// what the last kmeans_cuda() call did (kmamd_last_run_stats): iterations of the Lloyd / Yinyang loops and
+// the wall time spent in them (everything after seeding), for drivers that time the drop-in entry point
+struct RunStats { uint32_t iterations = 0; double loop_seconds = 0, setup_seconds = 0; uint32_t shards = 0, rccl = 0; };
+RunStats g_last_run;
 
 class Job {
  public:
@@ -234,8 +241,7 @@ class Job {
       if ((rc = sh->alloc(&sh->assignments, sh->length))) return rc;
       if ((rc = sh->alloc(&sh->prev, sh->length))) return rc;
       if ((rc = sh->alloc(&sh->ccounts, K))) return rc;
-      if ((rc = sh->alloc(&sh->delta, (size_t)K * D))) return rc;
-      if ((rc = sh->alloc(&sh->dcount, K))) return rc;
+      if ((rc = sh->alloc(&sh->reduce, (size_t)K * D + K + 4))) return rc;
       if ((rc = sh->alloc(&sh->dists, sh->length))) return rc;
       shards.push_back(std::move(sh));
     }
@@ -278,18 +284,17 @@ class Job {
     for (auto &s : shards)
       if (index >= s->offset && index < s->offset + s->length) owner = s.get();
     if (!owner) return kmcudaRuntimeError;
-    (void)hipSetDevice(owner->dev);
     const float *src = owner->samples + (size_t)(index - owner->offset) * D;
     for (auto &s : shards) {
       hipError_t e;
       float *dst = s->centroids + (size_t)slot * D;
-      if (s->dev == owner->dev) {
-        (void)hipSetDevice(owner->dev);
-        // order after anything pending on the destination shard's stream
+      // the copy is enqueued on the DESTINATION shard's stream (ordered after anything pending there),
+      // with that stream's device current
+      (void)hipSetDevice(s->dev);
+      if (s->dev == owner->dev)
         e = hipMemcpyAsync(dst, src, D * sizeof(float), hipMemcpyDeviceToDevice, s->eng->stream_);
-      } else {
+      else
         e = hipMemcpyPeerAsync(dst, s->dev, src, owner->dev, D * sizeof(float), s->eng->stream_);
-      }
       if (e != hipSuccess) return kmcudaMemoryCopyError;
     }
     return 0;
@@ -358,6 +363,7 @@ class Job {
         }
         if (device_ptrs < 0) return broadcast_centroids_from_host(host_centroids);
         for (auto &s : shards) {
+          (void)hipSetDevice(s->dev);
           hipError_t e = hipMemcpyPeerAsync(s->centroids, s->dev, host_centroids, device_ptrs,
                                             (size_t)K * D * sizeof(float), s->eng->stream_);
           if (e != hipSuccess) return kmcudaMemoryCopyError;
@@ -588,44 +594,59 @@ class Job {
     return 0;
   }
 
-  // ---- the per-iteration collective: delta (fp64 K*D) and dcount (int32 K) summed over shards ----
-  int allreduce_deltas() {
+  // runs fn(shard) for every shard -- on one host thread per shard when there are several, so that a
+  // step that has to wait for its GPU (the first iterations' update reads an event count) does not hold
+  // up the enqueueing for the other GPUs.  Returns the first non-zero code.
+  int for_shards(const std::function<int(Shard &)> &fn) {
+    if (shards.size() == 1) {
+      (void)hipSetDevice(shards[0]->dev);
+      return fn(*shards[0]);
+    }
+    std::vector<int> rcs(shards.size(), 0);
+    std::vector<std::thread> pool;
+    for (size_t i = 0; i < shards.size(); i++)
+      pool.emplace_back([&, i]() {
+        (void)hipSetDevice(shards[i]->dev);
+        rcs[i] = fn(*shards[i]);
+      });
+    for (auto &t : pool) t.join();
+    for (int rc : rcs)
+      if (rc) return rc;
+    return 0;
+  }
+
+  // ---- the per-iteration collective: ONE all-reduce of [delta (fp64 K*D) | dcount K | counters 4] ----
+  int allreduce_fused() {
     if (shards.size() == 1) return 0;
+    const size_t len = (size_t)K * D + K + 4;
     if (!comms.empty()) {
       if (rccl.GroupStart() != 0) return kmcudaRuntimeError;
       for (size_t i = 0; i < shards.size(); i++) {
         auto &s = shards[i];
         (void)hipSetDevice(s->dev);
-        if (rccl.AllReduce(s->delta, s->delta, (size_t)K * D, kNcclFloat64, kNcclSum, comms[i], s->eng->stream_) != 0)
-          return kmcudaRuntimeError;
-        if (rccl.AllReduce(s->dcount, s->dcount, K, kNcclInt32, kNcclSum, comms[i], s->eng->stream_) != 0)
+        if (rccl.AllReduce(s->reduce, s->reduce, len, kNcclFloat64, kNcclSum, comms[i], s->eng->stream_) != 0)
           return kmcudaRuntimeError;
       }
       if (rccl.GroupEnd() != 0) return kmcudaRuntimeError;
       return 0;
     }
     // several shards on ONE device (test hook KMCUDA_AMD_VIRTUAL_SHARDS): fixed-order host sum
-    std::vector<double> acc((size_t)K * D, 0.0), tmp((size_t)K * D);
-    std::vector<int32_t> cacc(K, 0), ctmp(K);
+    std::vector<double> acc(len, 0.0), tmp(len);
     for (auto &s : shards) {
+      (void)hipSetDevice(s->dev);
       RETERR(s->eng->sync());
-      if (hipMemcpy(tmp.data(), s->delta, tmp.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+      if (hipMemcpy(tmp.data(), s->reduce, len * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
         return kmcudaMemoryCopyError;
-      if (hipMemcpy(ctmp.data(), s->dcount, K * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
-        return kmcudaMemoryCopyError;
-      for (size_t i = 0; i < acc.size(); i++) acc[i] += tmp[i];
-      for (uint32_t c = 0; c < K; c++) cacc[c] += ctmp[c];
+      for (size_t i = 0; i < len; i++) acc[i] += tmp[i];
     }
-    for (auto &s : shards) {
-      if (hipMemcpy(s->delta, acc.data(), acc.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+    for (auto &s : shards)
+      if (hipMemcpy(s->reduce, acc.data(), len * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
         return kmcudaMemoryCopyError;
-      if (hipMemcpy(s->dcount, cacc.data(), K * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
-        return kmcudaMemoryCopyError;
-    }
     return 0;
   }
 
   // reference: check_changed, kmeans.cu:697-717.  Returns 1 to stop, 0 to go on, <0 error.
+  // Reads the shards' device counters (one stream synchronisation per shard).
   int check_changed(int iter, float tolerance, bool print, uint32_t *passed_total = nullptr) {
     uint32_t overall_changed = 0, overall_passed = 0, pair_rows = 0, scan_rows = 0;
     for (auto &s : shards) {
@@ -636,6 +657,24 @@ class Job {
       scan_rows += c[1];
       pair_rows += c[3];
     }
+    return judge_changed(iter, tolerance, print, overall_changed, overall_passed, pair_rows, scan_rows, passed_total);
+  }
+
+  // the same test from the REDUCED buffer's tail (the counters rode along in the iteration's all-reduce):
+  // one 32-byte read on the first shard instead of a synchronisation per GPU
+  int check_changed_reduced(int iter, float tolerance, bool print) {
+    Shard &f = *shards[0];
+    (void)hipSetDevice(f.dev);
+    double tail[4];
+    if (hipMemcpyAsync(tail, f.reduce + (size_t)K * D + K, sizeof(tail), hipMemcpyDeviceToHost, f.eng->stream_) != hipSuccess ||
+        hipStreamSynchronize(f.eng->stream_) != hipSuccess)
+      return -kmcudaMemoryCopyError;
+    return judge_changed(iter, tolerance, print, (uint32_t)tail[0], (uint32_t)tail[2], (uint32_t)tail[3], (uint32_t)tail[1],
+                         nullptr);
+  }
+
+  int judge_changed(int iter, float tolerance, bool print, uint32_t overall_changed, uint32_t overall_passed,
+                    uint32_t pair_rows, uint32_t scan_rows, uint32_t *passed_total) {
     if (print && passed_total == nullptr)
       DEBUG("filter: %u rows settled by two exact chains, %u by a full exact scan\n", pair_rows, scan_rows);
     if (print && passed_total != nullptr)
@@ -650,16 +689,29 @@ class Job {
 
   bool exact_update = false;  // KMCUDA_AMD_EXACT_UPDATE=1: the reference's serial Kahan chain (single shard)
 
-  int adjust() {  // reference: kmeans_adjust launch + peer exchange, kmeans.cu:1002-1024
+  // the update in three stream-ordered phases (reference: kmeans_adjust launch + peer exchange,
+  // kmeans.cu:1002-1024): fill every shard's reduce buffer, ONE all-reduce, apply on every shard
+  int fill_deltas() {
+    const uint32_t kd = K * D;
+    return for_shards([kd](Shard &s) {
+      return s.eng->move_deltas(s.samples, s.prev, s.assignments, s.reduce, nullptr, s.reduce + kd);
+    });
+  }
+  int apply_deltas() {
+    const uint32_t kd = K * D;
+    for (auto &s : shards) RETERR(s->eng->apply_delta(s->reduce, nullptr, s->reduce + kd, s->centroids, s->ccounts));
+    return quantize_centroids();
+  }
+
+  int adjust() {
     if (exact_update) {
       Shard &s = *shards[0];
       RETERR(s.eng->adjust_exact(s.samples, s.prev, s.assignments, s.centroids, s.ccounts));
       return quantize_centroids();
     }
-    for (auto &s : shards) RETERR(s->eng->move_deltas(s->samples, s->prev, s->assignments, s->delta, s->dcount));
-    RETERR(allreduce_deltas());
-    for (auto &s : shards) RETERR(s->eng->apply_delta(s->delta, s->dcount, s->centroids, s->ccounts));
-    return quantize_centroids();
+    RETERR(fill_deltas());
+    RETERR(allreduce_fused());
+    return apply_deltas();
   }
 
   // fp16x2: the reference keeps centroids in half2, i.e. every update is rounded to half
@@ -689,7 +741,10 @@ class Job {
     return 0;
   }
 
-  // reference: kmeans_cuda_lloyd, kmeans.cu:934-1026
+  // reference: kmeans_cuda_lloyd, kmeans.cu:934-1026.  Per iteration: assignment on every shard, the
+  // shards' move sums, ONE all-reduce that also carries the reassignment counters, the stop test on
+  // the reduced counters (before the update, as kmeans.cu:991-1000), the update.  One host read per
+  // iteration for the whole job; everything else is enqueued without waiting.
   int lloyd(float tolerance, bool resume, int *iterations) {
     RETERR(prepare_mem(resume));
     // the samples do not change inside one kmeans_cuda() call: let the coarse filter stage keep its
@@ -702,14 +757,25 @@ class Job {
       if (!resume || iter > 1) {
         for (auto &s : shards)
           RETERR(s->eng->lloyd_assign(s->samples, s->centroids, s->assignments, s->prev, false));
-        const int status = check_changed(iter, tolerance, true);
+        int status;
+        if (exact_update) {
+          status = check_changed(iter, tolerance, true);
+        } else {
+          RETERR(fill_deltas());
+          RETERR(allreduce_fused());
+          status = check_changed_reduced(iter, tolerance, true);
+        }
         if (status < 0) return -status;
+        g_last_run.iterations++;
         if (status == 1) {
           if (iterations) *iterations = iter;
           return 0;
         }
+        if (exact_update) RETERR(adjust());
+        else RETERR(apply_deltas());
+      } else {
+        RETERR(adjust());
       }
-      RETERR(adjust());
     }
   }
 
@@ -797,6 +863,7 @@ class Job {
         RETERR(s->eng->yy_filters(s->samples, s->centroids, s->drifts, s->gdrifts, s->assignments, s->prev, s->bounds,
                                   s->passed));
       }
+      g_last_run.iterations++;
     }
   }
 
@@ -1206,6 +1273,8 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
   // landed before our own non-blocking streams read it -- the reference got this from the legacy
   // default stream's implicit synchronisation
   if (device_ptrs >= 0 && hipSetDevice(device_ptrs) == hipSuccess) (void)hipDeviceSynchronize();
+  const auto t_begin = std::chrono::steady_clock::now();
+  g_last_run = RunStats();
   Job job;
   job.fp16 = fp16x2 != 0;
   // fp16x2: features_size counts half2 pairs (kmcuda.h:107-108); internally one feature per half
@@ -1219,6 +1288,11 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
   }
   const uint32_t afk_m = (init == kmcudaInitMethodAFKMC2 && init_params) ? *reinterpret_cast<const uint32_t *>(init_params) : 0;
   RETERR(job.init_centroids(init, seed, centroids, device_ptrs, afk_m));
+  RETERR(job.sync_all());
+  const auto t_loop = std::chrono::steady_clock::now();
+  g_last_run.setup_seconds = std::chrono::duration<double>(t_loop - t_begin).count();
+  g_last_run.shards = (uint32_t)job.shards.size();
+  g_last_run.rccl = job.comms.empty() ? 0u : (uint32_t)job.comms.size();
 
   if (yy_groups_size == 0 || kYinyangDraftReassignments <= tolerance) {  // kmeans.cu:1037-1050
     if (yy_groups_size == 0) INFO("too few clusters for this yinyang_t => Lloyd\n");
@@ -1232,6 +1306,8 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
     if (st < 0) return static_cast<KMCUDAResult>(-st);
     if (st == 0) RETERR(job.yinyang(tolerance, yy_groups_size, iter));
   }
+  RETERR(job.sync_all());
+  g_last_run.loop_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
   if (average_distance) RETERR(job.average_distance(average_distance));
   RETERR(job.gather_outputs(centroids, assignments, device_ptrs));
   DEBUG("return kmcudaSuccess\n");
@@ -1262,6 +1338,16 @@ KMCUDAResult knn_cuda(uint16_t k, KMCUDADistanceMetric metric, uint32_t samples_
   RETERR(job.run(devs, virtual_shards(), k, metric, samples_size, feats, clusters_size, device_ptrs, verbosity,
                  fp16x2 != 0, samples, centroids, assignments, neighbors));
   DEBUG("return kmcudaSuccess\n");
+  return kmcudaSuccess;
+}
+
+int kmamd_last_run_stats(uint32_t *iterations, double *loop_seconds, double *setup_seconds, uint32_t *shards,
+                         uint32_t *rccl_ranks) {
+  if (iterations) *iterations = g_last_run.iterations;
+  if (loop_seconds) *loop_seconds = g_last_run.loop_seconds;
+  if (setup_seconds) *setup_seconds = g_last_run.setup_seconds;
+  if (shards) *shards = g_last_run.shards;
+  if (rccl_ranks) *rccl_ranks = g_last_run.rccl;
   return kmcudaSuccess;
 }
 

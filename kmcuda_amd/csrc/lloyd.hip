@@ -64,7 +64,7 @@ __global__ void centroid_rows_kernel(const float *__restrict__ centroids, uint32
       if (ct) ct[(size_t)f * Kt + c] = v;
     }
     const bool fin = (plain - plain) == 0.f;  // false for NaN and inf
-    finite[c] = fin ? 1u : 0u;
+    if (finite) finite[c] = fin ? 1u : 0u;
     if (csqr) csqr[c] = (METRIC == 0) ? ssqr : 1.f;
     // uncentered max ||c||^2 for the bound on the REFERENCE's own rounding error
     if (fin) plain_max = plain * 1.0001f;
@@ -74,7 +74,7 @@ __global__ void centroid_rows_kernel(const float *__restrict__ centroids, uint32
   // one atomic per wave, not per centroid (K same-address atomics cost more than the kernel)
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) plain_max = fmaxf(plain_max, __shfl_xor(plain_max, off));
-  if ((threadIdx.x & 63) == 0 && plain_max > 0.f) atomicMax(&stats[2], __float_as_uint(plain_max));
+  if (stats && (threadIdx.x & 63) == 0 && plain_max > 0.f) atomicMax(&stats[2], __float_as_uint(plain_max));
 }
 
 // mean of the finite centroid rows, one thread per (padded) feature.  Any vector would do: the
@@ -649,8 +649,7 @@ hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, 
                                 uint32_t DP, uint32_t Kt, float *csqr, float *bias, float *bias2, float *cfil,
                                 float *ct, float *mu, bool freeze_mu, uint32_t *finite, uint32_t *stats,
                                 uint32_t *zero_a, uint32_t *zero_b, uint32_t *zero_c, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(stats, 0, 8 * sizeof(uint32_t), st);
-  if (e != hipSuccess) return e;
+  // (stats: zeroed by the caller)
   const dim3 block(64);
   if (metric == 0)
     hipLaunchKernelGGL((centroid_rows_kernel<0>), dim3((Kt + 63) / 64), block, 0, st, centroids, K, D, Kt, csqr, ct,
@@ -666,6 +665,17 @@ hipError_t launch_centroid_prep(int metric, const float *centroids, uint32_t K, 
   else
     hipLaunchKernelGGL((centroid_panel_kernel<1>), dim3((K_pad + 15) / 16), dim3(256), 0, st, centroids, K, D, K_pad, DP,
                        finite, mu, bias, bias2, cfil, stats);
+  return hipGetLastError();
+}
+
+hipError_t launch_centroid_rows(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t Kt, float *csqr,
+                                float *ct, hipStream_t st) {
+  if (metric == 0)
+    hipLaunchKernelGGL((centroid_rows_kernel<0>), dim3((Kt + 63) / 64), dim3(64), 0, st, centroids, K, D, Kt, csqr, ct,
+                       (uint32_t *)nullptr, (uint32_t *)nullptr);
+  else
+    hipLaunchKernelGGL((centroid_rows_kernel<1>), dim3((Kt + 63) / 64), dim3(64), 0, st, centroids, K, D, Kt, csqr, ct,
+                       (uint32_t *)nullptr, (uint32_t *)nullptr);
   return hipGetLastError();
 }
 

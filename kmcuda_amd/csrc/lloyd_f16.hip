@@ -3,25 +3,15 @@
 //
 // The filter only has to produce scores with a RIGOROUS error bound (lloyd.hip: rows it cannot
 // decide go to the exact kernels), so nothing forces it onto the f32 MFMA (64 FLOP/clk/SIMD, 1/16
-// of the f16 rate).  A centred fp32 operand split into two halves, a = a_hi + a_lo + r with
-// |r| <= 2^-22 |a| + 2^-25, keeps 22 of its 24 significand bits, the products of halves are exact
-// in the fp32 accumulator, and the residual is far below the bound the filter already carries.
-// fp16x2 semantics of this implementation are the fp32 reference arithmetic on the
-// half VALUES, so the half-row variant reproduces the fp32 path's decisions on the widened rows
-// (the exact kernels read the widened copy): same contract, half the HBM bytes.
-//
-//   * rows are read as fp32 (HALF_ROWS = false) or as HALVES (512 B instead of 1 KB at D = 256);
-//   * operands are CENTRED in fp32 (x' = x - mu, c' = c - mu: the centred bound, lloyd.hip) and
-//     split into two halves each, a = a_hi + a_lo + r, |r| <= 2^-22 |a| + 2^-25, so that
-//         x'.c' ~= x_hi.c_hi + x_hi.c_lo + x_lo.c_hi
-//     with every product exact in the fp32 accumulator of v_mfma_f32_32x32x16_f16: three f16 MFMAs
-//     (16 features each, 32 cycles) replace eight f32 MFMAs (2 features each, 64 cycles) -- 5.3x
-//     fewer matrix-pipe cycles per (row, centroid) pair;
-//   * the dropped lo.lo term and the split residuals are part of the error bound E.
-//
-// Layout: identical to the f32 filter (4 waves x 32 rows per block, 32-centroid tiles double
-// buffered in LDS, the lower half-wave contracts features [0, DP/2), the upper [DP/2, DP)); a panel
-// row holds DP hi halves followed by DP lo halves = the same 4*DP bytes as an f32 row.
+// of the f16 rate).  Two stages:
+//   1. lloyd_coarse2_kernel: operands CENTRED in fp32 (x' = x - mu, c' = c - mu) and rounded to halves;
+//      hi(x').hi(c') with ONE v_mfma_f32_32x32x16_f16 per 16 features, products exact in the fp32
+//      accumulator, the operand rounding carried explicitly in the bound.  Decides the
+//      rows whose best / second-best gap exceeds the bound (the large majority).
+//   2. lloyd_refine_kernel: the others -- contenders above the row's cut-off, scored in fp32.
+// (Round 1 also had a single-stage three-product pass, x_hi.c_hi + x_hi.c_lo + x_lo.c_hi; it was a third
+// copy of the filter kept only as a cross-check and is gone: the f32 matrix-core filter of lloyd.hip and
+// the exact kernels are the two cross-checks.)
 #include <hip/hip_fp16.h>
 
 #include "exact.hpp"
@@ -34,16 +24,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// c' = c - mu split into halves: panel16[c] = [hi(c'_0..DP-1) | lo(c'_0..DP-1)]; zero rows for
-// non-finite / padding centroids (their bias is -inf in the shared bias array).  One wave per centroid.
-// For the coarse stage the same pass writes the hi halves alone (panelhi: K_pad rounded up to whole
-// 64-row super-tiles, zero rows beyond K_pad) and, behind them, the biases with -inf clamped to a
+// hi(c - mu) as halves for the coarse stage: panelhi = K_pad rounded up to whole 64-row super-tiles
+// (zero rows for non-finite / padding centroids) and, behind them, the biases with -inf clamped to a
 // finite floor; stats[5] = max ||c' - hi(c')||^2, the rounding residual the coarse bound needs.
-__global__ __launch_bounds__(256) void centroid_panel16_kernel(
+// One wave per centroid.
+__global__ __launch_bounds__(256) void centroid_panelhi_kernel(
     const float *__restrict__ centroids, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP,
     const uint32_t *__restrict__ finite, const float *__restrict__ mu, const float *__restrict__ bias,
-    _Float16 *__restrict__ panel16, _Float16 *__restrict__ panelhi, uint32_t K_pad64,
-    uint32_t *__restrict__ stats) {
+    _Float16 *__restrict__ panelhi, uint32_t K_pad64, uint32_t *__restrict__ stats) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t c = blockIdx.x * 4 + wave;
   uint32_t res_bits = 0;
@@ -56,18 +44,14 @@ __global__ __launch_bounds__(256) void centroid_panel16_kernel(
       if (ok && f < D) v = centroids[(size_t)c * D + f] - mu[f];
       const _Float16 hi = (_Float16)v;
       const float r = v - (float)hi;  // exact: hi keeps the leading 11 bits of v
-      if (real) {
-        panel16[(size_t)c * 2 * DP + f] = hi;
-        panel16[(size_t)c * 2 * DP + DP + f] = (_Float16)r;
-      }
-      if (panelhi) panelhi[(size_t)c * DP + f] = hi;
+      panelhi[(size_t)c * DP + f] = hi;
       res2 = fmaf(r, r, res2);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) res2 += __shfl_xor(res2, o);
     // an overflowed half leaves inf - inf = NaN: "no bound", the coarse stage decides nothing
     res_bits = ((res2 - res2) == 0.f) ? __float_as_uint(res2 * 1.0001f) : 0x7F800000u;
-    if (panelhi && lane == 0)
+    if (lane == 0)
       reinterpret_cast<float *>(panelhi + (size_t)K_pad64 * DP)[c] = real ? fmaxf(bias[c], -3.0e38f) : -3.0e38f;
   }
   __shared__ uint32_t part[4];
@@ -76,212 +60,121 @@ __global__ __launch_bounds__(256) void centroid_panel16_kernel(
   if (threadIdx.x == 0) atomicMax(&stats[5], max(max(part[0], part[1]), max(part[2], part[3])));
 }
 
-template <int DP, bool HALF_ROWS, bool FAST>
-__global__ __launch_bounds__(256, 2) void lloyd_filter_f16_kernel(
-    const void *__restrict__ rows, uint32_t N, uint32_t D, const float *__restrict__ panel16f,
-    const float *__restrict__ bias, const float *__restrict__ mu, uint32_t K_pad, uint32_t K,
-    const uint32_t *__restrict__ stats, float eps, float tie_slack, uint32_t *__restrict__ assignments,
-    uint32_t *__restrict__ assignments_prev, uint32_t *__restrict__ flagged, uint32_t *__restrict__ pairs,
-    uint32_t *__restrict__ counters, const uint32_t *__restrict__ row_list, const uint32_t *__restrict__ n_list) {
-  constexpr int NKH = DP / 2;          // features per half-wave
-  constexpr int KS = NKH / 8;          // k-steps (8 features per lane per MFMA)
-  constexpr int LDW = DP + 4;          // padded LDS row in 4-byte words (row = 2*DP halves)
-  constexpr int TILE = 32 * LDW;
-  constexpr int NST = (8 * DP + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  auto tile_ptr = [&](int buf) { return lds + buf * TILE; };
-  auto bias_ptr = [&](int buf) { return lds + 2 * TILE + buf * 32; };
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
-  // all rows (row_list == nullptr: one 128-row group per block) or the rows the coarse stage could not
-  // decide (a device-side list: the grid strides over its 128-row groups)
-  const uint32_t total = row_list ? *n_list : N;
-  for (uint32_t group = blockIdx.x; (size_t)group * 128u < total; group += gridDim.x) {
-  const uint32_t pi = group * 128u + wave * 32u + col;
-  const bool live = pi < total;
-  const uint32_t s = row_list ? (live ? row_list[pi] : 0u) : pi;
-
-  // ---- B operand: my half row, centred in fp32, split into hi / lo halves ----
-  f16x8 xhi[KS], xlo[KS];
-  float xn2 = 0.f, xo2 = 0.f, x0 = 0.f;
-  {
-    const size_t row = (size_t)(live ? s : 0);
-    const float *m = mu + h * NKH;
+// The whole centroid preparation of a pass in ONE kernel, for the steady state of the two-stage filter
+// (mean frozen by the row cache): finite flags, the centred fp32 panel + biases (centroid_panel_kernel),
+// the hi halves + clamped biases + residual maximum (centroid_panelhi_kernel) and the uncentred norm
+// maximum (centroid_rows_kernel) -- what stage 1 waits for.  The reference's exact sum_squares chain
+// (serial, 256 steps) and the transposed panel are only read by the pair / exact kernels: they run
+// beside stage 1 on the side stream.  One wave per padded row.  Also zeroes the per-pass list counters
+// and the OTHER half of the double-buffered stats (the next pass's), saving the memset launches.
+template <int METRIC>
+__global__ __launch_bounds__(256) void centroid_prep_frozen_kernel(
+    const float *__restrict__ centroids, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP, uint32_t K_pad64,
+    const float *__restrict__ mu, uint32_t *__restrict__ finite, float *__restrict__ bias, float *__restrict__ bias2,
+    float *__restrict__ cfil, _Float16 *__restrict__ panelhi, uint32_t *__restrict__ stats,
+    uint32_t *__restrict__ stats_next, uint32_t *__restrict__ zero_a, uint32_t *__restrict__ zero_b,
+    uint32_t *__restrict__ zero_c) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && threadIdx.x < 8) {
+    stats_next[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) { *zero_a = 0u; *zero_b = 0u; *zero_c = 0u; }
+  }
+  uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
+  for (uint32_t i = 0; i < 4; i++) {
+    const uint32_t c = blockIdx.x * 16 + wave * 4 + i;
+    if (c >= K_pad64) break;
+    const bool real = c < K_pad;
+    float plain = 0.f;
+    if (c < K)
+      for (uint32_t f = lane; f < D; f += 64) {
+        const float v = centroids[(size_t)c * D + f];
+        plain = fmaf(v, v, plain);
+      }
 #pragma unroll
-    for (int j = 0; j < KS; j++) {
-      float xv[8];
-      if (FAST && HALF_ROWS) {
-        const f16x8 raw = reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(rows) + row * DP + h * NKH)[j];
+    for (int off = 32; off > 0; off >>= 1) plain += __shfl_xor(plain, off);
+    const bool ok = c < K && (plain - plain) == 0.f;   // false for a row holding a NaN or an inf
+    if (c < K && lane == 0) finite[c] = ok ? 1u : 0u;
+    float n2 = 0.f, mc = 0.f, m2 = 0.f, res2 = 0.f;
+    for (uint32_t f = lane; f < DP; f += 64) {
+      float v = 0.f, m = 0.f;
+      if (ok && f < D) {
+        m = mu[f];
+        v = centroids[(size_t)c * D + f] - m;
+      }
+      const _Float16 hi = (_Float16)v;
+      const float r = v - (float)hi;
+      if (real) cfil[(size_t)c * DP + f] = v;
+      panelhi[(size_t)c * DP + f] = hi;
+      n2 = fmaf(v, v, n2);
+      mc = fmaf(m, v, mc);
+      m2 = fmaf(m, m, m2);
+      res2 = fmaf(r, r, res2);
+    }
 #pragma unroll
-        for (int q = 0; q < 8; q++) xv[q] = (float)raw[q];
-      } else if (FAST) {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(rows) + row * DP + h * NKH);
-        const f32x4 a = src[2 * j], b = src[2 * j + 1];
-        xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w;
-        xv[4] = b.x; xv[5] = b.y; xv[6] = b.z; xv[7] = b.w;
+    for (int off = 32; off > 0; off >>= 1) {
+      n2 += __shfl_xor(n2, off);
+      mc += __shfl_xor(mc, off);
+      m2 += __shfl_xor(m2, off);
+      res2 += __shfl_xor(res2, off);
+    }
+    float b = -INFINITY, b2 = -INFINITY;
+    if (ok) {
+      float bmag;
+      if (METRIC == 0) {
+        b = -0.5f * n2;
+        bmag = 0.5f * n2;
       } else {
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const uint32_t f = h * NKH + 8 * j + q;
-          float v = 0.f;
-          if (f < D) v = HALF_ROWS ? (float)reinterpret_cast<const _Float16 *>(rows)[row * D + f]
-                                   : reinterpret_cast<const float *>(rows)[row * D + f];
-          xv[q] = v;
-        }
+        b = mc;
+        bmag = sqrtf(m2) * sqrtf(n2) * 1.0001f;
       }
-      f16x8 hi, lo;
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const bool on = live && (FAST || h * NKH + 8 * j + q < (int)D);
-        const float x = on ? xv[q] : 0.f;
-        const float xc = on ? x - m[8 * j + q] : 0.f;
-        const _Float16 a = (_Float16)xc;
-        hi[q] = a;
-        lo[q] = (_Float16)(xc - (float)a);
-        xo2 = fmaf(x, x, xo2);
-        xn2 = fmaf(xc, xc, xn2);
-        if (j == 0 && q == 0) x0 = live ? xv[q] : 0.f;
-      }
-      xhi[j] = hi;
-      xlo[j] = lo;
+      const float mag2 = (METRIC == 0) ? sqrtf(m2) * sqrtf(n2) * 1.0001f + 0.5f * n2 : 0.f;
+      b2 = (METRIC == 0) ? -mc - 0.5f * n2 : 0.f;
+      s0 = max(s0, __float_as_uint(n2 * 1.0001f));
+      s1 = max(s1, __float_as_uint(bmag * 1.0001f));
+      s2 = max(s2, __float_as_uint(plain * 1.0001f));
+      s3 = max(s3, __float_as_uint(m2 * 1.0001f));
+      s4 = max(s4, __float_as_uint(mag2 * 1.0001f));
+    }
+    s5 = max(s5, ((res2 - res2) == 0.f) ? __float_as_uint(res2 * 1.0001f) : 0x7F800000u);
+    if (lane == 0) {
+      if (real) { bias[c] = b; bias2[c] = b2; }
+      reinterpret_cast<float *>(panelhi + (size_t)K_pad64 * DP)[c] = real ? fmaxf(b, -3.0e38f) : -3.0e38f;
     }
   }
-  xn2 += __shfl_xor(xn2, 32);
-  xo2 += __shfl_xor(xo2, 32);
-  x0 = __shfl(x0, col);  // feature 0 lives in the lower half-wave
-  const bool insane = (x0 != x0);  // kmeans.cu:312
-
-  // ---- staging of panel tiles: byte-identical to the f32 filter's ----
-  f32x4 stage[NST];
-  float bstage = 0.f;
-  auto stage_load = [&](uint32_t tile) {
-    const float *src = panel16f + (size_t)tile * 32 * DP;
-#pragma unroll
-    for (int i = 0; i < NST; i++) {
-      const int q = tid + i * 256;
-      if (q < 8 * DP) stage[i] = reinterpret_cast<const f32x4 *>(src)[q];
-    }
-    if (tid < 32) bstage = bias[tile * 32 + tid];
-  };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NST; i++) {
-      const int q = tid + i * 256;
-      if (q < 8 * DP) {
-        const int row = q / (DP / 4), c4 = q % (DP / 4);
-        *reinterpret_cast<f32x4 *>(tile_ptr(buf) + row * LDW + c4 * 4) = stage[i];
-      }
-    }
-    if (tid < 32) bias_ptr(buf)[tid] = bstage;
-  };
-
-  const uint32_t ntiles = K_pad / 32;
-  stage_load(0);
-  stage_store(0);
+  __shared__ uint32_t red[4][6];
+  if (lane == 0) { red[wave][0] = s0; red[wave][1] = s1; red[wave][2] = s2; red[wave][3] = s3; red[wave][4] = s4; red[wave][5] = s5; }
   __syncthreads();
-
-  float v1 = -INFINITY, v2 = -INFINITY, v3 = -INFINITY;
-  uint32_t c1 = 0xFFFFFFFFu, c2 = 0xFFFFFFFFu;
-  for (uint32_t t = 0; t < ntiles; t++) {
-    const int buf = t & 1;
-    if (t + 1 < ntiles) stage_load(t + 1);
-    // ONE accumulator on purpose: three independent ones (one per product kind) measured 15.4 ms
-    // against 12.9 ms -- under the f16 matrix load the chip is power limited (1.75 GHz, PMC in
-    // profiles/), extra matrix-level parallelism only lowers the clock further
-    f32x16 acc0;
-    {
-      const float *bb = bias_ptr(buf) + 4 * h;
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bb + 8 * g);
-        acc0[4 * g + 0] = b4.x; acc0[4 * g + 1] = b4.y; acc0[4 * g + 2] = b4.z; acc0[4 * g + 3] = b4.w;
-      }
-    }
-    // my centroid row of the tile: hi halves at [0, DP), lo halves at [DP, 2 DP).  Fragments are
-    // read TWO k-steps (6 MFMAs) ahead of their use and the order is pinned: left alone, hipcc sinks
-    // each ds_read_b128 right in front of its first MFMA and the LDS latency lands on the pipe
-    const _Float16 *arow = reinterpret_cast<const _Float16 *>(tile_ptr(buf) + col * LDW) + h * NKH;
-    auto frag = [&](int j, int lo) { return *reinterpret_cast<const f16x8 *>(arow + lo * DP + 8 * j); };
-    if constexpr (KS >= 2) {
-      f16x8 h0 = frag(0, 0), l0 = frag(0, 1), h1 = frag(1, 0), l1 = frag(1, 1);
-#pragma unroll
-      for (int j = 0; j < KS; j++) {
-        f16x8 h2 = h1, l2 = l1;
-        if (j + 2 < KS) {
-          h2 = frag(j + 2, 0);
-          l2 = frag(j + 2, 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, xhi[j], acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(l0, xhi[j], acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, xlo[j], acc0, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        h0 = h1; l0 = l1;
-        h1 = h2; l1 = l2;
-      }
-    } else {
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(0, 0), xhi[0], acc0, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(0, 1), xhi[0], acc0, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(0, 0), xlo[0], acc0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const float v = acc0[r];
-      const uint32_t code = t * 16u + r;
-      // sorted insert with 3 value ops (v_med3 / v_max ignore a NaN operand, like the strict
-      // compares do) + the two index selects
-      const bool g1 = v > v1, g2 = v > v2;
-      v3 = __builtin_amdgcn_fmed3f(v2, v3, v);
-      c2 = g1 ? c1 : (g2 ? code : c2);
-      v2 = __builtin_amdgcn_fmed3f(v1, v2, v);
-      c1 = g1 ? code : c1;
-      v1 = fmaxf(v1, v);
-    }
-    if (t + 1 < ntiles) stage_store(buf ^ 1);
-    __syncthreads();
-  }
-
-  // ---- decide: the f32 filter's bound plus the hi/lo split terms ----
-  //   accumulation of 3 DP exact products + bias in fp32:       gamma_{3DP+1} (||x'|| C'max + B'max)
-  //   dropped lo.lo and split residuals (|r| <= 2^-22|a| + 2^-25): 3 * 2^-22 ||x'|| C'max
-  //                                                              + 2^-25 sqrt(DP) (||x'|| + C'max)
-  const float cmaxc = sqrtf(__uint_as_float(stats[0])) * 1.000001f;
-  const float bmaxc = __uint_as_float(stats[1]);
-  const float cmaxo = sqrtf(__uint_as_float(stats[2])) * 1.000001f;
-  const float xn = sqrtf(xn2) * 1.0001f, xo = sqrtf(xo2) * 1.0001f;
-  const float u = 5.9604645e-8f;
-  const float e_mfma = 2.0f * (3.0f * eps) * (xn * cmaxc + bmaxc) + 12.0f * u * xn * cmaxc +
-                       2.9802322e-8f * sqrtf((float)DP) * (xn + cmaxc);
-  const float e_ref = u * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
-  const float thr = 2.0f * (e_mfma + e_ref) * 1.001f + tie_slack;
-  // filter_finish treats a row as present iff s < N: present rows carry their index, absent ones N
-  filter_finish(v1, v2, v3, c1, c2, h, lane, live ? s : N, N, K, insane, thr, assignments, assignments_prev, flagged,
-                pairs, counters);
-  __syncthreads();  // the LDS tiles are reused by the next group
+  if (threadIdx.x < 6) {
+    const uint32_t m = max(max(red[0][threadIdx.x], red[1][threadIdx.x]), max(red[2][threadIdx.x], red[3][threadIdx.x]));
+    if (m) atomicMax(&stats[threadIdx.x], m);
   }
 }
 
+hipError_t launch_centroid_prep_frozen(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad,
+                                       uint32_t DP, const float *mu, uint32_t *finite, float *bias, float *bias2,
+                                       float *cfil, void *panelhi, uint32_t *stats, uint32_t *stats_next,
+                                       uint32_t *zero_a, uint32_t *zero_b, uint32_t *zero_c, hipStream_t st) {
+  const uint32_t K_pad64 = (K_pad + 63u) / 64u * 64u;
+  if (metric == 0)
+    hipLaunchKernelGGL((centroid_prep_frozen_kernel<0>), dim3(K_pad64 / 16), dim3(256), 0, st, centroids, K, D, K_pad,
+                       DP, K_pad64, mu, finite, bias, bias2, cfil, reinterpret_cast<_Float16 *>(panelhi), stats,
+                       stats_next, zero_a, zero_b, zero_c);
+  else
+    hipLaunchKernelGGL((centroid_prep_frozen_kernel<1>), dim3(K_pad64 / 16), dim3(256), 0, st, centroids, K, D, K_pad,
+                       DP, K_pad64, mu, finite, bias, bias2, cfil, reinterpret_cast<_Float16 *>(panelhi), stats,
+                       stats_next, zero_a, zero_b, zero_c);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------
-// Stage 1 of the default filter: ONE f16 MFMA per 16 features (hi.hi only).  Under the f16 matrix
-// load the chip is power limited (profiles/: 1.7 GHz), so the lever is fewer matrix operations:
-// the coarse scores carry |error| <= E_c ~ 2^-10 ||x'|| C'max, enough to decide the rows whose
-// best / second-best gap exceeds 2 E_c (the large majority); only the others go through the
-// three-product kernel above.
-//
-// History of this kernel (profiles/r1e_pmc_summary.json for the first generation: matrix pipe busy
-// 22-28 %, waves parked 65 % of their cycles).  Three structural causes, three changes:
-//   * every wave re-read the whole centroid panel from LDS for only 32 rows (1 KB of ds_read per
-//     MFMA = half the LDS bandwidth at full matrix rate): a wave now owns 64 rows (two B-operand
-//     sets), so each A fragment feeds two MFMAs;
-//   * 8-wave blocks put two waves of the SAME block on every SIMD, in step through the barriers, so
-//     the top-2 bookkeeping (VALU) of both ran with the matrix pipe idle: blocks are 4 waves, one per
-//     SIMD, two blocks per CU; the bookkeeping is 3 ops per score instead of 4 -- the accumulator
-//     register number travels in the low 4 mantissa bits of the score (<= 16 ulp, part of the
-//     bound), the tile index is noted once per tile;
-//   * staging went global -> 32 VGPRs -> ds_write_b128: tiles now arrive by LDS-DMA
-//     (global_load_lds_dwordx4, no registers, no LDS-write issue slots).  The DMA writes lane-linear,
-//     so the bank swizzle (16-byte chunk j of row r sits in slot j ^ (r & 15) of its half row) is
-//     applied to the SOURCE address and again by the fragment reads.
+// Stage 1: ONE f16 MFMA per 16 features (hi.hi only).  What shaped the kernel (DESIGN.md 4.6,
+// profiles/r1e..r1k): a wave owns 64 rows (two B-operand sets) so each A fragment read from LDS feeds
+// two MFMAs; blocks are 4 waves, one per SIMD, two blocks per CU, so one block's bookkeeping runs under
+// the other's MFMAs; the accumulator register number travels in the low 4 mantissa bits of the score
+// (<= 16 ulp, part of the bound), the tile index is noted once per tile; tiles arrive by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write issue slots) with the bank swizzle
+// (16-byte chunk j of row r sits in slot j ^ (r & 15) of its half row) applied to the SOURCE address
+// and again by the fragment reads.
 // ---------------------------------------------------------------------------------------
 // hand-issued LDS fragment read + counted wait (see lloyd_coarse2_kernel)
 __device__ __forceinline__ f16x8 lds_frag_issue(uint32_t addr) {
@@ -295,7 +188,27 @@ __device__ __forceinline__ void lds_frag_wait(f16x8 &f) {
 }
 
 #ifndef KMX_ABL
-#define KMX_ABL 0  // timing ablations (scratch/abl_variants.sh): results are WRONG when non-zero
+#define KMX_ABL 0  // timing ablations (scripts/coarse_variants.sh): results are WRONG when non-zero
+#endif
+// experiment switches of the stage-1 kernel (scripts/coarse_variants.sh builds them side by side; results
+// are CORRECT in every combination, tests/test_gpu_lloyd.py runs against whatever the library was built with)
+#ifndef KMX_BOOK
+#define KMX_BOOK 0    // 1: pair bookkeeping, 2.5 VALU ops per score (v_max3 on the packed pair) instead of 3
+#endif
+#ifndef KMX_BIASPF
+#define KMX_BIASPF 0  // 1: per-wave bias copies; the next tile's biases are fetched BEFORE this tile's bookkeeping
+#endif
+#ifndef KMX_PRIO
+#define KMX_PRIO 0    // 1: s_setprio 1 around the bookkeeping, 2: around the MFMA loop
+#endif
+#ifndef KMX_TRACE
+#define KMX_TRACE 0   // 1: s_memtime stamps of one block's tile phases -> kmx_trace_buf (kmamd_debug_trace)
+#endif
+#if KMX_TRACE
+__device__ unsigned long long kmx_trace_buf[4 * 40 * 8];
+#ifndef KMX_TRACE_BLOCK
+#define KMX_TRACE_BLOCK 8191
+#endif
 #endif
 // 4 waves x 64 rows per block, 2 independent blocks per CU (2 x 67 KB of LDS).  (Tried and dropped:
 // one 8-wave block per CU run as a ping-pong -- the waves sharing a SIMD, read from HW_ID, alternate
@@ -321,7 +234,8 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   // raw LDS byte addresses (the fragment address is built with XOR: needs the 1-KB aligned base)
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte *)lds2;
   if (lds0 & 1023u) __builtin_trap();
-  const uint32_t bias0 = lds0 + 2 * SUPB;   // 2 x 64 floats
+  const uint32_t bias0 = lds0 + 2 * SUPB;   // 2 x 64 floats (KMX_BIASPF: one such pair per wave)
+  constexpr uint32_t BIASB = KMX_BIASPF ? 2048u : 512u;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 31, h = lane >> 5;
   constexpr int WV = 4;
@@ -368,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   // block), and the other block's LDS-DMA pieces queue behind those misses in the in-order texture path.
   // The mean comes from LDS (staged by DMA with super-tile 0): an ordinary global load would drain vmcnt.
   constexpr int BJ = KS > 8 ? 8 : KS;
-  const uint32_t mu_lds = bias0 + 512 + 64;
+  const uint32_t mu_lds = bias0 + BIASB + 64;
   auto load_rows = [&]() {
     if constexpr (CACHED) {
       // rows = the row cache: per 32-row block KS pieces of 64 lanes x 16 bytes, already centred halves
@@ -433,13 +347,14 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   };
   // the 64 biases of the super-tile (clamped copy behind the panel): one 4-byte DMA.  No ordinary
   // global load lives in the loop: hipcc waits vmcnt(0) at its first use, draining the DMA
+  const uint32_t mybias = KMX_BIASPF ? bias0 + (uint32_t)wave * 512u : bias0;   // this wave's bias pair
   auto stage_bias = [&](uint32_t sp, int buf) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(biashi + sp * 64u + lane),
-                                     (__attribute__((address_space(3))) void *)(uintptr_t)(bias0 + buf * 256), 4, 0, 0);
+                                     (__attribute__((address_space(3))) void *)(uintptr_t)(mybias + buf * 256), 4, 0, 0);
   };
   auto stage_issue = [&](uint32_t sp, int buf, int nw, int me) {   // nw waves share the pieces, I am number me
     for (int p = me; p < NP; p += nw) stage_piece(sp, buf, p);
-    if (me == 0) stage_bias(sp, buf);
+    if (me == 0 || KMX_BIASPF) stage_bias(sp, buf);
   };
 
   {  // the mean -> LDS: DP floats = DP / 4 sixteen-byte lanes
@@ -458,26 +373,63 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   // max(v1, pk) as med3(v1, pk, +inf): fmaxf() costs a canonicalising v_max per operand on top
   float pinf = INFINITY;
   asm volatile("" : "+s"(pinf));
+  auto pack = [&](float v, int r) { return __uint_as_float((__float_as_uint(v) & 0xFFFFFFF0u) | (uint32_t)r); };
   auto book = [&](float v, int r, float &v1, float &v2) {
-    const float pk = __uint_as_float((__float_as_uint(v) & 0xFFFFFFF0u) | (uint32_t)r);
+    const float pk = pack(v, r);
     v2 = __builtin_amdgcn_fmed3f(v1, v2, pk);
     v1 = __builtin_amdgcn_fmed3f(v1, pk, pinf);
   };
+  // two scores at once: the new second = max(second, median(best, a, b)), the new best = max3(best, a, b):
+  // 3 ops for the pair + 2 packs.  v_max3 only sees PACKED values (results of VALU ops the compiler
+  // scheduled itself), never an MFMA result: the MFMA -> VALU read hazard stays the compiler's business
+  auto book2 = [&](float a, float b, int r, float &v1, float &v2) {
+    const float pa = pack(a, r), pb = pack(b, r + 1);
+    const float m = __builtin_amdgcn_fmed3f(v1, pa, pb);
+    v2 = __builtin_amdgcn_fmed3f(v2, m, pinf);
+    float t;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v1), "v"(pa), "v"(pb));
+    v1 = t;
+  };
+  auto lds_f4 = [](uint32_t addr) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>((uintptr_t)addr);
+  };
+  auto load_bias = [&](uint32_t biasaddr, f32x16 &b) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const f32x4 b4 = lds_f4(biasaddr + (8 * g + 4 * h) * 4);
+      b[4 * g + 0] = b4.x; b[4 * g + 1] = b4.y; b[4 * g + 2] = b4.z; b[4 * g + 3] = b4.w;
+    }
+  };
+#if KMX_TRACE
+  const bool tracing = blockIdx.x == KMX_TRACE_BLOCK && lane == 0;
+  auto stamp = [&](uint32_t t, int k) {
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    if (tracing) kmx_trace_buf[(wave * 40 + t) * 8 + k] = now;
+  };
+#else
+  auto stamp = [&](uint32_t, int) {};
+#endif
+  f32x16 nb;   // KMX_BIASPF: the coming tile's biases
+  if (KMX_BIASPF) load_bias(mybias, nb);
   // One tile: 2 x KS MFMAs (each A fragment feeds both row sets), then the top-2 bookkeeping of its
   // 2 x 16 scores on the VALU.  The two waves a SIMD holds belong to DIFFERENT blocks (4 waves per
   // block, one per SIMD), so they are not in step: one's bookkeeping runs under the other's MFMAs.
   // (Double-buffered accumulators with the bookkeeping interleaved in-wave need ~230 registers: the
   // B operands spill, measured slower.)
-  auto tile_pass = [&](uint32_t ldsbase, uint32_t biasaddr, uint32_t t, bool stage, uint32_t sp_next, int buf_next) {
+  auto tile_pass = [&](uint32_t ldsbase, uint32_t biasaddr, uint32_t next_bias, bool drain, uint32_t t, bool stage,
+                       uint32_t sp_next, int buf_next) {
     f32x16 accA, accB;
-    {
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const f32x4 b4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>((uintptr_t)(biasaddr + (8 * g + 4 * h) * 4));
-        accA[4 * g + 0] = b4.x; accA[4 * g + 1] = b4.y; accA[4 * g + 2] = b4.z; accA[4 * g + 3] = b4.w;
-      }
-      accB = accA;
+    stamp(t, 0);
+    if (KMX_BIASPF) {
+      accA = nb;
+    } else {
+      load_bias(biasaddr, accA);
     }
+    accB = accA;
+#if KMX_TRACE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    stamp(t, 1);
+#endif
     // (the 1-KB aligned tile base adds into bits the XOR never touches.)  Opaque on purpose: left
     // visible, the KS addresses are hoisted out of the tile loop and the B operands spill instead
     uint32_t fb = fragbase + ldsbase;
@@ -492,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     f16x8 fr[PD + 1];
 #pragma unroll
     for (int j = 0; j < PD; j++) fr[j] = lds_frag_issue(fb ^ (uint32_t)(j * 16));
-    if (KMX_ABL == 12) __builtin_amdgcn_s_setprio(1);
+    if (KMX_ABL == 12 || KMX_PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int j = 0; j < KS; j++) {
       if (j + PD < KS && KMX_ABL != 6) fr[(j + PD) % (PD + 1)] = lds_frag_issue(fb ^ (uint32_t)((j + PD) * 16));
@@ -520,30 +472,57 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
       if (stage && (j % SPREAD) == SPREAD / 2 && j / SPREAD < 8) {
         const int slot = j / SPREAD;                           // 0..7
         for (int p = slot * 4 + wave; p < NP; p += 32) stage_piece(sp_next, buf_next, p);
-        if (slot == 0 && wave == 0) stage_bias(sp_next, buf_next);
+        if (slot == 0 && (wave == 0 || KMX_BIASPF)) stage_bias(sp_next, buf_next);
       }
     }
-    if (KMX_ABL == 12) __builtin_amdgcn_s_setprio(0);
+    if (KMX_ABL == 12 || KMX_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+    stamp(t, 2);
+    if (KMX_BIASPF) {
+      // the coming tile's biases travel while this tile's scores are booked.  Across a super-tile boundary
+      // they sit in THIS wave's own copy, written by its own DMA: its vmcnt wait is all the ordering needed
+      if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (next_bias) load_bias(next_bias, nb);
+    }
+#if KMX_TRACE
+    {
+      float tmp;
+      asm volatile("v_mov_b32 %0, %1" : "=v"(tmp) : "v"(TWO ? accB[15] : accA[15]));
+      asm volatile("" :: "v"(tmp));
+      stamp(t, 3);
+    }
+#endif
+    if (KMX_PRIO == 1) __builtin_amdgcn_s_setprio(1);
     const float v1a_in = v1a, v1b_in = v1b;
+    if (KMX_BOOK == 1) {
 #pragma unroll
-    for (int r = 0; r < ((KMX_ABL == 1 || (KMX_ABL >= 5 && KMX_ABL <= 11)) ? 1 : 16); r++) {
-      book(accA[r], r, v1a, v2a);
-      if constexpr (TWO) book(accB[r], r, v1b, v2b);
+      for (int r = 0; r < 16; r += 2) {
+        book2(accA[r], accA[r + 1], r, v1a, v2a);
+        if constexpr (TWO) book2(accB[r], accB[r + 1], r, v1b, v2b);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < ((KMX_ABL == 1 || (KMX_ABL >= 5 && KMX_ABL <= 11)) ? 1 : 16); r++) {
+        book(accA[r], r, v1a, v2a);
+        if constexpr (TWO) book(accB[r], r, v1b, v2b);
+      }
     }
     tba = (v1a != v1a_in) ? t : tba;
     tbb = (v1b != v1b_in) ? t : tbb;
+    if (KMX_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    stamp(t, 4);
   };
 
   for (uint32_t sp = 0; sp < (KMX_ABL == 10 ? 1u : nsuper); sp++) {  // ABL 10: prologue + one super-tile
     const int buf = sp & 1;
     const bool stage = sp + 1 < nsuper && !(KMX_ABL == 2 || KMX_ABL == 5 || KMX_ABL == 6 || KMX_ABL == 7);  // ABL 7: barrier without DMA
-    const uint32_t base = buf * SUPB, bb = bias0 + buf * 256;
-    tile_pass(base, bb, 2 * sp, stage, sp + 1, buf ^ 1);
-    tile_pass(base + 32 * ROWB, bb + 128, 2 * sp + 1, false, sp + 1, buf ^ 1);
+    const uint32_t base = buf * SUPB, bb = mybias + buf * 256;
+    tile_pass(base, bb, bb + 128, false, 2 * sp, stage, sp + 1, buf ^ 1);
+    tile_pass(base + 32 * ROWB, bb + 128, stage ? mybias + (buf ^ 1) * 256 : 0u, true, 2 * sp + 1, false, sp + 1, buf ^ 1);
     if (!(KMX_ABL == 2 || KMX_ABL == 3 || KMX_ABL == 5 || KMX_ABL == 6)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
+    stamp(2 * sp + 1, 5);
   }
 
   // |coarse score - reference score| <= E_c: the f32-accumulated hi.hi products (gamma_{DP+1}), the
@@ -578,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     // (with the row cache mu is frozen: its norm is stored behind the per-row records)
     const float xn = sqrtf(xn2) * 1.0001f, xo = (xn + mu_norm) * 1.0001f;
     // operand rounding: x'.c' - hi(x').hi(c') = x'.dc + dx.c' - dx.dc with dx = x' - hi(x'), dc likewise,
-    // bounded by Cauchy-Schwarz on MEASURED residual norms (row cache / centroid_panel16_kernel; about
+    // bounded by Cauchy-Schwarz on MEASURED residual norms (row cache / centroid_panelhi_kernel; about
     // half the worst case 2^-11 ||.||, which the uncached path uses for its rows)
     const float dx = dx2 >= 0.f ? sqrtf(dx2) * 1.0001f : 4.8829e-4f * xn;
     const float e_c = 2.0f * eps * (xn * cmaxc + bmaxc) + (xn * dcmax + dx * cmaxc + dx * dcmax) * 1.001f +
@@ -628,57 +607,24 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   }
 }
 
-hipError_t launch_centroid_panel16(const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP,
-                                   const uint32_t *finite, const float *mu, const float *bias, void *panel16,
-                                   void *panelhi, uint32_t *stats, hipStream_t st) {
+hipError_t launch_centroid_panelhi(const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP,
+                                   const uint32_t *finite, const float *mu, const float *bias, void *panelhi,
+                                   uint32_t *stats, hipStream_t st) {
   const uint32_t K_pad64 = (K_pad + 63u) / 64u * 64u;
-  hipLaunchKernelGGL(centroid_panel16_kernel, dim3(K_pad64 / 4), dim3(256), 0, st, centroids, K, D, K_pad, DP, finite,
-                     mu, bias, reinterpret_cast<_Float16 *>(panel16), reinterpret_cast<_Float16 *>(panelhi), K_pad64,
-                     stats);
-  return hipGetLastError();
-}
-
-template <int DP>
-static hipError_t launch_f16_dp(const LloydArgs &a, const void *rows, bool half_rows, const void *panel16,
-                                const uint32_t *row_list, const uint32_t *n_list, hipStream_t st) {
-  const size_t lds_bytes = (2 * 32 * (DP + 4) + 64) * sizeof(float);
-  uint32_t grid = (a.N + 127) / 128;
-  if (row_list && grid > 4096) grid = 4096;  // the list kernel strides over the device-side count
-  const bool fast = a.D == (uint32_t)DP;
-#define KMX_F16_LAUNCH(H, F)                                                                                       \
-  hipLaunchKernelGGL((lloyd_filter_f16_kernel<DP, H, F>), dim3(grid), dim3(256), lds_bytes, st, rows, a.N, a.D,     \
-                     reinterpret_cast<const float *>(panel16), a.bias, a.mu, a.K_pad, a.K, a.stats, a.eps,           \
-                     a.tie_slack, a.assignments, a.assignments_prev, a.flagged, a.pairs, a.counters, row_list, n_list)
-  if (half_rows) {
-    if (fast) KMX_F16_LAUNCH(true, true); else KMX_F16_LAUNCH(true, false);
-  } else {
-    if (fast) KMX_F16_LAUNCH(false, true); else KMX_F16_LAUNCH(false, false);
-  }
-#undef KMX_F16_LAUNCH
+  hipLaunchKernelGGL(centroid_panelhi_kernel, dim3(K_pad64 / 4), dim3(256), 0, st, centroids, K, D, K_pad, DP, finite,
+                     mu, bias, reinterpret_cast<_Float16 *>(panelhi), K_pad64, stats);
   return hipGetLastError();
 }
 
 // one MFMA consumes 8 features per half-wave: the padded width must be at least 16
 bool lloyd_filter_f16_supported(uint32_t D, uint32_t DP) { return DP >= 16 && D <= DP; }
 
-hipError_t launch_lloyd_filter_f16(const LloydArgs &a, const void *rows, bool half_rows, const void *panel16,
-                                   const uint32_t *row_list, const uint32_t *n_list, hipStream_t st) {
-  switch (a.DP) {
-    case 16: return launch_f16_dp<16>(a, rows, half_rows, panel16, row_list, n_list, st);
-    case 32: return launch_f16_dp<32>(a, rows, half_rows, panel16, row_list, n_list, st);
-    case 64: return launch_f16_dp<64>(a, rows, half_rows, panel16, row_list, n_list, st);
-    case 128: return launch_f16_dp<128>(a, rows, half_rows, panel16, row_list, n_list, st);
-    case 256: return launch_f16_dp<256>(a, rows, half_rows, panel16, row_list, n_list, st);
-    default: return hipErrorInvalidValue;
-  }
-}
-
 template <int DP>
 static hipError_t launch_coarse2_dp(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
                                     const float *xmeta, const void *panelhi, uint32_t *undecided, float *und_thr,
                                     hipStream_t st) {
   constexpr int NSET = DP <= 256 ? 2 : 1;
-  const size_t lds_bytes = 2 * 64 * (size_t)(DP * 2) + 512 + 64 + (size_t)DP * 4;
+  const size_t lds_bytes = 2 * 64 * (size_t)(DP * 2) + (KMX_BIASPF ? 2048 : 512) + 64 + (size_t)DP * 4;
   const uint32_t rows_per_block = 128u * NSET;
   const uint32_t grid = (a.N + rows_per_block - 1) / rows_per_block;
   const bool fast = a.D == (uint32_t)DP;
@@ -696,6 +642,12 @@ static hipError_t launch_coarse2_dp(const LloydArgs &a, const void *rows, bool h
 #undef KMX_CRS2_LAUNCH
   return hipGetLastError();
 }
+
+#if KMX_TRACE
+extern "C" int kmamd_debug_trace(unsigned long long *host, size_t words) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(kmx_trace_buf), words * sizeof(unsigned long long)) == hipSuccess ? 0 : 4;
+}
+#endif
 
 hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
                                const float *xmeta, const void *panelhi, uint32_t *undecided, float *und_thr,

@@ -231,17 +231,24 @@ __global__ void segment_sums_kernel(const float *__restrict__ samples, uint32_t 
   }
 }
 
+// tail (may be null): the fused reduce buffer's end, [dcount as doubles (K) | counters 0..3 as doubles]
+// right behind delta -- everything one all-reduce carries (exact in fp64: |values| < 2^32)
 __global__ void fold_delta_kernel(const double *__restrict__ partial, const uint32_t *__restrict__ offsets,
-                                  uint32_t K, uint32_t D, double *__restrict__ delta, int32_t *__restrict__ dcount) {
+                                  uint32_t K, uint32_t D, double *__restrict__ delta, int32_t *__restrict__ dcount,
+                                  double *__restrict__ tail, const uint32_t *__restrict__ counters) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tail && i < 4) tail[K + i] = (double)counters[i];
   if (i >= (size_t)K * D) return;
   const uint32_t c = i / D, f = i % D;
   double in = 0, out = 0;
   for (uint32_t j = 0; j < kSumSplit; j++) in += partial[((size_t)(2 * c) * kSumSplit + j) * D + f];
   for (uint32_t j = 0; j < kSumSplit; j++) out += partial[((size_t)(2 * c + 1) * kSumSplit + j) * D + f];
   delta[i] = in - out;
-  if (f == 0)
-    dcount[c] = (int32_t)(offsets[2 * c + 1] - offsets[2 * c]) - (int32_t)(offsets[2 * c + 2] - offsets[2 * c + 1]);
+  if (f == 0) {
+    const int32_t dc = (int32_t)(offsets[2 * c + 1] - offsets[2 * c]) - (int32_t)(offsets[2 * c + 2] - offsets[2 * c + 1]);
+    if (dcount) dcount[c] = dc;
+    if (tail) tail[c] = (double)dc;
+  }
 }
 
 // ---- bucket path: histogram / scan / scatter / per-bucket LDS sort ----------------------------
@@ -329,13 +336,29 @@ __global__ __launch_bounds__(256) void move_scatter_kernel(const uint32_t *__res
   if (eout) rows_out[atomicAdd(&cursors[(size_t)(2u * p + 1u) * stride], 1u)] = s;
 }
 
-// one block per bucket: ascending row order (bitonic in LDS; the scatter order above is arbitrary)
-constexpr uint32_t kBucketCap = 1024;   // larger buckets: the radix path (a bitonic pass costs n log^2 n per block)
+// one block per bucket: ascending row order (bitonic in LDS; the scatter order above is arbitrary).
+// A bucket beyond the LDS capacity is ranked by counting through `scratch` (same offsets): O(n^2), only
+// there so that the bucket path is CORRECT for any input without the host having looked at the counts
+// first -- the host steers such iterations to the radix path as soon as it sees them (launch_move_deltas).
+constexpr uint32_t kBucketCap = 4096;
 __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint32_t *__restrict__ offsets,
-                                                          uint32_t *__restrict__ rows) {
+                                                          uint32_t *__restrict__ rows,
+                                                          uint32_t *__restrict__ scratch) {
   __shared__ uint32_t v[kBucketCap];
   const uint32_t beg = offsets[blockIdx.x], n = offsets[blockIdx.x + 1] - beg;
-  if (n < 2 || n > kBucketCap) return;  // n > cap: a speculative launch (below); the radix path redoes the list
+  if (n < 2) return;
+  if (n > kBucketCap) {
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+      const uint32_t mine = rows[beg + i];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < n; j++) rank += rows[beg + j] < mine ? 1u : 0u;   // rows are distinct
+      scratch[beg + rank] = mine;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 256) rows[beg + i] = scratch[beg + i];
+    return;
+  }
   uint32_t m = 2;
   while (m < n) m <<= 1;
   for (uint32_t i = threadIdx.x; i < m; i += 256) v[i] = i < n ? rows[beg + i] : 0xFFFFFFFFu;
@@ -356,108 +379,132 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint32_t *__rest
   for (uint32_t i = threadIdx.x; i < n; i += 256) rows[beg + i] = v[i];
 }
 
+// The host side of the update.  Three ways through it, all leaving per (cluster, sign) segments with
+// rows ascending (bit-identical sums):
+//   radix   the first iterations (most rows move: the histogram's atomics alone would cost more):
+//           compaction + rocprim sort sized by the event count -> ONE host read
+//   bucket, checked   histogram, scan, the host reads (events, largest bucket) and picks bucket / radix
+//   bucket, unchecked (steady state; MoveState::async_ok) histogram, scan, scatter, LDS sort -- NO host
+//           read: the counts go to the pinned words by an async copy nobody waits for; the host looks at
+//           whatever has landed (an EARLIER call's counts) only to steer later calls.  A bucket beyond the
+//           LDS sort's capacity is still sorted correctly by the kernel's fallback, so nothing depends on
+//           the prediction but speed.
 hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint32_t K, const uint32_t *prev,
                               const uint32_t *cur, uint32_t *keys_tmp, uint32_t *vals_tmp, uint32_t *keys_sorted,
                               uint32_t *rows_sorted, uint32_t *offsets2, void *temp, size_t temp_bytes,
-                              double *partial, double *delta, int32_t *dcount, uint32_t *blockoff,
-                              uint32_t *bucket_work, uint32_t *host_count, uint32_t *last_events, hipEvent_t copied,
-                              hipStream_t st) {
+                              double *partial, double *delta, int32_t *dcount, double *tail,
+                              const uint32_t *counters, uint32_t *blockoff, uint32_t *bucket_work, MoveState *ms,
+                              hipEvent_t copied, hipStream_t st) {
   // blockoff: N / 1024 + 2 words; bucket_work: move_bucket_words(K) words = histogram | cursors (both
   // 2 K counters, move_bucket_stride(K) words apart) | 2 results; the histogram is zero on entry (engine:
-  // zeroed at creation, left zero by the scan); host_count: 2 pinned words
+  // zeroed at creation, left zero by the scan); ms->host: 4 pinned words
   const uint32_t stride = move_bucket_stride(K);
   uint32_t *hist = bucket_work, *cursors = bucket_work + 2 * (size_t)K * stride,
            *res = bucket_work + 4 * (size_t)K * stride;
+  uint32_t *host_count = ms->host;
   hipError_t e = hipSuccess;
   uint32_t m = 0, maxb = 0;
-  bool speculated = false;
-  const bool force_radix = getenv("KMCUDA_AMD_UPDATE_RADIX") != nullptr;  // A/B and tests
-  // *last_events: the previous call's event count (2 N before the first one).  While most rows still
-  // move (the first iterations) the histogram's atomics alone cost more than the whole radix path
-  const bool direct_radix = force_radix || *last_events > N / 2;
+  const bool force_radix = ms->force == 1, force_sync = ms->force == 2, force_bucket = ms->force == 3;
+  // last_events: the newest event count the host knows (2 N before the first call)
+  const bool direct_radix = !force_bucket && (force_radix || ms->last_events > N / 2);
+  auto bucket_kernels = [&]() {
+    hipLaunchKernelGGL(move_scatter_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, cursors,
+                       stride, rows_sorted);
+    hipLaunchKernelGGL(bucket_sort_kernel, dim3(2 * K), dim3(256), 0, st, offsets2, rows_sorted, keys_sorted);
+  };
   if (N == 0) {
     e = hipMemsetAsync(offsets2, 0, (2 * (size_t)K + 1) * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
-  } else if (!direct_radix) {
-    hipLaunchKernelGGL(move_hist_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, hist, stride);
-    hipLaunchKernelGGL(move_bucket_scan_kernel, dim3(1), dim3(1024), 0, st, hist, 2 * K, stride, offsets2, cursors, res);
-    e = hipGetLastError();
-    if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("move events: %s\n", hipGetErrorString(e)); return e; }
-    // the one host round trip of the update: which path, and (radix path) the sort's size.  While the
-    // previous call took the bucket path (host_count[3], the owner's pinned word) its two kernels are
-    // launched BEFORE the host waits for the counts -- the GPU runs them instead of idling through the
-    // round trip; if the counts say otherwise the radix path below simply redoes rows_sorted
-    e = hipMemcpyAsync(host_count, res, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess && copied) e = hipEventRecord(copied, st);
-    if (e != hipSuccess) return e;
-    const bool speculate = copied && host_count[3] == 1u;
-    if (speculate) {
-      hipLaunchKernelGGL(move_scatter_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, cursors,
-                         stride, rows_sorted);
-      hipLaunchKernelGGL(bucket_sort_kernel, dim3(2 * K), dim3(256), 0, st, offsets2, rows_sorted);
-    }
-    e = copied ? hipEventSynchronize(copied) : hipStreamSynchronize(st);   // the copy, not what was queued behind it
-    if (e != hipSuccess) return e;
-    m = host_count[0];
-    maxb = host_count[1];
-    speculated = speculate;
-  }
-  host_count[3] = 0u;
-  if (N && !direct_radix && m && maxb <= kBucketCap) {
-    host_count[3] = 1u;
-    if (!speculated) {
-      hipLaunchKernelGGL(move_scatter_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, cursors,
-                         stride, rows_sorted);
-      hipLaunchKernelGGL(bucket_sort_kernel, dim3(2 * K), dim3(256), 0, st, offsets2, rows_sorted);
-    }
-    e = hipGetLastError();
-    if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("bucket path: %s\n", hipGetErrorString(e)); return e; }
-  } else if (N && (direct_radix || m)) {
+  } else if (direct_radix) {
+    ms->async_ok = false;
     const uint32_t nb = (N + kMoveRows - 1) / kMoveRows;
     hipLaunchKernelGGL(move_count_kernel, dim3(nb), dim3(256), 0, st, prev, cur, N, K, blockoff);
     hipLaunchKernelGGL(move_scan_kernel, dim3(1), dim3(1024), 0, st, blockoff, nb, blockoff + nb + 1);
     hipLaunchKernelGGL(move_write_kernel, dim3(nb), dim3(256), 0, st, prev, cur, N, K, blockoff, keys_tmp, vals_tmp);
     e = hipGetLastError();
-    if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("move events: %s\n", hipGetErrorString(e)); return e; }
-    if (direct_radix) {   // the event count was not read yet
-      e = hipMemcpyAsync(host_count, blockoff + nb + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
-      if (e == hipSuccess) e = hipStreamSynchronize(st);
-      if (e != hipSuccess) return e;
-      m = host_count[0];
-    }
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(host_count, blockoff + nb + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    m = host_count[0];
     if (m) {
       e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t *)keys_tmp, keys_sorted,
                                     (const uint32_t *)vals_tmp, rows_sorted, (size_t)m, 0u, bits_for(2ull * K), st);
-      if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("radix_sort_pairs(%zu bytes temp): %s\n", temp_bytes, hipGetErrorString(e)); return e; }
-    }
-    if (direct_radix) {   // no histogram ran: segment starts by binary search in the sorted keys
-      hipLaunchKernelGGL(offsets_kernel, dim3((2 * K + 1 + 255) / 256), dim3(256), 0, st, keys_sorted, m, 2 * K, offsets2);
-      e = hipGetLastError();
       if (e != hipSuccess) return e;
     }
+    // no histogram ran: segment starts by binary search in the sorted keys
+    hipLaunchKernelGGL(offsets_kernel, dim3((2 * K + 1 + 255) / 256), dim3(256), 0, st, keys_sorted, m, 2 * K, offsets2);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    ms->last_events = m;
+  } else {
+    hipLaunchKernelGGL(move_hist_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, hist, stride);
+    hipLaunchKernelGGL(move_bucket_scan_kernel, dim3(1), dim3(1024), 0, st, hist, 2 * K, stride, offsets2, cursors, res);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(host_count, res, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return e;
+    if (force_bucket || (ms->async_ok && !force_sync)) {
+      bucket_kernels();
+      e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      // whatever has landed: an earlier call's counts (this call's copy is still queued)
+      m = host_count[0];
+      maxb = host_count[1];
+      if (maxb > kBucketCap - kBucketCap / 4 || m > N / 2) ms->async_ok = false;   // look before leaping next time
+      ms->last_events = m;
+    } else {
+      if (copied) e = hipEventRecord(copied, st);
+      if (e != hipSuccess) return e;
+      // while the previous call took the bucket path its two kernels are launched BEFORE the host waits for
+      // the counts: the GPU runs them during the round trip; if the counts say otherwise the radix path
+      // below simply redoes rows_sorted
+      const bool speculate = copied && ms->bucket_last;
+      if (speculate) bucket_kernels();
+      e = copied ? hipEventSynchronize(copied) : hipStreamSynchronize(st);   // the copy, not what was queued behind it
+      if (e != hipSuccess) return e;
+      m = host_count[0];
+      maxb = host_count[1];
+      ms->last_events = m;
+      ms->bucket_last = false;
+      if (m && maxb <= kBucketCap) {
+        ms->bucket_last = true;
+        ms->async_ok = maxb <= kBucketCap - kBucketCap / 4;   // comfortably inside: stop looking first
+        if (!speculate) bucket_kernels();
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+      } else if (m) {
+        const uint32_t nb = (N + kMoveRows - 1) / kMoveRows;
+        hipLaunchKernelGGL(move_count_kernel, dim3(nb), dim3(256), 0, st, prev, cur, N, K, blockoff);
+        hipLaunchKernelGGL(move_scan_kernel, dim3(1), dim3(1024), 0, st, blockoff, nb, blockoff + nb + 1);
+        hipLaunchKernelGGL(move_write_kernel, dim3(nb), dim3(256), 0, st, prev, cur, N, K, blockoff, keys_tmp, vals_tmp);
+        e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t *)keys_tmp, keys_sorted,
+                                      (const uint32_t *)vals_tmp, rows_sorted, (size_t)m, 0u, bits_for(2ull * K), st);
+        if (e != hipSuccess) return e;
+      }
+    }
   }
-  *last_events = m;
-  // offsets2 (segment starts per key) came out of the histogram scan in both paths
+  // offsets2 (segment starts per key) came out of the histogram scan or the binary search
   const uint32_t bs = D >= 256 ? 256 : (D > 64 ? 128 : 64);
   hipLaunchKernelGGL(segment_sums_kernel, dim3(2 * K, kSumSplit), dim3(bs), 0, st, samples, D, rows_sorted, offsets2,
                      partial);
-  e = hipGetLastError();
-  if (e != hipSuccess) { if (getenv("KMCUDA_AMD_DEBUG")) printf("segment_sums: %s\n", hipGetErrorString(e)); return e; }
   const size_t n = (size_t)K * D;
   hipLaunchKernelGGL(fold_delta_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, partial, offsets2, K, D,
-                     delta, dcount);
+                     delta, dcount, tail, counters);
   return hipGetLastError();
 }
 
 // one block per centroid: c = normalize(c*count + delta), count += dcount
 template <int METRIC>
-__global__ void apply_delta_kernel(const double *__restrict__ delta, const int32_t *__restrict__ dcount, uint32_t D,
-                                   float *__restrict__ centroids, uint32_t *__restrict__ ccounts) {
+__global__ void apply_delta_kernel(const double *__restrict__ delta, const int32_t *__restrict__ dcount,
+                                   const double *__restrict__ dcount_d, uint32_t D, float *__restrict__ centroids,
+                                   uint32_t *__restrict__ ccounts) {
   const uint32_t c = blockIdx.x;
   const double *d = delta + (size_t)c * D;
   float *cen = centroids + (size_t)c * D;
   const uint32_t cnt_old = ccounts[c];
-  const uint32_t cnt_new = cnt_old + (uint32_t)dcount[c];
+  // (dcount_d: the fused reduce buffer's tail -- sums of int32 counts, exact in fp64)
+  const uint32_t cnt_new = cnt_old + (uint32_t)(dcount_d ? (int32_t)dcount_d[c] : dcount[c]);
   const double w = (double)cnt_old;
   if (cnt_new == 0) {
     // empty cluster => NaN centroid row, never chosen again (kmeans.cu:425-426, README "NaN
@@ -488,13 +535,13 @@ __global__ void apply_delta_kernel(const double *__restrict__ delta, const int32
   if (threadIdx.x == 0) ccounts[c] = cnt_new;
 }
 
-hipError_t launch_apply_delta(int metric, const double *delta, const int32_t *dcount, uint32_t K, uint32_t D,
-                              float *centroids, uint32_t *ccounts, hipStream_t st) {
+hipError_t launch_apply_delta(int metric, const double *delta, const int32_t *dcount, const double *dcount_d,
+                              uint32_t K, uint32_t D, float *centroids, uint32_t *ccounts, hipStream_t st) {
   const uint32_t bs = D >= 256 ? 256 : (D > 64 ? 128 : 64);
   if (metric == 0)
-    hipLaunchKernelGGL((apply_delta_kernel<0>), dim3(K), dim3(bs), 0, st, delta, dcount, D, centroids, ccounts);
+    hipLaunchKernelGGL((apply_delta_kernel<0>), dim3(K), dim3(bs), 0, st, delta, dcount, dcount_d, D, centroids, ccounts);
   else
-    hipLaunchKernelGGL((apply_delta_kernel<1>), dim3(K), dim3(bs), 0, st, delta, dcount, D, centroids, ccounts);
+    hipLaunchKernelGGL((apply_delta_kernel<1>), dim3(K), dim3(bs), 0, st, delta, dcount, dcount_d, D, centroids, ccounts);
   return hipGetLastError();
 }
 
@@ -606,29 +653,6 @@ hipError_t launch_adjust_exact(int metric, const float *samples, uint32_t N, uin
     if (metric == 0) KMX_ADJ(0, false); else KMX_ADJ(1, false);
   }
 #undef KMX_ADJ
-  return hipGetLastError();
-}
-
-__global__ void pack_reduce_tail_kernel(const int32_t *__restrict__ dcount, const uint32_t *__restrict__ counters,
-                                        uint32_t K, double *__restrict__ dst) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < K) dst[i] = (double)dcount[i];
-  else if (i < K + 4) dst[i] = (double)counters[i - K];
-}
-
-__global__ void unpack_dcount_kernel(const double *__restrict__ src, uint32_t K, int32_t *__restrict__ dcount) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < K) dcount[i] = (int32_t)src[i];
-}
-
-hipError_t launch_pack_reduce_tail(const int32_t *dcount, const uint32_t *counters, uint32_t K, double *dst,
-                                   hipStream_t st) {
-  hipLaunchKernelGGL(pack_reduce_tail_kernel, dim3((K + 4 + 255) / 256), dim3(256), 0, st, dcount, counters, K, dst);
-  return hipGetLastError();
-}
-
-hipError_t launch_unpack_dcount(const double *src, uint32_t K, int32_t *dcount, hipStream_t st) {
-  hipLaunchKernelGGL(unpack_dcount_kernel, dim3((K + 255) / 256), dim3(256), 0, st, src, K, dcount);
   return hipGetLastError();
 }
 

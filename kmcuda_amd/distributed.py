@@ -46,12 +46,10 @@ class HipBackend:
         self.assignments = torch.full((self.n_local,), -1, **i32)   # 0xFFFFFFFF (prepare_mem)
         self.assignments_prev = torch.full((self.n_local,), -1, **i32)
         self.ccounts = torch.zeros(clusters, **i32)
-        self.dcount = torch.zeros(clusters, **i32)
         self.centroids = torch.empty((clusters, self.features), dtype=torch.float32, device=self.device)
 
     def new_reduce_buffer(self):
-        return torch.zeros(self.clusters * self.features + self.clusters + 4, dtype=torch.float64,
-                           device=self.device)
+        return torch.zeros(self.engine.reduce_len(), dtype=torch.float64, device=self.device)
 
     def reset_changed(self):
         self.engine.reset_counters(0)
@@ -60,14 +58,10 @@ class HipBackend:
         self.engine.lloyd_assign(self.samples, self.centroids, self.assignments, self.assignments_prev)
 
     def fill_reduce_buffer(self, buf):
-        kd = self.clusters * self.features
-        self.engine.move_deltas(self.samples, self.assignments_prev, self.assignments, buf, self.dcount)
-        self.engine.pack_reduce_tail(self.dcount, buf[kd:])
+        self.engine.reduce_fill(self.samples, self.assignments_prev, self.assignments, buf)
 
     def apply(self, buf):
-        kd = self.clusters * self.features
-        self.engine.unpack_dcount(buf[kd:], self.dcount)
-        self.engine.apply_delta(buf, self.dcount, self.centroids, self.ccounts)
+        self.engine.reduce_apply(buf, self.centroids, self.ccounts)
         if self.half:   # fp16x2: centroids live in half2 in the reference -> rounded after every update
             self.centroids.copy_(self.centroids.to(torch.float16).to(torch.float32))
 

@@ -61,9 +61,8 @@ class Engine:
                    "kmamd_lloyd_assign")
 
     def set_filter(self, mode):
-        """"f16" (default): two-stage f16 matrix-core filter; "f32": f32 matrix cores; "f16x3": the
-        single-stage hi/lo-split f16 pass."""
-        _lib.check(self.lib.kmamd_set_filter(self.h, {"f16": 0, "f32": 1, "f16x3": 2}[mode]), "kmamd_set_filter")
+        """"f16" (default): two-stage f16 matrix-core filter; "f32": f32 matrix cores (cross-check)."""
+        _lib.check(self.lib.kmamd_set_filter(self.h, {"f16": 0, "f32": 1}[mode]), "kmamd_set_filter")
 
     def set_half_rows(self, rows16):
         """rows16: float16 CUDA tensor with the same values as the fp32 rows (or None)."""
@@ -98,11 +97,25 @@ class Engine:
         _lib.check(self.lib.kmamd_adjust_exact(self.h, self._p(samples), self._p(prev), self._p(cur),
                                                self._p(centroids), self._p(ccounts)), "kmamd_adjust_exact")
 
-    def pack_reduce_tail(self, dcount, dst):
-        _lib.check(self.lib.kmamd_pack_reduce_tail(self.h, self._p(dcount), self._p(dst)), "kmamd_pack_reduce_tail")
+    def reduce_len(self):
+        """Doubles in the fused reduce buffer: [delta K*D | dcount K | counters 4]."""
+        return int(self.lib.kmamd_reduce_len(self.h))
 
-    def unpack_dcount(self, src, dcount):
-        _lib.check(self.lib.kmamd_unpack_dcount(self.h, self._p(src), self._p(dcount)), "kmamd_unpack_dcount")
+    def reduce_fill(self, samples, prev, cur, buf):
+        """This shard's move sums, count changes and counters into `buf` (float64, reduce_len())."""
+        _lib.check(self.lib.kmamd_reduce_fill(self.h, self._p(samples), self._p(prev), self._p(cur), self._p(buf)),
+                   "kmamd_reduce_fill")
+
+    def reduce_apply(self, buf, centroids, ccounts):
+        """The centroid update from the (all-reduced) buffer."""
+        _lib.check(self.lib.kmamd_reduce_apply(self.h, self._p(buf), self._p(centroids), self._p(ccounts)),
+                   "kmamd_reduce_apply")
+
+    def set_update_mode(self, mode):
+        """"auto" | "radix" | "sync" | "bucket": the update's host logic (kmamd_set_update_mode); sums are
+        bit-identical on every path."""
+        _lib.check(self.lib.kmamd_set_update_mode(self.h, {"auto": 0, "radix": 1, "sync": 2, "bucket": 3}[mode]),
+                   "kmamd_set_update_mode")
 
     def transpose(self, src, rows, cols, dst):
         _lib.check(self.lib.kmamd_transpose(self.h, self._p(src), rows, cols, self._p(dst)), "kmamd_transpose")

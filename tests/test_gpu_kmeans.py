@@ -239,42 +239,50 @@ def test_256d_uniform_matches_oracle():
 
 @pytest.mark.parametrize("k", [3, 64, 1024])
 def test_update_paths_bit_identical(monkeypatch, k):
-    """The centroid update sorts the move events by (cluster, sign) either in per-key buckets (LDS sort,
-    when no bucket exceeds 8192 rows) or with a stable radix sort: both give rows ascending per
-    segment, so whole runs must agree bit for bit -- including k = 3, whose first buckets are far
-    beyond the bucket path's capacity and take the radix path either way."""
+    """The centroid update orders the move events by (cluster, sign) either in per-key buckets (LDS sort;
+    counting fallback for a bucket beyond its capacity) or with a stable radix sort, and picks between
+    them with or without reading the counts first (KMCUDA_AMD_UPDATE=radix | sync | bucket; default:
+    unchecked bucket path once the counts have settled): rows come out ascending per segment every
+    way, so whole runs must agree bit for bit -- including k = 3, whose buckets are far beyond the LDS
+    sort's capacity."""
     from kmcuda_amd import kmeans_cuda
     rs = numpy.random.RandomState(k)
     x = rs.rand(40000, 32).astype(numpy.float32)
     res = []
-    for force in (False, True):
-        if force:
-            monkeypatch.setenv("KMCUDA_AMD_UPDATE_RADIX", "1")
+    for mode in (None, "radix", "sync", "bucket"):
+        if mode:
+            monkeypatch.setenv("KMCUDA_AMD_UPDATE", mode)
         else:
-            monkeypatch.delenv("KMCUDA_AMD_UPDATE_RADIX", raising=False)
+            monkeypatch.delenv("KMCUDA_AMD_UPDATE", raising=False)
         c, a = kmeans_cuda(x, k, tolerance=0.001, init="random", seed=3, yinyang_t=0, verbosity=0)
         res.append((c.copy(), a.copy()))
-    assert (res[0][1] == res[1][1]).all()
-    assert numpy.array_equal(res[0][0], res[1][0], equal_nan=True)
+    for r in res[1:]:
+        assert (res[0][1] == r[1]).all()
+        assert numpy.array_equal(res[0][0], r[0], equal_nan=True)
 
 
-def test_update_bucket_speculation_falls_back():
-    """The update launches the bucket path's scatter + sort BEFORE it has read the move counts while the
-    previous call took that path; when the counts then demand the radix path (a bucket beyond the LDS
-    sort's capacity, fewer than N / 2 events in all) the list is redone.  Engine.move_deltas directly:
-    few moves (bucket path), one huge bucket (speculation wrong), few moves again; every delta against
-    numpy in fp64."""
+@pytest.mark.parametrize("mode", ["auto", "sync", "bucket", "radix"])
+def test_update_host_logic(mode):
+    """Engine.move_deltas through every way the host can steer it.  auto: the first call reads the counts
+    (nothing known), later calls enqueue the bucket path WITHOUT reading them -- also the call whose one
+    bucket (~6000 rows) is beyond the LDS sort's capacity, which the kernel's counting fallback must sort
+    correctly -- and the stale counts then send the following call back to the checked path.  sync: counts
+    read every time (bucket path launched speculatively, redone by the radix path for the big bucket).
+    bucket: never read.  radix: always the radix sort.  Every delta against numpy in fp64, and the
+    sequence of deltas bit-identical across the modes (module-level record)."""
     from kmcuda_amd.engine import Engine
     torch = pytest.importorskip("torch")
     dev = torch.device("cuda", 0)
-    n, d, k = 20000, 24, 16
+    n, d, k = 60000, 24, 16
     rs = numpy.random.RandomState(5)
     x = rs.rand(n, d).astype(numpy.float32)
     base = rs.randint(0, k, n).astype(numpy.int32)
     eng = Engine(n, d, k, "L2", device=0)
+    eng.set_update_mode(mode)
     xs = torch.from_numpy(x).to(dev)
     delta = torch.zeros(k * d, dtype=torch.float64, device=dev)
     dcount = torch.zeros(k, dtype=torch.int32, device=dev)
+    record = []
 
     def step(prev, cur):
         eng.move_deltas(xs, torch.from_numpy(prev).to(dev), torch.from_numpy(cur).to(dev), delta, dcount)
@@ -286,28 +294,82 @@ def test_update_bucket_speculation_falls_back():
         numpy.subtract.at(want, prev[moved], x[moved].astype(numpy.float64))
         numpy.add.at(wc, cur[moved], 1)
         numpy.subtract.at(wc, prev[moved], 1)
-        numpy.testing.assert_allclose(delta.cpu().numpy().reshape(k, d), want, rtol=1e-12, atol=1e-9)
+        got = delta.cpu().numpy().copy()
+        numpy.testing.assert_allclose(got.reshape(k, d), want, rtol=1e-12, atol=1e-9)
         assert (dcount.cpu().numpy() == wc).all()
+        record.append(got)
 
-    a0 = base.copy()
-    a1 = a0.copy()
-    a1[:300] = (a1[:300] + 1) % k                    # 600 events: bucket path, first of its kind
-    step(a0, a1)
+    a0 = numpy.full(n, -1, numpy.int32)              # nothing assigned yet: every row moves in (radix path)
+    step(a0, base)
+    a1 = base.copy()
+    a1[:300] = (a1[:300] + 1) % k                    # 600 events: the first bucket-path call (counts read)
+    step(base, a1)
     a2 = a1.copy()
-    a2[rs.choice(n, 50, replace=False)] = 3          # still the bucket path, now launched speculatively
+    a2[rs.choice(n, 50, replace=False)] = 3          # bucket path, auto: unchecked from here on
     step(a1, a2)
     a3 = a2.copy()
     src = numpy.nonzero(a2 == 5)[0]
-    a3[src] = 7                                      # one bucket of ~1250 rows (> 1024): radix path after all
-    assert len(src) > 1024 and 2 * len(src) < n // 2
+    a3[src] = 7                                      # one bucket of ~3700 rows x 2 signs ...
+    src2 = numpy.nonzero(a2 == 6)[0]
+    a3[src2] = 7                                     # ... and ~7400 into cluster 7: beyond the LDS sort (4096)
+    assert len(src) + len(src2) > 4096 and 2 * (len(src) + len(src2)) < n // 2
     step(a2, a3)
     a4 = a3.copy()
     a4[:100] = (a4[:100] + 2) % k
-    step(a3, a4)                                     # not speculative (the previous call was radix), bucket again
+    step(a3, a4)
     a5 = a4.copy()
     a5[200:260] = 0
-    step(a4, a5)                                     # speculative again
+    step(a4, a5)
+    a6 = a5.copy()
+    a6[1000:1040] = 1
+    step(a5, a6)
     eng.close()
+    ref = _UPDATE_RECORD.setdefault("ref", record)
+    for i, (a, b) in enumerate(zip(ref, record)):
+        assert numpy.array_equal(a, b), "call %d differs between update modes" % i
+
+
+_UPDATE_RECORD = {}
+
+
+def test_fused_reduce_buffer():
+    """kmamd_reduce_fill / kmamd_reduce_apply (one buffer [delta | dcount | counters] around the all-reduce)
+    against the separate move_deltas / apply_delta calls: identical centroids and counts."""
+    from kmcuda_amd.engine import Engine
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    n, d, k = 30000, 40, 50
+    rs = numpy.random.RandomState(11)
+    x = rs.rand(n, d).astype(numpy.float32)
+    xs = torch.from_numpy(x).to(dev)
+    c0 = x[rs.choice(n, k, replace=False)].copy()
+    out = []
+    for fused in (False, True):
+        eng = Engine(n, d, k, "L2", device=0)
+        cen = torch.from_numpy(c0.copy()).to(dev)
+        asg = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        prev = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        ccounts = torch.zeros(k, dtype=torch.int32, device=dev)
+        buf = torch.zeros(eng.reduce_len(), dtype=torch.float64, device=dev)
+        dcount = torch.zeros(k, dtype=torch.int32, device=dev)
+        changed = []
+        for _ in range(4):
+            eng.reset_counters(0)
+            eng.lloyd_assign(xs, cen, asg, prev)
+            if fused:
+                eng.reduce_fill(xs, prev, asg, buf)
+                eng.reduce_apply(buf, cen, ccounts)
+                changed.append(int(buf[k * d + k].item()))
+            else:
+                eng.move_deltas(xs, prev, asg, buf, dcount)
+                eng.apply_delta(buf, dcount, cen, ccounts)
+                changed.append(eng.counters()[0])
+        eng.sync()
+        out.append((cen.cpu().numpy(), ccounts.cpu().numpy(), asg.cpu().numpy(), changed))
+        eng.close()
+    assert numpy.array_equal(out[0][0], out[1][0], equal_nan=True)
+    assert (out[0][1] == out[1][1]).all() and (out[0][2] == out[1][2]).all()
+    assert out[0][3] == out[1][3]
 
 
 @pytest.mark.parametrize("case", ["uniform", "blobs", "duplicates", "wide", "tiny", "ragged"])

@@ -40,11 +40,10 @@ def _assign(x, c, metric="L2", exact=False, asg0=None, filt="f16"):
 @pytest.mark.parametrize("n,d,k", [(3000, 2, 50), (1000, 7, 33), (2500, 16, 100), (2000, 64, 257),
                                    (4096, 128, 64), (5000, 256, 1024), (777, 300, 40), (3000, 384, 500),
                                    (2500, 512, 1024), (1500, 600, 64)])
-@pytest.mark.parametrize("mode", ["f16", "f16x3", "f32", "exact"])
+@pytest.mark.parametrize("mode", ["f16", "f32", "exact"])
 def test_assign_bit_exact(n, d, k, mode):
-    """f16: two-stage f16 matrix-core filter (default), f16x3: its hi/lo-split stage alone, f32: f32
-    matrix-core filter, exact: the reference arithmetic for every pair -- all must reproduce the oracle
-    bit for bit."""
+    """f16: two-stage f16 matrix-core filter (default), f32: f32 matrix-core filter, exact: the reference
+    arithmetic for every pair -- all must reproduce the oracle bit for bit."""
     rs = numpy.random.RandomState(n + d + k)
     x = rs.rand(n, d).astype(numpy.float32)
     c = x[rs.choice(n, k, replace=False)].copy()
@@ -55,7 +54,7 @@ def test_assign_bit_exact(n, d, k, mode):
     assert counters[0] == ref_changed
 
 
-@pytest.mark.parametrize("filt", ["f16", "f16x3", "f32"])
+@pytest.mark.parametrize("filt", ["f16", "f32"])
 def test_assign_gaussian_and_second_pass(filt):
     rs = numpy.random.RandomState(5)
     x = (rs.randn(6000, 256) * 3 + rs.randn(1, 256)).astype(numpy.float32)
@@ -71,7 +70,7 @@ def test_assign_gaussian_and_second_pass(filt):
     assert counters[0] == ref_changed
 
 
-@pytest.mark.parametrize("filt", ["f16", "f16x3", "f32"])
+@pytest.mark.parametrize("filt", ["f16", "f32"])
 def test_assign_ties_duplicates_nans(filt):
     rs = numpy.random.RandomState(11)
     x = rs.rand(4000, 256).astype(numpy.float32)
@@ -94,7 +93,7 @@ def test_assign_ties_duplicates_nans(filt):
     assert not numpy.isin(got, [10, 11, 40, 77]).any()
 
 
-@pytest.mark.parametrize("filt", ["f16", "f16x3", "f32"])
+@pytest.mark.parametrize("filt", ["f16", "f32"])
 def test_assign_all_rows_flagged_still_exact(filt):
     # every centroid duplicated: the filter can decide nothing, the exact kernel decides all
     rs = numpy.random.RandomState(13)
@@ -174,7 +173,7 @@ def test_transpose_roundtrip():
         eng.close()
 
 
-@pytest.mark.parametrize("filt", ["f16", "f16x3", "f32"])
+@pytest.mark.parametrize("filt", ["f16", "f32"])
 def test_config_a_100k_256_1024(filt):
     """BASELINE config A shape: one assignment pass at 100000x256, K=1024, bit-exact."""
     rs = numpy.random.RandomState(0)
@@ -214,15 +213,9 @@ def test_orders_with_torch_default_stream():
     eng.close()
 
 
-@pytest.mark.parametrize("refine", ["contenders", "split"])
-def test_stage2_variants_on_a_converged_state(monkeypatch, refine):
-    """Stage 2 of the default filter -- contenders scored in fp32 (default) or the three-product f16
-    pass over all centroids (KMCUDA_AMD_REFINE=split) -- on centroids that have converged onto
+def test_stage2_on_a_converged_state():
+    """Stage 2 of the default filter (contenders scored in fp32) on centroids that have converged onto
     unstructured data (small best/second gaps: the state that sends most rows past stage 1)."""
-    if refine == "split":
-        monkeypatch.setenv("KMCUDA_AMD_REFINE", "split")
-    else:
-        monkeypatch.delenv("KMCUDA_AMD_REFINE", raising=False)
     rs = numpy.random.RandomState(123)
     n, d, k = 20000, 256, 300
     x = rs.rand(n, d).astype(numpy.float32)
