@@ -193,7 +193,7 @@ __device__ __forceinline__ void lds_frag_wait(f16x8 &f) {
 // experiment switches of the stage-1 kernel (scripts/coarse_variants.sh builds them side by side; results
 // are CORRECT in every combination, tests/test_gpu_lloyd.py runs against whatever the library was built with)
 #ifndef KMX_BOOK
-#define KMX_BOOK 0    // 1: pair bookkeeping, 2.5 VALU ops per score (v_max3 on the packed pair) instead of 3
+#define KMX_BOOK 1    // 1 (default): pair bookkeeping, 2.5 VALU ops per score (v_max3 on the packed pair); 0: 3 ops per score
 #endif
 #ifndef KMX_BIASPF
 #define KMX_BIASPF 0  // 1: per-wave bias copies; the next tile's biases are fetched BEFORE this tile's bookkeeping
@@ -205,10 +205,11 @@ __device__ __forceinline__ void lds_frag_wait(f16x8 &f) {
 #define KMX_TRACE 0   // 1: s_memtime stamps of one block's tile phases -> kmx_trace_buf (kmamd_debug_trace)
 #endif
 #if KMX_TRACE
-__device__ unsigned long long kmx_trace_buf[4 * 40 * 8];
-#ifndef KMX_TRACE_BLOCK
-#define KMX_TRACE_BLOCK 8191
-#endif
+// one record per WAVE that ran on the traced CU (XCC 0, SE 0, SH 0, CU 0): [0] block, [1] wave | HW_ID << 8,
+// then 6 stamps per tile
+constexpr int kTraceRec = 200, kTraceMax = 1024;
+__device__ unsigned long long kmx_trace_buf[kTraceRec * kTraceMax];
+__device__ unsigned int kmx_trace_n;
 #endif
 // 4 waves x 64 rows per block, 2 independent blocks per CU (2 x 67 KB of LDS).  (Tried and dropped:
 // one 8-wave block per CU run as a ping-pong -- the waves sharing a SIMD, read from HW_ID, alternate
@@ -401,10 +402,21 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     }
   };
 #if KMX_TRACE
-  const bool tracing = blockIdx.x == KMX_TRACE_BLOCK && lane == 0;
+  uint32_t trace_slot = 0xFFFFFFFFu;
+  {
+    const uint32_t hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    if ((xcc & 15u) == 0u && (hwid & 0xFF00u) == 0u && lane == 0) {
+      const uint32_t at = atomicAdd(&kmx_trace_n, 1u);
+      if (at < (uint32_t)kTraceMax) {
+        trace_slot = at;
+        kmx_trace_buf[(size_t)at * kTraceRec] = blockIdx.x;
+        kmx_trace_buf[(size_t)at * kTraceRec + 1] = (unsigned long long)wave | ((unsigned long long)hwid << 8);
+      }
+    }
+  }
   auto stamp = [&](uint32_t t, int k) {
     const unsigned long long now = __builtin_amdgcn_s_memtime();
-    if (tracing) kmx_trace_buf[(wave * 40 + t) * 8 + k] = now;
+    if (trace_slot != 0xFFFFFFFFu && t < 33u) kmx_trace_buf[(size_t)trace_slot * kTraceRec + 2 + t * 6 + k] = now;
   };
 #else
   auto stamp = [&](uint32_t, int) {};
@@ -483,14 +495,6 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
       if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (next_bias) load_bias(next_bias, nb);
     }
-#if KMX_TRACE
-    {
-      float tmp;
-      asm volatile("v_mov_b32 %0, %1" : "=v"(tmp) : "v"(TWO ? accB[15] : accA[15]));
-      asm volatile("" :: "v"(tmp));
-      stamp(t, 3);
-    }
-#endif
     if (KMX_PRIO == 1) __builtin_amdgcn_s_setprio(1);
     const float v1a_in = v1a, v1b_in = v1b;
     if (KMX_BOOK == 1) {
@@ -509,7 +513,10 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     tba = (v1a != v1a_in) ? t : tba;
     tbb = (v1b != v1b_in) ? t : tbb;
     if (KMX_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-    stamp(t, 4);
+#if KMX_TRACE
+    asm volatile("" :: "v"(v1a), "v"(v2a), "v"(v1b), "v"(v2b), "v"(tba), "v"(tbb));
+#endif
+    stamp(t, 3);
   };
 
   for (uint32_t sp = 0; sp < (KMX_ABL == 10 ? 1u : nsuper); sp++) {  // ABL 10: prologue + one super-tile
@@ -520,6 +527,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     tile_pass(base + 32 * ROWB, bb + 128, stage ? mybias + (buf ^ 1) * 256 : 0u, true, 2 * sp + 1, false, sp + 1, buf ^ 1);
     if (!(KMX_ABL == 2 || KMX_ABL == 3 || KMX_ABL == 5 || KMX_ABL == 6)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp(2 * sp + 1, 4);
       __syncthreads();
     }
     stamp(2 * sp + 1, 5);
@@ -644,8 +652,12 @@ static hipError_t launch_coarse2_dp(const LloydArgs &a, const void *rows, bool h
 }
 
 #if KMX_TRACE
-extern "C" int kmamd_debug_trace(unsigned long long *host, size_t words) {
-  return hipMemcpyFromSymbol(host, HIP_SYMBOL(kmx_trace_buf), words * sizeof(unsigned long long)) == hipSuccess ? 0 : 4;
+// copies the records out and rearms the trace (the NEXT launch is recorded from slot 0)
+extern "C" int kmamd_debug_trace(unsigned long long *host, size_t words, unsigned int *nrec) {
+  unsigned int zero = 0;
+  if (hipMemcpyFromSymbol(nrec, HIP_SYMBOL(kmx_trace_n), sizeof(unsigned int)) != hipSuccess) return 4;
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(kmx_trace_buf), words * sizeof(unsigned long long)) != hipSuccess) return 4;
+  return hipMemcpyToSymbol(HIP_SYMBOL(kmx_trace_n), &zero, sizeof(zero)) == hipSuccess ? 0 : 4;
 }
 #endif
 

@@ -72,6 +72,11 @@ def lib():
         L.kmo_kmeans.argtypes = [i32, f32, f32, i32, u32, u32, u32, u32, _f32p, _f32p, _u32p, _f32p,
                                  _u32p, u32, _u32p]
         L.kmo_set_fp16_storage.argtypes = [i32]
+        L.kmo_set_fp16_mode.argtypes = [i32]
+        L.kmo_h_rn.restype = f32
+        L.kmo_h_rn.argtypes = [ctypes.c_double]
+        L.kmo_h_from_int_rd.restype = f32
+        L.kmo_h_from_int_rd.argtypes = [ctypes.c_longlong]
         L.kmo_quantize_half.restype = f32
         L.kmo_quantize_half.argtypes = [f32]
         L.kmo_knn_inverse.argtypes = [u32, u32, _u32p, _u32p, _u32p]
@@ -155,17 +160,20 @@ def init_centroids(samples, clusters, init="kmeans++", seed=0, metric=L2):
 
 
 def kmeans(samples, clusters, tolerance=0.01, init="kmeans++", yinyang_t=0.1, metric="L2",
-           average_distance=False, seed=0):
+           average_distance=False, seed=0, half2=False):
     """Mirror of libKMCUDA.kmeans_cuda on the CPU oracle.
     Returns (centroids, assignments, iteration_log[, average_distance]).
-    float16 samples select this repository's fp16x2 semantics: fp32 arithmetic on the half values,
-    centroids rounded to half after every update (returned as float16)."""
+    float16 samples select fp16x2: by default this repository's product semantics (fp32 arithmetic on the
+    half values, centroids rounded to half after every update); half2=True the REFERENCE's half2 arithmetic
+    (fp_abstraction.h:100-182, kmo_set_fp16_mode(2)).  Centroids come back as float16."""
     fp16 = isinstance(samples, np.ndarray) and samples.dtype == np.float16
-    lib().kmo_set_fp16_storage(1 if fp16 else 0)
+    if half2 and not fp16:
+        raise ValueError("half2 arithmetic needs float16 samples")
+    lib().kmo_set_fp16_mode((2 if half2 else 1) if fp16 else 0)
     try:
         out = _kmeans(samples, clusters, tolerance, init, yinyang_t, metric, average_distance, seed)
     finally:
-        lib().kmo_set_fp16_storage(0)
+        lib().kmo_set_fp16_mode(0)
     if fp16:
         out = (out[0].astype(np.float16),) + out[1:]
     return out

@@ -151,9 +151,105 @@ static float cos_dist_from_prod(float fp) {
   return acosf(fp);
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* fp16x2: the reference's half2 arithmetic (fp_abstraction.h:100-182, CUDA_ARCH >= 60).     */
+/* F = half2: every sample / centroid element is a PAIR of halves (low = feature 2i, high =  */
+/* feature 2i+1), every _add/_sub/_mul/_fma is the packed IEEE binary16 operation rounded to  */
+/* nearest even (__hadd2, __hsub2, __hmul2, __hfma2 = one rounding), Kahan sums therefore run  */
+/* as TWO interleaved half accumulators (even / odd features) with their own compensation       */
+/* terms, _fin(v) = __hadd(high, low) folds them in half precision, _const<half2>(int) =        */
+/* __int2half_rd (round DOWN), _fmax = 65504, compares are half compares (__hlt).  Values are  */
+/* carried here as floats that hold exactly-representable halves; each operation is evaluated */
+/* in double (exact for halves: products have 22 significant bits, sums of a product and a   */
+/* half fit 53 bits whenever the result is in half range) and rounded ONCE to binary16 by     */
+/* h_rn() -- no dependence on the host's _Float16 support.                                    */
+/* g_fp16_mode: 0 = fp32 arithmetic, 1 = "storage" (this product's fp16 semantics: the fp32     */
+/* arithmetic on half VALUES, centroids rounded to half after every update), 2 = the             */
+/* reference's half2 arithmetic restated.                                                      */
+/* ------------------------------------------------------------------------------------ */
+static int g_fp16_mode = 0;
+
+static float h_rn(double v) {                       /* double -> nearest-even binary16, as float */
+  if (v != v || v == 0.0) return (float)v;
+  const double a = fabs(v);
+  if (a == (double)INFINITY) return (float)v;
+  int e;
+  (void)frexp(a, &e);                               /* a = m * 2^e, m in [0.5, 1) */
+  e -= 1;                                           /* a in [2^e, 2^(e+1)) */
+  if (e < -14) e = -14;                             /* subnormal halves: fixed quantum 2^-24 */
+  const double q = ldexp(1.0, e - 10);
+  const double r = rint(a / q) * q;                 /* exact scaling; rint = nearest-even (default mode) */
+  if (r > 65504.0) return v < 0 ? -INFINITY : INFINITY;
+  return (float)(v < 0 ? -r : r);
+}
+static inline float h_add(float a, float b) { return h_rn((double)a + (double)b); }
+static inline float h_sub(float a, float b) { return h_rn((double)a - (double)b); }
+static inline float h_mul(float a, float b) { return h_rn((double)a * (double)b); }
+static inline float h_fma(float a, float b, float c) { return h_rn((double)a * (double)b + (double)c); }  /* __hfma */
+static inline float h_from_float(float v) { return h_rn((double)v); }                                   /* __float2half (RN) */
+static float h_from_int_rd(int64_t v) {                                                                  /* __int2half_rd */
+  float h = h_rn((double)v);
+  if (h == INFINITY) return 65504.f;                /* rounding down never reaches +inf */
+  if ((double)h > (double)v) {                      /* step to the next half below */
+    int e;
+    (void)frexp(fabs((double)h), &e);
+    e -= 1;
+    if (e < -14) e = -14;
+    double q = ldexp(1.0, e - 10);
+    if (h > 0 && fabs((double)h) == ldexp(1.0, e) && e > -14) q *= 0.5;   /* crossing a binade downward */
+    h = (float)((double)h - q);
+  }
+  return h;
+}
+#define H2_KAHAN(acc, corr, a, b) do { const float y__ = h_fma((a), (b), (corr)); const float t__ = h_add((acc), y__); \
+                                       (corr) = h_sub(y__, h_sub(t__, (acc))); (acc) = t__; } while (0)
+
+/* metric_abstraction.h:21-36, F = half2: returns the two lanes' sums */
+static void h2_sum_squares(int metric, const float *vec, uint32_t D, float *lo, float *hi) {
+  if (metric != KMO_L2) { *lo = 1.f; *hi = 1.f; return; }   /* :149-158 */
+  float s[2] = {0.f, 0.f}, c[2] = {0.f, 0.f};
+  for (uint32_t f = 0; f + 1 < D; f += 2)
+    for (int l = 0; l < 2; l++) H2_KAHAN(s[l], c[l], vec[f + l], vec[f + l]);
+  *lo = s[0]; *hi = s[1];
+}
+/* Kahan dot product per lane (kmeans.cu:331-341 with F = half2) */
+static void h2_dot(const float *a, const float *b, uint32_t D, float *lo, float *hi) {
+  float s[2] = {0.f, 0.f}, c[2] = {0.f, 0.f};
+  for (uint32_t f = 0; f + 1 < D; f += 2)
+    for (int l = 0; l < 2; l++) H2_KAHAN(s[l], c[l], a[f + l], b[f + l]);
+  *lo = s[0]; *hi = s[1];
+}
+/* METRIC::distance(sqr1, sqr2, prod) -> half (metric_abstraction.h:55-57, :171-177) */
+static float h2_distance3(int metric, float sq_lo, float sq_hi, float p_lo, float p_hi) {
+  if (metric == KMO_L2) {
+    const float lo = h_fma(-2.f, p_lo, h_add(0.f, sq_lo)), hi = h_fma(-2.f, p_hi, h_add(0.f, sq_hi));
+    return h_add(hi, lo);                           /* _fin */
+  }
+  const float fp = h_add(p_hi, p_lo);               /* _float(_fin(prod)) */
+  if (fp >= 1.f) return 0.f;
+  if (fp <= -1.f) return h_from_float((float)M_PI);
+  return h_from_float(acosf(fp));
+}
+/* METRIC::distance / distance_t / distance_tt (:59-101, :179-218) -> float */
+static float h2_distance(int metric, const float *a, const float *b, uint32_t D) {
+  float s[2] = {0.f, 0.f}, c[2] = {0.f, 0.f};
+  if (metric == KMO_L2) {
+    for (uint32_t f = 0; f + 1 < D; f += 2)
+      for (int l = 0; l < 2; l++) {
+        const float d = h_sub(a[f + l], b[f + l]);
+        H2_KAHAN(s[l], c[l], d, d);
+      }
+    return sqrtf(h_add(s[1], s[0]));                /* _sqrt(_float(_fin(dist))): float sqrt of the half sum */
+  }
+  for (uint32_t f = 0; f + 1 < D; f += 2)
+    for (int l = 0; l < 2; l++) H2_KAHAN(s[l], c[l], a[f + l], b[f + l]);
+  return h2_distance3(metric, 1.f, 1.f, s[0], s[1]);
+}
+
 /* metric_abstraction.h:59-101 (L2: sqrt of Kahan sum of squared differences),
  * :179-218 (cos: acos of Kahan dot).  distance, distance_t and distance_tt share it. */
 float kmo_distance(int metric, const float *a, const float *b, uint32_t D) {
+  if (g_fp16_mode == 2) return h2_distance(metric, a, b, D);
   if (metric == KMO_L2) return sqrtf(kahan_sqdiff(a, b, D));
   return cos_dist_from_prod(kmo_kahan_dot(a, b, D));
 }
@@ -275,9 +371,40 @@ __attribute__((target("avx512f"))) static void lloyd_assign_avx512(
 }
 #endif
 
+/* kmeans.cu:293-364 with F = half2: products, csqr, distance and the running minimum are halves */
+static void lloyd_assign_h2(int metric, uint32_t N, uint32_t D, uint32_t K, const float *X, const float *C,
+                            uint32_t *asg, uint32_t *prev, uint32_t *changed) {
+  float *sq = (float *)malloc(sizeof(float) * 2 * (size_t)K);
+  for (uint32_t c = 0; c < K; c++) h2_sum_squares(metric, C + (size_t)c * D, D, &sq[2 * c], &sq[2 * c + 1]);
+  uint32_t total = 0;
+#pragma omp parallel for schedule(static) reduction(+ : total)
+  for (uint32_t s = 0; s < N; s++) {
+    const float *x = X + (size_t)s * D;
+    const int insane = (x[0] != x[0]) || (x[1] != x[1]);   /* _neq(half2, half2) = !__hbeq2: either lane NaN */
+    float min_dist = 65504.f;                               /* _fmax<half>() */
+    uint32_t nearest = UINT32_MAX;
+    if (!insane)
+      for (uint32_t c = 0; c < K; c++) {
+        float plo, phi;
+        h2_dot(x, C + (size_t)c * D, D, &plo, &phi);
+        const float dist = h2_distance3(metric, sq[2 * c], sq[2 * c + 1], plo, phi);
+        if (dist < min_dist) { min_dist = dist; nearest = c; }   /* __hlt: false for NaN */
+      }
+    uint32_t ch = 0;
+    lloyd_finish_row(s, insane, nearest, K, asg, prev, &ch);
+    total += ch;
+  }
+  *changed += total;
+  free(sq);
+}
+
 void kmo_lloyd_assign(int metric, uint32_t N, uint32_t D, uint32_t K, const float *samples,
                       const float *centroids, uint32_t *assignments, uint32_t *assignments_prev,
                       uint32_t *changed) {
+  if (g_fp16_mode == 2) {
+    lloyd_assign_h2(metric, N, D, K, samples, centroids, assignments, assignments_prev, changed);
+    return;
+  }
   float *csqr = (float *)malloc(sizeof(float) * (K + 64));
   kmo_sum_squares(metric, K, D, centroids, csqr);
 #if defined(__x86_64__)
@@ -332,6 +459,39 @@ void kmo_adjust(int metric, uint32_t N, uint32_t D, uint32_t K, const float *sam
   for (uint32_t c = 0; c < K; c++) {
     float *cen = centroids + (size_t)c * D;
     uint32_t my_count = ccounts[c];
+    if (g_fp16_mode == 2) {                                 /* kmeans.cu:366-429 with F = half2 */
+      const float fmy = h_from_int_rd(my_count);            /* _const<half2>(my_count) = __int2half_rd */
+      for (uint32_t f = 0; f < D; f++) cen[f] = h_mul(cen[f], fmy);
+      float corr[2] = {0.f, 0.f};                           /* ONE half2 corr for all f and s: one per lane */
+      for (uint32_t e = cnt[c]; e < cnt[c + 1]; e++) {
+        const float *x = samples + (size_t)ev[e] * D;
+        const float fsign = (float)sg[e];
+        if (sg[e] < 0) my_count--; else my_count++;
+        for (uint32_t f = 0; f + 1 < D; f += 2)
+          for (int l = 0; l < 2; l++) {
+            const float y = h_fma(x[f + l], fsign, corr[l]);
+            const float t = h_add(cen[f + l], y);
+            corr[l] = h_sub(y, h_sub(t, cen[f + l]));
+            cen[f + l] = t;
+          }
+      }
+      if (metric == KMO_L2) {                               /* metric_abstraction.h:138-144: h2rcp(_const(count)) */
+        const float cnt_h = h_from_int_rd(my_count);
+        const float rc = h_rn(1.0 / (double)cnt_h);
+        for (uint32_t f = 0; f < D; f++) cen[f] = h_mul(cen[f], rc);
+      } else {                                              /* :274-300: fp32 norm, HIGH half first, then low */
+        float norm = 0.f, ncorr = 0.f;
+        for (uint32_t f = 0; f + 1 < D; f += 2) {
+          KAHAN_STEP(kmo_fma_rd, norm, ncorr, cen[f + 1], cen[f + 1]);
+          KAHAN_STEP(kmo_fma_rd, norm, ncorr, cen[f], cen[f]);
+        }
+        norm = 1.0f / sqrtf(norm);
+        const float norm2 = h_from_float(norm);
+        for (uint32_t f = 0; f < D; f++) cen[f] = h_mul(cen[f], norm2);
+      }
+      ccounts[c] = my_count;
+      continue;
+    }
     const float fmy = (float)my_count;                      /* _const<F>(my_count) */
     for (uint32_t f = 0; f < D; f++) cen[f] = cen[f] * fmy; /* kmeans.cu:381-385 */
     float corr = 0.f;                                       /* ONE corr for all f and s, :388 */
@@ -509,7 +669,7 @@ static double kmpp_step(int metric, uint32_t N, uint32_t D, uint32_t cc, const f
   for (uint32_t s = 0; s < N; s++) {
     const float *x = samples + (size_t)s * D;
     float dist = 0.f;
-    if (x[0] == x[0]) dist = kmo_distance(metric, x, centroid, D);
+    if (x[0] == x[0] && (g_fp16_mode != 2 || x[1] == x[1])) dist = kmo_distance(metric, x, centroid, D);
     if (cc == 1 || dist < dists[s]) dists[s] = dist;
   }
   double sum = 0.0;
@@ -753,8 +913,12 @@ static int check_changed(float tolerance, uint32_t N, uint32_t *changed, iterlog
 /* fp16x2 storage mode (fp_abstraction.h:100-182 keeps centroids in half2): this repository's fp16
  * semantics are "the fp32 arithmetic on the half values, centroids rounded to half (RN) after every
  * update"  -- NOT the reference's half2 accumulation, which is tolerance-only. */
-static int g_fp16_storage = 0;
-void kmo_set_fp16_storage(int on) { g_fp16_storage = on; }
+#define g_fp16_storage (g_fp16_mode == 1)
+void kmo_set_fp16_storage(int on) { g_fp16_mode = on ? 1 : 0; }
+/* 0 fp32, 1 storage semantics, 2 the reference's half2 arithmetic (inputs must hold half values, D even) */
+void kmo_set_fp16_mode(int mode) { g_fp16_mode = mode; }
+float kmo_h_rn(double v) { return h_rn(v); }
+float kmo_h_from_int_rd(long long v) { return h_from_int_rd(v); }
 
 /* round-to-nearest-even float -> IEEE half -> float */
 float kmo_quantize_half(float x) {

@@ -88,6 +88,14 @@ int kmo_kmeans(int init, float tolerance, float yinyang_t, int metric, uint32_t 
 /* fp16x2 storage mode of THIS repository (fp32 arithmetic on half values, centroids rounded to half
  * after every update); affects kmo_kmeans only.  kmo_quantize_half: float -> half (RN) -> float. */
 void kmo_set_fp16_storage(int on);
+/* fp16x2 arithmetic of the oracle: 0 = fp32, 1 = the storage mode above, 2 = the REFERENCE's half2
+ * arithmetic (fp_abstraction.h:100-182: packed binary16 add / sub / mul / fma rounded to nearest, two
+ * interleaved Kahan accumulators folded by _fin = hi + lo, __int2half_rd constants, half compares);
+ * inputs must hold half-representable values and D must be even.  Affects every kmo_* entry point that
+ * computes distances, assignments or updates.  kmo_h_rn / kmo_h_from_int_rd expose the two roundings. */
+void kmo_set_fp16_mode(int mode);
+float kmo_h_rn(double v);
+float kmo_h_from_int_rd(long long v);
 /* m of init = KMO_INIT_AFKMC2 (0 => 200), kmcuda.h:89-92 */
 void kmo_set_afkmc2_m(uint32_t m);
 float kmo_quantize_half(float x);

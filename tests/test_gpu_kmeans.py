@@ -291,9 +291,10 @@ def test_update_host_logic(mode):
         wc = numpy.zeros(k, numpy.int64)
         moved = numpy.nonzero(prev != cur)[0]
         numpy.add.at(want, cur[moved], x[moved].astype(numpy.float64))
-        numpy.subtract.at(want, prev[moved], x[moved].astype(numpy.float64))
         numpy.add.at(wc, cur[moved], 1)
-        numpy.subtract.at(wc, prev[moved], 1)
+        left = moved[prev[moved] >= 0]                   # -1: the row had no cluster yet
+        numpy.subtract.at(want, prev[left], x[left].astype(numpy.float64))
+        numpy.subtract.at(wc, prev[left], 1)
         got = delta.cpu().numpy().copy()
         numpy.testing.assert_allclose(got.reshape(k, d), want, rtol=1e-12, atol=1e-9)
         assert (dcount.cpu().numpy() == wc).all()

@@ -180,3 +180,79 @@ def test_fp16_storage_mode_quantises_centroids(fixture13k):
     c, a, log = oracle.kmeans(fixture13k.astype(numpy.float16), 50, init="random", seed=3, tolerance=0.05, yinyang_t=0)
     assert c.dtype == numpy.float16 and len(log) in (6, 7, 8)
     _validate(fixture13k, c.astype(numpy.float32), a, 0.05)
+
+
+# ---- the reference's half2 arithmetic (fp_abstraction.h:100-182), restated in the oracle (half2=True) ----
+def test_half2_roundings_match_numpy():
+    L = oracle.lib()
+    rs = numpy.random.RandomState(0)
+    v = numpy.concatenate([rs.randn(50000) * 10 ** rs.uniform(-8, 5, 50000),
+                           [65504, 65519.9, 65520, 2 ** -25, 2 ** -24 * 1.5, 0.1, -0.0, 0.0]])
+    with numpy.errstate(over="ignore"):
+        want = v.astype(numpy.float16).astype(numpy.float32)
+    got = numpy.array([L.kmo_h_rn(float(x)) for x in v], numpy.float32)
+    assert (got.view(numpy.uint32) == want.view(numpy.uint32)).all()
+    # __int2half_rd: the largest half not above the integer; never +inf
+    for c, h in [(0, 0), (1, 1), (2047, 2047), (2048, 2048), (2049, 2048), (2050, 2050), (4097, 4096),
+                 (65503, 65472), (65504, 65504), (70000, 65504)]:
+        assert L.kmo_h_from_int_rd(c) == h
+
+
+@pytest.mark.parametrize("kw,pin", [
+    (dict(init="random", tolerance=0.05, yinyang_t=0), 7),        # test.py:468-485
+    (dict(init="kmeans++", tolerance=0.05, yinyang_t=0), 5),      # test.py:487-497
+    (dict(init="afkmc2", tolerance=0.05, yinyang_t=0), 4),        # test.py:499-509
+    (dict(init="kmeans++", tolerance=0.01, yinyang_t=0.1), 16 + 7),  # test.py:523-533
+])
+def test_half2_iteration_pins(fixture13k, kw, pin):
+    """The reference's fp16 known answers, reproduced by the half2 restatement -- including the 16 + 7 of
+    the Yinyang run, which the fp32-arithmetic-on-half-values semantics of the product (22) misses: the
+    extra iteration is the half2 accumulation's own rounding noise ("fp16 precision increases the number of
+    iterations", test.py:531)."""
+    c, a, log = oracle.kmeans(fixture13k.astype(numpy.float16), 50, seed=3, half2=True, **kw)
+    assert len(log) == pin
+    assert c.dtype == numpy.float16
+    _validate(fixture13k, c.astype(numpy.float32), a, 0.0105 if kw["yinyang_t"] else 0.05)
+
+
+def test_half2_cosine_5():
+    # test.py:535-560
+    from sklearn.metrics.pairwise import cosine_distances
+    numpy.random.seed(0)
+    arr = numpy.empty((10000, 2), dtype=numpy.float16)
+    angs = numpy.random.rand(10000) * 2 * numpy.pi
+    for i in range(10000):
+        arr[i] = numpy.sin(angs[i]), numpy.cos(angs[i])
+    c, a, log = oracle.kmeans(arr, 4, init="kmeans++", metric="cos", seed=3, half2=True)
+    assert len(log) == 5
+    c = c.astype(numpy.float32)
+    for row in c:
+        assert 0.9995 < numpy.linalg.norm(row) < 1.0005
+    d = numpy.round(cosine_distances(c)).astype(int)
+    assert sorted(map(tuple, d.tolist())) == sorted([(0, 2, 1, 1), (2, 0, 1, 1), (1, 1, 0, 2), (1, 1, 2, 0)])
+    assert a.min() == 0 and a.max() == 3
+
+
+def test_half2_vs_storage_semantics(fixture13k):
+    """What the product's fp16 semantics (oracle storage mode = the product, bit for bit, tests/test_gpu_fp16.py)
+    deviate from the reference's half2 arithmetic on the reference fixture.  Whole runs: same iteration
+    counts on the Lloyd pins, 22 vs 23 on the Yinyang pin (the seeds of k-means++ already differ -- its
+    distances are half sums in one, float sums in the other -- so labels are not comparable), equal
+    clustering quality.  One assignment pass + update from the SAME centroids: about 0.8 % of the rows land
+    elsewhere (rows whose two best centroids tie within half rounding), centroids within half resolution."""
+    s16 = fixture13k.astype(numpy.float16)
+    x32 = s16.astype(numpy.float32)
+    a = oracle.kmeans(s16, 50, init="kmeans++", seed=3, tolerance=0.01, yinyang_t=0.1, average_distance=True)
+    b = oracle.kmeans(s16, 50, init="kmeans++", seed=3, tolerance=0.01, yinyang_t=0.1, average_distance=True,
+                      half2=True)
+    assert len(a[2]) == 22 and len(b[2]) == 23
+
+    def inertia(c, asg):
+        return float(((x32 - c.astype(numpy.float32)[asg]) ** 2).sum())
+    assert abs(inertia(a[0], a[1]) / inertia(b[0], b[1]) - 1) < 0.05
+    init = oracle.init_centroids(x32, 50, "kmeans++", seed=3).astype(numpy.float16)
+    p = oracle.kmeans(s16, 50, init=init, tolerance=0.5, yinyang_t=0)
+    q = oracle.kmeans(s16, 50, init=init, tolerance=0.5, yinyang_t=0, half2=True)
+    assert len(p[2]) == len(q[2]) == 2           # first pass (13000 changes), one update, second pass
+    assert (p[1] != q[1]).mean() < 0.012         # measured 0.78 %
+    assert abs(p[0].astype(numpy.float32) - q[0].astype(numpy.float32)).max() < 0.02
