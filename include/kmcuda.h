@@ -29,7 +29,7 @@ typedef enum {
 typedef enum {
   kmcudaInitMethodRandom = 0,  /* first K entries of a random_shuffle over rand() */
   kmcudaInitMethodPlusPlus,    /* k-means++ (distance-proportional, as the reference does it) */
-  kmcudaInitMethodAFKMC2,      /* AFK-MC2: not built in this tier -> kmcudaInvalidArguments */
+  kmcudaInitMethodAFKMC2,      /* AFK-MC2 (init_params: uint32_t* m, 0 => 200); draws restated from the published XORWOW */
   kmcudaInitMethodImport       /* caller supplies the centroids in `centroids` */
 } KMCUDAInitMethod;
 

@@ -149,6 +149,10 @@ int kmamd_profile_enable(kmamd_engine *e, int on);
 int kmamd_last_run_stats(uint32_t *iterations, double *loop_seconds, double *setup_seconds, uint32_t *shards,
                          uint32_t *rccl_ranks);
 
+/* host -> raw device pointer copy on `device` (what python.cc:330-345 does with cudaMemcpy for imported
+ * centroids in device-pointer mode; lets a binding without a HIP runtime of its own fill caller-owned memory). */
+int kmamd_copy_to_device(int device, void *dst, const void *host_src, size_t bytes);
+
 /* Library identification: returns the gfx arch string this library was compiled for. */
 const char *kmamd_build_arch(void);
 

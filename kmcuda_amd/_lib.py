@@ -23,7 +23,7 @@ EXPORTS = [
     "kmamd_lloyd_assign", "kmamd_lloyd_assign_exact", "kmamd_set_half_rows", "kmamd_set_row_cache", "kmamd_profile_read_coarse", "kmamd_set_filter", "kmamd_counters_read", "kmamd_counters_reset", "kmamd_yy_hint_stats",
     "kmamd_move_deltas", "kmamd_apply_delta", "kmamd_transpose", "kmamd_reduce_len", "kmamd_reduce_fill",
     "kmamd_reduce_apply", "kmamd_set_update_mode", "kmamd_last_run_stats", "kmamd_adjust_exact", "kmamd_yy_configure", "kmamd_yy_init", "kmamd_yy_drifts", "kmamd_yy_filters",
-    "kmamd_profile_reset", "kmamd_profile_read", "kmamd_profile_enable", "kmamd_build_arch",
+    "kmamd_copy_to_device", "kmamd_profile_reset", "kmamd_profile_read", "kmamd_profile_enable", "kmamd_build_arch",
 ]
 
 
@@ -101,6 +101,8 @@ def lib():
     L.kmamd_profile_read.restype = i32
     L.kmamd_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u32),
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    L.kmamd_copy_to_device.restype = i32
+    L.kmamd_copy_to_device.argtypes = [i32, vp, vp, ctypes.c_size_t]
     L.kmamd_build_arch.restype = ctypes.c_char_p
     _lib = L
     return L

@@ -148,8 +148,8 @@ def kmeans_cuda(samples, clusters, tolerance=.01, init="k-means++", yinyang_t=.1
         if device_ptrs < 0:
             centroids[...] = imp
         else:
-            import torch
-            _DEVICE_ALLOCS[cen_ptr].copy_(torch.from_numpy(imp))
+            # python.cc:330-345: cudaMemcpy of the imported centroids into the (possibly caller-owned) buffer
+            _raise_for(lib.kmamd_copy_to_device(device_ptrs, cen_ptr, imp.ctypes.data, imp.nbytes), "kmeans_cuda")
     avg = ctypes.c_float(0)
     rc = lib.kmeans_cuda(init_id, ctypes.byref(afkmc2_m), tolerance, yinyang_t, metric_id, n, d, clusters,
                          seed & 0xFFFFFFFF, device, device_ptrs, int(fp16x2), verbosity, samples_ptr, cen_ptr,

@@ -164,10 +164,6 @@ int Engine::yy_configure(uint32_t G, const uint32_t *groups_host) {
   if (const char *v = getenv("KMCUDA_AMD_YY_HINT")) {
     yy_hint_ = atoi(v) != 0;
     yy_hint_f32_ = atoi(v) == 2;
-    yy_hint_lists_ = atoi(v) == 3;
-  }
-  if (const char *v = getenv("KMCUDA_AMD_YY_REC")) {
-    yy_rec_ = atoi(v) != 0;
   }
   G_ = G;
   // centroids in group order; group >= G (a NaN centroid keeps the 0xFFFFFFFF "assignment" of
@@ -237,8 +233,6 @@ static void fill_yy_args(Engine &e, YyArgs &a, const float *samples, const float
   a.passed = nullptr; a.counters = e.counters_; a.count_ptr = e.counters_ + 2;
   a.panelhi = nullptr; a.hint = nullptr; a.flag_rows = nullptr; a.gfirst = e.gfirst_; a.gsecond = e.gsecond_;
   a.hint_f32_sweep = e.yy_hint_f32_ ? 1 : 0;
-  a.cand = nullptr; a.cand_n = nullptr; a.sweep_rows = nullptr;
-  a.rec_lb = nullptr; a.rec_g = nullptr;
   a.pfil = e.pfil_; a.pbias = e.pbias_; a.pids = e.pids_; a.pmeta = e.pmeta_; a.cperm = e.cperm_;
   a.gstart = e.gstart_; a.nslots = e.nslots_;
 }
@@ -277,16 +271,8 @@ int Engine::yy_filters(const float *samples, const float *centroids, const float
                        uint32_t *assignments, uint32_t *assignments_prev, float *bounds, uint32_t *passed) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   if (N_ == 0) return kSuccess;
-  const bool hinted = DP_ && DP_ <= 256 && !yy_exact_ && yy_hint_ && yy_hint_supported(DP_);
-  if (hinted && yy_rec_ && !yy_rec_lb_) {
-    int rc;
-    if ((rc = alloc(&yy_rec_lb_, (size_t)N_ * 4))) return rc;
-    if ((rc = alloc(&yy_rec_g_, (size_t)N_ * 4))) return rc;
-  }
-  const bool rec = hinted && yy_rec_;
   KMX_HIP(launch_yy_global_filter(metric_, samples, N_, D_, K_, G_, centroids, drifts, gdrifts, assignments,
-                                  assignments_prev, bounds, passed, counters_, rec ? yy_rec_lb_ : nullptr,
-                                  rec ? yy_rec_g_ : nullptr, stream_),
+                                  assignments_prev, bounds, passed, counters_, stream_),
           kRuntimeError);
   if (DP_ && DP_ <= 256 && !yy_exact_) {
     int rc = prepare_centroids(centroids);
@@ -308,24 +294,7 @@ int Engine::yy_filters(const float *samples, const float *centroids, const float
               kRuntimeError);
       KMX_HIP(hipMemsetAsync(counters_ + 5, 0, sizeof(uint32_t), stream_), kRuntimeError);
       a.panelhi = yy_panelhi_; a.hint = yy_hint_buf_; a.flag_rows = yy_flag_rows_;
-      if (rec) { a.rec_lb = yy_rec_lb_; a.rec_g = yy_rec_g_; }
-      if (yy_hint_lists_) {
-        // the estimate kernel also certifies and lists the candidates; the local filter runs from the
-        // lists, the rows without a certificate keep the sweep
-        if (!yy_cand_) {
-          if ((rc = alloc(&yy_cand_, (size_t)N_ * 8))) return rc;
-          if ((rc = alloc(&yy_cand_n_, N_))) return rc;
-          if ((rc = alloc(&yy_sweep_rows_, N_))) return rc;
-        }
-        KMX_HIP(hipMemsetAsync(counters_ + 12, 0, sizeof(uint32_t), stream_), kRuntimeError);
-        a.cand = yy_cand_; a.cand_n = yy_cand_n_; a.sweep_rows = yy_sweep_rows_;
-        KMX_HIP(launch_yy_hint_list(metric_, a, stream_), kRuntimeError);
-        KMX_HIP(launch_yy_local_list(metric_, a, stream_), kRuntimeError);
-        a.passed = yy_sweep_rows_;
-        a.count_ptr = counters_ + 12;
-      } else {
-        KMX_HIP(launch_yy_hint(metric_, a, stream_), kRuntimeError);
-      }
+      KMX_HIP(launch_yy_hint(metric_, a, stream_), kRuntimeError);
       KMX_HIP(launch_yy_local_hint(metric_, a, stream_), kRuntimeError);
       a.passed = yy_flag_rows_;
       a.count_ptr = counters_ + 5;
@@ -652,6 +621,10 @@ int kmamd_profile_read_coarse(kmamd_engine *e, double *coarse_ms) {
   e->e.profile_collect();
   if (coarse_ms) *coarse_ms = e->e.coarse_ms_;
   return kmx::kSuccess;
+}
+int kmamd_copy_to_device(int device, void *dst, const void *host_src, size_t bytes) {
+  if (hipSetDevice(device) != hipSuccess) return kmx::kNoSuchDevice;
+  return hipMemcpy(dst, host_src, bytes, hipMemcpyHostToDevice) == hipSuccess ? kmx::kSuccess : kmx::kMemoryCopyError;
 }
 const char *kmamd_build_arch(void) { return "gfx950"; }
 

@@ -111,11 +111,6 @@ class Engine {
   bool yy_exact_ = false;  // KMCUDA_AMD_YY_EXACT=1: plain exact kernels (cross-check)
   bool yy_hint_ = true;    // KMCUDA_AMD_YY_HINT=0: local filter without the second-best estimate (yinyang_hint.hip)
   bool yy_hint_f32_ = false;  // KMCUDA_AMD_YY_HINT=2: its candidate sweep on the f32 matrix cores
-  bool yy_hint_lists_ = false;  // KMCUDA_AMD_YY_HINT=3: candidates listed by the estimate kernel (no second sweep)
-  uint32_t *yy_cand_ = nullptr, *yy_cand_n_ = nullptr, *yy_sweep_rows_ = nullptr;
-  bool yy_rec_ = false;         // KMCUDA_AMD_YY_REC=1: the global filter notes every row's four smallest group bounds
-  float *yy_rec_lb_ = nullptr;
-  uint32_t *yy_rec_g_ = nullptr;
   uint32_t *gfirst_ = nullptr, *gsecond_ = nullptr, *yy_flag_rows_ = nullptr;
   float *yy_hint_buf_ = nullptr;
   void *yy_panelhi_ = nullptr;

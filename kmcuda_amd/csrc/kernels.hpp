@@ -147,17 +147,11 @@ struct YyArgs {
   const uint32_t *count_ptr; // length of `passed` (counters + 2, or counters + 5 for the fall-back list)
   uint32_t *counters;        // + [5] rows of the hinted kernel handed to the plain one, [6] / [7] running totals
   // hinted local filter (yinyang_hint.hip)
-  const void *panelhi;       // hi halves of the centred panel (centroid_panel16_kernel), DP halves per row
+  const void *panelhi;       // hi halves of the centred panel (centroid_panelhi_kernel), DP halves per row
   float *hint;               // per passed row: S' >= upper bound (or +inf: no hint)
   uint32_t *flag_rows;       // rows the hinted kernel could not settle
   const uint32_t *gfirst, *gsecond;  // G: the two smallest member indices of every group (0xFFFFFFFF: none)
   int hint_f32_sweep;        // candidate sweep of the hinted kernel on the f32 matrix cores (cross-check)
-  // candidate lists from the estimate kernel (KMCUDA_AMD_YY_HINT=3): 8 centroid indices per row, their
-  // number (0xFFFFFFFF: not certified complete), and the rows that keep the sweep (counters[12])
-  uint32_t *cand, *cand_n, *sweep_rows;
-  // per row: its four smallest group bounds (ascending) and their groups, noted by yy_global_filter (or null)
-  const float *rec_lb;
-  const uint32_t *rec_g;
   // yy_init: group-sorted padded panel
   const float *pfil, *pbias;
   const uint32_t *pids, *pmeta, *cperm, *gstart;
@@ -170,15 +164,12 @@ hipError_t launch_yy_init_mfma(int metric, const YyArgs &a, hipStream_t st);
 bool yy_hint_supported(uint32_t DP);
 hipError_t launch_yy_hint(int metric, const YyArgs &a, hipStream_t st);
 hipError_t launch_yy_local_hint(int metric, const YyArgs &a, hipStream_t st);
-hipError_t launch_yy_hint_list(int metric, const YyArgs &a, hipStream_t st);
-hipError_t launch_yy_local_list(int metric, const YyArgs &a, hipStream_t st);
 hipError_t launch_yy_sorted_panel(const float *cfil, const float *bias, uint32_t DP, const uint32_t *pids,
                                   uint32_t nslots, float *pfil, float *pbias, hipStream_t st);
 hipError_t launch_yy_global_filter(int metric, const float *samples, uint32_t len, uint32_t D, uint32_t K, uint32_t G,
                                    const float *centroids, const float *drifts, const float *gdrifts,
                                    const uint32_t *assignments, uint32_t *assignments_prev, float *bounds,
-                                   uint32_t *passed, uint32_t *counters, float *rec_lb /* 4 N, or null */,
-                                   uint32_t *rec_g /* 4 N, or null */, hipStream_t st);
+                                   uint32_t *passed, uint32_t *counters, hipStream_t st);
 hipError_t launch_yy_local_filter(int metric, const float *samples, uint32_t len, uint32_t D, uint32_t K, uint32_t G,
                                   const float *centroids, const uint32_t *groups, const float *drifts,
                                   const float *gdrifts, uint32_t *assignments, float *bounds, const uint32_t *passed,

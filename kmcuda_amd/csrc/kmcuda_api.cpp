@@ -1004,6 +1004,18 @@ class KnnJob {
           const uint32_t *assignments, uint32_t *neighbors) {
     std::vector<int> shard_devs = devs;
     if (nvirtual > 1 && devs.size() == 1) shard_devs.assign(nvirtual, devs[0]);  // test hook
+    // measurement hook KMCUDA_AMD_KNN_SHARD="i/n": plan the queries for n GPUs but run ONLY share i, on the
+    // first GPU of the mask (what one rank of an n-GPU search does: whole corpus resident, 1/n of the
+    // queries); the other rows of `neighbors` are left untouched
+    size_t plan_shards = shard_devs.size(), plan_first = 0;
+    if (const char *only = getenv("KMCUDA_AMD_KNN_SHARD")) {
+      unsigned i = 0, n = 0;
+      if (sscanf(only, "%u/%u", &i, &n) == 2 && n >= 1 && i < n) {
+        plan_shards = n;
+        plan_first = i;
+        shard_devs.assign(1, devs[0]);
+      }
+    }
     const char *force_exact = getenv("KMCUDA_AMD_KNN_EXACT");
     const uint32_t dp_filter = (force_exact && atoi(force_exact)) ? 0 : filter_dp_for(D);
     const uint32_t DP = dp_filter ? dp_filter : D;
@@ -1079,7 +1091,7 @@ class KnnJob {
       if ((rc = sh->alloc(&sh->stats, 4))) return rc;
       if ((rc = sh->alloc(&sh->calced, 1))) return rc;
       if (use_f16) {
-        if ((rc = sh->alloc(&sh->xs16, (size_t)N * 2 * DP))) return rc;
+        if ((rc = sh->alloc(&sh->xs16, (size_t)N * DP))) return rc;
         if ((rc = sh->alloc(&sh->mu, DP))) return rc;
         if ((rc = sh->alloc(&sh->mux, N))) return rc;
         if (hipMemcpyAsync(sh->mu, mu_host.data(), DP * sizeof(float), hipMemcpyHostToDevice, sh->stream) != hipSuccess)
@@ -1126,15 +1138,16 @@ class KnnJob {
       }
     const uint32_t total_blocks = (uint32_t)(blocks.size() / 2);
     const uint32_t assigned = offsets[K];  // positions >= assigned belong to no cluster (NaN samples)
-    for (size_t i = 0; i < shards.size(); i++) {
-      KnnShard &s = *shards[i];
-      s.first_block = (uint32_t)((uint64_t)total_blocks * i / shards.size());
-      const uint32_t next = (uint32_t)((uint64_t)total_blocks * (i + 1) / shards.size());
+    for (size_t si = 0; si < shards.size(); si++) {
+      KnnShard &s = *shards[si];
+      const size_t i = plan_first + si;
+      s.first_block = (uint32_t)((uint64_t)total_blocks * i / plan_shards);
+      const uint32_t next = (uint32_t)((uint64_t)total_blocks * (i + 1) / plan_shards);
       s.nblocks = next - s.first_block;
       s.p_base = s.nblocks ? blocks[2 * (size_t)s.first_block + 1] : assigned;
       s.p_end = next < total_blocks ? blocks[2 * (size_t)next + 1] : assigned;
       if (!s.nblocks) s.p_end = s.p_base;
-      if (i + 1 == shards.size() && !dp_filter) s.p_end = N;  // the exact kernel also fills the unassigned rows
+      if (i + 1 == plan_shards && !dp_filter) s.p_end = N;  // the exact kernel also fills the unassigned rows
     }
     if (use_f16) {  // after the radii / member distances, which read the plain norms' buffer no more
       for (auto &s : shards) {
@@ -1169,6 +1182,12 @@ class KnnJob {
       if (e != hipSuccess) return kmcudaRuntimeError;
     }
     // ---- outputs: rows back in sample order ----
+    if (device_ptrs >= 0 && dp_filter && assigned < N) {
+      // rows without a cluster (NaN samples) get no neighbours: 0xFFFFFFFF, as the host branch writes
+      // (the scatter below only covers the assigned positions)
+      (void)hipSetDevice(device_ptrs);
+      if (hipMemset(neighbors, 0xFF, (size_t)N * k * sizeof(uint32_t)) != hipSuccess) return kmcudaRuntimeError;
+    }
     unsigned long long dists_calced = 0;
     std::vector<uint32_t> host_inv, host_out;
     if (device_ptrs < 0) {
@@ -1201,6 +1220,8 @@ class KnnJob {
         // scatter on the caller's device
         const uint32_t *src_out = s.out, *src_inv = s.inv;
         uint32_t *tmp_out = nullptr, *tmp_inv = nullptr;
+        struct TmpFree { uint32_t **a, **b; ~TmpFree() { if (*a) (void)hipFree(*a); if (*b) (void)hipFree(*b); } }
+            tmp_guard{&tmp_out, &tmp_inv};   // also on the early returns below
         if (s.dev != device_ptrs) {
           (void)hipSetDevice(device_ptrs);
           if (hipMalloc((void **)&tmp_out, (size_t)len * k * sizeof(uint32_t)) != hipSuccess ||
@@ -1215,8 +1236,6 @@ class KnnJob {
         (void)hipSetDevice(device_ptrs);
         hipError_t e = launch_knn_scatter(src_out, src_inv, s.p_base, s.p_end, k, neighbors, nullptr);
         if (e == hipSuccess) e = hipDeviceSynchronize();
-        if (tmp_out) (void)hipFree(tmp_out);
-        if (tmp_inv) (void)hipFree(tmp_inv);
         if (e != hipSuccess) return kmcudaRuntimeError;
       }
     }

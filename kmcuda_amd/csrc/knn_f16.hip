@@ -2,12 +2,12 @@
 // filter on the f16 matrix cores.  Same contract as knn.hip's knn_filter_kernel (heap evolution,
 // prune decisions, neighbour indices and order identical to the reference's); what changes:
 //
-//   * the corpus is additionally stored CENTRED and split into two halves per value,
-//     xs16[p] = [hi(x_p - mu) | lo(x_p - mu)] (same bytes as an fp32 row; mu = mean of the centroids:
-//     distances are translation invariant, centring shrinks the norms in the error bound), so
-//     ||x - y||^2 ~= ||x'||^2 + ||y'||^2 - 2 (x_hi.y_hi + x_hi.y_lo + x_lo.y_hi) runs as three
-//     v_mfma_f32_32x32x16_f16 per 16 features (lloyd_f16.hip has the bound: products of halves are
-//     exact in the fp32 accumulator, |residual| <= 2^-22 |a| + 2^-25 per value);
+//   * the corpus is additionally stored CENTRED and rounded to halves, xs16[p] = hi(x_p - mu) (half the
+//     bytes of an fp32 row; mu = mean of the centroids: distances are translation invariant, centring
+//     shrinks the norms in the error bound), so ||x - y||^2 ~= ||x'||^2 + ||y'||^2 - 2 x_hi.y_hi runs as
+//     ONE v_mfma_f32_32x32x16_f16 per 16 features: products of halves are exact in the fp32 accumulator,
+//     the operand rounding |x'.y' - hi(x').hi(y')| <= (2^-10 + 2^-22) ||x'|| ||y'|| widens the acceptance
+//     band (the candidate test only has to never drop a candidate the reference would accept);
 //     angular: x.y = x'.y' + mu.y' + (mu.x' + ||mu||^2): bias mu.y' per candidate, the rest per query;
 //   * survivors are QUEUED per query, four deep, and a flush evaluates the exact distances as four
 //     interleaved chains (exact_split.hpp; original fp32 rows from the cluster-sorted copy), then
@@ -29,7 +29,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr float kFltMaxK = 3.402823466e+38f;
 
-// one wave per sorted row: xs16 (centred, split), centred squared norm, mu.x', max norm
+// one wave per sorted row: xs16 (centred halves), centred squared norm, mu.x', max norm
 template <int METRIC>
 __global__ __launch_bounds__(256) void knn_split_kernel(const float *__restrict__ xs, uint32_t N, uint32_t D,
                                                         uint32_t DP, const float *__restrict__ mu,
@@ -39,14 +39,12 @@ __global__ __launch_bounds__(256) void knn_split_kernel(const float *__restrict_
   const uint32_t lane = threadIdx.x & 63;
   if (p >= N) return;
   const float *src = xs + (size_t)p * DP;
-  _Float16 *dst = xs16 + (size_t)p * 2 * DP;
+  _Float16 *dst = xs16 + (size_t)p * DP;
   float a = 0.f, b = 0.f;
   for (uint32_t f = lane; f < DP; f += 64) {
     const float m = f < D ? mu[f] : 0.f;
     const float v = f < D ? src[f] - m : 0.f;
-    const _Float16 hi = (_Float16)v;
-    dst[f] = hi;
-    dst[DP + f] = (_Float16)(v - (float)hi);
+    dst[f] = (_Float16)v;
     a = fmaf(v, v, a);
     b = fmaf(m, v, b);
   }
@@ -92,17 +90,15 @@ __device__ __forceinline__ void knn_push_sample(uint32_t k, float dist, uint32_t
   }
 }
 
-// COARSE (default): hi.hi products only, ONE MFMA per 16 features.  The candidate test only has to
-// never drop a candidate the reference would accept; the operand rounding it then carries,
-// |x'.y' - hi(x').hi(y')| <= (2^-10 + 2^-22) ||x'|| ||y'||, widens the acceptance band by ~0.1 % of a
-// typical squared distance, i.e. lets through about one more candidate per query for the exact chain,
-// and saves two of three MFMAs and half the LDS fragment traffic.  (KMCUDA_AMD_KNN_SPLIT=1: the
-// three-product filter.)
-template <int DP, int METRIC, bool FASTX, bool COARSE>
+// hi.hi products only, ONE MFMA per 16 features: the operand rounding widens the acceptance band by
+// ~0.1 % of a typical squared distance, i.e. lets through about one more candidate per query for the
+// exact chain.  (Round 1 kept a three-product hi/lo variant as a second cross-check; the f32 matrix-core
+// filter of knn.hip and the unfiltered exact search are the two that remain.)
+template <int DP, int METRIC, bool FASTX>
 __global__ __launch_bounds__(256, 2) void knn_filter_f16_kernel(KnnArgs a) {
   constexpr int NKH = DP / 2;   // features per half-wave
   constexpr int KS = NKH / 8;   // k-steps
-  constexpr int LDW = DP + 4;   // padded LDS row (4-byte words; a row = 2*DP halves)
+  constexpr int LDW = DP / 2 + 4;   // padded LDS row (4-byte words; a row = DP halves)
   constexpr int TILE = 32 * LDW;
   constexpr int NST = (8 * DP + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -120,19 +116,15 @@ __global__ __launch_bounds__(256, 2) void knn_filter_f16_kernel(KnnArgs a) {
   const bool live = qp < own_end;
 
   // B operand: my half of my query's split row
-  f16x8 xhi[KS], xlo[COARSE ? 1 : KS];
+  f16x8 xhi[KS];
   {
-    const _Float16 *src = reinterpret_cast<const _Float16 *>(a.xs16) + (size_t)(live ? qp : p0) * 2 * DP + h * NKH;
+    const _Float16 *src = reinterpret_cast<const _Float16 *>(a.xs16) + (size_t)(live ? qp : p0) * DP + h * NKH;
 #pragma unroll
     for (int j = 0; j < KS; j++) {
       xhi[j] = reinterpret_cast<const f16x8 *>(src)[j];
-      if (!COARSE) xlo[j] = reinterpret_cast<const f16x8 *>(src + DP)[j];
       if (!live) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-          xhi[j][q] = (_Float16)0.f;
-          if (!COARSE) xlo[j][q] = (_Float16)0.f;
-        }
+        for (int q = 0; q < 8; q++) xhi[j][q] = (_Float16)0.f;
       }
     }
   }
@@ -154,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void knn_filter_f16_kernel(KnnArgs a) {
   const float qn = sqrtf(qn2) * 1.0001f, nmx = sqrtf(nmax2) * 1.0001f;
   float E, kq = 0.f;
   // operand rounding of the hi.hi-only score, in the units of the respective test
-  const float e_round = COARSE ? 9.78e-4f * qn * nmx : 0.f;
+  const float e_round = 9.78e-4f * qn * nmx;
   if (METRIC == 0) {
     E = 4.04f * (3.0f * a.eps + 16.0f * u) * (qn2 + nmax2) + 6e-8f * sqrtf((float)DP) * (qn + nmx) + 2.0f * e_round;
   } else {
@@ -173,8 +165,8 @@ __global__ __launch_bounds__(256, 2) void knn_filter_f16_kernel(KnnArgs a) {
   };
   float amin = amin_of(mndist);
 
-  // pieces of 16 bytes per staged row: the whole [hi | lo] row, or (COARSE) its hi half only
-  constexpr int RP = COARSE ? DP / 8 : DP / 4;
+  // pieces of 16 bytes per staged row (DP halves)
+  constexpr int RP = DP / 8;
   constexpr int NSTG = (32 * RP + 255) / 256;
   static_assert(NSTG <= NST, "staging registers");
   f32x4 stage[NSTG];
@@ -187,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void knn_filter_f16_kernel(KnnArgs a) {
       if (q < 32 * RP) {
         const uint32_t row = base + q / RP;
         const uint32_t rr = row <= last ? row : last;
-        stage[i] = reinterpret_cast<const f32x4 *>(panel + (size_t)rr * DP)[q % RP];
+        stage[i] = reinterpret_cast<const f32x4 *>(panel + (size_t)rr * (DP / 2))[q % RP];
       }
     }
     if (tid < 32) {
@@ -277,11 +269,6 @@ __global__ __launch_bounds__(256, 2) void knn_filter_f16_kernel(KnnArgs a) {
         for (int j = 0; j < KS; j++) {
           const f16x8 ahi = *reinterpret_cast<const f16x8 *>(arow + 8 * j);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, xhi[j], acc, 0, 0, 0);
-          if constexpr (!COARSE) {
-            const f16x8 alo = *reinterpret_cast<const f16x8 *>(arow + DP + 8 * j);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, xhi[j], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, xlo[j], acc, 0, 0, 0);
-          }
         }
         uint32_t m16 = 0;
         if (!pruned) {
@@ -342,15 +329,11 @@ hipError_t launch_knn_split(int metric, const float *xs, uint32_t N, uint32_t D,
 
 template <int DP, int METRIC>
 static hipError_t launch_knn_f16_t(const KnnArgs &a, uint32_t nblocks, hipStream_t st) {
-  const size_t lds_bytes = (2 * 32 * (DP + 4) + 64 + 8) * sizeof(float);
-  const bool split = getenv("KMCUDA_AMD_KNN_SPLIT") != nullptr;
-  if (a.D == (uint32_t)DP) {
-    if (split) hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, true, false>), dim3(nblocks), dim3(256), lds_bytes, st, a);
-    else hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, true, true>), dim3(nblocks), dim3(256), lds_bytes, st, a);
-  } else {
-    if (split) hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, false, false>), dim3(nblocks), dim3(256), lds_bytes, st, a);
-    else hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, false, true>), dim3(nblocks), dim3(256), lds_bytes, st, a);
-  }
+  const size_t lds_bytes = (2 * 32 * (DP / 2 + 4) + 64 + 8) * sizeof(float);
+  if (a.D == (uint32_t)DP)
+    hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, true>), dim3(nblocks), dim3(256), lds_bytes, st, a);
+  else
+    hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, false>), dim3(nblocks), dim3(256), lds_bytes, st, a);
   return hipGetLastError();
 }
 

@@ -118,51 +118,103 @@ __global__ void yy_group_max_drifts_kernel(const uint32_t *__restrict__ groups, 
 // yy_global_filter (kmeans.cu:540-582): streams the bounds matrix; rows that survive both
 // group-filter tries are appended to `passed` (order irrelevant: each is handled independently)
 // ---------------------------------------------------------------------------------------
-// REC: also note the row's four smallest (updated) group bounds and their groups: all the hinted local
-// filter needs from the bounds matrix (yinyang_hint.hip: low_bound_fold), which this kernel streams anyway
-// while the local filter would walk it a second time, G lines 4 N bytes apart per row.
-template <int METRIC, bool REC>
+// Round 2: the tightening distance (row to its own centroid, needed by every row that fails try #1 --
+// all of them on unstructured data) used to be walked by each thread along its own row and its own
+// centroid row: every 16-byte load of a wave touched 64 different lines.  Now both come in through LDS
+// in 32-feature chunks, 8 lanes per 128-byte line (the staging of kmpp_step2_kernel, seeding.hip), and
+// the chain -- same operations, same order -- reads its operands from two 36-float-stride tiles.
+template <int METRIC>
 __global__ __launch_bounds__(256) void yy_global_filter_kernel(
     const float *__restrict__ samples, uint32_t len, uint32_t D, uint32_t K, uint32_t G,
     const float *__restrict__ centroids, const float *__restrict__ drifts, const float *__restrict__ gdrifts,
     const uint32_t *__restrict__ assignments, uint32_t *__restrict__ assignments_prev, float *__restrict__ bounds,
-    uint32_t *__restrict__ passed, uint32_t *__restrict__ counters, float *__restrict__ rec_lb,
-    uint32_t *__restrict__ rec_g) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  bool pass = false;
+    uint32_t *__restrict__ passed, uint32_t *__restrict__ counters) {
+  extern __shared__ __attribute__((aligned(16))) float gf_lds[];   // 2 x 256 x 36 floats + 256 cluster ids
+  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+  bool pass = false, need = false;
+  float upper_bound = 0.f, min_lower_bound = 3.402823466e+38f;
+  uint32_t cluster = 0;
   if (s < len) {
-    const uint32_t cluster = assignments[s];
+    cluster = assignments[s];
     assignments_prev[s] = cluster;
-    float upper_bound = bounds[s];
+    upper_bound = bounds[s];
     const float cluster_drift = drifts[(size_t)K * D + cluster];
     upper_bound += cluster_drift;
-    float min_lower_bound = 3.402823466e+38f;
-    float l0 = INFINITY, l1 = INFINITY, l2 = INFINITY, l3 = INFINITY;   // ascending; a NaN bound is never noted
-    uint32_t g0 = 0xFFFFFFFFu, g1 = 0xFFFFFFFFu, g2 = 0xFFFFFFFFu, g3 = 0xFFFFFFFFu;
-    for (uint32_t g = 0; g < G; g++) {
+    uint32_t g = 0;
+    for (; g + 8 <= G; g += 8) {   // eight independent loads in flight per thread
+      float lb[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) lb[q] = bounds[(size_t)len * (1 + g + q) + s];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const float lower_bound = lb[q] - gdrifts[g + q];
+        bounds[(size_t)len * (1 + g + q) + s] = lower_bound;
+        if (lower_bound < min_lower_bound) min_lower_bound = lower_bound;
+      }
+    }
+    for (; g < G; g++) {
       const size_t gi = (size_t)len * (1 + g) + s;
       const float lower_bound = bounds[gi] - gdrifts[g];
       bounds[gi] = lower_bound;
       if (lower_bound < min_lower_bound) min_lower_bound = lower_bound;
-      if (REC) {
-        const float v = lower_bound;
-        const bool c0 = v < l0, c1 = v < l1, c2 = v < l2, c3 = v < l3;
-        l3 = c2 ? l2 : (c3 ? v : l3); g3 = c2 ? g2 : (c3 ? g : g3);
-        l2 = c1 ? l1 : (c2 ? v : l2); g2 = c1 ? g1 : (c2 ? g : g2);
-        l1 = c0 ? l0 : (c1 ? v : l1); g1 = c0 ? g0 : (c1 ? g : g1);
-        l0 = c0 ? v : l0;             g0 = c0 ? g : g0;
+    }
+    if (min_lower_bound >= upper_bound) bounds[s] = upper_bound;  // group filter try #1
+    else need = true;
+  }
+  if (__syncthreads_or(need ? 1 : 0)) {
+    const bool staged = (D & 3u) == 0 && (((uintptr_t)samples | (uintptr_t)centroids) & 15u) == 0;
+    if (staged) {
+      float *tx = gf_lds, *tc = gf_lds + 256 * 36;
+      uint32_t *cid = reinterpret_cast<uint32_t *>(gf_lds + 2 * 256 * 36);
+      cid[threadIdx.x] = (s < len && cluster < K) ? cluster : 0xFFFFFFFFu;
+      __syncthreads();
+      const uint32_t nchunk = (D + 31) / 32;
+      float4 sx[8], sc[8];
+      auto fetch = [&](uint32_t ch) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const uint32_t p = threadIdx.x + 256u * q, r = p >> 3, c4 = p & 7u;
+          const uint32_t row = blockIdx.x * 256u + r, f = ch * 32 + c4 * 4;
+          const uint32_t c = cid[r];
+          const bool on = row < len && f < D;
+          sx[q] = on ? *reinterpret_cast<const float4 *>(samples + (size_t)row * D + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+          sc[q] = (on && c != 0xFFFFFFFFu) ? *reinterpret_cast<const float4 *>(centroids + (size_t)c * D + f)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      };
+      float acc = 0.f, corr = 0.f;
+      fetch(0);
+      for (uint32_t ch = 0; ch < nchunk; ch++) {
+        __syncthreads();   // the previous chunk has been consumed
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const uint32_t p = threadIdx.x + 256u * q, r = p >> 3, c4 = p & 7u;
+          *reinterpret_cast<float4 *>(&tx[r * 36 + c4 * 4]) = sx[q];
+          *reinterpret_cast<float4 *>(&tc[r * 36 + c4 * 4]) = sc[q];
+        }
+        __syncthreads();
+        if (ch + 1 < nchunk) fetch(ch + 1);
+        const uint32_t fmax = D - ch * 32 < 32u ? D - ch * 32 : 32u;   // multiple of 4
+        for (uint32_t c4 = 0; c4 * 4 < fmax; c4++) {
+          const float4 xv = *reinterpret_cast<const float4 *>(&tx[threadIdx.x * 36 + c4 * 4]);
+          const float4 cv = *reinterpret_cast<const float4 *>(&tc[threadIdx.x * 36 + c4 * 4]);
+          const float aa[4] = {xv.x, xv.y, xv.z, xv.w}, bb[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            if (METRIC == 0) {
+              const float d = aa[q] - bb[q];
+              kahan_fold(fma_rd(d, d, corr), acc, corr);
+            } else {
+              kahan_fold(fma_rd(aa[q], bb[q], corr), acc, corr);
+            }
+          }
+        }
       }
-    }
-    if (REC) {  // (rows that do not pass never read theirs)
-      reinterpret_cast<float4 *>(rec_lb)[s] = make_float4(l0, l1, l2, l3);
-      reinterpret_cast<uint4 *>(rec_g)[s] = make_uint4(g0, g1, g2, g3);
-    }
-    if (min_lower_bound >= upper_bound) {  // group filter try #1
-      bounds[s] = upper_bound;
-    } else {
-      // row-major row walked by its own thread: the tightening is needed by a minority of rows and
-      // the (G+1) bounds streamed above dominate the traffic, so no feature-major copy is kept for it
+      if (need) upper_bound = METRIC == 0 ? sqrtf(acc) : angular_from_prod(acc);
+    } else if (need) {
       upper_bound = distance_vv<METRIC>(samples + (size_t)s * D, centroids + (size_t)cluster * D, D);
+    }
+    if (need) {
       bounds[s] = upper_bound;
       pass = !(min_lower_bound >= upper_bound);  // try #2
     }
@@ -265,19 +317,21 @@ hipError_t launch_yy_drifts(int metric, const float *centroids, uint32_t K, uint
 hipError_t launch_yy_global_filter(int metric, const float *samples, uint32_t len, uint32_t D, uint32_t K, uint32_t G,
                                    const float *centroids, const float *drifts, const float *gdrifts,
                                    const uint32_t *assignments, uint32_t *assignments_prev, float *bounds,
-                                   uint32_t *passed, uint32_t *counters, float *rec_lb, uint32_t *rec_g,
-                                   hipStream_t st) {
+                                   uint32_t *passed, uint32_t *counters, hipStream_t st) {
   if (len == 0) return hipSuccess;
-  const dim3 grid((len + 255) / 256), block(256);
-#define KMX_GF_LAUNCH(M, R)                                                                                         \
-  hipLaunchKernelGGL((yy_global_filter_kernel<M, R>), grid, block, 0, st, samples, len, D, K, G, centroids, drifts, \
-                     gdrifts, assignments, assignments_prev, bounds, passed, counters, rec_lb, rec_g)
-  if (rec_lb && rec_g) {
-    if (metric == 0) KMX_GF_LAUNCH(0, true); else KMX_GF_LAUNCH(1, true);
-  } else {
-    if (metric == 0) KMX_GF_LAUNCH(0, false); else KMX_GF_LAUNCH(1, false);
+  const size_t lds = (2 * 256 * 36 + 256) * sizeof(float);
+  static bool attr_set = false;   // > 64 KB of dynamic LDS
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)yy_global_filter_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)yy_global_filter_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
   }
-#undef KMX_GF_LAUNCH
+  if (metric == 0)
+    hipLaunchKernelGGL((yy_global_filter_kernel<0>), dim3((len + 255) / 256), dim3(256), lds, st, samples, len, D, K, G,
+                       centroids, drifts, gdrifts, assignments, assignments_prev, bounds, passed, counters);
+  else
+    hipLaunchKernelGGL((yy_global_filter_kernel<1>), dim3((len + 255) / 256), dim3(256), lds, st, samples, len, D, K, G,
+                       centroids, drifts, gdrifts, assignments, assignments_prev, bounds, passed, counters);
   return hipGetLastError();
 }
 

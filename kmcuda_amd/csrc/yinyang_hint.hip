@@ -42,38 +42,15 @@ typedef _Float16 f16x8h __attribute__((ext_vector_type(8)));
 
 // The (a) rule's share of the second minimum, folded up front (header): the smallest group bound that is
 // >= the upper bound, belongs to a group the reference's scan meets (a member other than the row's own
-// centroid), and is <= S'.  From the global filter's record of the row's four smallest bounds when there is
-// one -- scanning them in ascending order finds it unless all four are below the upper bound (or memberless)
-// while the fourth is still <= S' -- else by walking all G bounds (G lines, 4 N bytes apart per row: this
-// walk, not the matrix sweep, was most of the local filter's time).  Both half-waves return the same value.
+// centroid), and is <= S' -- by walking all G bounds of the row (G lines, 4 N bytes apart).  Both
+// half-waves return the same value.
 __device__ __forceinline__ float low_bound_fold(const YyArgs &a, uint32_t s, int h, uint32_t cluster, float upper_bound,
                                                 float hint, bool on) {
   const uint32_t G = a.G, len = a.len;
-  bool walk = on;
   float alow = kFltMax;
-  if (on && a.rec_lb) {
-    const float4 l4 = reinterpret_cast<const float4 *>(a.rec_lb)[s];
-    const uint4 g4 = reinterpret_cast<const uint4 *>(a.rec_g)[s];
-    const float l[4] = {l4.x, l4.y, l4.z, l4.w};
-    const uint32_t g[4] = {g4.x, g4.y, g4.z, g4.w};
-    bool found = false;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      if (!found && g[i] < G && l[i] >= upper_bound) {
-        uint32_t p = a.gfirst[g[i]];
-        if (p == cluster) p = a.gsecond[g[i]];
-        if (p != 0xFFFFFFFFu) {
-          found = true;
-          if (l[i] <= hint) alow = l[i];
-        }
-      }
-    }
-    // not found: every bound that is not recorded is >= the fourth (+inf when fewer than four exist)
-    walk = !found && !(l[3] > hint);
-  }
-  if (__ballot(walk) != 0ull) {
+  if (__ballot(on) != 0ull) {
     float mine = kFltMax;
-    if (walk) {
+    if (on) {
       for (uint32_t g0 = h; g0 < G; g0 += 16) {
         float lb8[8];
 #pragma unroll
@@ -95,7 +72,7 @@ __device__ __forceinline__ float low_bound_fold(const YyArgs &a, uint32_t s, int
     }
     const float other = __shfl_xor(mine, 32);
     const float both = other < mine ? other : mine;
-    if (walk) alow = both;
+    if (on) alow = both;
   }
   return alow;
 }
@@ -271,404 +248,6 @@ __global__ __launch_bounds__(256, 2) void yy_hint_kernel(YyArgs a) {
       if (!(hint >= upper_bound)) hint = INFINITY;
     }
     a.hint[row] = hint;
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// the estimate WITH the candidate list (KMCUDA_AMD_YY_HINT=3): the estimate sweep already computes
-// every score the local filter's candidate sweep recomputes.  Keeping the best FOUR scores per
-// half-wave and row, the kernel can certify "every score not kept is below the candidate threshold
-// amin(S')" (both halves' fourth-best < amin, rigorous f16 bound as in yy_local_hint_kernel<F16>
-// plus the 16 ulp of the packed register number) and hand the local filter its candidates
-// (yy_local_list_kernel: no matrix sweep at all).  Rows it cannot certify keep the sweep.
-// Measured (8M x 256, K = 1024, uniform): 6.5 + 10.7 ms against 5.2 + 12.9 ms with the second sweep --
-// every row certified, outcomes bit-identical, but the local filter's time turns out NOT to be its sweep
-// (nor its exact chains: prefetching them changed nothing): it is the per-row walk over the G group
-// bounds, G lines 4 N bytes apart.  Hence an option, not the default.
-// ---------------------------------------------------------------------------------------
-template <int DP, int METRIC, bool FAST>
-__global__ __launch_bounds__(256, 2) void yy_hint_list_kernel(YyArgs a) {
-  constexpr int NK = DP / 2, KS = NK / 8, LDWH = DP / 2 + 4, TILE = 32 * LDWH, NSTH = (4 * DP + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  auto tile_ptr = [&](int buf) { return lds + buf * TILE; };
-  auto bias_ptr = [&](int buf) { return lds + 2 * TILE + buf * 32; };
-
-  const uint32_t npassed = *a.count_ptr;
-  if (blockIdx.x * 256u >= npassed) return;  // block-uniform
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
-  const uint32_t D = a.D, K = a.K, G = a.G, len = a.len;
-  uint32_t pi[2], s[2];
-  bool live[2];
-#pragma unroll
-  for (int e = 0; e < 2; e++) {
-    pi[e] = blockIdx.x * 256u + wave * 64u + 32u * e + col;
-    live[e] = pi[e] < npassed;
-    s[e] = live[e] ? a.passed[pi[e]] : 0u;
-  }
-
-  f16x8h xh[2][KS];
-  float xc2[2], xmu[2], xo2s[2], dx2[2];
-#pragma unroll
-  for (int e = 0; e < 2; e++) {
-    float xc2e, xmue, xo2e, dx2e = 0.f;
-    {
-      KMX_YY_LOAD_ROWS(a.samples, s[e], live[e])
-      (void)xrow;
-#pragma unroll
-      for (int j = 0; j < KS; j++) {
-        f16x8h v;
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const _Float16 hi = (_Float16)xb[8 * j + q];
-          const float r = xb[8 * j + q] - (float)hi;  // exact
-          dx2e = fmaf(r, r, dx2e);
-          v[q] = hi;
-        }
-        xh[e][j] = v;
-      }
-      xc2e = xc2;
-      xmue = xmu;
-      xo2e = xo2;
-    }
-    xc2[e] = xc2e;
-    xmu[e] = xmue;
-    xo2s[e] = xo2e;
-    dx2[e] = dx2e + __shfl_xor(dx2e, 32);
-#pragma unroll
-    for (int j = 0; j < KS; j++) asm volatile("" : "+v"(xh[e][j]));
-    __builtin_amdgcn_sched_barrier(0);
-  }
-
-  f32x4 stage[NSTH];
-  float bstage = 0.f;
-  auto stage_load = [&](uint32_t tile) {
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(reinterpret_cast<const _Float16 *>(a.panelhi) + (size_t)tile * 32 * DP);
-#pragma unroll
-    for (int i = 0; i < NSTH; i++) {
-      const int q = tid + i * 256;
-      if (q < 4 * DP) stage[i] = src[q];
-    }
-    if (tid < 32) bstage = a.bias[tile * 32 + tid];
-  };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NSTH; i++) {
-      const int q = tid + i * 256;
-      if (q < 4 * DP) {
-        const int row = q / (DP / 8), c8 = q % (DP / 8);
-        *reinterpret_cast<f32x4 *>(tile_ptr(buf) + row * LDWH + c8 * 4) = stage[i];
-      }
-    }
-    if (tid < 32) bias_ptr(buf)[tid] = bstage;
-  };
-
-  // best four scores (descending) of my 16 accumulator rows per tile, register number in the low 4
-  // mantissa bits, tile index noted once per tile
-  float v[2][4];
-  uint32_t tl[2][4];
-#pragma unroll
-  for (int e = 0; e < 2; e++)
-#pragma unroll
-    for (int i = 0; i < 4; i++) { v[e][i] = -INFINITY; tl[e][i] = 0; }
-  const uint32_t ntiles = a.K_pad / 32;
-  stage_load(0);
-  stage_store(0);
-  __syncthreads();
-  for (uint32_t t = 0; t < ntiles; t++) {
-    const int buf = t & 1;
-    if (t + 1 < ntiles) stage_load(t + 1);
-    f32x16 acc[2];
-    {
-      const float *bb = bias_ptr(buf) + 4 * h;
-#pragma unroll
-      for (int g4 = 0; g4 < 4; g4++) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bb + 8 * g4);
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-          acc[e][4 * g4 + 0] = b4.x; acc[e][4 * g4 + 1] = b4.y; acc[e][4 * g4 + 2] = b4.z; acc[e][4 * g4 + 3] = b4.w;
-        }
-      }
-      const _Float16 *arow = reinterpret_cast<const _Float16 *>(tile_ptr(buf) + col * LDWH) + h * NK;
-#pragma unroll
-      for (int j = 0; j < KS; j++) {
-        const f16x8h af = *reinterpret_cast<const f16x8h *>(arow + 8 * j);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xh[0][j], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xh[1][j], acc[1], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 2; e++) {
-      const float o[4] = {v[e][0], v[e][1], v[e][2], v[e][3]};
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const float x = __uint_as_float((__float_as_uint(acc[e][r]) & ~15u) | (uint32_t)r);
-        v[e][3] = __builtin_amdgcn_fmed3f(v[e][2], v[e][3], x);
-        v[e][2] = __builtin_amdgcn_fmed3f(v[e][1], v[e][2], x);
-        v[e][1] = __builtin_amdgcn_fmed3f(v[e][0], v[e][1], x);
-        v[e][0] = fmaxf(v[e][0], x);
-      }
-      uint32_t nt[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-        nt[i] = (v[e][i] == o[0]) ? tl[e][0] : ((v[e][i] == o[1]) ? tl[e][1] : ((v[e][i] == o[2]) ? tl[e][2] : ((v[e][i] == o[3]) ? tl[e][3] : t)));
-#pragma unroll
-      for (int i = 0; i < 4; i++) tl[e][i] = nt[i];
-    }
-    if (t + 1 < ntiles) stage_store(buf ^ 1);
-    __syncthreads();
-  }
-
-  const float cmaxc = sqrtf(__uint_as_float(a.stats[0])) * 1.000001f;
-  const float bmaxc = __uint_as_float(a.stats[1]);
-  const float dcmax = sqrtf(__uint_as_float(a.stats[5])) * 1.0001f;
-#pragma unroll
-  for (int e = 0; e < 2; e++) {
-    float pv[4];
-    uint32_t pt[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      pv[i] = __shfl_xor(v[e][i], 32);
-      pt[i] = __shfl_xor(tl[e][i], 32);
-    }
-    if (!live[e] || h != 0) continue;
-    const uint32_t row = s[e];
-    const float upper_bound = a.bounds[row];
-    const uint32_t cluster = a.assignments[row];
-    float cv[8];
-    uint32_t cc[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      cv[i] = i < 4 ? v[e][i] : pv[i - 4];
-      const uint32_t r = __float_as_uint(cv[i]) & 15u;
-      cc[i] = (i < 4 ? tl[e][i] : pt[i - 4]) * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (i >= 4 ? 1u : 0u);
-    }
-    // the estimate, as in yy_hint_kernel: the best kept centroid that is neither the row's own nor groupless
-    float best = -INFINITY;
-    uint32_t best_g = 0xFFFFFFFFu;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      if (cc[i] < K && cc[i] != cluster && cv[i] > best) {
-        const uint32_t g = a.groups[cc[i]];
-        if (g < G) {
-          best = cv[i];
-          best_g = g;
-        }
-      }
-    }
-    const float xc = sqrtf(xc2[e]) * 1.0001f;
-    float hint = INFINITY;
-    if (best_g < G) {
-      const float lbg = a.bounds[(size_t)len * (1 + best_g) + row];
-      float y;
-      if (lbg >= upper_bound) {
-        y = lbg;
-      } else {
-        const float frac = fminf(1.0f, 4.0f / sqrtf((float)DP));
-        const float e_h = 9.8e-4f * frac * xc * cmaxc + 4e-6f * fabsf(best) + 1e-6f * xc2[e];
-        if (METRIC == 0) {
-          y = sqrtf(fmaxf(xc2[e] - 2.0f * (best - e_h), 0.f)) * 1.00001f;
-        } else {
-          const float dot = best + xmu[e] - e_h;
-          y = (dot >= 1.f ? 0.f : (dot <= -1.f ? 3.1415927f : acosf(dot))) * 1.00001f + 1e-6f;
-        }
-      }
-      hint = fmaxf(upper_bound, y);
-      if (!(hint >= upper_bound)) hint = INFINITY;
-    }
-    a.hint[row] = hint;
-    // the candidate threshold for S' = hint, rigorous (yy_local_hint_kernel<F16>'s bound + 16 ulp for the
-    // register number), and the certificate that nothing above it was dropped
-    uint32_t ncand = 0xFFFFFFFFu;
-    if (hint < INFINITY) {
-      const float dx = sqrtf(dx2[e]) * 1.0001f;
-      const float e16 = 2.0f * a.eps * (xc * cmaxc + bmaxc) * 1.01f + (xc * dcmax + dx * cmaxc + dx * dcmax) * 1.001f +
-                        6e-8f * sqrtf((float)DP) * (xc + cmaxc) + 2.0e-6f * (1.001f * xc * cmaxc + bmaxc);
-      float amin;
-      if (METRIC == 0) {
-        const float T2 = hint * hint * 1.000002f;
-        amin = 0.5f * (xc2[e] - T2) - e16 - 1e-6f * (xc2[e] + T2);
-      } else {
-        const float xo = sqrtf(xo2s[e]) * 1.0001f;
-        const float e_cos = e16 + a.eps * xo * sqrtf(__uint_as_float(a.stats[3])) * 1.01f + 1e-6f;
-        amin = hint >= 3.1415925f ? -INFINITY : cosf(hint) - xmu[e] - e_cos;
-      }
-      const bool in_range = xc < 6.0e4f && cmaxc < 6.0e4f && e16 < INFINITY;
-      bool ok = in_range && cv[3] < amin && cv[7] < amin;   // NaN anywhere: not certified
-      uint32_t n = 0;
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const bool take = cv[i] >= amin;
-        if (take) {
-#pragma unroll
-          for (int j = 0; j < 8; j++)
-            if (j < i && cv[j] >= amin && cc[j] == cc[i]) ok = false;   // equal scores share a tile label: ambiguous
-          a.cand[(size_t)row * 8 + n] = cc[i];
-          n++;
-        }
-      }
-      if (ok) ncand = n;
-    }
-    a.cand_n[row] = ncand;
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// the local filter from the candidate list: yy_local_hint_kernel without its matrix sweep
-// ---------------------------------------------------------------------------------------
-template <int DP, int METRIC, bool FAST>
-__global__ __launch_bounds__(256) void yy_local_list_kernel(YyArgs a) {
-  constexpr int NK = DP / 2;
-  const uint32_t npassed = *a.count_ptr;
-  if (blockIdx.x * 128u >= npassed) return;  // block-uniform
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
-  const uint32_t D = a.D, K = a.K, G = a.G, len = a.len;
-  const uint32_t pi = blockIdx.x * 128u + wave * 32u + col;
-  const bool live = pi < npassed;
-  const uint32_t s = live ? a.passed[pi] : 0u;
-  const float *xrow = a.samples + (size_t)s * D;
-
-  const float upper_bound = live ? a.bounds[s] : 0.f;
-  const uint32_t cluster = live ? a.assignments[s] : 0xFFFFFFFFu;
-  const float hint = live ? a.hint[s] : INFINITY;
-  const uint32_t ncand = live ? a.cand_n[s] : 0xFFFFFFFFu;
-  const bool sweep = live && ncand == 0xFFFFFFFFu;   // not certified (or no estimate): the sweep kernel's row
-  const bool work = live && !sweep;
-  float min_dist = upper_bound, second_min = kFltMax;
-  uint32_t nearest = cluster;
-  bool bad = false;
-  uint32_t why = 0u;
-
-  second_min = low_bound_fold(a, s, h, cluster, upper_bound, hint, work);
-
-  // the kept candidates that the reference's scan would look at, ascending
-  uint32_t cs[8];
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    uint32_t c = 0xFFFFFFFFu;
-    if (work && (uint32_t)i < ncand) {
-      c = a.cand[(size_t)s * 8 + i];
-      const uint32_t g = c < K ? a.groups[c] : 0xFFFFFFFFu;
-      bool keep = g < G && c != cluster;
-      if (keep) {
-        const float lbg = a.bounds[(size_t)len * (1 + g) + s];
-        keep = !(lbg >= upper_bound);   // else an (a) centroid: folded above if its bound is <= S'
-      }
-      if (!keep) c = 0xFFFFFFFFu;
-    }
-    cs[i] = c;
-  }
-  {  // odd-even merge sort network for 8 keys (19 compare-exchanges)
-#define KMX_CE(i, j) { const uint32_t lo_ = cs[i] < cs[j] ? cs[i] : cs[j], hi_ = cs[i] < cs[j] ? cs[j] : cs[i]; cs[i] = lo_; cs[j] = hi_; }
-    KMX_CE(0, 1) KMX_CE(2, 3) KMX_CE(4, 5) KMX_CE(6, 7)
-    KMX_CE(0, 2) KMX_CE(1, 3) KMX_CE(4, 6) KMX_CE(5, 7)
-    KMX_CE(1, 2) KMX_CE(5, 6)
-    KMX_CE(0, 4) KMX_CE(1, 5) KMX_CE(2, 6) KMX_CE(3, 7)
-    KMX_CE(2, 4) KMX_CE(3, 5)
-    KMX_CE(1, 2) KMX_CE(3, 4) KMX_CE(5, 6)
-#undef KMX_CE
-  }
-
-  uint32_t n_flush = 0, n_cand = 0;
-#pragma unroll
-  for (int b4 = 0; b4 < 2; b4++) {
-    uint32_t qc[4];
-    int qn = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      qc[i] = cs[4 * b4 + i];
-      if (qc[i] != 0xFFFFFFFFu) qn++;   // sorted: the valid ones come first
-    }
-    if (__ballot(qn > 0) == 0ull) continue;  // wave-uniform
-    n_flush++;
-    n_cand += (uint32_t)qn;
-    const float *crow[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) crow[i] = a.centroids + (size_t)(i < qn ? qc[i] : 0) * D;
-    float dist[4];
-    exact_distance4<NK, METRIC, FAST>(xrow, crow, D, h, col, dist);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      if (i < qn) {
-        const uint32_t c = qc[i];
-        const uint32_t g = a.groups[c];
-        float lb = a.bounds[(size_t)len * (1 + g) + s];
-        lb += a.gdrifts[g] - a.drifts[(size_t)K * D + c];    // kmeans.cu:637
-        if (!(second_min < lb)) {                            // :638-640
-          if (lb > hint) {                                   // F1
-            bad = true;
-            if (!why) why = 3u;
-          }
-          const float d = dist[i];                           // :641-652
-          if (d < min_dist) {
-            second_min = min_dist;
-            min_dist = d;
-            nearest = c;
-          } else if (d < second_min) {
-            second_min = d;
-          }
-        } else if (dist[i] < lb) {                           // F3
-          bad = true;
-          if (!why) why = 2u;
-        }
-      }
-    }
-  }
-  if (!(second_min <= hint)) {  // F2
-    bad = true;
-    if (!why) why = 4u;
-  }
-
-  bool changed = false;
-  const bool mine = work && h == 0;
-  if (mine && !bad) {
-    const uint32_t nearest_group = a.groups[nearest], previous_group = a.groups[cluster];
-    a.bounds[(size_t)len * (1 + nearest_group) + s] = second_min;
-    if (nearest_group != previous_group) {
-      const size_t gi = (size_t)len * (1 + previous_group) + s;
-      const float pb = a.bounds[gi];
-      if (pb > upper_bound) a.bounds[gi] = upper_bound;
-    }
-    a.bounds[s] = min_dist;
-    if (cluster != nearest) {
-      a.assignments[s] = nearest;
-      changed = true;
-    }
-  }
-  const unsigned long long cm = __ballot(changed);
-  if (lane == 0 && cm) atomicAdd(&a.counters[0], (uint32_t)__popcll(cm));
-  const unsigned long long fm = __ballot(mine && bad);
-  if (fm) {
-    uint32_t base = 0;
-    if (lane == 0) {
-      base = atomicAdd(&a.counters[5], (uint32_t)__popcll(fm));
-      atomicAdd(&a.counters[7], (uint32_t)__popcll(fm));
-    }
-    base = __shfl(base, 0);
-    if (mine && bad) a.flag_rows[base + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = s;
-  }
-  const unsigned long long sm = __ballot(sweep && h == 0);
-  if (sm) {
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&a.counters[12], (uint32_t)__popcll(sm));
-    base = __shfl(base, 0);
-    if (sweep && h == 0) a.sweep_rows[base + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = s;
-  }
-  {  // statistics
-    uint32_t nc = (mine && !bad) ? n_cand : 0u;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) nc += __shfl_xor(nc, off);
-    const uint32_t nmine = (uint32_t)__popcll(__ballot(mine));
-    uint32_t nwhy[4];
-#pragma unroll
-    for (int w = 0; w < 4; w++) nwhy[w] = (uint32_t)__popcll(__ballot(mine && why == (uint32_t)(w + 1)));
-    if (lane == 0) {
-      atomicAdd(&a.counters[3], nc);
-      atomicAdd(&a.counters[1], n_flush);
-      atomicAdd(&a.counters[6], nmine);
-#pragma unroll
-      for (int w = 0; w < 4; w++)
-        if (nwhy[w]) atomicAdd(&a.counters[8 + w], nwhy[w]);
-    }
   }
 }
 
@@ -983,26 +562,6 @@ static hipError_t launch_local_hint_t(const YyArgs &a, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int DP, int METRIC>
-static hipError_t launch_hint_list_t(const YyArgs &a, hipStream_t st) {
-  const size_t lds_bytes = (2 * 32 * (DP / 2 + 4) + 64) * sizeof(float);
-  const uint32_t grid = (a.len + 255) / 256;
-  if (a.D == (uint32_t)DP)
-    hipLaunchKernelGGL((yy_hint_list_kernel<DP, METRIC, true>), dim3(grid), dim3(256), lds_bytes, st, a);
-  else
-    hipLaunchKernelGGL((yy_hint_list_kernel<DP, METRIC, false>), dim3(grid), dim3(256), lds_bytes, st, a);
-  return hipGetLastError();
-}
-template <int DP, int METRIC>
-static hipError_t launch_local_list_t(const YyArgs &a, hipStream_t st) {
-  const uint32_t grid = (a.len + 127) / 128;
-  if (a.D == (uint32_t)DP)
-    hipLaunchKernelGGL((yy_local_list_kernel<DP, METRIC, true>), dim3(grid), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((yy_local_list_kernel<DP, METRIC, false>), dim3(grid), dim3(256), 0, st, a);
-  return hipGetLastError();
-}
-
 #define KMX_YYH_SWITCH(fn)                                                             \
   switch (a.DP) {                                                                      \
     case 16: return metric == 0 ? fn<16, 0>(a, st) : fn<16, 1>(a, st);                 \
@@ -1021,16 +580,6 @@ hipError_t launch_yy_hint(int metric, const YyArgs &a, hipStream_t st) {
 hipError_t launch_yy_local_hint(int metric, const YyArgs &a, hipStream_t st) {
   if (a.len == 0) return hipSuccess;
   KMX_YYH_SWITCH(launch_local_hint_t)
-}
-
-hipError_t launch_yy_hint_list(int metric, const YyArgs &a, hipStream_t st) {
-  if (a.len == 0) return hipSuccess;
-  KMX_YYH_SWITCH(launch_hint_list_t)
-}
-
-hipError_t launch_yy_local_list(int metric, const YyArgs &a, hipStream_t st) {
-  if (a.len == 0) return hipSuccess;
-  KMX_YYH_SWITCH(launch_local_list_t)
 }
 
 }  // namespace kmx

@@ -19,7 +19,13 @@ def main():
     ap.add_argument("--data", default="gaussian", choices=["uniform", "gaussian"])
     ap.add_argument("--sigma", type=float, default=1.0)
     ap.add_argument("--check", type=int, default=0, help="verify this many rows against a brute-force torch search")
+    ap.add_argument("--shard", default="", help="i/n: what rank i of an n-GPU search does -- the whole corpus resident, "
+                                                 "1/n of the queries (KMCUDA_AMD_KNN_SHARD); BASELINE config D is "
+                                                 "--samples 8000000 --shard 0/8")
+    ap.add_argument("--init", default="random")
     args = ap.parse_args()
+    if args.shard:
+        os.environ["KMCUDA_AMD_KNN_SHARD"] = args.shard
     import torch
     from kmcuda_amd import kmeans_cuda, knn_cuda
     from kmcuda_amd.api import _DEVICE_ALLOCS
@@ -39,16 +45,22 @@ def main():
             x[s:e] += centres[lab]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    cptr, aptr = kmeans_cuda((x.data_ptr(), 0, (n, d)), K, init="random", seed=777, tolerance=0.01, yinyang_t=0,
+    cptr, aptr = kmeans_cuda((x.data_ptr(), 0, (n, d)), K, init=args.init, seed=777, tolerance=0.01, yinyang_t=0,
                              device=1, verbosity=0)
     t1 = time.perf_counter()
-    nptr = knn_cuda(args.k, (x.data_ptr(), 0, (n, d)), (cptr, K), aptr, device=1, verbosity=1)
+    nbuf = torch.full((n, args.k), -1, dtype=torch.int32, device=dev)   # rows outside the shard stay 0xFFFFFFFF
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    knn_cuda(args.k, (x.data_ptr(), 0, (n, d), nbuf.data_ptr()), (cptr, K), aptr, device=1, verbosity=1)
+    torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print("kmeans_cuda %.3f s; knn_cuda %.3f s => %.3e neighbour lists/s" % (t1 - t0, t2 - t1, n / (t2 - t1)),
-          flush=True)
+    done = int((nbuf[:, 0] != -1).sum().item())
+    print("kmeans_cuda %.3f s; knn_cuda %.3f s for %d of %d queries => %.3e neighbour lists/s" %
+          (t1 - t0, t2 - t1, done, n, done / (t2 - t1)), flush=True)
     if args.check:
-        nb = _DEVICE_ALLOCS[nptr].view(n, args.k)
-        rows = torch.randint(0, n, (args.check,), device=dev, generator=gen)
+        nb = nbuf
+        have = torch.nonzero(nbuf[:, 0] != -1).ravel()
+        rows = have[torch.randint(0, have.numel(), (args.check,), device=dev, generator=gen)]
         bad = 0
         for r in rows.tolist():
             dist = ((x - x[r]) ** 2).sum(1)

@@ -169,6 +169,25 @@ def test_device_ptr_in_out_and_samples_untouched(fixture13k):
     free_device_ptr(aptr)
 
 
+def test_device_ptr_caller_outputs_and_imported_centroids(fixture13k):
+    """Device-pointer mode with caller-supplied output buffers (a samples tuple of length 5) AND centroids
+    imported from a host array: the import is a host -> device copy into the caller's buffer
+    (python.cc:330-345), which must not need that buffer to be one of ours.  Same run as the host-array call."""
+    from kmcuda_amd import kmeans_cuda
+    dev = torch.device("cuda", 0)
+    rs = numpy.random.RandomState(4)
+    init = fixture13k[rs.choice(len(fixture13k), 50, replace=False)].copy()
+    ref_c, ref_a = kmeans_cuda(fixture13k, 50, init=init, device=1, tolerance=0.02, yinyang_t=0)
+    st = torch.from_numpy(fixture13k).to(dev)
+    cen = torch.zeros((50, 2), dtype=torch.float32, device=dev)
+    asg = torch.zeros(13000, dtype=torch.int32, device=dev)
+    cptr, aptr = kmeans_cuda((st.data_ptr(), 0, fixture13k.shape, cen.data_ptr(), asg.data_ptr()), 50, init=init,
+                             device=1, tolerance=0.02, yinyang_t=0)
+    assert cptr == cen.data_ptr() and aptr == asg.data_ptr()
+    assert numpy.array_equal(cen.cpu().numpy(), ref_c)
+    assert (asg.cpu().numpy().view(numpy.uint32) == ref_a).all()
+
+
 def test_cosine_metric_5():
     from kmcuda_amd import kmeans_cuda
     numpy.random.seed(0)

@@ -37,15 +37,11 @@ def test_small_equals_sklearn_and_oracle(clustered13k, k, dmax):
 
 
 def test_exact_search_matches_filtered(clustered13k, monkeypatch):
-    """Four searches, one answer: coarse f16 matrix-core filter (default: hi.hi products), the
-    three-product f16 filter, the f32 matrix-core filter, no filter."""
+    """Three searches, one answer: coarse f16 matrix-core filter (default: hi.hi products), the f32
+    matrix-core filter, no filter."""
     from kmcuda_amd import knn_cuda
     x, c, a = clustered13k
     nb = knn_cuda(10, x, c, a, device=1)
-    monkeypatch.setenv("KMCUDA_AMD_KNN_SPLIT", "1")
-    nb3 = knn_cuda(10, x, c, a, device=1)
-    monkeypatch.delenv("KMCUDA_AMD_KNN_SPLIT")
-    assert (nb == nb3).all()
     monkeypatch.setenv("KMCUDA_AMD_FILTER", "f32")
     nb32 = knn_cuda(10, x, c, a, device=1)
     monkeypatch.delenv("KMCUDA_AMD_FILTER")
@@ -103,14 +99,10 @@ def test_device_ptr(clustered13k):
 
 @pytest.mark.parametrize("n,d,K,k", [(8000, 48, 160, 10), (6000, 256, 64, 10), (5000, 7, 40, 3), (3000, 100, 20, 33),
                                      (2000, 300, 16, 5)])
-@pytest.mark.parametrize("filt", ["f16", "f16split", "f32"])
+@pytest.mark.parametrize("filt", ["f16", "f32"])
 def test_matches_oracle_bit_exact(n, d, K, k, filt, monkeypatch):
     from kmcuda_amd import knn_cuda
-    monkeypatch.setenv("KMCUDA_AMD_FILTER", "f32" if filt == "f32" else "f16")
-    if filt == "f16split":
-        monkeypatch.setenv("KMCUDA_AMD_KNN_SPLIT", "1")
-    else:
-        monkeypatch.delenv("KMCUDA_AMD_KNN_SPLIT", raising=False)
+    monkeypatch.setenv("KMCUDA_AMD_FILTER", filt)
     rs = numpy.random.RandomState(n + d)
     x = rs.rand(n, d).astype(numpy.float32)
     q = n // 4

@@ -164,105 +164,3 @@ def test_unflagged_rows_equal_the_reference_scan():
                                        list(cdrift), cluster, (m, s2, n), ref)
     # the generator must exercise both outcomes heavily, or the check above says little
     assert settled > 80000 and flagged > 20000, (settled, flagged)
-
-
-def test_four_smallest_record_settles_the_fold_or_asks_for_the_walk():
-    """low_bound_fold with the global filter's record (KMCUDA_AMD_YY_REC=1): the four smallest group bounds
-    either determine the folded value or the function walks all G bounds; never a different value."""
-    rs = numpy.random.RandomState(777)
-    decided = walked = 0
-    vals = numpy.array([0.5, 1.0, 1.5, 2.0, 2.5, 3.0, numpy.nan], numpy.float32)
-    for trial in range(60000):
-        G = int(rs.randint(1, 9))
-        lbg = rs.choice(vals, G) if trial % 2 else (rs.rand(G) * 3).astype(numpy.float32)
-        has_member = rs.rand(G) < 0.85          # a group whose only member is the row's own centroid has none
-        ub = F(rs.choice(vals[:-1])) if trial % 2 else F(rs.rand() * 3)
-        hint = max(ub, F(ub + rs.rand() * 1.5)) if rs.rand() < 0.8 else ub
-        want = FLT_MAX                           # the walk
-        for g in range(G):
-            if lbg[g] >= ub and lbg[g] <= hint and lbg[g] < want and has_member[g]:
-                want = lbg[g]
-        # the record, as yy_global_filter_kernel<REC> builds it (a NaN bound is never noted)
-        l = [F(numpy.inf)] * 4
-        gi = [NONE] * 4
-        for g in range(G):
-            v = lbg[g]
-            c = [v < l[0], v < l[1], v < l[2], v < l[3]]
-            l[3], gi[3] = (l[2], gi[2]) if c[2] else ((v, g) if c[3] else (l[3], gi[3]))
-            l[2], gi[2] = (l[1], gi[1]) if c[1] else ((v, g) if c[2] else (l[2], gi[2]))
-            l[1], gi[1] = (l[0], gi[0]) if c[0] else ((v, g) if c[1] else (l[1], gi[1]))
-            l[0], gi[0] = (v, g) if c[0] else (l[0], gi[0])
-        found, got = False, FLT_MAX
-        for i in range(4):
-            if not found and gi[i] < G and l[i] >= ub and has_member[gi[i]]:
-                found = True
-                if l[i] <= hint:
-                    got = l[i]
-        walk = not found and not (l[3] > hint)
-        if walk:
-            walked += 1
-            continue
-        decided += 1
-        assert got == want, (trial, list(lbg), list(has_member), ub, hint, l, gi, got, want)
-    assert decided > 30000 and walked > 2000, (decided, walked)
-
-
-def _med3(a, b, c):
-    return sorted([a, b, c])[1]
-
-
-def test_candidate_list_certificate_is_complete():
-    """yy_hint_list_kernel's bookkeeping: the best four packed scores per half-wave (register number in the
-    low 4 mantissa bits), tile labels tracked by value equality once per tile, the certificate "both
-    halves' fourth-best < amin and no two taken entries decode to the same centroid".  Claim: a certified
-    list is EXACTLY the set of centroids whose packed score is >= amin -- also when scores tie, which is
-    where equality-tracked labels can go wrong (and must then be caught by the duplicate test)."""
-    rs = numpy.random.RandomState(99)
-    certified = refused = 0
-    for trial in range(6000):
-        ntiles = int(rs.randint(1, 5))
-        K = 32 * ntiles
-        if trial % 3 == 0:
-            raw = rs.choice(numpy.array([-2.0, -1.0, -0.5, 0.25, 0.5, 1.0], numpy.float32), K)   # ties galore
-        else:
-            raw = (rs.randn(K) * (0.2 if trial % 3 == 1 else 2.0)).astype(numpy.float32)
-        raw[rs.rand(K) < 0.05] = -numpy.inf                                                     # padding / NaN centroids
-        amin = F(rs.choice([-3.0, -0.75, 0.0, 0.3, 0.75, 1.5]) if trial % 2 else numpy.sort(raw)[-int(rs.randint(1, 7))])
-        packed_of = numpy.empty(K, numpy.float32)
-        lists = []
-        for half in (0, 1):
-            v = [F(-numpy.inf)] * 4
-            t = [0] * 4
-            for tile in range(ntiles):
-                o = list(v)
-                for r in range(16):
-                    c = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * half
-                    bits = (numpy.array([raw[c]], numpy.float32).view(numpy.uint32)[0] & numpy.uint32(0xFFFFFFF0)) | numpy.uint32(r)
-                    x = numpy.array([bits], numpy.uint32).view(numpy.float32)[0]
-                    if numpy.isnan(x):          # -inf packs into a NaN pattern: v_med3 / v_max ignore it
-                        packed_of[c] = -numpy.inf
-                        continue
-                    packed_of[c] = x
-                    v[3] = _med3(v[2], v[3], x)
-                    v[2] = _med3(v[1], v[2], x)
-                    v[1] = _med3(v[0], v[1], x)
-                    v[0] = max(v[0], x)
-                t = [t[o.index(v[i])] if v[i] in o else tile for i in range(4)]
-            lists.append((v, t, half))
-        taken, ok = [], True
-        for v, t, half in lists:
-            ok = ok and bool(v[3] < amin)
-            for i in range(4):
-                if v[i] >= amin:
-                    r = int(numpy.array([v[i]], numpy.float32).view(numpy.uint32)[0] & 15)
-                    c = t[i] * 32 + (r & 3) + 8 * (r >> 2) + 4 * half
-                    if c in taken:
-                        ok = False
-                    taken.append(c)
-        want = set(int(c) for c in range(K) if packed_of[c] >= amin)
-        if not ok:
-            refused += 1
-            continue
-        certified += 1
-        assert set(taken) == want and len(taken) == len(want), (trial, amin, sorted(taken), sorted(want))
-    assert certified > 1500 and refused > 1000, (certified, refused)
