@@ -397,6 +397,14 @@ __global__ __launch_bounds__(256, 2) void yy_init_mfma_kernel(YyArgs a) {
       insert(pv1, pc1);
       insert(pv2, pc2);
       insert(pv3, 0xFFFFFFFFu);
+      // Both lanes of a (col, col + 32) pair must now hold the SAME contenders: they evaluate one exact
+      // chain between them (lower half: features [0, NK), upper half: the rest).  The merge above keeps a
+      // lane's own entry ahead of an EQUAL score from the partner, so on an exact tie of two approximate
+      // scores the two lanes disagreed on which centroid is first -- and the chain came out as the first
+      // half of one centroid's distance and the second half of the other's (found by the 1M-row parity
+      // test, tests/test_gpu_scale.py: 2 bounds in 1e8).  The lower half-wave's view wins.
+      v1 = __shfl(v1, col); v2 = __shfl(v2, col); v3 = __shfl(v3, col);
+      c1 = __shfl(c1, col); c2 = __shfl(c2, col);
     }
     const bool has1 = live && c1 != 0xFFFFFFFFu;
     const bool sure1 = has1 && ((v1 - v2) > thr);                      // NaN gap => not sure
