@@ -78,7 +78,40 @@ def test_c_abi_validation_codes_without_gpu():
 
 def test_reference_module_name():
     """`from libKMCUDA import kmeans_cuda, knn_cuda, supports_fp16` (test.py:8) works."""
+    from libKMCUDA import kmeans_cuda, knn_cuda, supports_fp16
+    assert callable(kmeans_cuda) and callable(knn_cuda) and supports_fp16 is True
+
+
+def test_native_cpython_module_in_the_library():
+    """`libKMCUDA` as a CPython extension module inside libKMCUDA.so (PyInit_libKMCUDA, reference
+    python.cc:32-55): importable through the import machinery, the reference's two functions and
+    `supports_fp16`, its argument errors (python.cc:186-262) -- all before any GPU is touched -- and no
+    undefined Python symbol in the library (a plain C program can still load it)."""
+    import subprocess
+    import numpy
     import libKMCUDA
-    from kmcuda_amd import api
-    assert libKMCUDA.kmeans_cuda is api.kmeans_cuda and libKMCUDA.knn_cuda is api.knn_cuda
+    assert type(libKMCUDA.kmeans_cuda).__name__ == "builtin_function_or_method"
+    assert type(libKMCUDA.knn_cuda).__name__ == "builtin_function_or_method"
     assert libKMCUDA.supports_fp16 is True
+    x = numpy.random.RandomState(0).rand(100, 4).astype(numpy.float32)
+    with pytest.raises(TypeError):
+        libKMCUDA.kmeans_cuda(x, "bullshit", init="random")
+    with pytest.raises(ValueError):
+        libKMCUDA.kmeans_cuda(x, 50, init="bullshit")
+    with pytest.raises(ValueError):
+        libKMCUDA.kmeans_cuda(x, 1)
+    with pytest.raises(TypeError):
+        libKMCUDA.kmeans_cuda(x.astype(numpy.float64), 5)
+    with pytest.raises(ValueError):
+        libKMCUDA.kmeans_cuda(x, 5, metric="zzz")
+    with pytest.raises(ValueError):
+        libKMCUDA.kmeans_cuda((0, 0, (100, 4)), 5)            # null pointer
+    with pytest.raises(ValueError):
+        libKMCUDA.kmeans_cuda((1, 0, (100, 4), 2), 5)         # tuple of length 4
+    with pytest.raises(ValueError):
+        libKMCUDA.knn_cuda(0, x, x[:5], numpy.zeros(100, numpy.uint32))
+    with pytest.raises(ValueError):
+        libKMCUDA.knn_cuda(3, x, x[:5, :3], numpy.zeros(100, numpy.uint32))
+    from kmcuda_amd import _lib
+    syms = subprocess.check_output(["nm", "-D", "--undefined-only", _lib.LIB_PATH]).decode()
+    assert not [l for l in syms.splitlines() if " Py" in l or "_Py" in l]

@@ -429,3 +429,32 @@ def test_kmeanspp_device_chooser_equals_host(monkeypatch, case):
         res.append((c.copy(), a.copy()))
     assert numpy.array_equal(res[0][0], res[1][0], equal_nan=True)   # after one update: same seeds
     assert (res[0][1] == res[1][1]).all()
+
+
+def test_native_module_equals_ctypes_mirror(fixture13k):
+    """The CPython module inside libKMCUDA.so (`import libKMCUDA`, python.cc's counterpart) against the
+    ctypes mirror: same centroids / assignments / average distance, result arrays referenced by the caller
+    alone (test.py:214-216 checks sys.getrefcount == 2), samples untouched; k-NN through both."""
+    import sys
+    import libKMCUDA
+    from kmcuda_amd import kmeans_cuda, knn_cuda
+    c0, a0, d0 = kmeans_cuda(fixture13k, 50, init="random", device=1, seed=3, tolerance=0.05, yinyang_t=0,
+                             average_distance=True)
+    before = sys.getrefcount(fixture13k)
+    c1, a1, d1 = libKMCUDA.kmeans_cuda(fixture13k, 50, init="random", device=1, seed=3, tolerance=0.05, yinyang_t=0,
+                                       average_distance=True)
+    assert sys.getrefcount(c1) == 2 and sys.getrefcount(a1) == 2 and sys.getrefcount(fixture13k) == before
+    assert c1.dtype == numpy.float32 and a1.dtype == numpy.uint32 and c1.shape == (50, 2) and a1.shape == (13000,)
+    assert numpy.array_equal(c0, c1, equal_nan=True) and (a0 == a1).all() and d0 == d1
+    n0 = knn_cuda(10, fixture13k, c0, a0, device=1)
+    n1 = libKMCUDA.knn_cuda(10, fixture13k, c1, a1, device=1)
+    assert sys.getrefcount(n1) == 2 and n1.shape == (13000, 10) and (n0 == n1).all()
+    h0, ha0 = kmeans_cuda(fixture13k.astype(numpy.float16), 50, init="kmeans++", device=1, seed=3, tolerance=0.05,
+                          yinyang_t=0)
+    h1, ha1 = libKMCUDA.kmeans_cuda(fixture13k.astype(numpy.float16), 50, init="kmeans++", device=1, seed=3,
+                                    tolerance=0.05, yinyang_t=0)
+    assert h1.dtype == numpy.float16 and numpy.array_equal(h0, h1, equal_nan=True) and (ha0 == ha1).all()
+    imp = c0.copy()
+    i0, ia0 = kmeans_cuda(fixture13k, 50, init=imp, device=1, tolerance=0.02, yinyang_t=0)
+    i1, ia1 = libKMCUDA.kmeans_cuda(fixture13k, 50, init=imp, device=1, tolerance=0.02, yinyang_t=0)
+    assert numpy.array_equal(i0, i1, equal_nan=True) and (ia0 == ia1).all()
