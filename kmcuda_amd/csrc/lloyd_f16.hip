@@ -1052,9 +1052,11 @@ static hipError_t launch_refine_dp(const LloydArgs &a, const void *rows, bool ha
   if constexpr (DP > 256) {
     return launch_refine_dp_n<DP, 1>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, rows_hint, st);
   } else if constexpr (DP >= 64) {
-    // a short list (an 8-GPU shard's: ~70k rows) in 256-row blocks is one block per CU, one wave per SIMD,
-    // and the kernel's gather / contender phases are latency: 128-row blocks put two on every CU
-    if (rows_hint != 0xFFFFFFFFu && rows_hint < 256u * 512u)
+    // a short list in 256-row blocks is one block per CU, one wave per SIMD, and the kernel's gather /
+    // contender phases are latency: 128-row blocks put two on every CU -- while they all fit in ONE round
+    // of 512 resident blocks.  Beyond that (an 8-GPU shard's ~70k rows: 547 blocks, the second round
+    // nearly empty, 0.10 ms) a single round of 256-row blocks is faster again
+    if (rows_hint != 0xFFFFFFFFu && rows_hint <= 128u * 500u)
       return launch_refine_dp_n<DP, 1>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, rows_hint, st);
     return launch_refine_dp_n<DP, 2>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, rows_hint, st);
   } else {
