@@ -240,6 +240,11 @@ static void fill_yy_args(Engine &e, YyArgs &a, const float *samples, const float
 int Engine::yy_init(const float *samples, const float *centroids, const uint32_t *assignments, float *bounds) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   if (N_ == 0) return kSuccess;
+  if (strict_h2_) {
+    KMX_HIP(launch_h2_yy_init(metric_, samples, N_, D_, K_, G_, centroids, assignments, groups_, bounds, stream_),
+            kRuntimeError);
+    return kSuccess;
+  }
   if (DP_ && DP_ <= 256 && !yy_exact_) {
     int rc = prepare_centroids(centroids);
     if (rc) return rc;
@@ -263,6 +268,11 @@ int Engine::yy_init(const float *samples, const float *centroids, const uint32_t
 
 int Engine::yy_drifts(const float *centroids, float *drifts, float *gdrifts) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  if (strict_h2_) {   // the per-centroid drifts in half2 arithmetic; the group maxima are plain fp32 compares
+    KMX_HIP(launch_h2_yy_drifts(metric_, centroids, K_, D_, drifts, stream_), kRuntimeError);
+    KMX_HIP(launch_yy_group_max(K_, D_, G_, groups_, drifts, gdrifts, stream_), kRuntimeError);
+    return kSuccess;
+  }
   KMX_HIP(launch_yy_drifts(metric_, centroids, K_, D_, G_, groups_, drifts, gdrifts, stream_), kRuntimeError);
   return kSuccess;
 }
@@ -271,6 +281,15 @@ int Engine::yy_filters(const float *samples, const float *centroids, const float
                        uint32_t *assignments, uint32_t *assignments_prev, float *bounds, uint32_t *passed) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   if (N_ == 0) return kSuccess;
+  if (strict_h2_) {
+    KMX_HIP(launch_h2_yy_global(metric_, samples, N_, D_, K_, G_, centroids, drifts, gdrifts, assignments,
+                                assignments_prev, bounds, passed, counters_, stream_),
+            kRuntimeError);
+    KMX_HIP(launch_h2_yy_local(metric_, samples, N_, D_, K_, G_, passed, centroids, groups_, drifts, gdrifts,
+                               assignments, bounds, counters_, stream_),
+            kRuntimeError);
+    return kSuccess;
+  }
   KMX_HIP(launch_yy_global_filter(metric_, samples, N_, D_, K_, G_, centroids, drifts, gdrifts, assignments,
                                   assignments_prev, bounds, passed, counters_, stream_),
           kRuntimeError);
@@ -311,6 +330,19 @@ int Engine::yy_filters(const float *samples, const float *centroids, const float
 int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t *assignments,
                          uint32_t *assignments_prev, bool exact_only) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  if (strict_h2_) {
+    if (!h2_sq_) {
+      int rc = alloc(&h2_sq_, 2 * (size_t)K_);
+      if (rc) return rc;
+    }
+    span_begin(1);
+    KMX_HIP(launch_h2_csqr(metric_, centroids, K_, D_, h2_sq_, stream_), kRuntimeError);
+    KMX_HIP(launch_h2_assign(metric_, samples, N_, D_, centroids, K_, h2_sq_, assignments, assignments_prev, counters_,
+                             stream_),
+            kRuntimeError);
+    span_end();
+    return kSuccess;
+  }
   // row cache (two-stage f16 filter only): x - mu as halves in operand order, built on the first pass
   // after set_row_cache(1); mu is frozen from then on, so the copy stays valid for every later pass
   const bool two_stage = !exact_only && DP_ != 0 && filter_mode_ == 0 && lloyd_filter_f16_supported(D_, DP_);
@@ -453,6 +485,10 @@ int Engine::apply_delta(const double *delta, const int32_t *dcount, const double
 int Engine::adjust_exact(const float *samples, const uint32_t *prev, const uint32_t *cur, float *centroids,
                          uint32_t *ccounts) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  if (strict_h2_) {
+    KMX_HIP(launch_h2_adjust(metric_, samples, N_, D_, K_, prev, cur, centroids, ccounts, stream_), kRuntimeError);
+    return kSuccess;
+  }
   if (2ull * N_ >= 0xFFFFFFFFull) return kInvalidArguments;
   if ((size_t)D_ * 64 * sizeof(float) > 128 * 1024 && !exact_work_) {
     int rc = alloc(&exact_work_, (size_t)((K_ + 63) / 64) * 64 * D_);

@@ -76,6 +76,10 @@ class Engine {
   hipEvent_t ev_rows_ = nullptr;        // csqr / ct ready on the side stream (steady-state preparation)
   uint32_t N_ = 0, D_ = 0, K_ = 0, K_pad_ = 0, Kt_ = 0, DP_ = 0;
   int metric_ = 0, fp16x2_ = 0;
+  // KMCUDA_AMD_FP16_STRICT (set by kmeans_cuda for an fp16x2 job): every step in the reference's half2
+  // arithmetic (half2_strict.hip) instead of the fp32 arithmetic on the half values
+  bool strict_h2_ = false;
+  float *h2_sq_ = nullptr;   // K x 2 half2 squared norms
   float eps_ = 0, tie_slack_ = 0;
 
   // assignment workspace

@@ -128,6 +128,8 @@ hipError_t launch_member_distances(int metric, const float *samples, uint32_t N,
 hipError_t launch_yy_init(int metric, const float *xt, uint32_t len, uint32_t D, uint32_t G, const float *centroids,
                           const uint32_t *assignments, const uint32_t *cperm, const uint32_t *gstart, float *bounds,
                           hipStream_t st);
+hipError_t launch_yy_group_max(uint32_t K, uint32_t D, uint32_t G, const uint32_t *groups, const float *drifts,
+                               float *gdrifts, hipStream_t st);
 hipError_t launch_yy_drifts(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t G,
                             const uint32_t *groups, float *drifts, float *gdrifts, hipStream_t st);
 
@@ -214,6 +216,33 @@ hipError_t launch_knn_scatter(const uint32_t *sorted_out, const uint32_t *inv, u
 hipError_t launch_half_to_float(const void *src, size_t n, float *dst, hipStream_t st);
 hipError_t launch_float_to_half(const float *src, size_t n, void *dst, hipStream_t st);
 hipError_t launch_quantize_half(float *v, size_t n, hipStream_t st);
+
+// half2_strict.hip -- the reference's half2 arithmetic (fp_abstraction.h:100-182) kernel by kernel; plain
+// thread-per-item kernels on fp32 words holding halves (KMCUDA_AMD_FP16_STRICT=1: verification mode)
+hipError_t launch_h2_csqr(int metric, const float *centroids, uint32_t K, uint32_t D, float *sq2, hipStream_t st);
+hipError_t launch_h2_assign(int metric, const float *samples, uint32_t N, uint32_t D, const float *centroids, uint32_t K,
+                            const float *sq2, uint32_t *assignments, uint32_t *assignments_prev, uint32_t *counters,
+                            hipStream_t st);
+hipError_t launch_h2_adjust(int metric, const float *samples, uint32_t N, uint32_t D, uint32_t K, const uint32_t *prev,
+                            const uint32_t *cur, float *centroids, uint32_t *ccounts, hipStream_t st);
+hipError_t launch_h2_to_row(int metric, const float *samples, uint32_t N, uint32_t D, const float *row, uint32_t cc,
+                            int mode /* 0 k-means++ step, 1 squared distance */, float *dists, hipStream_t st);
+hipError_t launch_h2_member(int metric, const float *samples, uint32_t N, uint32_t D, const float *centroids,
+                            const uint32_t *assignments, uint32_t K, float *dists, hipStream_t st);
+hipError_t launch_h2_afk_min_dist(int metric, uint32_t m, uint32_t k, const float *samples, uint32_t D,
+                                  const uint32_t *choices, const float *centroids, float *min_dists, hipStream_t st);
+hipError_t launch_h2_yy_init(int metric, const float *samples, uint32_t len, uint32_t D, uint32_t K, uint32_t G,
+                             const float *centroids, const uint32_t *assignments, const uint32_t *groups, float *bounds,
+                             hipStream_t st);
+hipError_t launch_h2_yy_drifts(int metric, const float *centroids, uint32_t K, uint32_t D, float *drifts, hipStream_t st);
+hipError_t launch_h2_yy_global(int metric, const float *samples, uint32_t len, uint32_t D, uint32_t K, uint32_t G,
+                               const float *centroids, const float *drifts, const float *gdrifts,
+                               const uint32_t *assignments, uint32_t *assignments_prev, float *bounds, uint32_t *passed,
+                               uint32_t *counters, hipStream_t st);
+hipError_t launch_h2_yy_local(int metric, const float *samples, uint32_t len, uint32_t D, uint32_t K, uint32_t G,
+                              const uint32_t *passed, const float *centroids, const uint32_t *groups, const float *drifts,
+                              const float *gdrifts, uint32_t *assignments, float *bounds, uint32_t *counters,
+                              hipStream_t st);
 
 // transpose.hip (reference: transpose.cu:16-54)
 hipError_t launch_transpose(const float *in, uint32_t rows, uint32_t cols, float *out, hipStream_t st);

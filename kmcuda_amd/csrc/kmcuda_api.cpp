@@ -176,6 +176,9 @@ class Job {
   uint32_t N = 0, D = 0, K = 0;
   int metric = 0, verbosity = 0;
   bool fp16 = false;  // fp16x2 boundary: half buffers outside, fp32 arithmetic on the half values inside
+  // KMCUDA_AMD_FP16_STRICT=1 (fp16x2 jobs, one GPU): every step in the reference's half2 ARITHMETIC
+  // (half2_strict.hip) -- the verification mode the oracle's half2 restatement is compared with
+  bool strict_h2 = false;
   std::vector<std::unique_ptr<Shard>> shards;
   Rccl rccl;
   std::vector<void *> comms;
@@ -200,6 +203,7 @@ class Job {
       sh->eng = std::make_unique<Engine>();
       int rc = sh->eng->init(sh->dev, sh->length, D, K, metric, 0, nullptr);
       if (rc) return rc;
+      sh->eng->strict_h2_ = strict_h2;
       const float *src = samples + (size_t)sh->offset * D;
       if (fp16) {
         // `samples` holds halves: stage the raw halves on the device, widen into the fp32 working copy
@@ -397,7 +401,7 @@ class Job {
         // holds a NaN / inf distance) takes the host way.
         float *host_dists = nullptr;
         struct HostFree { float **p; ~HostFree() { if (*p) (void)hipHostFree(*p); } } host_dists_guard{&host_dists};
-        const bool device_chooser = shards.size() == 1 && getenv("KMCUDA_AMD_KMPP_HOST") == nullptr;
+        const bool device_chooser = shards.size() == 1 && !strict_h2 && getenv("KMCUDA_AMD_KMPP_HOST") == nullptr;
         struct Totals { double sum_g, sum_d; uint32_t emin, emax, bad, chosen; };
         Totals *totals_host = nullptr;
         struct TotalsFree { Totals **p; ~TotalsFree() { if (*p) (void)hipHostFree(*p); } } totals_guard{&totals_host};
@@ -456,9 +460,12 @@ class Job {
           } else {
             for (auto &s : shards) {
               (void)hipSetDevice(s->dev);
-              if (launch_kmpp_step(metric, s->samples, s->length, D, s->centroids + (size_t)(i - 1) * D, i, s->dists,
-                                   s->eng->stream_) != hipSuccess)
-                return kmcudaRuntimeError;
+              const hipError_t ke = strict_h2
+                  ? launch_h2_to_row(metric, s->samples, s->length, D, s->centroids + (size_t)(i - 1) * D, i, 0, s->dists,
+                                     s->eng->stream_)
+                  : launch_kmpp_step(metric, s->samples, s->length, D, s->centroids + (size_t)(i - 1) * D, i, s->dists,
+                                     s->eng->stream_);
+              if (ke != hipSuccess) return kmcudaRuntimeError;
             }
           }
           if (!chosen) {   // the reference's way, on the host
@@ -550,7 +557,8 @@ class Job {
         std::vector<uint32_t> cand_ind(m);
         // q(x) = 1 / 2N + d(x, c1)^2 / (2 sum d^2), with c1 = sample (first_index / D): the reference
         // seeds q from THAT sample while centroid 0 is sample first_index (kmcuda.cc:356-362)
-        if (launch_afk_qdist(metric, all, N, D, all + (size_t)(first_index / D) * D, qdev, st) != hipSuccess)
+        if ((strict_h2 ? launch_h2_to_row(metric, all, N, D, all + (size_t)(first_index / D) * D, 0, 1, qdev, st)
+                       : launch_afk_qdist(metric, all, N, D, all + (size_t)(first_index / D) * D, qdev, st)) != hipSuccess)
           return kmcudaRuntimeError;
         if (hipMemcpyAsync(q.data(), qdev, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess)
@@ -568,7 +576,8 @@ class Job {
           }
           (void)hipSetDevice(s0.dev);
           if (launch_afk_random_step(m, seed, k, qdev, N, choice_dev, rand_dev, st) != hipSuccess ||
-              launch_afk_min_dist(metric, m, k, all, D, choice_dev, s0.centroids, mind_dev, st) != hipSuccess)
+              (strict_h2 ? launch_h2_afk_min_dist(metric, m, k, all, D, choice_dev, s0.centroids, mind_dev, st)
+                         : launch_afk_min_dist(metric, m, k, all, D, choice_dev, s0.centroids, mind_dev, st)) != hipSuccess)
             return kmcudaRuntimeError;
           if (hipMemcpyAsync(cand_ind.data(), choice_dev, m * sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
               hipMemcpyAsync(rand_a.data(), rand_dev, m * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -788,6 +797,7 @@ class Job {
     Shard &first = *shards[0];
     RETERR(first.eng->sync());
     Job gjob;
+    gjob.strict_h2 = strict_h2;   // (before setup: the engines take the flag there)
     std::vector<int> one{first.dev};
     RETERR(gjob.setup(one, 0, K, D, G, metric, verbosity, first.centroids, first.dev));  // fp32 replica in place
     gjob.exact_update = exact_update;
@@ -909,8 +919,10 @@ class Job {
     std::vector<float> host(N);
     for (auto &s : shards) {
       (void)hipSetDevice(s->dev);
-      if (launch_member_distances(metric, s->samples, s->length, D, s->centroids, s->assignments, K, s->dists,
-                                  s->eng->stream_) != hipSuccess)
+      if ((strict_h2 ? launch_h2_member(metric, s->samples, s->length, D, s->centroids, s->assignments, K, s->dists,
+                                        s->eng->stream_)
+                     : launch_member_distances(metric, s->samples, s->length, D, s->centroids, s->assignments, K, s->dists,
+                                               s->eng->stream_)) != hipSuccess)
         return kmcudaRuntimeError;
       if (hipMemcpyAsync(host.data() + s->offset, s->dists, (size_t)s->length * sizeof(float), hipMemcpyDeviceToHost,
                          s->eng->stream_) != hipSuccess)
@@ -1296,11 +1308,13 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
   g_last_run = RunStats();
   Job job;
   job.fp16 = fp16x2 != 0;
+  if (const char *v = getenv("KMCUDA_AMD_FP16_STRICT")) job.strict_h2 = job.fp16 && atoi(v) != 0;
   // fp16x2: features_size counts half2 pairs (kmcuda.h:107-108); internally one feature per half
   const uint32_t feats = fp16x2 ? 2u * features_size : features_size;
   RETERR(job.setup(devs, virtual_shards(), samples_size, feats, clusters_size, metric, verbosity, samples,
                    device_ptrs));
   if (const char *v = getenv("KMCUDA_AMD_EXACT_UPDATE")) job.exact_update = atoi(v) != 0;
+  if (job.strict_h2) job.exact_update = true;   // the reference's serial update, in half2 arithmetic
   if (job.exact_update && job.shards.size() > 1) {
     INFO("KMCUDA_AMD_EXACT_UPDATE needs all rows on one GPU (the reference's update order is global)\n");
     return kmcudaInvalidArguments;

@@ -306,12 +306,17 @@ hipError_t launch_yy_init(int metric, const float *xt, uint32_t len, uint32_t D,
   return hipGetLastError();
 }
 
-hipError_t launch_yy_drifts(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t G,
-                            const uint32_t *groups, float *drifts, float *gdrifts, hipStream_t st) {
-  KMX_DISPATCH(metric, yy_calc_drifts_kernel, dim3((K + 63) / 64), dim3(64), st, centroids, K, D, drifts);
+hipError_t launch_yy_group_max(uint32_t K, uint32_t D, uint32_t G, const uint32_t *groups, const float *drifts,
+                               float *gdrifts, hipStream_t st) {
   hipLaunchKernelGGL(yy_group_max_drifts_kernel, dim3((G + 63) / 64), dim3(64), 0, st, groups, K, D, G, drifts,
                      gdrifts);
   return hipGetLastError();
+}
+
+hipError_t launch_yy_drifts(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t G,
+                            const uint32_t *groups, float *drifts, float *gdrifts, hipStream_t st) {
+  KMX_DISPATCH(metric, yy_calc_drifts_kernel, dim3((K + 63) / 64), dim3(64), st, centroids, K, D, drifts);
+  return launch_yy_group_max(K, D, G, groups, drifts, gdrifts, st);
 }
 
 hipError_t launch_yy_global_filter(int metric, const float *samples, uint32_t len, uint32_t D, uint32_t K, uint32_t G,

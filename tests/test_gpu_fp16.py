@@ -194,3 +194,64 @@ def test_f16_matrix_core_filter_bit_exact(n, d, k, metric):
     assert (got16 == ref).all() and (got32 == ref).all()
     assert c16[0] == ref_changed
     assert c16[1] + c16[3] < 0.2 * n     # the filter itself decides the bulk of the rows
+
+
+# ---- KMCUDA_AMD_FP16_STRICT=1: the reference's half2 ARITHMETIC on the GPU (half2_strict.hip) ----
+@pytest.mark.parametrize("kw,pin", [
+    (dict(init="random", tolerance=0.05, yinyang_t=0), 7),           # test.py:468-485
+    (dict(init="kmeans++", tolerance=0.05, yinyang_t=0), 5),         # test.py:487-497
+    (dict(init="afkmc2", tolerance=0.05, yinyang_t=0), 4),           # test.py:499-509
+    (dict(init="kmeans++", tolerance=0.01, yinyang_t=0.1), 16 + 7),  # test.py:523-533
+])
+def test_fp16_strict_reproduces_the_reference_pins(fixture13k, monkeypatch, kw, pin):
+    """The reference's fp16 known answers through the boundary in strict mode -- including the 16 + 7 the
+    default fp16 semantics miss -- and, beyond the iteration count, the WHOLE run equal to the oracle's
+    half2 restatement: the per-iteration reassignment counts, every assignment, every centroid half."""
+    from kmcuda_amd import kmeans_cuda
+    monkeypatch.setenv("KMCUDA_AMD_FP16_STRICT", "1")
+    samples = fixture13k.astype(numpy.float16)
+    out = StdoutListener()
+    with out:
+        centroids, assignments = kmeans_cuda(samples, 50, device=1, verbosity=2, seed=3, **kw)
+    assert out.iterations() == pin
+    assert centroids.dtype == numpy.float16
+    ref_c, ref_a, ref_log = oracle.kmeans(samples, 50, seed=3, half2=True, **kw)
+    got_log = [int(l.split()[2]) for l in out.text.split("\n") if l.startswith("iteration")]
+    assert got_log == [int(v) for v in ref_log]
+    assert (assignments == ref_a).all()
+    assert numpy.array_equal(centroids.view(numpy.uint16), ref_c.view(numpy.uint16))
+
+
+def test_fp16_strict_cosine(monkeypatch):
+    # test.py:535-560 in strict mode; acosf is libm on the oracle and ocml here: iteration pin + properties
+    from kmcuda_amd import kmeans_cuda
+    from sklearn.metrics.pairwise import cosine_distances
+    monkeypatch.setenv("KMCUDA_AMD_FP16_STRICT", "1")
+    numpy.random.seed(0)
+    arr = numpy.empty((10000, 2), dtype=numpy.float16)
+    angs = numpy.random.rand(10000) * 2 * numpy.pi
+    for i in range(10000):
+        arr[i] = numpy.sin(angs[i]), numpy.cos(angs[i])
+    out = StdoutListener()
+    with out:
+        centroids, assignments = kmeans_cuda(arr, 4, init="kmeans++", metric="cos", device=1, verbosity=2, seed=3)
+    assert out.iterations() == 5
+    for c in centroids.astype(numpy.float32):
+        assert 0.9995 < numpy.linalg.norm(c) < 1.0005
+    d = numpy.round(cosine_distances(centroids.astype(numpy.float32))).astype(int)
+    assert sorted(map(tuple, d.tolist())) == sorted([(0, 2, 1, 1), (2, 0, 1, 1), (1, 1, 0, 2), (1, 1, 2, 0)])
+
+
+def test_fp16_strict_wider_rows_equal_the_half2_oracle(monkeypatch):
+    """D = 64 halves (32 half2 pairs per row: the interleaved accumulators actually interleave), L2 and
+    angular, Lloyd with average distance: assignments and centroids equal to the half2 oracle."""
+    from kmcuda_amd import kmeans_cuda
+    monkeypatch.setenv("KMCUDA_AMD_FP16_STRICT", "1")
+    rs = numpy.random.RandomState(8)
+    x = (rs.rand(4000, 64) * 2 - 0.5).astype(numpy.float16)
+    c, a, avg = kmeans_cuda(x, 20, init="random", seed=5, tolerance=0.01, yinyang_t=0, device=1, average_distance=True)
+    rc, ra, rlog, ravg = oracle.kmeans(x, 20, init="random", seed=5, tolerance=0.01, yinyang_t=0, half2=True,
+                                       average_distance=True)
+    assert (a == ra).all()
+    assert numpy.array_equal(c.view(numpy.uint16), rc.view(numpy.uint16))
+    assert abs(avg - ravg) < 1e-6 * max(1.0, abs(ravg))
