@@ -410,6 +410,7 @@ def main():
             out["cpu_baseline_sklearn"] = sklearn_baseline(D, K)
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()   # rank 0 may still have been verifying / timing the CPU baseline: leave together
         dist.destroy_process_group()
 
 

@@ -13,9 +13,12 @@ typedef float f32x4_es __attribute__((ext_vector_type(4)));
 // four round-down FMAs of a feature share one rounding-mode window (exact.hpp).  Rolled loops: the
 // function is instantiated at several call sites and must stay small.
 // metric_abstraction.h:73-86 (L2 distance_t) / :193-205 (angular).
+// nq (wave-uniform, 1..4): only the first nq candidate rows are real -- the others are neither loaded nor
+// meaningful (their dist[] is garbage).  The gathers, not the arithmetic, bound this path: a flush whose
+// fullest queue holds two candidates issues three loads per step instead of five.
 template <int NK, int METRIC, bool FAST>
 __device__ __forceinline__ void exact_distance4(const float *__restrict__ xrow, const float *const (&crow)[4],
-                                                uint32_t D, int h, int col, float (&dist)[4]) {
+                                                uint32_t D, int h, int col, float (&dist)[4], int nq = 4) {
   float acc[4] = {0.f, 0.f, 0.f, 0.f}, corr[4] = {0.f, 0.f, 0.f, 0.f};
   const int nvalid = (int)D - h * NK < 0 ? 0 : ((int)D - h * NK > NK ? NK : (int)D - h * NK);
   for (int pass = 0; pass < 2; pass++) {
@@ -38,7 +41,8 @@ __device__ __forceinline__ void exact_distance4(const float *__restrict__ xrow, 
           xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
 #pragma unroll
           for (int i = 0; i < 4; i++) {
-            const f32x4_es v = *reinterpret_cast<const f32x4_es *>(crow[i] + h * NK + j);
+            f32x4_es v = {0.f, 0.f, 0.f, 0.f};
+            if (i < nq) v = *reinterpret_cast<const f32x4_es *>(crow[i] + h * NK + j);   // nq: scalar
             cv[i][0] = v.x; cv[i][1] = v.y; cv[i][2] = v.z; cv[i][3] = v.w;
           }
         } else {

@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256, 2) void knn_filter_f16_kernel(KnnArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; i++) crow[i] = a.xs + (size_t)(i < qn_ ? qc[i] : 0) * DP;
     float dist[4];
-    exact_distance4<NKH, METRIC, FASTX>(xrow, crow, D, h, col, dist);
+    const int nq = __ballot(qn_ >= 4) ? 4 : (__ballot(qn_ >= 3) ? 3 : (__ballot(qn_ >= 2) ? 2 : 1));
+    exact_distance4<NKH, METRIC, FASTX>(xrow, crow, D, h, col, dist, nq);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       if (h == 0 && i < qn_ && dist[i] <= mndist) {  // knn.cu:209-212

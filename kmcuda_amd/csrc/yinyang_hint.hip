@@ -378,7 +378,9 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; i++) crow[i] = a.centroids + (size_t)(i < qn ? qc[i] : 0) * D;
     float dist[4];
-    exact_distance4<NK, METRIC, FAST>(xrow, crow, D, h, col, dist);
+    // the fullest queue of the wave sets how many candidate rows are gathered (a row has 0.2 - 2 real ones)
+    const int nq = __ballot(qn >= 4) ? 4 : (__ballot(qn >= 3) ? 3 : (__ballot(qn >= 2) ? 2 : 1));
+    exact_distance4<NK, METRIC, FAST>(xrow, crow, D, h, col, dist, nq);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       if (i < qn) {
