@@ -178,6 +178,11 @@ hipError_t launch_yy_local_filter(int metric, const float *samples, uint32_t len
                                   uint32_t *counters, hipStream_t st);
 
 // knn.hip (reference: knn.cu)
+// queries (consecutive sorted positions of one cluster) per block: f32 filter 4 waves, f16 filter 8 waves
+#define KNN16_WAVES 8
+#define KNN16_NBUF 4        // LDS ring of candidate tiles (knn_f16.hip)
+#define KNN16_PAD_ROWS 64   // rows of xs16 / entries of kbias the caller allocates (and the split zeroes) past N
+constexpr uint32_t KNN_QPB_F32 = 128, KNN_QPB_F16 = KNN16_WAVES * 32;
 struct KnnArgs {
   const float *xs;          // N x DP cluster-sorted rows (zero padded to DP)
   const float *n2s;         // N plain squared norms of the sorted rows
@@ -185,15 +190,16 @@ struct KnnArgs {
   const uint32_t *offsets;  // K+1: cluster c occupies positions [offsets[c], offsets[c+1])
   const float *mydist;      // N: exact distance of each sorted row to its own centroid
   const float *R, *C;       // K radii, K x K centroid distances
-  const uint32_t *blocks;   // (cluster, first position) per 128-query block
+  const uint32_t *blocks;   // (cluster, first position) per block of KNN_QPB_* queries
   const uint32_t *stats;    // [0] max squared norm bits
   uint32_t N, D, DP, K, k;
   uint32_t p_base, p_end;   // this launch covers sorted positions [p_base, p_end)
   float eps;
   // f16 matrix-core filter (knn_f16.hip): centred hi/lo-split rows; n2s then holds the CENTRED squared
   // norms, mux[p] = mu.(x_p - mu), mu2 = ||mu||^2
-  const void *xs16;
+  const void *xs16;         // (N + KNN16_PAD_ROWS) x DP halves
   const float *mux;
+  const float *kbias;       // N + KNN16_PAD_ROWS: -0.5 * centred squared norm (L2) / mu.(x - mu) (angular)
   float mu2;
   float *heaps;             // (p_end - p_base) x 2k
   uint32_t *out;            // (p_end - p_base) x k, sorted-position order
@@ -207,7 +213,7 @@ hipError_t launch_knn_prep(int metric, const float *xs, uint32_t N, uint32_t D, 
 hipError_t launch_knn_filter(int metric, const KnnArgs &a, uint32_t nblocks, hipStream_t st);
 hipError_t launch_knn_exact(int metric, const KnnArgs &a, hipStream_t st);
 hipError_t launch_knn_split(int metric, const float *xs, uint32_t N, uint32_t D, uint32_t DP, const float *mu,
-                            void *xs16, float *n2c, float *mux, uint32_t *stats, hipStream_t st);
+                            void *xs16, float *n2c, float *mux, float *kbias, uint32_t *stats, hipStream_t st);
 hipError_t launch_knn_filter_f16(int metric, const KnnArgs &a, uint32_t nblocks, hipStream_t st);
 hipError_t launch_knn_scatter(const uint32_t *sorted_out, const uint32_t *inv, uint32_t p_base, uint32_t p_end,
                               uint32_t k, uint32_t *neighbors, hipStream_t st);

@@ -948,7 +948,7 @@ struct KnnShard {
   const float *samples = nullptr, *centroids = nullptr;
   const uint32_t *assignments = nullptr;
   float *xs = nullptr, *n2s = nullptr, *mydist = nullptr, *rdist = nullptr, *R = nullptr, *C = nullptr, *heaps = nullptr;
-  float *mu = nullptr, *mux = nullptr;
+  float *mu = nullptr, *mux = nullptr, *kbias = nullptr;
   uint16_t *xs16 = nullptr;
   uint32_t *inv = nullptr, *offsets = nullptr, *keys_tmp = nullptr, *vals_tmp = nullptr, *keys_sorted = nullptr,
            *stats = nullptr, *blocks = nullptr, *out = nullptr;
@@ -1103,7 +1103,8 @@ class KnnJob {
       if ((rc = sh->alloc(&sh->stats, 4))) return rc;
       if ((rc = sh->alloc(&sh->calced, 1))) return rc;
       if (use_f16) {
-        if ((rc = sh->alloc(&sh->xs16, (size_t)N * DP))) return rc;
+        if ((rc = sh->alloc(&sh->xs16, ((size_t)N + KNN16_PAD_ROWS) * DP))) return rc;
+        if ((rc = sh->alloc(&sh->kbias, (size_t)N + KNN16_PAD_ROWS))) return rc;
         if ((rc = sh->alloc(&sh->mu, DP))) return rc;
         if ((rc = sh->alloc(&sh->mux, N))) return rc;
         if (hipMemcpyAsync(sh->mu, mu_host.data(), DP * sizeof(float), hipMemcpyHostToDevice, sh->stream) != hipSuccess)
@@ -1133,7 +1134,7 @@ class KnnJob {
                           s->stream) != hipSuccess)
         return kmcudaRuntimeError;
     }
-    // ---- the block list: 128 consecutive sorted positions of one cluster per block ----
+    // ---- the block list: KNN_QPB_* consecutive sorted positions of one cluster per block ----
     std::vector<uint32_t> offsets(K + 1);
     {
       KnnShard &f = *shards[0];
@@ -1143,8 +1144,9 @@ class KnnJob {
         return kmcudaMemoryCopyError;
     }
     std::vector<uint32_t> blocks;  // (cluster, first position) pairs
+    const uint32_t qpb = use_f16 ? KNN_QPB_F16 : KNN_QPB_F32;
     for (uint32_t c = 0; c < K; c++)
-      for (uint32_t p = offsets[c]; p < offsets[c + 1]; p += 128) {
+      for (uint32_t p = offsets[c]; p < offsets[c + 1]; p += qpb) {
         blocks.push_back(c);
         blocks.push_back(p);
       }
@@ -1164,7 +1166,7 @@ class KnnJob {
     if (use_f16) {  // after the radii / member distances, which read the plain norms' buffer no more
       for (auto &s : shards) {
         (void)hipSetDevice(s->dev);
-        if (launch_knn_split(metric, s->xs, N, D, DP, s->mu, s->xs16, s->n2s, s->mux, s->stats, s->stream) != hipSuccess)
+        if (launch_knn_split(metric, s->xs, N, D, DP, s->mu, s->xs16, s->n2s, s->mux, s->kbias, s->stats, s->stream) != hipSuccess)
           return kmcudaRuntimeError;
       }
     }
@@ -1187,7 +1189,7 @@ class KnnJob {
       a.p_base = s.p_base; a.p_end = s.p_end;
       a.eps = (float)(1.02 * ((double)D + 12.0) * ldexp(1.0, -24));  // as the Lloyd filter
       a.heaps = s.heaps; a.out = s.out; a.calced = s.calced;
-      a.xs16 = s.xs16; a.mux = s.mux; a.mu2 = mu2;
+      a.xs16 = s.xs16; a.mux = s.mux; a.kbias = s.kbias; a.mu2 = mu2;
       const hipError_t e = !dp_filter ? launch_knn_exact(metric, a, s.stream)
                            : use_f16 ? launch_knn_filter_f16(metric, a, s.nblocks, s.stream)
                                      : launch_knn_filter(metric, a, s.nblocks, s.stream);

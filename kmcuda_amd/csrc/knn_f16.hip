@@ -29,12 +29,30 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr float kFltMaxK = 3.402823466e+38f;
 
+// hand-issued LDS reads (raw LDS byte address) with counted waits: the compiler neither knows these reads nor
+// drains the tile DMA in front of them
+__device__ __forceinline__ f16x8 knn_frag_issue(uint32_t addr) {
+  f16x8 f;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(f) : "v"(addr) : "memory");
+  return f;
+}
+__device__ __forceinline__ f32x4 knn_lds_read4(uint32_t addr) {
+  f32x4 f;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(f) : "v"(addr) : "memory");
+  return f;
+}
+template <int N>
+__device__ __forceinline__ void knn_frag_wait(f16x8 &f) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N));
+}
+
 // one wave per sorted row: xs16 (centred halves), centred squared norm, mu.x', max norm
 template <int METRIC>
 __global__ __launch_bounds__(256) void knn_split_kernel(const float *__restrict__ xs, uint32_t N, uint32_t D,
                                                         uint32_t DP, const float *__restrict__ mu,
                                                         _Float16 *__restrict__ xs16, float *__restrict__ n2c,
-                                                        float *__restrict__ mux, uint32_t *__restrict__ stats) {
+                                                        float *__restrict__ mux, float *__restrict__ kbias,
+                                                        uint32_t *__restrict__ stats) {
   const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63;
   if (p >= N) return;
@@ -56,6 +74,7 @@ __global__ __launch_bounds__(256) void knn_split_kernel(const float *__restrict_
   if (lane == 0) {
     n2c[p] = a;
     mux[p] = b;
+    kbias[p] = METRIC == 0 ? -0.5f * a : b;   // what a candidate adds to the matrix-core score
     if ((a - a) == 0.f) atomicMax(&stats[0], __float_as_uint(a));
   }
   (void)METRIC;
@@ -94,21 +113,32 @@ __device__ __forceinline__ void knn_push_sample(uint32_t k, float dist, uint32_t
 // ~0.1 % of a typical squared distance, i.e. lets through about one more candidate per query for the
 // exact chain.  (Round 1 kept a three-product hi/lo variant as a second cross-check; the f32 matrix-core
 // filter of knn.hip and the unfiltered exact search are the two that remain.)
+// A block is KNN16_WAVES waves = KNN16_QPB queries of ONE cluster sharing every candidate tile it visits.
+// Round 2 measured the 4-wave version (128 queries per tile fetch) against the counters: 3.5 TB/s of fetch
+// traffic, waves parked 65 % of their cycles, the matrix pipe busy 26 % -- the kernel was bound by the
+// candidate fetches, not by the MFMAs, and every compute-side change (deeper prefetch, hand-issued LDS
+// reads, split accumulators) left the time unchanged.  Eight waves halve the bytes fetched per query-candidate
+// pair at the same occupancy (one 8-wave block per CU instead of two 4-wave ones).
 template <int DP, int METRIC, bool FASTX>
-__global__ __launch_bounds__(256, 2) void knn_filter_f16_kernel(KnnArgs a) {
+__global__ __launch_bounds__(KNN16_WAVES * 64, 1) void knn_filter_f16_kernel(KnnArgs a) {
+  constexpr int WV = KNN16_WAVES;
   constexpr int NKH = DP / 2;   // features per half-wave
-  constexpr int KS = NKH / 8;   // k-steps
-  constexpr int LDW = DP / 2 + 4;   // padded LDS row (4-byte words; a row = DP halves)
-  constexpr int TILE = 32 * LDW;
-  constexpr int NST = (8 * DP + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  auto tile_ptr = [&](int buf) { return lds + buf * TILE; };
-  auto bias_ptr = [&](int buf) { return lds + 2 * TILE + buf * 32; };
-  uint32_t *flags = reinterpret_cast<uint32_t *>(lds + 2 * TILE + 64);  // 2 x 4 words
+  constexpr int KS = NKH / 8;   // k-steps = 16-byte chunks per half row
+  constexpr int ROWB = DP * 2;  // bytes of one candidate row (DP halves)
+  constexpr int TILEB = 32 * ROWB;
+  constexpr int NP = (TILEB + 1023) / 1024;   // 1-KB LDS-DMA pieces per tile
+  constexpr int SWM = (KS < 16 ? KS : 16) - 1;
+  constexpr int NBUF = KNN16_NBUF;            // ring of tile buffers: NBUF - 1 tiles in flight
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds2[];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte *)lds2;
+  if (lds0 & 1023u) __builtin_trap();
+  constexpr uint32_t TILES = (uint32_t)(NBUF * (TILEB < 1024 ? 1024 : TILEB));
+  const uint32_t bias0 = lds0 + TILES;                       // NBUF x 64 floats
+  uint32_t *flags = reinterpret_cast<uint32_t *>(lds2 + TILES + NBUF * 256);  // 2 x WV words
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 31, h = lane >> 5;
   const uint32_t K = a.K, k = a.k, D = a.D;
-  const float *panel = reinterpret_cast<const float *>(a.xs16);
 
   const uint32_t cls0 = a.blocks[2 * (size_t)blockIdx.x], p0 = a.blocks[2 * (size_t)blockIdx.x + 1];
   const uint32_t own_end = a.offsets[cls0 + 1];
@@ -165,40 +195,43 @@ __global__ __launch_bounds__(256, 2) void knn_filter_f16_kernel(KnnArgs a) {
   };
   float amin = amin_of(mndist);
 
-  // pieces of 16 bytes per staged row (DP halves)
-  constexpr int RP = DP / 8;
-  constexpr int NSTG = (32 * RP + 255) / 256;
-  static_assert(NSTG <= NST, "staging registers");
-  f32x4 stage[NSTG];
-  float bstage = 0.f;
-  auto stage_load = [&](uint32_t base, uint32_t end) {  // 32 sorted rows from `base`
-    const uint32_t last = a.N - 1;
-#pragma unroll
-    for (int i = 0; i < NSTG; i++) {
-      const int q = tid + i * 256;
-      if (q < 32 * RP) {
-        const uint32_t row = base + q / RP;
-        const uint32_t rr = row <= last ? row : last;
-        stage[i] = reinterpret_cast<const f32x4 *>(panel + (size_t)rr * (DP / 2))[q % RP];
-      }
+  // A tile = 32 consecutive sorted rows = TILEB contiguous bytes of xs16, copied by LDS-DMA
+  // (global_load_lds_dwordx4: no staging registers, no ds_write issue slots, no address arithmetic per row).
+  // Linear byte P of the tile lands in LDS at P and is fetched from source byte P ^ (((P / ROWB) & SWM) << 4):
+  // the 16-byte chunk index XORed with the row's low bits (inside a half row), which makes the 16 rows that one
+  // ds_read_b128 pass touches fall into 16 different bank groups.  Rows past the cluster's end (other clusters'
+  // rows, or the zero padding behind the corpus) are scored like any other and dropped when queued.
+  // The biases of the tile: one 4-byte DMA by wave 0.
+  const int my_dma = (NP > wave ? (NP - wave + WV - 1) / WV : 0) + (wave == 0 ? 1 : 0);   // DMAs I issue per tile
+  auto issue_tile = [&](uint32_t tile_base, int buf) {
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(a.xs16) + (size_t)tile_base * ROWB;
+    for (int p = wave; p < NP; p += WV) {
+      uint32_t P0 = (uint32_t)lane * 16u;
+      asm volatile("" : "+v"(P0));
+      const uint32_t P = (uint32_t)p * 1024u + P0;
+      const uint32_t from = P ^ (((P / ROWB) & SWM) << 4);
+      if (TILEB >= 1024 || P < (uint32_t)TILEB)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + from),
+                                         (__attribute__((address_space(3))) void *)(uintptr_t)(lds0 + buf * (TILEB < 1024 ? 1024 : TILEB) + p * 1024), 16, 0, 0);
     }
-    if (tid < 32) {
-      const uint32_t row = base + tid;
-      if (row < end) bstage = METRIC == 0 ? -0.5f * a.n2s[row] : a.mux[row];
-      else bstage = -INFINITY;  // rows past the cluster never pass the filter (and are re-checked)
-    }
+    if (wave == 0)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.kbias + tile_base + lane),
+                                       (__attribute__((address_space(3))) void *)(uintptr_t)(bias0 + buf * 256), 4, 0, 0);
   };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NSTG; i++) {
-      const int q = tid + i * 256;
-      if (q < 32 * RP) {
-        const int row = q / RP, c4 = q % RP;
-        *reinterpret_cast<f32x4 *>(tile_ptr(buf) + row * LDW + c4 * 4) = stage[i];
-      }
-    }
-    if (tid < 32) bias_ptr(buf)[tid] = bstage;
+  // waits until at most `newer` tiles' worth of my DMAs are still in flight (they complete in order)
+  auto wait_tiles = [&](int newer) {
+    const int n = newer * my_dma;   // wave-uniform, 0 .. (NBUF - 2) * 3
+    if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n <= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   };
+  static_assert(NBUF >= 2 && NBUF <= 5, "wait_tiles covers (NBUF - 2) * 3 <= 9");
+  const uint32_t fragbase = lds0 + (uint32_t)col * ROWB + (uint32_t)h * (KS * 16);
+  const uint32_t fragswz = (uint32_t)(col & SWM) * 16u;
 
   // queue of survivors (sorted positions, in visiting order)
   uint32_t qc[4] = {0, 0, 0, 0};
@@ -240,36 +273,58 @@ __global__ __launch_bounds__(256, 2) void knn_filter_f16_kernel(KnnArgs a) {
     if (beg == end) continue;                     // nothing to visit (block-uniform)
     const unsigned long long visiting = __ballot(!pruned);
     const bool wave_need = visiting != 0ull;
-    if (lane == 0) flags[ph * 4 + wave] = wave_need ? 1u : 0u;
+    if (lane == 0) flags[ph * WV + wave] = wave_need ? 1u : 0u;
     __syncthreads();
-    const bool need = (flags[ph * 4] | flags[ph * 4 + 1] | flags[ph * 4 + 2] | flags[ph * 4 + 3]) != 0u;
+    uint32_t any_need = 0;
+#pragma unroll
+    for (int w = 0; w < WV; w++) any_need |= flags[ph * WV + w];
+    const bool need = any_need != 0u;
     ph ^= 1;
     if (!need) continue;
     calced += (unsigned long long)__popcll(visiting & 0xFFFFFFFFull) * (end - beg);  // knn.cu:228 per query
 
     const uint32_t ntiles = (end - beg + 31) / 32;
-    stage_load(beg, end);
-    stage_store(0);
-    __syncthreads();
-    for (uint32_t t = 0; t < ntiles; t++) {
-      const int buf = t & 1;
-      const uint32_t tile_base = beg + t * 32;
-      if (t + 1 < ntiles) stage_load(tile_base + 32, end);
-      if (wave_need) {
-        f32x16 acc;
-        {
-          const float *bb = bias_ptr(buf) + 4 * h;
+    // (the barrier above ordered every wave's reads of the previous cluster's tiles before these writes)
 #pragma unroll
-          for (int g = 0; g < 4; g++) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bb + 8 * g);
-            acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
-          }
+    for (int i = 0; i < NBUF - 1; i++)
+      if ((uint32_t)i < ntiles) issue_tile(beg + 32u * i, i);
+    for (uint32_t t = 0; t < ntiles; t++) {
+      const int buf = (int)(t % NBUF);
+      const uint32_t tile_base = beg + t * 32;
+      // tile t has landed (my pieces: counted wait; everybody's: the barrier), and every wave is done with
+      // tile t - 1, whose buffer the tile NBUF - 1 ahead goes into
+      const uint32_t ahead = ntiles - 1 - t;
+      wait_tiles(ahead < (uint32_t)(NBUF - 2) ? (int)ahead : NBUF - 2);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (t + (NBUF - 1) < ntiles) issue_tile(tile_base + 32u * (NBUF - 1), (int)((t + NBUF - 1) % NBUF));
+      if (wave_need) {
+        const uint32_t tb = fragbase + (uint32_t)buf * TILEB;
+        const uint32_t bb = bias0 + (uint32_t)buf * 256u + 16u * h;
+        f32x4 b4[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) b4[g] = knn_lds_read4(bb + 32u * g);
+        constexpr int PD = KS < 4 ? KS : 4;   // fragments in flight
+        f16x8 fr[PD + 1];
+#pragma unroll
+        for (int j = 0; j < PD; j++) fr[j] = knn_frag_issue(tb + ((16u * j) ^ fragswz));
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]) : "n"(PD));
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          acc[4 * g + 0] = b4[g].x; acc[4 * g + 1] = b4[g].y; acc[4 * g + 2] = b4[g].z; acc[4 * g + 3] = b4[g].w;
         }
-        const _Float16 *arow = reinterpret_cast<const _Float16 *>(tile_ptr(buf) + col * LDW) + h * NKH;
 #pragma unroll
         for (int j = 0; j < KS; j++) {
-          const f16x8 ahi = *reinterpret_cast<const f16x8 *>(arow + 8 * j);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, xhi[j], acc, 0, 0, 0);
+          if (j + PD < KS) fr[(j + PD) % (PD + 1)] = knn_frag_issue(tb + ((16u * (j + PD)) ^ fragswz));
+          const int behind = (KS - 1 - j) < PD ? (KS - 1 - j) : PD;
+          f16x8 &f = fr[j % (PD + 1)];
+          if (behind == 4) knn_frag_wait<4>(f);
+          else if (behind == 3) knn_frag_wait<3>(f);
+          else if (behind == 2) knn_frag_wait<2>(f);
+          else if (behind == 1) knn_frag_wait<1>(f);
+          else knn_frag_wait<0>(f);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, xhi[j], acc, 0, 0, 0);
         }
         uint32_t m16 = 0;
         if (!pruned) {
@@ -300,8 +355,6 @@ __global__ __launch_bounds__(256, 2) void knn_filter_f16_kernel(KnnArgs a) {
           }
         }
       }
-      if (t + 1 < ntiles) stage_store(buf ^ 1);
-      __syncthreads();
     }
   }
   if (__ballot(qn_ > 0) != 0ull) flush();
@@ -316,25 +369,42 @@ __global__ __launch_bounds__(256, 2) void knn_filter_f16_kernel(KnnArgs a) {
 }
 
 hipError_t launch_knn_split(int metric, const float *xs, uint32_t N, uint32_t D, uint32_t DP, const float *mu,
-                            void *xs16, float *n2c, float *mux, uint32_t *stats, hipStream_t st) {
+                            void *xs16, float *n2c, float *mux, float *kbias, uint32_t *stats, hipStream_t st) {
   hipError_t e = hipMemsetAsync(stats, 0, sizeof(uint32_t), st);
+  if (e != hipSuccess) return e;
+  // the tile DMA of the filter reads whole 32-row tiles: KNN16_PAD_ROWS rows / biases past the last one
+  e = hipMemsetAsync(reinterpret_cast<_Float16 *>(xs16) + (size_t)N * DP, 0, (size_t)KNN16_PAD_ROWS * DP * 2, st);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(kbias + N, 0, (size_t)KNN16_PAD_ROWS * sizeof(float), st);
   if (e != hipSuccess) return e;
   if (metric == 0)
     hipLaunchKernelGGL((knn_split_kernel<0>), dim3((N + 3) / 4), dim3(256), 0, st, xs, N, D, DP, mu,
-                       reinterpret_cast<_Float16 *>(xs16), n2c, mux, stats);
+                       reinterpret_cast<_Float16 *>(xs16), n2c, mux, kbias, stats);
   else
     hipLaunchKernelGGL((knn_split_kernel<1>), dim3((N + 3) / 4), dim3(256), 0, st, xs, N, D, DP, mu,
-                       reinterpret_cast<_Float16 *>(xs16), n2c, mux, stats);
+                       reinterpret_cast<_Float16 *>(xs16), n2c, mux, kbias, stats);
   return hipGetLastError();
 }
 
 template <int DP, int METRIC>
 static hipError_t launch_knn_f16_t(const KnnArgs &a, uint32_t nblocks, hipStream_t st) {
-  const size_t lds_bytes = (2 * 32 * (DP / 2 + 4) + 64 + 8) * sizeof(float);
+  const size_t lds_bytes = (size_t)KNN16_NBUF * (32 * DP * 2 < 1024 ? 1024 : 32 * DP * 2) + KNN16_NBUF * 256 + 2 * KNN16_WAVES * 4;
+  if (lds_bytes > 65536) {
+    static bool raised = false;   // per instantiation
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_filter_f16_kernel<DP, METRIC, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_filter_f16_kernel<DP, METRIC, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) return e;
+      raised = true;
+    }
+  }
   if (a.D == (uint32_t)DP)
-    hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, true>), dim3(nblocks), dim3(256), lds_bytes, st, a);
+    hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, true>), dim3(nblocks), dim3(KNN16_WAVES * 64), lds_bytes, st, a);
   else
-    hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, false>), dim3(nblocks), dim3(256), lds_bytes, st, a);
+    hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, false>), dim3(nblocks), dim3(KNN16_WAVES * 64), lds_bytes, st, a);
   return hipGetLastError();
 }
 
