@@ -179,8 +179,17 @@ hipError_t launch_yy_local_filter(int metric, const float *samples, uint32_t len
 
 // knn.hip (reference: knn.cu)
 // queries (consecutive sorted positions of one cluster) per block: f32 filter 4 waves, f16 filter 8 waves
+#ifndef KNN16_WAVES
 #define KNN16_WAVES 8
-#define KNN16_NBUF 4        // LDS ring of candidate tiles (knn_f16.hip)
+#define KNN16_BLOCKS_PER_CU 1
+#endif
+#ifndef KNN16_SUB
+#define KNN16_SUB 2
+#endif
+#ifndef KNN16_NBUF
+#define KNN16_NBUF 3
+#endif
+// ^       // LDS ring of candidate tiles (knn_f16.hip)
 #define KNN16_PAD_ROWS 64   // rows of xs16 / entries of kbias the caller allocates (and the split zeroes) past N
 constexpr uint32_t KNN_QPB_F32 = 128, KNN_QPB_F16 = KNN16_WAVES * 32;
 struct KnnArgs {
