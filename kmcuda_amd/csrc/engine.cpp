@@ -179,13 +179,24 @@ int Engine::yy_configure(uint32_t G, const uint32_t *groups_host) {
       if (groups_host[c] < G) cperm[fill[groups_host[c]]++] = c;
   }
   // padded panel: every group gets whole 4-slot chunks (at least one, so that an empty group still
-  // gets its FLT_MAX bound written), the panel whole 32-slot tiles
+  // gets its FLT_MAX bound written), the panel whole 32-slot tiles.  A group of up to 8 chunks never
+  // crosses a tile boundary (the tile is padded instead); a larger one starts a tile and carries a start
+  // flag on the first chunk of every further tile: the kernels close a (part of a) group with contenders
+  // from ONE tile, and the group's minimum is carried across its parts (yinyang_init.hip)
   std::vector<uint32_t> pids, pmeta;
   for (uint32_t g = 0; g < G; g++) {
     const uint32_t n = gstart[g + 1] - gstart[g];
     const uint32_t chunks = n ? (n + 3) / 4 : 1;
+    const uint32_t used = (uint32_t)(pids.size() / 4) % 8;
+    if (used && (chunks > 8 || used + chunks > 8)) {
+      for (uint32_t ch = used; ch < 8; ch++) {
+        pmeta.push_back((g ? g - 1 : 0) << 1);
+        for (uint32_t q = 0; q < 4; q++) pids.push_back(0xFFFFFFFFu);
+      }
+    }
     for (uint32_t ch = 0; ch < chunks; ch++) {
-      pmeta.push_back((g << 1) | (ch == 0 ? 1u : 0u));
+      const bool tile_start = (pids.size() / 4) % 8 == 0;
+      pmeta.push_back((g << 1) | ((ch == 0 || tile_start) ? 1u : 0u));
       for (uint32_t q = 0; q < 4; q++) {
         const uint32_t i = ch * 4 + q;
         pids.push_back(i < n ? cperm[gstart[g] + i] : 0xFFFFFFFFu);
@@ -248,12 +259,12 @@ int Engine::yy_init(const float *samples, const float *centroids, const uint32_t
   if (DP_ && DP_ <= 256 && !yy_exact_) {
     int rc = prepare_centroids(centroids);
     if (rc) return rc;
-    KMX_HIP(launch_yy_sorted_panel(cfil_, bias_, DP_, pids_, nslots_, pfil_, pbias_, stream_), kRuntimeError);
     YyArgs a;
     fill_yy_args(*this, a, samples, centroids);
     a.assignments = const_cast<uint32_t *>(assignments);
     a.bounds = bounds;
-    KMX_HIP(launch_yy_init_mfma(metric_, a, stream_), kRuntimeError);
+    KMX_HIP(launch_yy_orig_panel(metric_, centroids, D_, DP_, pids_, nslots_, pfil_, pbias_, stream_), kRuntimeError);
+    KMX_HIP(launch_yy_init_lds(metric_, a, stream_), kRuntimeError);
     return kSuccess;
   }
   if (!xt_) {

@@ -43,6 +43,22 @@ __device__ __forceinline__ void fma_rd4(float a, const float (&b)[4], const floa
                  "v"(c[3]));
 }
 
+// two independent round-down FMAs sharing the multiplicand a / two squares (one lane, two chains)
+__device__ __forceinline__ void fma_rd2(float a, const float (&b)[2], const float (&c)[2], float (&y)[2]) {
+  asm volatile(KMX_RD_ON
+               "v_fma_f32 %0, %2, %3, %5\n\t"
+               "v_fma_f32 %1, %2, %4, %6\n\t" KMX_RD_OFF
+               : "=&v"(y[0]), "=&v"(y[1])
+               : "v"(a), "v"(b[0]), "v"(b[1]), "v"(c[0]), "v"(c[1]));
+}
+__device__ __forceinline__ void sqfma_rd2(const float (&d)[2], const float (&c)[2], float (&y)[2]) {
+  asm volatile(KMX_RD_ON
+               "v_fma_f32 %0, %2, %2, %4\n\t"
+               "v_fma_f32 %1, %3, %3, %5\n\t" KMX_RD_OFF
+               : "=&v"(y[0]), "=&v"(y[1])
+               : "v"(d[0]), "v"(d[1]), "v"(c[0]), "v"(c[1]));
+}
+
 // eight independent round-down FMAs sharing the multiplicand a
 __device__ __forceinline__ void fma_rd8(float a, const float (&b)[8], const float (&c)[8], float (&y)[8]) {
   asm volatile(KMX_RD_ON

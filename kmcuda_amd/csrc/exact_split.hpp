@@ -86,83 +86,13 @@ __device__ __forceinline__ void exact_distance4(const float *__restrict__ xrow, 
 }
 
 
-// The same chains as a two-stage pipeline over consecutive batches: in one call the lower half-wave
-// runs features [0, NK) of the NEW batch while the upper half-wave finishes features [NK, D) of the
-// PREVIOUS one, whose (acc, corr) it received at the end of the previous call -- every lane works in
-// every call (exact_distance4 leaves one half idle per pass), at the price of results arriving one call
-// late.  The chains themselves are unchanged: same operations, same order, per candidate.
+// State of the same chains run as a two-stage pipeline over consecutive batches (yinyang_init.hip:
+// exact_chain4_lds_pipe): in one call the lower half-wave runs features [0, NK) of the NEW batch while the
+// upper half-wave finishes features [NK, D) of the PREVIOUS one, whose (acc, corr) it received at the end of
+// the previous call -- every lane works in every call (exact_distance4 leaves one half idle per pass), at the
+// price of results arriving one call late.  The chains themselves are unchanged: same operations, same order.
 struct ExactPipe4 {
   float acc[4] = {0.f, 0.f, 0.f, 0.f}, corr[4] = {0.f, 0.f, 0.f, 0.f};  // upper half: the pending batch
 };
-
-// cbase / cidx: the centroid matrix and this lane's four candidate rows (the NEW batch's in the lower
-// half-wave, the PREVIOUS batch's in the upper one).
-// (Tried and dropped: the four lanes of a quad reading 64 contiguous bytes of one row, for each of the
-// quad's rows in turn, plus a 4 x 4 DPP transpose -- PMC shows one L1 access per cycle per CU on this
-// path, but the transposes and the 64 extra live registers cost more than the coalescing saved:
-// yy_init 203 -> 232 ms per 8M rows.)
-template <int NK, int METRIC, bool FAST>
-__device__ __forceinline__ void exact_distance4_pipe(const float *__restrict__ xrow, const float *__restrict__ cbase,
-                                                     const uint32_t (&cidx)[4], uint32_t D, int h, int col,
-                                                     ExactPipe4 &st, float (&dist_old)[4]) {
-  float acc[4], corr[4];
-  const float *crow[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    acc[i] = h ? st.acc[i] : 0.f;
-    corr[i] = h ? st.corr[i] : 0.f;
-    crow[i] = cbase + (size_t)cidx[i] * D;
-  }
-  const int nvalid = (int)D - h * NK < 0 ? 0 : ((int)D - h * NK > NK ? NK : (int)D - h * NK);
-#pragma unroll 2
-  for (int j = 0; j < NK; j += 4) {
-    float xv[4], cv[4][4];
-    if (FAST) {
-      const f32x4_es x4 = *reinterpret_cast<const f32x4_es *>(xrow + h * NK + j);
-      xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const f32x4_es v = *reinterpret_cast<const f32x4_es *>(crow[i] + h * NK + j);
-        cv[i][0] = v.x; cv[i][1] = v.y; cv[i][2] = v.z; cv[i][3] = v.w;
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const bool in = j + q < nvalid;
-        xv[q] = in ? xrow[h * NK + j + q] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; i++) cv[i][q] = in ? crow[i][h * NK + j + q] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      float y[4];
-      if (METRIC == 0) {
-        float d[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) d[i] = xv[q] - cv[i][q];
-        sqfma_rd4(d, corr, y);
-      } else {
-        const float b[4] = {cv[0][q], cv[1][q], cv[2][q], cv[3][q]};
-        fma_rd4(xv[q], b, corr, y);
-      }
-      const bool on = FAST || (j + q < nvalid);
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const float t = acc[i] + y[i];
-        const float nc = y[i] - (t - acc[i]);
-        acc[i] = on ? t : acc[i];
-        corr[i] = on ? nc : corr[i];
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const float total = __shfl(acc[i], col + 32);   // the previous batch, finished by the upper half
-    dist_old[i] = METRIC == 0 ? sqrtf(total) : angular_from_prod(total);
-    st.acc[i] = __shfl(acc[i], col);                // the new batch after its first half
-    st.corr[i] = __shfl(corr[i], col);
-  }
-}
 
 }  // namespace kmx

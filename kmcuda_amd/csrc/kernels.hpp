@@ -160,14 +160,15 @@ struct YyArgs {
   uint32_t nslots;
 };
 hipError_t launch_yy_local_mfma(int metric, const YyArgs &a, hipStream_t st);
-hipError_t launch_yy_init_mfma(int metric, const YyArgs &a, hipStream_t st);
 // yinyang_hint.hip: coarse second-best estimate per passed row (f16 matrix cores), then the local filter
 // with that estimate as its candidate threshold; rows it cannot settle go to flag_rows (counters[5])
 bool yy_hint_supported(uint32_t DP);
 hipError_t launch_yy_hint(int metric, const YyArgs &a, hipStream_t st);
 hipError_t launch_yy_local_hint(int metric, const YyArgs &a, hipStream_t st);
-hipError_t launch_yy_sorted_panel(const float *cfil, const float *bias, uint32_t DP, const uint32_t *pids,
-                                  uint32_t nslots, float *pfil, float *pbias, hipStream_t st);
+// yinyang_init.hip: the same step with the exact chains fed from registers and LDS (original-value panel)
+hipError_t launch_yy_init_lds(int metric, const YyArgs &a, hipStream_t st);
+hipError_t launch_yy_orig_panel(int metric, const float *centroids, uint32_t D, uint32_t DP, const uint32_t *pids,
+                                uint32_t nslots, float *pfil, float *pbias, hipStream_t st);
 hipError_t launch_yy_global_filter(int metric, const float *samples, uint32_t len, uint32_t D, uint32_t K, uint32_t G,
                                    const float *centroids, const float *drifts, const float *gdrifts,
                                    const uint32_t *assignments, uint32_t *assignments_prev, float *bounds,

@@ -28,12 +28,7 @@
 //   reference would have skipped is harmless) and then replays the reference's tests and updates
 //   in ascending c order with the live state -- the state evolves exactly as in the reference.
 //
-// yy_init (kmeans.cu:431-485).  bounds[1+g] = min over the group's centroids (other than the
-//   row's own) of the exact distance: a minimum does not depend on the visiting order, so the panel
-//   is streamed GROUP-SORTED (groups padded to multiples of 4 rows = one half-wave's accumulator
-//   quad), each half-wave keeps a running top-3 of the approximate scores of the current group, and
-//   at the group boundary the 1-2 contenders are queued (all members, evaluated at once, when
-//   three or more are within the error bound); queued distances are evaluated four at a time.
+// yy_init (kmeans.cu:431-485): yinyang_init.hip.
 #include "yinyang_tiles.hpp"
 
 namespace kmx {
@@ -248,256 +243,6 @@ __global__ __launch_bounds__(256, 2) void yy_local_mfma_kernel(YyArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// yy_init with the MFMA filter: group-sorted panel, groups padded to multiples of 4 slots
-// ---------------------------------------------------------------------------------------
-// pids[slot]  centroid id of the slot or 0xFFFFFFFF (padding)
-// pmeta[8*tile + ch]  (group << 1) | starts_new_group, for the 4-slot chunk ch of the tile
-template <int DP, int METRIC, bool FAST>
-__global__ __launch_bounds__(256, 2) void yy_init_mfma_kernel(YyArgs a) {
-  constexpr int NK = DP / 2, LDW = DP + 4, TILE = 32 * LDW, NST = (8 * DP + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  auto tile_ptr = [&](int buf) { return lds + buf * TILE; };
-  auto bias_ptr = [&](int buf) { return lds + 2 * TILE + buf * 32; };
-  auto id_ptr = [&](int buf) { return reinterpret_cast<uint32_t *>(lds + 2 * TILE + 64) + buf * 32; };
-  auto meta_ptr = [&](int buf) { return reinterpret_cast<uint32_t *>(lds + 2 * TILE + 128) + buf * 8; };
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
-  const uint32_t D = a.D, K = a.K, G = a.G, len = a.len;
-  const uint32_t s = blockIdx.x * 128u + wave * 32u + col;
-  const bool live = s < len;
-
-  KMX_YY_LOAD_ROWS(a.samples, s, live)
-  (void)xmu;
-
-  const uint32_t nearest = live ? a.assignments[s] : 0xFFFFFFFFu;
-
-  // two scores closer than thr cannot be ordered by the filter
-  const float cmaxc = sqrtf(__uint_as_float(a.stats[0])) * 1.000001f;
-  const float bmaxc = __uint_as_float(a.stats[1]);
-  const float xo = sqrtf(xo2) * 1.0001f, xc = sqrtf(xc2) * 1.0001f;
-  const float u = 5.9604645e-8f;
-  float thr = 2.0f * (2.0f * a.eps * (xc * cmaxc + bmaxc)) * 1.01f;
-  if (METRIC == 0) thr += 16.0f * u * (xc + cmaxc) * (xc + cmaxc);
-  else thr += 16.0f * u * xo * sqrtf(__uint_as_float(a.stats[2])) + 2e-6f;
-
-  f32x4 stage[NST];
-  float bstage = 0.f;
-  uint32_t istage = 0xFFFFFFFFu, mstage = 0;
-  auto stage_load = [&](uint32_t tile) {
-    const float *src = a.pfil + (size_t)tile * 32 * DP;
-#pragma unroll
-    for (int i = 0; i < NST; i++) {
-      const int q = tid + i * 256;
-      if (q < 8 * DP) stage[i] = reinterpret_cast<const f32x4 *>(src)[q];
-    }
-    if (tid < 32) {
-      bstage = a.pbias[tile * 32 + tid];
-      istage = a.pids[tile * 32 + tid];
-    }
-    if (tid < 8) mstage = a.pmeta[tile * 8 + tid];
-  };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NST; i++) {
-      const int q = tid + i * 256;
-      if (q < 8 * DP) {
-        const int row = q / (DP / 4), c4 = q % (DP / 4);
-        *reinterpret_cast<f32x4 *>(tile_ptr(buf) + row * LDW + c4 * 4) = stage[i];
-      }
-    }
-    if (tid < 32) {
-      bias_ptr(buf)[tid] = bstage;
-      id_ptr(buf)[tid] = istage;
-    }
-    if (tid < 8) meta_ptr(buf)[tid] = mstage;
-  };
-
-  // queue of (group, centroid) distance evaluations; a group's entries are adjacent, its minimum
-  // is carried across flushes and stored when the next group's first entry is replayed (or at the end)
-  uint32_t qc[4] = {0, 0, 0, 0}, qg[4] = {0, 0, 0, 0};
-  int qn = 0;
-  uint32_t carry_g = 0xFFFFFFFFu;
-  float carry_min = kFltMax;
-  auto store_carry = [&]() __attribute__((always_inline)) {
-    if (carry_g != 0xFFFFFFFFu && live && h == 0) a.bounds[(size_t)len * (1 + carry_g) + s] = carry_min;
-  };
-  // the exact chains run as a two-batch pipeline (exact_split.hpp): a flush starts the queued batch and
-  // completes -- and replays -- the one before it
-  uint32_t pqc[4] = {0, 0, 0, 0}, pqg[4] = {0, 0, 0, 0};
-  int pqn = 0;
-  ExactPipe4 pipe;
-  auto flush = [&]() __attribute__((always_inline)) {  // wave-uniform call
-    uint32_t cidx[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) cidx[i] = h ? (i < pqn ? pqc[i] : 0u) : (i < qn ? qc[i] : 0u);
-    float dist[4];
-    exact_distance4_pipe<NK, METRIC, FAST>(xrow, a.centroids, cidx, D, h, col, pipe, dist);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      if (i < pqn) {
-        if (pqg[i] != carry_g) {
-          store_carry();
-          carry_g = pqg[i];
-          carry_min = kFltMax;
-        }
-        if (dist[i] < carry_min) carry_min = dist[i];   // kmeans.cu:477-481 (NaN never "less")
-      }
-      pqc[i] = qc[i];
-      pqg[i] = qg[i];
-    }
-    pqn = qn;
-    qn = 0;
-  };
-  auto drain = [&]() __attribute__((always_inline)) {  // wave-uniform call: nothing queued, nothing pending afterwards
-    if (__ballot(qn > 0) != 0ull) flush();
-    if (__ballot(pqn > 0) != 0ull) flush();
-  };
-  auto enqueue = [&](uint32_t g, uint32_t c, bool on) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-      if (on && i == qn) {
-        qc[i] = c;
-        qg[i] = g;
-      }
-    if (on) qn++;
-  };
-
-  // upper bound: exact distance to the row's own centroid (kmeans.cu:474-476); stays FLT_MAX if the
-  // row has none (NaN row) or its centroid is in no group (NaN centroid)
-  float upper = kFltMax;
-  {
-    const bool has = live && nearest < K && a.groups[nearest] < G;
-    if (__ballot(has) != 0ull) {
-      const float *crow[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) crow[i] = a.centroids + (size_t)(has ? nearest : 0) * D;
-      float dist[4];
-      exact_distance4<NK, METRIC, FAST>(xrow, crow, D, h, col, dist);
-      if (has) upper = dist[0];
-    }
-  }
-
-  // running top-3 (by score = smallest distance first) of the CURRENT group in this half-wave
-  float v1 = -INFINITY, v2 = -INFINITY, v3 = -INFINITY;
-  uint32_t c1 = 0xFFFFFFFFu, c2 = 0xFFFFFFFFu;
-  uint32_t cur_group = 0xFFFFFFFFu;
-  auto insert = [&](float v, uint32_t idx) {
-    const bool g1 = v > v1, g2 = v > v2, g3 = v > v3;
-    v3 = g2 ? v2 : (g3 ? v : v3);
-    c2 = g1 ? c1 : (g2 ? idx : c2);
-    v2 = g1 ? v1 : (g2 ? v : v2);
-    c1 = g1 ? idx : c1;
-    v1 = g1 ? v : v1;
-  };
-  auto finalize_group = [&]() __attribute__((always_inline)) {  // wave-uniform call
-    if (cur_group == 0xFFFFFFFFu) return;
-    {  // merge the partner half-wave's top-3
-      const float pv1 = __shfl_xor(v1, 32), pv2 = __shfl_xor(v2, 32), pv3 = __shfl_xor(v3, 32);
-      const uint32_t pc1 = __shfl_xor(c1, 32), pc2 = __shfl_xor(c2, 32);
-      insert(pv1, pc1);
-      insert(pv2, pc2);
-      insert(pv3, 0xFFFFFFFFu);
-      // Both lanes of a (col, col + 32) pair must now hold the SAME contenders: they evaluate one exact
-      // chain between them (lower half: features [0, NK), upper half: the rest).  The merge above keeps a
-      // lane's own entry ahead of an EQUAL score from the partner, so on an exact tie of two approximate
-      // scores the two lanes disagreed on which centroid is first -- and the chain came out as the first
-      // half of one centroid's distance and the second half of the other's (found by the 1M-row parity
-      // test, tests/test_gpu_scale.py: 2 bounds in 1e8).  The lower half-wave's view wins.
-      v1 = __shfl(v1, col); v2 = __shfl(v2, col); v3 = __shfl(v3, col);
-      c1 = __shfl(c1, col); c2 = __shfl(c2, col);
-    }
-    const bool has1 = live && c1 != 0xFFFFFFFFu;
-    const bool sure1 = has1 && ((v1 - v2) > thr);                      // NaN gap => not sure
-    const bool sure2 = has1 && !sure1 && c2 != 0xFFFFFFFFu && ((v1 - v3) > thr);
-    const bool scan = has1 && !sure1 && !sure2;
-    if (__ballot(qn > 2) != 0ull) flush();                              // room for two more everywhere
-    if (!has1) {
-      // no member other than the row's own centroid (or an empty group): the bound stays FLT_MAX.
-      // Replayed through the carry so that the store order stays one group at a time.
-      if (carry_g != cur_group) {
-        store_carry();
-        carry_g = cur_group;
-        carry_min = kFltMax;
-      }
-    }
-    enqueue(cur_group, c1, has1 && !scan);
-    enqueue(cur_group, c2, sure2);
-    if (__ballot(scan) != 0ull) {  // three or more contenders: every member of the group, exactly
-      drain();
-      if (scan && carry_g != cur_group) {
-        store_carry();
-        carry_g = cur_group;
-        carry_min = kFltMax;
-      }
-      const uint32_t gb = a.gstart[cur_group], ge = a.gstart[cur_group + 1];
-      for (uint32_t i0 = gb; i0 < ge; i0 += 4) {
-        const float *crow[4];
-        bool on[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const uint32_t c = (i0 + i < ge) ? a.cperm[i0 + i] : a.cperm[gb];
-          on[i] = scan && (i0 + i < ge) && c != nearest;
-          crow[i] = a.centroids + (size_t)c * D;
-        }
-        float dist[4];
-        exact_distance4<NK, METRIC, FAST>(xrow, crow, D, h, col, dist);
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-          if (on[i] && dist[i] < carry_min) carry_min = dist[i];
-      }
-    }
-    v1 = v2 = v3 = -INFINITY;
-    c1 = c2 = 0xFFFFFFFFu;
-  };
-
-  const uint32_t ntiles = a.nslots / 32;
-  stage_load(0);
-  stage_store(0);
-  __syncthreads();
-  for (uint32_t t = 0; t < ntiles; t++) {
-    const int buf = t & 1;
-    if (t + 1 < ntiles) stage_load(t + 1);
-    KMX_YY_MFMA_TILE(acc, buf)
-#pragma unroll
-    for (int ch = 0; ch < 8; ch++) {
-      const uint32_t meta = meta_ptr(buf)[ch];
-      if (meta & 1u) {  // this chunk starts a new group: close the previous one (wave-uniform)
-        finalize_group();
-        cur_group = meta >> 1;
-      }
-      if ((ch & 1) == h) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int r = 4 * (ch >> 1) + q;
-          const uint32_t row = 8 * (ch >> 1) + q + 4 * h;
-          const uint32_t id = id_ptr(buf)[row];
-          const float v = (id != 0xFFFFFFFFu && id != nearest) ? acc[r] : -INFINITY;
-          insert(v, id);
-        }
-      }
-    }
-    if (t + 1 < ntiles) stage_store(buf ^ 1);
-    __syncthreads();
-  }
-  finalize_group();
-  drain();
-  store_carry();
-  if (live && h == 0) a.bounds[s] = upper;
-}
-
-// group-sorted padded panel from the centred panel of centroid_prep
-__global__ void yy_sorted_panel_kernel(const float *__restrict__ cfil, const float *__restrict__ bias, uint32_t DP,
-                                       const uint32_t *__restrict__ pids, uint32_t nslots,
-                                       float *__restrict__ pfil, float *__restrict__ pbias) {
-  const uint32_t slot = blockIdx.x;
-  const uint32_t id = pids[slot];
-  for (uint32_t f = threadIdx.x; f < DP; f += blockDim.x)
-    pfil[(size_t)slot * DP + f] = id != 0xFFFFFFFFu ? cfil[(size_t)id * DP + f] : 0.f;
-  if (threadIdx.x == 0) pbias[slot] = id != 0xFFFFFFFFu ? bias[id] : -INFINITY;
-  (void)nslots;
-}
-
-// ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
 template <int DP, int METRIC>
@@ -510,17 +255,6 @@ static hipError_t launch_local_t(const YyArgs &a, hipStream_t st) {
     hipLaunchKernelGGL((yy_local_mfma_kernel<DP, METRIC, false>), dim3(grid), dim3(256), lds_bytes, st, a);
   return hipGetLastError();
 }
-template <int DP, int METRIC>
-static hipError_t launch_init_t(const YyArgs &a, hipStream_t st) {
-  const size_t lds_bytes = (2 * 32 * (DP + 4) + 64 + 64 + 16) * sizeof(float);
-  const uint32_t grid = (a.len + 127) / 128;
-  if (a.D == (uint32_t)DP)
-    hipLaunchKernelGGL((yy_init_mfma_kernel<DP, METRIC, true>), dim3(grid), dim3(256), lds_bytes, st, a);
-  else
-    hipLaunchKernelGGL((yy_init_mfma_kernel<DP, METRIC, false>), dim3(grid), dim3(256), lds_bytes, st, a);
-  return hipGetLastError();
-}
-
 #define KMX_YY_SWITCH(fn)                                                              \
   switch (a.DP) {                                                                      \
     case 8: return metric == 0 ? fn<8, 0>(a, st) : fn<8, 1>(a, st);                    \
@@ -535,18 +269,6 @@ static hipError_t launch_init_t(const YyArgs &a, hipStream_t st) {
 hipError_t launch_yy_local_mfma(int metric, const YyArgs &a, hipStream_t st) {
   if (a.len == 0) return hipSuccess;
   KMX_YY_SWITCH(launch_local_t)
-}
-
-hipError_t launch_yy_init_mfma(int metric, const YyArgs &a, hipStream_t st) {
-  if (a.len == 0) return hipSuccess;
-  KMX_YY_SWITCH(launch_init_t)
-}
-
-hipError_t launch_yy_sorted_panel(const float *cfil, const float *bias, uint32_t DP, const uint32_t *pids,
-                                  uint32_t nslots, float *pfil, float *pbias, hipStream_t st) {
-  if (nslots == 0) return hipSuccess;
-  hipLaunchKernelGGL(yy_sorted_panel_kernel, dim3(nslots), dim3(64), 0, st, cfil, bias, DP, pids, nslots, pfil, pbias);
-  return hipGetLastError();
 }
 
 }  // namespace kmx
