@@ -179,20 +179,24 @@ hipError_t launch_yy_local_filter(int metric, const float *samples, uint32_t len
                                   uint32_t *counters, hipStream_t st);
 
 // knn.hip (reference: knn.cu)
-// queries (consecutive sorted positions of one cluster) per block: f32 filter 4 waves, f16 filter 8 waves
+// queries (consecutive sorted positions of one cluster) per block: f32 filter 4 waves x 32, f16 filter
+// KNN16_WAVES x KNN16_NSET x 32
 #ifndef KNN16_WAVES
-#define KNN16_WAVES 8
-#define KNN16_BLOCKS_PER_CU 1
+#define KNN16_WAVES 4           // waves per block
+#define KNN16_NSET 2            // 32-query operand sets per wave
+#define KNN16_BLOCKS_PER_CU 2
 #endif
 #ifndef KNN16_SUB
-#define KNN16_SUB 2
+#define KNN16_SUB 2             // 32-candidate sub-tiles per staged tile (per barrier)
 #endif
 #ifndef KNN16_NBUF
-#define KNN16_NBUF 3
+#define KNN16_NBUF 2            // LDS ring of candidate tiles (knn_f16.hip)
 #endif
-// ^       // LDS ring of candidate tiles (knn_f16.hip)
+#ifndef KNN16_PD
+#define KNN16_PD 3              // candidate fragments in flight per wave
+#endif
 #define KNN16_PAD_ROWS 64   // rows of xs16 / entries of kbias the caller allocates (and the split zeroes) past N
-constexpr uint32_t KNN_QPB_F32 = 128, KNN_QPB_F16 = KNN16_WAVES * 32;
+constexpr uint32_t KNN_QPB_F32 = 128, KNN_QPB_F16 = KNN16_WAVES * KNN16_NSET * 32;
 struct KnnArgs {
   const float *xs;          // N x DP cluster-sorted rows (zero padded to DP)
   const float *n2s;         // N plain squared norms of the sorted rows
