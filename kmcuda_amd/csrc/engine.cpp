@@ -161,10 +161,7 @@ int Engine::prepare_centroids(const float *centroids) {
 int Engine::yy_configure(uint32_t G, const uint32_t *groups_host) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   if (const char *v = getenv("KMCUDA_AMD_YY_EXACT")) yy_exact_ = atoi(v) != 0;
-  if (const char *v = getenv("KMCUDA_AMD_YY_HINT")) {
-    yy_hint_ = atoi(v) != 0;
-    yy_hint_f32_ = atoi(v) == 2;
-  }
+  if (const char *v = getenv("KMCUDA_AMD_YY_HINT")) yy_hint_ = atoi(v) != 0;
   G_ = G;
   // centroids in group order; group >= G (a NaN centroid keeps the 0xFFFFFFFF "assignment" of
   // its failed search, kmeans.cu:468-471) is left out
@@ -220,7 +217,8 @@ int Engine::yy_configure(uint32_t G, const uint32_t *groups_host) {
   if ((rc = alloc(&gsecond_, gsecond.size()))) return rc;
   KMX_HIP(hipMemcpy(gfirst_, gfirst.data(), gfirst.size() * sizeof(uint32_t), hipMemcpyHostToDevice), kMemoryCopyError);
   KMX_HIP(hipMemcpy(gsecond_, gsecond.data(), gsecond.size() * sizeof(uint32_t), hipMemcpyHostToDevice), kMemoryCopyError);
-  if ((rc = alloc(&groups_, K_))) return rc;
+  const uint32_t k_pad64 = (K_ + 63u) / 64u * 64u;   // whole 64-centroid super-tiles (yy_local_hint_kernel's DMA)
+  if ((rc = alloc(&groups_, k_pad64))) return rc;
   if ((rc = alloc(&cperm_, cperm.size()))) return rc;
   if ((rc = alloc(&gstart_, G + 1))) return rc;
   if ((rc = alloc(&pids_, pids.size()))) return rc;
@@ -228,7 +226,11 @@ int Engine::yy_configure(uint32_t G, const uint32_t *groups_host) {
   const uint32_t dp = DP_ ? DP_ : 8;
   if ((rc = alloc(&pfil_, (size_t)nslots_ * dp))) return rc;
   if ((rc = alloc(&pbias_, nslots_))) return rc;
-  KMX_HIP(hipMemcpy(groups_, groups_host, K_ * sizeof(uint32_t), hipMemcpyHostToDevice), kMemoryCopyError);
+  {
+    std::vector<uint32_t> gp(k_pad64, 0xFFFFFFFFu);
+    for (uint32_t c = 0; c < K_; c++) gp[c] = groups_host[c];
+    KMX_HIP(hipMemcpy(groups_, gp.data(), k_pad64 * sizeof(uint32_t), hipMemcpyHostToDevice), kMemoryCopyError);
+  }
   KMX_HIP(hipMemcpy(cperm_, cperm.data(), cperm.size() * sizeof(uint32_t), hipMemcpyHostToDevice), kMemoryCopyError);
   KMX_HIP(hipMemcpy(gstart_, gstart.data(), (G + 1) * sizeof(uint32_t), hipMemcpyHostToDevice), kMemoryCopyError);
   KMX_HIP(hipMemcpy(pids_, pids.data(), pids.size() * sizeof(uint32_t), hipMemcpyHostToDevice), kMemoryCopyError);
@@ -243,7 +245,6 @@ static void fill_yy_args(Engine &e, YyArgs &a, const float *samples, const float
   a.groups = e.groups_; a.drifts = nullptr; a.gdrifts = nullptr; a.assignments = nullptr; a.bounds = nullptr;
   a.passed = nullptr; a.counters = e.counters_; a.count_ptr = e.counters_ + 2;
   a.panelhi = nullptr; a.hint = nullptr; a.flag_rows = nullptr; a.gfirst = e.gfirst_; a.gsecond = e.gsecond_;
-  a.hint_f32_sweep = e.yy_hint_f32_ ? 1 : 0;
   a.pfil = e.pfil_; a.pbias = e.pbias_; a.pids = e.pids_; a.pmeta = e.pmeta_; a.cperm = e.cperm_;
   a.gstart = e.gstart_; a.nslots = e.nslots_;
 }

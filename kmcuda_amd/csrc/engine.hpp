@@ -114,7 +114,6 @@ class Engine {
   uint32_t G_ = 0, nslots_ = 0;
   bool yy_exact_ = false;  // KMCUDA_AMD_YY_EXACT=1: plain exact kernels (cross-check)
   bool yy_hint_ = true;    // KMCUDA_AMD_YY_HINT=0: local filter without the second-best estimate (yinyang_hint.hip)
-  bool yy_hint_f32_ = false;  // KMCUDA_AMD_YY_HINT=2: its candidate sweep on the f32 matrix cores
   uint32_t *gfirst_ = nullptr, *gsecond_ = nullptr, *yy_flag_rows_ = nullptr;
   float *yy_hint_buf_ = nullptr;
   void *yy_panelhi_ = nullptr;

@@ -141,7 +141,7 @@ struct YyArgs {
   const float *cfil, *bias, *mu;  // centred panel of centroid_prep (ascending c)
   const uint32_t *stats;
   float eps;
-  const uint32_t *groups;    // K
+  const uint32_t *groups;    // K, padded with 0xFFFFFFFF to a multiple of 64
   const float *drifts, *gdrifts;
   uint32_t *assignments;
   float *bounds;
@@ -153,7 +153,6 @@ struct YyArgs {
   float *hint;               // per passed row: S' >= upper bound (or +inf: no hint)
   uint32_t *flag_rows;       // rows the hinted kernel could not settle
   const uint32_t *gfirst, *gsecond;  // G: the two smallest member indices of every group (0xFFFFFFFF: none)
-  int hint_f32_sweep;        // candidate sweep of the hinted kernel on the f32 matrix cores (cross-check)
   // yy_init: group-sorted padded panel
   const float *pfil, *pbias;
   const uint32_t *pids, *pmeta, *cperm, *gstart;

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(KNN16_WAVES * 64, KNN16_BLOCKS_PER_CU) void knn_fil
     for (int i = 0; i < 4; i++) crow[i] = a.xs + (size_t)(i < qn_[e] ? qc[e][i] : 0) * DP;
     float dist[4];
     const int nq = __ballot(qn_[e] >= 4) ? 4 : (__ballot(qn_[e] >= 3) ? 3 : (__ballot(qn_[e] >= 2) ? 2 : 1));
-    exact_distance4<NKH, METRIC, FASTX>(xrow, crow, D, h, col, dist, nq);
+    exact_distance4<NKH, METRIC, FASTX>(xrow, crow, D, h, col, dist, nq, qn_[e]);
     float mnd = mndist[e];
 #pragma unroll
     for (int i = 0; i < 4; i++) {

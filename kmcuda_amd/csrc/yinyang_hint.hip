@@ -34,24 +34,76 @@
 // Flagged rows (also: no estimate) are left untouched and appended to flag_rows; the engine runs
 // yy_local_mfma_kernel -- the reference's scan replayed state for state -- over that list.  Every
 // row's outcome is therefore the reference's, bit for bit, whatever the estimate was.
+#include <type_traits>
 #include "yinyang_tiles.hpp"
 
 namespace kmx {
 
 typedef _Float16 f16x8h __attribute__((ext_vector_type(8)));
 
+// hand-issued LDS reads (raw LDS byte address) with counted waits: the compiler neither knows these reads nor
+// drains the panel DMA in front of them (lloyd_f16.hip, knn_f16.hip)
+__device__ __forceinline__ f16x8h yyh_frag_issue(uint32_t addr) {
+  f16x8h f;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(f) : "v"(addr) : "memory");
+  return f;
+}
+__device__ __forceinline__ f32x4 yyh_lds_read4(uint32_t addr) {
+  f32x4 f;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(f) : "v"(addr) : "memory");
+  return f;
+}
+__device__ __forceinline__ uint32_t yyh_lds_read1(uint32_t addr) {   // read and wait
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void yyh_frag_wait(f16x8h &f) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N));
+}
+
 // The (a) rule's share of the second minimum, folded up front (header): the smallest group bound that is
 // >= the upper bound, belongs to a group the reference's scan meets (a member other than the row's own
 // centroid), and is <= S' -- by walking all G bounds of the row (G lines, 4 N bytes apart).  Both
-// half-waves return the same value.
+// half-waves return the same value.  amask (G <= 128): bit g set iff bound[g] >= upper bound -- the (a) test of a
+// candidate's group without another trip to global memory (the row's bounds do not change until its write-back).
 __device__ __forceinline__ float low_bound_fold(const YyArgs &a, uint32_t s, int h, uint32_t cluster, float upper_bound,
-                                                float hint, bool on) {
+                                                float hint, bool on, uint32_t (&amask)[4]) {
   const uint32_t G = a.G, len = a.len;
   float alow = kFltMax;
+#pragma unroll
+  for (int w = 0; w < 4; w++) amask[w] = 0u;
   if (__ballot(on) != 0ull) {
     float mine = kFltMax;
     if (on) {
-      for (uint32_t g0 = h; g0 < G; g0 += 16) {
+      // the bounds of the first 128 groups are all requested before the first is looked at (one memory round
+      // trip instead of eight); further groups in batches of eight per lane
+      float lbv[8][8];
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const uint32_t g = (uint32_t)h + 16u * it + 2u * q;
+          lbv[it][q] = g < G ? a.bounds[(size_t)len * (1 + g) + s] : -INFINITY;
+        }
+      }
+      auto look = [&](float lb, uint32_t g) {
+        const uint32_t bit = (lb >= upper_bound && g < 128u) ? 1u << (g & 31u) : 0u;
+#pragma unroll
+        for (int w = 0; w < 4; w++) amask[w] |= (g >> 5) == (uint32_t)w ? bit : 0u;
+        if (lb >= upper_bound && lb <= hint && lb < mine) {
+          uint32_t p = a.gfirst[g];
+          if (p == cluster) p = a.gsecond[g];
+          if (p != 0xFFFFFFFFu) mine = lb;  // the group has a member the reference's scan meets
+        }
+      };
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) look(lbv[it][q], (uint32_t)h + 16u * it + 2u * q);
+      }
+      for (uint32_t g0 = 128u + h; g0 < G; g0 += 16) {
         float lb8[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) {
@@ -59,20 +111,14 @@ __device__ __forceinline__ float low_bound_fold(const YyArgs &a, uint32_t s, int
           lb8[q] = g < G ? a.bounds[(size_t)len * (1 + g) + s] : -INFINITY;
         }
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const float lb = lb8[q];
-          if (lb >= upper_bound && lb <= hint && lb < mine) {
-            const uint32_t g = g0 + 2 * q;
-            uint32_t p = a.gfirst[g];
-            if (p == cluster) p = a.gsecond[g];
-            if (p != 0xFFFFFFFFu) mine = lb;  // the group has a member the reference's scan meets
-          }
-        }
+        for (int q = 0; q < 8; q++) look(lb8[q], g0 + 2 * q);
       }
     }
     const float other = __shfl_xor(mine, 32);
     const float both = other < mine ? other : mine;
     if (on) alow = both;
+#pragma unroll
+    for (int w = 0; w < 4; w++) amask[w] |= __shfl_xor(amask[w], 32);
   }
   return alow;
 }
@@ -84,14 +130,21 @@ __device__ __forceinline__ float low_bound_fold(const YyArgs &a, uint32_t s, int
 // matrix products (with one set the LDS reads alone are half the LDS bandwidth at full matrix rate).
 template <int DP, int METRIC, bool FAST>
 __global__ __launch_bounds__(256, 2) void yy_hint_kernel(YyArgs a) {
-  constexpr int NK = DP / 2, KS = NK / 8, LDWH = DP / 2 + 4, TILE = 32 * LDWH, NSTH = (4 * DP + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  auto tile_ptr = [&](int buf) { return lds + buf * TILE; };
-  auto bias_ptr = [&](int buf) { return lds + 2 * TILE + buf * 32; };
+  constexpr int NK = DP / 2, KS = NK / 8;
+  constexpr int ROWB = DP * 2;              // bytes of one panel row (DP hi halves)
+  constexpr int SUPB = 64 * ROWB;           // one super-tile: 64 centroids
+  constexpr int NP = SUPB / 1024;           // 1-KB LDS-DMA pieces per super-tile
+  constexpr int SWM = (KS < 16 ? KS : 16) - 1;
+  constexpr int WV = 4, PPW = (NP + WV - 1) / WV;
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds2[];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte *)lds2;
+  if (lds0 & 1023u) __builtin_trap();
+  const uint32_t bias0 = lds0 + 2 * SUPB;   // 2 x 64 floats
 
   const uint32_t npassed = *a.count_ptr;
   if (blockIdx.x * 256u >= npassed) return;  // block-uniform
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 31, h = lane >> 5;
   const uint32_t D = a.D, K = a.K, G = a.G, len = a.len;
   uint32_t pi[2], s[2];
   bool live[2];
@@ -128,75 +181,98 @@ __global__ __launch_bounds__(256, 2) void yy_hint_kernel(YyArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   }
 
-  f32x4 stage[NSTH];
-  float bstage = 0.f;
-  auto stage_load = [&](uint32_t tile) {
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(reinterpret_cast<const _Float16 *>(a.panelhi) + (size_t)tile * 32 * DP);
-#pragma unroll
-    for (int i = 0; i < NSTH; i++) {
-      const int q = tid + i * 256;
-      if (q < 4 * DP) stage[i] = src[q];
+  const uint32_t nsuper = (a.K_pad + 63u) / 64u;
+  const float *biashi = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(a.panelhi) + (size_t)nsuper * SUPB);
+  // the panel streams as in yy_local_hint_kernel below (and lloyd_f16.hip): 64-centroid super-tiles by LDS-DMA
+  auto issue_piece = [&](uint32_t sp, int buf, int i) {
+    if (i == PPW) {
+      if (wave == 0)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(biashi + sp * 64u + lane),
+                                         (__attribute__((address_space(3))) void *)(uintptr_t)(bias0 + buf * 256), 4, 0, 0);
+      return;
     }
-    if (tid < 32) bstage = a.bias[tile * 32 + tid];
+    const int p = wave + WV * i;
+    if (p >= NP) return;   // wave-uniform
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(a.panelhi) + (size_t)sp * SUPB;
+    uint32_t P0 = (uint32_t)lane * 16u;
+    asm volatile("" : "+v"(P0));
+    const uint32_t P = (uint32_t)p * 1024u + P0;
+    const uint32_t from = P ^ (((P / ROWB) & SWM) << 4);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + from),
+                                     (__attribute__((address_space(3))) void *)(uintptr_t)(lds0 + buf * SUPB + p * 1024), 16, 0, 0);
   };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NSTH; i++) {
-      const int q = tid + i * 256;
-      if (q < 4 * DP) {
-        const int row = q / (DP / 8), c8 = q % (DP / 8);
-        *reinterpret_cast<f32x4 *>(tile_ptr(buf) + row * LDWH + c8 * 4) = stage[i];
-      }
-    }
-    if (tid < 32) bias_ptr(buf)[tid] = bstage;
-  };
+  const uint32_t fragbase = lds0 + (uint32_t)col * ROWB + (uint32_t)h * (KS * 16);
+  const uint32_t fragswz = (uint32_t)(col & SWM) * 16u;
 
   // best two scores of my 16 accumulator rows per tile; the register number rides in the low 4
   // mantissa bits, the tile index is noted once per tile
   float v1[2] = {-INFINITY, -INFINITY}, v2[2] = {-INFINITY, -INFINITY};
   uint32_t t1[2] = {0, 0}, t2[2] = {0, 0};
-  const uint32_t ntiles = a.K_pad / 32;
-  stage_load(0);
-  stage_store(0);
-  __syncthreads();
-  for (uint32_t t = 0; t < ntiles; t++) {
-    const int buf = t & 1;
-    if (t + 1 < ntiles) stage_load(t + 1);
-    f32x16 acc[2];
-    {
-      const float *bb = bias_ptr(buf) + 4 * h;
+#pragma unroll
+  for (int i = 0; i <= PPW; i++) issue_piece(0, 0, i);
+  constexpr int DSTR = (2 * KS) / (PPW + 1) > 0 ? (2 * KS) / (PPW + 1) : 1;   // a piece every DSTR k-steps
+  for (uint32_t sp = 0; sp < nsuper; sp++) {
+    const int buf = sp & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of super-tile sp have landed
+    __builtin_amdgcn_s_barrier();                      // everybody's have, and everybody is done with sp - 1
+    asm volatile("" ::: "memory");
+    const bool dma = sp + 1 < nsuper;
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+      const uint32_t t = sp * 2u + (uint32_t)sub;   // 32-centroid tile index
+      const uint32_t tb = fragbase + (uint32_t)buf * SUPB + (uint32_t)sub * (32 * ROWB);
+      const uint32_t bb = bias0 + (uint32_t)buf * 256u + (uint32_t)sub * 128u + 16u * h;
+      f32x4 b4[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) b4[g4] = yyh_lds_read4(bb + 32u * g4);
+      constexpr int PD = KS < 3 ? KS : 3;   // fragments in flight
+      f16x8h fr[PD + 1];
+#pragma unroll
+      for (int j = 0; j < PD; j++) fr[j] = yyh_frag_issue(tb + ((16u * j) ^ fragswz));
+      asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]) : "n"(PD));
+      f32x16 acc[2];
 #pragma unroll
       for (int g4 = 0; g4 < 4; g4++) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bb + 8 * g4);
 #pragma unroll
         for (int e = 0; e < 2; e++) {
-          acc[e][4 * g4 + 0] = b4.x; acc[e][4 * g4 + 1] = b4.y; acc[e][4 * g4 + 2] = b4.z; acc[e][4 * g4 + 3] = b4.w;
+          acc[e][4 * g4 + 0] = b4[g4].x; acc[e][4 * g4 + 1] = b4[g4].y; acc[e][4 * g4 + 2] = b4[g4].z; acc[e][4 * g4 + 3] = b4[g4].w;
         }
       }
-      const _Float16 *arow = reinterpret_cast<const _Float16 *>(tile_ptr(buf) + col * LDWH) + h * NK;
 #pragma unroll
       for (int j = 0; j < KS; j++) {
-        const f16x8h af = *reinterpret_cast<const f16x8h *>(arow + 8 * j);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xh[0][j], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xh[1][j], acc[1], 0, 0, 0);
+        if (j + PD < KS) fr[(j + PD) % (PD + 1)] = yyh_frag_issue(tb + ((16u * (j + PD)) ^ fragswz));
+        const int behind = (KS - 1 - j) < PD ? (KS - 1 - j) : PD;
+        f16x8h &f = fr[j % (PD + 1)];
+        if (behind == 3) yyh_frag_wait<3>(f);
+        else if (behind == 2) yyh_frag_wait<2>(f);
+        else if (behind == 1) yyh_frag_wait<1>(f);
+        else yyh_frag_wait<0>(f);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, xh[0][j], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, xh[1][j], acc[1], 0, 0, 0);
+        {
+          const int slot = sub * KS + j;   // compile-time after unrolling
+          if (dma && slot % DSTR == 0 && slot / DSTR <= PPW) issue_piece(sp + 1, buf ^ 1, slot / DSTR);
+        }
+      }
+      if (sub == 1 && dma) {   // pieces the slots did not cover (very short rows)
+#pragma unroll
+        for (int i = (2 * KS - 1) / DSTR + 1; i <= PPW; i++) issue_piece(sp + 1, buf ^ 1, i);
+      }
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const float o1 = v1[e], o2 = v2[e];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float v = __uint_as_float((__float_as_uint(acc[e][r]) & ~15u) | (uint32_t)r);
+          v2[e] = __builtin_amdgcn_fmed3f(v1[e], v2[e], v);
+          v1[e] = fmaxf(v1[e], v);
+        }
+        const uint32_t n1 = (v1[e] == o1) ? t1[e] : ((v1[e] == o2) ? t2[e] : t);
+        const uint32_t n2 = (v2[e] == o1) ? t1[e] : ((v2[e] == o2) ? t2[e] : t);
+        t1[e] = n1;
+        t2[e] = n2;
       }
     }
-#pragma unroll
-    for (int e = 0; e < 2; e++) {
-      const float o1 = v1[e], o2 = v2[e];
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const float v = __uint_as_float((__float_as_uint(acc[e][r]) & ~15u) | (uint32_t)r);
-        v2[e] = __builtin_amdgcn_fmed3f(v1[e], v2[e], v);
-        v1[e] = fmaxf(v1[e], v);
-      }
-      const uint32_t n1 = (v1[e] == o1) ? t1[e] : ((v1[e] == o2) ? t2[e] : t);
-      const uint32_t n2 = (v2[e] == o1) ? t1[e] : ((v2[e] == o2) ? t2[e] : t);
-      t1[e] = n1;
-      t2[e] = n2;
-    }
-    if (t + 1 < ntiles) stage_store(buf ^ 1);
-    __syncthreads();
   }
 
 #pragma unroll
@@ -251,36 +327,87 @@ __global__ __launch_bounds__(256, 2) void yy_hint_kernel(YyArgs a) {
   }
 }
 
+#ifdef KMX_YYL_DBG
+// [0] wave cycles [1] prologue (rows, bounds fold) [2] flushes (count) [3] cycles in flushes [4] slow-path entries
+// (sub-tiles with a candidate) [5] cycles in the slow path (incl. its flushes) [6] cycles waiting (vmcnt + barrier) [7] epilogue
+__device__ unsigned long long kmx_yyl_dbg[8];
+extern "C" int kmamd_yyl_debug(unsigned long long *host8) {
+  unsigned long long z[8] = {0};
+  if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(kmx_yyl_dbg), sizeof(z)) != hipSuccess) return 4;
+  return hipMemcpyToSymbol(HIP_SYMBOL(kmx_yyl_dbg), z, sizeof(z)) == hipSuccess ? 0 : 4;
+}
+#endif
 // ---------------------------------------------------------------------------------------
 // the local filter against the estimate
 // ---------------------------------------------------------------------------------------
-// F16: the candidate sweep on the f16 matrix cores (hi halves only, like the estimate) with the
-// coarse Lloyd stage's rigorous bound on the dropped parts (lloyd_f16.hip): the
-// measured ||x' - hi(x')|| of the row and max ||c' - hi(c')|| of the panel (stats[5]).  !F16: the f32
-// matrix cores of yinyang_mfma.hip (KMCUDA_AMD_YY_HINT=2, cross-check).
-template <int DP, int METRIC, bool FAST, bool F16>
+// The candidate sweep runs on the f16 matrix cores (hi halves only, like the estimate) with the coarse Lloyd
+// stage's rigorous bound on the dropped parts (lloyd_f16.hip): the measured ||x' - hi(x')|| of the
+// row and max ||c' - hi(c')|| of the panel (stats[5]).  The panel streams like the Lloyd coarse stage's: 64-centroid
+// super-tiles by LDS-DMA (bank-swizzled by source address, biases behind the panel), double buffered, the next
+// super-tile's pieces issued between this one's matrix products, fragments read by hand with counted waits --
+// round 1 staged 32-centroid tiles through registers with a barrier each: 7900 wave cycles per tile for 512
+// cycles of products.
+template <int DP, int METRIC, bool FAST>
 __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
   constexpr int NK = DP / 2, KS = NK / 8;
-  constexpr int LDW = F16 ? DP / 2 + 4 : DP + 4;          // LDS row in 4-byte words
-  constexpr int TILE = 32 * LDW;
-  constexpr int NST = ((F16 ? 4 : 8) * DP + 255) / 256;    // 16-byte pieces of a tile per thread
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  auto tile_ptr = [&](int buf) { return lds + buf * TILE; };
-  auto bias_ptr = [&](int buf) { return lds + 2 * TILE + buf * 32; };
-  auto grp_ptr = [&](int buf) { return reinterpret_cast<uint32_t *>(lds + 2 * TILE + 64) + buf * 32; };
+  constexpr int ROWB = DP * 2;              // bytes of one panel row (DP hi halves)
+  constexpr int SUPB = 64 * ROWB;           // one super-tile: 64 centroids
+  constexpr int NP = SUPB / 1024;           // 1-KB LDS-DMA pieces per super-tile
+  constexpr int SWM = (KS < 16 ? KS : 16) - 1;
+  constexpr int WV = 4, PPW = (NP + WV - 1) / WV;
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds2[];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte *)lds2;
+  if (lds0 & 1023u) __builtin_trap();
+  const uint32_t bias0 = lds0 + 2 * SUPB;   // 2 x 64 floats
+  const uint32_t grp0 = bias0 + 512;        // 2 x 64 group numbers
 
   const uint32_t npassed = *a.count_ptr;
   if (blockIdx.x * 128u >= npassed) return;  // block-uniform
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+#ifdef KMX_YYL_DBG
+  unsigned long long dbg[8] = {0};
+  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
+#endif
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 31, h = lane >> 5;
   const uint32_t D = a.D, K = a.K, G = a.G, len = a.len;
   const uint32_t pi = blockIdx.x * 128u + wave * 32u + col;
   const bool live = pi < npassed;
   const uint32_t s = live ? a.passed[pi] : 0u;
 
-  KMX_YY_LOAD_ROWS(a.samples, s, live)
-  f16x8h xh[F16 ? KS : 1];
+  f16x8h xh[KS];
   float dx2 = 0.f;  // ||x' - hi(x')||^2, measured
-  if constexpr (F16) {
+  float xo2 = 0.f, xc2 = 0.f, xmu = 0.f;
+  const float *xrow = a.samples + (size_t)(live ? s : 0) * D;
+  if constexpr (FAST && DP >= 64) {
+    // coalesced through a per-wave LDS scratch (yinyang_tiles.hpp); the tile buffers are not in use yet
+    constexpr int CH = NK / 4;
+    const uint32_t s_any = live ? s : 0u;
+    yy_rows_staged<DP>(a.samples, reinterpret_cast<float *>(lds2), (uint32_t)wave * (32u * (DP / 4 + 4)), lane,
+                       [&](int r) { return (uint32_t)__shfl((int)s_any, r); },
+                       [&](int c, int k, f32x4 v) {
+                         const int jf = c * CH + 4 * k;   // first of four features of my half
+                         const f32x4 m4 = *reinterpret_cast<const f32x4 *>(a.mu + h * NK + jf);
+                         const float vv[4] = {v.x, v.y, v.z, v.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+                         for (int q = 0; q < 4; q++) {
+                           const float x = live ? vv[q] : 0.f;
+                           const float xc = live ? vv[q] - mm[q] : 0.f;
+                           xo2 = fmaf(x, x, xo2);
+                           xc2 = fmaf(xc, xc, xc2);
+                           xmu = fmaf(x, mm[q], xmu);
+                           const _Float16 hi = (_Float16)xc;
+                           const float r = xc - (float)hi;  // exact
+                           dx2 = fmaf(r, r, dx2);
+                           xh[(jf + q) / 8][(jf + q) % 8] = hi;
+                         }
+                       });
+    xo2 += __shfl_xor(xo2, 32);
+    xc2 += __shfl_xor(xc2, 32);
+    xmu += __shfl_xor(xmu, 32);
+    dx2 += __shfl_xor(dx2, 32);
+    __syncthreads();   // the scratch is tile buffer space: no DMA before every wave is done with it
+  } else {
+    KMX_YY_LOAD_ROWS_INTO(a.samples, s, live, xb, xo2, xc2, xmu)
 #pragma unroll
     for (int j = 0; j < KS; j++) {
       f16x8h v;
@@ -305,14 +432,15 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
   uint32_t why = bad ? 1u : 0u;   // statistics: first reason the row was handed over
 
   // (a) groups (bound >= upper bound) whose bound can still matter (<= S'): folded up front
-  second_min = low_bound_fold(a, s, h, cluster, upper_bound, hint, !bad);
+  uint32_t amask[4];
+  second_min = low_bound_fold(a, s, h, cluster, upper_bound, hint, !bad, amask);
 
   // threshold in accumulator space (yinyang_mfma.hip): a centroid can only matter if acc >= amin
   const float cmaxc = sqrtf(__uint_as_float(a.stats[0])) * 1.000001f;
   const float bmaxc = __uint_as_float(a.stats[1]);
   const float xo = sqrtf(xo2) * 1.0001f, xc = sqrtf(xc2) * 1.0001f;
   float e_mfma = 2.0f * a.eps * (xc * cmaxc + bmaxc) * 1.01f;
-  if constexpr (F16) {
+  {
     // x'.c' - hi(x').hi(c') = x'.dc + dx.c' - dx.dc, Cauchy-Schwarz on the measured residual norms; the
     // last term covers the absolute rounding of halves below the normal range
     const float dcmax = sqrtf(__uint_as_float(a.stats[5])) * 1.0001f;
@@ -334,60 +462,72 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
   };
   float amin = amin_of(fminf(second_min, hint));
 
-  f32x4 stage[NST];
-  float bstage = 0.f;
-  uint32_t gstage = 0;
-  constexpr int PIECES = (F16 ? 4 : 8) * DP;   // 16-byte pieces per tile
-  constexpr int PPR = F16 ? DP / 8 : DP / 4;    // ... per centroid row
-  auto stage_load = [&](uint32_t tile) {
-    const f32x4 *src = F16 ? reinterpret_cast<const f32x4 *>(reinterpret_cast<const _Float16 *>(a.panelhi) + (size_t)tile * 32 * DP)
-                           : reinterpret_cast<const f32x4 *>(a.cfil + (size_t)tile * 32 * DP);
-#pragma unroll
-    for (int i = 0; i < NST; i++) {
-      const int q = tid + i * 256;
-      if (q < PIECES) stage[i] = src[q];
+  const uint32_t nsuper = (a.K_pad + 63u) / 64u;
+  const float *biashi = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(a.panelhi) + (size_t)nsuper * SUPB);
+  // my i-th piece of super-tile sp (i = PPW: the 64 biases, wave 0).  Linear byte P of the super-tile lands in
+  // LDS at P and is fetched from source byte P ^ (((P / ROWB) & SWM) << 4) (lloyd_f16.hip)
+  auto issue_piece = [&](uint32_t sp, int buf, int i) {
+    if (i == PPW) {
+      if (wave == 0)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(biashi + sp * 64u + lane),
+                                         (__attribute__((address_space(3))) void *)(uintptr_t)(bias0 + buf * 256), 4, 0, 0);
+      return;
     }
-    if (tid < 32) {
-      const uint32_t c = tile * 32 + tid;
-      bstage = a.bias[c];
-      gstage = c < K ? a.groups[c] : 0xFFFFFFFFu;
+    if (i == PPW + 1) {   // the 64 centroids' groups (yy_configure pads the array to whole super-tiles)
+      if (wave == 1)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.groups + sp * 64u + lane),
+                                         (__attribute__((address_space(3))) void *)(uintptr_t)(grp0 + buf * 256), 4, 0, 0);
+      return;
     }
+    const int p = wave + WV * i;
+    if (p >= NP) return;   // wave-uniform
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(a.panelhi) + (size_t)sp * SUPB;
+    uint32_t P0 = (uint32_t)lane * 16u;
+    asm volatile("" : "+v"(P0));
+    const uint32_t P = (uint32_t)p * 1024u + P0;
+    const uint32_t from = P ^ (((P / ROWB) & SWM) << 4);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + from),
+                                     (__attribute__((address_space(3))) void *)(uintptr_t)(lds0 + buf * SUPB + p * 1024), 16, 0, 0);
   };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NST; i++) {
-      const int q = tid + i * 256;
-      if (q < PIECES) {
-        const int row = q / PPR, c4 = q % PPR;
-        *reinterpret_cast<f32x4 *>(tile_ptr(buf) + row * LDW + c4 * 4) = stage[i];
-      }
-    }
-    if (tid < 32) {
-      bias_ptr(buf)[tid] = bstage;
-      grp_ptr(buf)[tid] = gstage;
-    }
-  };
+  const uint32_t fragbase = lds0 + (uint32_t)col * ROWB + (uint32_t)h * (KS * 16);
+  const uint32_t fragswz = (uint32_t)(col & SWM) * 16u;
 
   // queue of candidates (ascending c)
   uint32_t qc[4] = {0, 0, 0, 0};
   int qn = 0;
   uint32_t n_flush = 0, n_cand = 0;
-  auto flush = [&]() {  // wave-uniform call
+  auto flush = [&](auto deep_c) {  // wave-uniform call; deep_c: std::true_type for the wave's last flush
+    constexpr bool DEEPF = decltype(deep_c)::value;
     n_flush++;
+#ifdef KMX_YYL_DBG
+    const unsigned long long f0 = __builtin_amdgcn_s_memtime();
+    dbg[2]++;
+#endif
     const float *crow[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) crow[i] = a.centroids + (size_t)(i < qn ? qc[i] : 0) * D;
+    // what the replay below needs of each queued centroid, requested BEFORE the chains run: the group's bound
+    // and drift, the centroid's drift (kmeans.cu:637) -- fetched one dependent load after the other inside the
+    // replay they were 40 % of a flush
+    float lbq[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      lbq[i] = 0.f;
+      if (i < qn) {
+        const uint32_t c = qc[i];
+        const uint32_t g = a.groups[c];
+        lbq[i] = a.bounds[(size_t)len * (1 + g) + s] + (a.gdrifts[g] - a.drifts[(size_t)K * D + c]);
+      }
+    }
     float dist[4];
     // the fullest queue of the wave sets how many candidate rows are gathered (a row has 0.2 - 2 real ones)
     const int nq = __ballot(qn >= 4) ? 4 : (__ballot(qn >= 3) ? 3 : (__ballot(qn >= 2) ? 2 : 1));
-    exact_distance4<NK, METRIC, FAST>(xrow, crow, D, h, col, dist, nq);
+    exact_distance4<NK, METRIC, FAST, DEEPF>(xrow, crow, D, h, col, dist, nq, qn);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       if (i < qn) {
         const uint32_t c = qc[i];
-        const uint32_t g = a.groups[c];
-        float lb = a.bounds[(size_t)len * (1 + g) + s];
-        lb += a.gdrifts[g] - a.drifts[(size_t)K * D + c];    // kmeans.cu:637
+        const float lb = lbq[i];                             // kmeans.cu:637
         if (!(second_min < lb)) {                            // :638-640
           if (lb > hint) {                                   // F1: the reference may have skipped it
             bad = true;
@@ -409,74 +549,141 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
     }
     qn = 0;
     amin = amin_of(fminf(second_min, hint));
+#ifdef KMX_YYL_DBG
+    asm volatile("" :: "v"(amin));
+    dbg[3] += __builtin_amdgcn_s_memtime() - f0;
+#endif
   };
 
-  const uint32_t ntiles = a.K_pad / 32;
   const bool wave_live = __ballot(live && !bad) != 0ull;
-  stage_load(0);
-  stage_store(0);
-  __syncthreads();
-  for (uint32_t t = 0; t < ntiles; t++) {
-    const int buf = t & 1;
-    if (t + 1 < ntiles) stage_load(t + 1);
+#ifdef KMX_YYL_DBG
+  asm volatile("" :: "v"(amin), "v"(second_min));
+  dbg[1] = __builtin_amdgcn_s_memtime() - dbg_t0;
+#endif
+#pragma unroll
+  for (int i = 0; i <= PPW + 1; i++) issue_piece(0, 0, i);
+  constexpr int DSTR = (2 * KS) / (PPW + 2) > 0 ? (2 * KS) / (PPW + 2) : 1;   // a piece every DSTR k-steps
+  for (uint32_t sp = 0; sp < nsuper; sp++) {
+    const int buf = sp & 1;
+#ifdef KMX_YYL_DBG
+    const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of super-tile sp have landed
+    __builtin_amdgcn_s_barrier();                      // everybody's have, and everybody is done with sp - 1
+    asm volatile("" ::: "memory");
+#ifdef KMX_YYL_DBG
+    dbg[6] += __builtin_amdgcn_s_memtime() - w0;
+#endif
+    const bool dma = sp + 1 < nsuper;
+    if (dma && !wave_live) {
+#pragma unroll
+      for (int i = 0; i <= PPW + 1; i++) issue_piece(sp + 1, buf ^ 1, i);
+    }
     if (wave_live) {
-      f32x16 acc;
-      if constexpr (F16) {
-        const float *bb = bias_ptr(buf) + 4 * h;
+#pragma unroll
+      for (int sub = 0; sub < 2; sub++) {
+        const uint32_t tb = fragbase + (uint32_t)buf * SUPB + (uint32_t)sub * (32 * ROWB);
+        const uint32_t bb = bias0 + (uint32_t)buf * 256u + (uint32_t)sub * 128u + 16u * h;
+        f32x4 b4[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) b4[g4] = yyh_lds_read4(bb + 32u * g4);
+        constexpr int PD = KS < 4 ? KS : 4;   // fragments in flight
+        f16x8h fr[PD + 1];
+#pragma unroll
+        for (int j = 0; j < PD; j++) fr[j] = yyh_frag_issue(tb + ((16u * j) ^ fragswz));
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]) : "n"(PD));
+        f32x16 acc;
 #pragma unroll
         for (int g4 = 0; g4 < 4; g4++) {
-          const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bb + 8 * g4);
-          acc[4 * g4 + 0] = b4.x; acc[4 * g4 + 1] = b4.y; acc[4 * g4 + 2] = b4.z; acc[4 * g4 + 3] = b4.w;
+          acc[4 * g4 + 0] = b4[g4].x; acc[4 * g4 + 1] = b4[g4].y; acc[4 * g4 + 2] = b4[g4].z; acc[4 * g4 + 3] = b4[g4].w;
         }
-        const _Float16 *arow = reinterpret_cast<const _Float16 *>(tile_ptr(buf) + col * LDW) + h * NK;
 #pragma unroll
         for (int j = 0; j < KS; j++) {
-          const f16x8h af = *reinterpret_cast<const f16x8h *>(arow + 8 * j);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xh[j], acc, 0, 0, 0);
+          if (j + PD < KS) fr[(j + PD) % (PD + 1)] = yyh_frag_issue(tb + ((16u * (j + PD)) ^ fragswz));
+          const int behind = (KS - 1 - j) < PD ? (KS - 1 - j) : PD;
+          f16x8h &f = fr[j % (PD + 1)];
+          if (behind == 4) yyh_frag_wait<4>(f);
+          else if (behind == 3) yyh_frag_wait<3>(f);
+          else if (behind == 2) yyh_frag_wait<2>(f);
+          else if (behind == 1) yyh_frag_wait<1>(f);
+          else yyh_frag_wait<0>(f);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, xh[j], acc, 0, 0, 0);
+          {
+            const int slot = sub * KS + j;   // compile-time after unrolling
+            if (dma && slot % DSTR == 0 && slot / DSTR <= PPW + 1) issue_piece(sp + 1, buf ^ 1, slot / DSTR);
+          }
         }
-      } else {
-        KMX_YY_MFMA_TILE(acc32, buf)
-        acc = acc32;
-      }
-      uint32_t m16 = 0;
-      if (live && !bad) {
+        if (sub == 1 && dma) {   // pieces the slots did not cover (very short rows)
 #pragma unroll
-        for (int r = 0; r < 16; r++)
-          if (acc[r] >= amin) m16 |= 1u << r;
-      }
-      if (__ballot(m16 != 0u) != 0ull) {
-        const uint32_t pm = __shfl_xor(m16, 32);
-        const uint32_t m0 = h ? pm : m16, m1 = h ? m16 : pm;
-        uint32_t rowmask = 0;
+          for (int i = (2 * KS - 1) / DSTR + 1; i <= PPW + 1; i++) issue_piece(sp + 1, buf ^ 1, i);
+        }
+        // the sub-tile's best score first: most sub-tiles hold no candidate for any row of the wave
+        bool some = false;
+        if (live && !bad) {
+          const float m0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
+          const float m1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
+          const float m2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]);
+          const float m3 = __builtin_fmaxf(__builtin_fmaxf(acc[9], acc[10]), acc[11]);
+          const float m4 = __builtin_fmaxf(__builtin_fmaxf(acc[12], acc[13]), acc[14]);
+          const float m5 = __builtin_fmaxf(__builtin_fmaxf(m0, m1), acc[15]);
+          const float m6 = __builtin_fmaxf(__builtin_fmaxf(m2, m3), m4);
+          some = __builtin_fmaxf(m5, m6) >= amin;
+        }
+        if (__ballot(some) != 0ull) {
+#ifdef KMX_YYL_DBG
+          const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+          dbg[4]++;
+#endif
+          uint32_t m16 = 0;
+          if (some) {
 #pragma unroll
-        for (int g4 = 0; g4 < 4; g4++)
-          rowmask |= (((m0 >> (4 * g4)) & 0xFu) << (8 * g4)) | (((m1 >> (4 * g4)) & 0xFu) << (8 * g4 + 4));
-        while (__ballot(rowmask != 0u) != 0ull) {
-          if (__ballot(qn == 4) != 0ull) flush();  // some row's queue is full
-          const bool active = rowmask != 0u;
-          const uint32_t rho = active ? (uint32_t)__ffs((int)rowmask) - 1u : 0u;
-          rowmask &= rowmask - 1u;
-          if (active) {
-            const uint32_t c = t * 32 + rho;
-            const uint32_t g = grp_ptr(buf)[rho];
-            if (g < G && c != cluster) {  // g >= G: NaN centroid or padding
-              const float lbg = a.bounds[(size_t)len * (1 + g) + s];
-              if (!(lbg >= upper_bound)) {  // else an (a) centroid: an event if its bound is <= S'
+            for (int r = 0; r < 16; r++)
+              if (acc[r] >= amin) m16 |= 1u << r;
+          }
+          const uint32_t pm = __shfl_xor(m16, 32);
+          const uint32_t m0 = h ? pm : m16, m1 = h ? m16 : pm;
+          uint32_t rowmask = 0;
 #pragma unroll
-                for (int i = 0; i < 4; i++)
-                  if (i == qn) qc[i] = c;
-                qn++;
-                n_cand++;
+          for (int g4 = 0; g4 < 4; g4++)
+            rowmask |= (((m0 >> (4 * g4)) & 0xFu) << (8 * g4)) | (((m1 >> (4 * g4)) & 0xFu) << (8 * g4 + 4));
+          while (__ballot(rowmask != 0u) != 0ull) {
+            if (__ballot(qn == 4) != 0ull) flush(std::false_type());  // some row's queue is full
+            const bool active = rowmask != 0u;
+            const uint32_t rho = active ? (uint32_t)__ffs((int)rowmask) - 1u : 0u;
+            rowmask &= rowmask - 1u;
+            if (active) {
+              const uint32_t c = sp * 64u + (uint32_t)sub * 32u + rho;
+              const uint32_t g = yyh_lds_read1(grp0 + (uint32_t)buf * 256u + ((uint32_t)sub * 32u + rho) * 4u);
+              if (g < G && c != cluster) {  // g >= G: NaN centroid or padding
+                bool a_group;               // (a): group bound >= upper bound
+                if (G <= 128u) {
+                  const uint32_t word = g < 32u ? amask[0] : (g < 64u ? amask[1] : (g < 96u ? amask[2] : amask[3]));
+                  a_group = (word >> (g & 31u)) & 1u;
+                } else {
+                  a_group = a.bounds[(size_t)len * (1 + g) + s] >= upper_bound;
+                }
+                if (!a_group) {  // else an (a) centroid: an event if its bound is <= S'
+#pragma unroll
+                  for (int i = 0; i < 4; i++)
+                    if (i == qn) qc[i] = c;
+                  qn++;
+                  n_cand++;
+                }
               }
             }
           }
+#ifdef KMX_YYL_DBG
+          asm volatile("" :: "v"(qn));
+          dbg[5] += __builtin_amdgcn_s_memtime() - s0;
+#endif
         }
       }
     }
-    if (t + 1 < ntiles) stage_store(buf ^ 1);
-    __syncthreads();
   }
-  if (wave_live && __ballot(qn > 0) != 0ull) flush();
+#ifdef KMX_YYL_DBG
+  const unsigned long long e0 = __builtin_amdgcn_s_memtime();
+#endif
+  if (wave_live && __ballot(qn > 0) != 0ull) flush(std::true_type());
   if (!(second_min <= hint)) {  // F2: the reference's second minimum may be a value we never saw
     bad = true;
     if (!why) why = 4u;
@@ -528,6 +735,12 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
         if (nwhy[w]) atomicAdd(&a.counters[8 + w], nwhy[w]);
     }
   }
+#ifdef KMX_YYL_DBG
+  dbg[0] = __builtin_amdgcn_s_memtime() - dbg_t0;
+  dbg[7] = __builtin_amdgcn_s_memtime() - e0;
+  if (lane == 0)
+    for (int i = 0; i < 8; i++) atomicAdd(&kmx_yyl_dbg[i], dbg[i]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -537,7 +750,19 @@ bool yy_hint_supported(uint32_t DP) { return DP >= 16 && DP <= 256; }
 
 template <int DP, int METRIC>
 static hipError_t launch_hint_t(const YyArgs &a, hipStream_t st) {
-  const size_t lds_bytes = (2 * 32 * (DP / 2 + 4) + 64) * sizeof(float);
+  const size_t lds_bytes = 2 * 64 * DP * 2 + 512;
+  if (lds_bytes > 65536) {
+    static bool raised = false;   // per instantiation
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&yy_hint_kernel<DP, METRIC, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&yy_hint_kernel<DP, METRIC, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) return e;
+      raised = true;
+    }
+  }
   const uint32_t grid = (a.len + 255) / 256;  // worst case; blocks beyond the passed count exit at once
   if (a.D == (uint32_t)DP)
     hipLaunchKernelGGL((yy_hint_kernel<DP, METRIC, true>), dim3(grid), dim3(256), lds_bytes, st, a);
@@ -548,19 +773,23 @@ static hipError_t launch_hint_t(const YyArgs &a, hipStream_t st) {
 template <int DP, int METRIC>
 static hipError_t launch_local_hint_t(const YyArgs &a, hipStream_t st) {
   const uint32_t grid = (a.len + 127) / 128;
-  if (a.hint_f32_sweep) {
-    const size_t lds_bytes = (2 * 32 * (DP + 4) + 64 + 64) * sizeof(float);
-    if (a.D == (uint32_t)DP)
-      hipLaunchKernelGGL((yy_local_hint_kernel<DP, METRIC, true, false>), dim3(grid), dim3(256), lds_bytes, st, a);
-    else
-      hipLaunchKernelGGL((yy_local_hint_kernel<DP, METRIC, false, false>), dim3(grid), dim3(256), lds_bytes, st, a);
-  } else {
-    const size_t lds_bytes = (2 * 32 * (DP / 2 + 4) + 64 + 64) * sizeof(float);
-    if (a.D == (uint32_t)DP)
-      hipLaunchKernelGGL((yy_local_hint_kernel<DP, METRIC, true, true>), dim3(grid), dim3(256), lds_bytes, st, a);
-    else
-      hipLaunchKernelGGL((yy_local_hint_kernel<DP, METRIC, false, true>), dim3(grid), dim3(256), lds_bytes, st, a);
+  const size_t lds_bytes = 2 * 64 * DP * 2 + 1024;
+  if (lds_bytes > 65536) {
+    static bool raised = false;   // per instantiation
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&yy_local_hint_kernel<DP, METRIC, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&yy_local_hint_kernel<DP, METRIC, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) return e;
+      raised = true;
+    }
   }
+  if (a.D == (uint32_t)DP)
+    hipLaunchKernelGGL((yy_local_hint_kernel<DP, METRIC, true>), dim3(grid), dim3(256), lds_bytes, st, a);
+  else
+    hipLaunchKernelGGL((yy_local_hint_kernel<DP, METRIC, false>), dim3(grid), dim3(256), lds_bytes, st, a);
   return hipGetLastError();
 }
 

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void yy_init_lds_kernel(YyArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; i++) crow[i] = a.centroids + (size_t)(has ? nearest : 0) * D;
       float dist[4];
-      exact_distance4<NK, METRIC, FAST>(xrow, crow, D, h, col, dist, 1);
+      exact_distance4<NK, METRIC, FAST>(xrow, crow, D, h, col, dist, 1, has ? 1 : 0);
       if (has) upper = dist[0];
     }
   }

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void yy_local_mfma_kernel(YyArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; i++) crow[i] = a.centroids + (size_t)(i < qn ? qc[i] : 0) * D;
     float dist[4];
-    exact_distance4<NK, METRIC, FAST>(xrow, crow, D, h, col, dist);
+    exact_distance4<NK, METRIC, FAST>(xrow, crow, D, h, col, dist, 4, qn);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       if (i < qn) {
