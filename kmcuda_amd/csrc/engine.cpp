@@ -245,6 +245,7 @@ static void fill_yy_args(Engine &e, YyArgs &a, const float *samples, const float
   a.groups = e.groups_; a.drifts = nullptr; a.gdrifts = nullptr; a.assignments = nullptr; a.bounds = nullptr;
   a.passed = nullptr; a.counters = e.counters_; a.count_ptr = e.counters_ + 2;
   a.panelhi = nullptr; a.hint = nullptr; a.flag_rows = nullptr; a.gfirst = e.gfirst_; a.gsecond = e.gsecond_;
+  a.xcache = nullptr; a.xmeta = nullptr;
   a.pfil = e.pfil_; a.pbias = e.pbias_; a.pids = e.pids_; a.pmeta = e.pmeta_; a.cperm = e.cperm_;
   a.gstart = e.gstart_; a.nslots = e.nslots_;
 }
@@ -325,6 +326,11 @@ int Engine::yy_filters(const float *samples, const float *centroids, const float
               kRuntimeError);
       KMX_HIP(hipMemsetAsync(counters_ + 5, 0, sizeof(uint32_t), stream_), kRuntimeError);
       a.panelhi = yy_panelhi_; a.hint = yy_hint_buf_; a.flag_rows = yy_flag_rows_;
+      // the coarse Lloyd stage's row cache holds exactly the sweeps' B operands when it was built for this mean
+      if (row_cache_on_ && row_cache_valid_ && mu_frozen_ && xcache_ && metric_ == 0 && D_ == DP_) {
+        a.xcache = xcache_;
+        a.xmeta = xmeta_;
+      }
       KMX_HIP(launch_yy_hint(metric_, a, stream_), kRuntimeError);
       KMX_HIP(launch_yy_local_hint(metric_, a, stream_), kRuntimeError);
       a.passed = yy_flag_rows_;

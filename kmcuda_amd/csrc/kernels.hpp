@@ -150,6 +150,8 @@ struct YyArgs {
   uint32_t *counters;        // + [5] rows of the hinted kernel handed to the plain one, [6] / [7] running totals
   // hinted local filter (yinyang_hint.hip)
   const void *panelhi;       // hi halves of the centred panel (centroid_panelhi_kernel), DP halves per row
+  const void *xcache;        // the engine's row cache (lloyd_f16.hip: row_cache_kernel) for the SAME mean, or null:
+  const float *xmeta;        //   hi halves of x - mu in operand order + (||x'||^2, ||x' - hi(x')||^2) per row
   float *hint;               // per passed row: S' >= upper bound (or +inf: no hint)
   uint32_t *flag_rows;       // rows the hinted kernel could not settle
   const uint32_t *gfirst, *gsecond;  // G: the two smallest member indices of every group (0xFFFFFFFF: none)

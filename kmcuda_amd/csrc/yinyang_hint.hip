@@ -157,28 +157,46 @@ __global__ __launch_bounds__(256, 2) void yy_hint_kernel(YyArgs a) {
 
   f16x8h xh[2][KS];
   float xc2[2], xmu[2];
+  if (FAST && METRIC == 0 && a.xcache) {   // block-uniform: the Lloyd coarse stage's row cache (see yy_local_hint_kernel)
 #pragma unroll
-  for (int e = 0; e < 2; e++) {
-    float xc2e, xmue;
-    {
-      KMX_YY_LOAD_ROWS(a.samples, s[e], live[e])
-      (void)xo2; (void)xrow;
+    for (int e = 0; e < 2; e++) {
+      const uint32_t sr = live[e] ? s[e] : 0u;
+      const f16x8h *src = reinterpret_cast<const f16x8h *>(a.xcache) + (size_t)(sr >> 5) * KS * 64 + (sr & 31u) + 32u * h;
 #pragma unroll
       for (int j = 0; j < KS; j++) {
-        f16x8h v;
+        xh[e][j] = src[(size_t)j * 64];
+        if (!live[e]) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = (_Float16)xb[8 * j + q];
-        xh[e][j] = v;
+          for (int q = 0; q < 8; q++) xh[e][j][q] = (_Float16)0.f;
+        }
       }
-      xc2e = xc2;
-      xmue = xmu;
+      xc2[e] = live[e] ? reinterpret_cast<const float2 *>(a.xmeta)[sr].x : 0.f;
+      xmu[e] = 0.f;   // angular only
     }
-    xc2[e] = xc2e;
-    xmu[e] = xmue;
-    // one set at a time: both sets' fp32 rows in flight at once would not fit the register file
+  } else {
 #pragma unroll
-    for (int j = 0; j < KS; j++) asm volatile("" : "+v"(xh[e][j]));
-    __builtin_amdgcn_sched_barrier(0);
+    for (int e = 0; e < 2; e++) {
+      float xc2e, xmue;
+      {
+        KMX_YY_LOAD_ROWS(a.samples, s[e], live[e])
+        (void)xo2; (void)xrow;
+#pragma unroll
+        for (int j = 0; j < KS; j++) {
+          f16x8h v;
+#pragma unroll
+          for (int q = 0; q < 8; q++) v[q] = (_Float16)xb[8 * j + q];
+          xh[e][j] = v;
+        }
+        xc2e = xc2;
+        xmue = xmu;
+      }
+      xc2[e] = xc2e;
+      xmu[e] = xmue;
+      // one set at a time: both sets' fp32 rows in flight at once would not fit the register file
+#pragma unroll
+      for (int j = 0; j < KS; j++) asm volatile("" : "+v"(xh[e][j]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
   const uint32_t nsuper = (a.K_pad + 63u) / 64u;
@@ -378,7 +396,23 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
   float dx2 = 0.f;  // ||x' - hi(x')||^2, measured
   float xo2 = 0.f, xc2 = 0.f, xmu = 0.f;
   const float *xrow = a.samples + (size_t)(live ? s : 0) * D;
-  if constexpr (FAST && DP >= 64) {
+  if (FAST && METRIC == 0 && a.xcache) {   // block-uniform
+    // the Lloyd coarse stage's row cache: hi(x - mu) in operand order, 2 D bytes per row instead of 4 D, nothing
+    // to convert; its records carry the two norms the L2 bound needs (x.mu and ||x|| are angular-only)
+    const uint32_t sr = live ? s : 0u;
+    const f16x8h *src = reinterpret_cast<const f16x8h *>(a.xcache) + (size_t)(sr >> 5) * KS * 64 + (sr & 31u) + 32u * h;
+#pragma unroll
+    for (int j = 0; j < KS; j++) {
+      xh[j] = src[(size_t)j * 64];
+      if (!live) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) xh[j][q] = (_Float16)0.f;
+      }
+    }
+    const float2 m = reinterpret_cast<const float2 *>(a.xmeta)[sr];
+    xc2 = live ? m.x : 0.f;
+    dx2 = live ? (m.y < 0.f ? INFINITY : m.y) : 0.f;   // -1: a NaN first feature -- no bound, the plain kernel's row
+  } else if constexpr (FAST && DP >= 64) {
     // coalesced through a per-wave LDS scratch (yinyang_tiles.hpp); the tile buffers are not in use yet
     constexpr int CH = NK / 4;
     const uint32_t s_any = live ? s : 0u;

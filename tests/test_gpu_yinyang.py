@@ -90,7 +90,7 @@ def test_yinyang_steps_bit_exact(n, d, k, G, metric, mode, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("hint", ["f16", "off"])
+@pytest.mark.parametrize("hint", ["f16", "f16cache", "off"])
 @pytest.mark.parametrize("n,d,k,G,data", [(6000, 256, 256, 25, "uniform"), (8000, 64, 100, 10, "uniform"),
                                           (5000, 16, 64, 6, "uniform"), (6000, 256, 128, 12, "blobs"),
                                           (4000, 100, 60, 6, "blobs"), (3000, 24, 200, 20, "uniform")])
@@ -98,10 +98,11 @@ def test_yinyang_many_passes_bit_exact(n, d, k, G, data, hint, monkeypatch):
     """Six consecutive update + drift + filter passes against the oracle: bounds, assignments and
     the passed set stay BIT-EXACT from pass to pass, with the local filter's second-best estimate
     (yinyang_hint.hip: estimate kernel, hinted kernel, plain kernel for the rows it hands over) and
-    without it (KMCUDA_AMD_YY_HINT=0: the f32 matrix-core kernel of yinyang_mfma.hip alone, the cross-check)."""
+    without it (KMCUDA_AMD_YY_HINT=0: the f32 matrix-core kernel of yinyang_mfma.hip alone, the cross-check);
+    "f16cache": the hinted kernels take their operands from the engine's row cache."""
     from kmcuda_amd.engine import Engine
     monkeypatch.setenv("KMCUDA_AMD_YY_EXACT", "0")
-    monkeypatch.setenv("KMCUDA_AMD_YY_HINT", {"f16": "1", "off": "0"}[hint])
+    monkeypatch.setenv("KMCUDA_AMD_YY_HINT", {"f16": "1", "f16cache": "1", "off": "0"}[hint])
     dev = torch.device("cuda", 0)
     rs = numpy.random.RandomState(n + d + k)
     if data == "uniform":
@@ -120,6 +121,14 @@ def test_yinyang_many_passes_bit_exact(n, d, k, G, data, hint, monkeypatch):
     eng = Engine(n, d, k, "L2", device=0)
     eng.yy_configure(G, groups)
     xs = _t(x, dev)
+    if hint == "f16cache":
+        # the sweeps' operands from the Lloyd coarse stage's row cache (what a kmeans_cuda() run has by the
+        # time Yinyang starts): one assignment pass builds it and freezes the mean
+        eng.set_row_cache(True)
+        tmp_a = torch.zeros(n, dtype=torch.int32, device=dev)
+        tmp_p = torch.zeros(n, dtype=torch.int32, device=dev)
+        eng.lloyd_assign(xs, _t(cen, dev), tmp_a, tmp_p)
+        eng.sync()
     gb = _t(bounds.ravel().copy(), dev)
     gasg = _t(asg, dev)
     gprev = torch.empty(n, dtype=torch.int32, device=dev)
