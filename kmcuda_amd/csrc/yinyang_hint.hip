@@ -345,6 +345,11 @@ __global__ __launch_bounds__(256, 2) void yy_hint_kernel(YyArgs a) {
   }
 }
 
+#ifdef KMX_STAMPS
+extern "C" int kmamd_stamps(unsigned long long *host64) {
+  return hipMemcpyFromSymbol(host64, HIP_SYMBOL(kmx_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : 4;
+}
+#endif
 #ifdef KMX_YYL_DBG
 // [0] wave cycles [1] prologue (rows, bounds fold) [2] flushes (count) [3] cycles in flushes [4] slow-path entries
 // (sub-tiles with a candidate) [5] cycles in the slow path (incl. its flushes) [6] cycles waiting (vmcnt + barrier) [7] epilogue
@@ -386,11 +391,21 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
   unsigned long long dbg[8] = {0};
   const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef KMX_STAMPS
+  const bool stamp_on = blockIdx.x == 20000u && threadIdx.x == 0;
+  KMX_STAMP(stamp_on, 0);
+#else
+  const bool stamp_on = false; (void)stamp_on;
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 31, h = lane >> 5;
   const uint32_t D = a.D, K = a.K, G = a.G, len = a.len;
   const uint32_t pi = blockIdx.x * 128u + wave * 32u + col;
   const bool live = pi < npassed;
   const uint32_t s = live ? a.passed[pi] : 0u;
+#ifdef KMX_STAMPS
+  asm volatile("" :: "v"(s));
+  KMX_STAMP(stamp_on, 1);
+#endif
 
   f16x8h xh[KS];
   float dx2 = 0.f;  // ||x' - hi(x')||^2, measured
@@ -457,6 +472,10 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
     dx2 += __shfl_xor(dx2, 32);
   }
 
+#ifdef KMX_STAMPS
+  asm volatile("" :: "v"(xh[0]), "v"(xh[KS - 1]), "v"(xc2), "v"(dx2));
+  KMX_STAMP(stamp_on, 2);
+#endif
   const float upper_bound = live ? a.bounds[s] : 0.f;
   const uint32_t cluster = live ? a.assignments[s] : 0xFFFFFFFFu;
   const float hint = live ? a.hint[s] : INFINITY;
@@ -543,6 +562,7 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
     // what the replay below needs of each queued centroid, requested BEFORE the chains run: the group's bound
     // and drift, the centroid's drift (kmeans.cu:637) -- fetched one dependent load after the other inside the
     // replay they were 40 % of a flush
+    KMX_STAMP(stamp_on && DEEPF, 5);
     float lbq[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -556,7 +576,13 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
     float dist[4];
     // the fullest queue of the wave sets how many candidate rows are gathered (a row has 0.2 - 2 real ones)
     const int nq = __ballot(qn >= 4) ? 4 : (__ballot(qn >= 3) ? 3 : (__ballot(qn >= 2) ? 2 : 1));
-    exact_distance4<NK, METRIC, FAST, DEEPF>(xrow, crow, D, h, col, dist, nq, qn);
+    KMX_STAMP(stamp_on && DEEPF, 6);
+    exact_distance4<NK, METRIC, FAST, DEEPF>(xrow, crow, D, h, col, dist, nq, qn, stamp_on && DEEPF);
+#ifdef KMX_STAMPS
+    asm volatile("" :: "v"(dist[0]));
+    KMX_STAMP(stamp_on && DEEPF, 40);
+    if (stamp_on && DEEPF) kmx_stamps[43] = (unsigned long long)nq;
+#endif
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       if (i < qn) {
@@ -583,6 +609,10 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
     }
     qn = 0;
     amin = amin_of(fminf(second_min, hint));
+#ifdef KMX_STAMPS
+    asm volatile("" :: "v"(amin));
+    KMX_STAMP(stamp_on && DEEPF, 41);
+#endif
 #ifdef KMX_YYL_DBG
     asm volatile("" :: "v"(amin));
     dbg[3] += __builtin_amdgcn_s_memtime() - f0;
@@ -590,6 +620,10 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
   };
 
   const bool wave_live = __ballot(live && !bad) != 0ull;
+#ifdef KMX_STAMPS
+  asm volatile("" :: "v"(amin), "v"(second_min));
+  KMX_STAMP(stamp_on, 3);
+#endif
 #ifdef KMX_YYL_DBG
   asm volatile("" :: "v"(amin), "v"(second_min));
   dbg[1] = __builtin_amdgcn_s_memtime() - dbg_t0;
@@ -717,7 +751,12 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
 #ifdef KMX_YYL_DBG
   const unsigned long long e0 = __builtin_amdgcn_s_memtime();
 #endif
+  KMX_STAMP(stamp_on, 4);
   if (wave_live && __ballot(qn > 0) != 0ull) flush(std::true_type());
+#ifdef KMX_STAMPS
+  asm volatile("" :: "v"(second_min), "v"(min_dist));
+  KMX_STAMP(stamp_on, 42);
+#endif
   if (!(second_min <= hint)) {  // F2: the reference's second minimum may be a value we never saw
     bad = true;
     if (!why) why = 4u;
