@@ -77,31 +77,37 @@ __device__ __forceinline__ float low_bound_fold(const YyArgs &a, uint32_t s, int
   if (__ballot(on) != 0ull) {
     float mine = kFltMax;
     if (on) {
-      // the bounds of the first 128 groups are all requested before the first is looked at (one memory round
-      // trip instead of eight); further groups in batches of eight per lane
-      float lbv[8][8];
-#pragma unroll
-      for (int it = 0; it < 8; it++) {
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const uint32_t g = (uint32_t)h + 16u * it + 2u * q;
-          lbv[it][q] = g < G ? a.bounds[(size_t)len * (1 + g) + s] : -INFINITY;
-        }
-      }
-      auto look = [&](float lb, uint32_t g) {
+      // The bounds of 16 groups at a time -- and the two smallest members of each, which decide whether the reference's
+      // scan meets the group at all -- are requested before the first is looked at, and looked at without a
+      // branch: as a conditional load of gfirst / gsecond per qualifying group the fold was a chain of
+      // dependent round trips (29 K of a wave's 167 K cycles, profiles/r2m_*timeline*).
+      auto look = [&](float lb, uint32_t g, uint32_t gf, uint32_t gs) {
         const uint32_t bit = (lb >= upper_bound && g < 128u) ? 1u << (g & 31u) : 0u;
 #pragma unroll
         for (int w = 0; w < 4; w++) amask[w] |= (g >> 5) == (uint32_t)w ? bit : 0u;
-        if (lb >= upper_bound && lb <= hint && lb < mine) {
-          uint32_t p = a.gfirst[g];
-          if (p == cluster) p = a.gsecond[g];
-          if (p != 0xFFFFFFFFu) mine = lb;  // the group has a member the reference's scan meets
-        }
+        const uint32_t p = gf == cluster ? gs : gf;   // 0xFFFFFFFF: no member the scan meets
+        if (lb >= upper_bound && lb <= hint && lb < mine && p != 0xFFFFFFFFu) mine = lb;
       };
+#pragma unroll 1
+      for (int half = 0; half < 4; half++) {   // four batches of 16 groups per lane (rolled: 48 registers, not 192)
+        float lbv[2][8];
+        uint32_t gfv[2][8], gsv[2][8];
 #pragma unroll
-      for (int it = 0; it < 8; it++) {
+        for (int it = 0; it < 2; it++) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) look(lbv[it][q], (uint32_t)h + 16u * it + 2u * q);
+          for (int q = 0; q < 8; q++) {
+            const uint32_t g = (uint32_t)h + 16u * (2 * half + it) + 2u * q;
+            lbv[it][q] = g < G ? a.bounds[(size_t)len * (1 + g) + s] : -INFINITY;
+            gfv[it][q] = g < G ? a.gfirst[g] : 0xFFFFFFFFu;
+            gsv[it][q] = g < G ? a.gsecond[g] : 0xFFFFFFFFu;
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+#pragma unroll
+          for (int q = 0; q < 8; q++)
+            look(lbv[it][q], (uint32_t)h + 16u * (2 * half + it) + 2u * q, gfv[it][q], gsv[it][q]);
+        }
       }
       for (uint32_t g0 = 128u + h; g0 < G; g0 += 16) {
         float lb8[8];
@@ -111,7 +117,10 @@ __device__ __forceinline__ float low_bound_fold(const YyArgs &a, uint32_t s, int
           lb8[q] = g < G ? a.bounds[(size_t)len * (1 + g) + s] : -INFINITY;
         }
 #pragma unroll
-        for (int q = 0; q < 8; q++) look(lb8[q], g0 + 2 * q);
+        for (int q = 0; q < 8; q++) {
+          const uint32_t g = g0 + 2 * q;
+          look(lb8[q], g, g < G ? a.gfirst[g] : 0xFFFFFFFFu, g < G ? a.gsecond[g] : 0xFFFFFFFFu);
+        }
       }
     }
     const float other = __shfl_xor(mine, 32);
