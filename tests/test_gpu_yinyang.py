@@ -90,6 +90,33 @@ def test_yinyang_steps_bit_exact(n, d, k, G, metric, mode, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("n,d,k,sizes", [(2000, 64, 200, (150, 49, 1)), (1500, 256, 300, (1, 70, 33, 32, 31, 133)),
+                                         (1000, 16, 100, (97, 0, 3))])
+def test_yinyang_init_large_and_tiny_groups(n, d, k, sizes):
+    """kmeans_yy_init (kmeans.cu:431-485) with groups of more than one 32-slot tile (the panel restarts them at
+    every tile boundary and carries the minimum), of exactly a tile, of a single member (rows of that cluster
+    have no other member: the bound stays FLT_MAX) and an empty one: bounds bit-exact against the oracle."""
+    from kmcuda_amd.engine import Engine
+    dev = torch.device("cuda", 0)
+    rs = numpy.random.RandomState(k + d)
+    x = rs.rand(n, d).astype(numpy.float32)
+    cen = x[rs.choice(n, k, replace=False)].copy()
+    asg, _, _ = oracle.lloyd_assign(x, cen)
+    G = len(sizes)
+    groups = numpy.concatenate([numpy.full(m, g, numpy.uint32) for g, m in enumerate(sizes)])
+    assert len(groups) == k
+    groups = groups[rs.permutation(k)]
+    bounds = oracle.yy_init(x, cen, asg, groups, G)
+    eng = Engine(n, d, k, "L2", device=0)
+    eng.yy_configure(G, groups)
+    gb = torch.empty((G + 1) * n, dtype=torch.float32, device=dev)
+    eng.yy_init(_t(x, dev), _t(cen, dev), _t(asg, dev), gb)
+    eng.sync()
+    got = gb.cpu().numpy().reshape(G + 1, n)
+    assert (got.view(numpy.uint32) == bounds.view(numpy.uint32)).all()
+    eng.close()
+
+
 @pytest.mark.parametrize("hint", ["f16", "f16cache", "off"])
 @pytest.mark.parametrize("n,d,k,G,data", [(6000, 256, 256, 25, "uniform"), (8000, 64, 100, 10, "uniform"),
                                           (5000, 16, 64, 6, "uniform"), (6000, 256, 128, 12, "blobs"),
