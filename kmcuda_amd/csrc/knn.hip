@@ -58,7 +58,10 @@ __global__ __launch_bounds__(256) void knn_gather_kernel(const float *__restrict
   for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
   if (lane == 0) {
     n2s[p] = a;
-    if ((a - a) == 0.f) atomicMax(&stats[0], __float_as_uint(a));  // finite, non-negative: bits order like values
+    // finite, non-negative: bits order like values.  Look before the atomic: N of them on one address serialise
+    // in L2 (8M rows: 90 ms for a kernel that moves 16 GB), and the running maximum rarely moves
+    if ((a - a) == 0.f && __float_as_uint(a) > *reinterpret_cast<volatile uint32_t *>(&stats[0]))
+      atomicMax(&stats[0], __float_as_uint(a));
   }
 }
 
