@@ -492,17 +492,13 @@ hipError_t launch_knn_split(int metric, const float *xs, uint32_t N, uint32_t D,
 template <int DP, int METRIC>
 static hipError_t launch_knn_f16_t(const KnnArgs &a, uint32_t nblocks, hipStream_t st) {
   const size_t lds_bytes = (size_t)KNN16_NBUF * (32 * KNN16_SUB * DP * 2) + KNN16_NBUF * 256 + 2 * KNN16_WAVES * 4;
-  if (lds_bytes > 65536) {
-    static bool raised = false;   // per instantiation
-    if (!raised) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_filter_f16_kernel<DP, METRIC, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_filter_f16_kernel<DP, METRIC, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      if (e != hipSuccess) return e;
-      raised = true;
-    }
+  if (lds_bytes > 65536) {   // (per launch: the attribute belongs to the current device's copy of the kernel)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_filter_f16_kernel<DP, METRIC, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_filter_f16_kernel<DP, METRIC, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
   }
   if (a.D == (uint32_t)DP)
     hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, true>), dim3(nblocks), dim3(KNN16_WAVES * 64), lds_bytes, st, a);

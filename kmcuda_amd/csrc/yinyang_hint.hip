@@ -833,17 +833,13 @@ bool yy_hint_supported(uint32_t DP) { return DP >= 16 && DP <= 256; }
 template <int DP, int METRIC>
 static hipError_t launch_hint_t(const YyArgs &a, hipStream_t st) {
   const size_t lds_bytes = 2 * 64 * DP * 2 + 512;
-  if (lds_bytes > 65536) {
-    static bool raised = false;   // per instantiation
-    if (!raised) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&yy_hint_kernel<DP, METRIC, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&yy_hint_kernel<DP, METRIC, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      if (e != hipSuccess) return e;
-      raised = true;
-    }
+  if (lds_bytes > 65536) {   // (per launch: the attribute belongs to the current device's copy of the kernel)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&yy_hint_kernel<DP, METRIC, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&yy_hint_kernel<DP, METRIC, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
   }
   const uint32_t grid = (a.len + 255) / 256;  // worst case; blocks beyond the passed count exit at once
   if (a.D == (uint32_t)DP)
@@ -856,17 +852,13 @@ template <int DP, int METRIC>
 static hipError_t launch_local_hint_t(const YyArgs &a, hipStream_t st) {
   const uint32_t grid = (a.len + 127) / 128;
   const size_t lds_bytes = 2 * 64 * DP * 2 + 1024;
-  if (lds_bytes > 65536) {
-    static bool raised = false;   // per instantiation
-    if (!raised) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&yy_local_hint_kernel<DP, METRIC, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&yy_local_hint_kernel<DP, METRIC, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      if (e != hipSuccess) return e;
-      raised = true;
-    }
+  if (lds_bytes > 65536) {   // (per launch: the attribute belongs to the current device's copy of the kernel)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&yy_local_hint_kernel<DP, METRIC, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&yy_local_hint_kernel<DP, METRIC, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
   }
   if (a.D == (uint32_t)DP)
     hipLaunchKernelGGL((yy_local_hint_kernel<DP, METRIC, true>), dim3(grid), dim3(256), lds_bytes, st, a);
