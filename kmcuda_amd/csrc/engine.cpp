@@ -219,6 +219,10 @@ int Engine::yy_configure(uint32_t G, const uint32_t *groups_host) {
   KMX_HIP(hipMemcpy(gsecond_, gsecond.data(), gsecond.size() * sizeof(uint32_t), hipMemcpyHostToDevice), kMemoryCopyError);
   const uint32_t k_pad64 = (K_ + 63u) / 64u * 64u;   // whole 64-centroid super-tiles (yy_local_hint_kernel's DMA)
   if ((rc = alloc(&groups_, k_pad64))) return rc;
+  if (!yy_stats_) {
+    if ((rc = alloc(&yy_stats_, 64 * 16))) return rc;
+    KMX_HIP(hipMemsetAsync(yy_stats_, 0, 64 * 16 * sizeof(uint32_t), stream_), kRuntimeError);
+  }
   if ((rc = alloc(&cperm_, cperm.size()))) return rc;
   if ((rc = alloc(&gstart_, G + 1))) return rc;
   if ((rc = alloc(&pids_, pids.size()))) return rc;
@@ -245,7 +249,7 @@ static void fill_yy_args(Engine &e, YyArgs &a, const float *samples, const float
   a.groups = e.groups_; a.drifts = nullptr; a.gdrifts = nullptr; a.assignments = nullptr; a.bounds = nullptr;
   a.passed = nullptr; a.counters = e.counters_; a.count_ptr = e.counters_ + 2;
   a.panelhi = nullptr; a.hint = nullptr; a.flag_rows = nullptr; a.gfirst = e.gfirst_; a.gsecond = e.gsecond_;
-  a.xcache = nullptr; a.xmeta = nullptr;
+  a.xcache = nullptr; a.xmeta = nullptr; a.stat_stripes = e.yy_stats_;
   a.pfil = e.pfil_; a.pbias = e.pbias_; a.pids = e.pids_; a.pmeta = e.pmeta_; a.cperm = e.cperm_;
   a.gstart = e.gstart_; a.nslots = e.nslots_;
 }
@@ -532,10 +536,14 @@ int Engine::counters_read(uint32_t *host4) {
 
 int Engine::yy_hint_stats(uint32_t *host6) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
-  KMX_HIP(hipMemcpyAsync(host_counters_, counters_ + 6, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_),
+  for (int i = 0; i < 6; i++) host6[i] = 0;
+  if (!yy_stats_) return kSuccess;
+  std::vector<uint32_t> st(64 * 16);
+  KMX_HIP(hipMemcpyAsync(st.data(), yy_stats_, st.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_),
           kMemoryCopyError);
   KMX_HIP(hipStreamSynchronize(stream_), kRuntimeError);
-  memcpy(host6, host_counters_, 6 * sizeof(uint32_t));
+  for (int b = 0; b < 64; b++)
+    for (int i = 0; i < 6; i++) host6[i] += st[b * 16 + 6 + i];   // striped by block number (yinyang_hint.hip)
   return kSuccess;
 }
 

@@ -122,6 +122,7 @@ class Engine {
   float *pfil_ = nullptr, *pbias_ = nullptr, *xt_ = nullptr;
   float *exact_work_ = nullptr;  // adjust_exact scratch when 64 centroid rows exceed LDS (lazy)
   uint32_t *host_counters_ = nullptr;  // pinned
+  uint32_t *yy_stats_ = nullptr;       // 64 x 16 words: the hinted local filter's statistics, striped
 
   // profiling of the step kernels with HIP events on stream_
   bool profile_ = false;

@@ -147,7 +147,8 @@ struct YyArgs {
   float *bounds;
   const uint32_t *passed;
   const uint32_t *count_ptr; // length of `passed` (counters + 2, or counters + 5 for the fall-back list)
-  uint32_t *counters;        // + [5] rows of the hinted kernel handed to the plain one, [6] / [7] running totals
+  uint32_t *counters;        // + [5] rows of the hinted kernel handed to the plain one
+  uint32_t *stat_stripes;    // 64 x 16 words: the hinted kernel's statistics ([6] rows, [7] handed over, [8..11] why), summed by the reader
   // hinted local filter (yinyang_hint.hip)
   const void *panelhi;       // hi halves of the centred panel (centroid_panelhi_kernel), DP halves per row
   const void *xcache;        // the engine's row cache (lloyd_f16.hip: row_cache_kernel) for the SAME mean, or null:

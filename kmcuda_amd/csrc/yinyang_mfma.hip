@@ -112,9 +112,7 @@ __global__ __launch_bounds__(256, 2) void yy_local_mfma_kernel(YyArgs a) {
   float qpre[4] = {kFltMax, kFltMax, kFltMax, kFltMax};
   float tail_a = kFltMax;
   int qn = 0;
-  uint32_t n_flush = 0, n_cand = 0;  // statistics: counters[1] += flushes (per wave), [3] += candidates
   auto flush = [&]() {  // wave-uniform call
-    n_flush++;
     const float *crow[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) crow[i] = a.centroids + (size_t)(i < qn ? qc[i] : 0) * D;
@@ -203,8 +201,7 @@ __global__ __launch_bounds__(256, 2) void yy_local_mfma_kernel(YyArgs a) {
                 }
               tail_a = kFltMax;
               qn++;
-              n_cand++;
-            }
+              }
           }
         }
       }
@@ -231,15 +228,6 @@ __global__ __launch_bounds__(256, 2) void yy_local_mfma_kernel(YyArgs a) {
   }
   const unsigned long long cm = __ballot(changed);
   if (lane == 0 && cm) atomicAdd(&a.counters[0], (uint32_t)__popcll(cm));
-  {  // statistics (not part of the reference's state)
-    uint32_t nc = (live && h == 0) ? n_cand : 0u;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) nc += __shfl_xor(nc, off);
-    if (lane == 0) {
-      atomicAdd(&a.counters[3], nc);
-      atomicAdd(&a.counters[1], n_flush);
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------------
