@@ -219,13 +219,22 @@ __global__ __launch_bounds__(256) void yy_global_filter_kernel(
       pass = !(min_lower_bound >= upper_bound);  // try #2
     }
   }
+  // survivors appended per BLOCK: one list cursor bump for the four waves (the cursor's cache line serves
+  // same-address atomics one at a time; 125 K waves per launch each wanting their own base was measurable)
   const unsigned long long m = __ballot(pass);
-  if (m) {
-    const int lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&counters[2], (uint32_t)__popcll(m));
-    base = __shfl(base, __ffsll((long long)m) - 1);
-    if (pass) passed[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = s;
+  __shared__ uint32_t blk_cnt[4], blk_base;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) blk_cnt[wv] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = blk_cnt[0] + blk_cnt[1] + blk_cnt[2] + blk_cnt[3];
+    blk_base = tot ? atomicAdd(&counters[2], tot) : 0u;
+  }
+  __syncthreads();
+  if (pass) {
+    uint32_t base = blk_base;
+    for (int w = 0; w < wv; w++) base += blk_cnt[w];
+    passed[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = s;
   }
 }
 
