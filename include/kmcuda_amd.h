@@ -97,6 +97,19 @@ size_t kmamd_reduce_len(kmamd_engine *e);
 int kmamd_reduce_fill(kmamd_engine *e, const float *samples, const uint32_t *assignments_prev,
                       const uint32_t *assignments, double *buf);
 int kmamd_reduce_apply(kmamd_engine *e, const double *buf, float *centroids, uint32_t *ccounts);
+/* reduce_apply with the reference's stop rule (check_changed, kmeans.cu:697-717: evaluated BEFORE the update)
+ * decided ON THE DEVICE, so that the caller can enqueue the next pass without waiting for the count:
+ *   stop_threshold  tolerance * N as a float; the update happens only if (float)buf[K*D + K] (the reduced number
+ *                   of reassigned rows) exceeds it, and then counters[0] is zeroed for the next pass.  Otherwise
+ *                   NOTHING is modified and the engine's stop flag is raised: from then on kmamd_lloyd_assign
+ *                   returns without touching anything (a pass enqueued speculatively leaves the state as the
+ *                   reference returns it) until kmamd_stop_clear.  < 0: no test.
+ *   host_tail6      NULL, or 6 uint32 of pinned host memory the kernel reports to: [0..3] the reduced counters,
+ *                   [4] 1 if it stopped, [5] `seq` (written last).  Valid once the stream has passed the call
+ *                   (record an event behind it; nothing has to wait in front of the next pass). */
+int kmamd_reduce_apply_stop(kmamd_engine *e, const double *buf, float *centroids, uint32_t *ccounts,
+                            float stop_threshold, uint32_t *host_tail6, uint32_t seq);
+int kmamd_stop_clear(kmamd_engine *e);
 /* Test / A-B hook for the update's host logic: 0 default, 1 radix path always, 2 always read the
  * counts before choosing (the pre-round-2 behaviour), 3 bucket path always without reading (exercises
  * the device-side fallback of oversized buckets).  Env KMCUDA_AMD_UPDATE=radix|sync|bucket sets it at

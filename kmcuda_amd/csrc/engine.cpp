@@ -496,11 +496,29 @@ int Engine::move_deltas(const float *samples, const uint32_t *prev, const uint32
 }
 
 int Engine::apply_delta(const double *delta, const int32_t *dcount, const double *dcount_d, float *centroids,
-                        uint32_t *ccounts) {
+                        uint32_t *ccounts, float stop_threshold, uint32_t *host_tail, uint32_t seq) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  StopCtl ctl;
+  if (stop_threshold >= 0.f || host_tail) {
+    if (!dcount_d) return kInvalidArguments;   // the stop rule reads the fused buffer's reduced counters
+    ctl.threshold = stop_threshold;
+    ctl.counters = counters_;
+    ctl.seq = seq;
+    if (host_tail) {
+      void *dp = nullptr;
+      KMX_HIP(hipHostGetDevicePointer(&dp, host_tail, 0), kInvalidArguments);
+      ctl.host_tail = static_cast<uint32_t *>(dp);
+    }
+  }
   span_begin(2);
-  KMX_HIP(launch_apply_delta(metric_, delta, dcount, dcount_d, K_, D_, centroids, ccounts, stream_), kRuntimeError);
+  KMX_HIP(launch_apply_delta(metric_, delta, dcount, dcount_d, K_, D_, centroids, ccounts, ctl, stream_), kRuntimeError);
   span_end();
+  return kSuccess;
+}
+
+int Engine::stop_clear() {
+  KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  KMX_HIP(hipMemsetAsync(counters_ + kStopFlag, 0, sizeof(uint32_t), stream_), kRuntimeError);
   return kSuccess;
 }
 
@@ -616,6 +634,12 @@ int kmamd_reduce_fill(kmamd_engine *e, const float *samples, const uint32_t *ass
 int kmamd_reduce_apply(kmamd_engine *e, const double *buf, float *centroids, uint32_t *ccounts) {
   return e->e.apply_delta(buf, nullptr, buf + (size_t)e->e.K_ * e->e.D_, centroids, ccounts);
 }
+int kmamd_reduce_apply_stop(kmamd_engine *e, const double *buf, float *centroids, uint32_t *ccounts,
+                            float stop_threshold, uint32_t *host_tail6, uint32_t seq) {
+  return e->e.apply_delta(buf, nullptr, buf + (size_t)e->e.K_ * e->e.D_, centroids, ccounts, stop_threshold, host_tail6,
+                          seq);
+}
+int kmamd_stop_clear(kmamd_engine *e) { return e->e.stop_clear(); }
 int kmamd_set_update_mode(kmamd_engine *e, int mode) {
   if (mode < 0 || mode > 3) return kmx::kInvalidArguments;
   e->e.ms_.force = mode;

@@ -43,8 +43,12 @@ class Engine {
   // tail: the fused reduce buffer's [dcount | counters] behind delta (or null); dcount may be null then
   int move_deltas(const float *samples, const uint32_t *prev, const uint32_t *cur, double *delta, int32_t *dcount,
                   double *tail);
+  // stop_threshold >= 0: the reference's stop rule decided on the device from the reduced counters behind
+  // dcount_d (kernels.hpp: StopCtl); host_tail: 6 pinned words the kernel reports to ([0..3] counters, [4]
+  // stopped, [5] seq)
   int apply_delta(const double *delta, const int32_t *dcount, const double *dcount_d, float *centroids,
-                  uint32_t *ccounts);
+                  uint32_t *ccounts, float stop_threshold = -1.f, uint32_t *host_tail = nullptr, uint32_t seq = 0);
+  int stop_clear();   // lowers the device-side stop flag (start of a run)
   int adjust_exact(const float *samples, const uint32_t *prev, const uint32_t *cur, float *centroids,
                    uint32_t *ccounts);
   int prepare_centroids(const float *centroids);

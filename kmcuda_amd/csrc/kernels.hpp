@@ -23,7 +23,18 @@ struct LloydArgs {
   uint32_t *assignments, *assignments_prev;
   uint32_t *flagged;         // N: rows with three or more contenders (full exact scan)
   uint32_t *pairs;           // 3N: (row, i1, i2) rows with exactly two contenders
-  uint32_t *counters;        // [0] changed, [1] flagged, [2] passed (yinyang), [3] pairs, [4] undecided by stage 1
+  uint32_t *counters;        // [0] changed, [1] flagged, [2] passed (yinyang), [3] pairs, [4] undecided by stage 1,
+                             // [kStopFlag] the device-side stop flag
+};
+// counters[kStopFlag] != 0: the stop rule fired ON THE DEVICE (apply_delta_kernel with a threshold): the kernels
+// that assign every row return at once, so iterations enqueued past the stop leave the state untouched
+constexpr uint32_t kStopFlag = 8;
+// the device-side stop rule of launch_apply_delta (reference: check_changed, kmeans.cu:697-717)
+struct StopCtl {
+  float threshold = -1.f;         // stop when (float)reassigned <= threshold (= tolerance * N in float); < 0: no test
+  uint32_t *counters = nullptr;   // engine counters: [0] zeroed when the run goes on, [kStopFlag] raised when it stops
+  uint32_t *host_tail = nullptr;  // device-visible pinned words: [0..3] reduced counters, [4] stopped, [5] seq
+  uint32_t seq = 0;
 };
 
 uint32_t filter_dp_for(uint32_t D);
@@ -97,7 +108,10 @@ hipError_t launch_adjust_exact(int metric, const float *samples, uint32_t N, uin
                                size_t temp_bytes, float *work, float *centroids, uint32_t *ccounts, hipStream_t st);
 hipError_t launch_apply_delta(int metric, const double *delta, const int32_t *dcount /* or */,
                               const double *dcount_d /* the fused buffer's tail */, uint32_t K, uint32_t D,
-                              float *centroids, uint32_t *ccounts, hipStream_t st);
+                              float *centroids, uint32_t *ccounts, const StopCtl &stop, hipStream_t st);
+// out[b][i] = sum over b of bufs[b][i] in ascending b, written to every buffer (the one-device stand-in for the
+// all-reduce: KMCUDA_AMD_VIRTUAL_SHARDS)
+hipError_t launch_sum_buffers(double *const *bufs_dev, uint32_t nbuf, size_t len, hipStream_t st);
 
 // seeding.hip (reference: kmeans.cu:42-67 kmeans_plus_plus, transpose.cu:6-14 copy_sample_t,
 // kmeans.cu:674-691 kmeans_calc_average_distance)

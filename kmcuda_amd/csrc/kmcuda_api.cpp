@@ -18,8 +18,10 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -135,6 +137,73 @@ double butterfly_sum(const float *v, uint32_t n) {
 }
 
 // ---------------------------------------------------------------------------------------
+// One host thread per shard for the lifetime of the job.  A multi-GPU iteration is a dozen launches per GPU
+// and lasts well under a millisecond on a 1M-row shard: enqueueing eight GPUs from one thread, or creating and
+// joining eight threads per iteration, costs about as much as the GPUs take to run it.
+// ---------------------------------------------------------------------------------------
+class ShardWorkers {
+ public:
+  ~ShardWorkers() {
+    {
+      std::lock_guard<std::mutex> l(m_);
+      quit_ = true;
+      gen_++;
+    }
+    cv_go_.notify_all();
+    for (auto &t : threads_) t.join();
+  }
+  size_t size() const { return threads_.size(); }
+  void start(size_t n) {
+    rcs_.assign(n, 0);
+    for (size_t i = 0; i < n; i++) threads_.emplace_back([this, i]() { loop(i); });
+  }
+  // fn(i) on worker i, for every i; returns when all are done, with the first non-zero code
+  int run(const std::function<int(size_t)> &fn) {
+    {
+      std::lock_guard<std::mutex> l(m_);
+      fn_ = &fn;
+      pending_ = threads_.size();
+      gen_++;
+    }
+    cv_go_.notify_all();
+    std::unique_lock<std::mutex> l(m_);
+    cv_done_.wait(l, [this]() { return pending_ == 0; });
+    for (int rc : rcs_)
+      if (rc) return rc;
+    return 0;
+  }
+
+ private:
+  void loop(size_t i) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<int(size_t)> *fn;
+      {
+        std::unique_lock<std::mutex> l(m_);
+        cv_go_.wait(l, [&]() { return gen_ != seen; });
+        seen = gen_;
+        if (quit_) return;
+        fn = fn_;
+      }
+      const int rc = (*fn)(i);
+      {
+        std::lock_guard<std::mutex> l(m_);
+        rcs_[i] = rc;
+        if (--pending_ == 0) cv_done_.notify_one();
+      }
+    }
+  }
+  std::mutex m_;
+  std::condition_variable cv_go_, cv_done_;
+  std::vector<std::thread> threads_;
+  std::vector<int> rcs_;
+  const std::function<int(size_t)> *fn_ = nullptr;
+  uint64_t gen_ = 0;
+  size_t pending_ = 0;
+  bool quit_ = false;
+};
+
+// ---------------------------------------------------------------------------------------
 // one GPU's share of the job
 // ---------------------------------------------------------------------------------------
 struct Shard {
@@ -151,9 +220,11 @@ struct Shard {
   float *drifts = nullptr;         // K*D old centroids + K per-centroid drifts
   float *gdrifts = nullptr;        // G per-group max drifts
   uint32_t *passed = nullptr;      // length
+  hipEvent_t ev_filled = nullptr;  // several shards on one device: this shard's reduce buffer is written
   std::vector<void *> owned;
   ~Shard() {
     (void)hipSetDevice(dev);
+    if (ev_filled) (void)hipEventDestroy(ev_filled);
     for (void *p : owned) (void)hipFree(p);
   }
   template <typename T>
@@ -169,7 +240,8 @@ struct Shard {
 // what the last kmeans_cuda() call did (kmamd_last_run_stats): iterations of the Lloyd / Yinyang loops and
 // the wall time spent in them (everything after seeding), for drivers that time the drop-in entry point
 struct RunStats { uint32_t iterations = 0; double loop_seconds = 0, setup_seconds = 0; uint32_t shards = 0, rccl = 0; };
-RunStats g_last_run;
+RunStats g_last_run;        // published once per kmeans_cuda() call, under g_last_run_mutex (the Python module
+std::mutex g_last_run_mutex;  // releases the GIL around the call: two threads may be inside the library)
 
 class Job {
  public:
@@ -179,13 +251,29 @@ class Job {
   // KMCUDA_AMD_FP16_STRICT=1 (fp16x2 jobs, one GPU): every step in the reference's half2 ARITHMETIC
   // (half2_strict.hip) -- the verification mode the oracle's half2 restatement is compared with
   bool strict_h2 = false;
+  RunStats stats;   // this job's own counts (a nested group-clustering job has its own)
   std::vector<std::unique_ptr<Shard>> shards;
+  ShardWorkers workers;   // (after `shards`: joined before the shards go)
   Rccl rccl;
   std::vector<void *> comms;
+  // several shards on ONE device (KMCUDA_AMD_VIRTUAL_SHARDS): the all-reduce's stand-in is a sum kernel on the
+  // first shard's stream, ordered with the others by events -- the dependency structure of the real collective
+  double **reduce_ptrs_dev = nullptr;
+  hipEvent_t ev_summed = nullptr;
+  // the stop rule's outcome, reported by the first shard's apply kernel: 2 slots x 8 pinned words
+  uint32_t *host_tail = nullptr;
+  hipEvent_t ev_tail[2] = {nullptr, nullptr};
+  bool speculate = true;   // KMCUDA_AMD_SPECULATE=0: every iteration waits for its stop test before its update
 
   ~Job() {
     for (void *c : comms)
       if (c) rccl.CommDestroy(c);
+    if (!shards.empty()) (void)hipSetDevice(shards[0]->dev);
+    if (reduce_ptrs_dev) (void)hipFree(reduce_ptrs_dev);
+    if (ev_summed) (void)hipEventDestroy(ev_summed);
+    for (hipEvent_t e : ev_tail)
+      if (e) (void)hipEventDestroy(e);
+    if (host_tail) (void)hipHostFree(host_tail);
   }
 
   int setup(const std::vector<int> &devs, int nvirtual, uint32_t N_, uint32_t D_, uint32_t K_, int metric_,
@@ -262,7 +350,27 @@ class Job {
       for (auto &s : shards) ids.push_back(s->dev);
       comms.resize(ids.size(), nullptr);
       if (rccl.CommInitAll(comms.data(), (int)ids.size(), ids.data()) != 0) return kmcudaRuntimeError;
+    } else if (shards.size() > 1) {
+      std::vector<double *> ptrs;
+      for (auto &s : shards) {
+        ptrs.push_back(s->reduce);
+        (void)hipSetDevice(s->dev);
+        if (hipEventCreateWithFlags(&s->ev_filled, hipEventDisableTiming) != hipSuccess) return kmcudaRuntimeError;
+      }
+      (void)hipSetDevice(shards[0]->dev);
+      if (hipMalloc((void **)&reduce_ptrs_dev, ptrs.size() * sizeof(double *)) != hipSuccess)
+        return kmcudaMemoryAllocationFailure;
+      if (hipMemcpy(reduce_ptrs_dev, ptrs.data(), ptrs.size() * sizeof(double *), hipMemcpyHostToDevice) != hipSuccess)
+        return kmcudaMemoryCopyError;
+      if (hipEventCreateWithFlags(&ev_summed, hipEventDisableTiming) != hipSuccess) return kmcudaRuntimeError;
     }
+    (void)hipSetDevice(shards[0]->dev);
+    if (hipHostMalloc(reinterpret_cast<void **>(&host_tail), 16 * sizeof(uint32_t), hipHostMallocCoherent) != hipSuccess)
+      return kmcudaMemoryAllocationFailure;
+    memset(host_tail, 0, 16 * sizeof(uint32_t));
+    for (hipEvent_t &e : ev_tail)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return kmcudaRuntimeError;
+    if (const char *v = getenv("KMCUDA_AMD_SPECULATE")) speculate = atoi(v) != 0;
     return sync_all();  // uploads complete: later cross-stream reads of the samples are safe
   }
 
@@ -611,17 +719,12 @@ class Job {
       (void)hipSetDevice(shards[0]->dev);
       return fn(*shards[0]);
     }
-    std::vector<int> rcs(shards.size(), 0);
-    std::vector<std::thread> pool;
-    for (size_t i = 0; i < shards.size(); i++)
-      pool.emplace_back([&, i]() {
-        (void)hipSetDevice(shards[i]->dev);
-        rcs[i] = fn(*shards[i]);
-      });
-    for (auto &t : pool) t.join();
-    for (int rc : rcs)
-      if (rc) return rc;
-    return 0;
+    if (workers.size() == 0) workers.start(shards.size());   // persistent: one thread per shard, for the job's lifetime
+    const std::function<int(size_t)> each = [&](size_t i) {
+      (void)hipSetDevice(shards[i]->dev);
+      return fn(*shards[i]);
+    };
+    return workers.run(each);
   }
 
   // ---- the per-iteration collective: ONE all-reduce of [delta (fp64 K*D) | dcount K | counters 4] ----
@@ -639,18 +742,20 @@ class Job {
       if (rccl.GroupEnd() != 0) return kmcudaRuntimeError;
       return 0;
     }
-    // several shards on ONE device (test hook KMCUDA_AMD_VIRTUAL_SHARDS): fixed-order host sum
-    std::vector<double> acc(len, 0.0), tmp(len);
+    // several shards on ONE device (test hook KMCUDA_AMD_VIRTUAL_SHARDS): a fixed-order sum kernel on the first
+    // shard's stream once every shard's buffer is written; the other streams go on when it is done.  No host wait:
+    // the host loop is exercised exactly as with the real collective
+    Shard &f = *shards[0];
+    (void)hipSetDevice(f.dev);
     for (auto &s : shards) {
-      (void)hipSetDevice(s->dev);
-      RETERR(s->eng->sync());
-      if (hipMemcpy(tmp.data(), s->reduce, len * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
-        return kmcudaMemoryCopyError;
-      for (size_t i = 0; i < len; i++) acc[i] += tmp[i];
+      if (hipEventRecord(s->ev_filled, s->eng->stream_) != hipSuccess) return kmcudaRuntimeError;
+      if (s.get() != &f && hipStreamWaitEvent(f.eng->stream_, s->ev_filled, 0) != hipSuccess) return kmcudaRuntimeError;
     }
+    if (launch_sum_buffers(reduce_ptrs_dev, (uint32_t)shards.size(), len, f.eng->stream_) != hipSuccess)
+      return kmcudaRuntimeError;
+    if (hipEventRecord(ev_summed, f.eng->stream_) != hipSuccess) return kmcudaRuntimeError;
     for (auto &s : shards)
-      if (hipMemcpy(s->reduce, acc.data(), len * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
-        return kmcudaMemoryCopyError;
+      if (s.get() != &f && hipStreamWaitEvent(s->eng->stream_, ev_summed, 0) != hipSuccess) return kmcudaRuntimeError;
     return 0;
   }
 
@@ -706,9 +811,17 @@ class Job {
       return s.eng->move_deltas(s.samples, s.prev, s.assignments, s.reduce, nullptr, s.reduce + kd);
     });
   }
-  int apply_deltas() {
+  // stop_threshold >= 0: every shard's apply kernel evaluates the stop rule itself from the reduced counters (the
+  // same words on every shard) and leaves everything untouched when it fires; slot >= 0: the first shard's kernel
+  // reports the outcome to the pinned words of that slot, ev_tail[slot] marks it
+  int apply_deltas(float stop_threshold = -1.f, int slot = -1, uint32_t seq = 0) {
     const uint32_t kd = K * D;
-    for (auto &s : shards) RETERR(s->eng->apply_delta(s->reduce, nullptr, s->reduce + kd, s->centroids, s->ccounts));
+    for (size_t i = 0; i < shards.size(); i++) {
+      auto &s = shards[i];
+      RETERR(s->eng->apply_delta(s->reduce, nullptr, s->reduce + kd, s->centroids, s->ccounts, stop_threshold,
+                                 (i == 0 && slot >= 0) ? host_tail + 8 * slot : nullptr, seq));
+      if (i == 0 && slot >= 0 && hipEventRecord(ev_tail[slot], s->eng->stream_) != hipSuccess) return kmcudaRuntimeError;
+    }
     return quantize_centroids();
   }
 
@@ -751,43 +864,100 @@ class Job {
   }
 
   // reference: kmeans_cuda_lloyd, kmeans.cu:934-1026.  Per iteration: assignment on every shard, the
-  // shards' move sums, ONE all-reduce that also carries the reassignment counters, the stop test on
-  // the reduced counters (before the update, as kmeans.cu:991-1000), the update.  One host read per
-  // iteration for the whole job; everything else is enqueued without waiting.
-  int lloyd(float tolerance, bool resume, int *iterations) {
-    RETERR(prepare_mem(resume));
+  // shards' move sums, ONE all-reduce that also carries the reassignment counters, the stop test on the
+  // reduced counters (before the update, as kmeans.cu:991-1000), the update.
+  //
+  // The stop test is decided ON THE DEVICE by the update kernel (update.hip: apply_delta_kernel + StopCtl), so
+  // the host enqueues iteration i + 1 before it has seen iteration i's count: the GPUs never wait for the 32-byte
+  // round trip (on a 1M-row shard it is worth several percent of an iteration).  When the rule fires the update
+  // kernel leaves everything untouched and raises a device flag that turns the already-enqueued next pass into
+  // no-ops, so the state is exactly what the reference returns (assignments of the stop iteration, centroids one
+  // update behind); the host reads the outcome one iteration late from pinned words and prints the same lines.
+  //   leave:  asked after every iteration that goes on; true = "return BEFORE the next update" (the caller wants
+  //           to start Yinyang from the reference's hand-over state).  It takes effect one iteration later: that
+  //           iteration is judged by the host before its update, as in the reference.
+  //   *left:  the loop returned for `leave`, not for the stop rule
+  using LeaveFn = std::function<bool(int iter, uint32_t changed)>;
+  int lloyd(float tolerance, int *iterations, const LeaveFn *leave = nullptr, bool *left = nullptr) {
+    RETERR(prepare_mem(false));
+    if (left) *left = false;
     // the samples do not change inside one kmeans_cuda() call: let the coarse filter stage keep its
     // centred half copy of the rows across the iterations (kmamd_set_row_cache, include/kmcuda_amd.h)
     for (auto &s : shards) {
       s->eng->row_cache_on_ = s->eng->row_cache_allowed_;
       s->eng->row_cache_valid_ = false;
+      RETERR(s->eng->stop_clear());
     }
-    for (int iter = 1;; iter++) {
-      if (!resume || iter > 1) {
+    if (exact_update) {   // strict-parity mode: the reference's sequence, step by step
+      for (int iter = 1;; iter++) {
         for (auto &s : shards)
           RETERR(s->eng->lloyd_assign(s->samples, s->centroids, s->assignments, s->prev, false));
-        int status;
-        if (exact_update) {
-          status = check_changed(iter, tolerance, true);
-        } else {
-          RETERR(fill_deltas());
-          RETERR(allreduce_fused());
-          status = check_changed_reduced(iter, tolerance, true);
-        }
+        const int status = check_changed(iter, tolerance, true);
         if (status < 0) return -status;
-        g_last_run.iterations++;
+        stats.iterations++;
         if (status == 1) {
           if (iterations) *iterations = iter;
           return 0;
         }
-        if (exact_update) RETERR(adjust());
-        else RETERR(apply_deltas());
-      } else {
         RETERR(adjust());
       }
     }
+    const float threshold = tolerance * N;   // the float product of kmeans.cu:707
+    bool leave_next = false;
+    int unjudged = 0;   // a speculative iteration whose outcome the host has not looked at yet
+    for (int iter = 1;; iter++) {
+      const bool spec = speculate && !leave_next;
+      RETERR(for_shards([](Shard &s) {
+        const int rc = s.eng->lloyd_assign(s.samples, s.centroids, s.assignments, s.prev, false);
+        if (rc) return rc;
+        const uint32_t kd = s.eng->K_ * s.eng->D_;
+        return s.eng->move_deltas(s.samples, s.prev, s.assignments, s.reduce, nullptr, s.reduce + kd);
+      }));
+      RETERR(allreduce_fused());
+      if (spec) RETERR(apply_deltas(threshold, iter & 1, (uint32_t)iter));
+      if (unjudged) {
+        uint32_t changed = 0;
+        const int status = judge_reported(unjudged, &changed);
+        if (status < 0) return -status;
+        if (status == 1) {   // the pass enqueued above found the flag raised: nothing was touched
+          if (iterations) *iterations = unjudged;
+          return 0;
+        }
+        if (leave && (*leave)(unjudged, changed)) leave_next = true;
+        unjudged = 0;
+      }
+      if (spec) {
+        unjudged = iter;
+        continue;
+      }
+      const int status = check_changed_reduced(iter, tolerance, true);   // the host waits: one 32-byte read
+      if (status < 0) return -status;
+      stats.iterations++;
+      if (status == 1 || leave_next) {
+        if (left) *left = status != 1;
+        if (iterations) *iterations = iter;
+        return 0;
+      }
+      RETERR(apply_deltas(threshold));   // (the same decision once more on the device; zeroes the counter)
+    }
   }
 
+  // the outcome of speculative iteration `iter`, as its update kernel reported it.  1: stopped, 0: went on
+  int judge_reported(int iter, uint32_t *changed) {
+    const int slot = iter & 1;
+    (void)hipSetDevice(shards[0]->dev);
+    if (hipEventSynchronize(ev_tail[slot]) != hipSuccess) return -kmcudaRuntimeError;
+    volatile uint32_t *t = host_tail + 8 * slot;
+    if (t[5] != (uint32_t)iter) {
+      INFO("internal error: iteration %d reported as %u\n", iter, t[5]);
+      return -kmcudaRuntimeError;
+    }
+    DEBUG("filter: %u rows settled by two exact chains, %u by a full exact scan\n", t[3], t[1]);
+    INFO("iteration %d: %u reassignments\n", iter, t[0]);
+    if (changed) *changed = t[0];
+    stats.iterations++;
+    return t[4] ? 1 : 0;
+  }
 
   // ---- Yinyang (reference: kmeans_cuda_yy, kmeans.cu:1028-1263) ----
   // Clusters the K centroids into G groups: k-means++ (srand(0), kmeans.cu:1081-1084 passes seed 0)
@@ -803,7 +973,7 @@ class Job {
     gjob.exact_update = exact_update;
     gjob.fp16 = fp16;  // centroids_yy is half2 in the reference too (kmeans.cu:1084-1091)
     RETERR(gjob.init_centroids(kmcudaInitMethodPlusPlus, 0, nullptr, first.dev));
-    RETERR(gjob.lloyd((float)kYinyangGroupTolerance, false, nullptr));
+    RETERR(gjob.lloyd((float)kYinyangGroupTolerance, nullptr));
     RETERR(gjob.sync_all());
     groups->resize(K);
     (void)hipSetDevice(first.dev);
@@ -873,7 +1043,7 @@ class Job {
         RETERR(s->eng->yy_filters(s->samples, s->centroids, s->drifts, s->gdrifts, s->assignments, s->prev, s->bounds,
                                   s->passed));
       }
-      g_last_run.iterations++;
+      stats.iterations++;
     }
   }
 
@@ -1264,6 +1434,39 @@ class KnnJob {
   }
 };
 
+// When do Yinyang's bounds pay?  (measured on MI355X at 8M x 256, K = 1024, G = 102.)  In units of
+// one Lloyd assignment pass per row, t_L = 2 D K flop at ~1 PFLOP/s algorithmic on the f16 matrix cores:
+//   bounds refresh (kmeans_yy_init: >= G exact chains per row)       ~38 t_L
+//   global filter (streams 2 (G + 1) floats + the row)                (8 (G + 1) + 4 D + 12) B at 4.8 TB/s
+//   local filter per PASSED row (estimate + candidate sweeps)         ~2.9 t_L
+// so an iteration with bounds beats a plain pass only while few rows pass the global filter, and the refresh needs
+// that saving many times over.  The forecast: reassignments decay geometrically (ratio fitted to the last four
+// counts), the passed fraction is taken as 8 x the reassigned fraction.  It is a schedule, not a semantic: every
+// step either way is the reference's arithmetic.  KMCUDA_AMD_YY_SWITCH=<fraction> forces the hand-over at that
+// reassignment fraction instead (0.11 = the reference's).
+struct BoundsModel {
+  double N, D, K, G, target, force = -1.0;
+  std::vector<double> hist;
+  BoundsModel(uint32_t n, uint32_t d, uint32_t k, uint32_t g, float tolerance)
+      : N(n), D(d), K(k), G(g), target(std::max((double)(tolerance * n), 0.5)) {
+    if (const char *v = getenv("KMCUDA_AMD_YY_SWITCH")) force = atof(v);
+  }
+  bool pays(uint32_t changed) {
+    hist.push_back((double)changed);
+    if (force >= 0) return (double)changed <= force * N;
+    if (hist.size() < 4) return false;
+    const double a = hist[hist.size() - 4], b = hist.back();
+    if (!(b > target) || !(a > b)) return false;   // about to stop, or not decaying: no forecast
+    const double rho = std::min(std::pow(b / a, 1.0 / 3.0), 0.995);
+    const double remaining = std::min(std::log(target / b) / std::log(rho), 1.0e4);
+    const double t_l = 2.0 * D * K / 1.0e15;
+    const double t_g = (8.0 * (G + 1.0) + 4.0 * D + 12.0) / 4.8e12;
+    const double passed = std::min(1.0, 8.0 * b / N);
+    const double gain = t_l - (t_g + 2.9 * passed * t_l);
+    return gain > 0 && remaining * gain > 38.0 * t_l;
+  }
+};
+
 int virtual_shards() {
   const char *v = getenv("KMCUDA_AMD_VIRTUAL_SHARDS");
   return v ? atoi(v) : 0;
@@ -1307,7 +1510,6 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
   // default stream's implicit synchronisation
   if (device_ptrs >= 0 && hipSetDevice(device_ptrs) == hipSuccess) (void)hipDeviceSynchronize();
   const auto t_begin = std::chrono::steady_clock::now();
-  g_last_run = RunStats();
   Job job;
   job.fp16 = fp16x2 != 0;
   if (const char *v = getenv("KMCUDA_AMD_FP16_STRICT")) job.strict_h2 = job.fp16 && atoi(v) != 0;
@@ -1325,24 +1527,45 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
   RETERR(job.init_centroids(init, seed, centroids, device_ptrs, afk_m));
   RETERR(job.sync_all());
   const auto t_loop = std::chrono::steady_clock::now();
-  g_last_run.setup_seconds = std::chrono::duration<double>(t_loop - t_begin).count();
-  g_last_run.shards = (uint32_t)job.shards.size();
-  g_last_run.rccl = job.comms.empty() ? 0u : (uint32_t)job.comms.size();
+  job.stats.setup_seconds = std::chrono::duration<double>(t_loop - t_begin).count();
+  job.stats.shards = (uint32_t)job.shards.size();
+  job.stats.rccl = job.comms.empty() ? 0u : (uint32_t)job.comms.size();
 
   if (yy_groups_size == 0 || kYinyangDraftReassignments <= tolerance) {  // kmeans.cu:1037-1050
     if (yy_groups_size == 0) INFO("too few clusters for this yinyang_t => Lloyd\n");
     else INFO("tolerance is too high (>= %.2f) => Lloyd\n", kYinyangDraftReassignments);
-    RETERR(job.lloyd(tolerance, false, nullptr));
+    RETERR(job.lloyd(tolerance, nullptr));
   } else {
-    INFO("running Lloyd until reassignments drop below %u\n", (uint32_t)(kYinyangDraftReassignments * samples_size));
-    int iter = 0;
-    RETERR(job.lloyd((float)kYinyangDraftReassignments, false, &iter));
-    const int st = job.check_changed(iter, tolerance, false);  // kmeans.cu:1058
-    if (st < 0) return static_cast<KMCUDAResult>(-st);
-    if (st == 0) RETERR(job.yinyang(tolerance, yy_groups_size, iter));
+    // KMCUDA_AMD_YY=reference: the reference's fixed schedule (Lloyd down to 11 % reassignments, then bounds).
+    // Default: the same hand-over, but only when the bounds can pay for their refresh on this hardware
+    // (BoundsModel) -- an assignment pass costs 0.5 ns per row here, a bounds refresh 38 of them.  The strict
+    // parity modes keep the reference's schedule.
+    const char *yym = getenv("KMCUDA_AMD_YY");
+    const bool adaptive = !(yym && strcmp(yym, "reference") == 0) && !job.exact_update &&
+                          job.shards[0]->eng->DP_ != 0 && job.shards[0]->eng->filter_mode_ == 0;
+    if (!adaptive) {
+      INFO("running Lloyd until reassignments drop below %u\n", (uint32_t)(kYinyangDraftReassignments * samples_size));
+      int iter = 0;
+      RETERR(job.lloyd((float)kYinyangDraftReassignments, &iter));
+      const int st = job.check_changed(iter, tolerance, false);  // kmeans.cu:1058
+      if (st < 0) return static_cast<KMCUDAResult>(-st);
+      if (st == 0) RETERR(job.yinyang(tolerance, yy_groups_size, iter));
+    } else {
+      INFO("running Lloyd; Yinyang's bounds take over when they can pay for their refresh\n");
+      BoundsModel model(samples_size, feats, clusters_size, yy_groups_size, tolerance);
+      const Job::LeaveFn leave = [&model](int, uint32_t changed) { return model.pays(changed); };
+      int iter = 0;
+      bool left = false;
+      RETERR(job.lloyd(tolerance, &iter, &leave, &left));
+      if (left) RETERR(job.yinyang(tolerance, yy_groups_size, iter));
+    }
   }
   RETERR(job.sync_all());
-  g_last_run.loop_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
+  job.stats.loop_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
+  {
+    std::lock_guard<std::mutex> lock(g_last_run_mutex);
+    g_last_run = job.stats;
+  }
   if (average_distance) RETERR(job.average_distance(average_distance));
   RETERR(job.gather_outputs(centroids, assignments, device_ptrs));
   DEBUG("return kmcudaSuccess\n");
@@ -1378,6 +1601,7 @@ KMCUDAResult knn_cuda(uint16_t k, KMCUDADistanceMetric metric, uint32_t samples_
 
 int kmamd_last_run_stats(uint32_t *iterations, double *loop_seconds, double *setup_seconds, uint32_t *shards,
                          uint32_t *rccl_ranks) {
+  std::lock_guard<std::mutex> lock(g_last_run_mutex);
   if (iterations) *iterations = g_last_run.iterations;
   if (loop_seconds) *loop_seconds = g_last_run.loop_seconds;
   if (setup_seconds) *setup_seconds = g_last_run.setup_seconds;

@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_kernel(
   constexpr int TILE = 32 * LDW;       // one centroid tile
   constexpr int NST = (8 * DP + 255) / 256;  // float4 staging registers per thread
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (counters[kStopFlag] != 0u) return;   // the run has stopped on the device (apply_delta_kernel): touch nothing
   auto tile_ptr = [&](int buf) { return lds + buf * TILE; };
   auto bias_ptr = [&](int buf) { return lds + 2 * TILE + buf * 32; };
 
@@ -497,6 +498,7 @@ __global__ __launch_bounds__(256) void lloyd_exact_kernel(
   __shared__ float sh_dist[4];
   __shared__ uint32_t sh_idx[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (counters[kStopFlag] != 0u) return;   // stopped on the device: touch nothing
   const uint32_t total = rows ? *nrows : N;
   for (uint32_t ri = blockIdx.x; ri < total; ri += gridDim.x) {
     const uint32_t s = rows ? rows[ri] : ri;

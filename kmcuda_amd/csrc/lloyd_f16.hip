@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   constexpr int SWM = (KS < 16 ? KS : 16) - 1;
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds2[];
+  if (counters[kStopFlag] != 0u) return;   // the run has stopped on the device (apply_delta_kernel): touch nothing
   // raw LDS byte addresses (the fragment address is built with XOR: needs the 1-KB aligned base)
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte *)lds2;
   if (lds0 & 1023u) __builtin_trap();

@@ -31,6 +31,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "exact.hpp"
@@ -495,11 +497,34 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
 }
 
 // one block per centroid: c = normalize(c*count + delta), count += dcount
+// StopCtl (kernels.hpp): the reference's stop rule -- check_changed, kmeans.cu:697-717, evaluated BEFORE the
+// update -- decided here, on the device, from the reduced reassignment count behind dcount_d: every block reads
+// the same word and takes the same branch.  Stopping: nothing is modified, the flag is raised (the kernels that
+// assign every row return at once from then on, so whatever the host has enqueued past this point leaves the
+// state as the reference returns it: assignments of this iteration, centroids one update behind).  Going on:
+// counters[0] is zeroed for the next pass (kmeans.cu:710-714).  The host learns the outcome from the pinned
+// words, without a stream synchronisation in front of the next pass.
 template <int METRIC>
 __global__ void apply_delta_kernel(const double *__restrict__ delta, const int32_t *__restrict__ dcount,
                                    const double *__restrict__ dcount_d, uint32_t D, float *__restrict__ centroids,
-                                   uint32_t *__restrict__ ccounts) {
+                                   uint32_t *__restrict__ ccounts, StopCtl ctl) {
   const uint32_t c = blockIdx.x;
+  if (ctl.counters) {
+    bool stop = ctl.counters[kStopFlag] != 0u;   // once stopped, stay stopped
+    if (ctl.threshold >= 0.f && dcount_d) stop = stop || (float)(uint32_t)dcount_d[gridDim.x] <= ctl.threshold;
+    if (c == 0 && threadIdx.x == 0) {
+      if (stop) ctl.counters[kStopFlag] = 1u;
+      else if (ctl.threshold >= 0.f) ctl.counters[0] = 0u;
+      if (ctl.host_tail) {
+        volatile uint32_t *ht = ctl.host_tail;
+        for (uint32_t i = 0; i < 4; i++) ht[i] = dcount_d ? (uint32_t)dcount_d[gridDim.x + i] : 0u;
+        ht[4] = stop ? 1u : 0u;
+        __threadfence_system();
+        ht[5] = ctl.seq;
+      }
+    }
+    if (stop) return;
+  }
   const double *d = delta + (size_t)c * D;
   float *cen = centroids + (size_t)c * D;
   const uint32_t cnt_old = ccounts[c];
@@ -536,12 +561,30 @@ __global__ void apply_delta_kernel(const double *__restrict__ delta, const int32
 }
 
 hipError_t launch_apply_delta(int metric, const double *delta, const int32_t *dcount, const double *dcount_d,
-                              uint32_t K, uint32_t D, float *centroids, uint32_t *ccounts, hipStream_t st) {
+                              uint32_t K, uint32_t D, float *centroids, uint32_t *ccounts, const StopCtl &stop,
+                              hipStream_t st) {
   const uint32_t bs = D >= 256 ? 256 : (D > 64 ? 128 : 64);
   if (metric == 0)
-    hipLaunchKernelGGL((apply_delta_kernel<0>), dim3(K), dim3(bs), 0, st, delta, dcount, dcount_d, D, centroids, ccounts);
+    hipLaunchKernelGGL((apply_delta_kernel<0>), dim3(K), dim3(bs), 0, st, delta, dcount, dcount_d, D, centroids, ccounts,
+                       stop);
   else
-    hipLaunchKernelGGL((apply_delta_kernel<1>), dim3(K), dim3(bs), 0, st, delta, dcount, dcount_d, D, centroids, ccounts);
+    hipLaunchKernelGGL((apply_delta_kernel<1>), dim3(K), dim3(bs), 0, st, delta, dcount, dcount_d, D, centroids, ccounts,
+                       stop);
+  return hipGetLastError();
+}
+
+// several row shards on ONE device (KMCUDA_AMD_VIRTUAL_SHARDS): the all-reduce's stand-in.  Ascending buffer
+// order, the same sum in every buffer
+__global__ __launch_bounds__(256) void sum_buffers_kernel(double *const *__restrict__ bufs, uint32_t nbuf, size_t len) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (size_t)gridDim.x * 256) {
+    double a = bufs[0][i];
+    for (uint32_t b = 1; b < nbuf; b++) a += bufs[b][i];
+    for (uint32_t b = 0; b < nbuf; b++) bufs[b][i] = a;
+  }
+}
+hipError_t launch_sum_buffers(double *const *bufs_dev, uint32_t nbuf, size_t len, hipStream_t st) {
+  const uint32_t grid = (uint32_t)std::min<size_t>((len + 255) / 256, 2048);
+  hipLaunchKernelGGL(sum_buffers_kernel, dim3(grid ? grid : 1), dim3(256), 0, st, bufs_dev, nbuf, len);
   return hipGetLastError();
 }
 

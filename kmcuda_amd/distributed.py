@@ -68,6 +68,40 @@ class HipBackend:
     def synchronize(self):
         torch.cuda.synchronize(self.device)
 
+    # ---- the stop rule on the device (kmamd_reduce_apply_stop): the loop enqueues pass i + 1 before it has
+    # ---- seen pass i's count, and reads the outcome one pass late from pinned words
+    def stop_clear(self):
+        self.engine.stop_clear()
+        self.engine.reset_counters(0)
+
+    def apply_stop(self, buf, threshold, seq):
+        """The update, unless the reduced reassignment count is <= threshold (then nothing is touched and
+        later assign() calls are no-ops).  Returns a handle for read_report()."""
+        if not hasattr(self, "_tails"):
+            self._tails = [torch.zeros(8, dtype=torch.int32).pin_memory() for _ in range(2)]
+            self._events = [torch.cuda.Event() for _ in range(2)]
+        slot = seq & 1
+        self.engine.reduce_apply_stop(buf, self.centroids, self.ccounts, threshold, self._tails[slot], seq)
+        if self.half:
+            self.centroids.copy_(self.centroids.to(torch.float16).to(torch.float32))
+        self._events[slot].record(torch.cuda.current_stream(self.device))
+        return slot, seq
+
+    def read_report(self, handle):
+        """(global number of reassigned rows, stopped?) of the pass behind `handle`; waits for that pass only."""
+        slot, seq = handle
+        self._events[slot].synchronize()
+        t = self._tails[slot]
+        if int(t[5]) != seq:
+            raise RuntimeError("pass %d reported as %d" % (seq, int(t[5])))
+        return int(t[0]) & 0xFFFFFFFF, bool(int(t[4]))
+
+
+def stop_threshold(tolerance, n_total):
+    """tolerance * N as the reference forms it: a float product (kmeans.cu:707)."""
+    import numpy
+    return float(numpy.float32(tolerance) * numpy.float32(n_total))
+
 
 class ShardedLloyd:
     """kmeans_cuda_lloyd (kmeans.cu:934-1026) over row shards."""
@@ -79,6 +113,7 @@ class ShardedLloyd:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buf = backend.new_reduce_buffer()
         self.iterations = 0
+        self.stopped = False
 
     def set_centroids(self, centroids):
         """Replicated initial centroids (rank 0's are broadcast)."""
@@ -87,11 +122,32 @@ class ShardedLloyd:
             dist.broadcast(self.b.centroids, src=0, group=self.group)
 
     def step(self, tolerance=None):
-        """One Lloyd iteration: assign, reduce, (stop test), update.  Returns the global number
-        of reassigned rows.  With `tolerance` the reference's stop rule is evaluated BEFORE the
-        update (kmeans.cu:991-1000) and the update is skipped when it fires."""
+        """One Lloyd iteration: assign, reduce, (stop test), update.  With `tolerance` the reference's
+        stop rule is evaluated BEFORE the update (kmeans.cu:991-1000) and the update is skipped when it
+        fires.
+
+        A backend with `apply_stop` (HipBackend) decides the rule on the device: this call enqueues the
+        whole iteration without waiting and returns the PREVIOUS iteration's global number of reassigned
+        rows (None for the first call), read from pinned words -- the way kmeans_cuda() iterates.
+        `self.stopped` turns True once an iteration has fired the rule; the passes enqueued after it
+        leave the state untouched.  Other backends wait for the count before the update and return it."""
         b = self.b
         kd = b.clusters * b.features
+        if tolerance is not None and hasattr(b, "apply_stop"):
+            if self.iterations == 0:
+                b.stop_clear()
+            b.assign()
+            b.fill_reduce_buffer(self.buf)
+            if self.world > 1:
+                dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
+            self.iterations += 1
+            handle = b.apply_stop(self.buf, stop_threshold(tolerance, self.n_total), self.iterations)
+            prev, self._pending = getattr(self, "_pending", None), handle
+            if prev is None:
+                return None
+            changed, stopped = b.read_report(prev)
+            self.stopped = self.stopped or stopped
+            return changed
         b.reset_changed()
         b.assign()
         b.fill_reduce_buffer(self.buf)
@@ -107,17 +163,42 @@ class ShardedLloyd:
         self.iterations += 1
         return changed
 
+    def drain(self):
+        """The report of the last enqueued iteration (device-side stop rule): (changed, stopped)."""
+        pending, self._pending = getattr(self, "_pending", None), None
+        if pending is None:
+            return None
+        changed, stopped = self.b.read_report(pending)
+        self.stopped = self.stopped or stopped
+        return changed
+
     def changed_last(self):
         kd = self.b.clusters * self.b.features
         return int(self.buf[kd + self.b.clusters].item())
 
     def run(self, tolerance, max_iter=10000, verbosity=0):
         log = []
-        for it in range(1, max_iter + 1):
-            changed = self.step(tolerance)
+
+        def note(changed):
             log.append(changed)
             if verbosity > 0 and (not dist.is_initialized() or dist.get_rank(self.group) == 0):
-                print("iteration %d: %d reassignments" % (it, changed))
+                print("iteration %d: %d reassignments" % (len(log), changed))
+
+        if hasattr(self.b, "apply_stop"):
+            # pass i + 1 is enqueued before pass i's count is looked at; after the stop the extra pass is a no-op
+            for _ in range(max_iter):
+                changed = self.step(tolerance)
+                if changed is not None:
+                    note(changed)
+                if self.stopped:
+                    self._pending = None
+                    self.iterations = len(log)
+                    return log
+            note(self.drain())
+            return log
+        for it in range(1, max_iter + 1):
+            changed = self.step(tolerance)
+            note(changed)
             if changed <= tolerance * self.n_total:
                 break
         return log

@@ -111,6 +111,18 @@ class Engine:
         _lib.check(self.lib.kmamd_reduce_apply(self.h, self._p(buf), self._p(centroids), self._p(ccounts)),
                    "kmamd_reduce_apply")
 
+    def reduce_apply_stop(self, buf, centroids, ccounts, stop_threshold, host_tail=None, seq=0):
+        """reduce_apply with the stop rule decided on the device (kmamd_reduce_apply_stop): nothing is
+        modified and the engine's stop flag is raised when the reduced reassignment count is <=
+        stop_threshold.  host_tail: pinned int32 tensor of >= 6 words the kernel reports to."""
+        _lib.check(self.lib.kmamd_reduce_apply_stop(self.h, self._p(buf), self._p(centroids), self._p(ccounts),
+                                                    float(stop_threshold),
+                                                    self._p(host_tail) if host_tail is not None else None, int(seq)),
+                   "kmamd_reduce_apply_stop")
+
+    def stop_clear(self):
+        _lib.check(self.lib.kmamd_stop_clear(self.h), "kmamd_stop_clear")
+
     def set_update_mode(self, mode):
         """"auto" | "radix" | "sync" | "bucket": the update's host logic (kmamd_set_update_mode); sums are
         bit-identical on every path."""

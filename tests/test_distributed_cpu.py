@@ -79,6 +79,38 @@ class OracleBackend:
         pass
 
 
+class OracleBackendStop(OracleBackend):
+    """+ the device-side stop rule's interface (HipBackend.apply_stop / read_report / stop_clear): the
+    loop then enqueues pass i + 1 before looking at pass i's count, and a pass after the stop must be a
+    no-op.  Here everything is synchronous; what is exercised is ShardedLloyd's lagged bookkeeping."""
+
+    def stop_clear(self):
+        self.stopped = False
+        self.changed = 0
+
+    def assign(self):
+        if self.stopped:
+            return
+        OracleBackend.assign(self)
+
+    def apply_stop(self, buf, threshold, seq):
+        k, d = self.clusters, self.features
+        changed = int(buf.numpy()[k * d + k])
+        stop = self.stopped or numpy.float32(changed) <= numpy.float32(threshold)
+        if stop:
+            self.stopped = True
+        else:
+            self.apply(buf)
+            self.changed = 0
+        return seq, changed, stop
+
+    def read_report(self, handle):
+        return handle[1], handle[2]
+
+
+BACKENDS = {"host-stop": OracleBackend, "device-stop": OracleBackendStop}
+
+
 def _data():
     rs = numpy.random.RandomState(5)
     x = numpy.concatenate([rs.randn(700, 8) + 4 * rs.randn(1, 8) for _ in range(6)]).astype(numpy.float32)
@@ -86,7 +118,7 @@ def _data():
     return x, init
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, kind):
     import torch.distributed as dist
     from kmcuda_amd.distributed import ShardedLloyd, row_block
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -94,7 +126,7 @@ def _worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     x, init = _data()
     lo, hi = row_block(len(x), rank, world)
-    loop = ShardedLloyd(OracleBackend(x[lo:hi], 12), len(x))
+    loop = ShardedLloyd(BACKENDS[kind](x[lo:hi], 12), len(x))
     loop.set_centroids(torch.from_numpy(init) if rank == 0 else torch.zeros_like(torch.from_numpy(init)))
     log = loop.run(tolerance=0.005, max_iter=50)
     gathered = [None] * world
@@ -113,21 +145,23 @@ def test_row_block_partition():
         assert max(b[1] - b[0] for b in blocks) - min(b[1] - b[0] for b in blocks) <= 1
 
 
-def test_sharded_lloyd_world2_matches_single(tmp_path):
+@pytest.mark.parametrize("kind", ["host-stop", "device-stop"])
+def test_sharded_lloyd_world2_matches_single(tmp_path, kind):
     import torch.multiprocessing as mp
     from kmcuda_amd.distributed import ShardedLloyd
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "w2.npz")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, kind), nprocs=2, join=True)
     got = numpy.load(out)
     # single process, same loop, no process group
     x, init = _data()
-    loop = ShardedLloyd(OracleBackend(x, 12), len(x))
+    loop = ShardedLloyd(BACKENDS[kind](x, 12), len(x))
     loop.set_centroids(torch.from_numpy(init))
     log = loop.run(tolerance=0.005, max_iter=50)
     assert list(got["log"]) == log
+    assert loop.iterations == len(log)
     assert len(log) > 3 and log[-1] <= 0.005 * len(x)
     assert (got["asg"] == loop.b.assignments).all()
     numpy.testing.assert_allclose(got["cen"], loop.b.centroids.numpy(), rtol=1e-6, atol=1e-7)

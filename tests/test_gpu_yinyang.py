@@ -190,16 +190,53 @@ def test_yinyang_many_passes_bit_exact(n, d, k, G, data, hint, monkeypatch):
     eng.close()
 
 
-def test_kmeanspp_yinyang_15_3(fixture13k):
-    # test.py:228-234
+@pytest.mark.parametrize("schedule", ["default", "reference", "switch-at-0.11", "switch-at-0.03"])
+def test_kmeanspp_yinyang_15_3(fixture13k, monkeypatch, schedule):
+    """test.py:228-234: 15 Lloyd + 3 Yinyang iterations.  `reference`: the reference's fixed schedule (bounds from
+    11 % reassignments on).  `default`: bounds only when they can pay for their refresh (kmcuda_api.cpp:
+    BoundsModel) -- on this fixture they cannot, every iteration is the reference's Lloyd pass, and the count is the
+    same 18 because Yinyang is exact.  `switch-at-*`: the default loop forced to hand over to the bounds at that
+    reassignment fraction (the hand-over takes effect one iteration after it is asked for)."""
     from kmcuda_amd import kmeans_cuda
+    if schedule == "reference":
+        monkeypatch.setenv("KMCUDA_AMD_YY", "reference")
+    elif schedule.startswith("switch-at-"):
+        monkeypatch.setenv("KMCUDA_AMD_YY_SWITCH", schedule[len("switch-at-"):])
     out = StdoutListener()
     with out:
         centroids, assignments = kmeans_cuda(fixture13k, 50, init="kmeans++", device=1, verbosity=2, seed=3,
                                              tolerance=0.01, yinyang_t=0.1)
     assert out.iterations() == 15 + 3
     _validate(fixture13k, centroids, assignments, 0.01)
-    assert "refreshing Yinyang bounds" in out.text
+    if schedule != "default":
+        assert "refreshing Yinyang bounds" in out.text
+    else:
+        assert "refreshing Yinyang bounds" not in out.text
+
+
+@pytest.mark.parametrize("speculate", ["1", "0"])
+def test_lloyd_stop_rule_on_device_equals_host(fixture13k, monkeypatch, speculate):
+    """The stop rule decided by the update kernel, with the next pass enqueued before the host has seen the
+    count (default), against the host-side test in front of every update (KMCUDA_AMD_SPECULATE=0): same
+    progress lines, same assignments, same centroids (one update behind the assignments, kmeans.cu:991-1000)."""
+    from kmcuda_amd import kmeans_cuda
+    monkeypatch.setenv("KMCUDA_AMD_SPECULATE", speculate)
+    out = StdoutListener()
+    with out:
+        c, a = kmeans_cuda(fixture13k, 50, init="kmeans++", device=1, verbosity=1, seed=3, tolerance=0.01, yinyang_t=0)
+    lines = [ln for ln in out.text.splitlines() if ln.startswith("iteration")]
+    monkeypatch.setenv("KMCUDA_AMD_SPECULATE", "0" if speculate == "1" else "1")
+    out2 = StdoutListener()
+    with out2:
+        c2, a2 = kmeans_cuda(fixture13k, 50, init="kmeans++", device=1, verbosity=1, seed=3, tolerance=0.01, yinyang_t=0)
+    lines2 = [ln for ln in out2.text.splitlines() if ln.startswith("iteration")]
+    assert lines == lines2 and len(lines) > 5
+    assert (a == a2).all()
+    assert numpy.array_equal(c, c2, equal_nan=True)
+    # the returned centroids are the ones the returned assignments were computed FROM
+    import oracle
+    ref, _, _ = oracle.lloyd_assign(fixture13k, c)
+    assert (ref == a).all()
 
 
 def test_256_features_cosine_yinyang_9():
