@@ -104,11 +104,14 @@ int kmamd_reduce_apply(kmamd_engine *e, const double *buf, float *centroids, uin
  *                   NOTHING is modified and the engine's stop flag is raised: from then on kmamd_lloyd_assign
  *                   returns without touching anything (a pass enqueued speculatively leaves the state as the
  *                   reference returns it) until kmamd_stop_clear.  < 0: no test.
- *   host_tail6      NULL, or 6 uint32 of pinned host memory the kernel reports to: [0..3] the reduced counters,
- *                   [4] 1 if it stopped, [5] `seq` (written last).  Valid once the stream has passed the call
- *                   (record an event behind it; nothing has to wait in front of the next pass). */
+ *   seq             the caller's pass number.  The kernel reports to pinned words of the engine (two slots,
+ *                   seq & 1); kmamd_stop_report(seq) waits for THIS call only (an event behind it on the engine's
+ *                   stream; nothing has to wait in front of the next pass) and returns [0..3] the reduced
+ *                   counters, [4] 1 if it stopped, [5] seq.  Reading a pass after the one after next has been
+ *                   enqueued is an error (its slot has been reused). */
 int kmamd_reduce_apply_stop(kmamd_engine *e, const double *buf, float *centroids, uint32_t *ccounts,
-                            float stop_threshold, uint32_t *host_tail6, uint32_t seq);
+                            float stop_threshold, uint32_t seq);
+int kmamd_stop_report(kmamd_engine *e, uint32_t seq, uint32_t *host_out6);
 int kmamd_stop_clear(kmamd_engine *e);
 /* Test / A-B hook for the update's host logic: 0 default, 1 radix path always, 2 always read the
  * counts before choosing (the pre-round-2 behaviour), 3 bucket path always without reading (exercises

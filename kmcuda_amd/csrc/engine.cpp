@@ -25,7 +25,9 @@ Engine::~Engine() {
     (void)hipEventDestroy(ev_fork_);
     (void)hipEventDestroy(ev_join_);
   }
-  if (ev_move_) (void)hipEventDestroy(ev_move_);
+  if (host_report_) (void)hipHostFree(host_report_);
+  for (hipEvent_t e : ev_report_)
+    if (e) (void)hipEventDestroy(e);
   if (ev_rows_) (void)hipEventDestroy(ev_rows_);
   if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
@@ -87,12 +89,18 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if ((rc = alloc(&move_blocks_, (size_t)n_rows / 1024 + 4))) return rc;
   if ((rc = alloc(&bucket_work_, move_bucket_words(K)))) return rc;
   KMX_HIP(hipMemsetAsync(bucket_work_, 0, move_bucket_words(K) * sizeof(uint32_t), stream_), kRuntimeError);
+  bucket_cap_ = move_bucket_cap(n_rows, K);
+  if ((rc = alloc(&bucket_rows_, 2 * (size_t)K * bucket_cap_))) return rc;
   KMX_HIP(hipMemsetAsync(stats_base_, 0, 16 * sizeof(uint32_t), stream_), kRuntimeError);
-  KMX_HIP(hipHostMalloc(reinterpret_cast<void **>(&host_move_count_), 4 * sizeof(uint32_t), hipHostMallocDefault), kMemoryAllocationFailure);
+  KMX_HIP(hipHostMalloc(reinterpret_cast<void **>(&host_move_count_), 4 * sizeof(uint32_t), hipHostMallocCoherent), kMemoryAllocationFailure);
   memset(host_move_count_, 0, 4 * sizeof(uint32_t));
   host_move_count_[2] = 0xFFFFFFFFu;   // undecided rows: not known yet
   ms_.host = host_move_count_;
-  KMX_HIP(hipEventCreateWithFlags(&ev_move_, hipEventDisableTiming), kRuntimeError);
+  {
+    void *dp = nullptr;
+    KMX_HIP(hipHostGetDevicePointer(&dp, host_move_count_, 0), kRuntimeError);
+    ms_.host_dev = static_cast<uint32_t *>(dp);
+  }
   KMX_HIP(hipEventCreateWithFlags(&ev_rows_, hipEventDisableTiming), kRuntimeError);
   sort_temp_bytes_ = sort_temp_bytes(2 * (size_t)n_rows, 2 * K);
   {
@@ -104,7 +112,6 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
     if ((rc = alloc(&t, sort_temp_bytes_ + 16))) return rc;
     sort_temp_ = t;
   }
-  if ((rc = alloc(&partial_, (size_t)2 * K * kSumSplit * D))) return rc;
   KMX_HIP(hipHostMalloc((void **)&host_counters_, 8 * sizeof(uint32_t), hipHostMallocDefault), kMemoryAllocationFailure);
   KMX_HIP(hipMemsetAsync(counters_, 0, 16 * sizeof(uint32_t), stream_), kRuntimeError);
   return kSuccess;
@@ -484,36 +491,54 @@ int Engine::move_deltas(const float *samples, const uint32_t *prev, const uint32
                         int32_t *dcount, double *tail) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   span_begin(2);
-  // the length of this pass's undecided list, for a LATER pass's stage-2 grid (async: nobody waits)
-  KMX_HIP(hipMemcpyAsync(host_move_count_ + 2, counters_ + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_),
-          kMemoryCopyError);
+  // (the kernel also reports the length of this pass's undecided list to the pinned words, for a LATER pass's
+  // stage-2 grid: nobody waits for it)
   KMX_HIP(launch_move_deltas(samples, N_, D_, K_, prev, cur, keys_tmp_, vals_tmp_, keys_sorted_, rows_sorted_,
-                             offsets2_, sort_temp_, sort_temp_bytes_, partial_, delta, dcount, tail, counters_,
-                             move_blocks_, bucket_work_, &ms_, ev_move_, stream_),
+                             offsets2_, sort_temp_, sort_temp_bytes_, bucket_rows_, bucket_cap_, delta, dcount, tail,
+                             counters_, move_blocks_, bucket_work_, &ms_, stream_),
           kRuntimeError);
   span_end();
   return kSuccess;
 }
 
 int Engine::apply_delta(const double *delta, const int32_t *dcount, const double *dcount_d, float *centroids,
-                        uint32_t *ccounts, float stop_threshold, uint32_t *host_tail, uint32_t seq) {
+                        uint32_t *ccounts, float stop_threshold, bool report, uint32_t seq) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   StopCtl ctl;
-  if (stop_threshold >= 0.f || host_tail) {
+  if (stop_threshold >= 0.f || report) {
     if (!dcount_d) return kInvalidArguments;   // the stop rule reads the fused buffer's reduced counters
     ctl.threshold = stop_threshold;
     ctl.counters = counters_;
     ctl.seq = seq;
-    if (host_tail) {
-      void *dp = nullptr;
-      KMX_HIP(hipHostGetDevicePointer(&dp, host_tail, 0), kInvalidArguments);
-      ctl.host_tail = static_cast<uint32_t *>(dp);
+    if (report) {
+      if (!host_report_) {
+        KMX_HIP(hipHostMalloc(reinterpret_cast<void **>(&host_report_), 16 * sizeof(uint32_t), hipHostMallocCoherent),
+                kMemoryAllocationFailure);
+        memset(host_report_, 0xFF, 16 * sizeof(uint32_t));
+        void *dp = nullptr;
+        KMX_HIP(hipHostGetDevicePointer(&dp, host_report_, 0), kRuntimeError);
+        host_report_dev_ = static_cast<uint32_t *>(dp);
+        for (hipEvent_t &e : ev_report_) KMX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming), kRuntimeError);
+      }
+      ctl.host_tail = host_report_dev_ + 8 * (seq & 1u);
     }
   }
   span_begin(2);
   KMX_HIP(launch_apply_delta(metric_, delta, dcount, dcount_d, K_, D_, centroids, ccounts, ctl, stream_), kRuntimeError);
   span_end();
+  // (on the engine's own stream: an event on the caller's legacy default stream would order every blocking
+  // stream of the device behind it)
+  if (report) KMX_HIP(hipEventRecord(ev_report_[seq & 1u], stream_), kRuntimeError);
   return kSuccess;
+}
+
+int Engine::stop_report(uint32_t seq, uint32_t *host_out6) {
+  KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  if (!host_report_) return kInvalidArguments;
+  KMX_HIP(hipEventSynchronize(ev_report_[seq & 1u]), kRuntimeError);
+  const volatile uint32_t *t = host_report_ + 8 * (seq & 1u);
+  for (int i = 0; i < 6; i++) host_out6[i] = t[i];
+  return host_out6[5] == seq ? kSuccess : kRuntimeError;   // another call has reused the slot
 }
 
 int Engine::stop_clear() {
@@ -635,15 +660,14 @@ int kmamd_reduce_apply(kmamd_engine *e, const double *buf, float *centroids, uin
   return e->e.apply_delta(buf, nullptr, buf + (size_t)e->e.K_ * e->e.D_, centroids, ccounts);
 }
 int kmamd_reduce_apply_stop(kmamd_engine *e, const double *buf, float *centroids, uint32_t *ccounts,
-                            float stop_threshold, uint32_t *host_tail6, uint32_t seq) {
-  return e->e.apply_delta(buf, nullptr, buf + (size_t)e->e.K_ * e->e.D_, centroids, ccounts, stop_threshold, host_tail6,
-                          seq);
+                            float stop_threshold, uint32_t seq) {
+  return e->e.apply_delta(buf, nullptr, buf + (size_t)e->e.K_ * e->e.D_, centroids, ccounts, stop_threshold, true, seq);
 }
+int kmamd_stop_report(kmamd_engine *e, uint32_t seq, uint32_t *host_out6) { return e->e.stop_report(seq, host_out6); }
 int kmamd_stop_clear(kmamd_engine *e) { return e->e.stop_clear(); }
 int kmamd_set_update_mode(kmamd_engine *e, int mode) {
   if (mode < 0 || mode > 3) return kmx::kInvalidArguments;
   e->e.ms_.force = mode;
-  e->e.ms_.async_ok = false;
   return kmx::kSuccess;
 }
 int kmamd_set_filter(kmamd_engine *e, int mode) {

@@ -47,8 +47,11 @@ class Engine {
   // dcount_d (kernels.hpp: StopCtl); host_tail: 6 pinned words the kernel reports to ([0..3] counters, [4]
   // stopped, [5] seq)
   int apply_delta(const double *delta, const int32_t *dcount, const double *dcount_d, float *centroids,
-                  uint32_t *ccounts, float stop_threshold = -1.f, uint32_t *host_tail = nullptr, uint32_t seq = 0);
+                  uint32_t *ccounts, float stop_threshold = -1.f, bool report = false, uint32_t seq = 0);
   int stop_clear();   // lowers the device-side stop flag (start of a run)
+  // the outcome of the apply_delta(..., report = true, seq) call: waits for THAT call only (an event behind it on
+  // stream_), then [0..3] the reduced counters, [4] stopped, [5] seq
+  int stop_report(uint32_t seq, uint32_t *host_out6);
   int adjust_exact(const float *samples, const uint32_t *prev, const uint32_t *cur, float *centroids,
                    uint32_t *ccounts);
   int prepare_centroids(const float *centroids);
@@ -76,7 +79,6 @@ class Engine {
   bool own_stream_ = false, blocking_stream_ = false;
   hipStream_t side_stream_ = nullptr;   // the full-scan refine kernel beside the pair kernel
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
-  hipEvent_t ev_move_ = nullptr;        // the update's count copy (launch_move_deltas waits for it alone)
   hipEvent_t ev_rows_ = nullptr;        // csqr / ct ready on the side stream (steady-state preparation)
   uint32_t N_ = 0, D_ = 0, K_ = 0, K_pad_ = 0, Kt_ = 0, DP_ = 0;
   int metric_ = 0, fp16x2_ = 0;
@@ -107,13 +109,13 @@ class Engine {
   uint32_t *stats_base_ = nullptr, *stats_ = nullptr, *flagged_ = nullptr, *pairs_ = nullptr, *counters_ = nullptr;
   // update workspace
   uint32_t *keys_tmp_ = nullptr, *vals_tmp_ = nullptr, *keys_sorted_ = nullptr, *rows_sorted_ = nullptr,
-           *offsets2_ = nullptr, *move_blocks_ = nullptr, *bucket_work_ = nullptr;
+           *offsets2_ = nullptr, *move_blocks_ = nullptr, *bucket_work_ = nullptr, *bucket_rows_ = nullptr;
+  uint32_t bucket_cap_ = 0;               // rows per (centroid, sign) bucket of the update's direct path
   uint32_t last_undecided_ = 0xFFFFFFFFu;     // an earlier pass's undecided rows (sizes stage 2's grid)
   MoveState ms_;                          // the update's host-side state (update.hip: launch_move_deltas)
   uint32_t *host_move_count_ = nullptr;   // 4 pinned words: [0] events [1] largest bucket [2] undecided rows
   void *sort_temp_ = nullptr;
   size_t sort_temp_bytes_ = 0;
-  double *partial_ = nullptr;
   // Yinyang
   uint32_t G_ = 0, nslots_ = 0;
   bool yy_exact_ = false;  // KMCUDA_AMD_YY_EXACT=1: plain exact kernels (cross-check)
@@ -126,6 +128,9 @@ class Engine {
   float *pfil_ = nullptr, *pbias_ = nullptr, *xt_ = nullptr;
   float *exact_work_ = nullptr;  // adjust_exact scratch when 64 centroid rows exceed LDS (lazy)
   uint32_t *host_counters_ = nullptr;  // pinned
+  uint32_t *host_report_ = nullptr;    // pinned, 2 slots x 8 words: what apply_delta_kernel reports (StopCtl)
+  uint32_t *host_report_dev_ = nullptr;
+  hipEvent_t ev_report_[2] = {nullptr, nullptr};
   uint32_t *yy_stats_ = nullptr;       // 64 x 16 words: the hinted local filter's statistics, striped
 
   // profiling of the step kernels with HIP events on stream_

@@ -80,28 +80,27 @@ hipError_t launch_row_cache(const void *rows, bool half_rows, uint32_t N, uint32
                             void *xcache, float *xmeta, hipStream_t st);
 
 // update.hip -- centroid update (reference: kmeans.cu:366-429 kmeans_adjust)
-constexpr uint32_t kSumSplit = 8;
 size_t sort_temp_bytes(size_t n, uint32_t max_key);
 uint32_t move_bucket_stride(uint32_t K);
-size_t move_bucket_words(uint32_t K);   // launch_move_deltas' bucket_work, zero-initialised by the owner
+size_t move_bucket_words(uint32_t K);        // launch_move_deltas' bucket_work, zero-initialised by the owner
+uint32_t move_bucket_cap(uint32_t N, uint32_t K);   // rows per (centroid, sign) bucket: bucket_rows is 2 K x cap words
 hipError_t launch_inverse_assignments(const uint32_t *assignments, uint32_t N, uint32_t K, uint32_t *keys_tmp,
                                       uint32_t *vals_tmp, uint32_t *keys_sorted, uint32_t *inv,
                                       uint32_t *offsets, void *temp, size_t temp_bytes, hipStream_t st);
 // host-side state of the update across calls (engine-owned)
 struct MoveState {
-  uint32_t *host = nullptr;            // 4 pinned words: [0] events, [1] largest bucket (async copies land here)
+  uint32_t *host = nullptr;            // 4 pinned words the kernels report to: [0] events, [1] largest list,
+  uint32_t *host_dev = nullptr;        //   [2] undecided rows of the last assignment pass; host_dev: their device address
   uint32_t last_events = 0xFFFFFFFFu;  // newest event count the host knows
-  bool async_ok = false;               // bucket path without reading the counts first
-  bool bucket_last = false;            // the last CHECKED call took the bucket path (speculation)
   int force = 0;                       // kmamd_set_update_mode
 };
 hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint32_t K, const uint32_t *prev,
                               const uint32_t *cur, uint32_t *keys_tmp, uint32_t *vals_tmp, uint32_t *keys_sorted,
                               uint32_t *rows_sorted, uint32_t *offsets2, void *temp, size_t temp_bytes,
-                              double *partial, double *delta, int32_t *dcount /* may be null */,
+                              uint32_t *bucket_rows, uint32_t cap, double *delta, int32_t *dcount /* may be null */,
                               double *tail /* fused buffer's [dcount | counters], may be null */,
                               const uint32_t *counters, uint32_t *blockoff, uint32_t *bucket_work, MoveState *ms,
-                              hipEvent_t copied /* may be null */, hipStream_t st);
+                              hipStream_t st);
 hipError_t launch_adjust_exact(int metric, const float *samples, uint32_t N, uint32_t D, uint32_t K,
                                const uint32_t *prev, const uint32_t *cur, uint32_t *keys_tmp, uint32_t *vals_tmp,
                                uint32_t *keys_sorted, uint32_t *rows_sorted, uint32_t *offsets2, void *temp,

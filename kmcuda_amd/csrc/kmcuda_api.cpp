@@ -260,9 +260,6 @@ class Job {
   // first shard's stream, ordered with the others by events -- the dependency structure of the real collective
   double **reduce_ptrs_dev = nullptr;
   hipEvent_t ev_summed = nullptr;
-  // the stop rule's outcome, reported by the first shard's apply kernel: 2 slots x 8 pinned words
-  uint32_t *host_tail = nullptr;
-  hipEvent_t ev_tail[2] = {nullptr, nullptr};
   bool speculate = true;   // KMCUDA_AMD_SPECULATE=0: every iteration waits for its stop test before its update
 
   ~Job() {
@@ -271,9 +268,6 @@ class Job {
     if (!shards.empty()) (void)hipSetDevice(shards[0]->dev);
     if (reduce_ptrs_dev) (void)hipFree(reduce_ptrs_dev);
     if (ev_summed) (void)hipEventDestroy(ev_summed);
-    for (hipEvent_t e : ev_tail)
-      if (e) (void)hipEventDestroy(e);
-    if (host_tail) (void)hipHostFree(host_tail);
   }
 
   int setup(const std::vector<int> &devs, int nvirtual, uint32_t N_, uint32_t D_, uint32_t K_, int metric_,
@@ -364,12 +358,6 @@ class Job {
         return kmcudaMemoryCopyError;
       if (hipEventCreateWithFlags(&ev_summed, hipEventDisableTiming) != hipSuccess) return kmcudaRuntimeError;
     }
-    (void)hipSetDevice(shards[0]->dev);
-    if (hipHostMalloc(reinterpret_cast<void **>(&host_tail), 16 * sizeof(uint32_t), hipHostMallocCoherent) != hipSuccess)
-      return kmcudaMemoryAllocationFailure;
-    memset(host_tail, 0, 16 * sizeof(uint32_t));
-    for (hipEvent_t &e : ev_tail)
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return kmcudaRuntimeError;
     if (const char *v = getenv("KMCUDA_AMD_SPECULATE")) speculate = atoi(v) != 0;
     return sync_all();  // uploads complete: later cross-stream reads of the samples are safe
   }
@@ -812,15 +800,14 @@ class Job {
     });
   }
   // stop_threshold >= 0: every shard's apply kernel evaluates the stop rule itself from the reduced counters (the
-  // same words on every shard) and leaves everything untouched when it fires; slot >= 0: the first shard's kernel
-  // reports the outcome to the pinned words of that slot, ev_tail[slot] marks it
-  int apply_deltas(float stop_threshold = -1.f, int slot = -1, uint32_t seq = 0) {
+  // same words on every shard) and leaves everything untouched when it fires; report: the first shard's kernel
+  // reports the outcome to its engine's pinned words (Engine::stop_report(seq) reads them)
+  int apply_deltas(float stop_threshold = -1.f, bool report = false, uint32_t seq = 0) {
     const uint32_t kd = K * D;
     for (size_t i = 0; i < shards.size(); i++) {
       auto &s = shards[i];
       RETERR(s->eng->apply_delta(s->reduce, nullptr, s->reduce + kd, s->centroids, s->ccounts, stop_threshold,
-                                 (i == 0 && slot >= 0) ? host_tail + 8 * slot : nullptr, seq));
-      if (i == 0 && slot >= 0 && hipEventRecord(ev_tail[slot], s->eng->stream_) != hipSuccess) return kmcudaRuntimeError;
+                                 report && i == 0, seq));
     }
     return quantize_centroids();
   }
@@ -878,18 +865,23 @@ class Job {
   //           iteration is judged by the host before its update, as in the reference.
   //   *left:  the loop returned for `leave`, not for the stop rule
   using LeaveFn = std::function<bool(int iter, uint32_t changed)>;
-  int lloyd(float tolerance, int *iterations, const LeaveFn *leave = nullptr, bool *left = nullptr) {
-    RETERR(prepare_mem(false));
+  //   after:  0 = a fresh run.  > 0: carry on after iteration `after`, whose stop test said "go on" and whose
+  //           (reduced) move sums still sit in the reduce buffers: its update first, then iteration after + 1
+  int lloyd(float tolerance, int *iterations, const LeaveFn *leave = nullptr, bool *left = nullptr, int after = 0) {
+    if (after == 0) RETERR(prepare_mem(false));
     if (left) *left = false;
     // the samples do not change inside one kmeans_cuda() call: let the coarse filter stage keep its
     // centred half copy of the rows across the iterations (kmamd_set_row_cache, include/kmcuda_amd.h)
     for (auto &s : shards) {
-      s->eng->row_cache_on_ = s->eng->row_cache_allowed_;
-      s->eng->row_cache_valid_ = false;
+      if (after == 0) {
+        s->eng->row_cache_on_ = s->eng->row_cache_allowed_;
+        s->eng->row_cache_valid_ = false;
+      }
       RETERR(s->eng->stop_clear());
     }
     if (exact_update) {   // strict-parity mode: the reference's sequence, step by step
-      for (int iter = 1;; iter++) {
+      if (after) RETERR(adjust());
+      for (int iter = after + 1;; iter++) {
         for (auto &s : shards)
           RETERR(s->eng->lloyd_assign(s->samples, s->centroids, s->assignments, s->prev, false));
         const int status = check_changed(iter, tolerance, true);
@@ -905,7 +897,11 @@ class Job {
     const float threshold = tolerance * N;   // the float product of kmeans.cu:707
     bool leave_next = false;
     int unjudged = 0;   // a speculative iteration whose outcome the host has not looked at yet
-    for (int iter = 1;; iter++) {
+    if (after) {
+      for (auto &s : shards) RETERR(s->eng->counters_reset(0));   // (the stop that ended the last run left it, kmeans.cu:707-709)
+      RETERR(apply_deltas());
+    }
+    for (int iter = after + 1;; iter++) {
       const bool spec = speculate && !leave_next;
       RETERR(for_shards([](Shard &s) {
         const int rc = s.eng->lloyd_assign(s.samples, s.centroids, s.assignments, s.prev, false);
@@ -914,7 +910,7 @@ class Job {
         return s.eng->move_deltas(s.samples, s.prev, s.assignments, s.reduce, nullptr, s.reduce + kd);
       }));
       RETERR(allreduce_fused());
-      if (spec) RETERR(apply_deltas(threshold, iter & 1, (uint32_t)iter));
+      if (spec) RETERR(apply_deltas(threshold, true, (uint32_t)iter));
       if (unjudged) {
         uint32_t changed = 0;
         const int status = judge_reported(unjudged, &changed);
@@ -942,14 +938,11 @@ class Job {
     }
   }
 
-  // the outcome of speculative iteration `iter`, as its update kernel reported it.  1: stopped, 0: went on
+  // the outcome of speculative iteration `iter`, as the first shard's update kernel reported it.  1: stopped, 0: went on
   int judge_reported(int iter, uint32_t *changed) {
-    const int slot = iter & 1;
-    (void)hipSetDevice(shards[0]->dev);
-    if (hipEventSynchronize(ev_tail[slot]) != hipSuccess) return -kmcudaRuntimeError;
-    volatile uint32_t *t = host_tail + 8 * slot;
-    if (t[5] != (uint32_t)iter) {
-      INFO("internal error: iteration %d reported as %u\n", iter, t[5]);
+    uint32_t t[6];
+    if (shards[0]->eng->stop_report((uint32_t)iter, t) != 0) {
+      INFO("internal error: no report of iteration %d\n", iter);
       return -kmcudaRuntimeError;
     }
     DEBUG("filter: %u rows settled by two exact chains, %u by a full exact scan\n", t[3], t[1]);
@@ -983,9 +976,7 @@ class Job {
     return 0;
   }
 
-  int yinyang(float tolerance, uint32_t G, int iter) {
-    std::vector<uint32_t> groups;
-    RETERR(cluster_groups(G, &groups));
+  int yinyang(float tolerance, uint32_t G, int iter, const std::vector<uint32_t> &groups) {
     for (auto &s : shards) {
       (void)hipSetDevice(s->dev);
       RETERR(s->eng->yy_configure(G, groups.data()));
@@ -1543,21 +1534,25 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
     const char *yym = getenv("KMCUDA_AMD_YY");
     const bool adaptive = !(yym && strcmp(yym, "reference") == 0) && !job.exact_update &&
                           job.shards[0]->eng->DP_ != 0 && job.shards[0]->eng->filter_mode_ == 0;
-    if (!adaptive) {
-      INFO("running Lloyd until reassignments drop below %u\n", (uint32_t)(kYinyangDraftReassignments * samples_size));
-      int iter = 0;
-      RETERR(job.lloyd((float)kYinyangDraftReassignments, &iter));
-      const int st = job.check_changed(iter, tolerance, false);  // kmeans.cu:1058
-      if (st < 0) return static_cast<KMCUDAResult>(-st);
-      if (st == 0) RETERR(job.yinyang(tolerance, yy_groups_size, iter));
-    } else {
-      INFO("running Lloyd; Yinyang's bounds take over when they can pay for their refresh\n");
-      BoundsModel model(samples_size, feats, clusters_size, yy_groups_size, tolerance);
-      const Job::LeaveFn leave = [&model](int, uint32_t changed) { return model.pays(changed); };
-      int iter = 0;
-      bool left = false;
-      RETERR(job.lloyd(tolerance, &iter, &leave, &left));
-      if (left) RETERR(job.yinyang(tolerance, yy_groups_size, iter));
+    INFO("running Lloyd until reassignments drop below %u\n", (uint32_t)(kYinyangDraftReassignments * samples_size));
+    BoundsModel model(samples_size, feats, clusters_size, yy_groups_size, tolerance);
+    const Job::LeaveFn record = [&model](int, uint32_t changed) { (void)model.pays(changed); return false; };
+    int iter = 0;
+    RETERR(job.lloyd((float)kYinyangDraftReassignments, &iter, adaptive ? &record : nullptr));
+    const int st = job.check_changed(iter, tolerance, false);  // kmeans.cu:1058
+    if (st < 0) return static_cast<KMCUDAResult>(-st);
+    if (st == 0) {
+      // the reference's hand-over point: the K centroids are clustered into groups here (its progress lines are
+      // part of what a caller sees, its srand(0) of what a caller's rand() sees) -- whichever schedule follows
+      std::vector<uint32_t> groups;
+      RETERR(job.cluster_groups(yy_groups_size, &groups));
+      bool bounds = !adaptive;
+      if (adaptive) {
+        INFO("Lloyd goes on; Yinyang's bounds take over when they can pay for their refresh\n");
+        const Job::LeaveFn leave = [&model](int, uint32_t changed) { return model.pays(changed); };
+        RETERR(job.lloyd(tolerance, &iter, &leave, &bounds, iter));
+      }
+      if (bounds) RETERR(job.yinyang(tolerance, yy_groups_size, iter, groups));
     }
   }
   RETERR(job.sync_all());

@@ -12,20 +12,22 @@
 // pairs with a serial fp32 Kahan chain.  Here:
 //   move events      key 2*cur if the row moved in, 2*prev+1 if it moved out.  Late iterations move a
 //                    few percent of the rows, so nothing here is sized by N except one read of
-//                    (prev, cur): histogram of the keys (integer atomics: exact) -> scan -> the host
-//                    reads (event count, largest bucket), then either
-//     buckets        (largest bucket <= 8192) rows scattered to their key's bucket through atomic
-//                    cursors, each bucket sorted ascending in LDS: the set is exact, the order fixed
-//     radix sort     (else) events compacted in row order (count per 1024-row block, scan, write)
-//                    and sorted stably by key (rocprim)
-//                    -- both give per (cluster, sign) segments with rows ascending, bit-identical sums
-//   segment_sums     grid (2K, kSumSplit): fp64 column sums of each segment slice, rows read as
-//                    whole coalesced rows (only MOVED rows are touched: late iterations are cheap)
-//   fold_delta       delta[c] = sum_in - sum_out (fixed order), dcount[c] = n_in - n_out
+//                    (prev, cur):
+//     direct         every event's row dropped into its key's bucket through an atomic cursor
+//                    (move_scatter), then ONE kernel with a block per centroid (cluster_sums): both
+//                    buckets sorted ascending in LDS -- the set is exact, the order fixed again --
+//                    summed, folded.  No host read; an overflowing bucket is rebuilt in order from
+//                    (prev, cur) by that block
+//     radix sort     (the first iterations: most rows move) events compacted in row order (count per
+//                    1024-row block, scan, write) and sorted stably by key (rocprim); the same
+//                    cluster_sums kernel reads its segments
+//                    -- both give per (cluster, sign) lists with rows ascending, bit-identical sums
+//   cluster_sums     fp64 column sums of each list in a fixed association (only MOVED rows are touched),
+//                    delta[c] = sum_in - sum_out, dcount[c] = n_in - n_out, the reduce buffer's tail
 //   [row-sharded multi-GPU: all-reduce of delta / dcount happens here]
-//   apply_delta      the formula above in fp64, rounded once to fp32
+//   apply_delta      the formula above in fp64, rounded once to fp32; the stop rule on the device
 // Centroids agree with the reference's fp32 Kahan chain to a few ulp (tests: 2e-6 relative);
-// they are bit-reproducible run to run and independent of kSumSplit.  An empty cluster yields
+// they are bit-reproducible run to run and across the two paths.  An empty cluster yields
 // a non-finite row that is never chosen again, as in the reference (kmeans.cu:425-426).
 #include <stdio.h>
 #include <stdlib.h>
@@ -208,295 +210,295 @@ __global__ __launch_bounds__(256) void move_write_kernel(const uint32_t *__restr
   }
 }
 
-// grid (2K, kSumSplit); thread t owns features t, t+blockDim, ...
-__global__ void segment_sums_kernel(const float *__restrict__ samples, uint32_t D, const uint32_t *__restrict__ rows,
-                                    const uint32_t *__restrict__ offsets, double *__restrict__ partial) {
-  const uint32_t seg = blockIdx.x, j = blockIdx.y;
-  const uint32_t beg = offsets[seg], end = offsets[seg + 1];
-  const uint32_t n = end - beg;
-  const uint32_t chunk = (n + kSumSplit - 1) / kSumSplit;
-  uint32_t r0 = beg + j * chunk, r1 = r0 + chunk;
-  if (r0 > end) r0 = end;
-  if (r1 > end) r1 = end;
-  for (uint32_t f = threadIdx.x; f < D; f += blockDim.x) {
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    uint32_t r = r0;
-    for (; r + 4 <= r1; r += 4) {
-      const float x0 = samples[(size_t)rows[r + 0] * D + f];
-      const float x1 = samples[(size_t)rows[r + 1] * D + f];
-      const float x2 = samples[(size_t)rows[r + 2] * D + f];
-      const float x3 = samples[(size_t)rows[r + 3] * D + f];
-      a0 += x0; a1 += x1; a2 += x2; a3 += x3;
+// ---------------------------------------------------------------------------------------
+// cluster_sums: ONE kernel per update, one block per centroid -- the ordered move lists of the centroid (rows
+// that joined it, rows that left it), their fp64 column sums, delta = in - out, the count change, and the
+// fused reduce buffer's tail.  The lists come from one of two places:
+//   DIRECT   move_scatter_kernel has dropped every event's row into its key's bucket (key = 2 c + sign, `cap`
+//            slots) through an atomic cursor: arbitrary positions, exact set.  The block sorts the bucket
+//            ascending in LDS -- the order is fixed again.  A bucket that overflowed (the cursor counts every
+//            attempt) is rebuilt from (prev, cur) themselves by an ordered compaction over all N rows: O(N) per
+//            such bucket, correct for any input, so the host never has to look at the counts first.
+//   SORTED   the radix path's stably sorted events (first iterations: most rows move).
+// Either way a list is ascending by row and the summation below depends on nothing else: the update is
+// bit-reproducible across the two paths, the host's choice of path, and run to run.
+//
+// Summation of a list of n rows (threads = groups x fl, fl lanes across the features): group g takes the
+// contiguous rows [g * ceil(n / groups), ...), eight independent accumulators by row position, folded as
+// ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)); the groups' sums are added in ascending g.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t kSumThreads = 1024;
+constexpr uint32_t kBucketCapMax = 4096;   // rows an LDS sort holds (two lists: 32 KB)
+
+uint32_t move_bucket_cap(uint32_t N, uint32_t K) {
+  // about the rows per centroid, as a power of two in [32, 4096]: steady iterations move a few percent of them
+  uint32_t cap = 32;
+  while (cap < kBucketCapMax && (uint64_t)cap * 2 * K <= (uint64_t)N) cap <<= 1;
+  return cap;
+}
+
+struct SumArgs {
+  const float *samples;
+  uint32_t N, D, K;
+  const uint32_t *prev, *cur;           // DIRECT: the overflow fallback re-reads them
+  uint32_t *cursors;                    // DIRECT: 2 K event counts, `stride` words apart; left zero
+  uint32_t stride;
+  const uint32_t *bucket_rows;          // DIRECT: 2 K x cap
+  uint32_t cap;
+  uint32_t *overflow;                   // DIRECT: 2 N words for rebuilt lists
+  const uint32_t *rows_sorted, *offsets2;   // SORTED
+  double *delta;
+  int32_t *dcount;                      // may be null
+  double *tail;                         // may be null: [dcount K | counters 4] behind delta
+  const uint32_t *counters;
+  uint32_t *res;                        // device: [0] events, [1] largest list, [2] ticket, [3] overflow cursor
+  uint32_t *host;                       // pinned, device-visible: [0] events, [1] largest list, [2] counters[4]
+};
+
+__device__ __forceinline__ double list_sum(const float *__restrict__ samples, uint32_t D, const uint32_t *rows,
+                                           uint32_t r0, uint32_t r1, uint32_t f) {
+  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = samples[(size_t)rows[r + j] * D + f];
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] += (double)x[j];
+  }
+  for (uint32_t j = 0; r < r1; r++, j++) a[j] += (double)samples[(size_t)rows[r] * D + f];
+  return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
+template <bool DIRECT>
+__global__ __launch_bounds__(kSumThreads) void cluster_sums_kernel(SumArgs a) {
+  __shared__ uint32_t srt[2][kBucketCapMax];
+  __shared__ double part[kSumThreads];
+  __shared__ uint32_t wcnt[16];
+  __shared__ uint32_t sh_base;
+  const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t D = a.D;
+  const uint32_t *rows[2];
+  uint32_t n[2];
+  if (DIRECT) {
+    n[0] = a.cursors[(size_t)(2 * c) * a.stride];
+    n[1] = a.cursors[(size_t)(2 * c + 1) * a.stride];
+    __syncthreads();   // everybody has read the counts
+    if (tid < 2) a.cursors[(size_t)(2 * c + tid) * a.stride] = 0u;   // zero again for the next update
+#pragma unroll
+    for (int sg = 0; sg < 2; sg++) {
+      const uint32_t cnt = n[sg], key = 2 * c + sg;
+      if (cnt <= a.cap) {
+        // bitonic sort of the bucket, padded to a power of two with 0xFFFFFFFF
+        uint32_t m = 2;
+        while (m < cnt) m <<= 1;
+        uint32_t *v = srt[sg];
+        for (uint32_t i = tid; i < m; i += kSumThreads) v[i] = i < cnt ? a.bucket_rows[(size_t)key * a.cap + i] : 0xFFFFFFFFu;
+        __syncthreads();
+        if (cnt > 1) {
+          for (uint32_t k = 2; k <= m; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+              for (uint32_t i = tid; i < m; i += kSumThreads) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                  const uint32_t x = v[i], y = v[l];
+                  const bool up = (i & k) == 0;
+                  if ((x > y) == up) { v[i] = y; v[l] = x; }
+                }
+              }
+              __syncthreads();
+            }
+          }
+        }
+        rows[sg] = v;
+      } else {
+        // the bucket overflowed: rebuild the list, ascending, from (prev, cur) -- 4 consecutive rows per thread
+        if (tid == 0) sh_base = atomicAdd(&a.res[3], cnt);
+        __syncthreads();
+        uint32_t *dst = a.overflow + sh_base;
+        uint32_t done = 0;
+        for (uint32_t base = 0; base < a.N; base += 4 * kSumThreads) {
+          uint32_t hit[4], cntme = 0;
+#pragma unroll
+          for (uint32_t q = 0; q < 4; q++) {
+            const uint32_t s = base + tid * 4 + q;
+            uint32_t p, cu;
+            bool ein, eout;
+            move_flags(a.prev, a.cur, s, a.N, a.K, p, cu, ein, eout);
+            const bool mine = sg == 0 ? (ein && cu == c) : (eout && p == c);
+            hit[q] = mine ? s : 0xFFFFFFFFu;
+            cntme += mine ? 1u : 0u;
+          }
+          uint32_t inc = cntme;   // inclusive scan over the wave
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o);
+            if ((int)lane >= o) inc += t;
+          }
+          if (lane == 63) wcnt[wave] = inc;
+          __syncthreads();
+          uint32_t wbase = 0, all = 0;
+#pragma unroll
+          for (uint32_t k = 0; k < 16; k++) {
+            const uint32_t t = wcnt[k];
+            if (k < wave) wbase += t;
+            all += t;
+          }
+          uint32_t at = done + wbase + inc - cntme;
+#pragma unroll
+          for (uint32_t q = 0; q < 4; q++)
+            if (hit[q] != 0xFFFFFFFFu) dst[at++] = hit[q];
+          done += all;
+          __syncthreads();
+        }
+        __threadfence_block();
+        rows[sg] = dst;
+      }
     }
-    for (; r < r1; r++) a0 += samples[(size_t)rows[r] * D + f];
-    partial[((size_t)seg * kSumSplit + j) * D + f] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+  } else {
+    const uint32_t o0 = a.offsets2[2 * c], o1 = a.offsets2[2 * c + 1], o2 = a.offsets2[2 * c + 2];
+    n[0] = o1 - o0; n[1] = o2 - o1;
+    rows[0] = a.rows_sorted + o0;
+    rows[1] = a.rows_sorted + o1;
   }
+
+  // ---- sums: fl lanes across the features, groups of rows ----
+  const uint32_t fl = D > 128 ? 256u : (D > 64 ? 128u : 64u), groups = kSumThreads / fl;
+  const uint32_t g = tid / fl, lf = tid % fl;
+  for (uint32_t f0 = 0; f0 < D; f0 += fl) {
+    const uint32_t f = f0 + lf;
+    const bool fv = f < D;
+    double tot[2] = {0, 0};
+#pragma unroll
+    for (int sg = 0; sg < 2; sg++) {
+      const uint32_t cnt = n[sg], chunk = (cnt + groups - 1) / groups;
+      const uint32_t r0 = min(cnt, g * chunk), r1 = min(cnt, r0 + chunk);
+      part[tid] = (fv && r1 > r0) ? list_sum(a.samples, D, rows[sg], r0, r1, f) : 0.0;
+      __syncthreads();
+      if (g == 0) {
+        double t = part[lf];
+        for (uint32_t gg = 1; gg < groups; gg++) t += part[gg * fl + lf];
+        tot[sg] = t;
+      }
+      __syncthreads();
+    }
+    if (g == 0 && fv) a.delta[(size_t)c * D + f] = tot[0] - tot[1];
+  }
+  if (tid == 0) {
+    const int32_t dc = (int32_t)n[0] - (int32_t)n[1];
+    if (a.dcount) a.dcount[c] = dc;
+    if (a.tail) a.tail[c] = (double)dc;
+    atomicAdd(&a.res[0], n[0] + n[1]);
+    atomicMax(&a.res[1], max(n[0], n[1]));
+    __threadfence();
+    const uint32_t ticket = atomicAdd(&a.res[2], 1u);
+    if (ticket == gridDim.x - 1) {   // the last block: report to the host's pinned words, reset for the next update
+      volatile uint32_t *h = a.host;
+      h[0] = atomicAdd(&a.res[0], 0u);
+      h[1] = atomicAdd(&a.res[1], 0u);
+      h[2] = a.counters[4];
+      a.res[0] = 0u; a.res[1] = 0u; a.res[2] = 0u; a.res[3] = 0u;
+    }
+  }
+  if (a.tail && c == 0 && tid < 4) a.tail[a.K + tid] = (double)a.counters[tid];
 }
 
-// tail (may be null): the fused reduce buffer's end, [dcount as doubles (K) | counters 0..3 as doubles]
-// right behind delta -- everything one all-reduce carries (exact in fp64: |values| < 2^32)
-__global__ void fold_delta_kernel(const double *__restrict__ partial, const uint32_t *__restrict__ offsets,
-                                  uint32_t K, uint32_t D, double *__restrict__ delta, int32_t *__restrict__ dcount,
-                                  double *__restrict__ tail, const uint32_t *__restrict__ counters) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tail && i < 4) tail[K + i] = (double)counters[i];
-  if (i >= (size_t)K * D) return;
-  const uint32_t c = i / D, f = i % D;
-  double in = 0, out = 0;
-  for (uint32_t j = 0; j < kSumSplit; j++) in += partial[((size_t)(2 * c) * kSumSplit + j) * D + f];
-  for (uint32_t j = 0; j < kSumSplit; j++) out += partial[((size_t)(2 * c + 1) * kSumSplit + j) * D + f];
-  delta[i] = in - out;
-  if (f == 0) {
-    const int32_t dc = (int32_t)(offsets[2 * c + 1] - offsets[2 * c]) - (int32_t)(offsets[2 * c + 2] - offsets[2 * c + 1]);
-    if (dcount) dcount[c] = dc;
-    if (tail) tail[c] = (double)dc;
-  }
-}
-
-// ---- bucket path: histogram / scan / scatter / per-bucket LDS sort ----------------------------
 // counters one cache line apart while that stays under ~1 MB per array
 uint32_t move_bucket_stride(uint32_t K) {
   uint32_t s = 32;
   while (s > 1 && 2ull * K * s > 262144ull) s >>= 1;
   return s;
 }
-size_t move_bucket_words(uint32_t K) { return 4 * (size_t)K * move_bucket_stride(K) + 4; }
+// cursors (2 K, `stride` apart) + 4 result words; zero-initialised by the owner, left zero by every update
+size_t move_bucket_words(uint32_t K) { return 2 * (size_t)K * move_bucket_stride(K) + 4; }
 
-__global__ __launch_bounds__(256) void move_hist_kernel(const uint32_t *__restrict__ prev,
-                                                        const uint32_t *__restrict__ cur, uint32_t N, uint32_t K,
-                                                        uint32_t *__restrict__ hist, uint32_t stride) {
-  // counters `stride` words apart: packed, the 2K counters of K = 1024 share 64 cache lines and the
-  // L2 serialises the atomics per line (measured 118 us for 6e5 events; one line each: ~20 us)
-  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-  uint32_t p, a;
-  bool ein, eout;
-  move_flags(prev, cur, s, N, K, p, a, ein, eout);
-  if (ein) atomicAdd(&hist[(size_t)(2u * a) * stride], 1u);
-  if (eout) atomicAdd(&hist[(size_t)(2u * p + 1u) * stride], 1u);
-}
-
-// hist[0..nkeys) -> offsets[0..nkeys] (exclusive), cursors = offsets, hist zeroed for the next call;
-// out[0] = events, out[1] = largest bucket.  One block.
-__global__ __launch_bounds__(1024) void move_bucket_scan_kernel(uint32_t *__restrict__ hist, uint32_t nkeys,
-                                                                uint32_t stride, uint32_t *__restrict__ offsets,
-                                                                uint32_t *__restrict__ cursors,
-                                                                uint32_t *__restrict__ out) {
-  __shared__ uint32_t wsum[16], wmax[16];
-  __shared__ uint32_t carry_s, max_s;
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) { carry_s = 0; max_s = 0; }
-  __syncthreads();
-  for (uint32_t base = 0; base < nkeys; base += 1024) {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t v = i < nkeys ? hist[(size_t)i * stride] : 0u;
-    if (i < nkeys) hist[(size_t)i * stride] = 0u;
-    uint32_t inc = v, mx = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t t = __shfl_up(inc, o);
-      if ((int)lane >= o) inc += t;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
-    if (lane == 63) wsum[wave] = inc;
-    if (lane == 0) wmax[wave] = mx;
-    __syncthreads();
-    uint32_t wbase = 0, all = 0, m = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 16; k++) {
-      const uint32_t t = wsum[k];
-      if (k < wave) wbase += t;
-      all += t;
-      m = max(m, wmax[k]);
-    }
-    const uint32_t carry = carry_s;
-    if (i < nkeys) {
-      const uint32_t ex = carry + wbase + inc - v;
-      offsets[i] = ex;
-      cursors[(size_t)i * stride] = ex;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) { carry_s = carry + all; max_s = max(max_s, m); }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    offsets[nkeys] = carry_s;
-    out[0] = carry_s;
-    out[1] = max_s;
-  }
-}
-
+// every event's row into its key's bucket; the cursor counts every attempt, also beyond the capacity
+// (counters `stride` words apart: packed, the 2K counters of K = 1024 share 64 cache lines and the L2
+// serialises the atomics per line -- 118 us for 6e5 events, one line each ~20 us)
 __global__ __launch_bounds__(256) void move_scatter_kernel(const uint32_t *__restrict__ prev,
                                                            const uint32_t *__restrict__ cur, uint32_t N, uint32_t K,
                                                            uint32_t *__restrict__ cursors, uint32_t stride,
-                                                           uint32_t *__restrict__ rows_out) {
+                                                           uint32_t *__restrict__ bucket_rows, uint32_t cap) {
   const uint32_t s = blockIdx.x * 256u + threadIdx.x;
   uint32_t p, a;
   bool ein, eout;
   move_flags(prev, cur, s, N, K, p, a, ein, eout);
-  if (ein) rows_out[atomicAdd(&cursors[(size_t)(2u * a) * stride], 1u)] = s;
-  if (eout) rows_out[atomicAdd(&cursors[(size_t)(2u * p + 1u) * stride], 1u)] = s;
+  if (ein) {
+    const uint32_t at = atomicAdd(&cursors[(size_t)(2u * a) * stride], 1u);
+    if (at < cap) bucket_rows[(size_t)(2u * a) * cap + at] = s;
+  }
+  if (eout) {
+    const uint32_t at = atomicAdd(&cursors[(size_t)(2u * p + 1u) * stride], 1u);
+    if (at < cap) bucket_rows[(size_t)(2u * p + 1u) * cap + at] = s;
+  }
 }
 
-// one block per bucket: ascending row order (bitonic in LDS; the scatter order above is arbitrary).
-// A bucket beyond the LDS capacity is ranked by counting through `scratch` (same offsets): O(n^2), only
-// there so that the bucket path is CORRECT for any input without the host having looked at the counts
-// first -- the host steers such iterations to the radix path as soon as it sees them (launch_move_deltas).
-constexpr uint32_t kBucketCap = 4096;
-__global__ __launch_bounds__(256) void bucket_sort_kernel(const uint32_t *__restrict__ offsets,
-                                                          uint32_t *__restrict__ rows,
-                                                          uint32_t *__restrict__ scratch) {
-  __shared__ uint32_t v[kBucketCap];
-  const uint32_t beg = offsets[blockIdx.x], n = offsets[blockIdx.x + 1] - beg;
-  if (n < 2) return;
-  if (n > kBucketCap) {
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-      const uint32_t mine = rows[beg + i];
-      uint32_t rank = 0;
-      for (uint32_t j = 0; j < n; j++) rank += rows[beg + j] < mine ? 1u : 0u;   // rows are distinct
-      scratch[beg + rank] = mine;
-    }
-    __threadfence_block();
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += 256) rows[beg + i] = scratch[beg + i];
-    return;
-  }
-  uint32_t m = 2;
-  while (m < n) m <<= 1;
-  for (uint32_t i = threadIdx.x; i < m; i += 256) v[i] = i < n ? rows[beg + i] : 0xFFFFFFFFu;
-  __syncthreads();
-  for (uint32_t k = 2; k <= m; k <<= 1) {
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t i = threadIdx.x; i < m; i += 256) {
-        const uint32_t l = i ^ j;
-        if (l > i) {
-          const uint32_t a = v[i], b = v[l];
-          const bool up = (i & k) == 0;
-          if ((a > b) == up) { v[i] = b; v[l] = a; }
-        }
-      }
-      __syncthreads();
-    }
-  }
-  for (uint32_t i = threadIdx.x; i < n; i += 256) rows[beg + i] = v[i];
-}
-
-// The host side of the update.  Three ways through it, all leaving per (cluster, sign) segments with
-// rows ascending (bit-identical sums):
-//   radix   the first iterations (most rows move: the histogram's atomics alone would cost more):
-//           compaction + rocprim sort sized by the event count -> ONE host read
-//   bucket, checked   histogram, scan, the host reads (events, largest bucket) and picks bucket / radix
-//   bucket, unchecked (steady state; MoveState::async_ok) histogram, scan, scatter, LDS sort -- NO host
-//           read: the counts go to the pinned words by an async copy nobody waits for; the host looks at
-//           whatever has landed (an EARLIER call's counts) only to steer later calls.  A bucket beyond the
-//           LDS sort's capacity is still sorted correctly by the kernel's fallback, so nothing depends on
-//           the prediction but speed.
+// The host side of the update.  Two ways to the ordered move lists, bit-identical sums either way:
+//   radix    the first iterations (most rows move: the buckets would overflow): compaction + rocprim sort
+//            sized by the event count -> ONE host read
+//   direct   everything else: scatter + cluster_sums, NOTHING read.  The kernel reports (events, largest
+//            list) to pinned words; the host looks at whatever has landed -- an earlier update's figures --
+//            only to pick the path of LATER updates.  Nothing but speed depends on that choice.
 hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint32_t K, const uint32_t *prev,
                               const uint32_t *cur, uint32_t *keys_tmp, uint32_t *vals_tmp, uint32_t *keys_sorted,
                               uint32_t *rows_sorted, uint32_t *offsets2, void *temp, size_t temp_bytes,
-                              double *partial, double *delta, int32_t *dcount, double *tail,
+                              uint32_t *bucket_rows, uint32_t cap, double *delta, int32_t *dcount, double *tail,
                               const uint32_t *counters, uint32_t *blockoff, uint32_t *bucket_work, MoveState *ms,
-                              hipEvent_t copied, hipStream_t st) {
-  // blockoff: N / 1024 + 2 words; bucket_work: move_bucket_words(K) words = histogram | cursors (both
-  // 2 K counters, move_bucket_stride(K) words apart) | 2 results; the histogram is zero on entry (engine:
-  // zeroed at creation, left zero by the scan); ms->host: 4 pinned words
+                              hipStream_t st) {
+  // blockoff: N / 1024 + 2 words; bucket_work: move_bucket_words(K) words, zero on entry and on exit;
+  // ms->host / host_dev: 4 pinned words
   const uint32_t stride = move_bucket_stride(K);
-  uint32_t *hist = bucket_work, *cursors = bucket_work + 2 * (size_t)K * stride,
-           *res = bucket_work + 4 * (size_t)K * stride;
-  uint32_t *host_count = ms->host;
+  SumArgs a;
+  a.samples = samples; a.N = N; a.D = D; a.K = K; a.prev = prev; a.cur = cur;
+  a.cursors = bucket_work; a.stride = stride; a.bucket_rows = bucket_rows; a.cap = cap;
+  a.overflow = rows_sorted; a.rows_sorted = rows_sorted; a.offsets2 = offsets2;
+  a.delta = delta; a.dcount = dcount; a.tail = tail; a.counters = counters;
+  a.res = bucket_work + 2 * (size_t)K * stride; a.host = ms->host_dev;
   hipError_t e = hipSuccess;
-  uint32_t m = 0, maxb = 0;
-  const bool force_radix = ms->force == 1, force_sync = ms->force == 2, force_bucket = ms->force == 3;
+  const bool force_radix = ms->force == 1, force_sync = ms->force == 2, force_direct = ms->force == 3;
   // last_events: the newest event count the host knows (2 N before the first call)
-  const bool direct_radix = !force_bucket && (force_radix || ms->last_events > N / 2);
-  auto bucket_kernels = [&]() {
-    hipLaunchKernelGGL(move_scatter_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, cursors,
-                       stride, rows_sorted);
-    hipLaunchKernelGGL(bucket_sort_kernel, dim3(2 * K), dim3(256), 0, st, offsets2, rows_sorted, keys_sorted);
-  };
+  const bool radix = N != 0 && !force_direct && (force_radix || ms->last_events > N / 2);
   if (N == 0) {
     e = hipMemsetAsync(offsets2, 0, (2 * (size_t)K + 1) * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
-  } else if (direct_radix) {
-    ms->async_ok = false;
+    hipLaunchKernelGGL((cluster_sums_kernel<false>), dim3(K), dim3(kSumThreads), 0, st, a);
+  } else if (radix) {
     const uint32_t nb = (N + kMoveRows - 1) / kMoveRows;
     hipLaunchKernelGGL(move_count_kernel, dim3(nb), dim3(256), 0, st, prev, cur, N, K, blockoff);
     hipLaunchKernelGGL(move_scan_kernel, dim3(1), dim3(1024), 0, st, blockoff, nb, blockoff + nb + 1);
     hipLaunchKernelGGL(move_write_kernel, dim3(nb), dim3(256), 0, st, prev, cur, N, K, blockoff, keys_tmp, vals_tmp);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    e = hipMemcpyAsync(host_count, blockoff + nb + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    e = hipMemcpyAsync(ms->host + 3, blockoff + nb + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return e;
-    m = host_count[0];
+    const uint32_t m = ms->host[3];
     if (m) {
       e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t *)keys_tmp, keys_sorted,
                                     (const uint32_t *)vals_tmp, rows_sorted, (size_t)m, 0u, bits_for(2ull * K), st);
       if (e != hipSuccess) return e;
     }
-    // no histogram ran: segment starts by binary search in the sorted keys
+    // segment starts by binary search in the sorted keys
     hipLaunchKernelGGL(offsets_kernel, dim3((2 * K + 1 + 255) / 256), dim3(256), 0, st, keys_sorted, m, 2 * K, offsets2);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((cluster_sums_kernel<false>), dim3(K), dim3(kSumThreads), 0, st, a);
     ms->last_events = m;
+    ms->host[0] = m;   // (the kernel's report will say the same)
   } else {
-    hipLaunchKernelGGL(move_hist_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, hist, stride);
-    hipLaunchKernelGGL(move_bucket_scan_kernel, dim3(1), dim3(1024), 0, st, hist, 2 * K, stride, offsets2, cursors, res);
+    hipLaunchKernelGGL(move_scatter_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, bucket_work,
+                       stride, bucket_rows, cap);
+    hipLaunchKernelGGL((cluster_sums_kernel<true>), dim3(K), dim3(kSumThreads), 0, st, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    e = hipMemcpyAsync(host_count, res, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
-    if (e != hipSuccess) return e;
-    if (force_bucket || (ms->async_ok && !force_sync)) {
-      bucket_kernels();
-      e = hipGetLastError();
+    if (force_sync) {   // KMCUDA_AMD_UPDATE=sync: the next call decides on THIS call's figures
+      e = hipStreamSynchronize(st);
       if (e != hipSuccess) return e;
-      // whatever has landed: an earlier call's counts (this call's copy is still queued)
-      m = host_count[0];
-      maxb = host_count[1];
-      if (maxb > kBucketCap - kBucketCap / 4 || m > N / 2) ms->async_ok = false;   // look before leaping next time
-      ms->last_events = m;
-    } else {
-      if (copied) e = hipEventRecord(copied, st);
-      if (e != hipSuccess) return e;
-      // while the previous call took the bucket path its two kernels are launched BEFORE the host waits for
-      // the counts: the GPU runs them during the round trip; if the counts say otherwise the radix path
-      // below simply redoes rows_sorted
-      const bool speculate = copied && ms->bucket_last;
-      if (speculate) bucket_kernels();
-      e = copied ? hipEventSynchronize(copied) : hipStreamSynchronize(st);   // the copy, not what was queued behind it
-      if (e != hipSuccess) return e;
-      m = host_count[0];
-      maxb = host_count[1];
-      ms->last_events = m;
-      ms->bucket_last = false;
-      if (m && maxb <= kBucketCap) {
-        ms->bucket_last = true;
-        ms->async_ok = maxb <= kBucketCap - kBucketCap / 4;   // comfortably inside: stop looking first
-        if (!speculate) bucket_kernels();
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-      } else if (m) {
-        const uint32_t nb = (N + kMoveRows - 1) / kMoveRows;
-        hipLaunchKernelGGL(move_count_kernel, dim3(nb), dim3(256), 0, st, prev, cur, N, K, blockoff);
-        hipLaunchKernelGGL(move_scan_kernel, dim3(1), dim3(1024), 0, st, blockoff, nb, blockoff + nb + 1);
-        hipLaunchKernelGGL(move_write_kernel, dim3(nb), dim3(256), 0, st, prev, cur, N, K, blockoff, keys_tmp, vals_tmp);
-        e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t *)keys_tmp, keys_sorted,
-                                      (const uint32_t *)vals_tmp, rows_sorted, (size_t)m, 0u, bits_for(2ull * K), st);
-        if (e != hipSuccess) return e;
-      }
     }
+    ms->last_events = ms->host[0];   // whatever has landed: an earlier update's count
   }
-  // offsets2 (segment starts per key) came out of the histogram scan or the binary search
-  const uint32_t bs = D >= 256 ? 256 : (D > 64 ? 128 : 64);
-  hipLaunchKernelGGL(segment_sums_kernel, dim3(2 * K, kSumSplit), dim3(bs), 0, st, samples, D, rows_sorted, offsets2,
-                     partial);
-  const size_t n = (size_t)K * D;
-  hipLaunchKernelGGL(fold_delta_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, partial, offsets2, K, D,
-                     delta, dcount, tail, counters);
   return hipGetLastError();
 }
 
-// one block per centroid: c = normalize(c*count + delta), count += dcount
 // StopCtl (kernels.hpp): the reference's stop rule -- check_changed, kmeans.cu:697-717, evaluated BEFORE the
 // update -- decided here, on the device, from the reduced reassignment count behind dcount_d: every block reads
 // the same word and takes the same branch.  Stopping: nothing is modified, the flag is raised (the kernels that

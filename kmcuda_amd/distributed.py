@@ -77,24 +77,15 @@ class HipBackend:
     def apply_stop(self, buf, threshold, seq):
         """The update, unless the reduced reassignment count is <= threshold (then nothing is touched and
         later assign() calls are no-ops).  Returns a handle for read_report()."""
-        if not hasattr(self, "_tails"):
-            self._tails = [torch.zeros(8, dtype=torch.int32).pin_memory() for _ in range(2)]
-            self._events = [torch.cuda.Event() for _ in range(2)]
-        slot = seq & 1
-        self.engine.reduce_apply_stop(buf, self.centroids, self.ccounts, threshold, self._tails[slot], seq)
+        self.engine.reduce_apply_stop(buf, self.centroids, self.ccounts, threshold, seq)
         if self.half:
             self.centroids.copy_(self.centroids.to(torch.float16).to(torch.float32))
-        self._events[slot].record(torch.cuda.current_stream(self.device))
-        return slot, seq
+        return seq
 
     def read_report(self, handle):
         """(global number of reassigned rows, stopped?) of the pass behind `handle`; waits for that pass only."""
-        slot, seq = handle
-        self._events[slot].synchronize()
-        t = self._tails[slot]
-        if int(t[5]) != seq:
-            raise RuntimeError("pass %d reported as %d" % (seq, int(t[5])))
-        return int(t[0]) & 0xFFFFFFFF, bool(int(t[4]))
+        counters, stopped = self.engine.stop_report(handle)
+        return counters[0], stopped
 
 
 def stop_threshold(tolerance, n_total):

@@ -111,14 +111,18 @@ class Engine:
         _lib.check(self.lib.kmamd_reduce_apply(self.h, self._p(buf), self._p(centroids), self._p(ccounts)),
                    "kmamd_reduce_apply")
 
-    def reduce_apply_stop(self, buf, centroids, ccounts, stop_threshold, host_tail=None, seq=0):
+    def reduce_apply_stop(self, buf, centroids, ccounts, stop_threshold, seq):
         """reduce_apply with the stop rule decided on the device (kmamd_reduce_apply_stop): nothing is
         modified and the engine's stop flag is raised when the reduced reassignment count is <=
-        stop_threshold.  host_tail: pinned int32 tensor of >= 6 words the kernel reports to."""
+        stop_threshold.  stop_report(seq) returns what the kernel reported."""
         _lib.check(self.lib.kmamd_reduce_apply_stop(self.h, self._p(buf), self._p(centroids), self._p(ccounts),
-                                                    float(stop_threshold),
-                                                    self._p(host_tail) if host_tail is not None else None, int(seq)),
-                   "kmamd_reduce_apply_stop")
+                                                    float(stop_threshold), int(seq)), "kmamd_reduce_apply_stop")
+
+    def stop_report(self, seq):
+        """(reduced counters [4], stopped?) of the reduce_apply_stop call numbered `seq`; waits for that call only."""
+        out = (ctypes.c_uint32 * 6)()
+        _lib.check(self.lib.kmamd_stop_report(self.h, int(seq), out), "kmamd_stop_report")
+        return list(out[:4]), bool(out[4])
 
     def stop_clear(self):
         _lib.check(self.lib.kmamd_stop_clear(self.h), "kmamd_stop_clear")
