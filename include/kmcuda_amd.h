@@ -112,6 +112,12 @@ int kmamd_reduce_apply(kmamd_engine *e, const double *buf, float *centroids, uin
 int kmamd_reduce_apply_stop(kmamd_engine *e, const double *buf, float *centroids, uint32_t *ccounts,
                             float stop_threshold, uint32_t seq);
 int kmamd_stop_report(kmamd_engine *e, uint32_t seq, uint32_t *host_out6);
+/* kmamd_reduce_apply_stop with the NEXT kmamd_lloyd_assign's centroid preparation fused into the same launch
+ * (L2 metric, two-stage filter with the row cache in its steady state; in any other state it IS
+ * kmamd_reduce_apply_stop).  Contract: the caller does not modify `centroids` between this call and that
+ * kmamd_lloyd_assign, which recognises the buffer by its address. */
+int kmamd_reduce_apply_prepare(kmamd_engine *e, const double *buf, float *centroids, uint32_t *ccounts,
+                               float stop_threshold, uint32_t seq);
 int kmamd_stop_clear(kmamd_engine *e);
 /* Test / A-B hook for the update's host logic: 0 default, 1 radix path always, 2 always read the
  * counts before choosing (the pre-round-2 behaviour), 3 bucket path always without reading (exercises

@@ -36,6 +36,7 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if (getenv("KMCUDA_AMD_DEBUG")) g_verbosity = atoi(getenv("KMCUDA_AMD_DEBUG"));
   if (const char *f = getenv("KMCUDA_AMD_FILTER")) filter_mode_ = strcmp(f, "f32") == 0 ? 1 : 0;
   if (const char *c = getenv("KMCUDA_AMD_ROW_CACHE")) row_cache_allowed_ = atoi(c) != 0;
+  if (const char *c = getenv("KMCUDA_AMD_SETTLE")) settle_ = atoi(c) != 0;
   if (const char *u = getenv("KMCUDA_AMD_UPDATE"))
     ms_.force = strcmp(u, "radix") == 0 ? 1 : (strcmp(u, "sync") == 0 ? 2 : (strcmp(u, "bucket") == 0 ? 3 : 0));
   if (D == 0 || K < 1 || K >= 0x7FFFFFFFu) return kInvalidArguments;  // K == 1: Yinyang group clustering with one group
@@ -155,6 +156,7 @@ void Engine::profile_reset() {
 
 int Engine::prepare_centroids(const float *centroids) {
   const uint32_t dp = DP_ ? DP_ : 8;
+  prepared_for_ = nullptr;
   // this preparation's statistics go to the other half; both halves are zeroed here, which also leaves
   // the half after this one zero (the invariant centroid_prep_frozen_kernel relies on)
   stats_ = stats_ == stats_base_ ? stats_base_ + 8 : stats_base_;
@@ -395,19 +397,23 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   // Steady state of the two-stage filter (mean frozen, cache valid): ONE preparation kernel in front of
   // stage 1; the reference's serial sum_squares chain and the transposed panel, which only the pair /
   // exact kernels read, are computed beside stage 1 on the side stream.
-  const bool steady = two_stage && mu_frozen_ && row_cache_on_ && row_cache_valid_ && N_ != 0;
+  const bool steady = steady_state(exact_only);
+  const bool prepared = steady && prepared_for_ == centroids;   // apply_prepare() has done this pass's preparation
+  prepared_for_ = nullptr;
   bool rows_on_side = false;
   if (steady) {
-    uint32_t *next = stats_;
-    stats_ = stats_ == stats_base_ ? stats_base_ + 8 : stats_base_;
     KMX_HIP(hipEventRecord(ev_fork_, stream_), kRuntimeError);   // the centroids are final here
     KMX_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0), kRuntimeError);
     KMX_HIP(launch_centroid_rows(metric_, centroids, K_, D_, Kt_, csqr_, ct_, side_stream_), kRuntimeError);
     KMX_HIP(hipEventRecord(ev_rows_, side_stream_), kRuntimeError);
     rows_on_side = true;
-    KMX_HIP(launch_centroid_prep_frozen(metric_, centroids, K_, D_, K_pad_, DP_, mu_, finite_, bias_, bias2_, cfil_,
-                                        panelhi_, stats_, next, counters_ + 1, counters_ + 3, counters_ + 4, stream_),
-            kRuntimeError);
+    if (!prepared) {
+      uint32_t *next = stats_;
+      stats_ = stats_ == stats_base_ ? stats_base_ + 8 : stats_base_;
+      KMX_HIP(launch_centroid_prep_frozen(metric_, centroids, K_, D_, K_pad_, DP_, mu_, finite_, bias_, bias2_, cfil_,
+                                          panelhi_, stats_, next, counters_ + 1, counters_ + 3, counters_ + 4, stream_),
+              kRuntimeError);
+    }
   } else {
     int rc = prepare_centroids(centroids);
     if (rc) return rc;
@@ -472,6 +478,13 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   }
   span_end();
   span_begin(1);
+  if (settle_ && lloyd_settle_supported(a, centroids)) {
+    // both lists in one launch (KMCUDA_AMD_SETTLE=0: the two older kernels below, the cross-check)
+    if (rows_on_side) KMX_HIP(hipStreamWaitEvent(stream_, ev_rows_, 0), kRuntimeError);   // csqr / ct
+    KMX_HIP(launch_lloyd_settle(metric_, a, centroids, stream_), kRuntimeError);
+    span_end();
+    return kSuccess;
+  }
   // the two refine kernels work on disjoint row lists and are latency bound (one 256-step exact
   // chain per contender): the full-scan kernel runs on a side stream beside the pair kernel
   KMX_HIP(hipEventRecord(ev_fork_, stream_), kRuntimeError);
@@ -504,24 +517,12 @@ int Engine::move_deltas(const float *samples, const uint32_t *prev, const uint32
 int Engine::apply_delta(const double *delta, const int32_t *dcount, const double *dcount_d, float *centroids,
                         uint32_t *ccounts, float stop_threshold, bool report, uint32_t seq) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  prepared_for_ = nullptr;   // whatever preparation there was belongs to the old centroids
   StopCtl ctl;
   if (stop_threshold >= 0.f || report) {
     if (!dcount_d) return kInvalidArguments;   // the stop rule reads the fused buffer's reduced counters
-    ctl.threshold = stop_threshold;
-    ctl.counters = counters_;
-    ctl.seq = seq;
-    if (report) {
-      if (!host_report_) {
-        KMX_HIP(hipHostMalloc(reinterpret_cast<void **>(&host_report_), 16 * sizeof(uint32_t), hipHostMallocCoherent),
-                kMemoryAllocationFailure);
-        memset(host_report_, 0xFF, 16 * sizeof(uint32_t));
-        void *dp = nullptr;
-        KMX_HIP(hipHostGetDevicePointer(&dp, host_report_, 0), kRuntimeError);
-        host_report_dev_ = static_cast<uint32_t *>(dp);
-        for (hipEvent_t &e : ev_report_) KMX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming), kRuntimeError);
-      }
-      ctl.host_tail = host_report_dev_ + 8 * (seq & 1u);
-    }
+    int rc = stop_ctl(stop_threshold, report, seq, &ctl);
+    if (rc) return rc;
   }
   span_begin(2);
   KMX_HIP(launch_apply_delta(metric_, delta, dcount, dcount_d, K_, D_, centroids, ccounts, ctl, stream_), kRuntimeError);
@@ -532,6 +533,25 @@ int Engine::apply_delta(const double *delta, const int32_t *dcount, const double
   return kSuccess;
 }
 
+int Engine::stop_ctl(float stop_threshold, bool report, uint32_t seq, StopCtl *ctl) {
+  ctl->threshold = stop_threshold;
+  ctl->counters = counters_;
+  ctl->seq = seq;
+  if (report) {
+    if (!host_report_) {
+      KMX_HIP(hipHostMalloc(reinterpret_cast<void **>(&host_report_), 16 * sizeof(uint32_t), hipHostMallocCoherent),
+              kMemoryAllocationFailure);
+      memset(host_report_, 0xFF, 16 * sizeof(uint32_t));
+      void *dp = nullptr;
+      KMX_HIP(hipHostGetDevicePointer(&dp, host_report_, 0), kRuntimeError);
+      host_report_dev_ = static_cast<uint32_t *>(dp);
+      for (hipEvent_t &e : ev_report_) KMX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming), kRuntimeError);
+    }
+    ctl->host_tail = host_report_dev_ + 8 * (seq & 1u);
+  }
+  return kSuccess;
+}
+
 int Engine::stop_report(uint32_t seq, uint32_t *host_out6) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   if (!host_report_) return kInvalidArguments;
@@ -539,6 +559,37 @@ int Engine::stop_report(uint32_t seq, uint32_t *host_out6) {
   const volatile uint32_t *t = host_report_ + 8 * (seq & 1u);
   for (int i = 0; i < 6; i++) host_out6[i] = t[i];
   return host_out6[5] == seq ? kSuccess : kRuntimeError;   // another call has reused the slot
+}
+
+// the steady state of the two-stage filter: mean frozen, row cache valid, panel buffers allocated
+bool Engine::steady_state(bool exact_only) const {
+  const bool two_stage = !exact_only && DP_ != 0 && filter_mode_ == 0 && lloyd_filter_f16_supported(D_, DP_) && !strict_h2_;
+  return two_stage && mu_frozen_ && row_cache_on_ && row_cache_valid_ && N_ != 0 && panelhi_ != nullptr;
+}
+
+// apply_delta + the NEXT lloyd_assign's preparation in one launch (L2, steady state; anything else: apply_delta).
+// The caller promises not to touch `centroids` before that lloyd_assign (which recognises the buffer by address).
+int Engine::apply_prepare(const double *delta, const double *dcount_d, float *centroids, uint32_t *ccounts,
+                          float stop_threshold, bool report, uint32_t seq) {
+  if (!(metric_ == 0 && steady_state(false) && dcount_d)) {
+    prepared_for_ = nullptr;
+    return apply_delta(delta, nullptr, dcount_d, centroids, ccounts, stop_threshold, report, seq);
+  }
+  KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  StopCtl ctl;
+  int rc = stop_ctl(stop_threshold, report, seq, &ctl);
+  if (rc) return rc;
+  uint32_t *next = stats_;
+  stats_ = stats_ == stats_base_ ? stats_base_ + 8 : stats_base_;
+  span_begin(2);
+  KMX_HIP(launch_apply_prep_frozen(delta, dcount_d, centroids, ccounts, ctl, K_, D_, K_pad_, DP_, mu_, finite_, bias_,
+                                   bias2_, cfil_, panelhi_, stats_, next, counters_ + 1, counters_ + 3, counters_ + 4,
+                                   stream_),
+          kRuntimeError);
+  span_end();
+  if (report) KMX_HIP(hipEventRecord(ev_report_[seq & 1u], stream_), kRuntimeError);
+  prepared_for_ = centroids;
+  return kSuccess;
 }
 
 int Engine::stop_clear() {
@@ -663,6 +714,10 @@ int kmamd_reduce_apply_stop(kmamd_engine *e, const double *buf, float *centroids
                             float stop_threshold, uint32_t seq) {
   return e->e.apply_delta(buf, nullptr, buf + (size_t)e->e.K_ * e->e.D_, centroids, ccounts, stop_threshold, true, seq);
 }
+int kmamd_reduce_apply_prepare(kmamd_engine *e, const double *buf, float *centroids, uint32_t *ccounts,
+                               float stop_threshold, uint32_t seq) {
+  return e->e.apply_prepare(buf, buf + (size_t)e->e.K_ * e->e.D_, centroids, ccounts, stop_threshold, true, seq);
+}
 int kmamd_stop_report(kmamd_engine *e, uint32_t seq, uint32_t *host_out6) { return e->e.stop_report(seq, host_out6); }
 int kmamd_stop_clear(kmamd_engine *e) { return e->e.stop_clear(); }
 int kmamd_set_update_mode(kmamd_engine *e, int mode) {
@@ -673,16 +728,19 @@ int kmamd_set_update_mode(kmamd_engine *e, int mode) {
 int kmamd_set_filter(kmamd_engine *e, int mode) {
   if (mode < 0 || mode > 1) return kmx::kInvalidArguments;
   e->e.filter_mode_ = mode;
+  e->e.prepared_for_ = nullptr;
   return kmx::kSuccess;
 }
 int kmamd_set_half_rows(kmamd_engine *e, const void *rows16) {
   e->e.half_rows_ = rows16;
+  e->e.prepared_for_ = nullptr;
   e->e.row_cache_valid_ = false;  // a cache built from other rows is stale
   return kmx::kSuccess;
 }
 int kmamd_set_row_cache(kmamd_engine *e, int on) {
   e->e.row_cache_on_ = on != 0 && e->e.row_cache_allowed_;
   e->e.row_cache_valid_ = false;  // (re)built by the next kmamd_lloyd_assign
+  e->e.prepared_for_ = nullptr;
   if (!e->e.row_cache_on_) e->e.mu_frozen_ = false;
   return kmx::kSuccess;
 }

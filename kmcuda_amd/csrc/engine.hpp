@@ -48,6 +48,13 @@ class Engine {
   // stopped, [5] seq)
   int apply_delta(const double *delta, const int32_t *dcount, const double *dcount_d, float *centroids,
                   uint32_t *ccounts, float stop_threshold = -1.f, bool report = false, uint32_t seq = 0);
+  // the same update with the NEXT lloyd_assign's preparation fused behind it (L2 metric in the two-stage filter's
+  // steady state; otherwise plain apply_delta): the caller must leave `centroids` alone until that call
+  int apply_prepare(const double *delta, const double *dcount_d, float *centroids, uint32_t *ccounts,
+                    float stop_threshold = -1.f, bool report = false, uint32_t seq = 0);
+  bool steady_state(bool exact_only) const;
+  int stop_ctl(float stop_threshold, bool report, uint32_t seq, StopCtl *ctl);
+  const float *prepared_for_ = nullptr;   // the centroid buffer apply_prepare() has prepared the next pass for
   int stop_clear();   // lowers the device-side stop flag (start of a run)
   // the outcome of the apply_delta(..., report = true, seq) call: waits for THAT call only (an event behind it on
   // stream_), then [0..3] the reduced counters, [4] stopped, [5] seq
@@ -99,6 +106,7 @@ class Engine {
   // 0: two-stage f16 matrix-core filter (hi.hi, then the contenders in fp32; default),
   // 1: f32 matrix-core filter (KMCUDA_AMD_FILTER=f32; cross-check)
   int filter_mode_ = 0;
+  bool settle_ = true;   // KMCUDA_AMD_SETTLE=0: lloyd_pair + lloyd_exact instead of the one-launch lloyd_settle
   // row cache of the coarse filter stage (lloyd_f16.hip: row_cache_kernel); set_row_cache()
   bool row_cache_allowed_ = true;   // KMCUDA_AMD_ROW_CACHE=0 vetoes it
   bool row_cache_on_ = false, row_cache_valid_ = false, mu_frozen_ = false;

@@ -47,6 +47,10 @@ hipError_t launch_lloyd_filter(const LloydArgs &a, hipStream_t st);
 hipError_t launch_lloyd_pair(int metric, const LloydArgs &a, const float *centroids, uint32_t grid, hipStream_t st);
 hipError_t launch_lloyd_exact(int metric, const LloydArgs &a, const uint32_t *rows, const uint32_t *nrows,
                               uint32_t grid, hipStream_t st);
+// the pair rows and the full-scan rows of a pass in ONE launch, operands staged through LDS / prefetched three
+// groups deep (lloyd.hip: lloyd_settle_kernel); supported: D % 4 == 0 and 16-byte aligned rows
+bool lloyd_settle_supported(const LloydArgs &a, const float *centroids);
+hipError_t launch_lloyd_settle(int metric, const LloydArgs &a, const float *centroids, hipStream_t st);
 
 // lloyd_f16.hip -- the two-stage filter on the f16 matrix cores (centred operands), for fp32
 // rows and for the fp16x2 path's half rows; decisions identical in kind, refine kernels shared
@@ -62,6 +66,13 @@ hipError_t launch_centroid_prep_frozen(int metric, const float *centroids, uint3
                                        uint32_t DP, const float *mu, uint32_t *finite, float *bias, float *bias2,
                                        float *cfil, void *panelhi, uint32_t *stats, uint32_t *stats_next,
                                        uint32_t *zero_a, uint32_t *zero_b, uint32_t *zero_c, hipStream_t st);
+// L2 metric: the centroid update of launch_apply_delta (same formula, same StopCtl) fused in front of that
+// preparation -- one launch between the all-reduce and stage 1
+hipError_t launch_apply_prep_frozen(const double *delta, const double *dcount_d, float *centroids, uint32_t *ccounts,
+                                    const StopCtl &stop, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP,
+                                    const float *mu, uint32_t *finite, float *bias, float *bias2, float *cfil,
+                                    void *panelhi, uint32_t *stats, uint32_t *stats_next, uint32_t *zero_a,
+                                    uint32_t *zero_b, uint32_t *zero_c, hipStream_t st);
 // the reference's exact sum_squares (csqr) + the transposed panel (ct) alone: what the pair / exact kernels read
 hipError_t launch_centroid_rows(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t Kt, float *csqr,
                                 float *ct, hipStream_t st);

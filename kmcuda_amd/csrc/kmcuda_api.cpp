@@ -806,8 +806,14 @@ class Job {
     const uint32_t kd = K * D;
     for (size_t i = 0; i < shards.size(); i++) {
       auto &s = shards[i];
-      RETERR(s->eng->apply_delta(s->reduce, nullptr, s->reduce + kd, s->centroids, s->ccounts, stop_threshold,
-                                 report && i == 0, seq));
+      // (the next pass's centroid preparation rides in the same launch where it can: Engine::apply_prepare;
+      // fp16x2 rounds the centroids to halves first, so there it cannot)
+      if (fp16)
+        RETERR(s->eng->apply_delta(s->reduce, nullptr, s->reduce + kd, s->centroids, s->ccounts, stop_threshold,
+                                   report && i == 0, seq));
+      else
+        RETERR(s->eng->apply_prepare(s->reduce, s->reduce + kd, s->centroids, s->ccounts, stop_threshold,
+                                     report && i == 0, seq));
     }
     return quantize_centroids();
   }

@@ -605,6 +605,228 @@ __global__ __launch_bounds__(256) void lloyd_exact_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// 4. lloyd_settle: everything the filter could not decide, in ONE launch.  Blocks [0, kSettlePairBlocks) take the
+// two-contender rows, the other blocks the rows that need the full exact scan.  Both are latency problems -- one
+// serial D-step chain per contender whatever the row count -- and both used to pay a round trip to L2 / HBM per 8
+// features (32 of them at D = 256: ~45 us for any list length, with two launches and a fork / join of streams):
+//   pairs   a wave takes 32 rows at a time, ONE chain per lane (lane l: the lower-index contender of row l,
+//           lane l + 32: the other).  The 32 sample rows and the 64 centroid rows come in through LDS in chunks
+//           of 64 features -- 16 lanes fetch a row's 256 bytes, coalesced; the next chunk's loads fly during the
+//           chain; rows are stored 68 floats apart (conflict-free 16-byte reads by 16 consecutive rows).
+//   scans   one block of 4 waves per row as lloyd_exact_kernel, with three 8-feature groups of the transposed
+//           panel in flight instead of one.
+// The arithmetic and the tie rules are lloyd_pair_kernel's / lloyd_exact_kernel's (the reference's).  Needs
+// D % 4 == 0 and 16-byte aligned rows (else the host launches the two old kernels).
+// ---------------------------------------------------------------------------------------
+constexpr int kSettleFC = 64;                  // features per staged chunk
+constexpr int kSettleLD = kSettleFC + 4;       // LDS row stride in floats
+constexpr int kSettleRows = 96;                // per wave: 32 sample rows + 64 centroid rows
+constexpr uint32_t kSettlePairBlocks = 256, kSettleScanBlocks = 256;
+constexpr size_t kSettleLds = (size_t)4 * (kSettleRows * kSettleLD + kSettleRows) * sizeof(float);
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void lloyd_settle_kernel(
+    const float *__restrict__ samples, uint32_t N, uint32_t D, const float *__restrict__ centroids,
+    const float *__restrict__ ct, const float *__restrict__ csqr, uint32_t K, uint32_t Kt,
+    const uint32_t *__restrict__ pairs, const uint32_t *__restrict__ npairs, const uint32_t *__restrict__ flagged,
+    const uint32_t *__restrict__ nflagged, uint32_t *__restrict__ assignments,
+    uint32_t *__restrict__ assignments_prev, uint32_t *__restrict__ counters) {
+  extern __shared__ __attribute__((aligned(16))) float settle_lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (blockIdx.x < kSettlePairBlocks) {
+    // ---------------- pairs ----------------
+    const uint32_t total = *npairs;
+    float *tile = settle_lds + (size_t)wave * (kSettleRows * kSettleLD + kSettleRows);
+    uint32_t *rowid = reinterpret_cast<uint32_t *>(tile + kSettleRows * kSettleLD);
+    const uint32_t nch = (D + kSettleFC - 1) / kSettleFC;
+    // (every wave of the block makes the same number of trips: the barriers below are block barriers)
+    for (uint32_t base0 = blockIdx.x * 128u; base0 < total; base0 += kSettlePairBlocks * 128u) {
+      const uint32_t p = base0 + wave * 32u + (lane & 31);
+      const bool live = p < total;
+      uint32_t s = 0, lo = 0, hi = 0;
+      if (live) {
+        s = pairs[3 * (size_t)p];
+        const uint32_t ia = pairs[3 * (size_t)p + 1], ib = pairs[3 * (size_t)p + 2];
+        lo = ia < ib ? ia : ib;
+        hi = ia < ib ? ib : ia;
+      }
+      const uint32_t mine = lane < 32 ? lo : hi;
+      __syncthreads();   // the previous trip's tile and row table are no longer read
+      if (lane < 32) rowid[lane] = s;
+      rowid[32 + lane] = mine;
+      __syncthreads();
+      float4 stage[kSettleRows / 4];
+      auto fetch = [&](uint32_t ch) {
+#pragma unroll
+        for (int it = 0; it < kSettleRows / 4; it++) {
+          const uint32_t r = it * 4 + (lane >> 4), f = ch * kSettleFC + (lane & 15) * 4;
+          const float *src = (r < 32 ? samples : centroids) + (size_t)rowid[r] * D + f;
+          stage[it] = f < D ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      };
+      float acc = 0.f, corr = 0.f;
+      fetch(0);
+      for (uint32_t ch = 0; ch < nch; ch++) {
+        __syncthreads();   // the previous chunk has been consumed
+#pragma unroll
+        for (int it = 0; it < kSettleRows / 4; it++) {
+          const uint32_t r = it * 4 + (lane >> 4);
+          *reinterpret_cast<float4 *>(&tile[r * kSettleLD + (lane & 15) * 4]) = stage[it];
+        }
+        __syncthreads();
+        if (ch + 1 < nch) fetch(ch + 1);
+        const uint32_t fmax = D - ch * kSettleFC < (uint32_t)kSettleFC ? D - ch * kSettleFC : (uint32_t)kSettleFC;   // multiple of 4
+        const float *xr = tile + (lane & 31) * kSettleLD, *cr = tile + (32 + lane) * kSettleLD;
+        for (uint32_t c4 = 0; c4 * 4 < fmax; c4++) {
+          const float4 xv = *reinterpret_cast<const float4 *>(xr + c4 * 4);
+          const float4 cv = *reinterpret_cast<const float4 *>(cr + c4 * 4);
+          kahan_fold(fma_rd(xv.x, cv.x, corr), acc, corr);
+          kahan_fold(fma_rd(xv.y, cv.y, corr), acc, corr);
+          kahan_fold(fma_rd(xv.z, cv.z, corr), acc, corr);
+          kahan_fold(fma_rd(xv.w, cv.w, corr), acc, corr);
+        }
+      }
+      const float dist = lloyd_distance<METRIC>(csqr[mine], acc);
+      const float db = __shfl(dist, (lane & 31) + 32);
+      bool changed = false;
+      if (live && lane < 32) {
+        // ascending scan, strict '<', starting from FLT_MAX
+        float min_dist = 3.402823466e+38f;
+        uint32_t nearest = 0xFFFFFFFFu;
+        if (dist < min_dist) { min_dist = dist; nearest = lo; }
+        if (db < min_dist) { min_dist = db; nearest = hi; }
+        if (nearest != 0xFFFFFFFFu) changed = commit_row(s, nearest, assignments, assignments_prev);
+      }
+      const unsigned long long cm = __ballot(changed);
+      if (lane == 0 && cm) atomicAdd(&counters[0], (uint32_t)__popcll(cm));
+    }
+    return;
+  }
+  // ---------------- full scans: one block per row ----------------
+  constexpr int CH = 4, GF = 8, NB = 4;
+  float *sh_dist = settle_lds;
+  uint32_t *sh_idx = reinterpret_cast<uint32_t *>(settle_lds + 4);
+  const uint32_t total = *nflagged;
+  for (uint32_t ri = blockIdx.x - kSettlePairBlocks; ri < total; ri += gridDim.x - kSettlePairBlocks) {
+    const uint32_t s = flagged[ri];
+    const float *x = samples + (size_t)s * D;  // block-uniform address: scalar loads
+    const bool insane = (x[0] != x[0]);
+    float min_dist = 3.402823466e+38f;
+    uint32_t nearest = 0xFFFFFFFFu;
+    if (!insane) {
+      for (uint32_t cbase = wave * 64 * CH; cbase < K; cbase += 4 * 64 * CH) {
+        float acc[CH], corr[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) { acc[j] = 0.f; corr[j] = 0.f; }
+        const float *cp[CH];   // a column beyond the panel reads column `lane`; its result is dropped below
+#pragma unroll
+        for (int j = 0; j < CH; j++) cp[j] = ct + ((cbase + 64 * j + lane < Kt) ? cbase + 64 * j + lane : (uint32_t)lane);
+        float xg[NB][GF], cg[NB][GF][CH];
+        const uint32_t ngroups = D / GF;   // D % 4 == 0: a 4-feature tail is handled below
+        auto load_group = [&](uint32_t g, float (&xf)[GF], float (&cv)[GF][CH]) {
+#pragma unroll
+          for (int q = 0; q < GF; q++) {
+            xf[q] = x[g * GF + q];
+#pragma unroll
+            for (int j = 0; j < CH; j++) cv[q][j] = cp[j][(size_t)(g * GF + q) * Kt];
+          }
+        };
+        auto fold_group = [&](const float (&xf)[GF], float (&cv)[GF][CH]) {
+#pragma unroll
+          for (int q = 0; q < GF; q++) {
+            float y[CH];
+            fma_rd4(xf[q], cv[q], corr, y);
+#pragma unroll
+            for (int j = 0; j < CH; j++) kahan_fold(y[j], acc[j], corr[j]);
+          }
+        };
+#pragma unroll
+        for (int b = 0; b < NB - 1; b++)
+          if ((uint32_t)b < ngroups) load_group(b, xg[b], cg[b]);
+        for (uint32_t g0 = 0; g0 < ngroups; g0 += NB) {
+#pragma unroll
+          for (int b = 0; b < NB; b++) {
+            const uint32_t g = g0 + b;
+            if (g < ngroups) {
+              if (g + NB - 1 < ngroups) load_group(g + NB - 1, xg[(b + NB - 1) % NB], cg[(b + NB - 1) % NB]);
+              fold_group(xg[b], cg[b]);
+            }
+          }
+        }
+        for (uint32_t f = ngroups * GF; f < D; f++) {
+          const float xf = x[f];
+          float cv[CH], y[CH];
+#pragma unroll
+          for (int j = 0; j < CH; j++) cv[j] = cp[j][(size_t)f * Kt];
+          fma_rd4(xf, cv, corr, y);
+#pragma unroll
+          for (int j = 0; j < CH; j++) kahan_fold(y[j], acc[j], corr[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+          const uint32_t c = cbase + 64 * j + lane;
+          if (c < K) {
+            const float dist = lloyd_distance<METRIC>(csqr[c], acc[j]);
+            if (dist < min_dist) { min_dist = dist; nearest = c; }
+          }
+        }
+      }
+      // wave argmin, lowest index among equal minima; lanes without a candidate never win
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float od = __shfl_xor(min_dist, off);
+        const uint32_t oi = __shfl_xor(nearest, off);
+        const bool take = (oi != 0xFFFFFFFFu) &&
+                          (nearest == 0xFFFFFFFFu || od < min_dist || (od == min_dist && oi < nearest));
+        if (take) { min_dist = od; nearest = oi; }
+      }
+    }
+    if (lane == 0) {
+      sh_dist[wave] = min_dist;
+      sh_idx[wave] = nearest;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; w++) {
+        const float od = sh_dist[w];
+        const uint32_t oi = sh_idx[w];
+        const bool take = (oi != 0xFFFFFFFFu) &&
+                          (nearest == 0xFFFFFFFFu || od < min_dist || (od == min_dist && oi < nearest));
+        if (take) { min_dist = od; nearest = oi; }
+      }
+      if (nearest == 0xFFFFFFFFu && insane) nearest = K;  // kmeans.cu:349-356
+      if (nearest != 0xFFFFFFFFu) {                       // else: "search failed", row left untouched
+        if (commit_row(s, nearest, assignments, assignments_prev)) atomicAdd(&counters[0], 1u);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+bool lloyd_settle_supported(const LloydArgs &a, const float *centroids) {
+  return (a.D & 3u) == 0 && (((uintptr_t)a.samples | (uintptr_t)centroids) & 15u) == 0;
+}
+
+hipError_t launch_lloyd_settle(int metric, const LloydArgs &a, const float *centroids, hipStream_t st) {
+  static bool attr_set[2] = {false, false};
+  const void *fn = metric == 0 ? (const void *)lloyd_settle_kernel<0> : (const void *)lloyd_settle_kernel<1>;
+  // (per device: the attribute belongs to the current device's copy of the kernel; setting it again is cheap)
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSettleLds);
+  if (e != hipSuccess) return e;
+  (void)attr_set;
+  const dim3 grid(kSettlePairBlocks + kSettleScanBlocks);
+  if (metric == 0)
+    hipLaunchKernelGGL((lloyd_settle_kernel<0>), grid, dim3(256), kSettleLds, st, a.samples, a.N, a.D, centroids, a.ct,
+                       a.csqr, a.K, a.Kt, a.pairs, a.counters + 3, a.flagged, a.counters + 1, a.assignments,
+                       a.assignments_prev, a.counters);
+  else
+    hipLaunchKernelGGL((lloyd_settle_kernel<1>), grid, dim3(256), kSettleLds, st, a.samples, a.N, a.D, centroids, a.ct,
+                       a.csqr, a.K, a.Kt, a.pairs, a.counters + 3, a.flagged, a.counters + 1, a.assignments,
+                       a.assignments_prev, a.counters);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------
 // the Lloyd two-stage f16 filter also has a 512-wide instantiation (one operand set per wave)

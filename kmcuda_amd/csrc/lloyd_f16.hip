@@ -67,17 +67,38 @@ __global__ __launch_bounds__(256) void centroid_panelhi_kernel(
 // (serial, 256 steps) and the transposed panel are only read by the pair / exact kernels: they run
 // beside stage 1 on the side stream.  One wave per padded row.  Also zeroes the per-pass list counters
 // and the OTHER half of the double-buffered stats (the next pass's), saving the memset launches.
-template <int METRIC>
+// APPLY (L2 only): the centroid update of update.hip's apply_delta_kernel -- the same fp64 formula element by
+// element, the same device-side stop rule (StopCtl) -- runs first, on the row the wave is about to prepare: the
+// update and the next pass's preparation are ONE launch (Engine::apply_prepare).
+template <int METRIC, bool APPLY>
 __global__ __launch_bounds__(256) void centroid_prep_frozen_kernel(
-    const float *__restrict__ centroids, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP, uint32_t K_pad64,
+    float *__restrict__ centroids, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP, uint32_t K_pad64,
     const float *__restrict__ mu, uint32_t *__restrict__ finite, float *__restrict__ bias, float *__restrict__ bias2,
     float *__restrict__ cfil, _Float16 *__restrict__ panelhi, uint32_t *__restrict__ stats,
     uint32_t *__restrict__ stats_next, uint32_t *__restrict__ zero_a, uint32_t *__restrict__ zero_b,
-    uint32_t *__restrict__ zero_c) {
+    uint32_t *__restrict__ zero_c, const double *__restrict__ delta, const double *__restrict__ dcount_d,
+    uint32_t *__restrict__ ccounts, StopCtl ctl) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (blockIdx.x == 0 && threadIdx.x < 8) {
     stats_next[threadIdx.x] = 0u;
     if (threadIdx.x == 0) { *zero_a = 0u; *zero_b = 0u; *zero_c = 0u; }
+  }
+  bool update = APPLY;
+  if (APPLY && ctl.counters) {   // as apply_delta_kernel
+    bool stop = ctl.counters[kStopFlag] != 0u;
+    if (ctl.threshold >= 0.f) stop = stop || (float)(uint32_t)dcount_d[K] <= ctl.threshold;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (stop) ctl.counters[kStopFlag] = 1u;
+      else if (ctl.threshold >= 0.f) ctl.counters[0] = 0u;
+      if (ctl.host_tail) {
+        volatile uint32_t *ht = ctl.host_tail;
+        for (uint32_t i = 0; i < 4; i++) ht[i] = (uint32_t)dcount_d[K + i];
+        ht[4] = stop ? 1u : 0u;
+        __threadfence_system();
+        ht[5] = ctl.seq;
+      }
+    }
+    update = !stop;
   }
   uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
   for (uint32_t i = 0; i < 4; i++) {
@@ -85,7 +106,20 @@ __global__ __launch_bounds__(256) void centroid_prep_frozen_kernel(
     if (c >= K_pad64) break;
     const bool real = c < K_pad;
     float plain = 0.f;
-    if (c < K)
+    if (APPLY && update && c < K) {
+      // c = (c * count + delta) / new count in fp64, rounded once (apply_delta_kernel<0>); the row is read back
+      // below by the lanes that wrote it
+      const uint32_t cnt_old = ccounts[c];
+      const uint32_t cnt_new = cnt_old + (uint32_t)(int32_t)dcount_d[c];
+      const double w = (double)cnt_old, cn = (double)cnt_new;
+      for (uint32_t f = lane; f < D; f += 64) {
+        const float v = cnt_new == 0 ? __builtin_nanf("")
+                                     : (float)(((double)centroids[(size_t)c * D + f] * w + delta[(size_t)c * D + f]) / cn);
+        centroids[(size_t)c * D + f] = v;
+        plain = fmaf(v, v, plain);
+      }
+      if (lane == 0) ccounts[c] = cnt_new;
+    } else if (c < K)
       for (uint32_t f = lane; f < D; f += 64) {
         const float v = centroids[(size_t)c * D + f];
         plain = fmaf(v, v, plain);
@@ -155,14 +189,31 @@ hipError_t launch_centroid_prep_frozen(int metric, const float *centroids, uint3
                                        float *cfil, void *panelhi, uint32_t *stats, uint32_t *stats_next,
                                        uint32_t *zero_a, uint32_t *zero_b, uint32_t *zero_c, hipStream_t st) {
   const uint32_t K_pad64 = (K_pad + 63u) / 64u * 64u;
+  float *cen = const_cast<float *>(centroids);   // (only the APPLY instantiation writes)
   if (metric == 0)
-    hipLaunchKernelGGL((centroid_prep_frozen_kernel<0>), dim3(K_pad64 / 16), dim3(256), 0, st, centroids, K, D, K_pad,
+    hipLaunchKernelGGL((centroid_prep_frozen_kernel<0, false>), dim3(K_pad64 / 16), dim3(256), 0, st, cen, K, D, K_pad,
                        DP, K_pad64, mu, finite, bias, bias2, cfil, reinterpret_cast<_Float16 *>(panelhi), stats,
-                       stats_next, zero_a, zero_b, zero_c);
+                       stats_next, zero_a, zero_b, zero_c, (const double *)nullptr, (const double *)nullptr,
+                       (uint32_t *)nullptr, StopCtl());
   else
-    hipLaunchKernelGGL((centroid_prep_frozen_kernel<1>), dim3(K_pad64 / 16), dim3(256), 0, st, centroids, K, D, K_pad,
+    hipLaunchKernelGGL((centroid_prep_frozen_kernel<1, false>), dim3(K_pad64 / 16), dim3(256), 0, st, cen, K, D, K_pad,
                        DP, K_pad64, mu, finite, bias, bias2, cfil, reinterpret_cast<_Float16 *>(panelhi), stats,
-                       stats_next, zero_a, zero_b, zero_c);
+                       stats_next, zero_a, zero_b, zero_c, (const double *)nullptr, (const double *)nullptr,
+                       (uint32_t *)nullptr, StopCtl());
+  return hipGetLastError();
+}
+
+// L2: the centroid update (delta / dcount_d: the fused reduce buffer, StopCtl as launch_apply_delta) and the next
+// pass's preparation in one launch
+hipError_t launch_apply_prep_frozen(const double *delta, const double *dcount_d, float *centroids, uint32_t *ccounts,
+                                    const StopCtl &stop, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP,
+                                    const float *mu, uint32_t *finite, float *bias, float *bias2, float *cfil,
+                                    void *panelhi, uint32_t *stats, uint32_t *stats_next, uint32_t *zero_a,
+                                    uint32_t *zero_b, uint32_t *zero_c, hipStream_t st) {
+  const uint32_t K_pad64 = (K_pad + 63u) / 64u * 64u;
+  hipLaunchKernelGGL((centroid_prep_frozen_kernel<0, true>), dim3(K_pad64 / 16), dim3(256), 0, st, centroids, K, D, K_pad,
+                     DP, K_pad64, mu, finite, bias, bias2, cfil, reinterpret_cast<_Float16 *>(panelhi), stats, stats_next,
+                     zero_a, zero_b, zero_c, delta, dcount_d, ccounts, stop);
   return hipGetLastError();
 }
 

@@ -274,6 +274,7 @@ template <bool DIRECT>
 __global__ __launch_bounds__(kSumThreads) void cluster_sums_kernel(SumArgs a) {
   __shared__ uint32_t srt[2][kBucketCapMax];
   __shared__ double part[kSumThreads];
+  uint32_t *part_u = reinterpret_cast<uint32_t *>(part);   // scratch of the rank sort (before the sums use `part`)
   __shared__ uint32_t wcnt[16];
   __shared__ uint32_t sh_base;
   const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -288,7 +289,21 @@ __global__ __launch_bounds__(kSumThreads) void cluster_sums_kernel(SumArgs a) {
 #pragma unroll
     for (int sg = 0; sg < 2; sg++) {
       const uint32_t cnt = n[sg], key = 2 * c + sg;
-      if (cnt <= a.cap) {
+      if (cnt <= kSumThreads && cnt <= a.cap) {
+        // the usual case, a short list: every thread ranks its own row (rows are distinct) -- two barriers
+        // instead of the bitonic network's log^2
+        uint32_t *v = srt[sg];
+        const uint32_t mine = tid < cnt ? a.bucket_rows[(size_t)key * a.cap + tid] : 0xFFFFFFFFu;
+        if (tid < cnt) part_u[tid] = mine;
+        __syncthreads();
+        if (tid < cnt) {
+          uint32_t rank = 0;
+          for (uint32_t j = 0; j < cnt; j++) rank += part_u[j] < mine ? 1u : 0u;
+          v[rank] = mine;
+        }
+        __syncthreads();
+        rows[sg] = v;
+      } else if (cnt <= a.cap) {
         // bitonic sort of the bucket, padded to a power of two with 0xFFFFFFFF
         uint32_t m = 2;
         while (m < cnt) m <<= 1;

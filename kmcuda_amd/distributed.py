@@ -77,9 +77,11 @@ class HipBackend:
     def apply_stop(self, buf, threshold, seq):
         """The update, unless the reduced reassignment count is <= threshold (then nothing is touched and
         later assign() calls are no-ops).  Returns a handle for read_report()."""
-        self.engine.reduce_apply_stop(buf, self.centroids, self.ccounts, threshold, seq)
-        if self.half:
+        if self.half:   # the centroids are rounded to halves after the update: no fused preparation
+            self.engine.reduce_apply_stop(buf, self.centroids, self.ccounts, threshold, seq)
             self.centroids.copy_(self.centroids.to(torch.float16).to(torch.float32))
+        else:           # + the next pass's centroid preparation in the same launch (nobody touches them in between)
+            self.engine.reduce_apply_prepare(buf, self.centroids, self.ccounts, threshold, seq)
         return seq
 
     def read_report(self, handle):

@@ -118,6 +118,12 @@ class Engine:
         _lib.check(self.lib.kmamd_reduce_apply_stop(self.h, self._p(buf), self._p(centroids), self._p(ccounts),
                                                     float(stop_threshold), int(seq)), "kmamd_reduce_apply_stop")
 
+    def reduce_apply_prepare(self, buf, centroids, ccounts, stop_threshold, seq):
+        """reduce_apply_stop + the next lloyd_assign's centroid preparation in one launch where the engine can
+        (kmamd_reduce_apply_prepare); the caller must leave `centroids` alone until that lloyd_assign."""
+        _lib.check(self.lib.kmamd_reduce_apply_prepare(self.h, self._p(buf), self._p(centroids), self._p(ccounts),
+                                                       float(stop_threshold), int(seq)), "kmamd_reduce_apply_prepare")
+
     def stop_report(self, seq):
         """(reduced counters [4], stopped?) of the reduce_apply_stop call numbered `seq`; waits for that call only."""
         out = (ctypes.c_uint32 * 6)()

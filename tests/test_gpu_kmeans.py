@@ -392,6 +392,80 @@ def test_fused_reduce_buffer():
     assert out[0][3] == out[1][3]
 
 
+@pytest.mark.parametrize("d,k", [(256, 300), (64, 40), (24, 16)])
+def test_device_stop_rule_and_fused_preparation(d, k):
+    """The step API's three ways through an iteration agree bit for bit: reduce_apply after a host-side test,
+    reduce_apply_stop (the rule decided on the device, reported through pinned words) and reduce_apply_prepare
+    (+ the next pass's centroid preparation in the same launch, steady state of the row-cached filter).  A
+    threshold the count never reaches: same centroids / counts / assignments every iteration; then a threshold
+    that fires: nothing is touched any more, the flag turns later passes into no-ops, stop_clear revives them."""
+    from kmcuda_amd.engine import Engine
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    n = 20000
+    rs = numpy.random.RandomState(d)
+    x = rs.rand(n, d).astype(numpy.float32)
+    xs = torch.from_numpy(x).to(dev)
+    c0 = x[rs.choice(n, k, replace=False)].copy()
+    runs = {}
+    for how in ("host", "stop", "prepare"):
+        eng = Engine(n, d, k, "L2", device=0)
+        eng.set_row_cache(True)
+        cen = torch.from_numpy(c0.copy()).to(dev)
+        asg = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        prev = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        ccounts = torch.zeros(k, dtype=torch.int32, device=dev)
+        buf = torch.zeros(eng.reduce_len(), dtype=torch.float64, device=dev)
+        eng.stop_clear()
+        eng.reset_counters(0)
+        log = []
+        for it in range(1, 7):
+            eng.lloyd_assign(xs, cen, asg, prev)
+            eng.reduce_fill(xs, prev, asg, buf)
+            if how == "host":
+                log.append(int(buf[k * d + k].item()))
+                eng.reset_counters(0)
+                eng.reduce_apply(buf, cen, ccounts)
+            else:
+                (eng.reduce_apply_stop if how == "stop" else eng.reduce_apply_prepare)(buf, cen, ccounts, 0.0, it)
+                counters, stopped = eng.stop_report(it)
+                assert not stopped
+                log.append(counters[0])
+        eng.sync()
+        state = (cen.cpu().numpy().copy(), ccounts.cpu().numpy().copy(), asg.cpu().numpy().copy(), log)
+        if how != "host":
+            # a threshold above the count: the rule fires, nothing moves, later passes are no-ops
+            eng.lloyd_assign(xs, cen, asg, prev)
+            eng.reduce_fill(xs, prev, asg, buf)
+            asg7 = asg.cpu().numpy().copy()
+            (eng.reduce_apply_stop if how == "stop" else eng.reduce_apply_prepare)(buf, cen, ccounts, float(n), 7)
+            counters, stopped = eng.stop_report(7)
+            assert stopped
+            cen7 = cen.cpu().numpy().copy()
+            eng.lloyd_assign(xs, cen, asg, prev)          # no-op: flag raised
+            eng.reduce_fill(xs, prev, asg, buf)
+            (eng.reduce_apply_stop if how == "stop" else eng.reduce_apply_prepare)(buf, cen, ccounts, 0.0, 8)
+            c8, stopped8 = eng.stop_report(8)
+            eng.sync()
+            assert stopped8 and c8[0] == counters[0]
+            assert numpy.array_equal(cen.cpu().numpy(), cen7, equal_nan=True)
+            assert (asg.cpu().numpy() == asg7).all()
+            assert eng.counters()[0] == counters[0]       # not zeroed on stop (kmeans.cu:707-709)
+            eng.stop_clear()
+            eng.reset_counters(0)
+            eng.reduce_apply(buf, cen, ccounts)           # the pending update, then a live pass again
+            eng.lloyd_assign(xs, cen, asg, prev)
+            eng.sync()
+            ref, _, _ = oracle.lloyd_assign(x, cen.cpu().numpy())
+            assert (asg.cpu().numpy().view(numpy.uint32) == ref).all()
+        runs[how] = state
+        eng.close()
+    for how in ("stop", "prepare"):
+        assert numpy.array_equal(runs["host"][0], runs[how][0], equal_nan=True), how
+        assert (runs["host"][1] == runs[how][1]).all() and (runs["host"][2] == runs[how][2]).all(), how
+        assert runs["host"][3] == runs[how][3], how
+
+
 @pytest.mark.parametrize("case", ["uniform", "blobs", "duplicates", "wide", "tiny", "ragged"])
 def test_kmeanspp_device_chooser_equals_host(monkeypatch, case):
     """k-means++ with the chooser on the device (exact block sums; seeding.hip) against the reference's

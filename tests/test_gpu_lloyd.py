@@ -70,8 +70,11 @@ def test_assign_gaussian_and_second_pass(filt):
     assert counters[0] == ref_changed
 
 
+@pytest.mark.parametrize("settle", ["1", "0"])
 @pytest.mark.parametrize("filt", ["f16", "f32"])
-def test_assign_ties_duplicates_nans(filt):
+def test_assign_ties_duplicates_nans(filt, settle, monkeypatch):
+    # settle: the undecided rows in one launch (lloyd_settle_kernel, default) / the pair + full-scan kernels
+    monkeypatch.setenv("KMCUDA_AMD_SETTLE", settle)
     rs = numpy.random.RandomState(11)
     x = rs.rand(4000, 256).astype(numpy.float32)
     c = x[rs.choice(4000, 96, replace=False)].copy()
@@ -93,17 +96,21 @@ def test_assign_ties_duplicates_nans(filt):
     assert not numpy.isin(got, [10, 11, 40, 77]).any()
 
 
+@pytest.mark.parametrize("settle", ["1", "0"])
+@pytest.mark.parametrize("n,d", [(1500, 64), (5000, 256), (700, 20), (900, 132)])
 @pytest.mark.parametrize("filt", ["f16", "f32"])
-def test_assign_all_rows_flagged_still_exact(filt):
-    # every centroid duplicated: the filter can decide nothing, the exact kernel decides all
+def test_assign_all_rows_flagged_still_exact(filt, n, d, settle, monkeypatch):
+    # every centroid duplicated: the filter can decide nothing, the exact kernels decide all (d = 20, 132: the
+    # staged chunks of lloyd_settle_kernel end inside a chunk)
+    monkeypatch.setenv("KMCUDA_AMD_SETTLE", settle)
     rs = numpy.random.RandomState(13)
-    x = rs.rand(1500, 64).astype(numpy.float32)
-    base = x[rs.choice(1500, 20, replace=False)]
+    x = rs.rand(n, d).astype(numpy.float32)
+    base = x[rs.choice(n, 20, replace=False)]
     c = numpy.concatenate([base, base]).astype(numpy.float32)
     got, _, counters = _assign(x, c, filt=filt)
     ref, _, _ = oracle.lloyd_assign(x, c)
     assert (got == ref).all()
-    assert counters[1] + counters[3] == 1500  # nothing decided by the filter itself
+    assert counters[1] + counters[3] == n  # nothing decided by the filter itself
     assert (got < 20).all()
 
 

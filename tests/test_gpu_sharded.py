@@ -60,12 +60,15 @@ def _worker(rank, world, port, out):
     first = None
     log = []
     for it in range(60):
+        # the stop rule is decided on the device: step() enqueues pass it + 1 and returns pass it's count (one
+        # pass late, None at first); once a pass has fired the rule the later ones are no-ops
         changed = loop.step(0.002)
-        log.append(changed)
+        if changed is not None:
+            log.append(changed)
         if it == 0:
             torch.cuda.synchronize(dev)
             first = loop.b.assignments.cpu().numpy().view(numpy.uint32).copy()
-        if changed <= 0.002 * len(x):
+        if loop.stopped:
             break
     torch.cuda.synchronize(dev)
     mine = loop.b.assignments.cpu().numpy().view(numpy.uint32).copy()
