@@ -19,15 +19,6 @@
 
 namespace kmx {
 
-// optional timeline stamps of ONE wave (instrumented builds only: -DKMX_STAMPS): s_memtime into kmx_stamps[]
-#ifdef KMX_STAMPS
-__device__ unsigned long long kmx_stamps[64];
-__device__ unsigned int kmx_stamp_owner;   // 0: free; the first wave to ask owns the buffer
-#define KMX_STAMP(on, k) do { if (on) kmx_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define KMX_STAMP(on, k) do { } while (0)
-#endif
-
 #define KMX_RD_ON "s_nop 0\n\ts_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2\n\t"
 #define KMX_RD_OFF "s_nop 1\n\ts_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\t"
 

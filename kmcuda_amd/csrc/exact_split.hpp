@@ -23,11 +23,8 @@ typedef float f32x4_es __attribute__((ext_vector_type(4)));
 // otherwise idle: a wave's last flush).
 template <int NK, int METRIC, bool FAST, bool DEEP, int W>
 __device__ __forceinline__ void exact_distance_w(const float *__restrict__ xrow, const float *const (&crow)[4],
-                                                 uint32_t D, int h, int col, float (&dist)[4], int nq, int lane_q,
-                                                 bool stamp = false) {
+                                                 uint32_t D, int h, int col, float (&dist)[4], int nq, int lane_q) {
   float acc[W], corr[W];
-  int stamp_k = 8;
-  (void)stamp; (void)stamp_k;
 #pragma unroll
   for (int i = 0; i < W; i++) acc[i] = corr[i] = 0.f;
   const int nvalid = (int)D - h * NK < 0 ? 0 : ((int)D - h * NK > NK ? NK : (int)D - h * NK);
@@ -90,10 +87,6 @@ __device__ __forceinline__ void exact_distance_w(const float *__restrict__ xrow,
               if (i < nq && i < lane_q) cs[b][i] = *reinterpret_cast<const f32x4_es *>(crow[i] + h * NK + j0 + 4 * b);
             }
           }
-#ifdef KMX_STAMPS
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          KMX_STAMP(stamp, stamp_k); stamp_k++;    // the batch's gathers have landed
-#endif
 #pragma unroll
           for (int b = 0; b < NB; b++) {
             const float xv[4] = {xs[b].x, xs[b].y, xs[b].z, xs[b].w};
@@ -104,10 +97,6 @@ __device__ __forceinline__ void exact_distance_w(const float *__restrict__ xrow,
             }
             step(xv, cv, j0 + 4 * b);
           }
-#ifdef KMX_STAMPS
-          asm volatile("" :: "v"(acc[0]));
-          KMX_STAMP(stamp, stamp_k); stamp_k++;    // ... and their arithmetic is done
-#endif
         }
       } else {
 #pragma unroll 2
@@ -146,10 +135,9 @@ __device__ __forceinline__ void exact_distance_w(const float *__restrict__ xrow,
 
 template <int NK, int METRIC, bool FAST, bool DEEP = false>
 __device__ __forceinline__ void exact_distance4(const float *__restrict__ xrow, const float *const (&crow)[4],
-                                                uint32_t D, int h, int col, float (&dist)[4], int nq = 4, int lane_q = 4,
-                                                bool stamp = false) {
-  if (nq <= 2) exact_distance_w<NK, METRIC, FAST, DEEP, 2>(xrow, crow, D, h, col, dist, nq, lane_q, stamp);
-  else exact_distance_w<NK, METRIC, FAST, DEEP, 4>(xrow, crow, D, h, col, dist, nq, lane_q, stamp);
+                                                uint32_t D, int h, int col, float (&dist)[4], int nq = 4, int lane_q = 4) {
+  if (nq <= 2) exact_distance_w<NK, METRIC, FAST, DEEP, 2>(xrow, crow, D, h, col, dist, nq, lane_q);
+  else exact_distance_w<NK, METRIC, FAST, DEEP, 4>(xrow, crow, D, h, col, dist, nq, lane_q);
 }
 
 

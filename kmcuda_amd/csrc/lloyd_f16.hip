@@ -238,29 +238,8 @@ __device__ __forceinline__ void lds_frag_wait(f16x8 &f) {
   asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N));
 }
 
-#ifndef KMX_ABL
-#define KMX_ABL 0  // timing ablations (scripts/coarse_variants.sh): results are WRONG when non-zero
-#endif
-// experiment switches of the stage-1 kernel (scripts/coarse_variants.sh builds them side by side; results
-// are CORRECT in every combination, tests/test_gpu_lloyd.py runs against whatever the library was built with)
-#ifndef KMX_BOOK
-#define KMX_BOOK 1    // 1 (default): pair bookkeeping, 2.5 VALU ops per score (v_max3 on the packed pair); 0: 3 ops per score
-#endif
-#ifndef KMX_BIASPF
-#define KMX_BIASPF 0  // 1: per-wave bias copies; the next tile's biases are fetched BEFORE this tile's bookkeeping
-#endif
-#ifndef KMX_PRIO
-#define KMX_PRIO 0    // 1: s_setprio 1 around the bookkeeping, 2: around the MFMA loop
-#endif
-#ifndef KMX_TRACE
-#define KMX_TRACE 0   // 1: s_memtime stamps of one block's tile phases -> kmx_trace_buf (kmamd_debug_trace)
-#endif
-#if KMX_TRACE
-// one record per WAVE that ran on the traced CU (XCC 0, SE 0, SH 0, CU 0): [0] block, [1] wave | HW_ID << 8,
-// then 6 stamps per tile
-constexpr int kTraceRec = 200, kTraceMax = 1024;
-__device__ unsigned long long kmx_trace_buf[kTraceRec * kTraceMax];
-__device__ unsigned int kmx_trace_n;
+#ifndef KMX_DMA_BOOK
+#define KMX_DMA_BOOK 0
 #endif
 // 4 waves x 64 rows per block, 2 independent blocks per CU (2 x 67 KB of LDS).  (Tried and dropped:
 // one 8-wave block per CU run as a ping-pong -- the waves sharing a SIMD, read from HW_ID, alternate
@@ -287,8 +266,8 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   // raw LDS byte addresses (the fragment address is built with XOR: needs the 1-KB aligned base)
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte *)lds2;
   if (lds0 & 1023u) __builtin_trap();
-  const uint32_t bias0 = lds0 + 2 * SUPB;   // 2 x 64 floats (KMX_BIASPF: one such pair per wave)
-  constexpr uint32_t BIASB = KMX_BIASPF ? 2048u : 512u;
+  const uint32_t bias0 = lds0 + 2 * SUPB;   // 2 x 64 floats
+  constexpr uint32_t BIASB = 512u;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 31, h = lane >> 5;
   constexpr int WV = 4;
@@ -301,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   // both rows of a lane per k-step, sharing the mean chunk.  Lanes without a row read row 0: an MFMA
   // column only feeds its own outputs and theirs are never committed, so nothing is masked.
   auto load_chunk = [&](uint32_t s, bool live, int j, float (&xv)[8]) {
-    const size_t row = (size_t)(live ? (KMX_ABL == 9 ? (s & 65535u) : s) : 0);  // ABL 9: rows from a 64-MB window
+    const size_t row = (size_t)(live ? s : 0);
     if (FAST && HALF_ROWS) {
       const f16x8 raw = reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(rows) + row * DP + h * NKH)[j];
 #pragma unroll
@@ -392,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   auto stage_piece = [&](uint32_t sp, int buf, int p) {
     uint32_t P0 = (uint32_t)lane * 16u;
     asm volatile("" : "+v"(P0));
-    const unsigned char *src = reinterpret_cast<const unsigned char *>(panelhi) + (size_t)(KMX_ABL == 8 ? 0 : sp) * SUPB;  // ABL 8: always the same 32 KB
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(panelhi) + (size_t)sp * SUPB;
     const uint32_t P = (uint32_t)p * 1024u + P0;
     const uint32_t from = P ^ (((P / ROWB) & SWM) << 4);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + from),
@@ -400,14 +379,14 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   };
   // the 64 biases of the super-tile (clamped copy behind the panel): one 4-byte DMA.  No ordinary
   // global load lives in the loop: hipcc waits vmcnt(0) at its first use, draining the DMA
-  const uint32_t mybias = KMX_BIASPF ? bias0 + (uint32_t)wave * 512u : bias0;   // this wave's bias pair
+  const uint32_t mybias = bias0;
   auto stage_bias = [&](uint32_t sp, int buf) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(biashi + sp * 64u + lane),
                                      (__attribute__((address_space(3))) void *)(uintptr_t)(mybias + buf * 256), 4, 0, 0);
   };
   auto stage_issue = [&](uint32_t sp, int buf, int nw, int me) {   // nw waves share the pieces, I am number me
     for (int p = me; p < NP; p += nw) stage_piece(sp, buf, p);
-    if (me == 0 || KMX_BIASPF) stage_bias(sp, buf);
+    if (me == 0) stage_bias(sp, buf);
   };
 
   {  // the mean -> LDS: DP floats = DP / 4 sixteen-byte lanes
@@ -427,11 +406,6 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   float pinf = INFINITY;
   asm volatile("" : "+s"(pinf));
   auto pack = [&](float v, int r) { return __uint_as_float((__float_as_uint(v) & 0xFFFFFFF0u) | (uint32_t)r); };
-  auto book = [&](float v, int r, float &v1, float &v2) {
-    const float pk = pack(v, r);
-    v2 = __builtin_amdgcn_fmed3f(v1, v2, pk);
-    v1 = __builtin_amdgcn_fmed3f(v1, pk, pinf);
-  };
   // two scores at once: the new second = max(second, median(best, a, b)), the new best = max3(best, a, b):
   // 3 ops for the pair + 2 packs.  v_max3 only sees PACKED values (results of VALU ops the compiler
   // scheduled itself), never an MFMA result: the MFMA -> VALU read hazard stays the compiler's business
@@ -453,47 +427,15 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
       b[4 * g + 0] = b4.x; b[4 * g + 1] = b4.y; b[4 * g + 2] = b4.z; b[4 * g + 3] = b4.w;
     }
   };
-#if KMX_TRACE
-  uint32_t trace_slot = 0xFFFFFFFFu;
-  {
-    const uint32_t hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-    if ((xcc & 15u) == 0u && (hwid & 0xFF00u) == 0u && lane == 0) {
-      const uint32_t at = atomicAdd(&kmx_trace_n, 1u);
-      if (at < (uint32_t)kTraceMax) {
-        trace_slot = at;
-        kmx_trace_buf[(size_t)at * kTraceRec] = blockIdx.x;
-        kmx_trace_buf[(size_t)at * kTraceRec + 1] = (unsigned long long)wave | ((unsigned long long)hwid << 8);
-      }
-    }
-  }
-  auto stamp = [&](uint32_t t, int k) {
-    const unsigned long long now = __builtin_amdgcn_s_memtime();
-    if (trace_slot != 0xFFFFFFFFu && t < 33u) kmx_trace_buf[(size_t)trace_slot * kTraceRec + 2 + t * 6 + k] = now;
-  };
-#else
-  auto stamp = [&](uint32_t, int) {};
-#endif
-  f32x16 nb;   // KMX_BIASPF: the coming tile's biases
-  if (KMX_BIASPF) load_bias(mybias, nb);
   // One tile: 2 x KS MFMAs (each A fragment feeds both row sets), then the top-2 bookkeeping of its
   // 2 x 16 scores on the VALU.  The two waves a SIMD holds belong to DIFFERENT blocks (4 waves per
   // block, one per SIMD), so they are not in step: one's bookkeeping runs under the other's MFMAs.
   // (Double-buffered accumulators with the bookkeeping interleaved in-wave need ~230 registers: the
   // B operands spill, measured slower.)
-  auto tile_pass = [&](uint32_t ldsbase, uint32_t biasaddr, uint32_t next_bias, bool drain, uint32_t t, bool stage,
-                       uint32_t sp_next, int buf_next) {
+  auto tile_pass = [&](uint32_t ldsbase, uint32_t biasaddr, uint32_t t, bool stage, uint32_t sp_next, int buf_next) {
     f32x16 accA, accB;
-    stamp(t, 0);
-    if (KMX_BIASPF) {
-      accA = nb;
-    } else {
-      load_bias(biasaddr, accA);
-    }
+    load_bias(biasaddr, accA);
     accB = accA;
-#if KMX_TRACE
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    stamp(t, 1);
-#endif
     // (the 1-KB aligned tile base adds into bits the XOR never touches.)  Opaque on purpose: left
     // visible, the KS addresses are hoisted out of the tile loop and the B operands spill instead
     uint32_t fb = fragbase + ldsbase;
@@ -501,17 +443,13 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     // Fragment reads are issued by hand, PD k-steps ahead, with counted waits: while an LDS-DMA is in
     // flight hipcc turns every wait on a fragment into lgkmcnt(0), i.e. it waits for the read it
     // has just issued.  (LDS returns in order: lgkmcnt(n) = all but the youngest n reads landed.)
-#ifndef KMX_PD
-#define KMX_PD 3
-#endif
-    constexpr int PD = KS <= KMX_PD ? KS - 1 : KMX_PD;
+    constexpr int PD = KS <= 3 ? KS - 1 : 3;   // (every other depth spills the B operands at D = 256)
     f16x8 fr[PD + 1];
 #pragma unroll
     for (int j = 0; j < PD; j++) fr[j] = lds_frag_issue(fb ^ (uint32_t)(j * 16));
-    if (KMX_ABL == 12 || KMX_PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int j = 0; j < KS; j++) {
-      if (j + PD < KS && KMX_ABL != 6) fr[(j + PD) % (PD + 1)] = lds_frag_issue(fb ^ (uint32_t)((j + PD) * 16));
+      if (j + PD < KS) fr[(j + PD) % (PD + 1)] = lds_frag_issue(fb ^ (uint32_t)((j + PD) * 16));
       constexpr int kMaxBehind = PD;
       const int behind = (KS - 1 - j) < kMaxBehind ? (KS - 1 - j) : kMaxBehind;  // younger reads in flight
       f16x8 &f = fr[j % (PD + 1)];
@@ -523,66 +461,41 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
       else if (behind == 2) lds_frag_wait<2>(f);
       else if (behind == 1) lds_frag_wait<1>(f);
       else lds_frag_wait<0>(f);
-      if (KMX_ABL == 4 && j > 0) {  // no matrix work
-        accA[j] += (float)f[0];
-        continue;
-      }
       accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, xa[j], accA, 0, 0, 0);
       if constexpr (TWO) accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, xb[j], accB, 0, 0, 0);
       // the next super-tile's LDS-DMA pieces, one at a time in the shadow of the MFMAs: issued
       // back to back the four waves' 32 pieces queue up in the texture path and hold up the wave
       // (all of them during the super-tile's FIRST tile: the second one's 32 MFMAs cover the flight)
       constexpr int SPREAD = KS >= 8 ? KS / 8 : 1;            // a piece every SPREAD k-steps
-      if (stage && (j % SPREAD) == SPREAD / 2 && j / SPREAD < 8) {
+      if (!KMX_DMA_BOOK && stage && (j % SPREAD) == SPREAD / 2 && j / SPREAD < 8) {
         const int slot = j / SPREAD;                           // 0..7
         for (int p = slot * 4 + wave; p < NP; p += 32) stage_piece(sp_next, buf_next, p);
-        if (slot == 0 && (wave == 0 || KMX_BIASPF)) stage_bias(sp_next, buf_next);
+        if (slot == 0 && wave == 0) stage_bias(sp_next, buf_next);
       }
     }
-    if (KMX_ABL == 12 || KMX_PRIO == 2) __builtin_amdgcn_s_setprio(0);
-    stamp(t, 2);
-    if (KMX_BIASPF) {
-      // the coming tile's biases travel while this tile's scores are booked.  Across a super-tile boundary
-      // they sit in THIS wave's own copy, written by its own DMA: its vmcnt wait is all the ordering needed
-      if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (next_bias) load_bias(next_bias, nb);
-    }
-    if (KMX_PRIO == 1) __builtin_amdgcn_s_setprio(1);
     const float v1a_in = v1a, v1b_in = v1b;
-    if (KMX_BOOK == 1) {
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        book2(accA[r], accA[r + 1], r, v1a, v2a);
-        if constexpr (TWO) book2(accB[r], accB[r + 1], r, v1b, v2b);
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < ((KMX_ABL == 1 || (KMX_ABL >= 5 && KMX_ABL <= 11)) ? 1 : 16); r++) {
-        book(accA[r], r, v1a, v2a);
-        if constexpr (TWO) book(accB[r], r, v1b, v2b);
+    for (int r = 0; r < 16; r += 2) {
+      book2(accA[r], accA[r + 1], r, v1a, v2a);
+      if constexpr (TWO) book2(accB[r], accB[r + 1], r, v1b, v2b);
+      if (KMX_DMA_BOOK && stage) {   // experiment: the DMA pieces issued from the bookkeeping phase
+        const int slot = r / 2;
+        for (int p = slot * 4 + wave; p < NP; p += 32) stage_piece(sp_next, buf_next, p);
+        if (slot == 0 && wave == 0) stage_bias(sp_next, buf_next);
       }
     }
     tba = (v1a != v1a_in) ? t : tba;
     tbb = (v1b != v1b_in) ? t : tbb;
-    if (KMX_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-#if KMX_TRACE
-    asm volatile("" :: "v"(v1a), "v"(v2a), "v"(v1b), "v"(v2b), "v"(tba), "v"(tbb));
-#endif
-    stamp(t, 3);
   };
 
-  for (uint32_t sp = 0; sp < (KMX_ABL == 10 ? 1u : nsuper); sp++) {  // ABL 10: prologue + one super-tile
+  for (uint32_t sp = 0; sp < nsuper; sp++) {
     const int buf = sp & 1;
-    const bool stage = sp + 1 < nsuper && !(KMX_ABL == 2 || KMX_ABL == 5 || KMX_ABL == 6 || KMX_ABL == 7);  // ABL 7: barrier without DMA
+    const bool stage = sp + 1 < nsuper;
     const uint32_t base = buf * SUPB, bb = mybias + buf * 256;
-    tile_pass(base, bb, bb + 128, false, 2 * sp, stage, sp + 1, buf ^ 1);
-    tile_pass(base + 32 * ROWB, bb + 128, stage ? mybias + (buf ^ 1) * 256 : 0u, true, 2 * sp + 1, false, sp + 1, buf ^ 1);
-    if (!(KMX_ABL == 2 || KMX_ABL == 3 || KMX_ABL == 5 || KMX_ABL == 6)) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      stamp(2 * sp + 1, 4);
-      __syncthreads();
-    }
-    stamp(2 * sp + 1, 5);
+    tile_pass(base, bb, 2 * sp, stage, sp + 1, buf ^ 1);
+    tile_pass(base + 32 * ROWB, bb + 128, 2 * sp + 1, false, sp + 1, buf ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
 
   // |coarse score - reference score| <= E_c: the f32-accumulated hi.hi products (gamma_{DP+1}), the
@@ -703,7 +616,7 @@ static hipError_t launch_coarse2_dp(const LloydArgs &a, const void *rows, bool h
                                     const float *xmeta, const void *panelhi, uint32_t *undecided, float *und_thr,
                                     hipStream_t st) {
   constexpr int NSET = DP <= 256 ? 2 : 1;
-  const size_t lds_bytes = 2 * 64 * (size_t)(DP * 2) + (KMX_BIASPF ? 2048 : 512) + 64 + (size_t)DP * 4;
+  const size_t lds_bytes = 2 * 64 * (size_t)(DP * 2) + 512 + 64 + (size_t)DP * 4;
   const uint32_t rows_per_block = 128u * NSET;
   const uint32_t grid = (a.N + rows_per_block - 1) / rows_per_block;
   const bool fast = a.D == (uint32_t)DP;
@@ -721,16 +634,6 @@ static hipError_t launch_coarse2_dp(const LloydArgs &a, const void *rows, bool h
 #undef KMX_CRS2_LAUNCH
   return hipGetLastError();
 }
-
-#if KMX_TRACE
-// copies the records out and rearms the trace (the NEXT launch is recorded from slot 0)
-extern "C" int kmamd_debug_trace(unsigned long long *host, size_t words, unsigned int *nrec) {
-  unsigned int zero = 0;
-  if (hipMemcpyFromSymbol(nrec, HIP_SYMBOL(kmx_trace_n), sizeof(unsigned int)) != hipSuccess) return 4;
-  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(kmx_trace_buf), words * sizeof(unsigned long long)) != hipSuccess) return 4;
-  return hipMemcpyToSymbol(HIP_SYMBOL(kmx_trace_n), &zero, sizeof(zero)) == hipSuccess ? 0 : 4;
-}
-#endif
 
 hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
                                const float *xmeta, const void *panelhi, uint32_t *undecided, float *und_thr,

@@ -472,8 +472,13 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
   a.res = bucket_work + 2 * (size_t)K * stride; a.host = ms->host_dev;
   hipError_t e = hipSuccess;
   const bool force_radix = ms->force == 1, force_sync = ms->force == 2, force_direct = ms->force == 3;
-  // last_events: the newest event count the host knows (2 N before the first call)
-  const bool radix = N != 0 && !force_direct && (force_radix || ms->last_events > N / 2);
+  // last_events / host[1]: the newest event count and largest list the host knows (2 N before the first call).
+  // Lists shrink from iteration to iteration, so an older figure errs towards the radix path, which takes any
+  // size; after a radix call only the count is known yet and the largest list is taken as twice the average.
+  // A list beyond the bucket capacity would still be summed correctly (rebuilt from (prev, cur)), only slowly.
+  const uint32_t est_max = std::max((uint32_t)ms->host[1] /* whatever has landed */, ms->last_events / K);
+  const bool radix = N != 0 && !force_direct &&
+                     (force_radix || ms->last_events > N / 2 || est_max > cap - cap / 4);
   if (N == 0) {
     e = hipMemsetAsync(offsets2, 0, (2 * (size_t)K + 1) * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
@@ -498,7 +503,8 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
     hipLaunchKernelGGL(offsets_kernel, dim3((2 * K + 1 + 255) / 256), dim3(256), 0, st, keys_sorted, m, 2 * K, offsets2);
     hipLaunchKernelGGL((cluster_sums_kernel<false>), dim3(K), dim3(kSumThreads), 0, st, a);
     ms->last_events = m;
-    ms->host[0] = m;   // (the kernel's report will say the same)
+    ms->host[0] = m;    // (the kernel's report will say the same)
+    ms->host[1] = 0;
   } else {
     hipLaunchKernelGGL(move_scatter_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, bucket_work,
                        stride, bucket_rows, cap);
@@ -509,7 +515,7 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
       e = hipStreamSynchronize(st);
       if (e != hipSuccess) return e;
     }
-    ms->last_events = ms->host[0];   // whatever has landed: an earlier update's count
+    ms->last_events = ms->host[0];   // whatever has landed: an earlier update's figures
   }
   return hipGetLastError();
 }

@@ -354,21 +354,6 @@ __global__ __launch_bounds__(256, 2) void yy_hint_kernel(YyArgs a) {
   }
 }
 
-#ifdef KMX_STAMPS
-extern "C" int kmamd_stamps(unsigned long long *host64) {
-  return hipMemcpyFromSymbol(host64, HIP_SYMBOL(kmx_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : 4;
-}
-#endif
-#ifdef KMX_YYL_DBG
-// [0] wave cycles [1] prologue (rows, bounds fold) [2] flushes (count) [3] cycles in flushes [4] slow-path entries
-// (sub-tiles with a candidate) [5] cycles in the slow path (incl. its flushes) [6] cycles waiting (vmcnt + barrier) [7] epilogue
-__device__ unsigned long long kmx_yyl_dbg[8];
-extern "C" int kmamd_yyl_debug(unsigned long long *host8) {
-  unsigned long long z[8] = {0};
-  if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(kmx_yyl_dbg), sizeof(z)) != hipSuccess) return 4;
-  return hipMemcpyToSymbol(HIP_SYMBOL(kmx_yyl_dbg), z, sizeof(z)) == hipSuccess ? 0 : 4;
-}
-#endif
 // ---------------------------------------------------------------------------------------
 // the local filter against the estimate
 // ---------------------------------------------------------------------------------------
@@ -396,25 +381,11 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
 
   const uint32_t npassed = *a.count_ptr;
   if (blockIdx.x * 128u >= npassed) return;  // block-uniform
-#ifdef KMX_YYL_DBG
-  unsigned long long dbg[8] = {0};
-  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef KMX_STAMPS
-  const bool stamp_on = blockIdx.x == 20000u && threadIdx.x == 0;
-  KMX_STAMP(stamp_on, 0);
-#else
-  const bool stamp_on = false; (void)stamp_on;
-#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 31, h = lane >> 5;
   const uint32_t D = a.D, K = a.K, G = a.G, len = a.len;
   const uint32_t pi = blockIdx.x * 128u + wave * 32u + col;
   const bool live = pi < npassed;
   const uint32_t s = live ? a.passed[pi] : 0u;
-#ifdef KMX_STAMPS
-  asm volatile("" :: "v"(s));
-  KMX_STAMP(stamp_on, 1);
-#endif
 
   f16x8h xh[KS];
   float dx2 = 0.f;  // ||x' - hi(x')||^2, measured
@@ -481,10 +452,6 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
     dx2 += __shfl_xor(dx2, 32);
   }
 
-#ifdef KMX_STAMPS
-  asm volatile("" :: "v"(xh[0]), "v"(xh[KS - 1]), "v"(xc2), "v"(dx2));
-  KMX_STAMP(stamp_on, 2);
-#endif
   const float upper_bound = live ? a.bounds[s] : 0.f;
   const uint32_t cluster = live ? a.assignments[s] : 0xFFFFFFFFu;
   const float hint = live ? a.hint[s] : INFINITY;
@@ -559,17 +526,12 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
   int qn = 0;
   auto flush = [&](auto deep_c) {  // wave-uniform call; deep_c: std::true_type for the wave's last flush
     constexpr bool DEEPF = decltype(deep_c)::value;
-#ifdef KMX_YYL_DBG
-    const unsigned long long f0 = __builtin_amdgcn_s_memtime();
-    dbg[2]++;
-#endif
     const float *crow[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) crow[i] = a.centroids + (size_t)(i < qn ? qc[i] : 0) * D;
     // what the replay below needs of each queued centroid, requested BEFORE the chains run: the group's bound
     // and drift, the centroid's drift (kmeans.cu:637) -- fetched one dependent load after the other inside the
     // replay they were 40 % of a flush
-    KMX_STAMP(stamp_on && DEEPF, 5);
     float lbq[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -583,13 +545,7 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
     float dist[4];
     // the fullest queue of the wave sets how many candidate rows are gathered (a row has 0.2 - 2 real ones)
     const int nq = __ballot(qn >= 4) ? 4 : (__ballot(qn >= 3) ? 3 : (__ballot(qn >= 2) ? 2 : 1));
-    KMX_STAMP(stamp_on && DEEPF, 6);
-    exact_distance4<NK, METRIC, FAST, DEEPF>(xrow, crow, D, h, col, dist, nq, qn, stamp_on && DEEPF);
-#ifdef KMX_STAMPS
-    asm volatile("" :: "v"(dist[0]));
-    KMX_STAMP(stamp_on && DEEPF, 40);
-    if (stamp_on && DEEPF) kmx_stamps[43] = (unsigned long long)nq;
-#endif
+    exact_distance4<NK, METRIC, FAST, DEEPF>(xrow, crow, D, h, col, dist, nq, qn);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       if (i < qn) {
@@ -616,39 +572,17 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
     }
     qn = 0;
     amin = amin_of(fminf(second_min, hint));
-#ifdef KMX_STAMPS
-    asm volatile("" :: "v"(amin));
-    KMX_STAMP(stamp_on && DEEPF, 41);
-#endif
-#ifdef KMX_YYL_DBG
-    asm volatile("" :: "v"(amin));
-    dbg[3] += __builtin_amdgcn_s_memtime() - f0;
-#endif
   };
 
   const bool wave_live = __ballot(live && !bad) != 0ull;
-#ifdef KMX_STAMPS
-  asm volatile("" :: "v"(amin), "v"(second_min));
-  KMX_STAMP(stamp_on, 3);
-#endif
-#ifdef KMX_YYL_DBG
-  asm volatile("" :: "v"(amin), "v"(second_min));
-  dbg[1] = __builtin_amdgcn_s_memtime() - dbg_t0;
-#endif
 #pragma unroll
   for (int i = 0; i <= PPW + 1; i++) issue_piece(0, 0, i);
   constexpr int DSTR = (2 * KS) / (PPW + 2) > 0 ? (2 * KS) / (PPW + 2) : 1;   // a piece every DSTR k-steps
   for (uint32_t sp = 0; sp < nsuper; sp++) {
     const int buf = sp & 1;
-#ifdef KMX_YYL_DBG
-    const unsigned long long w0 = __builtin_amdgcn_s_memtime();
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of super-tile sp have landed
     __builtin_amdgcn_s_barrier();                      // everybody's have, and everybody is done with sp - 1
     asm volatile("" ::: "memory");
-#ifdef KMX_YYL_DBG
-    dbg[6] += __builtin_amdgcn_s_memtime() - w0;
-#endif
     const bool dma = sp + 1 < nsuper;
     if (dma && !wave_live) {
 #pragma unroll
@@ -705,10 +639,6 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
           some = __builtin_fmaxf(m5, m6) >= amin;
         }
         if (__ballot(some) != 0ull) {
-#ifdef KMX_YYL_DBG
-          const unsigned long long s0 = __builtin_amdgcn_s_memtime();
-          dbg[4]++;
-#endif
           uint32_t m16 = 0;
           if (some) {
 #pragma unroll
@@ -746,23 +676,11 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
               }
             }
           }
-#ifdef KMX_YYL_DBG
-          asm volatile("" :: "v"(qn));
-          dbg[5] += __builtin_amdgcn_s_memtime() - s0;
-#endif
         }
       }
     }
   }
-#ifdef KMX_YYL_DBG
-  const unsigned long long e0 = __builtin_amdgcn_s_memtime();
-#endif
-  KMX_STAMP(stamp_on, 4);
   if (wave_live && __ballot(qn > 0) != 0ull) flush(std::true_type());
-#ifdef KMX_STAMPS
-  asm volatile("" :: "v"(second_min), "v"(min_dist));
-  KMX_STAMP(stamp_on, 42);
-#endif
   if (!(second_min <= hint)) {  // F2: the reference's second minimum may be a value we never saw
     bad = true;
     if (!why) why = 4u;
@@ -813,12 +731,6 @@ __global__ __launch_bounds__(256, 2) void yy_local_hint_kernel(YyArgs a) {
         if (nwhy[w]) atomicAdd(&st[8 + w], nwhy[w]);
     }
   }
-#ifdef KMX_YYL_DBG
-  dbg[0] = __builtin_amdgcn_s_memtime() - dbg_t0;
-  dbg[7] = __builtin_amdgcn_s_memtime() - e0;
-  if (lane == 0)
-    for (int i = 0; i < 8; i++) atomicAdd(&kmx_yyl_dbg[i], dbg[i]);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------

@@ -87,17 +87,6 @@ __device__ __forceinline__ void exact_chain4_lds_pipe(const XV (&xv)[NK / VN], c
   }
 }
 
-#ifdef KMX_YYI_DBG
-// [0] flushes [1] entries completed [2] cycles in flushes [3] wave cycles [4] cycles in the matrix-core loop
-// [5] cycles in stage load/store + barriers [6] scans [7] forced flushes
-__device__ unsigned long long kmx_yyi_dbg[8];
-extern "C" int kmamd_yyi_debug(unsigned long long *host8) {
-  unsigned long long z[8] = {0};
-  if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(kmx_yyi_dbg), sizeof(z)) != hipSuccess) return 4;
-  return hipMemcpyToSymbol(HIP_SYMBOL(kmx_yyi_dbg), z, sizeof(z)) == hipSuccess ? 0 : 4;
-}
-#define KMX_YYI_T() __builtin_amdgcn_s_memtime()
-#endif
 // pids[slot]  centroid id of the slot or 0xFFFFFFFF (padding)
 // pmeta[8*tile + ch]  (group << 1) | starts_new_group, for the 4-slot chunk ch of the tile
 template <int DP, int METRIC, bool FAST>
@@ -192,21 +181,11 @@ __global__ __launch_bounds__(256, 2) void yy_init_lds_kernel(YyArgs a) {
   auto store_carry = [&]() __attribute__((always_inline)) {
     if (carry_g != 0xFFFFFFFFu && live && h == 0) a.bounds[(size_t)len * (1 + carry_g) + s] = carry_min;
   };
-#ifdef KMX_YYI_DBG
-  unsigned long long dbg[8] = {0};
-  const unsigned long long dbg_t0 = KMX_YYI_T();
-#endif
   // two-batch pipeline: a flush starts the queued batch and completes -- and replays -- the one before it
   uint32_t pqa[4] = {0, 0, 0, 0}, pqg[4] = {0, 0, 0, 0};
   int pqn = 0;
   ExactPipe4 pipe;
   auto flush = [&]() __attribute__((always_inline)) {  // wave-uniform call
-#ifdef KMX_YYI_DBG
-    const unsigned long long f0 = KMX_YYI_T();
-    dbg[0]++;
-    dbg[1] += (unsigned long long)__popcll(__ballot(pqn >= 1) & 0xFFFFFFFFull) + __popcll(__ballot(pqn >= 2) & 0xFFFFFFFFull) +
-              __popcll(__ballot(pqn >= 3) & 0xFFFFFFFFull) + __popcll(__ballot(pqn >= 4) & 0xFFFFFFFFull);
-#endif
     uint32_t crow[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) crow[i] = h ? (i < pqn ? pqa[i] : 0u) : (i < qn ? qa[i] : 0u);
@@ -228,10 +207,6 @@ __global__ __launch_bounds__(256, 2) void yy_init_lds_kernel(YyArgs a) {
     }
     pqn = qn;
     qn = 0;
-#ifdef KMX_YYI_DBG
-    asm volatile("" :: "v"(carry_min), "v"(pipe.acc[0]));
-    dbg[2] += KMX_YYI_T() - f0;
-#endif
   };
   auto drain = [&]() __attribute__((always_inline)) {  // wave-uniform call: nothing queued, nothing pending afterwards
 #pragma unroll 1
@@ -293,9 +268,6 @@ __global__ __launch_bounds__(256, 2) void yy_init_lds_kernel(YyArgs a) {
     const bool sure1 = has1 && ((v1 - v2) > thr);                      // NaN gap => not sure
     const bool sure2 = has1 && !sure1 && r2 != 0xFFFFFFFFu && ((v1 - v3) > thr);
     const bool scan = has1 && !sure1 && !sure2;
-#ifdef KMX_YYI_DBG
-    if (__ballot(scan) != 0ull) dbg[6]++;
-#endif
     // one loop, one flush site: the best, the second best, then -- for the rows with three or more contenders
     // within the error bound -- every member of this (part of the) group, which lies in the current tile
     const uint32_t nscan = __ballot(scan) != 0ull ? end_row - cur_row0 : 0u;
@@ -333,9 +305,6 @@ __global__ __launch_bounds__(256, 2) void yy_init_lds_kernel(YyArgs a) {
   for (uint32_t t = 0; t < ntiles; t++) {
     const int buf = t & 1;
     f32x16 acc;
-#ifdef KMX_YYI_DBG
-    const unsigned long long m0 = KMX_YYI_T();
-#endif
     {
       const float *bb = bias_ptr(buf) + 4 * h;
 #pragma unroll
@@ -353,10 +322,6 @@ __global__ __launch_bounds__(256, 2) void yy_init_lds_kernel(YyArgs a) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, xv[(4 * j + 3) / VN][(4 * j + 3) % VN], acc, 0, 0, 0);
       }
     }
-#ifdef KMX_YYI_DBG
-    asm volatile("" :: "v"(acc[0]), "v"(acc[15]));
-    dbg[4] += KMX_YYI_T() - m0;
-#endif
     // The eight 4-slot chunks as a ROLLED loop (the scores are read with a wave-uniform register index):
     // unrolled, the group-closing code below -- two flush sites, each a whole exact-chain loop -- was
     // instantiated nine times and the kernel came to 90 KB of code, more than the instruction cache.
@@ -395,33 +360,17 @@ __global__ __launch_bounds__(256, 2) void yy_init_lds_kernel(YyArgs a) {
       // (The tile is fetched here, not a tile ahead through registers: 32 staging registers live across
       // the matrix-core loop and the chains spilled; the block's second resident partner covers the trip.)
       if (__ballot(qn > 0 || pqn > 0) != 0ull) {
-#ifdef KMX_YYI_DBG
-        dbg[7]++;
-#endif
         flush();
       }
-#ifdef KMX_YYI_DBG
-      const unsigned long long s0 = KMX_YYI_T();
-#endif
       stage_load(t + 1);
       __syncthreads();   // the other waves' chains may still be reading that buffer
       stage_store(buf ^ 1);
-#ifdef KMX_YYI_DBG
-      __syncthreads();
-      dbg[5] += KMX_YYI_T() - s0;
-      continue;
-#endif
     }
     __syncthreads();
   }
   drain();
   store_carry();
   if (live && h == 0) a.bounds[s] = upper;
-#ifdef KMX_YYI_DBG
-  dbg[3] = KMX_YYI_T() - dbg_t0;
-  if (lane == 0)
-    for (int i = 0; i < 8; i++) atomicAdd(&kmx_yyi_dbg[i], dbg[i]);
-#endif
 }
 
 // group-sorted padded panel of the ORIGINAL centroid values, zero padded to DP; bias = -0.5 ||c||^2 (L2) or 0

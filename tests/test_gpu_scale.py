@@ -127,3 +127,154 @@ def test_knn_200k_rows_vs_oracle():
     assert (nb == ref).all()
     line = [l for l in out.text.split("\n") if l.startswith("calculated")][0]
     assert abs(float(line.split()[1]) - calced / (float(n) * n)) < 1e-6
+
+
+def test_config_c_shape_fp16_angular_yinyang_1m_rows_vs_oracle():
+    """BASELINE config C's shape on one of its eight shards: 1M x 256 fp16 rows of unit length, angular metric,
+    K = 1024, G = 102 -- bounds refresh, update (centroids rounded to halves, as the fp16x2 path keeps them),
+    drifts, global + local filter -- against the oracle on the same half VALUES (the product's fp16 semantics,
+    DESIGN.md 2).  The angular distance ends in acosf, which is libm on the CPU and ocml on the GPU (SURVEY 8c:
+    parity-unpinned), so the bar is a stated tolerance, not bits:
+      bounds       every one within 4e-6 rad of the oracle's (a few ulp of an angle near 1.5), >= 99 % bit-identical
+      assignments  < 1e-4 of the rows differ after the filter pass; the reassignment counts agree to that
+      passed set   symmetric difference < 1e-3 of the rows.
+    (The reference's own half2 ARITHMETIC is compared on small inputs -- test_gpu_fp16.py::test_fp16_strict_* and
+    test_half2_vs_storage_semantics; its thread-per-row verification kernels are not a 1M-row path.)"""
+    from kmcuda_amd.distributed import HipBackend, ShardedLloyd
+    from kmcuda_amd.engine import Engine
+    n, d, k, G = 1000000, 256, 1024, 102
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(11)
+    x = torch.empty((n, d), dtype=torch.float32, device=dev)
+    for s in range(0, n, 1 << 20):
+        x[s:s + (1 << 20)].uniform_(0.0, 1.0, generator=gen)
+    x /= x.norm(dim=1, keepdim=True)
+    x16 = x.to(torch.float16)
+    x = x16.to(torch.float32)                      # the half values, widened: what both sides compute on
+    b = HipBackend(x, k, "cos", device_index=0, half_rows=x16, row_cache=True)
+    loop = ShardedLloyd(b, n)
+    loop.set_centroids(x[torch.randperm(n, generator=gen, device=dev)[:k]].clone())
+    for _ in range(5):
+        loop.step()
+    torch.cuda.synchronize()
+    xh = x.cpu().numpy()
+    c1 = b.centroids.cpu().numpy()                 # halves (HipBackend.apply rounds them), widened
+    assert (c1.astype(numpy.float16).astype(numpy.float32) == c1).all()
+    a1 = b.assignments.cpu().numpy().view(numpy.uint32).copy()
+    cc1 = b.ccounts.cpu().numpy().view(numpy.uint32).copy()
+    b.engine.close()
+    a2, p2, _ = oracle.lloyd_assign(xh, c1, assignments=a1, metric=oracle.COS)
+    rs = numpy.random.RandomState(1)
+    groups = (rs.permutation(k) % G).astype(numpy.uint32)
+    bounds = oracle.yy_init(xh, c1, a2, groups, G, metric=oracle.COS)
+    c2, _ = oracle.adjust(xh, p2, a2, c1, cc1, metric=oracle.COS)
+    c2 = c2.astype(numpy.float16).astype(numpy.float32)
+    drifts = oracle.yy_drifts(c1, c2, groups, G, metric=oracle.COS)
+    ra, rprev, rb, rpassed, rchanged = oracle.yy_filters(xh, c2, groups, G, drifts, a2, bounds, metric=oracle.COS)
+
+    eng = Engine(n, d, k, "cos", device=0)
+    eng.yy_configure(G, groups)
+    gb = torch.empty((G + 1) * n, dtype=torch.float32, device=dev)
+    asg = _t(a2, dev)
+    eng.yy_init(x, _t(c1, dev), asg, gb)
+    eng.sync()
+    got = gb.cpu().numpy().reshape(G + 1, n)
+    assert numpy.abs(got - bounds).max() < 4e-6
+    same = (got.view(numpy.uint32) == bounds.view(numpy.uint32)).mean()
+    print("bounds after the refresh: %.4f %% bit-identical, max |diff| %.2e rad" % (100 * same, numpy.abs(got - bounds).max()))
+    assert same > 0.99
+    dr = torch.empty(k * d + k, dtype=torch.float32, device=dev)
+    dr[:k * d] = _t(c1, dev).ravel()
+    gdr = torch.empty(G, dtype=torch.float32, device=dev)
+    cen2 = _t(c2, dev)
+    eng.yy_drifts(cen2, dr, gdr)
+    prev = torch.empty(n, dtype=torch.int32, device=dev)
+    passed = torch.empty(n, dtype=torch.int32, device=dev)
+    eng.reset_counters(-1)
+    # (the filters start from the ORACLE's bounds so that the two sides compare one pass, not two)
+    gb.copy_(_t(bounds.ravel(), dev))
+    eng.yy_filters(x, cen2, dr, gdr, asg, prev, gb, passed)
+    counters = eng.counters()
+    gpassed = numpy.sort(passed.cpu().numpy().view(numpy.uint32)[:counters[2]])
+    sym = numpy.setxor1d(gpassed, rpassed).size
+    mism = (asg.cpu().numpy().view(numpy.uint32) != ra).sum()
+    gbounds = gb.cpu().numpy().reshape(G + 1, n)
+    print("filter pass: %d passed (oracle %d, symmetric difference %d), %d of %d assignments differ, "
+          "reassigned %d (oracle %d), bounds max |diff| %.2e" % (counters[2], len(rpassed), sym, mism, n, counters[0],
+                                                                 rchanged, numpy.abs(gbounds - rb).max()))
+    assert sym < 1e-3 * n
+    assert mism < 1e-4 * n
+    assert abs(int(counters[0]) - int(rchanged)) < 1e-4 * n
+    assert numpy.abs(gbounds - rb).max() < 1e-3     # a row decided the other way carries another centroid's bound
+    assert (numpy.abs(gbounds - rb) > 4e-6).mean() < 1e-4
+    eng.close()
+
+
+def test_config_d_shape_knn_8m_corpus_shard_vs_brute_force(monkeypatch):
+    """BASELINE config D as one of its eight ranks runs it: k-NN (k = 10) with the whole 8M x 256 fp32 corpus
+    resident (1024-Gaussian mixture, clustered by kmeans_cuda into K = 1024) and the first eighth of the sorted
+    positions as queries (KMCUDA_AMD_KNN_SHARD=0/8), everything through the C ABI with device pointers.  2048
+    of the answered rows are checked against an exhaustive search: candidates from an fp32 matrix product over
+    all 8M rows (top 64), re-ranked with the distances in float64.  The reference's lists are defined by ITS fp32
+    distance arithmetic, so a row may legitimately differ from the float64 ranking where two neighbours are closer
+    than fp32 resolution: such rows must be ties (relative gap < 1e-6), never a wrong neighbour."""
+    from kmcuda_amd import kmeans_cuda, knn_cuda
+    from kmcuda_amd.api import _DEVICE_ALLOCS
+    from test_gpu_kmeans import StdoutListener
+    monkeypatch.setenv("KMCUDA_AMD_KNN_SHARD", "0/8")
+    n, d, K, kk = 8000000, 256, 1024, 10
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    x = torch.empty((n, d), dtype=torch.float32, device=dev)
+    centres = torch.rand((K, d), device=dev, generator=gen) * 10.0
+    for s in range(0, n, 1 << 20):
+        e = min(n, s + (1 << 20))
+        lab = torch.randint(0, K, (e - s,), device=dev, generator=gen)
+        x[s:e].normal_(0.0, 1.0, generator=gen)
+        x[s:e] += centres[lab]
+    torch.cuda.synchronize()
+    cptr, aptr = kmeans_cuda((x.data_ptr(), 0, (n, d)), K, init="random", seed=777, tolerance=0.01, yinyang_t=0,
+                             device=1, verbosity=0)
+    nbuf = torch.full((n, kk), -1, dtype=torch.int32, device=dev)   # rows outside the shard stay 0xFFFFFFFF
+    out = StdoutListener()
+    with out:
+        knn_cuda(kk, (x.data_ptr(), 0, (n, d), nbuf.data_ptr()), (cptr, K), aptr, device=1, verbosity=1)
+    torch.cuda.synchronize()
+    line = [l for l in out.text.split("\n") if l.startswith("calculated")][0]
+    frac = float(line.split()[1])
+    have = torch.nonzero(nbuf[:, 0] != -1).ravel()
+    print("answered %d of %d rows; %s" % (have.numel(), n, line))
+    assert abs(have.numel() - n // 8) < n // 800           # rank 0's share of the sorted positions
+    assert 0.0 < frac < 0.05                               # the cluster pruning works (1 / 8 of ~7 % of N^2)
+    rows = have[torch.randperm(have.numel(), generator=gen, device=dev)[:2048]]
+    q = x[rows]
+    n2 = (x * x).sum(1)
+    ties = wrong = 0
+    for s in range(0, rows.numel(), 256):
+        qs = q[s:s + 256]
+        approx = n2[None, :] - 2.0 * (qs @ x.T)            # + |q|^2: constant per row
+        approx[torch.arange(qs.shape[0], device=dev), rows[s:s + 256]] = float("inf")
+        cand = torch.topk(approx, 64, dim=1, largest=False).indices
+        for i in range(qs.shape[0]):
+            cx = x[cand[i]].double()
+            dist = ((cx - qs[i].double()) ** 2).sum(1)
+            order = torch.argsort(dist)
+            best = cand[i][order[:kk]]
+            got = nbuf[rows[s + i]].to(torch.int64)
+            if set(best.tolist()) != set(got.tolist()):
+                # the k-th and (k+1)-th neighbours may swap inside fp32 resolution; anything else is a miss
+                dk, dk1 = float(dist[order[kk - 1]]), float(dist[order[kk]])
+                gd = ((x[got].double() - qs[i].double()) ** 2).sum(1)
+                if float(gd.max()) <= dk1 * (1 + 1e-6) and (dk1 - dk) <= 1e-6 * dk1:
+                    ties += 1
+                else:
+                    wrong += 1
+            else:
+                # ascending order of the returned list (knn.cu:239-242), up to the same resolution
+                gd = ((x[got].double() - qs[i].double()) ** 2).sum(1)
+                assert bool((gd[1:] >= gd[:-1] * (1 - 1e-6)).all())
+    print("brute force: %d rows, %d differ only by an fp32 tie, %d wrong" % (rows.numel(), ties, wrong))
+    assert wrong == 0
+    del _DEVICE_ALLOCS[cptr], _DEVICE_ALLOCS[aptr]
