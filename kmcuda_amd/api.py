@@ -6,6 +6,7 @@ include/kmcuda.h with ctypes (the reference binds the same two C functions from 
 extension; `import libKMCUDA` at the repo root re-exports this module under the reference's name).
 """
 import ctypes
+import operator
 import time
 
 import numpy
@@ -86,8 +87,10 @@ def kmeans_cuda(samples, clusters, tolerance=.01, init="k-means++", yinyang_t=.1
     lib = _lib.lib()
     if seed is None:
         seed = int(time.time())
-    if not isinstance(clusters, int) or isinstance(clusters, bool):
+    # any object with __index__ (python.cc parses it with the "I" format: numpy.int64(k) works), not bool / float
+    if isinstance(clusters, (bool, float)) or not hasattr(clusters, "__index__"):
         raise TypeError("\"clusters\" must be an integer")
+    clusters = operator.index(clusters)
     init_centroids = None
     if init is None:
         init_id = 1
@@ -105,7 +108,7 @@ def kmeans_cuda(samples, clusters, tolerance=.01, init="k-means++", yinyang_t=.1
         init_centroids = None
     else:
         init_id = 3
-    afkmc2_m = ctypes.c_uint32(int(init[1]) if isinstance(init, tuple) and len(init) > 1 and init_id == 2 else 0)
+    afkmc2_m = ctypes.c_uint32(operator.index(init[1]) if isinstance(init, tuple) and len(init) > 1 and init_id == 2 else 0)
     metric_id = _get_metric(metric)
     if clusters < 2 or clusters >= 0xFFFFFFFF:
         raise ValueError("\"clusters\" must be greater than 1 and less than (1 << 32) - 1")

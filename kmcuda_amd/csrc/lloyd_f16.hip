@@ -238,9 +238,6 @@ __device__ __forceinline__ void lds_frag_wait(f16x8 &f) {
   asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N));
 }
 
-#ifndef KMX_DMA_BOOK
-#define KMX_DMA_BOOK 0
-#endif
 // 4 waves x 64 rows per block, 2 independent blocks per CU (2 x 67 KB of LDS).  (Tried and dropped:
 // one 8-wave block per CU run as a ping-pong -- the waves sharing a SIMD, read from HW_ID, alternate
 // MFMA and bookkeeping phases between workgroup barriers; 65 barriers per block made it 20 % slower.)
@@ -465,9 +462,11 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
       if constexpr (TWO) accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, xb[j], accB, 0, 0, 0);
       // the next super-tile's LDS-DMA pieces, one at a time in the shadow of the MFMAs: issued
       // back to back the four waves' 32 pieces queue up in the texture path and hold up the wave
-      // (all of them during the super-tile's FIRST tile: the second one's 32 MFMAs cover the flight)
+      // (all of them during the super-tile's FIRST tile: the second one's 32 MFMAs cover the flight.  Issued from
+      // the bookkeeping phase instead -- the other block's MFMAs would cover the issue -- the kernel is 2 % slower:
+      // 3.51 against 3.44 ms on the same box, profiles/r3d_*)
       constexpr int SPREAD = KS >= 8 ? KS / 8 : 1;            // a piece every SPREAD k-steps
-      if (!KMX_DMA_BOOK && stage && (j % SPREAD) == SPREAD / 2 && j / SPREAD < 8) {
+      if (stage && (j % SPREAD) == SPREAD / 2 && j / SPREAD < 8) {
         const int slot = j / SPREAD;                           // 0..7
         for (int p = slot * 4 + wave; p < NP; p += 32) stage_piece(sp_next, buf_next, p);
         if (slot == 0 && wave == 0) stage_bias(sp_next, buf_next);
@@ -478,11 +477,6 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     for (int r = 0; r < 16; r += 2) {
       book2(accA[r], accA[r + 1], r, v1a, v2a);
       if constexpr (TWO) book2(accB[r], accB[r + 1], r, v1b, v2b);
-      if (KMX_DMA_BOOK && stage) {   // experiment: the DMA pieces issued from the bookkeeping phase
-        const int slot = r / 2;
-        for (int p = slot * 4 + wave; p < NP; p += 32) stage_piece(sp_next, buf_next, p);
-        if (slot == 0 && wave == 0) stage_bias(sp_next, buf_next);
-      }
     }
     tba = (v1a != v1a_in) ? t : tba;
     tbb = (v1b != v1b_in) ? t : tbb;
@@ -867,27 +861,37 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
   const float cmaxo = sqrtf(__uint_as_float(stats[2])) * 1.000001f;
   const float u = 5.9604645e-8f;
   auto settle = [&](uint32_t s, bool live, uint32_t rl) {
-    // my half of the centred fp32 row, FC <= 128 features at a time (the MFMA operands are dead: their
-    // registers hold it now), against every contender of the row.  One chunk (DP <= 256): the dot
-    // product of a contender lives in registers; more: its partial sums wait in LDS between chunks.
-    constexpr int FC = NKH < 128 ? NKH : 128, NCHUNK = NKH / FC;
-    const uint32_t part_lds = list_lds + 256 * kRefineCap * 4;   // NCHUNK > 1 only: 256 x 2 x kRefineCap floats
+    // my half of the centred fp32 row, 64 features at a time, against every contender of the row; a contender's
+    // partial dot products add up in a register of its own (at most kRefineCap of them).  (128 features at a time
+    // had the row chunk AND a contender's 32 sixteen-byte loads in flight: 256 registers, 650 bytes of scratch
+    // per lane -- a third of a gigabyte of spill traffic per 8M-row pass.)
+    constexpr int FC = NKH < 64 ? NKH : 64, NCHUNK = NKH / FC;
     float xn2 = 0.f, xo2 = 0.f, x0 = 0.f;
     float v1 = -INFINITY, v2 = -INFINITY, v3 = -INFINITY;
     uint32_t i1 = 0xFFFFFFFFu, i2 = 0xFFFFFFFFu;
-    uint32_t n = 0;
-    bool usable = false;
+    float part[kRefineCap];
 #pragma unroll
+    for (int i = 0; i < kRefineCap; i++) part[i] = 0.f;
+    const uint32_t n = *lds_u32(cnt_lds + rl * 4);
+    const bool usable = n >= 1 && n <= (uint32_t)kRefineCap;
+    uint32_t nmax = usable ? n : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off));
+    // (a rolled loop: unrolled, hipcc starts the next chunk's loads before this chunk's contenders are done and
+    // spills what it cannot hold; the mean comes from its copy in LDS)
+#pragma unroll 1
     for (int ch = 0; ch < NCHUNK; ch++) {
       const int f0 = ch * FC;
       float xv[FC];
       const float *xr = samples + (size_t)s * D + h * NKH + f0;
       const float *m = mu + h * NKH + f0;
+      const uint32_t m_lds = mu_lds + (uint32_t)(h * NKH + f0) * 4u;
 #pragma unroll
       for (int f = 0; f < FC; f += 4) {
         float x4[4], m4[4];
         if (FAST) {
-          const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + f), b = *reinterpret_cast<const f32x4 *>(m + f);
+          const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + f);
+          const f32x4 b = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>((uintptr_t)(m_lds + f * 4));
           x4[0] = a.x; x4[1] = a.y; x4[2] = a.z; x4[3] = a.w;
           m4[0] = b.x; m4[1] = b.y; m4[2] = b.z; m4[3] = b.w;
         } else {
@@ -907,37 +911,31 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
         }
         if (f == 0 && ch == 0) x0 = x4[0];
       }
-      // (read here, after the row chunk is in registers: earlier, hipcc spills around the loads)
-      n = *lds_u32(cnt_lds + rl * 4);
-      usable = n >= 1 && n <= (uint32_t)kRefineCap;
-      uint32_t nmax = usable ? n : 0u;
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off));
-      for (uint32_t i = 0; i < nmax; i++) {
-        const bool on = usable && i < n;
-        const uint32_t c = on ? *lds_u32(list_lds + (rl * kRefineCap + i) * 4) : 0u;
-        const float *cr = cfil + (size_t)c * DP + h * NKH + f0;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      for (int i = 0; i < kRefineCap; i++) {
+        if ((uint32_t)i < nmax) {   // wave-uniform
+          const bool on = usable && (uint32_t)i < n;
+          const uint32_t c = on ? *lds_u32(list_lds + (rl * kRefineCap + i) * 4) : 0u;
+          const float *cr = cfil + (size_t)c * DP + h * NKH + f0;
+          float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-        for (int f = 0; f < FC; f += 4) {
-          const f32x4 c4 = *reinterpret_cast<const f32x4 *>(cr + f);
-          a0 = fmaf(xv[f + 0], c4.x, a0);
-          a1 = fmaf(xv[f + 1], c4.y, a1);
-          a2 = fmaf(xv[f + 2], c4.z, a2);
-          a3 = fmaf(xv[f + 3], c4.w, a3);
-        }
-        float part = (a0 + a1) + (a2 + a3);
-        if constexpr (NCHUNK > 1) {
-          __attribute__((address_space(3))) float *slot =
-              reinterpret_cast<__attribute__((address_space(3))) float *>((uintptr_t)(part_lds + ((rl * 2 + h) * kRefineCap + i) * 4));
-          if (ch > 0) part += *slot;
-          if (ch + 1 < NCHUNK) {
-            *slot = part;   // my own slot: no other lane touches it
-            continue;
+          for (int f = 0; f < FC; f += 4) {
+            const f32x4 c4 = *reinterpret_cast<const f32x4 *>(cr + f);
+            a0 = fmaf(xv[f + 0], c4.x, a0);
+            a1 = fmaf(xv[f + 1], c4.y, a1);
+            a2 = fmaf(xv[f + 2], c4.z, a2);
+            a3 = fmaf(xv[f + 3], c4.w, a3);
           }
+          part[i] += (a0 + a1) + (a2 + a3);
         }
-        part += __shfl_xor(part, 32);
-        const float v = part + bias[c];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kRefineCap; i++) {
+      if ((uint32_t)i < nmax) {
+        const bool on = usable && (uint32_t)i < n;
+        const uint32_t c = on ? *lds_u32(list_lds + (rl * kRefineCap + i) * 4) : 0u;
+        const float v = (part[i] + __shfl_xor(part[i], 32)) + bias[c];
         if (on) {
           const bool g1 = v > v1, g2 = v > v2, g3 = v > v3;
           v3 = g2 ? v2 : (g3 ? v : v3);
@@ -994,8 +992,7 @@ template <int DP, int NSET>
 static hipError_t launch_refine_dp_n(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
                                      const uint32_t *row_list, const float *thr_list, const uint32_t *n_list,
                                      uint32_t rows_hint, hipStream_t st) {
-  const size_t lds_bytes = 2 * 64 * (size_t)(DP * 2) + 512 + 64 + (size_t)DP * 4 + 1024 + 256 * kRefineCap * 4 +
-                           (DP > 256 ? 256 * 2 * kRefineCap * 4 : 0);   // partial dot products between feature chunks
+  const size_t lds_bytes = 2 * 64 * (size_t)(DP * 2) + 512 + 64 + (size_t)DP * 4 + 1024 + 256 * kRefineCap * 4;
   const uint32_t rows_per_block = 128u * NSET;
   // blocks beyond the device-side list length leave at once, but dispatching 31k of them for a list
   // 2k long is not free: the grid follows the caller's estimate of the list (the kernel strides)

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <string.h>
 #include <time.h>
 
@@ -41,6 +42,8 @@ struct Api {
   Py_ssize_t (*TupleSize)(PyObject *);
   PyObject *(*TupleGetItem)(PyObject *, Py_ssize_t);
   int (*IsTrue)(PyObject *);
+  PyObject *(*NumberIndex)(PyObject *);
+  const char *(*GetVersion)();
   PyThreadState *(*SaveThread)();
   void (*RestoreThread)(PyThreadState *);
   PyObject *None, *True_, *False_;
@@ -70,7 +73,8 @@ bool bind_python() {
             sym(P.LongAsUnsignedLongLong, "PyLong_AsUnsignedLongLong") && sym(P.LongAsLong, "PyLong_AsLong") &&
             sym(P.TupleSize, "PyTuple_Size") && sym(P.TupleGetItem, "PyTuple_GetItem") &&
             sym(P.IsTrue, "PyObject_IsTrue") && sym(P.SaveThread, "PyEval_SaveThread") &&
-            sym(P.RestoreThread, "PyEval_RestoreThread");
+            sym(P.RestoreThread, "PyEval_RestoreThread") && sym(P.NumberIndex, "PyNumber_Index") &&
+            sym(P.GetVersion, "Py_GetVersion");
   P.None = reinterpret_cast<PyObject *>(dlsym(RTLD_DEFAULT, "_Py_NoneStruct"));
   P.True_ = reinterpret_cast<PyObject *>(dlsym(RTLD_DEFAULT, "_Py_TrueStruct"));
   P.False_ = reinterpret_cast<PyObject *>(dlsym(RTLD_DEFAULT, "_Py_FalseStruct"));
@@ -107,6 +111,15 @@ struct Buf {
 bool is_tuple(PyObject *o) { return o && PyTuple_Check(o); }
 bool is_str(PyObject *o) { return o && PyUnicode_Check(o); }
 bool is_int(PyObject *o) { return o && PyLong_Check(o) && o != P.True_ && o != P.False_; }
+// any object with __index__ (python.cc parses these with the "I" format: numpy.int64(k) is as good as k), but
+// neither a bool nor a float.  false: no such integer -- a Python error may be pending (cleared by the caller)
+bool as_index(PyObject *o, unsigned long long *out) {
+  if (!o || o == P.True_ || o == P.False_) return false;   // (a float has no __index__: PyNumber_Index refuses it)
+  Ref idx(P.NumberIndex(o));
+  if (!idx.o) return false;
+  *out = P.LongAsUnsignedLongLong(idx.o);
+  return !P.ErrOccurred();
+}
 
 PyObject *fail(PyObject *type, const char *msg) {
   P.ErrSetString(type, msg);
@@ -203,13 +216,16 @@ PyObject *py_kmeans_cuda(PyObject *, PyObject *args, PyObject *kwargs) {
   if (!P.ParseTupleAndKeywords(args, kwargs, "OO|fOfOpIIi", const_cast<char **>(kwlist), &samples_obj, &clusters_obj,
                                &tolerance, &init_obj, &yinyang_t, &metric_obj, &adflag, &seed, &device, &verbosity))
     return nullptr;
-  if (!is_int(clusters_obj)) return fail(P.TypeError, "\"clusters\" must be an integer");
   {
-    const unsigned long long c = P.LongAsUnsignedLongLong(clusters_obj);
-    if (P.ErrOccurred() || c < 2 || c >= 0xFFFFFFFFull) {
+    unsigned long long c = 0;
+    if (!as_index(clusters_obj, &c)) {
+      const bool negative_or_huge = P.ErrOccurred() && is_int(clusters_obj);   // an int, but not a uint64
       P.ErrClear();
-      return fail(P.ValueError, "\"clusters\" must be greater than 1 and less than (1 << 32) - 1");
+      if (!negative_or_huge) return fail(P.TypeError, "\"clusters\" must be an integer");
+      c = 0;
     }
+    if (c < 2 || c >= 0xFFFFFFFFull)
+      return fail(P.ValueError, "\"clusters\" must be greater than 1 and less than (1 << 32) - 1");
     clusters = (uint32_t)c;
   }
   // init: string | (string, m) | array (kmcuda.h:168-174, python.cc:196-217)
@@ -237,8 +253,12 @@ PyObject *py_kmeans_cuda(PyObject *, PyObject *args, PyObject *kwargs) {
       return fail(P.ValueError, "centroid initialization method may not be null.");
     if (!init_from_string(P.TupleGetItem(init_obj, 0))) return nullptr;
     if (init == kmcudaInitMethodAFKMC2 && P.TupleSize(init_obj) > 1) {
-      afkmc2_m = (uint32_t)P.LongAsUnsignedLongLong(P.TupleGetItem(init_obj, 1));
-      if (P.ErrOccurred()) return nullptr;
+      unsigned long long m = 0;
+      if (!as_index(P.TupleGetItem(init_obj, 1), &m) || m > 0xFFFFFFFFull) {
+        P.ErrClear();
+        return fail(P.ValueError, "afkmc2's m must be a non-negative integer below (1 << 32)");
+      }
+      afkmc2_m = (uint32_t)m;
     }
   } else {
     init = kmcudaInitMethodImport;
@@ -456,6 +476,18 @@ PyModuleDef moduledef = {PyModuleDef_HEAD_INIT, "libKMCUDA", module_doc, -1, mod
 
 extern "C" __attribute__((visibility("default"))) PyObject *PyInit_libKMCUDA(void) {
   if (!bind_python()) return nullptr;   // not inside a CPython process
+  {
+    // Python.h's inlined type checks and struct layouts are those of the interpreter this file was compiled
+    // against (non-limited API): refuse any other minor version instead of misreading its objects
+    const char *v = P.GetVersion();
+    char want[16];
+    snprintf(want, sizeof(want), "%d.%d.", PY_MAJOR_VERSION, PY_MINOR_VERSION);
+    if (!v || strncmp(v, want, strlen(want)) != 0) {
+      P.ErrSetString(exc("PyExc_ImportError") ? exc("PyExc_ImportError") : P.RuntimeError,
+                     "libKMCUDA was built for CPython " PY_VERSION ": rebuild it (make -C kmcuda_amd/csrc) for this interpreter");
+      return nullptr;
+    }
+  }
   PyObject *m = P.ModuleCreate2(&moduledef, PYTHON_API_VERSION);
   if (!m) return nullptr;
   P.numpy = P.ImportModule("numpy");

@@ -20,6 +20,14 @@ def _declared_symbols():
     return names
 
 
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
 def test_library_builds_and_exports_declared_symbols():
     import __graft_entry__
     __graft_entry__.build()
@@ -100,6 +108,20 @@ def test_native_cpython_module_in_the_library():
         libKMCUDA.kmeans_cuda(x, 50, init="bullshit")
     with pytest.raises(ValueError):
         libKMCUDA.kmeans_cuda(x, 1)
+    # "clusters" is parsed like python.cc's "I" format: any object with __index__ (numpy integers), never a
+    # bool or a float; the mirror module follows the same rule
+    import kmcuda_amd
+    for mod in (libKMCUDA, kmcuda_amd):
+        for bad in (True, 5.0, "5"):
+            with pytest.raises(TypeError):
+                mod.kmeans_cuda(x, bad)
+        for bad in (-3, numpy.int64(1)):
+            with pytest.raises(ValueError, match="clusters"):
+                mod.kmeans_cuda(x, bad)
+        if not _have_gpu():
+            for good in (numpy.int64(5), numpy.uint32(5), numpy.uint8(5)):
+                with pytest.raises(ValueError, match="device"):     # got past the parsing: no GPU here
+                    mod.kmeans_cuda(x, good)
     with pytest.raises(TypeError):
         libKMCUDA.kmeans_cuda(x.astype(numpy.float64), 5)
     with pytest.raises(ValueError):
