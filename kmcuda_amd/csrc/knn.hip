@@ -30,6 +30,7 @@
 // in-library cross-check, and the path for feature counts the filter is not instantiated for.
 #include "exact.hpp"
 #include "kernels.hpp"
+#include "knn_heap.hpp"
 
 namespace kmx {
 
@@ -153,38 +154,6 @@ __global__ void knn_cdist_kernel(const float *__restrict__ centroids, uint32_t K
     acc += partial_vv<METRIC>(a + fpos, b + fpos, fsize);
   }
   C[(size_t)i * K + j] = finalize<METRIC>(acc);
-}
-
-// ---------------------------------------------------------------------------------------
-// push_sample (knn.cu:133-175): replace-root + sift-down on a max-heap of interleaved
-// (distance, index) pairs.
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void push_sample(uint32_t k, float dist, uint32_t index, float *heap) {
-  uint32_t pos = 0;
-  uint32_t *heapi = reinterpret_cast<uint32_t *>(heap);
-  while (true) {
-    float left = 0.f, right = 0.f;
-    bool left_le, right_le;
-    if ((2 * pos + 1) < k) { left = heap[4 * pos + 2]; left_le = dist >= left; } else left_le = true;
-    if ((2 * pos + 2) < k) { right = heap[4 * pos + 4]; right_le = dist >= right; } else right_le = true;
-    if (left_le && right_le) {
-      heap[2 * pos] = dist;
-      heapi[2 * pos + 1] = index;
-      break;
-    }
-    bool go_right;
-    if (!left_le && !right_le) go_right = left <= right;
-    else go_right = left_le;
-    if (go_right) {
-      heap[2 * pos] = right;
-      heapi[2 * pos + 1] = heapi[4 * pos + 5];
-      pos = 2 * pos + 2;
-    } else {
-      heap[2 * pos] = left;
-      heapi[2 * pos + 1] = heapi[4 * pos + 3];
-      pos = 2 * pos + 1;
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -391,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void knn_filter_kernel(KnnArgs a) {
             }
             const float dist = finalize<METRIC>(__shfl(dacc, col + 32));
             if (h == 0 && active && dist <= mndist) {  // knn.cu:209-212
-              push_sample(k, dist, a.inv[cp], heap);
+              knn_push_sample(k, dist, a.inv[cp], heap);
               mndist = heap[0];
             }
             mndist = __shfl(mndist, col);
@@ -407,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void knn_filter_kernel(KnnArgs a) {
     uint32_t *out = a.out + (size_t)(qp - a.p_base) * k;
     for (int i = (int)k - 1; i >= 0; i--) {
       out[i] = reinterpret_cast<uint32_t *>(heap)[1];
-      push_sample(k, -1.f, 0xFFFFFFFFu, heap);
+      knn_push_sample(k, -1.f, 0xFFFFFFFFu, heap);
     }
   }
   if (lane == 0 && calced) atomicAdd(a.calced, calced);
@@ -450,14 +419,14 @@ __global__ __launch_bounds__(64) void knn_exact_kernel(KnnArgs a) {
       if (cp == qp) continue;
       const float dist = finalize<METRIC>(partial_vv<METRIC>(x, a.xs + (size_t)cp * DP, D));
       if (dist <= mndist) {
-        push_sample(k, dist, a.inv[cp], heap);
+        knn_push_sample(k, dist, a.inv[cp], heap);
         mndist = heap[0];
       }
     }
   }
   for (int i = (int)k - 1; i >= 0; i--) {
     out[i] = reinterpret_cast<uint32_t *>(heap)[1];
-    push_sample(k, -1.f, 0xFFFFFFFFu, heap);
+    knn_push_sample(k, -1.f, 0xFFFFFFFFu, heap);
   }
   atomicAdd(a.calced, calced);
 }
