@@ -84,35 +84,6 @@ __global__ __launch_bounds__(256) void knn_split_kernel(const float *__restrict_
   (void)METRIC;
 }
 
-// The heap in LDS (k <= kKnnLdsHeapMaxK): the reference keeps it in shared memory for the same reason (knn.cu:177-243)
-// -- a push is a chain of dependent reads, three to four round trips to L2 each when the heap lives in global
-// memory, with three other waves waiting at the next barrier.  LDS holds, per query, the k DISTANCES and a one-byte
-// SLOT per heap position; the neighbour's index sits in global memory at cand[slot] and never moves: a push writes
-// the new index into the evicted root's slot (one store, no load) and sifts (distance, slot) down in LDS.  The
-// compares, the moves and therefore the heap's evolution are knn_push_sample's (knn_heap.hpp), position for position.
-constexpr uint32_t kKnnLdsHeapMaxK = 12;   // 256 queries x (4 + 1) bytes x k of LDS beside two 32-KB tiles, two blocks per CU
-__device__ __forceinline__ void knn_push_lds(uint32_t k, float dist, uint32_t slot, float *hd, unsigned char *hs) {
-  uint32_t pos = 0;
-  while (true) {
-    float left = 0.f, right = 0.f;
-    bool left_le, right_le;
-    if ((2 * pos + 1) < k) { left = hd[2 * pos + 1]; left_le = dist >= left; } else left_le = true;
-    if ((2 * pos + 2) < k) { right = hd[2 * pos + 2]; right_le = dist >= right; } else right_le = true;
-    if (left_le && right_le) {
-      hd[pos] = dist;
-      hs[pos] = (unsigned char)slot;
-      break;
-    }
-    bool go_right;
-    if (!left_le && !right_le) go_right = left <= right;
-    else go_right = left_le;
-    const uint32_t child = go_right ? 2 * pos + 2 : 2 * pos + 1;
-    hd[pos] = go_right ? right : left;
-    hs[pos] = hs[child];
-    pos = child;
-  }
-}
-
 // hi.hi products only, ONE MFMA per 16 features: the operand rounding widens the acceptance band by
 // ~0.1 % of a typical squared distance, i.e. lets through about one more candidate per query for the
 // exact chain.  (Round 1 kept a three-product hi/lo variant as a second cross-check; the f32 matrix-core
@@ -132,7 +103,7 @@ __device__ __forceinline__ void knn_push_lds(uint32_t k, float dist, uint32_t sl
 //     holds are not in step, so one's mask phases and barriers run under the other's products.
 // Instrumented builds of the one-set kernel (per-phase s_memtime counters, per-wave timeline of one block):
 // profiles/r2e_knn_filter_phase_counters.log, r2e_knn_filter_block_timeline.log.
-template <int DP, int METRIC, bool FASTX, bool LHEAP>
+template <int DP, int METRIC, bool FASTX>
 __global__ __launch_bounds__(KNN16_WAVES * 64, KNN16_BLOCKS_PER_CU) void knn_filter_f16_kernel(KnnArgs a) {
   constexpr int WV = KNN16_WAVES, NSET = KNN16_NSET;
   constexpr int NKH = DP / 2;   // features per half-wave
@@ -150,9 +121,6 @@ __global__ __launch_bounds__(KNN16_WAVES * 64, KNN16_BLOCKS_PER_CU) void knn_fil
   constexpr uint32_t TILES = (uint32_t)(NBUF * TILEB);
   const uint32_t bias0 = lds0 + TILES;                       // NBUF x 64 floats
   uint32_t *flags = reinterpret_cast<uint32_t *>(lds2 + TILES + NBUF * 256);  // 2 x WV words
-  // LHEAP: the block's KNN_QPB_F16 heaps -- distances, then slots (see knn_push_lds)
-  float *heap_d = reinterpret_cast<float *>(lds2 + TILES + NBUF * 256 + 64);
-  unsigned char *heap_s = reinterpret_cast<unsigned char *>(heap_d + (size_t)KNN_QPB_F16 * a.k);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 31, h = lane >> 5;
   const uint32_t K = a.K, k = a.k, D = a.D;
@@ -194,18 +162,9 @@ __global__ __launch_bounds__(KNN16_WAVES * 64, KNN16_BLOCKS_PER_CU) void knn_fil
     md[e] = live[e] ? a.mydist[qp[e]] : 0.f;
     float *heap = a.heaps + (size_t)(qq - a.p_base) * 2 * k;
     if (live[e] && h == 0) {
-      if (LHEAP) {
-        const uint32_t ql = (uint32_t)wave * (32u * NSET) + 32u * e + col;   // my query's slot in the block
-        for (uint32_t i = 0; i < k; i++) {
-          heap_d[ql * k + i] = kFltMaxK;
-          heap_s[ql * k + i] = (unsigned char)i;
-          reinterpret_cast<uint32_t *>(heap)[i] = 0;   // cand[slot]
-        }
-      } else {
-        for (uint32_t i = 0; i < k; i++) {
-          heap[2 * i] = kFltMaxK;
-          reinterpret_cast<uint32_t *>(heap)[2 * i + 1] = 0;
-        }
+      for (uint32_t i = 0; i < k; i++) {
+        heap[2 * i] = kFltMaxK;
+        reinterpret_cast<uint32_t *>(heap)[2 * i + 1] = 0;
       }
     }
     mndist[e] = kFltMaxK;
@@ -281,6 +240,10 @@ __global__ __launch_bounds__(KNN16_WAVES * 64, KNN16_BLOCKS_PER_CU) void knn_fil
 #pragma unroll
     for (int i = 0; i < 4; i++) qc[e][i] = 0;
   }
+  // (The heaps stay in global memory, in the reference's interleaved layout.  Round 3 moved them into LDS for
+  // k <= 12 -- distances plus one-byte slots, the indices parked in global memory, so a push was LDS-only but
+  // for one store -- with identical lists and NO gain: 2.72 s against 2.59 s for the config D share
+  // (profiles/r3f_*).  The pushes were not what the other waves wait for at the barrier.)
   auto flush = [&](int e) {  // wave-uniform call
     const uint32_t qq = live[e] ? qp[e] : p0;
     const float *xrow = a.xs + (size_t)qq * DP;   // original values (exact chains)
@@ -292,21 +255,11 @@ __global__ __launch_bounds__(KNN16_WAVES * 64, KNN16_BLOCKS_PER_CU) void knn_fil
     const int nq = __ballot(qn_[e] >= 4) ? 4 : (__ballot(qn_[e] >= 3) ? 3 : (__ballot(qn_[e] >= 2) ? 2 : 1));
     exact_distance4<NKH, METRIC, FASTX>(xrow, crow, D, h, col, dist, nq, qn_[e]);
     float mnd = mndist[e];
-    const uint32_t ql = (uint32_t)wave * (32u * NSET) + 32u * e + col;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       if (h == 0 && i < qn_[e] && dist[i] <= mnd) {  // knn.cu:209-212
-        if (LHEAP) {
-          float *hd = heap_d + ql * k;
-          unsigned char *hs = heap_s + ql * k;
-          const uint32_t slot = hs[0];                                   // the evicted root's slot takes the newcomer
-          reinterpret_cast<uint32_t *>(heap)[slot] = a.inv[qc[e][i]];
-          knn_push_lds(k, dist[i], slot, hd, hs);
-          mnd = hd[0];
-        } else {
-          knn_push_sample(k, dist[i], a.inv[qc[e][i]], heap);
-          mnd = heap[0];
-        }
+        knn_push_sample(k, dist[i], a.inv[qc[e][i]], heap);
+        mnd = heap[0];
       }
     }
     mndist[e] = __shfl(mnd, col);
@@ -485,20 +438,9 @@ __global__ __launch_bounds__(KNN16_WAVES * 64, KNN16_BLOCKS_PER_CU) void knn_fil
     if (live[e] && h == 0) {  // knn.cu:239-242
       float *heap = a.heaps + (size_t)(qp[e] - a.p_base) * 2 * k;
       uint32_t *out = a.out + (size_t)(qp[e] - a.p_base) * k;
-      if (LHEAP) {
-        const uint32_t ql = (uint32_t)wave * (32u * NSET) + 32u * e + col;
-        float *hd = heap_d + ql * k;
-        unsigned char *hs = heap_s + ql * k;
-        for (int i = (int)k - 1; i >= 0; i--) {
-          const uint32_t slot = hs[0];
-          out[i] = reinterpret_cast<const uint32_t *>(heap)[slot];
-          knn_push_lds(k, -1.f, slot, hd, hs);   // (the popped slot sinks to a leaf: k pops never meet it again)
-        }
-      } else {
-        for (int i = (int)k - 1; i >= 0; i--) {
-          out[i] = reinterpret_cast<uint32_t *>(heap)[1];
-          knn_push_sample(k, -1.f, 0xFFFFFFFFu, heap);
-        }
+      for (int i = (int)k - 1; i >= 0; i--) {
+        out[i] = reinterpret_cast<uint32_t *>(heap)[1];
+        knn_push_sample(k, -1.f, 0xFFFFFFFFu, heap);
       }
     }
   }
@@ -523,33 +465,22 @@ hipError_t launch_knn_split(int metric, const float *xs, uint32_t N, uint32_t D,
   return hipGetLastError();
 }
 
-template <int DP, int METRIC, bool LHEAP>
-static hipError_t launch_knn_f16_h(const KnnArgs &a, uint32_t nblocks, hipStream_t st) {
-  size_t lds_bytes = (size_t)KNN16_NBUF * (32 * KNN16_SUB * DP * 2) + KNN16_NBUF * 256 + 64;
-  if (LHEAP) lds_bytes += (size_t)KNN_QPB_F16 * a.k * 5;
+template <int DP, int METRIC>
+static hipError_t launch_knn_f16_t(const KnnArgs &a, uint32_t nblocks, hipStream_t st) {
+  const size_t lds_bytes = (size_t)KNN16_NBUF * (32 * KNN16_SUB * DP * 2) + KNN16_NBUF * 256 + 2 * KNN16_WAVES * 4;
   if (lds_bytes > 65536) {   // (per launch: the attribute belongs to the current device's copy of the kernel)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_filter_f16_kernel<DP, METRIC, true, LHEAP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_filter_f16_kernel<DP, METRIC, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_filter_f16_kernel<DP, METRIC, false, LHEAP>),
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_filter_f16_kernel<DP, METRIC, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
   }
   if (a.D == (uint32_t)DP)
-    hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, true, LHEAP>), dim3(nblocks), dim3(KNN16_WAVES * 64), lds_bytes, st, a);
+    hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, true>), dim3(nblocks), dim3(KNN16_WAVES * 64), lds_bytes, st, a);
   else
-    hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, false, LHEAP>), dim3(nblocks), dim3(KNN16_WAVES * 64), lds_bytes, st, a);
+    hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, false>), dim3(nblocks), dim3(KNN16_WAVES * 64), lds_bytes, st, a);
   return hipGetLastError();
-}
-
-template <int DP, int METRIC>
-static hipError_t launch_knn_f16_t(const KnnArgs &a, uint32_t nblocks, hipStream_t st) {
-  // heaps in LDS while they fit beside the tiles of two blocks per CU (KMCUDA_AMD_KNN_LDS_HEAP=0: global memory,
-  // the cross-check)
-  const char *v = getenv("KMCUDA_AMD_KNN_LDS_HEAP");
-  const bool allow = !(v && atoi(v) == 0);
-  if (allow && a.k <= kKnnLdsHeapMaxK) return launch_knn_f16_h<DP, METRIC, true>(a, nblocks, st);
-  return launch_knn_f16_h<DP, METRIC, false>(a, nblocks, st);
 }
 
 hipError_t launch_knn_filter_f16(int metric, const KnnArgs &a, uint32_t nblocks, hipStream_t st) {

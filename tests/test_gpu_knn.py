@@ -99,14 +99,10 @@ def test_device_ptr(clustered13k):
 
 @pytest.mark.parametrize("n,d,K,k", [(8000, 48, 160, 10), (6000, 256, 64, 10), (5000, 7, 40, 3), (3000, 100, 20, 33),
                                      (2000, 300, 16, 5)])
-@pytest.mark.parametrize("filt", ["f16", "f16-global-heap", "f32"])
+@pytest.mark.parametrize("filt", ["f16", "f32"])
 def test_matches_oracle_bit_exact(n, d, K, k, filt, monkeypatch):
-    """f16: the default filter, heaps in LDS for k <= 12 (distances + one-byte slots, indices parked in global
-    memory); f16-global-heap: the same filter with the reference-layout heaps in global memory; f32: the f32
-    matrix-core filter.  k = 33 exceeds the LDS heap and takes the global one either way."""
     from kmcuda_amd import knn_cuda
-    monkeypatch.setenv("KMCUDA_AMD_FILTER", "f32" if filt == "f32" else "f16")
-    monkeypatch.setenv("KMCUDA_AMD_KNN_LDS_HEAP", "0" if filt == "f16-global-heap" else "1")
+    monkeypatch.setenv("KMCUDA_AMD_FILTER", filt)
     rs = numpy.random.RandomState(n + d)
     x = rs.rand(n, d).astype(numpy.float32)
     q = n // 4
@@ -129,7 +125,7 @@ def test_duplicates_and_ties():
     x = numpy.concatenate([base, base, base[:300]]).astype(numpy.float32)
     c, a, _ = oracle.kmeans(x, 12, seed=777, yinyang_t=0, tolerance=0.02)
     ref, _ = oracle.knn(8, x, c, a)
-    for k in (8, 12):          # (12: the largest heap that lives in LDS)
+    for k in (8, 12):
         nb = knn_cuda(k, x, c, a, device=1)
         refk = ref if k == 8 else oracle.knn(k, x, c, a)[0]
         assert (nb == refk).all()

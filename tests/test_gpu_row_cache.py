@@ -92,6 +92,36 @@ def test_cached_nan_rows_and_nonfinite_centroids():
         ref_asg = ref
 
 
+@pytest.mark.parametrize("cached", [False, True])
+def test_centroid_norms_at_the_edge_of_float_range(cached):
+    """Centroids whose squared norm sits at the float range's end: the reference's serial Kahan sum_squares
+    (csqr, what its distance uses) and the steady-state preparation's parallel sum of the same squares may land
+    on different sides of FLT_MAX -- one says inf, the other finite.  Nothing may be DECIDED from that flag: such
+    panels are far outside the half range, so every row goes to the exact kernels, which use csqr.  Passes 2 and
+    3 run the one-kernel steady-state preparation when the row cache is on."""
+    rs = numpy.random.RandomState(4)
+    n, d, k = 3000, 256, 48
+    x = rs.rand(n, d).astype(numpy.float32)
+    c0 = x[rs.choice(n, k, replace=False)].copy()
+
+    def edge(c, scale):
+        c = c.copy()
+        c[5] = (rs.rand(d).astype(numpy.float32) + 0.5) * numpy.float32(scale)   # ||c||^2 ~ FLT_MAX
+        c[17] = -c[5]
+        return c
+    # 256 squares of ~(1.15e18)^2: sums between 0.9 and 1.1 of FLT_MAX depending on the draw and the order
+    cs = [c0, edge(c0, 1.12e18), edge(c0 * 0.99, 1.16e18), edge(c0, 1.14e18)]
+    got = _run_passes(x, cs, cached=cached)
+    ref_asg = None
+    for (asg, prev, changed), c in zip(got, cs):
+        with numpy.errstate(over="ignore", invalid="ignore"):
+            ref, ref_prev, ref_changed = oracle.lloyd_assign(x, c, assignments=ref_asg)
+        assert (asg == ref).all()
+        assert (prev == ref_prev).all()
+        assert changed == ref_changed
+        ref_asg = ref
+
+
 def test_kmeans_cuda_iterations_unchanged_by_cache(monkeypatch):
     """whole kmeans_cuda() runs: cached (default inside the call) vs KMCUDA_AMD_ROW_CACHE=0."""
     from kmcuda_amd import kmeans_cuda
