@@ -7,7 +7,8 @@ cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out
 TAG=${1:-r1}
 mkdir -p $OUT
-CMD=${PMC_CMD:-"python bench.py --steps 3 --warmup 1 --no-cpu-baseline"}
+CMD=${PMC_CMD:-"python bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-verify"}
+export PMC_LAST=${PMC_LAST:-10}   # per kernel: the last PMC_LAST launches = the timed iterations 6-15
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
            "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
@@ -17,12 +18,14 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GR
   echo "pmc pass $i ($grp) rc=$?"
 done
 python3 - "$OUT/pmc_${TAG}_summary.json" <<'PY'
-import csv, sys, glob, json, collections
+import csv, sys, glob, json, collections, os
+LAST = int(os.environ.get("PMC_LAST", "10"))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 names = {}
 for f in glob.glob("/tmp/pmc_*/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    for r in rows:
         n = r["Kernel_Name"]
         if "kmx::" not in n:
             continue
@@ -31,14 +34,15 @@ for f in glob.glob("/tmp/pmc_*/**/*counter_collection.csv", recursive=True):
         if r["Counter_Name"] in ("GRBM_GUI_ACTIVE",):
             dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 out = {"source": "scripts/gpu_pmc_all.sh: rocprofv3 --pmc <group> --kernel-trace, one run per group, "
-                 "python bench.py --steps 3 --warmup 1 --no-cpu-baseline; per-launch means",
+                 "python bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-verify; per-launch means over each kernel's LAST 10 launches (the timed iterations)",
        "units": "FETCH_SIZE/WRITE_SIZE in KB as reported; fetch_bytes_corrected = 2 x FETCH_SIZE x 1024 (gfx950: "
                 "wide streaming reads are tallied at half, MI355X_MICROARCH.md HBM); SQ_* summed over SIMDs "
                 "(quad-cycles for *_CYCLES waits per the guide); GRBM_GUI_ACTIVE summed over 8 XCDs",
        "rows_per_launch": 8000000, "kernels": {}}
 for k, v in sorted(agg.items()):
-    e = {c: sum(x) / len(x) for c, x in v.items()}
+    e = {c: sum(x[-LAST:]) / len(x[-LAST:]) for c, x in v.items()}
     e["launches"] = max(len(x) for x in v.values())
+    e["launches_averaged"] = min(LAST, e["launches"])
     if "FETCH_SIZE" in e:
         e["fetch_bytes_corrected"] = 2.0 * e["FETCH_SIZE"] * 1024.0
     if "WRITE_SIZE" in e:
@@ -46,7 +50,7 @@ for k, v in sorted(agg.items()):
     if "fetch_bytes_corrected" in e and "write_bytes" in e:
         e["traffic_bytes_per_launch"] = e["fetch_bytes_corrected"] + e["write_bytes"]
     if dur[k] and "GRBM_GUI_ACTIVE" in e:
-        d = sum(dur[k]) / len(dur[k])
+        d = sum(dur[k][-LAST:]) / len(dur[k][-LAST:])
         e["launch_ms_under_pmc"] = d / 1e6
         e["effective_clock_GHz"] = e["GRBM_GUI_ACTIVE"] / 8.0 / d
         if "SQ_VALU_MFMA_BUSY_CYCLES" in e:
