@@ -660,9 +660,6 @@ hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_r
 //      cut-off, operands near the half range) goes to the full exact scan.
 // ---------------------------------------------------------------------------------------
 constexpr int kRefineCap = 8;   // contenders kept per row
-#ifndef KMX_SETTLE_PAIRS
-#define KMX_SETTLE_PAIRS 1
-#endif
 template <int DP, bool HALF_ROWS, bool FAST, int NSET>
 __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
     const void *__restrict__ rows, const float *__restrict__ samples, uint32_t N, uint32_t D,
@@ -985,152 +982,12 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
       if (flag_now) flagged[base + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = s;
     }
   };
-#if !KMX_SETTLE_PAIRS
+  // (Round 3 also scored (row, contender) PAIRS with 8 lanes each -- rows staged coalesced through the idle tile
+  // buffers 16 at a time, 128 contiguous bytes of a contender's row per load instruction instead of 64 cache
+  // lines.  Same decisions, stage 2 0.70 ms against 0.61 on the same box (profiles/r3g_*): the phase is a chain of
+  // dependent round trips, not address-path throughput, and the batching added more of them.  Removed.)
   settle(sA, liveA, rlA);
   if constexpr (TWO) settle(sB, liveB, rlB);
-#else
-  // (row, contender) pairs, 8 lanes each.  A lane scoring its own row's contenders makes every 16-byte load of
-  // a wave touch 64 different cache lines (the contenders' centred fp32 rows, `cfil`): the address path, not the
-  // arithmetic, was this phase's time.  Here the wave takes its rows 16 at a time: the rows come in coalesced
-  // (one 1-KB row per load instruction), are centred into LDS (the tile buffers are free after the sweep: 16 x DP
-  // floats per wave), and every contender row is read by 8 lanes, 128 contiguous bytes per instruction.
-  {
-    constexpr int RB = 16;                               // rows per batch
-    constexpr int NBATCH = (32 * NSET) / RB;
-    __attribute__((address_space(3))) float *xs =
-        reinterpret_cast<__attribute__((address_space(3))) float *>((uintptr_t)lds0) + (size_t)wave * (RB * DP);
-    const uint32_t ptab = list_lds + 256 * kRefineCap * 4 + (uint32_t)wave * (RB * kRefineCap * 12);   // centroid | row | score
-    auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
-#pragma unroll 1
-    for (int b = 0; b < NBATCH; b++) {
-      // ---- my row of the batch (lanes 0..15 own one each) ----
-      const int q = b * RB + (lane & 15);                // row slot inside the wave: set A = slots 0..31, set B = 32..63
-      const uint32_t s_q = (TWO && q >= 32) ? (uint32_t)__shfl((int)sB, q - 32) : (uint32_t)__shfl((int)sA, q & 31);
-      const bool live_q = (TWO && q >= 32) ? (bool)__shfl((int)liveB, q - 32) : (bool)__shfl((int)liveA, q & 31);
-      const uint32_t rl_q = (uint32_t)wave * (32u * NSET) + (uint32_t)q;
-      float my_xn2 = 0.f, my_xo2 = 0.f, my_x0 = 0.f;
-      // ---- 1. the batch's rows, coalesced, centred into LDS ----
-#pragma unroll 4
-      for (int r = 0; r < RB; r++) {
-        const uint32_t s_r = (uint32_t)__shfl((int)s_q, r);
-        const float *xr = samples + (size_t)s_r * D;
-        float p2 = 0.f, o2 = 0.f, first = 0.f;
-        for (int f = 4 * lane; f < DP; f += 256) {
-          float x4[4];
-          if (FAST) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + f);
-            x4[0] = a.x; x4[1] = a.y; x4[2] = a.z; x4[3] = a.w;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; e++) x4[e] = (uint32_t)(f + e) < D ? xr[f + e] : 0.f;
-          }
-          const f32x4 m4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>((uintptr_t)(mu_lds + f * 4));
-          f32x4 c4;
-          c4.x = x4[0] - m4.x; c4.y = x4[1] - m4.y; c4.z = x4[2] - m4.z; c4.w = x4[3] - m4.w;
-          *reinterpret_cast<__attribute__((address_space(3))) f32x4 *>(xs + r * DP + f) = c4;
-          p2 = fmaf(c4.x, c4.x, fmaf(c4.y, c4.y, fmaf(c4.z, c4.z, fmaf(c4.w, c4.w, p2))));
-          o2 = fmaf(x4[0], x4[0], fmaf(x4[1], x4[1], fmaf(x4[2], x4[2], fmaf(x4[3], x4[3], o2))));
-          if (f == 0) first = x4[0];
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-          p2 += __shfl_xor(p2, off);
-          o2 += __shfl_xor(o2, off);
-        }
-        first = __shfl(first, 0);
-        if ((lane & 15) == r) { my_xn2 = p2; my_xo2 = o2; my_x0 = first; }
-      }
-      // ---- 2. the pair table: lanes 0..15 lay out their rows' contenders one after the other ----
-      const uint32_t n_q = lane < RB ? *lds_u32(cnt_lds + rl_q * 4) : 0u;
-      const bool usable = n_q >= 1 && n_q <= (uint32_t)kRefineCap;
-      const uint32_t m_q = (lane < RB && usable) ? n_q : 0u;
-      uint32_t incl = m_q;
-#pragma unroll
-      for (int o = 1; o < RB; o <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
-        if ((lane & 63) >= o) incl += t;
-      }
-      const uint32_t base_q = incl - m_q;
-      const uint32_t P = (uint32_t)__shfl((int)incl, RB - 1);   // lanes >= RB hold 0 contenders: lane 15's sum is the total
-      for (uint32_t i = 0; i < m_q; i++) {
-        *lds_u32(ptab + (base_q + i) * 12) = *lds_u32(list_lds + (rl_q * kRefineCap + i) * 4);
-        *lds_u32(ptab + (base_q + i) * 12 + 4) = (uint32_t)(lane & 15);
-      }
-      wave_sync();
-      // ---- 3. scores: 8 lanes per pair, 128 contiguous bytes of the contender's row per instruction ----
-      const int g = lane >> 3, j = lane & 7;
-      for (uint32_t p0 = 0; p0 < P; p0 += 8) {
-        const uint32_t pp = p0 + (uint32_t)g;
-        const bool on = pp < P;
-        const uint32_t c = on ? *lds_u32(ptab + pp * 12) : 0u;
-        const uint32_t r = on ? *lds_u32(ptab + pp * 12 + 4) : 0u;
-        const float *cr = cfil + (size_t)c * DP;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-        for (int f = 4 * j; f < DP; f += 32) {
-          const f32x4 c4 = *reinterpret_cast<const f32x4 *>(cr + f);
-          const f32x4 x4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(xs + r * DP + f);
-          a0 = fmaf(x4.x, c4.x, a0);
-          a1 = fmaf(x4.y, c4.y, a1);
-          a2 = fmaf(x4.z, c4.z, a2);
-          a3 = fmaf(x4.w, c4.w, a3);
-        }
-        float part = (a0 + a1) + (a2 + a3);
-        part += __shfl_xor(part, 1);
-        part += __shfl_xor(part, 2);
-        part += __shfl_xor(part, 4);
-        if (on && j == 0) *reinterpret_cast<__attribute__((address_space(3))) float *>((uintptr_t)(ptab + pp * 12 + 8)) = part + bias[c];
-      }
-      wave_sync();
-      // ---- 4. lanes 0..15: the best three of their row, the decision (as the other filters) ----
-      float v1 = -INFINITY, v2 = -INFINITY, v3 = -INFINITY;
-      uint32_t i1 = 0xFFFFFFFFu, i2 = 0xFFFFFFFFu;
-      for (uint32_t i = 0; i < m_q; i++) {
-        const uint32_t c = *lds_u32(ptab + (base_q + i) * 12);
-        const float v = *reinterpret_cast<__attribute__((address_space(3))) float *>((uintptr_t)(ptab + (base_q + i) * 12 + 8));
-        const bool g1 = v > v1, g2 = v > v2, g3 = v > v3;
-        v3 = g2 ? v2 : (g3 ? v : v3);
-        i2 = g1 ? i1 : (g2 ? c : i2);
-        v2 = g1 ? v1 : (g2 ? v : v2);
-        i1 = g1 ? c : i1;
-        v1 = g1 ? v : v1;
-      }
-      const bool insane = (my_x0 != my_x0);   // kmeans.cu:312
-      const float xn = sqrtf(my_xn2) * 1.0001f, xo = sqrtf(my_xo2) * 1.0001f;
-      const float e_mfma = 2.0f * eps * (xn * cmaxc + bmaxc);
-      const float e_ref = u * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
-      const float thr = 2.0f * (e_mfma + e_ref) * 1.001f + tie_slack;
-      // (ranges: the contender lists came out of half operands)
-      const bool in_range = usable && (xn < 6.0e4f) && (cmaxc < 6.0e4f) && i1 < K;
-      const bool certain = insane || (in_range && ((v1 - v2) > thr));
-      const bool two = !certain && in_range && ((v1 - v3) > thr) && i2 < K;
-      const bool mine = lane < RB && live_q;
-      const bool pair_now = mine && two, flag_now = mine && !certain && !two;
-      bool changed = false;
-      if (mine && certain) changed = commit_row(s_q, insane ? K : i1, assignments, assignments_prev);
-      const unsigned long long cm = __ballot(changed), pm = __ballot(pair_now), fm = __ballot(flag_now);
-      if (lane == 0 && cm) atomicAdd(&counters[0], (uint32_t)__popcll(cm));
-      if (pm) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&counters[3], (uint32_t)__popcll(pm));
-        base = __shfl(base, 0);
-        if (pair_now) {
-          const uint32_t slot = base + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
-          pairs[3 * (size_t)slot + 0] = s_q;
-          pairs[3 * (size_t)slot + 1] = i1;
-          pairs[3 * (size_t)slot + 2] = i2;
-        }
-      }
-      if (fm) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&counters[1], (uint32_t)__popcll(fm));
-        base = __shfl(base, 0);
-        if (flag_now) flagged[base + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = s_q;
-      }
-      wave_sync();   // the next batch overwrites the staged rows and the pair table
-    }
-  }
-#endif
   __syncthreads();   // the lists and tile buffers are reused by the next group
   }
 }
@@ -1139,8 +996,7 @@ template <int DP, int NSET>
 static hipError_t launch_refine_dp_n(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
                                      const uint32_t *row_list, const float *thr_list, const uint32_t *n_list,
                                      uint32_t rows_hint, hipStream_t st) {
-  const size_t lds_bytes = 2 * 64 * (size_t)(DP * 2) + 512 + 64 + (size_t)DP * 4 + 1024 + 256 * kRefineCap * 4 +
-                           4 * 16 * kRefineCap * 12;   // + the waves' pair tables (centroid, row, score)
+  const size_t lds_bytes = 2 * 64 * (size_t)(DP * 2) + 512 + 64 + (size_t)DP * 4 + 1024 + 256 * kRefineCap * 4;
   const uint32_t rows_per_block = 128u * NSET;
   // blocks beyond the device-side list length leave at once, but dispatching 31k of them for a list
   // 2k long is not free: the grid follows the caller's estimate of the list (the kernel strides)
