@@ -270,10 +270,44 @@ __device__ __forceinline__ double list_sum(const float *__restrict__ samples, ui
   return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 
-template <bool DIRECT>
+// the same for four consecutive features per lane (16-byte loads; D % 4 == 0, aligned rows): four accumulator
+// sets by row position, folded as (a0 + a1) + (a2 + a3)
+__device__ __forceinline__ void list_sum4(const float *__restrict__ samples, uint32_t D, const uint32_t *rows,
+                                          uint32_t r0, uint32_t r1, uint32_t f, double (&out)[4]) {
+  double a[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) a[j][e] = 0.0;
+  uint32_t r = r0;
+  for (; r + 4 <= r1; r += 4) {
+    float4 x[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) x[j] = *reinterpret_cast<const float4 *>(samples + (size_t)rows[r + j] * D + f);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      a[j][0] += (double)x[j].x; a[j][1] += (double)x[j].y; a[j][2] += (double)x[j].z; a[j][3] += (double)x[j].w;
+    }
+  }
+  for (uint32_t j = 0; r < r1; r++, j++) {
+    const float4 x = *reinterpret_cast<const float4 *>(samples + (size_t)rows[r] * D + f);
+    // (j < 4: static indexing after unrolling)
+    if (j == 0) { a[0][0] += (double)x.x; a[0][1] += (double)x.y; a[0][2] += (double)x.z; a[0][3] += (double)x.w; }
+    else if (j == 1) { a[1][0] += (double)x.x; a[1][1] += (double)x.y; a[1][2] += (double)x.z; a[1][3] += (double)x.w; }
+    else { a[2][0] += (double)x.x; a[2][1] += (double)x.y; a[2][2] += (double)x.z; a[2][3] += (double)x.w; }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; e++) out[e] = (a[0][e] + a[1][e]) + (a[2][e] + a[3][e]);
+}
+
+// VEC4: lanes own four consecutive features each (16-byte loads), so a 1-KB row takes 64 lanes and the block's
+// 1024 threads are 16 row groups instead of 4: the lists of a steady iteration (tens to hundreds of rows) are
+// read in one or two trips.  D % 4 == 0 and 16-byte aligned rows; anything else takes the scalar mapping.
+template <bool DIRECT, bool VEC4>
 __global__ __launch_bounds__(kSumThreads) void cluster_sums_kernel(SumArgs a) {
-  __shared__ uint32_t srt[2][kBucketCapMax];
-  __shared__ double part[kSumThreads];
+  extern __shared__ __attribute__((aligned(16))) unsigned char sums_lds[];
+  double *part = reinterpret_cast<double *>(sums_lds);                               // VEC4: 4 per thread, else 1
+  uint32_t (*srt)[kBucketCapMax] = reinterpret_cast<uint32_t (*)[kBucketCapMax]>(sums_lds + kSumThreads * 4 * sizeof(double));
   uint32_t *part_u = reinterpret_cast<uint32_t *>(part);   // scratch of the rank sort (before the sums use `part`)
   __shared__ uint32_t wcnt[16];
   __shared__ uint32_t sh_base;
@@ -379,6 +413,39 @@ __global__ __launch_bounds__(kSumThreads) void cluster_sums_kernel(SumArgs a) {
   }
 
   // ---- sums: fl lanes across the features, groups of rows ----
+  if (VEC4) {
+    uint32_t fl = 16;   // lanes per row: a power of two covering D / 4, at most 256
+    while (fl < 256u && fl * 4u < D) fl <<= 1;
+    const uint32_t groups = kSumThreads / fl, g = tid / fl, lf = tid % fl;
+    for (uint32_t f0 = 0; f0 < D; f0 += 4u * fl) {
+      const uint32_t f = f0 + 4u * lf;
+      const bool fv = f < D;
+      double tot[2][4];
+#pragma unroll
+      for (int sg = 0; sg < 2; sg++) {
+        const uint32_t cnt = n[sg], chunk = (cnt + groups - 1) / groups;
+        const uint32_t r0 = min(cnt, g * chunk), r1 = min(cnt, r0 + chunk);
+        double mine[4] = {0.0, 0.0, 0.0, 0.0};
+        if (fv && r1 > r0) list_sum4(a.samples, D, rows[sg], r0, r1, f, mine);
+#pragma unroll
+        for (int e = 0; e < 4; e++) part[(size_t)tid * 4 + e] = mine[e];
+        __syncthreads();
+        if (g == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            double t = part[(size_t)lf * 4 + e];
+            for (uint32_t gg = 1; gg < groups; gg++) t += part[(size_t)(gg * fl + lf) * 4 + e];
+            tot[sg][e] = t;
+          }
+        }
+        __syncthreads();
+      }
+      if (g == 0 && fv) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) a.delta[(size_t)c * D + f + e] = tot[0][e] - tot[1][e];
+      }
+    }
+  } else {
   const uint32_t fl = D > 128 ? 256u : (D > 64 ? 128u : 64u), groups = kSumThreads / fl;
   const uint32_t g = tid / fl, lf = tid % fl;
   for (uint32_t f0 = 0; f0 < D; f0 += fl) {
@@ -399,6 +466,7 @@ __global__ __launch_bounds__(kSumThreads) void cluster_sums_kernel(SumArgs a) {
       __syncthreads();
     }
     if (g == 0 && fv) a.delta[(size_t)c * D + f] = tot[0] - tot[1];
+  }
   }
   if (tid == 0) {
     const int32_t dc = (int32_t)n[0] - (int32_t)n[1];
@@ -471,6 +539,22 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
   a.delta = delta; a.dcount = dcount; a.tail = tail; a.counters = counters;
   a.res = bucket_work + 2 * (size_t)K * stride; a.host = ms->host_dev;
   hipError_t e = hipSuccess;
+  // (the mapping depends on D and the rows' alignment only, never on the path: the two paths stay bit-identical)
+  const bool vec4 = (D & 3u) == 0 && (((uintptr_t)samples) & 15u) == 0;
+  const size_t sums_lds = kSumThreads * 4 * sizeof(double) + 2 * kBucketCapMax * sizeof(uint32_t) + 64;
+  auto launch_sums = [&](bool direct) {
+    const void *fn = direct ? (vec4 ? (const void *)cluster_sums_kernel<true, true> : (const void *)cluster_sums_kernel<true, false>)
+                            : (vec4 ? (const void *)cluster_sums_kernel<false, true> : (const void *)cluster_sums_kernel<false, false>);
+    // (per launch: the attribute belongs to the current device's copy of the kernel)
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sums_lds) != hipSuccess) return;
+    if (direct) {
+      if (vec4) hipLaunchKernelGGL((cluster_sums_kernel<true, true>), dim3(K), dim3(kSumThreads), sums_lds, st, a);
+      else hipLaunchKernelGGL((cluster_sums_kernel<true, false>), dim3(K), dim3(kSumThreads), sums_lds, st, a);
+    } else {
+      if (vec4) hipLaunchKernelGGL((cluster_sums_kernel<false, true>), dim3(K), dim3(kSumThreads), sums_lds, st, a);
+      else hipLaunchKernelGGL((cluster_sums_kernel<false, false>), dim3(K), dim3(kSumThreads), sums_lds, st, a);
+    }
+  };
   const bool force_radix = ms->force == 1, force_sync = ms->force == 2, force_direct = ms->force == 3;
   // last_events / host[1]: the newest event count and largest list the host knows (2 N before the first call).
   // Lists shrink from iteration to iteration, so an older figure errs towards the radix path, which takes any
@@ -482,7 +566,7 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
   if (N == 0) {
     e = hipMemsetAsync(offsets2, 0, (2 * (size_t)K + 1) * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((cluster_sums_kernel<false>), dim3(K), dim3(kSumThreads), 0, st, a);
+    launch_sums(false);
   } else if (radix) {
     const uint32_t nb = (N + kMoveRows - 1) / kMoveRows;
     hipLaunchKernelGGL(move_count_kernel, dim3(nb), dim3(256), 0, st, prev, cur, N, K, blockoff);
@@ -501,14 +585,14 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
     }
     // segment starts by binary search in the sorted keys
     hipLaunchKernelGGL(offsets_kernel, dim3((2 * K + 1 + 255) / 256), dim3(256), 0, st, keys_sorted, m, 2 * K, offsets2);
-    hipLaunchKernelGGL((cluster_sums_kernel<false>), dim3(K), dim3(kSumThreads), 0, st, a);
+    launch_sums(false);
     ms->last_events = m;
     ms->host[0] = m;    // (the kernel's report will say the same)
     ms->host[1] = 0;
   } else {
     hipLaunchKernelGGL(move_scatter_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, bucket_work,
                        stride, bucket_rows, cap);
-    hipLaunchKernelGGL((cluster_sums_kernel<true>), dim3(K), dim3(kSumThreads), 0, st, a);
+    launch_sums(true);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (force_sync) {   // KMCUDA_AMD_UPDATE=sync: the next call decides on THIS call's figures
