@@ -5,8 +5,6 @@ set -u
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out; mkdir -p $OUT; TAG=${1:-r3i}
-timeout 1200 python -m pytest -q -x -m gpu tests/test_gpu_kmeans.py tests/test_gpu_exact_update.py tests/test_gpu_sharded.py tests/test_gpu_lloyd.py -k "not afkmc2" > $OUT/pytest_${TAG}.log 2>&1
-echo "pytest rc=$?"; tail -6 $OUT/pytest_${TAG}.log
 for lib in default sums4b; do
   if [ $lib = default ]; then unset KMCUDA_AMD_LIB; else export KMCUDA_AMD_LIB=$PWD/kmcuda_amd/libKMCUDA_$lib.so; fi
   for n in 8000000 1000000; do
@@ -21,7 +19,9 @@ rows = list(cur.execute("select %s, start, end from kernels order by start" % na
 per = {}
 for nm, a, b in rows:
     if "kmx::" in nm or "_ZN3kmx" in nm:
-        key = nm.split("kmx::")[-1].split("(")[0][:40] if "kmx::" in nm else nm[7:40]
+        import re
+        m = re.search(r"(\w+_kernel)(<[^>]*>)?", nm)
+        key = (m.group(1) + (m.group(2) or ""))[:48] if m else nm[:48]
         per.setdefault(key, []).append(b - a)
 d = json.load(open("$OUT/bench_${TAG}_${lib}_$n.json"))
 out = {k: (len(v), round(sum(v[-10:]) / len(v[-10:]) / 1e3, 1), round(min(v) / 1e3, 1)) for k, v in per.items() if "cluster_sums" in k or "scatter" in k}
