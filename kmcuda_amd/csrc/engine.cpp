@@ -576,9 +576,11 @@ int Engine::apply_prepare(const double *delta, const double *dcount_d, float *ce
     return apply_delta(delta, nullptr, dcount_d, centroids, ccounts, stop_threshold, report, seq);
   }
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
-  StopCtl ctl;
-  int rc = stop_ctl(stop_threshold, report, seq, &ctl);
-  if (rc) return rc;
+  StopCtl ctl;   // (without a threshold or a report the update is unconditional: a raised stop flag is not looked at)
+  if (stop_threshold >= 0.f || report) {
+    int rc = stop_ctl(stop_threshold, report, seq, &ctl);
+    if (rc) return rc;
+  }
   uint32_t *next = stats_;
   stats_ = stats_ == stats_base_ ? stats_base_ + 8 : stats_base_;
   span_begin(2);

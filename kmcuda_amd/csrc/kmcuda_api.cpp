@@ -985,6 +985,7 @@ class Job {
   int yinyang(float tolerance, uint32_t G, int iter, const std::vector<uint32_t> &groups) {
     for (auto &s : shards) {
       (void)hipSetDevice(s->dev);
+      RETERR(s->eng->stop_clear());   // (the Lloyd phase's stop raised it; this phase decides on the host)
       RETERR(s->eng->yy_configure(G, groups.data()));
       int rc;
       if ((rc = s->alloc(&s->bounds, (size_t)s->length * (G + 1)))) return rc;

@@ -864,7 +864,9 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
     // my half of the centred fp32 row, 64 features at a time, against every contender of the row; a contender's
     // partial dot products add up in a register of its own (at most kRefineCap of them).  (128 features at a time
     // had the row chunk AND a contender's 32 sixteen-byte loads in flight: 256 registers, 650 bytes of scratch
-    // per lane -- a third of a gigabyte of spill traffic per 8M-row pass.)
+    // per lane -- a third of a gigabyte of spill traffic per 8M-row pass.  Requesting contender i + 1's chunk and the
+    // row's next chunk one step ahead -- 32-feature chunks, two buffers -- measured no better: 481 against 464 us per
+    // 8M-row pass, profiles/r3j_*.)
     constexpr int FC = NKH < 64 ? NKH : 64, NCHUNK = NKH / FC;
     float xn2 = 0.f, xo2 = 0.f, x0 = 0.f;
     float v1 = -INFINITY, v2 = -INFINITY, v3 = -INFINITY;

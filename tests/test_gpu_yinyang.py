@@ -214,6 +214,52 @@ def test_kmeanspp_yinyang_15_3(fixture13k, monkeypatch, schedule):
         assert "refreshing Yinyang bounds" not in out.text
 
 
+def test_schedules_agree_on_a_row_cached_shape(monkeypatch):
+    """yinyang_t > 0 at a shape whose Lloyd passes run the row-cached two-stage filter (D = 256: the centroid
+    update is then fused with the next pass's preparation), on the reference's schedule, the default one and with
+    the bounds forced in late: Yinyang is exact, so the runs agree up to rows within rounding of a tie.  (Round 3: the fused update looked at the Lloyd phase's raised stop flag and skipped every update
+    of the Yinyang phase on this path -- 8M x 256 "converged" after one bounds pass; the 13000 x 2 fixture never takes
+    the fused path and did not see it.)"""
+    from kmcuda_amd import kmeans_cuda
+    rs = numpy.random.RandomState(12)
+    x = rs.rand(30000, 256).astype(numpy.float32)
+    runs = {}
+    for schedule in ("default", "reference", "switch-at-0.05"):
+        monkeypatch.delenv("KMCUDA_AMD_YY", raising=False)
+        monkeypatch.delenv("KMCUDA_AMD_YY_SWITCH", raising=False)
+        if schedule == "reference":
+            monkeypatch.setenv("KMCUDA_AMD_YY", "reference")
+        elif schedule.startswith("switch-at-"):
+            monkeypatch.setenv("KMCUDA_AMD_YY_SWITCH", schedule[len("switch-at-"):])
+        out = StdoutListener()
+        with out:
+            c, a = kmeans_cuda(x, 96, init="random", device=1, verbosity=1, seed=5, tolerance=0.002, yinyang_t=0.1)
+        lines = [ln for ln in out.text.splitlines() if ln.startswith("iteration")]
+        runs[schedule] = (lines, a, c, "refreshing Yinyang bounds" in out.text)
+    assert runs["reference"][3] and runs["switch-at-0.05"][3] and not runs["default"][3]
+    assert len(runs["default"][0]) > 12
+
+    def counts(lines):
+        return [int(ln.split()[2]) for ln in lines]
+
+    def inertia(c, a):
+        return float(((x - c[a]) ** 2).sum())
+    base = counts(runs["default"][0])
+    for schedule in ("reference", "switch-at-0.05"):
+        got = counts(runs[schedule][0])
+        # a bounds pass decides by the reference's Yinyang arithmetic (sqrt of a Kahan sum of squared differences),
+        # a Lloyd pass by -2 x.c + |c|^2: a row within rounding of a tie may go either way (measured: the first
+        # difference is ONE row of 30000, at the first bounds pass), after which the two runs are two equally valid
+        # Lloyd trajectories.  Up to the hand-over the lines are identical; afterwards the counts track each other
+        hand_over = next(i for i, (u, v) in enumerate(zip(got, base)) if u != v) if got != base else len(base)
+        assert hand_over >= 4, (schedule, got[:8], base[:8])
+        assert abs(len(got) - len(base)) <= 3, schedule
+        for u, v in list(zip(got, base))[:12]:
+            assert abs(u - v) <= max(3, 0.02 * v), (schedule, got[:12], base[:12])
+        assert (runs[schedule][1] != runs["default"][1]).mean() < 0.02, schedule
+        assert abs(inertia(runs[schedule][2], runs[schedule][1]) / inertia(runs["default"][2], runs["default"][1]) - 1) < 1e-4
+
+
 @pytest.mark.parametrize("speculate", ["1", "0"])
 def test_lloyd_stop_rule_on_device_equals_host(fixture13k, monkeypatch, speculate):
     """The stop rule decided by the update kernel, with the next pass enqueued before the host has seen the
