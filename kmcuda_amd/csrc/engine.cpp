@@ -1,6 +1,7 @@
 // engine.cpp -- Engine implementation + the step-level C ABI of include/kmcuda_amd.h.
 #include "engine.hpp"
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -13,6 +14,37 @@
 namespace kmx {
 
 int g_verbosity = 0;
+
+// rocBLAS, loaded on first use (lloyd_gemm.hip's stage 1: one plain library GEMM per row chunk); a process that
+// never clusters rows wider than 512 features never loads it
+namespace {
+struct Rocblas {
+  void *lib = nullptr;
+  bool tried = false;
+  int (*create_handle)(void **) = nullptr;
+  int (*destroy_handle)(void *) = nullptr;
+  int (*set_stream)(void *, hipStream_t) = nullptr;
+  int (*gemm_ex)(void *, int, int, int, int, int, const void *, const void *, int, int, const void *, int, int,
+                 const void *, const void *, int, int, void *, int, int, int, int, int32_t, uint32_t) = nullptr;
+  bool load() {
+    if (tried) return gemm_ex != nullptr;
+    tried = true;
+    for (const char *name : {"librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so.5", "/opt/rocm/lib/librocblas.so"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) return false;
+    create_handle = (decltype(create_handle))dlsym(lib, "rocblas_create_handle");
+    destroy_handle = (decltype(destroy_handle))dlsym(lib, "rocblas_destroy_handle");
+    set_stream = (decltype(set_stream))dlsym(lib, "rocblas_set_stream");
+    gemm_ex = (decltype(gemm_ex))dlsym(lib, "rocblas_gemm_ex");
+    if (!(create_handle && destroy_handle && set_stream && gemm_ex)) gemm_ex = nullptr;
+    return gemm_ex != nullptr;
+  }
+};
+Rocblas g_rocblas;
+constexpr int kRbOpNone = 111, kRbOpTrans = 112, kRbF16 = 150, kRbF32 = 151;   // rocblas-types.h
+}  // namespace
 
 Engine::~Engine() {
   if (device_ >= 0) (void)hipSetDevice(device_);
@@ -28,6 +60,7 @@ Engine::~Engine() {
   if (host_report_) (void)hipHostFree(host_report_);
   for (hipEvent_t e : ev_report_)
     if (e) (void)hipEventDestroy(e);
+  if (rb_handle_ && g_rocblas.destroy_handle) (void)g_rocblas.destroy_handle(rb_handle_);
   if (ev_rows_) (void)hipEventDestroy(ev_rows_);
   if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
@@ -37,6 +70,7 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if (const char *f = getenv("KMCUDA_AMD_FILTER")) filter_mode_ = strcmp(f, "f32") == 0 ? 1 : 0;
   if (const char *c = getenv("KMCUDA_AMD_ROW_CACHE")) row_cache_allowed_ = atoi(c) != 0;
   if (const char *c = getenv("KMCUDA_AMD_SETTLE")) settle_ = atoi(c) != 0;
+  if (const char *c = getenv("KMCUDA_AMD_GEMM")) gemm_ok_ = atoi(c) != 0;
   if (const char *u = getenv("KMCUDA_AMD_UPDATE"))
     ms_.force = strcmp(u, "radix") == 0 ? 1 : (strcmp(u, "sync") == 0 ? 2 : (strcmp(u, "bucket") == 0 ? 3 : 0));
   if (D == 0 || K < 1 || K >= 0x7FFFFFFFu) return kInvalidArguments;  // K == 1: Yinyang group clustering with one group
@@ -68,7 +102,9 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   // same angle, so near-ties go to the exact kernel which applies acosf like the reference.
   tie_slack_ = metric == 0 ? 0.f : 1e-6f;
 
-  const uint32_t dp = DP_ ? DP_ : 8;
+  // no register-resident filter for this D: stage 1 through a library GEMM (lloyd_gemm.hip), operands padded to 32
+  gemm_dp_ = (DP_ == 0 && gemm_ok_) ? (D + 31) / 32 * 32 : 0;
+  const uint32_t dp = DP_ ? DP_ : (gemm_dp_ ? gemm_dp_ : 8);
   int rc;
   if ((rc = alloc(&csqr_, K))) return rc;
   if ((rc = alloc(&bias_, K_pad_))) return rc;
@@ -155,7 +191,7 @@ void Engine::profile_reset() {
 }
 
 int Engine::prepare_centroids(const float *centroids) {
-  const uint32_t dp = DP_ ? DP_ : 8;
+  const uint32_t dp = DP_ ? DP_ : (gemm_dp_ ? gemm_dp_ : 8);
   prepared_for_ = nullptr;
   // this preparation's statistics go to the other half; both halves are zeroed here, which also leaves
   // the half after this one zero (the invariant centroid_prep_frozen_kernel relies on)
@@ -425,6 +461,10 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   a.assignments = assignments; a.assignments_prev = assignments_prev;
   a.flagged = flagged_; a.pairs = pairs_; a.counters = counters_;
   if (N_ == 0) return kSuccess;
+  if (!exact_only && DP_ == 0 && gemm_dp_ != 0) {
+    const int rc = lloyd_assign_gemm(a, centroids);
+    if (rc != kNoSuchDevice + 100) return rc;   // (that code: rocBLAS is not there -- the exact kernel below serves the shape)
+  }
   if (exact_only || DP_ == 0 || (DP_ > 256 && filter_mode_ != 0)) {
     span_begin(1);
     const uint32_t grid = N_ < 8192u ? N_ : 8192u;
@@ -496,6 +536,81 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   KMX_HIP(launch_lloyd_pair(metric_, a, centroids, (N_ + 127) / 128 < 2048u ? (N_ + 127) / 128 : 2048u, stream_),
           kRuntimeError);
   KMX_HIP(hipStreamWaitEvent(stream_, ev_join_, 0), kRuntimeError);
+  span_end();
+  return kSuccess;
+}
+
+// D beyond the register-resident filters: lloyd_gemm.hip.  prepare_centroids() has run (csqr, ct, mean -- frozen
+// while a row copy is alive --, centred fp32 panel, biases, statistics, list counters zeroed).
+int Engine::lloyd_assign_gemm(const LloydArgs &a0, const float *centroids) {
+  constexpr int kNoRocblas = kNoSuchDevice + 100;
+  if (!g_rocblas.load()) return kNoRocblas;
+  if (!rb_handle_ && g_rocblas.create_handle(&rb_handle_) != 0) { rb_handle_ = nullptr; return kNoRocblas; }
+  if (g_rocblas.set_stream(rb_handle_, stream_) != 0) return kRuntimeError;
+  LloydArgs a = a0;
+  const uint32_t DG = gemm_dp_;
+  const uint32_t k_pad64 = (K_pad_ + 63u) / 64u * 64u;
+  int rc;
+  if (!panelhi_) {
+    uint16_t *phi = nullptr;
+    if ((rc = alloc(&phi, (size_t)k_pad64 * (DG + 2)))) return rc;
+    panelhi_ = phi;
+  }
+  const uint32_t chunk = gemm_chunk_rows(N_, K_pad_);
+  if (!gscores_) {
+    if ((rc = alloc(&gscores_, (size_t)chunk * K_pad_))) return rc;
+    if ((rc = alloc(&gund_rows_, gemm_rows_words(N_)))) return rc;
+    if ((rc = alloc(&gund_cont_, gemm_cont_words(N_)))) return rc;
+    if ((rc = alloc(&gcursors_, 64 * 32))) return rc;
+  }
+  if (!xg16_) {
+    uint16_t *xg = nullptr;
+    if ((rc = alloc(&xg, (size_t)N_ * DG))) return rc;
+    if ((rc = alloc(&xgmeta_, (size_t)N_ * 4))) return rc;
+    xg16_ = xg;
+  }
+  span_begin(0);
+  // hi halves of the centred centroids (+ their residual maximum, stats[5])
+  KMX_HIP(launch_centroid_panelhi(centroids, K_, D_, K_pad_, DG, finite_, mu_, bias_, panelhi_, stats_, stream_),
+          kRuntimeError);
+  // the rows as centred halves: kept while the caller has promised fixed rows (the mean is then frozen, any mean
+  // being valid), otherwise rebuilt for this pass's mean
+  if (!(row_cache_on_ && row_cache_valid_)) {
+    const void *rows = half_rows_ ? half_rows_ : (const void *)a.samples;
+    KMX_HIP(launch_row_halves(rows, half_rows_ != nullptr, N_, D_, DG, mu_, xg16_, xgmeta_, stream_), kRuntimeError);
+    if (row_cache_on_) {
+      row_cache_valid_ = true;
+      mu_frozen_ = true;
+    }
+  }
+  KMX_HIP(hipMemsetAsync(gcursors_, 0, 64 * 32 * sizeof(uint32_t), stream_), kRuntimeError);
+  const float one = 1.f, zero = 0.f;
+  for (uint32_t r0 = 0; r0 < N_; r0 += chunk) {
+    const uint32_t nr = N_ - r0 < chunk ? N_ - r0 : chunk;
+    // row-major S (nr x K_pad) = Xhi (nr x DG) . Chi^T, i.e. column-major S^T (K_pad x nr) = op(A) op(B) with
+    // A = Chi seen column-major as DG x K_pad (transposed), B = Xhi seen column-major as DG x nr
+    const int st = g_rocblas.gemm_ex(rb_handle_, kRbOpTrans, kRbOpNone, (int)K_pad_, (int)nr, (int)DG, &one, panelhi_,
+                                     kRbF16, (int)DG, reinterpret_cast<const uint16_t *>(xg16_) + (size_t)r0 * DG, kRbF16,
+                                     (int)DG, &zero, gscores_, kRbF32, (int)K_pad_, gscores_, kRbF32, (int)K_pad_, kRbF32,
+                                     0 /* rocblas_gemm_algo_standard */, 0, 0);
+    if (st != 0) {
+      if (g_verbosity > 0) printf("rocblas_gemm_ex -> %d\n", st);
+      return kRuntimeError;
+    }
+    KMX_HIP(launch_gemm_decide(a, gscores_, K_pad_, r0, nr, DG, xgmeta_, gund_rows_, gund_cont_, gcursors_, stream_),
+            kRuntimeError);
+  }
+  KMX_HIP(launch_gemm_contenders(a, DG, gund_rows_, gund_cont_, gcursors_, stream_), kRuntimeError);
+  span_end();
+  span_begin(1);
+  if (settle_ && lloyd_settle_supported(a, centroids)) {
+    KMX_HIP(launch_lloyd_settle(metric_, a, centroids, stream_), kRuntimeError);
+  } else {
+    KMX_HIP(launch_lloyd_pair(metric_, a, centroids, (N_ + 127) / 128 < 2048u ? (N_ + 127) / 128 : 2048u, stream_),
+            kRuntimeError);
+    const uint32_t grid = N_ < 4096u ? N_ : 4096u;
+    KMX_HIP(launch_lloyd_exact(metric_, a, flagged_, counters_ + 1, grid, stream_), kRuntimeError);
+  }
   span_end();
   return kSuccess;
 }

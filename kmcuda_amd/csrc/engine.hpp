@@ -107,6 +107,16 @@ class Engine {
   // 1: f32 matrix-core filter (KMCUDA_AMD_FILTER=f32; cross-check)
   int filter_mode_ = 0;
   bool settle_ = true;   // KMCUDA_AMD_SETTLE=0: lloyd_pair + lloyd_exact instead of the one-launch lloyd_settle
+  // D beyond the register-resident filters (lloyd_gemm.hip): stage 1 through rocBLAS.  gemm_dp_ = D rounded up to 32
+  // (0: not this path); KMCUDA_AMD_GEMM=0 leaves such shapes to the exact kernels (the cross-check)
+  uint32_t gemm_dp_ = 0;
+  bool gemm_ok_ = true;
+  void *rb_handle_ = nullptr;
+  void *xg16_ = nullptr;          // N x gemm_dp_ halves: x - mu, row-major (this path's row cache)
+  float *xgmeta_ = nullptr;       // 4 floats per row
+  float *gscores_ = nullptr;      // chunk x K_pad
+  uint32_t *gund_rows_ = nullptr, *gund_cont_ = nullptr, *gcursors_ = nullptr;
+  int lloyd_assign_gemm(const LloydArgs &a, const float *centroids);
   // row cache of the coarse filter stage (lloyd_f16.hip: row_cache_kernel); set_row_cache()
   bool row_cache_allowed_ = true;   // KMCUDA_AMD_ROW_CACHE=0 vetoes it
   bool row_cache_on_ = false, row_cache_valid_ = false, mu_frozen_ = false;

@@ -1,0 +1,120 @@
+"""Feature counts beyond the register-resident filters (D > 512): stage 1's scores come out of one library GEMM
+per row chunk (kmcuda_amd/csrc/lloyd_gemm.hip; rocBLAS, f16 operands, f32 accumulation), contenders are read off
+the score matrix, the exact kernels settle the rest.  Bar, as everywhere: assignments, previous assignments and the
+reassignment counter BIT-EXACT against the oracle (kmeans_assign_lloyd, kmeans.cu:293-364) for any input."""
+import numpy
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _passes(x, cs, metric="L2", cached=False, half=False):
+    from kmcuda_amd.engine import Engine
+    dev = torch.device("cuda", 0)
+    n, d = x.shape
+    k = cs[0].shape[0]
+    xs = torch.from_numpy(x).to(dev)
+    x16 = xs.to(torch.float16) if half else None
+    asg = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    prev = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    eng = Engine(n, d, k, metric, device=0)
+    if half:
+        eng.set_half_rows(x16)
+    if cached:
+        eng.set_row_cache(True)
+    out = []
+    for c in cs:
+        eng.reset_counters(0)
+        eng.lloyd_assign(xs, torch.from_numpy(c).to(dev), asg, prev)
+        counters = eng.counters()
+        out.append((asg.cpu().numpy().view(numpy.uint32).copy(), prev.cpu().numpy().view(numpy.uint32).copy(), counters))
+    eng.close()
+    return out
+
+
+@pytest.mark.parametrize("cached", [False, True])
+@pytest.mark.parametrize("n,d,k", [(3000, 1024, 1024), (1500, 600, 64), (2000, 520, 100), (900, 2048, 33),
+                                   (4097, 768, 257), (50, 1536, 7)])
+def test_wide_rows_bit_exact(n, d, k, cached):
+    rs = numpy.random.RandomState(n + d + k)
+    x = rs.rand(n, d).astype(numpy.float32)
+    c0 = x[rs.choice(n, k, replace=False)].copy()
+    cs = [c0, (c0 + rs.randn(k, d).astype(numpy.float32) * 0.01).astype(numpy.float32), (c0 * 0.9 + 0.05).astype(numpy.float32)]
+    got = _passes(x, cs, cached=cached)
+    ref_asg = None
+    for (asg, prev, counters), c in zip(got, cs):
+        ref, ref_prev, ref_changed = oracle.lloyd_assign(x, c, assignments=ref_asg)
+        assert (asg == ref).all()
+        assert (prev == ref_prev).all()
+        assert counters[0] == ref_changed
+        ref_asg = ref
+    # the filter, not the exact scan, did the work (counters[1]: rows handed to the full scan)
+    assert got[0][2][1] < n // 4
+
+
+def test_wide_rows_gemm_off_is_the_exact_kernel(monkeypatch):
+    monkeypatch.setenv("KMCUDA_AMD_GEMM", "0")
+    rs = numpy.random.RandomState(3)
+    x = rs.rand(700, 640).astype(numpy.float32)
+    c = x[rs.choice(700, 40, replace=False)].copy()
+    (asg, prev, counters), = _passes(x, [c])
+    ref, ref_prev, ref_changed = oracle.lloyd_assign(x, c)
+    assert (asg == ref).all() and (prev == ref_prev).all() and counters[0] == ref_changed
+
+
+def test_wide_rows_ties_nans_nonfinite_centroids():
+    rs = numpy.random.RandomState(11)
+    n, d, k = 2500, 800, 96
+    x = rs.rand(n, d).astype(numpy.float32)
+    c = x[rs.choice(n, k, replace=False)].copy()
+    c[40] = c[3]          # duplicate centroids: exact ties, the lower index must win
+    c[77] = c[3]
+    c[10, 5] = numpy.nan  # NaN centroid: never chosen (kmeans.cu:425-426)
+    c[11, :] = numpy.inf
+    x[5, 0] = numpy.nan   # "insane" sample -> assignment K (kmeans.cu:312, :349-356)
+    x[6, 17] = numpy.nan  # NaN elsewhere: search fails, row left untouched
+    x[7] = c[3]           # exact hit on a duplicated centroid
+    x[8, 3] = numpy.inf
+    x[9, :] = 1e30        # centred halves overflow: never decided from half scores
+    for cached in (False, True):
+        (asg, prev, counters), = _passes(x, [c], cached=cached)
+        ref, ref_prev, ref_changed = oracle.lloyd_assign(x, c)
+        assert (asg == ref).all()
+        assert (prev == ref_prev).all()
+        assert counters[0] == ref_changed
+        assert asg[5] == k and asg[6] == 0xFFFFFFFF and asg[7] == 3
+
+
+def test_wide_rows_angular_and_half_rows():
+    rs = numpy.random.RandomState(17)
+    x = rs.randn(2000, 768).astype(numpy.float32)
+    x /= numpy.linalg.norm(x, axis=1)[:, None]
+    c = x[rs.choice(2000, 64, replace=False)].copy()
+    (asg, _, _), = _passes(x, [c], metric="cos")
+    ref, _, _ = oracle.lloyd_assign(x, c, metric=oracle.COS)
+    assert (asg != ref).mean() < 1e-3     # acosf: libm vs ocml (tests/test_gpu_lloyd.py::test_assign_angular)
+    # fp16x2 path: the rows as halves feed the GEMM operand; results as on the widened values
+    xh = x.astype(numpy.float16).astype(numpy.float32)
+    ch = c.astype(numpy.float16).astype(numpy.float32)
+    (asg, prev, counters), = _passes(xh, [ch], half=True)
+    ref, ref_prev, ref_changed = oracle.lloyd_assign(xh, ch)
+    assert (asg == ref).all() and counters[0] == ref_changed
+
+
+def test_wide_rows_whole_run_through_the_boundary():
+    """kmeans_cuda() on 1024-feature rows: the stop rule on the device, the fp64 update, the row copy kept across the
+    iterations -- against the oracle's run from the same seeds (same stop iteration; assignments equal up to the
+    update's last-bit differences)."""
+    from kmcuda_amd import kmeans_cuda
+    rs = numpy.random.RandomState(2)
+    centres = rs.rand(40, 1024).astype(numpy.float32) * 4
+    x = (centres[rs.randint(0, 40, 6000)] + 0.5 * rs.randn(6000, 1024)).astype(numpy.float32)
+    cen, asg = kmeans_cuda(x, 40, init="k-means++", seed=7, tolerance=0.001, yinyang_t=0, device=1)
+    ocen, oasg, olog = oracle.kmeans(x, 40, init="k-means++", seed=7, tolerance=0.001, yinyang_t=0)
+    assert (asg != oasg).mean() < 1e-3
+    numpy.testing.assert_allclose(cen, ocen, rtol=2e-4, atol=2e-4)
+    ref, _, _ = oracle.lloyd_assign(x, cen)
+    assert (ref == asg).all()     # the returned assignments ARE the reference's for the returned centroids
