@@ -600,7 +600,7 @@ int Engine::lloyd_assign_gemm(const LloydArgs &a0, const float *centroids) {
     KMX_HIP(launch_gemm_decide(a, gscores_, K_pad_, r0, nr, DG, xgmeta_, gund_rows_, gund_cont_, gcursors_, stream_),
             kRuntimeError);
   }
-  KMX_HIP(launch_gemm_contenders(a, DG, gund_rows_, gund_cont_, gcursors_, stream_), kRuntimeError);
+  KMX_HIP(launch_gemm_contenders(metric_, a, centroids, DG, gund_rows_, gund_cont_, gcursors_, stream_), kRuntimeError);
   span_end();
   span_begin(1);
   if (settle_ && lloyd_settle_supported(a, centroids)) {

@@ -96,13 +96,14 @@ hipError_t launch_row_halves(const void *rows, bool half_rows, uint32_t N, uint3
                              void *xg, float *meta /* 4 floats per row */, hipStream_t st);
 uint32_t gemm_list_cap(uint32_t N);
 uint32_t gemm_chunk_rows(uint32_t N, uint32_t K_pad);
-size_t gemm_cont_words(uint32_t N);   // contender table: 64 lists x cap x (1 + 8) words
+size_t gemm_cont_words(uint32_t N);   // contender table: 64 lists x cap x (1 + 16) words
 size_t gemm_rows_words(uint32_t N);   // row lists: 64 x cap words
 hipError_t launch_gemm_decide(const LloydArgs &a, const float *scores, uint32_t ld, uint32_t row0, uint32_t nrows,
                               uint32_t DG, const float *meta, uint32_t *und_rows, uint32_t *und_cont,
                               uint32_t *cursors /* 64 x 32 words, zero on entry of a pass */, hipStream_t st);
-hipError_t launch_gemm_contenders(const LloydArgs &a, uint32_t DG, const uint32_t *und_rows, const uint32_t *und_cont,
-                                  const uint32_t *cursors, hipStream_t st);
+hipError_t launch_gemm_contenders(int metric, const LloydArgs &a, const float *centroids, uint32_t DG,
+                                  const uint32_t *und_rows, const uint32_t *und_cont, const uint32_t *cursors,
+                                  hipStream_t st);
 
 // update.hip -- centroid update (reference: kmeans.cu:366-429 kmeans_adjust)
 size_t sort_temp_bytes(size_t n, uint32_t max_key);

@@ -24,7 +24,7 @@
 namespace kmx {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kGemmCap = 8;        // contenders kept per row (as kRefineCap)
+constexpr int kGemmCap = 16;       // contenders kept per row
 constexpr int kGemmLists = 64;     // undecided rows are appended to 64 lists, cursors one cache line apart
 
 // x' = x - mu as halves (DG per row, zero padded) + the row's record
@@ -182,10 +182,15 @@ __global__ __launch_bounds__(256) void gemm_decide_kernel(
   }
 }
 
-// One wave per listed row: the contenders in fp32, the decision (as lloyd_refine_kernel's contender phase).
-template <bool FAST>
+// One wave per listed row: the contenders in fp32, the decision (as lloyd_refine_kernel's contender phase).  A row
+// whose best three are still within the f32 bound is settled HERE with the reference's exact chains over its
+// contenders only -- every other centroid is already ruled out by the cut-off -- one chain per lane (lanes beyond
+// the row's contenders idle: such rows are rare, and the alternative is a full scan of all K).  Only rows without a
+// usable list (more than kGemmCap contenders, operands out of the half range, NaN scores) go to the full scan.
+template <int METRIC, bool FAST>
 __global__ __launch_bounds__(256) void gemm_contenders_kernel(
-    const float *__restrict__ samples, uint32_t D, uint32_t DG, uint32_t K, const float *__restrict__ cfil,
+    const float *__restrict__ samples, uint32_t D, uint32_t DG, uint32_t K, const float *__restrict__ centroids,
+    const float *__restrict__ csqr, const float *__restrict__ cfil,
     const float *__restrict__ bias, const float *__restrict__ mu, const uint32_t *__restrict__ stats, float eps,
     float tie_slack, const uint32_t *__restrict__ und_rows, const uint32_t *__restrict__ und_cont, uint32_t list_cap,
     const uint32_t *__restrict__ cursors, uint32_t *__restrict__ assignments, uint32_t *__restrict__ assignments_prev,
@@ -273,9 +278,41 @@ __global__ __launch_bounds__(256) void gemm_contenders_kernel(
     const bool in_range = usable && (xn < 6.0e4f) && (cmaxc < 6.0e4f) && i1 < K;
     const bool certain = insane || (in_range && ((v1 - v2) > thr));
     const bool two = !certain && in_range && ((v1 - v3) > thr) && i2 < K;
-    const bool pair_now = live && two, flag_now = live && !certain && !two;
+    const bool multi = live && !certain && !two && usable;
+    const bool pair_now = live && two, flag_now = live && !certain && !two && !usable;
     bool changed = false;
     if (live && certain && lane == 0) changed = commit_row(s, insane ? K : i1, assignments, assignments_prev);
+    if (multi) {   // wave-uniform
+      uint32_t mine = 0;
+#pragma unroll
+      for (int i = 0; i < kGemmCap; i++) mine = ((int)lane == i) ? cid[i] : mine;
+      const bool on = lane < n;
+      const float *cr = centroids + (size_t)(on ? mine : 0) * D;
+      const float *xs = samples + (size_t)__builtin_amdgcn_readfirstlane(s) * D;   // wave-uniform: scalar loads
+      float ac = 0.f, co = 0.f;
+      uint32_t f = 0;
+      for (; f + 8 <= D; f += 8) {   // (the chain order is the reference's: features ascending)
+        float xv[8], cv[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) { xv[e] = xs[f + e]; cv[e] = cr[f + e]; }
+#pragma unroll
+        for (int e = 0; e < 8; e++) kahan_fold(fma_rd(xv[e], cv[e], co), ac, co);
+      }
+      for (; f < D; f++) kahan_fold(fma_rd(xs[f], cr[f], co), ac, co);
+      float dist = on ? lloyd_distance<METRIC>(csqr[mine], ac) : 0.f;
+      // the reference's ascending scan with strict '<' over the contenders = the smallest distance, the smallest
+      // index among equals; a NaN distance never wins
+      bool has = on && (dist < 3.402823466e+38f);
+      uint32_t best = has ? mine : 0xFFFFFFFFu;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float od = __shfl_xor(dist, off);
+        const uint32_t ob = __shfl_xor(best, off);
+        const bool take = (ob != 0xFFFFFFFFu) && (best == 0xFFFFFFFFu || od < dist || (od == dist && ob < best));
+        if (take) { dist = od; best = ob; }
+      }
+      if (lane == 0 && best != 0xFFFFFFFFu) changed = commit_row(s, best, assignments, assignments_prev);
+    }
     if (lane == 0) { sh_pair[wave] = pair_now ? 1u : 0u; sh_flag[wave] = flag_now ? 1u : 0u; sh_chg[wave] = changed ? 1u : 0u; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -316,7 +353,9 @@ hipError_t launch_row_halves(const void *rows, bool half_rows, uint32_t N, uint3
 // last spreads its blocks evenly over the lists
 uint32_t gemm_list_cap(uint32_t N) { return ((N + 15) / 16 + kGemmLists - 1) / kGemmLists * 16 + 32; }
 uint32_t gemm_chunk_rows(uint32_t N, uint32_t K_pad) {
-  // scores of a chunk: at most 1 GiB, whole multiples of 1024 rows
+  // scores of a chunk: at most 1 GiB, whole multiples of 1024 rows (measured at 2M x 1024, K = 1024: 9.9 ms per pass
+  // with 256K-row chunks, 10.7 with 64K, 12.0 with 16K: the GEMM wants the large n, the score matrix does not stay
+  // in cache either way)
   uint64_t r = (1ull << 28) / (K_pad ? K_pad : 1);
   r = r / 1024 * 1024;
   if (r < 1024) r = 1024;
@@ -337,19 +376,19 @@ hipError_t launch_gemm_decide(const LloydArgs &a, const float *scores, uint32_t 
   return hipGetLastError();
 }
 
-hipError_t launch_gemm_contenders(const LloydArgs &a, uint32_t DG, const uint32_t *und_rows, const uint32_t *und_cont,
-                                  const uint32_t *cursors, hipStream_t st) {
+hipError_t launch_gemm_contenders(int metric, const LloydArgs &a, const float *centroids, uint32_t DG,
+                                  const uint32_t *und_rows, const uint32_t *und_cont, const uint32_t *cursors,
+                                  hipStream_t st) {
   if (a.N == 0) return hipSuccess;
   const bool fast = a.D == DG && (((uintptr_t)a.samples) & 15u) == 0;
   const dim3 grid(64, kGemmLists);
-  if (fast)
-    hipLaunchKernelGGL((gemm_contenders_kernel<true>), grid, dim3(256), 0, st, a.samples, a.D, DG, a.K, a.cfil, a.bias,
-                       a.mu, a.stats, a.eps, a.tie_slack, und_rows, und_cont, gemm_list_cap(a.N), cursors,
-                       a.assignments, a.assignments_prev, a.flagged, a.pairs, a.counters);
-  else
-    hipLaunchKernelGGL((gemm_contenders_kernel<false>), grid, dim3(256), 0, st, a.samples, a.D, DG, a.K, a.cfil, a.bias,
-                       a.mu, a.stats, a.eps, a.tie_slack, und_rows, und_cont, gemm_list_cap(a.N), cursors,
-                       a.assignments, a.assignments_prev, a.flagged, a.pairs, a.counters);
+#define KMX_GC_LAUNCH(M, F)                                                                                          \
+  hipLaunchKernelGGL((gemm_contenders_kernel<M, F>), grid, dim3(256), 0, st, a.samples, a.D, DG, a.K, centroids, a.csqr,  \
+                     a.cfil, a.bias, a.mu, a.stats, a.eps, a.tie_slack, und_rows, und_cont, gemm_list_cap(a.N), cursors, \
+                     a.assignments, a.assignments_prev, a.flagged, a.pairs, a.counters)
+  if (metric == 0) { if (fast) KMX_GC_LAUNCH(0, true); else KMX_GC_LAUNCH(0, false); }
+  else { if (fast) KMX_GC_LAUNCH(1, true); else KMX_GC_LAUNCH(1, false); }
+#undef KMX_GC_LAUNCH
   return hipGetLastError();
 }
 
