@@ -1444,6 +1444,8 @@ class KnnJob {
 // reassignment fraction instead (0.11 = the reference's).
 struct BoundsModel {
   double N, D, K, G, target, force = -1.0;
+  bool wide = false;   // D > 512: the bounds kernels have no matrix-core filter there (exact VALU chains against a
+                       // GEMM-filtered Lloyd pass): they never pay
   std::vector<double> hist;
   BoundsModel(uint32_t n, uint32_t d, uint32_t k, uint32_t g, float tolerance)
       : N(n), D(d), K(k), G(g), target(std::max((double)(tolerance * n), 0.5)) {
@@ -1452,7 +1454,7 @@ struct BoundsModel {
   bool pays(uint32_t changed) {
     hist.push_back((double)changed);
     if (force >= 0) return (double)changed <= force * N;
-    if (hist.size() < 4) return false;
+    if (wide || hist.size() < 4) return false;
     const double a = hist[hist.size() - 4], b = hist.back();
     if (!(b > target) || !(a > b)) return false;   // about to stop, or not decaying: no forecast
     const double rho = std::min(std::pow(b / a, 1.0 / 3.0), 0.995);
@@ -1539,10 +1541,12 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
     // (BoundsModel) -- an assignment pass costs 0.5 ns per row here, a bounds refresh 38 of them.  The strict
     // parity modes keep the reference's schedule.
     const char *yym = getenv("KMCUDA_AMD_YY");
+    const bool wide = job.shards[0]->eng->DP_ == 0 && job.shards[0]->eng->gemm_dp_ != 0;   // D > 512: lloyd_gemm.hip
     const bool adaptive = !(yym && strcmp(yym, "reference") == 0) && !job.exact_update &&
-                          job.shards[0]->eng->DP_ != 0 && job.shards[0]->eng->filter_mode_ == 0;
+                          ((job.shards[0]->eng->DP_ != 0 && job.shards[0]->eng->filter_mode_ == 0) || wide);
     INFO("running Lloyd until reassignments drop below %u\n", (uint32_t)(kYinyangDraftReassignments * samples_size));
     BoundsModel model(samples_size, feats, clusters_size, yy_groups_size, tolerance);
+    model.wide = wide;
     const Job::LeaveFn record = [&model](int, uint32_t changed) { (void)model.pays(changed); return false; };
     int iter = 0;
     RETERR(job.lloyd((float)kYinyangDraftReassignments, &iter, adaptive ? &record : nullptr));
