@@ -118,3 +118,30 @@ def test_wide_rows_whole_run_through_the_boundary():
     numpy.testing.assert_allclose(cen, ocen, rtol=2e-4, atol=2e-4)
     ref, _, _ = oracle.lloyd_assign(x, cen)
     assert (ref == asg).all()     # the returned assignments ARE the reference's for the returned centroids
+
+
+def test_wide_rows_yinyang_schedules(monkeypatch):
+    """yinyang_t > 0 on 768-feature rows: the default schedule keeps running Lloyd passes through the GEMM filter (the
+    bounds kernels have no matrix-core filter at this width); the reference schedule runs the exact Yinyang kernels.
+    Same hand-over point and lines up to it; equally good clusterings."""
+    from kmcuda_amd import kmeans_cuda
+    from test_gpu_kmeans import StdoutListener
+    rs = numpy.random.RandomState(8)
+    centres = rs.rand(24, 768).astype(numpy.float32) * 3
+    x = (centres[rs.randint(0, 24, 5000)] + 0.4 * rs.randn(5000, 768)).astype(numpy.float32)
+    res = {}
+    for schedule in ("default", "reference"):
+        monkeypatch.delenv("KMCUDA_AMD_YY", raising=False)
+        if schedule == "reference":
+            monkeypatch.setenv("KMCUDA_AMD_YY", "reference")
+        out = StdoutListener()
+        with out:
+            c, a = kmeans_cuda(x, 24, init="k-means++", seed=3, tolerance=0.0005, yinyang_t=0.2, device=1, verbosity=1)
+        lines = [ln for ln in out.text.splitlines() if ln.startswith("iteration")]
+        res[schedule] = (lines, c, a, "refreshing Yinyang bounds" in out.text)
+    assert res["reference"][3] or len(res["reference"][0]) == len(res["default"][0])
+    assert not res["default"][3]
+    assert abs(len(res["default"][0]) - len(res["reference"][0])) <= 3
+    assert (res["default"][2] != res["reference"][2]).mean() < 0.02
+    ref, _, _ = oracle.lloyd_assign(x, res["default"][1])
+    assert (ref == res["default"][2]).all()
