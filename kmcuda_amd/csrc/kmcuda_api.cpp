@@ -335,7 +335,11 @@ class Job {
     for (size_t i = 0; i < shards.size() && distinct; i++)
       for (size_t j = 0; j < i; j++)
         if (shards[i]->dev == shards[j]->dev) distinct = false;
-    if (distinct) {
+    // KMCUDA_AMD_FORCE_RCCL=1 (test hook): a ONE-shard job also creates its (one-rank) communicator and sends its
+    // reduce buffer through ncclAllReduce every iteration -- the library loading, the entry points' signatures, the
+    // enum values and the stream the collective is enqueued on get exercised on a box with a single GPU
+    const bool force_rccl = shards.size() == 1 && getenv("KMCUDA_AMD_FORCE_RCCL") && atoi(getenv("KMCUDA_AMD_FORCE_RCCL")) != 0;
+    if (distinct || force_rccl) {
       if (!rccl.load()) {
         INFO("failed to load librccl.so: multi-GPU operation is unavailable\n");
         return kmcudaRuntimeError;
@@ -717,7 +721,7 @@ class Job {
 
   // ---- the per-iteration collective: ONE all-reduce of [delta (fp64 K*D) | dcount K | counters 4] ----
   int allreduce_fused() {
-    if (shards.size() == 1) return 0;
+    if (shards.size() == 1 && comms.empty()) return 0;
     const size_t len = (size_t)K * D + K + 4;
     if (!comms.empty()) {
       if (rccl.GroupStart() != 0) return kmcudaRuntimeError;

@@ -99,11 +99,15 @@ def stop_threshold(tolerance, n_total):
 class ShardedLloyd:
     """kmeans_cuda_lloyd (kmeans.cu:934-1026) over row shards."""
 
-    def __init__(self, backend, n_total, group=None):
+    def __init__(self, backend, n_total, group=None, reduce_always=False):
+        """reduce_always: call the all-reduce also when the group has ONE rank (a test hook: the collective's
+        plumbing -- RCCL on the engine's buffer, its ordering with the engine's stream -- on a single-GPU box)."""
         self.b = backend
         self.n_total = n_total
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if reduce_always and dist.is_initialized():
+            self.world = max(self.world, 2)   # only ever compared with 1 below
         self.buf = backend.new_reduce_buffer()
         self.iterations = 0
         self.stopped = False

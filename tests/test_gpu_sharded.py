@@ -107,3 +107,60 @@ def test_sharded_hip_backend_world2_matches_single(tmp_path):
     numpy.testing.assert_allclose(got["cen"], loop.b.centroids.cpu().numpy(), rtol=1e-6, atol=1e-7)
     ref, _, _ = oracle.lloyd_assign(x, init)
     assert (got["first"] == ref).all()
+
+
+def _rccl_worker(rank, port, out):
+    """ONE rank, backend "nccl" (= RCCL on ROCm): the all-reduce of the loop's fp64 buffer goes through RCCL on the
+    buffer the engine's kernels fill and consume (KMCUDA_AMD reduce_always hook)."""
+    import torch.distributed as dist
+    from kmcuda_amd.distributed import HipBackend, ShardedLloyd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=120))
+    x, init = _data()
+    loop = ShardedLloyd(HipBackend(torch.from_numpy(x).to(dev), len(init), "L2", device_index=0), len(x), reduce_always=True)
+    loop.set_centroids(torch.from_numpy(init).to(dev))
+    log = loop.run(tolerance=0.002, max_iter=60)
+    torch.cuda.synchronize(dev)
+    numpy.savez(out, log=numpy.array(log), asg=loop.b.assignments.cpu().numpy().view(numpy.uint32),
+                cen=loop.b.centroids.cpu().numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_one_rank_all_reduce_in_the_loop(tmp_path):
+    """The collective of a real multi-GPU run, as far as one GPU can go: RCCL (torch's "nccl" backend) reduces the
+    loop's buffer every iteration in a one-rank group; the run must equal the loop without any process group."""
+    import torch.multiprocessing as mp
+    from kmcuda_amd.distributed import HipBackend, ShardedLloyd
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "rccl1.npz")
+    mp.spawn(_rccl_worker, args=(port, out), nprocs=1, join=True)
+    got = numpy.load(out)
+    x, init = _data()
+    dev = torch.device("cuda", 0)
+    loop = ShardedLloyd(HipBackend(torch.from_numpy(x).to(dev), len(init), "L2", device_index=0), len(x))
+    loop.set_centroids(torch.from_numpy(init).to(dev))
+    log = loop.run(tolerance=0.002, max_iter=60)
+    torch.cuda.synchronize(dev)
+    assert list(got["log"]) == log
+    assert (got["asg"] == loop.b.assignments.cpu().numpy().view(numpy.uint32)).all()
+    assert numpy.array_equal(got["cen"], loop.b.centroids.cpu().numpy(), equal_nan=True)
+
+
+def test_rccl_one_rank_inside_kmeans_cuda(monkeypatch):
+    """kmeans_cuda() with KMCUDA_AMD_FORCE_RCCL=1: the library dlopens RCCL, creates a one-rank communicator
+    (ncclCommInitAll) and sends every iteration's reduce buffer through a grouped ncclAllReduce on the shard's stream --
+    the multi-GPU code path's calls, signatures and enum values on a single GPU.  Same run as without."""
+    from kmcuda_amd import kmeans_cuda
+    x, _ = _data()
+    c0, a0 = kmeans_cuda(x, 24, init="k-means++", seed=5, tolerance=0.002, yinyang_t=0, device=1)
+    monkeypatch.setenv("KMCUDA_AMD_FORCE_RCCL", "1")
+    c1, a1 = kmeans_cuda(x, 24, init="k-means++", seed=5, tolerance=0.002, yinyang_t=0, device=1)
+    assert (a0 == a1).all()
+    assert numpy.array_equal(c0, c1, equal_nan=True)
