@@ -264,9 +264,10 @@ hipError_t launch_knn_gather(const float *samples, uint32_t N, uint32_t D, uint3
                              float *xs, float *n2s, uint32_t *stats, hipStream_t st);
 hipError_t launch_knn_prep(int metric, const float *xs, uint32_t N, uint32_t D, uint32_t DP, const uint32_t *offsets,
                            uint32_t K, const float *centroids, float *mydist, float *rdist, float *R, float *C,
-                           hipStream_t st);
+                           bool strict_h2, hipStream_t st);
 hipError_t launch_knn_filter(int metric, const KnnArgs &a, uint32_t nblocks, hipStream_t st);
-hipError_t launch_knn_exact(int metric, const KnnArgs &a, hipStream_t st);
+// strict_h2 (both): the reference's half2 arithmetic on rows that hold half values (KMCUDA_AMD_FP16_STRICT)
+hipError_t launch_knn_exact(int metric, const KnnArgs &a, bool strict_h2, hipStream_t st);
 hipError_t launch_knn_split(int metric, const float *xs, uint32_t N, uint32_t D, uint32_t DP, const float *mu,
                             void *xs16, float *n2c, float *mux, float *kbias, uint32_t *stats, hipStream_t st);
 hipError_t launch_knn_filter_f16(int metric, const KnnArgs &a, uint32_t nblocks, hipStream_t st);

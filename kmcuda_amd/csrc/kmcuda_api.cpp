@@ -1201,7 +1201,13 @@ class KnnJob {
       }
     }
     const char *force_exact = getenv("KMCUDA_AMD_KNN_EXACT");
-    const uint32_t dp_filter = (force_exact && atoi(force_exact)) ? 0 : filter_dp_for(D);
+    // KMCUDA_AMD_FP16_STRICT (fp16x2 only): radii, centroid distances and every candidate distance in the reference's
+    // half2 arithmetic (knn.hip, half2_ops.hpp) -- the verification mode of half2_strict.hip for this entry point;
+    // no matrix-core filter (its bound is stated against the fp32 arithmetic)
+    const char *strict_env = getenv("KMCUDA_AMD_FP16_STRICT");
+    const bool strict_h2 = fp16 && strict_env && atoi(strict_env) != 0;
+    if (strict_h2) INFO("k-NN: the reference's half2 arithmetic (KMCUDA_AMD_FP16_STRICT)\n");
+    const uint32_t dp_filter = ((force_exact && atoi(force_exact)) || strict_h2) ? 0 : filter_dp_for(D);
     const uint32_t DP = dp_filter ? dp_filter : D;
     if (!dp_filter) INFO("k-NN: every candidate is evaluated with the exact arithmetic (no matrix-core filter)\n");
     // which matrix-core instruction filters the candidates: f16 on centred hi/lo-split rows (default,
@@ -1303,7 +1309,7 @@ class KnnJob {
     for (auto &s : shards) {
       (void)hipSetDevice(s->dev);
       if (launch_knn_prep(metric, s->xs, N, D, DP, s->offsets, K, s->centroids, s->mydist, s->rdist, s->R, s->C,
-                          s->stream) != hipSuccess)
+                          strict_h2, s->stream) != hipSuccess)
         return kmcudaRuntimeError;
     }
     // ---- the block list: KNN_QPB_* consecutive sorted positions of one cluster per block ----
@@ -1362,7 +1368,7 @@ class KnnJob {
       a.eps = (float)(1.02 * ((double)D + 12.0) * ldexp(1.0, -24));  // as the Lloyd filter
       a.heaps = s.heaps; a.out = s.out; a.calced = s.calced;
       a.xs16 = s.xs16; a.mux = s.mux; a.kbias = s.kbias; a.mu2 = mu2;
-      const hipError_t e = !dp_filter ? launch_knn_exact(metric, a, s.stream)
+      const hipError_t e = !dp_filter ? launch_knn_exact(metric, a, strict_h2, s.stream)
                            : use_f16 ? launch_knn_filter_f16(metric, a, s.nblocks, s.stream)
                                      : launch_knn_filter(metric, a, s.nblocks, s.stream);
       if (e != hipSuccess) return kmcudaRuntimeError;

@@ -29,6 +29,7 @@
 // knn_exact_kernel is the same search with every candidate evaluated exactly (no filter): the
 // in-library cross-check, and the path for feature counts the filter is not instantiated for.
 #include "exact.hpp"
+#include "half2_ops.hpp"
 #include "kernels.hpp"
 #include "knn_heap.hpp"
 
@@ -77,8 +78,10 @@ __device__ __forceinline__ uint32_t cluster_of(const uint32_t *__restrict__ offs
 }
 
 // metric_abstraction.h:103-118 partial (L2: Kahan sum of squared differences; angular: Kahan dot)
-template <int METRIC>
+// H2 (KMCUDA_AMD_FP16_STRICT): the same with F = half2 (half2_ops.hpp; the rows hold half values, n is even)
+template <int METRIC, bool H2 = false>
 __device__ __forceinline__ float partial_vv(const float *__restrict__ a, const float *__restrict__ b, uint32_t n) {
+  if constexpr (H2) return h2_partial<METRIC>(a, b, n);
   float acc = 0.f, corr = 0.f;
   for (uint32_t f = 0; f < n; f++) {
     if (METRIC == 0) {
@@ -99,7 +102,7 @@ __device__ __forceinline__ float finalize(float p) {  // metric_abstraction.h:13
 // prep 2: per member, distance to its own centroid (knn.cu:190-191, distance_t) and the CHUNKED
 // distance the radius is built from (knn.cu:31-45: 16-feature partials added with plain '+')
 // ---------------------------------------------------------------------------------------
-template <int METRIC>
+template <int METRIC, bool H2>
 __global__ void knn_member_kernel(const float *__restrict__ xs, uint32_t N, uint32_t D, uint32_t DP,
                                   const uint32_t *__restrict__ offsets, uint32_t K,
                                   const float *__restrict__ centroids, float *__restrict__ mydist,
@@ -113,12 +116,14 @@ __global__ void knn_member_kernel(const float *__restrict__ xs, uint32_t N, uint
     return;
   }
   const float *x = xs + (size_t)p * DP, *cen = centroids + (size_t)c * D;
-  mydist[p] = finalize<METRIC>(partial_vv<METRIC>(x, cen, D));
-  const uint32_t step = D < 16 ? D : 16;  // CLUSTER_RADIUSES_SHMEM / blockDim = 8192 / 512
+  // (half2: distance_t rounds the angle to half, finalize does not -- metric_abstraction.h:171-177 vs :248-253)
+  mydist[p] = H2 ? h2_distance<METRIC>(x, cen, D) : finalize<METRIC>(partial_vv<METRIC>(x, cen, D));
+  // CLUSTER_RADIUSES_SHMEM / blockDim = 8192 / 512 = 16 elements of F: 16 features, or 16 half2 = 32 halves
+  const uint32_t step = H2 ? (D < 32 ? D : 32) : (D < 16 ? D : 16);
   float sd = 0.f;
   for (uint32_t cfi = 0; cfi < D; cfi += step) {
     const uint32_t fsize = (D - cfi) < step ? (D - cfi) : step;
-    sd += partial_vv<METRIC>(x + cfi, cen + cfi, fsize);
+    sd += partial_vv<METRIC, H2>(x + cfi, cen + cfi, fsize);
   }
   rdist[p] = finalize<METRIC>(sd);
 }
@@ -142,16 +147,17 @@ __global__ __launch_bounds__(64) void knn_radii_kernel(const float *__restrict__
 }
 
 // knn.cu:61-131: K x K centroid distances from 24-feature partials (12288 / 512), finalized.
-template <int METRIC>
+template <int METRIC, bool H2>
 __global__ void knn_cdist_kernel(const float *__restrict__ centroids, uint32_t K, uint32_t D, float *__restrict__ C) {
   const uint32_t jb = (K + blockDim.x - 1) / blockDim.x;  // 1-D grid: K may exceed the grid.y limit
   const uint32_t i = blockIdx.x / jb, j = (blockIdx.x % jb) * blockDim.x + threadIdx.x;
   if (j >= K) return;
   const float *a = centroids + (size_t)i * D, *b = centroids + (size_t)j * D;
   float acc = 0.f;
-  for (uint32_t fpos = 0; fpos < D; fpos += 24) {
-    const uint32_t fsize = (D - fpos) < 24 ? (D - fpos) : 24;
-    acc += partial_vv<METRIC>(a + fpos, b + fpos, fsize);
+  constexpr uint32_t kStep = H2 ? 48 : 24;   // 24 elements of F (half2: 48 halves)
+  for (uint32_t fpos = 0; fpos < D; fpos += kStep) {
+    const uint32_t fsize = (D - fpos) < kStep ? (D - fpos) : kStep;
+    acc += partial_vv<METRIC, H2>(a + fpos, b + fpos, fsize);
   }
   C[(size_t)i * K + j] = finalize<METRIC>(acc);
 }
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void knn_filter_kernel(KnnArgs a) {
 // ---------------------------------------------------------------------------------------
 // the unfiltered search: one thread per sorted position, every candidate evaluated exactly
 // ---------------------------------------------------------------------------------------
-template <int METRIC>
+template <int METRIC, bool H2>
 __global__ __launch_bounds__(64) void knn_exact_kernel(KnnArgs a) {
   const uint32_t qp = a.p_base + blockIdx.x * blockDim.x + threadIdx.x;
   if (qp >= a.p_end) return;
@@ -417,7 +423,8 @@ __global__ __launch_bounds__(64) void knn_exact_kernel(KnnArgs a) {
     calced += end - beg;
     for (uint32_t cp = beg; cp < end; cp++) {
       if (cp == qp) continue;
-      const float dist = finalize<METRIC>(partial_vv<METRIC>(x, a.xs + (size_t)cp * DP, D));
+      const float dist = H2 ? h2_distance<METRIC>(x, a.xs + (size_t)cp * DP, D)   // distance_tt, F = half2
+                            : finalize<METRIC>(partial_vv<METRIC>(x, a.xs + (size_t)cp * DP, D));
       if (dist <= mndist) {
         knn_push_sample(k, dist, a.inv[cp], heap);
         mndist = heap[0];
@@ -454,16 +461,19 @@ hipError_t launch_knn_gather(const float *samples, uint32_t N, uint32_t D, uint3
 
 hipError_t launch_knn_prep(int metric, const float *xs, uint32_t N, uint32_t D, uint32_t DP, const uint32_t *offsets,
                            uint32_t K, const float *centroids, float *mydist, float *rdist, float *R, float *C,
-                           hipStream_t st) {
+                           bool strict_h2, hipStream_t st) {
+#define KMX_KNN_PREP(M, H)                                                                                          \
+  do {                                                                                                              \
+    hipLaunchKernelGGL((knn_member_kernel<M, H>), dim3((N + 127) / 128), dim3(128), 0, st, xs, N, D, DP, offsets, K, \
+                       centroids, mydist, rdist);                                                                   \
+    hipLaunchKernelGGL((knn_cdist_kernel<M, H>), dim3(((K + 127) / 128) * K), dim3(128), 0, st, centroids, K, D, C); \
+  } while (0)
   if (metric == 0) {
-    hipLaunchKernelGGL((knn_member_kernel<0>), dim3((N + 127) / 128), dim3(128), 0, st, xs, N, D, DP, offsets, K,
-                       centroids, mydist, rdist);
-    hipLaunchKernelGGL((knn_cdist_kernel<0>), dim3(((K + 127) / 128) * K), dim3(128), 0, st, centroids, K, D, C);
+    if (strict_h2) KMX_KNN_PREP(0, true); else KMX_KNN_PREP(0, false);
   } else {
-    hipLaunchKernelGGL((knn_member_kernel<1>), dim3((N + 127) / 128), dim3(128), 0, st, xs, N, D, DP, offsets, K,
-                       centroids, mydist, rdist);
-    hipLaunchKernelGGL((knn_cdist_kernel<1>), dim3(((K + 127) / 128) * K), dim3(128), 0, st, centroids, K, D, C);
+    if (strict_h2) KMX_KNN_PREP(1, true); else KMX_KNN_PREP(1, false);
   }
+#undef KMX_KNN_PREP
   hipLaunchKernelGGL(knn_radii_kernel, dim3(K), dim3(64), 0, st, rdist, offsets, K, R);
   return hipGetLastError();
 }
@@ -492,11 +502,16 @@ hipError_t launch_knn_filter(int metric, const KnnArgs &a, uint32_t nblocks, hip
 #undef KMX_KNN_CASE
 }
 
-hipError_t launch_knn_exact(int metric, const KnnArgs &a, hipStream_t st) {
+hipError_t launch_knn_exact(int metric, const KnnArgs &a, bool strict_h2, hipStream_t st) {
   if (a.p_end <= a.p_base) return hipSuccess;
   const uint32_t grid = (a.p_end - a.p_base + 63) / 64;
-  if (metric == 0) hipLaunchKernelGGL((knn_exact_kernel<0>), dim3(grid), dim3(64), 0, st, a);
-  else hipLaunchKernelGGL((knn_exact_kernel<1>), dim3(grid), dim3(64), 0, st, a);
+  if (metric == 0) {
+    if (strict_h2) hipLaunchKernelGGL((knn_exact_kernel<0, true>), dim3(grid), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((knn_exact_kernel<0, false>), dim3(grid), dim3(64), 0, st, a);
+  } else {
+    if (strict_h2) hipLaunchKernelGGL((knn_exact_kernel<1, true>), dim3(grid), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((knn_exact_kernel<1, false>), dim3(grid), dim3(64), 0, st, a);
+  }
   return hipGetLastError();
 }
 

@@ -209,13 +209,21 @@ def _kmeans(samples, clusters, tolerance, init, yinyang_t, metric, average_dista
     return out
 
 
-def knn(k, samples, centroids, assignments, metric="L2"):
+def knn(k, samples, centroids, assignments, metric="L2", half2=False):
+    """knn_cuda on the CPU oracle.  half2=True (float16 samples and centroids): the reference's half2 arithmetic
+    (fp_abstraction.h:100-182) for the radii, the centroid distances and every candidate distance."""
+    if half2 and not (samples.dtype == np.float16 and centroids.dtype == np.float16):
+        raise ValueError("half2 arithmetic needs float16 samples and centroids")
     x, c = _c32(samples), _c32(centroids)
     a = np.ascontiguousarray(assignments, dtype=np.uint32)
     nb = np.empty((x.shape[0], k), np.uint32)
     calced = ctypes.c_uint64(0)
-    rc = lib().kmo_knn(k, _metric(metric), x.shape[0], x.shape[1], c.shape[0], _fp(x), _fp(c),
-                       _up(a), _up(nb), ctypes.byref(calced))
+    lib().kmo_set_fp16_mode(2 if half2 else 0)
+    try:
+        rc = lib().kmo_knn(k, _metric(metric), x.shape[0], x.shape[1], c.shape[0], _fp(x), _fp(c),
+                           _up(a), _up(nb), ctypes.byref(calced))
+    finally:
+        lib().kmo_set_fp16_mode(0)
     if rc:
         raise ValueError("kmo_knn failed: %d" % rc)
     return nb, calced.value

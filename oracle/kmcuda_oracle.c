@@ -1059,6 +1059,15 @@ void kmo_knn_inverse(uint32_t N, uint32_t K, const uint32_t *assignments, uint32
 
 /* metric_abstraction.h:103-136 / :220-253: partial / finalize */
 static float knn_partial(int metric, const float *a, const float *b, uint32_t n) {
+  if (g_fp16_mode == 2) {                             /* F = half2: two interleaved half sums, _float(_fin(.)) */
+    float s[2] = {0.f, 0.f}, c[2] = {0.f, 0.f};
+    for (uint32_t f = 0; f + 1 < n; f += 2)
+      for (int l = 0; l < 2; l++) {
+        if (metric == KMO_L2) { const float d = h_sub(a[f + l], b[f + l]); H2_KAHAN(s[l], c[l], d, d); }
+        else H2_KAHAN(s[l], c[l], a[f + l], b[f + l]);
+      }
+    return h_add(s[1], s[0]);
+  }
   if (metric == KMO_L2) return kahan_sqdiff(a, b, n);
   return kmo_kahan_dot(a, b, n);
 }
@@ -1071,7 +1080,9 @@ static float knn_finalize(int metric, float p) {
 void kmo_knn_radiuses(int metric, uint32_t N, uint32_t D, uint32_t K, const float *samples,
                       const float *centroids, const uint32_t *inv, const uint32_t *offsets, float *radiuses) {
   (void)N;
-  const uint32_t cent_step = D < 16 ? D : 16;
+  /* 16 elements of F: with F = half2 (D counts halves here) that is 32 halves */
+  const uint32_t fstep16 = g_fp16_mode == 2 ? 32 : 16;
+  const uint32_t cent_step = D < fstep16 ? D : fstep16;
 #pragma omp parallel for schedule(dynamic, 4)
   for (uint32_t ci = 0; ci < K; ci++) {
     float max_dist = -1.f;
@@ -1091,7 +1102,7 @@ void kmo_knn_radiuses(int metric, uint32_t N, uint32_t D, uint32_t K, const floa
 
 /* knn.cu:61-131: fstep = 12288/512 = 24-feature chunks, distances += partial; finalize; mirror */
 void kmo_knn_cluster_distances(int metric, uint32_t D, uint32_t K, const float *centroids, float *dists) {
-  const uint32_t fstep = 24;
+  const uint32_t fstep = g_fp16_mode == 2 ? 48 : 24;   /* 24 elements of F */
 #pragma omp parallel for schedule(static)
   for (uint32_t i = 0; i < K; i++) {
     for (uint32_t j = 0; j < K; j++) {

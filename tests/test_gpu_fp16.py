@@ -255,3 +255,31 @@ def test_fp16_strict_wider_rows_equal_the_half2_oracle(monkeypatch):
     assert (a == ra).all()
     assert numpy.array_equal(c.view(numpy.uint16), rc.view(numpy.uint16))
     assert abs(avg - ravg) < 1e-6 * max(1.0, abs(ravg))
+
+
+@pytest.mark.parametrize("metric", ["L2", "cos"])
+def test_fp16_strict_knn_equals_the_half2_oracle(monkeypatch, metric):
+    """knn_cuda under KMCUDA_AMD_FP16_STRICT=1 (knn.cu:19-243 with F = half2: radii from 16-half2 partials,
+    centroid distances from 24-half2 partials, distance_tt per candidate; half distances tie constantly, so the
+    lists also pin the reference's visiting order and heap): neighbour lists equal to the half2 oracle's."""
+    from kmcuda_amd import kmeans_cuda, knn_cuda
+    rs = numpy.random.RandomState(11)
+    x = rs.rand(3000, 64).astype(numpy.float32)
+    if metric == "cos":
+        x /= numpy.linalg.norm(x, axis=1, keepdims=True)
+    x = x.astype(numpy.float16)
+    c, a = kmeans_cuda(x, 24, init="random", seed=3, tolerance=0.02, yinyang_t=0, metric=metric, device=1)
+    assert c.dtype == numpy.float16
+    monkeypatch.setenv("KMCUDA_AMD_FP16_STRICT", "1")
+    nb = knn_cuda(10, x, c, a, metric=metric, device=1)
+    ref, calced = oracle.knn(10, x, c, a, metric=metric, half2=True)
+    if metric == "L2":
+        assert (nb == ref).all()
+    else:
+        # acosf is libm on the oracle and ocml here; a half-rounded angle differs only when the two land on
+        # different sides of a half rounding boundary
+        assert (nb == ref).mean() > 0.999
+    # and the mode matters: the default fp16 semantics (fp32 arithmetic on the half values) give other lists
+    monkeypatch.delenv("KMCUDA_AMD_FP16_STRICT")
+    plain = knn_cuda(10, x, c, a, metric=metric, device=1)
+    assert (plain != ref).any()

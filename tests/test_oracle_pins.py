@@ -256,3 +256,105 @@ def test_half2_vs_storage_semantics(fixture13k):
     assert len(p[2]) == len(q[2]) == 2           # first pass (13000 changes), one update, second pass
     assert (p[1] != q[1]).mean() < 0.012         # measured 0.78 %
     assert abs(p[0].astype(numpy.float32) - q[0].astype(numpy.float32)).max() < 0.02
+
+
+def _np_h2_kahan_lanes(a, b, l2):
+    """numpy restatement of one half2 Kahan chain over halves a, b (even length): two interleaved accumulators,
+    every operation rounded once to binary16 (products of halves are exact in float64)."""
+    h = numpy.float16
+    s, c = [h(0), h(0)], [h(0), h(0)]
+    for f in range(0, len(a) - 1, 2):
+        for l in range(2):
+            if l2:
+                d = h(a[f + l]) - h(b[f + l])
+                p, q = d, d
+            else:
+                p, q = h(a[f + l]), h(b[f + l])
+            y = h(numpy.float64(p) * numpy.float64(q) + numpy.float64(c[l]))   # __hfma2: one rounding
+            t = h(s[l] + y)
+            c[l] = h(y - h(t - s[l]))
+            s[l] = t
+    return numpy.float32(h(s[1] + s[0]))   # _float(_fin(.))
+
+
+@pytest.mark.parametrize("metric", ["L2", "cos"])
+def test_half2_knn_against_a_numpy_restatement(metric):
+    """knn_cuda with F = half2 (knn.cu:19-243): radii from 16-half2 partials, centroid distances from 24-half2
+    partials, candidate distances by distance_tt -- a small case restated in numpy float16, lists equal."""
+    rs = numpy.random.RandomState(5)
+    n, d, kc, k = 90, 80, 4, 3          # 80 halves = 40 half2: chunks of 16 + 16 + 8 and 24 + 16
+    x = rs.rand(n, d).astype(numpy.float32)
+    if metric == "cos":
+        x /= numpy.linalg.norm(x, axis=1, keepdims=True)
+    x = x.astype(numpy.float16)
+    cen = x[:kc].copy()
+    a = (numpy.arange(n) % kc).astype(numpy.uint32)
+    l2 = metric == "L2"
+
+    def fin(p):
+        p = numpy.float32(p)
+        if l2:
+            return numpy.sqrt(p, dtype=numpy.float32)
+        return numpy.float32(0) if p >= 1 else (numpy.float32(numpy.pi) if p <= -1 else numpy.arccos(p, dtype=numpy.float32))
+
+    def dist(u, v):   # distance_t / distance_tt
+        p = _np_h2_kahan_lanes(u, v, l2)
+        if l2:
+            return numpy.sqrt(p, dtype=numpy.float32)
+        ang = numpy.float32(0) if p >= 1 else (numpy.float32(numpy.pi) if p <= -1 else numpy.arccos(p, dtype=numpy.float32))
+        return numpy.float32(numpy.float16(ang))    # Cosine::distance returns a HALF
+
+    def chunked(u, v, step):
+        acc = numpy.float32(0)
+        for f0 in range(0, d, step):
+            acc = numpy.float32(acc + _np_h2_kahan_lanes(u[f0:f0 + step], v[f0:f0 + step], l2))
+        return fin(acc)
+
+    members = [numpy.nonzero(a == c)[0] for c in range(kc)]
+    radii = [max(chunked(x[s], cen[c], 32) for s in members[c]) for c in range(kc)]
+    cd = [[chunked(cen[i], cen[j], 48) for j in range(kc)] for i in range(kc)]
+    want = numpy.empty((n, k), numpy.uint32)
+    for s in range(n):
+        mine = int(a[s])
+        md = dist(x[s], cen[mine])
+        heap_d = [numpy.float32(3.4028235e38)] * k   # knn.cu:133-175: max-heap of (distance, index), replace-root
+        heap_i = [0] * k
+
+        def push(dd, idx):
+            pos = 0
+            while True:
+                li, ri = 2 * pos + 1, 2 * pos + 2
+                left_le = dd >= heap_d[li] if li < k else True
+                right_le = dd >= heap_d[ri] if ri < k else True
+                if left_le and right_le:
+                    heap_d[pos], heap_i[pos] = dd, idx
+                    return
+                if not left_le and not right_le:
+                    go = ri if heap_d[li] <= heap_d[ri] else li
+                else:
+                    go = ri if left_le else li
+                heap_d[pos], heap_i[pos] = heap_d[go], heap_i[go]
+                pos = go
+
+        def visit(o):
+            dd = dist(x[s], x[o])
+            if dd <= heap_d[0]:
+                push(dd, o)
+        for o in members[mine]:
+            if o != s:
+                visit(o)
+        for c in range(kc):
+            if c == mine or cd[c][mine] != cd[c][mine]:
+                continue
+            if cd[c][mine] - md - radii[c] > heap_d[0]:
+                continue
+            for o in members[c]:
+                visit(o)
+        for i in range(k - 1, -1, -1):
+            want[s, i] = heap_i[0]
+            push(numpy.float32(-1), 0xFFFFFFFF)
+    got, _ = oracle.knn(k, x, cen, a, metric=metric, half2=True)
+    assert (got == want).all()
+    # the mode is reset: an fp32 call afterwards is the fp32 arithmetic
+    plain, _ = oracle.knn(k, x.astype(numpy.float32), cen.astype(numpy.float32), a, metric=metric)
+    assert plain.shape == got.shape
