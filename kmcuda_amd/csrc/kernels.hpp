@@ -237,7 +237,12 @@ hipError_t launch_yy_local_filter(int metric, const float *samples, uint32_t len
 #define KNN16_PD 3              // candidate fragments in flight per wave
 #endif
 #define KNN16_PAD_ROWS 64   // rows of xs16 / entries of kbias the caller allocates (and the split zeroes) past N
-constexpr uint32_t KNN_QPB_F32 = 128, KNN_QPB_F16 = KNN16_WAVES * KNN16_NSET * 32;
+// rows wider than 256 features (DP = 512): ONE operand set per wave (a lane's half of a 512-feature row in halves
+// is 128 registers) and one 32-candidate sub-tile per staged tile (32 KB)
+constexpr int knn16_nset(int DP) { return DP > 256 ? 1 : KNN16_NSET; }
+constexpr int knn16_sub(int DP) { return DP > 256 ? 1 : KNN16_SUB; }
+constexpr uint32_t KNN_QPB_F32 = 128;
+constexpr uint32_t knn_qpb_f16(uint32_t DP) { return KNN16_WAVES * (uint32_t)knn16_nset((int)DP) * 32u; }
 struct KnnArgs {
   const float *xs;          // N x DP cluster-sorted rows (zero padded to DP)
   const float *n2s;         // N plain squared norms of the sorted rows

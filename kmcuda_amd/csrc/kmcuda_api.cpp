@@ -1207,13 +1207,16 @@ class KnnJob {
     const char *strict_env = getenv("KMCUDA_AMD_FP16_STRICT");
     const bool strict_h2 = fp16 && strict_env && atoi(strict_env) != 0;
     if (strict_h2) INFO("k-NN: the reference's half2 arithmetic (KMCUDA_AMD_FP16_STRICT)\n");
-    const uint32_t dp_filter = ((force_exact && atoi(force_exact)) || strict_h2) ? 0 : filter_dp_for(D);
+    const char *fenv = getenv("KMCUDA_AMD_FILTER");
+    const bool want_f32 = fenv && strcmp(fenv, "f32") == 0;
+    uint32_t dp_filter = ((force_exact && atoi(force_exact)) || strict_h2) ? 0 : filter_dp_for(D);
+    // 256 < D <= 512: the f16 filter's one-operand-set instantiation (knn_f16.hip; the f32 filter stops at 256)
+    if (!dp_filter && !(force_exact && atoi(force_exact)) && !strict_h2 && !want_f32 && D > 256 && D <= 512) dp_filter = 512;
     const uint32_t DP = dp_filter ? dp_filter : D;
     if (!dp_filter) INFO("k-NN: every candidate is evaluated with the exact arithmetic (no matrix-core filter)\n");
     // which matrix-core instruction filters the candidates: f16 on centred hi/lo-split rows (default,
     // needs DP >= 16) or f32 (KMCUDA_AMD_FILTER=f32)
-    const char *fenv = getenv("KMCUDA_AMD_FILTER");
-    const bool use_f16 = dp_filter >= 16 && !(fenv && strcmp(fenv, "f32") == 0);
+    const bool use_f16 = dp_filter >= 16 && !want_f32;
     // mu = mean of the finite centroid rows (any vector works: distances are translation invariant)
     std::vector<float> mu_host(DP, 0.f);
     float mu2 = 0.f;
@@ -1322,7 +1325,7 @@ class KnnJob {
         return kmcudaMemoryCopyError;
     }
     std::vector<uint32_t> blocks;  // (cluster, first position) pairs
-    const uint32_t qpb = use_f16 ? KNN_QPB_F16 : KNN_QPB_F32;
+    const uint32_t qpb = use_f16 ? knn_qpb_f16(DP) : KNN_QPB_F32;
     for (uint32_t c = 0; c < K; c++)
       for (uint32_t p = offsets[c]; p < offsets[c + 1]; p += qpb) {
         blocks.push_back(c);

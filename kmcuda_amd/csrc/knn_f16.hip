@@ -105,11 +105,11 @@ __global__ __launch_bounds__(256) void knn_split_kernel(const float *__restrict_
 // profiles/r2e_knn_filter_phase_counters.log, r2e_knn_filter_block_timeline.log.
 template <int DP, int METRIC, bool FASTX>
 __global__ __launch_bounds__(KNN16_WAVES * 64, KNN16_BLOCKS_PER_CU) void knn_filter_f16_kernel(KnnArgs a) {
-  constexpr int WV = KNN16_WAVES, NSET = KNN16_NSET;
+  constexpr int WV = KNN16_WAVES, NSET = knn16_nset(DP);
   constexpr int NKH = DP / 2;   // features per half-wave
   constexpr int KS = NKH / 8;   // k-steps = 16-byte chunks per half row
   constexpr int ROWB = DP * 2;  // bytes of one candidate row (DP halves)
-  constexpr int SUB = KNN16_SUB;            // 32-candidate sub-tiles per staged tile (= per barrier)
+  constexpr int SUB = knn16_sub(DP);        // 32-candidate sub-tiles per staged tile (= per barrier)
   constexpr int TILEB = 32 * SUB * ROWB;
   constexpr int NP = (TILEB + 1023) / 1024;   // 1-KB LDS-DMA pieces per tile
   constexpr int SWM = (KS < 16 ? KS : 16) - 1;
@@ -467,7 +467,7 @@ hipError_t launch_knn_split(int metric, const float *xs, uint32_t N, uint32_t D,
 
 template <int DP, int METRIC>
 static hipError_t launch_knn_f16_t(const KnnArgs &a, uint32_t nblocks, hipStream_t st) {
-  const size_t lds_bytes = (size_t)KNN16_NBUF * (32 * KNN16_SUB * DP * 2) + KNN16_NBUF * 256 + 2 * KNN16_WAVES * 4;
+  const size_t lds_bytes = (size_t)KNN16_NBUF * (32 * knn16_sub(DP) * DP * 2) + KNN16_NBUF * 256 + 2 * KNN16_WAVES * 4;
   if (lds_bytes > 65536) {   // (per launch: the attribute belongs to the current device's copy of the kernel)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_filter_f16_kernel<DP, METRIC, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -494,6 +494,7 @@ hipError_t launch_knn_filter_f16(int metric, const KnnArgs &a, uint32_t nblocks,
     KMX_KNN16_CASE(64);
     KMX_KNN16_CASE(128);
     KMX_KNN16_CASE(256);
+    KMX_KNN16_CASE(512);
     default: return hipErrorInvalidValue;
   }
 #undef KMX_KNN16_CASE

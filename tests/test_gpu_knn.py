@@ -98,7 +98,8 @@ def test_device_ptr(clustered13k):
 
 
 @pytest.mark.parametrize("n,d,K,k", [(8000, 48, 160, 10), (6000, 256, 64, 10), (5000, 7, 40, 3), (3000, 100, 20, 33),
-                                     (2000, 300, 16, 5)])
+                                     (2000, 300, 16, 5),            # 256 < D <= 512: the one-operand-set f16 filter
+                                     (3000, 512, 24, 10), (2500, 400, 300, 4), (1500, 640, 12, 6)])   # 640: exact search
 @pytest.mark.parametrize("filt", ["f16", "f32"])
 def test_matches_oracle_bit_exact(n, d, K, k, filt, monkeypatch):
     from kmcuda_amd import knn_cuda
