@@ -149,8 +149,17 @@ hipError_t launch_kmpp_step2(int metric, const float *samples, uint32_t N, uint3
                              hipStream_t st);
 hipError_t launch_kmpp_choose(const float *dists, uint32_t N, const double *bpre, uint32_t choice_approx,
                               double choice_sum, void *totals_host, hipStream_t st);
+// filtered k-means++ steps (L2; seeding.hip): the centred half copy of the rows, then per step the survivors of
+// the k-NN candidate bound get the exact chain.  DP: D rounded up to 64; stats: 4 words ([2..3]: exact chains run so far, 64 bits); list: N words.
+hipError_t launch_kmpp_cache(const float *samples, uint32_t N, uint32_t D, uint32_t DP, double *part, float *mu,
+                             void *xs16, float *n2c, uint32_t *stats, hipStream_t st);
+hipError_t launch_kmpp_step_filtered(const float *samples, uint32_t N, uint32_t D, uint32_t DP, const void *xs16,
+                                     const float *n2c, const float *mu, uint32_t *stats, uint32_t *list,
+                                     const float *centroid, uint32_t cc, float *dists, void *block_stats, double *bpre,
+                                     void *totals_host, hipStream_t st);
 size_t kmpp_block_stat_bytes(uint32_t N);
 size_t kmpp_blocks(uint32_t N);
+size_t kmpp_prefix_doubles(uint32_t N);   // doubles of `bpre`
 // AFK-MC2 seeding (seeding.hip; reference kmeans.cu:69-212)
 hipError_t launch_afk_qdist(int metric, const float *samples, uint32_t N, uint32_t D, const float *c1, float *dists,
                             hipStream_t st);

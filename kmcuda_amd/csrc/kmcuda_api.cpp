@@ -501,7 +501,8 @@ class Job {
         // holds a NaN / inf distance) takes the host way.
         float *host_dists = nullptr;
         struct HostFree { float **p; ~HostFree() { if (*p) (void)hipHostFree(*p); } } host_dists_guard{&host_dists};
-        const bool device_chooser = shards.size() == 1 && !strict_h2 && getenv("KMCUDA_AMD_KMPP_HOST") == nullptr;
+        const bool device_chooser = shards.size() == 1 && !strict_h2 && getenv("KMCUDA_AMD_KMPP_HOST") == nullptr &&
+                                    kmpp_blocks(N) <= (1u << 20);   // (two-level prefix: 1024 x 1024 blocks of 256 rows)
         struct Totals { double sum_g, sum_d; uint32_t emin, emax, bad, chosen; };
         Totals *totals_host = nullptr;
         struct TotalsFree { Totals **p; ~TotalsFree() { if (*p) (void)hipHostFree(*p); } } totals_guard{&totals_host};
@@ -514,11 +515,55 @@ class Job {
           int rc;
           if ((rc = s.alloc(&bs, kmpp_block_stat_bytes(N)))) return rc;
           if ((rc = s.alloc(&td, sizeof(Totals)))) return rc;
-          if ((rc = s.alloc(&bpre, kmpp_blocks(N) + 1))) return rc;
+          if ((rc = s.alloc(&bpre, kmpp_prefix_doubles(N)))) return rc;
           block_stats = bs;
           totals_dev = td;
           if (hipHostMalloc(reinterpret_cast<void **>(&totals_host), sizeof(Totals), hipHostMallocDefault) != hipSuccess)
             return kmcudaMemoryAllocationFailure;
+        }
+        // Filtered steps (L2, seeding.hip): a centred half copy of the rows; a step's first kernel drops every row
+        // that provably is no closer to the new seed than to an earlier one, the exact chains run for the rest.
+        // Needs 2 DP + 8 bytes per row beside the rows; without that memory (or KMCUDA_AMD_KMPP_FILTER=0) every
+        // step is the plain one.  Same dists[] after every step either way, hence the same seeds.
+        const uint32_t kpp_dp = ((uint32_t)D + 63u) / 64u * 64u;
+        void *kpp_xs16 = nullptr;
+        float *kpp_n2c = nullptr, *kpp_mu = nullptr;
+        uint32_t *kpp_stats = nullptr, *kpp_list = nullptr;
+        double *kpp_part = nullptr;
+        struct KppFree {
+          void **a; float **b, **c; uint32_t **d, **e; double **f;
+          ~KppFree() {
+            if (*a) (void)hipFree(*a);
+            if (*b) (void)hipFree(*b);
+            if (*c) (void)hipFree(*c);
+            if (*d) (void)hipFree(*d);
+            if (*e) (void)hipFree(*e);
+            if (*f) (void)hipFree(*f);
+          }
+        } kpp_guard{&kpp_xs16, &kpp_n2c, &kpp_mu, &kpp_stats, &kpp_list, &kpp_part};
+        // (small jobs: the plain step is a few launches of nothing; KMCUDA_AMD_KMPP_FILTER=2 filters them too: tests)
+        bool kpp_filter = device_chooser && metric == 0 && K >= 8 && N >= 65536u && kpp_dp <= 16384u;
+        if (const char *v = getenv("KMCUDA_AMD_KMPP_FILTER")) {
+          const int f = atoi(v);
+          kpp_filter = f >= 2 ? (device_chooser && metric == 0 && K >= 3 && kpp_dp <= 16384u) : (kpp_filter && f != 0);
+        }
+        if (kpp_filter) {
+          Shard &s = *shards[0];
+          (void)hipSetDevice(s.dev);
+          const bool ok = hipMalloc(&kpp_xs16, (size_t)N * kpp_dp * 2) == hipSuccess &&
+                          hipMalloc(reinterpret_cast<void **>(&kpp_n2c), (size_t)N * sizeof(float)) == hipSuccess &&
+                          hipMalloc(reinterpret_cast<void **>(&kpp_mu), (size_t)kpp_dp * sizeof(float)) == hipSuccess &&
+                          hipMalloc(reinterpret_cast<void **>(&kpp_stats), 4 * sizeof(uint32_t)) == hipSuccess &&
+                          hipMalloc(reinterpret_cast<void **>(&kpp_list), (size_t)N * sizeof(uint32_t)) == hipSuccess &&
+                          hipMalloc(reinterpret_cast<void **>(&kpp_part), (size_t)64 * D * sizeof(double)) == hipSuccess;
+          if (!ok) {
+            (void)hipGetLastError();
+            kpp_filter = false;
+            DEBUG("k-means++: no memory for the half copy of the rows, plain steps\n");
+          } else if (launch_kmpp_cache(s.samples, N, D, kpp_dp, kpp_part, kpp_mu, kpp_xs16, kpp_n2c, kpp_stats,
+                                       s.eng->stream_) != hipSuccess) {
+            return kmcudaRuntimeError;
+          }
         }
         uint32_t log2n = 0;
         while ((1ull << log2n) < (uint64_t)N) log2n++;
@@ -534,9 +579,14 @@ class Job {
             Shard &s = *shards[0];
             (void)hipSetDevice(s.dev);
             hipStream_t st = s.eng->stream_;
-            if (launch_kmpp_step2(metric, s.samples, N, D, s.centroids + (size_t)(i - 1) * D, i, s.dists, block_stats,
-                                  bpre, totals_dev, st) != hipSuccess)
-              return kmcudaRuntimeError;
+            const hipError_t se =
+                (kpp_filter && i >= 2)
+                    ? launch_kmpp_step_filtered(s.samples, N, D, kpp_dp, kpp_xs16, kpp_n2c, kpp_mu, kpp_stats, kpp_list,
+                                                s.centroids + (size_t)(i - 1) * D, i, s.dists, block_stats, bpre,
+                                                totals_dev, st)
+                    : launch_kmpp_step2(metric, s.samples, N, D, s.centroids + (size_t)(i - 1) * D, i, s.dists,
+                                        block_stats, bpre, totals_dev, st);
+            if (se != hipSuccess) return kmcudaRuntimeError;
             if (hipMemcpyAsync(totals_host, totals_dev, sizeof(Totals), hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess)
               return kmcudaMemoryCopyError;
@@ -607,6 +657,12 @@ class Job {
         }
         if (device_chooser) DEBUG("k-means++: %u of %u steps took the host chooser\n", host_steps, K - 1);
         RETERR(sync_all());
+        if (kpp_filter) {
+          unsigned long long chains = 0;
+          if (hipMemcpy(&chains, kpp_stats + 2, sizeof(chains), hipMemcpyDeviceToHost) == hipSuccess)
+            DEBUG("k-means++: the filtered steps ran %llu exact chains for %llu (row, step) pairs\n", chains,
+                  (unsigned long long)N * (K - 2));
+        }
         break;
       }
       case kmcudaInitMethodAFKMC2: {   // kmcuda.cc:337-396

@@ -52,11 +52,106 @@ struct KmppBlockStat {   // one per block of kKmppBlock rows
   uint32_t pad;
 };
 
+// the reference's warpReduceSum over 32 lanes (kmeans.cu:63-66) + the block's exact double sums / exponent range
+// of its kKmppBlock values v (rows past N: 0)
+__device__ __forceinline__ void kmpp_block_stats(float v, KmppBlockStat *__restrict__ out) {
+  // a lane past the group reads itself
+  float g = v;
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) g = g + __shfl_down(g, off, 32);
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double sd = (double)v, sg = ((threadIdx.x & 31) == 0) ? (double)g : 0.0;
+  const uint32_t bits = __float_as_uint(v), ex = (bits >> 23) & 0xFFu;
+  const bool finite = ex != 0xFFu, nz = (bits & 0x7FFFFFFFu) != 0u;
+  uint32_t emin = (finite && nz) ? (ex ? ex : 1u) : 0xFFFFu, emax = (finite && nz) ? (ex ? ex : 1u) : 0u;
+  uint32_t bad = finite ? 0u : 1u;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    sd += __shfl_xor(sd, off);
+    sg += __shfl_xor(sg, off);
+    emin = min(emin, (uint32_t)__shfl_xor((int)emin, off));
+    emax = max(emax, (uint32_t)__shfl_xor((int)emax, off));
+    bad |= (uint32_t)__shfl_xor((int)bad, off);
+  }
+  __shared__ double wd[4], wg[4];
+  __shared__ uint32_t wmin[4], wmax[4], wbad[4];
+  if (lane == 0) { wd[wave] = sd; wg[wave] = sg; wmin[wave] = emin; wmax[wave] = emax; wbad[wave] = bad; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    KmppBlockStat st;
+    st.sum_d = (wd[0] + wd[1]) + (wd[2] + wd[3]);
+    st.sum_g = (wg[0] + wg[1]) + (wg[2] + wg[3]);
+    st.emin = min(min(wmin[0], wmin[1]), min(wmin[2], wmin[3]));
+    st.emax = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    st.bad = wbad[0] | wbad[1] | wbad[2] | wbad[3];
+    st.pad = 0;
+    *out = st;
+  }
+}
+
+// list != nullptr: the rows list[0 .. *count) only (kmpp_filter_kernel's survivors), blocks striding over the
+// list, no block statistics (kmpp_stats_kernel follows)
 template <int METRIC>
 __global__ __launch_bounds__(kKmppBlock) void kmpp_step2_kernel(const float *__restrict__ samples, uint32_t N,
                                                                 uint32_t D, const float *__restrict__ centroid,
                                                                 uint32_t cc, float *__restrict__ dists,
-                                                                KmppBlockStat *__restrict__ stats) {
+                                                                KmppBlockStat *__restrict__ stats,
+                                                                const uint32_t *__restrict__ list,
+                                                                const uint32_t *__restrict__ count) {
+  __shared__ __attribute__((aligned(16))) float tile[kKmppBlock * 36];
+  if (list) {
+    const uint32_t n = *count;
+    __shared__ uint32_t rows[kKmppBlock];
+    for (uint32_t base = blockIdx.x * kKmppBlock; base < n; base += gridDim.x * kKmppBlock) {
+      __syncthreads();   // the previous round's tile and rows[] are done with
+      rows[threadIdx.x] = base + threadIdx.x < n ? list[base + threadIdx.x] : 0xFFFFFFFFu;
+      __syncthreads();
+      const uint32_t s = rows[threadIdx.x];
+      float acc = 0.f, corr = 0.f, x0 = 0.f;
+      if ((D & 3u) == 0 && ((uintptr_t)samples & 15u) == 0) {
+        const uint32_t nchunk = (D + 31) / 32;
+        for (uint32_t ch = 0; ch < nchunk; ch++) {
+          __syncthreads();
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const uint32_t p = threadIdx.x + kKmppBlock * q, r = p >> 3, c4 = p & 7u;
+            const uint32_t row = rows[r], f = ch * 32 + c4 * 4;
+            const float4 v4 = (row < N && f < D) ? *reinterpret_cast<const float4 *>(samples + (size_t)row * D + f)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(&tile[r * 36 + c4 * 4]) = v4;
+          }
+          __syncthreads();
+          const uint32_t fmax = D - ch * 32 < 32u ? D - ch * 32 : 32u;   // multiple of 4
+          for (uint32_t c4 = 0; c4 * 4 < fmax; c4++) {
+            const float4 xv = *reinterpret_cast<const float4 *>(&tile[threadIdx.x * 36 + c4 * 4]);
+            const float4 cv = *reinterpret_cast<const float4 *>(centroid + ch * 32 + c4 * 4);
+            const float aa[4] = {xv.x, xv.y, xv.z, xv.w}, bb[4] = {cv.x, cv.y, cv.z, cv.w};
+            if (ch == 0 && c4 == 0) x0 = aa[0];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              if (METRIC == 0) {
+                const float d = aa[q] - bb[q];
+                kahan_fold(fma_rd(d, d, corr), acc, corr);
+              } else {
+                kahan_fold(fma_rd(aa[q], bb[q], corr), acc, corr);
+              }
+            }
+          }
+        }
+        if (s < N) {
+          float dist = 0.f;
+          if (x0 == x0) dist = METRIC == 0 ? sqrtf(acc) : angular_from_prod(acc);   // kmeans.cu:53-56
+          if (cc == 1 || dist < dists[s]) dists[s] = dist;                            // :57-62
+        }
+      } else if (s < N) {
+        const float *x = samples + (size_t)s * D;
+        float dist = 0.f;
+        if (x[0] == x[0]) dist = distance_vv<METRIC>(x, centroid, D);
+        if (cc == 1 || dist < dists[s]) dists[s] = dist;
+      }
+    }
+    return;
+  }
   const uint32_t s = blockIdx.x * kKmppBlock + threadIdx.x;
   float v = 0.f;   // rows past N count as 0, like the host emulation of the butterfly
   if ((D & 3u) == 0 && ((uintptr_t)samples & 15u) == 0) {
@@ -64,7 +159,6 @@ __global__ __launch_bounds__(kKmppBlock) void kmpp_step2_kernel(const float *__r
     // every 16-byte load of a wave touch 64 different lines (1.1 TB/s measured).  Chunks of 32
     // features: 8 lanes fetch a row's 128-byte line, the tile is stored with a 36-float row stride
     // (conflict-free b128 reads by 16 consecutive rows), the next chunk's loads fly during the chain.
-    __shared__ __attribute__((aligned(16))) float tile[kKmppBlock * 36];
     const uint32_t nchunk = (D + 31) / 32;
     float4 stage[8];
     auto fetch = [&](uint32_t ch) {
@@ -117,38 +211,192 @@ __global__ __launch_bounds__(kKmppBlock) void kmpp_step2_kernel(const float *__r
     if (cc == 1 || dist < dists[s]) dists[s] = dist; else dist = dists[s];   // :57-62
     v = dist;
   }
-  // the reference's warpReduceSum over 32 lanes (kmeans.cu:63-66): a lane past the group reads itself
-  float g = v;
+  kmpp_block_stats(v, &stats[blockIdx.x]);
+}
+
+// block statistics of the distances as they stand (after a filtered step)
+__global__ __launch_bounds__(kKmppBlock) void kmpp_stats_kernel(const float *__restrict__ dists, uint32_t N,
+                                                                KmppBlockStat *__restrict__ stats,
+                                                                uint32_t *__restrict__ list_count) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {   // the step's survivor list has been consumed (stream order); [1..2] behind it: the running total
+    *reinterpret_cast<unsigned long long *>(list_count + 1) += *list_count;
+    *list_count = 0u;
+  }
+  const uint32_t nb = (N + kKmppBlock - 1) / kKmppBlock;
+  for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+    const uint32_t s = b * kKmppBlock + threadIdx.x;
+    kmpp_block_stats(s < N ? dists[s] : 0.f, &stats[b]);
+    __syncthreads();   // kmpp_block_stats' shared words are read by thread 0 until here
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Filtered steps (L2).  A step only changes dists[s] where the new seed is CLOSER than the row's nearest seed so
+// far -- one row in i at step i on average -- but the plain step streams all N rows (4 D bytes each) to find out.
+// Here the rows are kept a second time as centred halves (2 DP bytes; kmpp_cache_kernel, once per call), a
+// step's first kernel forms hi(x').hi(s') per row (8 lanes per row, f32 accumulation) and drops every row whose
+// distance to the new seed provably is not below dists[s] -- the cluster-pruned k-NN search's candidate test with
+// one query, the seed, and a threshold per candidate (knn_f16.hip: same operands, same error bound E, DESIGN.md
+// 4.2 / 4.5) -- and only the survivors' exact chains run (kmpp_step2_kernel over the list).  dists[] afterwards is
+// the plain step's bit for bit: a dropped row keeps its value in both.
+// ---------------------------------------------------------------------------------------
+typedef _Float16 f16x8_kp __attribute__((ext_vector_type(8)));
+
+// column sums of (up to) the first `rows` rows, one partial per block in fixed order: part[b][f]
+__global__ __launch_bounds__(256) void kmpp_colsum_kernel(const float *__restrict__ samples, uint32_t rows, uint32_t D,
+                                                          double *__restrict__ part) {
+  for (uint32_t f = threadIdx.x; f < D; f += 256) {
+    double acc = 0.0;
+    for (uint32_t r = blockIdx.x; r < rows; r += gridDim.x) {
+      const float v = samples[(size_t)r * D + f];
+      if ((v - v) == 0.f) acc += (double)v;   // finite values only: mu is just a translation
+    }
+    part[(size_t)blockIdx.x * D + f] = acc;
+  }
+}
+__global__ __launch_bounds__(256) void kmpp_mean_kernel(const double *__restrict__ part, uint32_t nblocks, uint32_t rows,
+                                                        uint32_t D, uint32_t DP, float *__restrict__ mu) {
+  const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= DP) return;
+  double acc = 0.0;
+  if (f < D)
+    for (uint32_t b = 0; b < nblocks; b++) acc += part[(size_t)b * D + f];
+  mu[f] = f < D ? (float)(acc / (double)rows) : 0.f;
+}
+
+// one wave per row: x' = x - mu as halves (zero padded to DP), ||x'||^2 of the fp32 values, the largest finite one
+__global__ __launch_bounds__(256) void kmpp_cache_kernel(const float *__restrict__ samples, uint32_t N, uint32_t D,
+                                                         uint32_t DP, const float *__restrict__ mu,
+                                                         _Float16 *__restrict__ xs16, float *__restrict__ n2c,
+                                                         uint32_t *__restrict__ stats) {
+  const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  if (p >= N) return;
+  const float *src = samples + (size_t)p * D;
+  _Float16 *dst = xs16 + (size_t)p * DP;
+  float a = 0.f;
+  for (uint32_t f = lane; f < DP; f += 64) {
+    const float v = f < D ? src[f] - mu[f] : 0.f;
+    dst[f] = (_Float16)v;
+    a = fmaf(v, v, a);
+  }
 #pragma unroll
-  for (int off = 16; off > 0; off >>= 1) g = g + __shfl_down(g, off, 32);
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+  if (lane == 0) {
+    n2c[p] = a;
+    if ((a - a) == 0.f && __float_as_uint(a) > *reinterpret_cast<volatile uint32_t *>(&stats[0]))
+      atomicMax(&stats[0], __float_as_uint(a));
+  }
+}
+
+// PPL: 16-byte pieces per lane and row (DP = 64 PPL), 0 = any DP (rolled loops).  With PPL known a wave has the
+// pieces of 4 x 8 rows in flight before the first product (a 4-GB stream per step: bandwidth is the whole cost).
+template <int PPL>
+__global__ __launch_bounds__(256) void kmpp_filter_kernel(const _Float16 *__restrict__ xs16, const float *__restrict__ n2c,
+                                                          const float *__restrict__ mu, const float *__restrict__ seed,
+                                                          uint32_t N, uint32_t D, uint32_t DP,
+                                                          const uint32_t *__restrict__ stats, float eps,
+                                                          const float *__restrict__ dists, uint32_t *__restrict__ list,
+                                                          uint32_t *__restrict__ count) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 s16[];   // DP halves: hi(s - mu)
+  __shared__ float red[4];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double sd = (double)v, sg = ((threadIdx.x & 31) == 0) ? (double)g : 0.0;
-  const uint32_t bits = __float_as_uint(v), ex = (bits >> 23) & 0xFFu;
-  const bool finite = ex != 0xFFu, nz = (bits & 0x7FFFFFFFu) != 0u;
-  uint32_t emin = (finite && nz) ? (ex ? ex : 1u) : 0xFFFFu, emax = (finite && nz) ? (ex ? ex : 1u) : 0u;
-  uint32_t bad = finite ? 0u : 1u;
+  float part = 0.f;
+  for (uint32_t f = threadIdx.x; f < DP; f += 256) {
+    const float v = f < D ? seed[f] - mu[f] : 0.f;
+    s16[f] = (_Float16)v;
+    part = fmaf(v, v, part);
+  }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    sd += __shfl_xor(sd, off);
-    sg += __shfl_xor(sg, off);
-    emin = min(emin, (uint32_t)__shfl_xor((int)emin, off));
-    emax = max(emax, (uint32_t)__shfl_xor((int)emax, off));
-    bad |= (uint32_t)__shfl_xor((int)bad, off);
-  }
-  __shared__ double wd[4], wg[4];
-  __shared__ uint32_t wmin[4], wmax[4], wbad[4];
-  if (lane == 0) { wd[wave] = sd; wg[wave] = sg; wmin[wave] = emin; wmax[wave] = emax; wbad[wave] = bad; }
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+  if (lane == 0) red[wave] = part;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    KmppBlockStat st;
-    st.sum_d = (wd[0] + wd[1]) + (wd[2] + wd[3]);
-    st.sum_g = (wg[0] + wg[1]) + (wg[2] + wg[3]);
-    st.emin = min(min(wmin[0], wmin[1]), min(wmin[2], wmin[3]));
-    st.emax = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
-    st.bad = wbad[0] | wbad[1] | wbad[2] | wbad[3];
-    st.pad = 0;
-    stats[blockIdx.x] = st;
+  const float sn2 = (red[0] + red[1]) + (red[2] + red[3]);   // ||s'||^2 (the "query" of knn_f16.hip)
+  // the k-NN filter's bound with one query: a row can only come closer than T = dists[s] if
+  //   hi(x').hi(s') - ||x'||^2 / 2  >=  (||s'||^2 - T^2 - E) / 2 - 1e-6 (||s'||^2 + T^2)
+  const float nmax2 = __uint_as_float(stats[0]);
+  const float u = 5.9604645e-8f;
+  const float qn = sqrtf(sn2) * 1.0001f, nmx = sqrtf(nmax2) * 1.0001f;
+  const float e_round = 9.78e-4f * qn * nmx;
+  const float E = 4.04f * (3.0f * eps + 16.0f * u) * (sn2 + nmax2) + 6e-8f * sqrtf((float)DP) * (qn + nmx) + 2.0f * e_round;
+  // operands near the half range could round to inf: then nothing is dropped
+  const bool usable = (sn2 - sn2) == 0.f && qn < 6.0e4f && nmx < 6.0e4f && (E - E) == 0.f;
+  const uint32_t l8 = lane & 7u, rsub = lane >> 3;
+  constexpr uint32_t kBuf = 128;
+  __shared__ uint32_t buf[4][kBuf];
+  uint32_t *mine = buf[wave];
+  uint32_t buffered = 0;   // wave-uniform
+  auto flush = [&]() {
+    if (buffered == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(count, buffered);
+    base = __shfl(base, 0);
+    for (uint32_t i = lane; i < buffered; i += 64) list[base + i] = mine[i];
+    buffered = 0;
+  };
+  auto decide = [&](uint32_t s, bool live, float acc) {
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 4);
+    bool need = false;
+    if (live && l8 == 0) {
+      const float n2 = n2c[s], T = dists[s];
+      const float score = acc - 0.5f * n2;
+      const float T2 = T * T * 1.000001f;
+      const float amin = 0.5f * (sn2 - T2 - E) - 1e-6f * (sn2 + T2);
+      need = !(usable && score < amin);   // NaN anywhere: not dropped
+    }
+    // Survivors wait in the wave's LDS buffer: one global atomic per kBuf of them, not one per 8-row group (same-
+    // address atomics are served one at a time by L2: 50 K of them per step were half of the kernel's time)
+    const unsigned long long m = __ballot(need);
+    if (m) {
+      const uint32_t n = (uint32_t)__popcll(m);
+      if (buffered + n > kBuf) flush();
+      if (need) mine[buffered + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = s;
+      buffered += n;
+    }
+  };
+  auto dot8 = [](const f16x8_kp &xv, const f16x8_kp &sv, float acc) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) acc = fmaf((float)xv[q], (float)sv[q], acc);   // products of halves: exact in fp32
+    return acc;
+  };
+  if constexpr (PPL > 0) {
+    constexpr int R = 4;   // 8-row groups in flight per wave
+    f16x8_kp sv[PPL];
+#pragma unroll
+    for (int i = 0; i < PPL; i++) sv[i] = *reinterpret_cast<const f16x8_kp *>(&s16[(l8 + 8 * i) * 8]);
+    for (uint32_t row0 = (blockIdx.x * 4 + wave) * (8 * R); row0 < N; row0 += gridDim.x * (32 * R)) {
+      f16x8_kp xv[R][PPL];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const uint32_t s = row0 + 8 * r + rsub;
+        const f16x8_kp *xr = reinterpret_cast<const f16x8_kp *>(xs16 + (size_t)(s < N ? s : 0) * DP);
+#pragma unroll
+        for (int i = 0; i < PPL; i++) xv[r][i] = __builtin_nontemporal_load(&xr[l8 + 8 * i]);
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const uint32_t s = row0 + 8 * r + rsub;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) acc = dot8(xv[r][i], sv[i], acc);
+        decide(s, s < N, acc);
+      }
+    }
+  } else {
+    const uint32_t npieces = DP / 8;   // 16-byte pieces per row; DP is a multiple of 64
+    for (uint32_t row0 = (blockIdx.x * 4 + wave) * 8; row0 < N; row0 += gridDim.x * 32) {
+      const uint32_t s = row0 + rsub;
+      const bool live = s < N;
+      const f16x8_kp *xr = reinterpret_cast<const f16x8_kp *>(xs16 + (size_t)(live ? s : 0) * DP);
+      float acc = 0.f;
+      for (uint32_t p = l8; p < npieces; p += 8)
+        acc = dot8(xr[p], *reinterpret_cast<const f16x8_kp *>(&s16[p * 8]), acc);
+      decide(s, live, acc);
+    }
   }
+  flush();
 }
 
 struct KmppTotals {   // pinned host memory
@@ -156,64 +404,103 @@ struct KmppTotals {   // pinned host memory
   uint32_t emin, emax, bad, chosen;
 };
 
-// one block: totals + exclusive prefix of the block sums (bpre[nb] = total)
-__global__ __launch_bounds__(1024) void kmpp_reduce_kernel(const KmppBlockStat *__restrict__ stats, uint32_t nb,
-                                                           double *__restrict__ bpre, KmppTotals *__restrict__ out) {
+// Exclusive prefix of the block sums in two launches.  (a) every 1024 block statistics: their local exclusive
+// prefix -> bpre[i], their totals -> aux[b]; (b) one block: exclusive prefix of the aux sums -> carry[b],
+// carry[nchunks] = the total, the other totals -> out.  prefix of block i = bpre[i] + carry[i / 1024]: every
+// partial sum is exact (caller's exponent-range test), so the association does not matter.
+struct KmppChunk {
+  double sum, sg;
+  uint32_t emin, emax, bad, pad;
+};
+__global__ __launch_bounds__(1024) void kmpp_reduce_a_kernel(const KmppBlockStat *__restrict__ stats, uint32_t nb,
+                                                             double *__restrict__ bpre, KmppChunk *__restrict__ aux) {
   __shared__ double wsum[16], wsg[16];
   __shared__ uint32_t wmin[16], wmax[16], wbad[16];
-  __shared__ double carry_s, sg_s;
-  __shared__ uint32_t min_s, max_s, bad_s;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) { carry_s = 0.0; sg_s = 0.0; min_s = 0xFFFFu; max_s = 0u; bad_s = 0u; }
-  __syncthreads();
-  for (uint32_t base = 0; base < nb; base += 1024) {
-    const uint32_t i = base + threadIdx.x;
-    const bool in = i < nb;
-    const double v = in ? stats[i].sum_d : 0.0;
-    double sg = in ? stats[i].sum_g : 0.0;
-    uint32_t emin = in ? stats[i].emin : 0xFFFFu, emax = in ? stats[i].emax : 0u, bad = in ? stats[i].bad : 0u;
-    double inc = v;
+  const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+  const bool in = i < nb;
+  const double v = in ? stats[i].sum_d : 0.0;
+  double sg = in ? stats[i].sum_g : 0.0;
+  uint32_t emin = in ? stats[i].emin : 0xFFFFu, emax = in ? stats[i].emax : 0u, bad = in ? stats[i].bad : 0u;
+  double inc = v;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const double t = __shfl_up(inc, o);
-      if ((int)lane >= o) inc += t;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      sg += __shfl_xor(sg, o);
-      emin = min(emin, (uint32_t)__shfl_xor((int)emin, o));
-      emax = max(emax, (uint32_t)__shfl_xor((int)emax, o));
-      bad |= (uint32_t)__shfl_xor((int)bad, o);
-    }
-    if (lane == 63) wsum[wave] = inc;
-    if (lane == 0) { wsg[wave] = sg; wmin[wave] = emin; wmax[wave] = emax; wbad[wave] = bad; }
-    __syncthreads();
-    double wbase = 0.0, all = 0.0;
-#pragma unroll
-    for (uint32_t k = 0; k < 16; k++) {
-      const double t = wsum[k];
-      if (k < wave) wbase += t;
-      all += t;
-    }
-    const double carry = carry_s;
-    if (in) bpre[i] = carry + wbase + inc - v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      carry_s = carry + all;
-      double g = sg_s;
-      uint32_t mn = min_s, mx = max_s, bd = bad_s;
-      for (uint32_t k = 0; k < 16; k++) { g += wsg[k]; mn = min(mn, wmin[k]); mx = max(mx, wmax[k]); bd |= wbad[k]; }
-      sg_s = g; min_s = mn; max_s = mx; bad_s = bd;
-    }
-    __syncthreads();
+  for (int o = 1; o < 64; o <<= 1) {
+    const double t = __shfl_up(inc, o);
+    if ((int)lane >= o) inc += t;
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sg += __shfl_xor(sg, o);
+    emin = min(emin, (uint32_t)__shfl_xor((int)emin, o));
+    emax = max(emax, (uint32_t)__shfl_xor((int)emax, o));
+    bad |= (uint32_t)__shfl_xor((int)bad, o);
+  }
+  if (lane == 63) wsum[wave] = inc;
+  if (lane == 0) { wsg[wave] = sg; wmin[wave] = emin; wmax[wave] = emax; wbad[wave] = bad; }
+  __syncthreads();
+  double wbase = 0.0, all = 0.0;
+#pragma unroll
+  for (uint32_t k = 0; k < 16; k++) {
+    const double t = wsum[k];
+    if (k < wave) wbase += t;
+    all += t;
+  }
+  if (in) bpre[i] = wbase + inc - v;
   if (threadIdx.x == 0) {
-    bpre[nb] = carry_s;
-    out->sum_g = sg_s;
-    out->sum_d = carry_s;
-    out->emin = min_s;
-    out->emax = max_s;
-    out->bad = bad_s;
+    KmppChunk c;
+    c.sum = all;
+    double g = 0.0;
+    uint32_t mn = 0xFFFFu, mx = 0u, bd = 0u;
+    for (uint32_t k = 0; k < 16; k++) { g += wsg[k]; mn = min(mn, wmin[k]); mx = max(mx, wmax[k]); bd |= wbad[k]; }
+    c.sg = g; c.emin = mn; c.emax = mx; c.bad = bd; c.pad = 0;
+    aux[blockIdx.x] = c;
+  }
+}
+// nchunks <= 1024
+__global__ __launch_bounds__(1024) void kmpp_reduce_b_kernel(const KmppChunk *__restrict__ aux, uint32_t nchunks,
+                                                             double *__restrict__ carry, KmppTotals *__restrict__ out) {
+  __shared__ double wsum[16], wsg[16];
+  __shared__ uint32_t wmin[16], wmax[16], wbad[16];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool in = threadIdx.x < nchunks;
+  const double v = in ? aux[threadIdx.x].sum : 0.0;
+  double sg = in ? aux[threadIdx.x].sg : 0.0;
+  uint32_t emin = in ? aux[threadIdx.x].emin : 0xFFFFu, emax = in ? aux[threadIdx.x].emax : 0u,
+           bad = in ? aux[threadIdx.x].bad : 0u;
+  double inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double t = __shfl_up(inc, o);
+    if ((int)lane >= o) inc += t;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sg += __shfl_xor(sg, o);
+    emin = min(emin, (uint32_t)__shfl_xor((int)emin, o));
+    emax = max(emax, (uint32_t)__shfl_xor((int)emax, o));
+    bad |= (uint32_t)__shfl_xor((int)bad, o);
+  }
+  if (lane == 63) wsum[wave] = inc;
+  if (lane == 0) { wsg[wave] = sg; wmin[wave] = emin; wmax[wave] = emax; wbad[wave] = bad; }
+  __syncthreads();
+  double wbase = 0.0, all = 0.0;
+#pragma unroll
+  for (uint32_t k = 0; k < 16; k++) {
+    const double t = wsum[k];
+    if (k < wave) wbase += t;
+    all += t;
+  }
+  if (in) carry[threadIdx.x] = wbase + inc - v;
+  if (threadIdx.x == 0) {
+    carry[nchunks] = all;
+    double g = 0.0;
+    uint32_t mn = 0xFFFFu, mx = 0u, bd = 0u;
+    for (uint32_t k = 0; k < 16; k++) { g += wsg[k]; mn = min(mn, wmin[k]); mx = max(mx, wmax[k]); bd |= wbad[k]; }
+    out->sum_g = g;
+    out->sum_d = all;
+    out->emin = mn;
+    out->emax = mx;
+    out->bad = bd;
   }
 }
 
@@ -222,8 +509,16 @@ __global__ __launch_bounds__(1024) void kmpp_reduce_kernel(const KmppBlockStat *
 //   choice_approx < 100, or prefix(ca) < cs :  j = m0(0)
 //   else (backward loop, which subtracts d[ca] first):  j = max(2, min(m0(d[ca]) - 1, ca + 1))
 __global__ __launch_bounds__(kKmppBlock) void kmpp_choose_kernel(const float *__restrict__ dists, uint32_t N,
-                                                                 const double *__restrict__ bpre, uint32_t nb,
+                                                                 const double *__restrict__ bpre_local, uint32_t nb,
                                                                  uint32_t ca, double cs, KmppTotals *__restrict__ out) {
+  // exclusive prefix of block i (i <= nb): the chunk-local part + the chunk's carry (kmpp_reduce_*), stored behind
+  // the nb local values: carry[c] = bpre_local[nb + c], carry[nchunks] = the total
+  const uint32_t nchunks = (nb + 1023u) / 1024u;
+  struct Pre {
+    const double *local, *carry;
+    uint32_t nb, nchunks;
+    __device__ double operator[](uint32_t i) const { return i >= nb ? carry[nchunks] : local[i] + carry[i >> 10]; }
+  } bpre{bpre_local, bpre_local + nb, nb, nchunks};
   __shared__ double incl[kKmppBlock];
   __shared__ uint32_t best;
   __shared__ double pca_s;
@@ -286,19 +581,75 @@ __global__ __launch_bounds__(kKmppBlock) void kmpp_choose_kernel(const float *__
   if (tid == 0) out->chosen = j;
 }
 
+// bpre: nb local prefixes, then nchunks + 1 carries, then (16-byte aligned) the nchunks chunk records
+static hipError_t launch_kmpp_reduce(const void *block_stats, uint32_t nb, double *bpre, void *totals, hipStream_t st) {
+  const uint32_t nchunks = (nb + 1023u) / 1024u;
+  if (nchunks > 1024u) return hipErrorInvalidValue;   // (N > 2^28 rows: kmpp_supported() keeps such jobs on the host chooser)
+  double *carry = bpre + nb;
+  KmppChunk *aux = reinterpret_cast<KmppChunk *>(bpre + (((size_t)nb + nchunks + 1 + 1) & ~(size_t)1));
+  hipLaunchKernelGGL(kmpp_reduce_a_kernel, dim3(nchunks), dim3(1024), 0, st,
+                     reinterpret_cast<const KmppBlockStat *>(block_stats), nb, bpre, aux);
+  hipLaunchKernelGGL(kmpp_reduce_b_kernel, dim3(1), dim3(1024), 0, st, aux, nchunks, carry,
+                     reinterpret_cast<KmppTotals *>(totals));
+  return hipGetLastError();
+}
+
 hipError_t launch_kmpp_step2(int metric, const float *samples, uint32_t N, uint32_t D, const float *centroid,
                              uint32_t cc, float *dists, void *block_stats, double *bpre, void *totals_host,
                              hipStream_t st) {
   const uint32_t nb = (N + kKmppBlock - 1) / kKmppBlock;
   if (metric == 0)
     hipLaunchKernelGGL((kmpp_step2_kernel<0>), dim3(nb), dim3(kKmppBlock), 0, st, samples, N, D, centroid, cc, dists,
-                       reinterpret_cast<KmppBlockStat *>(block_stats));
+                       reinterpret_cast<KmppBlockStat *>(block_stats), (const uint32_t *)nullptr, (const uint32_t *)nullptr);
   else
     hipLaunchKernelGGL((kmpp_step2_kernel<1>), dim3(nb), dim3(kKmppBlock), 0, st, samples, N, D, centroid, cc, dists,
-                       reinterpret_cast<KmppBlockStat *>(block_stats));
-  hipLaunchKernelGGL(kmpp_reduce_kernel, dim3(1), dim3(1024), 0, st, reinterpret_cast<const KmppBlockStat *>(block_stats),
-                     nb, bpre, reinterpret_cast<KmppTotals *>(totals_host));
+                       reinterpret_cast<KmppBlockStat *>(block_stats), (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+  return launch_kmpp_reduce(block_stats, nb, bpre, totals_host, st);
+}
+
+// The centred half copy of the rows for the filtered steps (L2): mu = column means of the first <= 65536 rows
+// (any vector is valid; a central one keeps the norms in the error bound small).  part: 64 x D doubles of scratch.
+hipError_t launch_kmpp_cache(const float *samples, uint32_t N, uint32_t D, uint32_t DP, double *part, float *mu,
+                             void *xs16, float *n2c, uint32_t *stats, hipStream_t st) {
+  const uint32_t rows = N < 65536u ? N : 65536u;
+  hipError_t e = hipMemsetAsync(stats, 0, 4 * sizeof(uint32_t), st);   // [0] max ||x'||^2, [1] survivors of the step, [2..3] of all steps
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kmpp_colsum_kernel, dim3(64), dim3(256), 0, st, samples, rows, D, part);
+  hipLaunchKernelGGL(kmpp_mean_kernel, dim3((DP + 255) / 256), dim3(256), 0, st, part, 64u, rows, D, DP, mu);
+  hipLaunchKernelGGL(kmpp_cache_kernel, dim3((N + 3) / 4), dim3(256), 0, st, samples, N, D, DP, mu,
+                     reinterpret_cast<_Float16 *>(xs16), n2c, stats);
   return hipGetLastError();
+}
+
+// One filtered step (cc >= 2; the first step has nothing to compare with: launch_kmpp_step2): survivors of the
+// bound -> exact chains -> block statistics -> totals, as launch_kmpp_step2 leaves them.
+hipError_t launch_kmpp_step_filtered(const float *samples, uint32_t N, uint32_t D, uint32_t DP, const void *xs16,
+                                     const float *n2c, const float *mu, uint32_t *stats, uint32_t *list,
+                                     const float *centroid, uint32_t cc, float *dists, void *block_stats, double *bpre,
+                                     void *totals_host, hipStream_t st) {
+  const uint32_t nb = (N + kKmppBlock - 1) / kKmppBlock;
+  const float eps = (float)(1.02 * ((double)D + 12.0) * 5.9604644775390625e-8);   // as the k-NN filter
+  const uint32_t fgrid = (N + 127) / 128 < 1024u ? (N + 127) / 128 : 1024u;   // 16 waves per CU; one list atomic per wave
+#define KMX_KPP_FILTER(P)                                                                                           \
+  hipLaunchKernelGGL((kmpp_filter_kernel<P>), dim3(fgrid), dim3(256), (size_t)DP * 2, st,                           \
+                     reinterpret_cast<const _Float16 *>(xs16), n2c, mu, centroid, N, D, DP, stats, eps, dists, list, \
+                     stats + 1)
+  switch (DP / 64) {
+    case 1: KMX_KPP_FILTER(1); break;
+    case 2: KMX_KPP_FILTER(2); break;
+    case 3: KMX_KPP_FILTER(3); break;
+    case 4: KMX_KPP_FILTER(4); break;
+    case 6: KMX_KPP_FILTER(6); break;
+    case 8: KMX_KPP_FILTER(8); break;
+    default: KMX_KPP_FILTER(0); break;
+  }
+#undef KMX_KPP_FILTER
+  const uint32_t lgrid = nb < 1024u ? nb : 1024u;
+  hipLaunchKernelGGL((kmpp_step2_kernel<0>), dim3(lgrid), dim3(kKmppBlock), 0, st, samples, N, D, centroid, cc, dists,
+                     (KmppBlockStat *)nullptr, list, stats + 1);
+  hipLaunchKernelGGL(kmpp_stats_kernel, dim3(nb < 4096u ? nb : 4096u), dim3(kKmppBlock), 0, st, dists, N,
+                     reinterpret_cast<KmppBlockStat *>(block_stats), stats + 1);
+  return launch_kmpp_reduce(block_stats, nb, bpre, totals_host, st);
 }
 
 hipError_t launch_kmpp_choose(const float *dists, uint32_t N, const double *bpre, uint32_t choice_approx,
@@ -311,6 +662,11 @@ hipError_t launch_kmpp_choose(const float *dists, uint32_t N, const double *bpre
 
 size_t kmpp_block_stat_bytes(uint32_t N) { return (size_t)((N + kKmppBlock - 1) / kKmppBlock) * sizeof(KmppBlockStat); }
 size_t kmpp_blocks(uint32_t N) { return (N + kKmppBlock - 1) / kKmppBlock; }
+// doubles the caller allocates for bpre (local prefixes + carries + chunk records)
+size_t kmpp_prefix_doubles(uint32_t N) {
+  const size_t nb = kmpp_blocks(N), nchunks = (nb + 1023) / 1024;
+  return nb + nchunks + 3 + nchunks * (sizeof(KmppChunk) / sizeof(double));
+}
 
 // ---------------------------------------------------------------------------------------
 // AFK-MC2 seeding (reference: kmeans.cu:69-212, host chain kmcuda.cc:337-396).

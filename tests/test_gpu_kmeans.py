@@ -505,6 +505,49 @@ def test_kmeanspp_device_chooser_equals_host(monkeypatch, case):
     assert (res[0][1] == res[1][1]).all()
 
 
+@pytest.mark.parametrize("case", ["uniform", "blobs", "duplicates", "wide", "ragged", "nan", "huge", "big", "fp16"])
+def test_kmeanspp_filtered_steps_equal_plain_steps(monkeypatch, case):
+    """k-means++ steps with the half-copy filter in front (seeding.hip: rows that provably are no closer to the new
+    seed than to an earlier one are dropped, the exact chains run for the rest) against the plain steps
+    (KMCUDA_AMD_KMPP_FILTER=0): the same distances after every step, hence the same seeds and identical runs.
+    'nan': rows with NaN in the first / a later feature; 'huge': rows beyond the half range (nothing may be dropped
+    on a non-finite score); 'big': the size at which the filter is on by default; 'fp16': half input."""
+    from kmcuda_amd import kmeans_cuda
+    rs = numpy.random.RandomState(sum(map(ord, case)))
+    force = "2"
+    if case == "uniform":
+        x, k = rs.rand(30000, 64).astype(numpy.float32), 200
+    elif case == "blobs":
+        cen = rs.rand(40, 32) * 20
+        x, k = (cen[rs.randint(0, 40, 25000)] + rs.randn(25000, 32)).astype(numpy.float32), 64
+    elif case == "duplicates":
+        base = rs.rand(500, 16).astype(numpy.float32)
+        x, k = base[rs.randint(0, 500, 20000)].copy(), 100
+    elif case == "wide":
+        x, k = (rs.rand(20000, 8) * numpy.exp(rs.uniform(-12, 12, (20000, 1)))).astype(numpy.float32), 50
+    elif case == "ragged":
+        x, k = rs.rand(10007, 33).astype(numpy.float32), 257
+    elif case == "nan":
+        x, k = rs.rand(20000, 48).astype(numpy.float32), 60
+        x[::97, 0] = numpy.nan
+        x[5::101, 7] = numpy.nan
+    elif case == "huge":
+        x, k = rs.rand(20000, 24).astype(numpy.float32), 40
+        x[::50] *= 1e6
+        x[3::77, 2] = numpy.inf
+    elif case == "big":
+        x, k, force = rs.rand(200000, 256).astype(numpy.float32), 48, "1"
+    else:
+        x, k = rs.rand(30000, 64).astype(numpy.float16), 100
+    res = []
+    for filt in (force, "0"):
+        monkeypatch.setenv("KMCUDA_AMD_KMPP_FILTER", filt)
+        c, a = kmeans_cuda(x, k, tolerance=0.5, init="k-means++", seed=11, yinyang_t=0, verbosity=0)
+        res.append((c.copy(), a.copy()))
+    assert numpy.array_equal(res[0][0], res[1][0], equal_nan=True)   # after one update: same seeds
+    assert (res[0][1] == res[1][1]).all()
+
+
 def test_native_module_equals_ctypes_mirror(fixture13k):
     """The CPython module inside libKMCUDA.so (`import libKMCUDA`, python.cc's counterpart) against the
     ctypes mirror: same centroids / assignments / average distance, result arrays referenced by the caller
