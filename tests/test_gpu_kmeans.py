@@ -76,8 +76,11 @@ def test_random_lloyd_7(fixture13k):
     assert reass == list(olog)
 
 
-def test_kmeanspp_lloyd_4(fixture13k):
+@pytest.mark.parametrize("filtered", ["0", "2"])
+def test_kmeanspp_lloyd_4(fixture13k, monkeypatch, filtered):
+    # (test.py:207-216; "2": through the filtered k-means++ steps, which a 13000-row job does not take by default)
     from kmcuda_amd import kmeans_cuda
+    monkeypatch.setenv("KMCUDA_AMD_KMPP_FILTER", filtered)
     out = StdoutListener()
     with out:
         centroids, assignments = kmeans_cuda(fixture13k, 50, init="kmeans++", device=1, verbosity=2, seed=3,
