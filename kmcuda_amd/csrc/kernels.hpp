@@ -144,11 +144,16 @@ hipError_t launch_kmpp_step(int metric, const float *samples, uint32_t N, uint32
                             uint32_t cc, float *dists, hipStream_t st);
 // k-means++ with the chooser on the device (seeding.hip): step = distances + exact block sums + exponent
 // range; totals_host = pinned { double sum_g, sum_d; uint32 emin, emax, bad, chosen } (32 bytes)
+// fail (one device word, 0 while all is well): raised by launch_kmpp_choose's kernel at a step the device cannot
+// decide; every kmpp kernel launched with it returns at once while it is set (the host enqueues steps ahead)
 hipError_t launch_kmpp_step2(int metric, const float *samples, uint32_t N, uint32_t D, const float *centroid,
-                             uint32_t cc, float *dists, void *block_stats, double *bpre, void *totals_host,
-                             hipStream_t st);
-hipError_t launch_kmpp_choose(const float *dists, uint32_t N, const double *bpre, uint32_t choice_approx,
-                              double choice_sum, void *totals_host, hipStream_t st);
+                             uint32_t cc, float *dists, void *block_stats, double *bpre, void *totals,
+                             const uint32_t *fail, hipStream_t st);
+// the reference's chooser (kmcuda.cc:300-326) for step `step` with random number `choice`, on the device: the
+// totals the step left in `totals`; copies the chosen row into centroid slot `step`, or raises *fail = step
+hipError_t launch_kmpp_choose(const float *dists, uint32_t N, const double *bpre, double choice, uint32_t log2n,
+                              uint32_t step, const float *samples, float *centroids, uint32_t D, uint32_t *fail,
+                              void *totals, hipStream_t st);
 // filtered k-means++ steps (L2; seeding.hip): the centred half copy of the rows, then per step the survivors of
 // the k-NN candidate bound get the exact chain.  DP: D rounded up to 64; stats: 4 words ([2..3]: exact chains run so far, 64 bits); list: N words.
 hipError_t launch_kmpp_cache(const float *samples, uint32_t N, uint32_t D, uint32_t DP, double *part, float *mu,
@@ -156,7 +161,7 @@ hipError_t launch_kmpp_cache(const float *samples, uint32_t N, uint32_t D, uint3
 hipError_t launch_kmpp_step_filtered(const float *samples, uint32_t N, uint32_t D, uint32_t DP, const void *xs16,
                                      const float *n2c, const float *mu, uint32_t *stats, uint32_t *list,
                                      const float *centroid, uint32_t cc, float *dists, void *block_stats, double *bpre,
-                                     void *totals_host, hipStream_t st);
+                                     void *totals, const uint32_t *fail, hipStream_t st);
 size_t kmpp_block_stat_bytes(uint32_t N);
 size_t kmpp_blocks(uint32_t N);
 size_t kmpp_prefix_doubles(uint32_t N);   // doubles of `bpre`

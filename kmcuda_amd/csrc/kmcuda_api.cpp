@@ -568,46 +568,111 @@ class Job {
         uint32_t log2n = 0;
         while ((1ull << log2n) < (uint64_t)N) log2n++;
         uint32_t host_steps = 0;
-        for (uint32_t i = 1; i < K; i++) {
+        auto progress = [&](uint32_t i) {
           if (verbosity > 1 || (verbosity > 0 && (K < 100 || i % (K / 100) == 0))) {
             printf("\rstep %d", i);
             fflush(stdout);
           }
+        };
+        // the reference's chooser on the host (kmcuda.cc:286-326) for step i with random number `choice`: all N
+        // distances come back, butterfly sum, sequential double prefix sums; copies the seed
+        auto host_choose = [&](uint32_t i, double choice) -> int {
+          host_steps++;
+          if (!host_dists &&
+              hipHostMalloc(reinterpret_cast<void **>(&host_dists), (size_t)N * sizeof(float), hipHostMallocDefault) != hipSuccess)
+            return kmcudaMemoryAllocationFailure;
+          for (auto &s : shards) {
+            (void)hipSetDevice(s->dev);
+            if (hipMemcpyAsync(host_dists + s->offset, s->dists, (size_t)s->length * sizeof(float),
+                               hipMemcpyDeviceToHost, s->eng->stream_) != hipSuccess)
+              return kmcudaMemoryCopyError;
+          }
+          RETERR(sync_all());
+          const double dist_sum = butterfly_sum(host_dists, N);
+          const uint32_t choice_approx = choice * N;
+          const double choice_sum = choice * dist_sum;
           uint32_t j = 0;
-          bool chosen = false;
-          if (device_chooser) {
-            Shard &s = *shards[0];
-            (void)hipSetDevice(s.dev);
-            hipStream_t st = s.eng->stream_;
-            const hipError_t se =
-                (kpp_filter && i >= 2)
-                    ? launch_kmpp_step_filtered(s.samples, N, D, kpp_dp, kpp_xs16, kpp_n2c, kpp_mu, kpp_stats, kpp_list,
-                                                s.centroids + (size_t)(i - 1) * D, i, s.dists, block_stats, bpre,
-                                                totals_dev, st)
-                    : launch_kmpp_step2(metric, s.samples, N, D, s.centroids + (size_t)(i - 1) * D, i, s.dists,
-                                        block_stats, bpre, totals_dev, st);
-            if (se != hipSuccess) return kmcudaRuntimeError;
-            if (hipMemcpyAsync(totals_host, totals_dev, sizeof(Totals), hipMemcpyDeviceToHost, st) != hipSuccess ||
+          if (choice_approx < 100) {
+            double dist_sum2 = 0;
+            for (j = 0; j < N && dist_sum2 < choice_sum; j++) dist_sum2 += host_dists[j];
+          } else {
+            double dist_sum2 = 0;
+            for (uint32_t t = 0; t < choice_approx; t++) dist_sum2 += host_dists[t];
+            if (dist_sum2 < choice_sum) {
+              for (j = choice_approx; j < N && dist_sum2 < choice_sum; j++) dist_sum2 += host_dists[j];
+            } else {
+              for (j = choice_approx; j > 1 && dist_sum2 >= choice_sum; j--) dist_sum2 -= host_dists[j];
+              j++;
+            }
+          }
+          if (j == 0 || j > N) {
+            INFO("\ninternal bug in kmeans_init_centroids: j = %u\n", j);
+            return kmcudaRuntimeError;
+          }
+          return copy_sample_to_centroid(j - 1, i);
+        };
+        if (device_chooser) {
+          // The host only draws the random numbers (one rand() per step, in order, as the reference) and enqueues:
+          // distances, statistics, prefix sums, the chooser and the copy of the chosen row all run on the device
+          // (seeding.hip).  A step the device cannot decide raises a flag that turns the rest of the enqueued
+          // kernels into no-ops; the host looks after every batch of steps, chooses that seed the reference's way from the
+          // distances as that step left them, lowers the flag and goes on behind it.
+          Shard &s = *shards[0];
+          (void)hipSetDevice(s.dev);
+          hipStream_t st = s.eng->stream_;
+          uint32_t *fail_dev = nullptr;
+          {
+            int rc = s.alloc(&fail_dev, 1);
+            if (rc) return rc;
+          }
+          if (hipMemsetAsync(fail_dev, 0, sizeof(uint32_t), st) != hipSuccess) return kmcudaRuntimeError;
+          std::vector<double> choices(K, 0.0);
+          // (steps enqueued behind an undecided one are wasted launches: the batch starts small, doubles while the
+          //  device decides, and falls back to one step after a hand-over -- a data set whose distances span too many
+          //  binades hands over every step)
+          constexpr uint32_t kBatchMax = 256;
+          uint32_t batch = 8;
+          uint32_t drawn = 1;   // choices[1 .. drawn) are drawn
+          uint32_t i = 1;
+          while (i < K) {
+            const uint32_t end = i + batch < K ? i + batch : K;
+            for (uint32_t t = i; t < end; t++) {
+              progress(t);
+              if (t >= drawn) {
+                choices[t] = ((rand() + .0) / RAND_MAX);   // kmcuda.cc:300
+                drawn = t + 1;
+              }
+              const float *newest = s.centroids + (size_t)(t - 1) * D;
+              const hipError_t se =
+                  (kpp_filter && t >= 2)
+                      ? launch_kmpp_step_filtered(s.samples, N, D, kpp_dp, kpp_xs16, kpp_n2c, kpp_mu, kpp_stats, kpp_list,
+                                                  newest, t, s.dists, block_stats, bpre, totals_dev, fail_dev, st)
+                      : launch_kmpp_step2(metric, s.samples, N, D, newest, t, s.dists, block_stats, bpre, totals_dev,
+                                          fail_dev, st);
+              if (se != hipSuccess) return kmcudaRuntimeError;
+              if (launch_kmpp_choose(s.dists, N, bpre, choices[t], log2n, t, s.samples, s.centroids, D, fail_dev,
+                                     totals_dev, st) != hipSuccess)
+                return kmcudaRuntimeError;
+            }
+            uint32_t failed = 0;
+            if (hipMemcpyAsync(totals_host, fail_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess)
               return kmcudaMemoryCopyError;
-            // every partial sum of the distances (and of their butterfly sums) is exact in double iff
-            // (emax + 1 + log2 N) - (emin - 23) <= 53
-            const bool none = totals_host->emin > totals_host->emax;
-            const bool exact = !totals_host->bad && (none || totals_host->emax - totals_host->emin + log2n <= 29u);
-            if (exact) {
-              const double dist_sum = totals_host->sum_g;
-              const double choice = ((rand() + .0) / RAND_MAX);   // kmcuda.cc:300-302
-              const uint32_t choice_approx = choice * N;
-              const double choice_sum = choice * dist_sum;
-              if (launch_kmpp_choose(s.dists, N, bpre, choice_approx, choice_sum, totals_dev, st) != hipSuccess)
-                return kmcudaRuntimeError;
-              if (hipMemcpyAsync(totals_host, totals_dev, sizeof(Totals), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                  hipStreamSynchronize(st) != hipSuccess)
-                return kmcudaMemoryCopyError;
-              j = totals_host->chosen;
-              chosen = true;
+            memcpy(&failed, totals_host, sizeof(uint32_t));
+            if (failed == 0) {
+              i = end;
+              batch = batch * 2 < kBatchMax ? batch * 2 : kBatchMax;
+              continue;
             }
-          } else {
+            batch = 1;
+            if (failed < i || failed >= end) return kmcudaRuntimeError;
+            RETERR(host_choose(failed, choices[failed]));
+            if (hipMemsetAsync(fail_dev, 0, sizeof(uint32_t), st) != hipSuccess) return kmcudaRuntimeError;
+            i = failed + 1;
+          }
+        } else {
+          for (uint32_t i = 1; i < K; i++) {
+            progress(i);
             for (auto &s : shards) {
               (void)hipSetDevice(s->dev);
               const hipError_t ke = strict_h2
@@ -617,43 +682,8 @@ class Job {
                                      s->eng->stream_);
               if (ke != hipSuccess) return kmcudaRuntimeError;
             }
+            RETERR(host_choose(i, ((rand() + .0) / RAND_MAX)));
           }
-          if (!chosen) {   // the reference's way, on the host
-            host_steps++;
-            if (!host_dists &&
-                hipHostMalloc(reinterpret_cast<void **>(&host_dists), (size_t)N * sizeof(float), hipHostMallocDefault) != hipSuccess)
-              return kmcudaMemoryAllocationFailure;
-            for (auto &s : shards) {
-              (void)hipSetDevice(s->dev);
-              if (hipMemcpyAsync(host_dists + s->offset, s->dists, (size_t)s->length * sizeof(float),
-                                 hipMemcpyDeviceToHost, s->eng->stream_) != hipSuccess)
-                return kmcudaMemoryCopyError;
-            }
-            RETERR(sync_all());
-            const double dist_sum = butterfly_sum(host_dists, N);
-            // the reference's chooser, kmcuda.cc:300-326
-            const double choice = ((rand() + .0) / RAND_MAX);
-            const uint32_t choice_approx = choice * N;
-            const double choice_sum = choice * dist_sum;
-            if (choice_approx < 100) {
-              double dist_sum2 = 0;
-              for (j = 0; j < N && dist_sum2 < choice_sum; j++) dist_sum2 += host_dists[j];
-            } else {
-              double dist_sum2 = 0;
-              for (uint32_t t = 0; t < choice_approx; t++) dist_sum2 += host_dists[t];
-              if (dist_sum2 < choice_sum) {
-                for (j = choice_approx; j < N && dist_sum2 < choice_sum; j++) dist_sum2 += host_dists[j];
-              } else {
-                for (j = choice_approx; j > 1 && dist_sum2 >= choice_sum; j--) dist_sum2 -= host_dists[j];
-                j++;
-              }
-            }
-          }
-          if (j == 0 || j > N) {
-            INFO("\ninternal bug in kmeans_init_centroids: j = %u\n", j);
-            return kmcudaRuntimeError;
-          }
-          RETERR(copy_sample_to_centroid(j - 1, i));
         }
         if (device_chooser) DEBUG("k-means++: %u of %u steps took the host chooser\n", host_steps, K - 1);
         RETERR(sync_all());

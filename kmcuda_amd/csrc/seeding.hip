@@ -97,7 +97,11 @@ __global__ __launch_bounds__(kKmppBlock) void kmpp_step2_kernel(const float *__r
                                                                 uint32_t cc, float *__restrict__ dists,
                                                                 KmppBlockStat *__restrict__ stats,
                                                                 const uint32_t *__restrict__ list,
-                                                                const uint32_t *__restrict__ count) {
+                                                                const uint32_t *__restrict__ count,
+                                                                const uint32_t *__restrict__ fail) {
+  // *fail != 0: an earlier step of the enqueued run could not be decided on the device (kmpp_choose_kernel): the
+  // distances stay as that step left them until the host has chosen its seed
+  if (fail && *fail) return;
   __shared__ __attribute__((aligned(16))) float tile[kKmppBlock * 36];
   if (list) {
     const uint32_t n = *count;
@@ -217,7 +221,9 @@ __global__ __launch_bounds__(kKmppBlock) void kmpp_step2_kernel(const float *__r
 // block statistics of the distances as they stand (after a filtered step)
 __global__ __launch_bounds__(kKmppBlock) void kmpp_stats_kernel(const float *__restrict__ dists, uint32_t N,
                                                                 KmppBlockStat *__restrict__ stats,
-                                                                uint32_t *__restrict__ list_count) {
+                                                                uint32_t *__restrict__ list_count,
+                                                                const uint32_t *__restrict__ fail) {
+  if (*fail) return;
   if (blockIdx.x == 0 && threadIdx.x == 0) {   // the step's survivor list has been consumed (stream order); [1..2] behind it: the running total
     *reinterpret_cast<unsigned long long *>(list_count + 1) += *list_count;
     *list_count = 0u;
@@ -297,8 +303,9 @@ __global__ __launch_bounds__(256) void kmpp_filter_kernel(const _Float16 *__rest
                                                           uint32_t N, uint32_t D, uint32_t DP,
                                                           const uint32_t *__restrict__ stats, float eps,
                                                           const float *__restrict__ dists, uint32_t *__restrict__ list,
-                                                          uint32_t *__restrict__ count) {
+                                                          uint32_t *__restrict__ count, const uint32_t *__restrict__ fail) {
   extern __shared__ __attribute__((aligned(16))) _Float16 s16[];   // DP halves: hi(s - mu)
+  if (*fail) return;
   __shared__ float red[4];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float part = 0.f;
@@ -413,7 +420,9 @@ struct KmppChunk {
   uint32_t emin, emax, bad, pad;
 };
 __global__ __launch_bounds__(1024) void kmpp_reduce_a_kernel(const KmppBlockStat *__restrict__ stats, uint32_t nb,
-                                                             double *__restrict__ bpre, KmppChunk *__restrict__ aux) {
+                                                             double *__restrict__ bpre, KmppChunk *__restrict__ aux,
+                                                             const uint32_t *__restrict__ fail) {
+  if (fail && *fail) return;
   __shared__ double wsum[16], wsg[16];
   __shared__ uint32_t wmin[16], wmax[16], wbad[16];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -458,7 +467,9 @@ __global__ __launch_bounds__(1024) void kmpp_reduce_a_kernel(const KmppBlockStat
 }
 // nchunks <= 1024
 __global__ __launch_bounds__(1024) void kmpp_reduce_b_kernel(const KmppChunk *__restrict__ aux, uint32_t nchunks,
-                                                             double *__restrict__ carry, KmppTotals *__restrict__ out) {
+                                                             double *__restrict__ carry, KmppTotals *__restrict__ out,
+                                                             const uint32_t *__restrict__ fail) {
+  if (fail && *fail) return;
   __shared__ double wsum[16], wsg[16];
   __shared__ uint32_t wmin[16], wmax[16], wbad[16];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -508,9 +519,31 @@ __global__ __launch_bounds__(1024) void kmpp_reduce_b_kernel(const KmppChunk *__
 //   forward search  m0(dca) = min { m in [0, N] : prefix(m) - dca >= cs }  (N when there is none)
 //   choice_approx < 100, or prefix(ca) < cs :  j = m0(0)
 //   else (backward loop, which subtracts d[ca] first):  j = max(2, min(m0(d[ca]) - 1, ca + 1))
+// Called with the step's random number only (choice in [0, 1], kmcuda.cc:300): the totals of the step are read from
+// the device, so the host need not wait for them -- it enqueues step after step.  A step the device cannot decide (a
+// NaN / inf distance, an exponent range too wide for exact sums, an index out of range) raises *fail = step: every
+// later kmpp kernel of the run returns at once, and the host chooses that seed the reference's way before it goes on.
+// Otherwise the chosen row is copied into centroid slot `step` here.
 __global__ __launch_bounds__(kKmppBlock) void kmpp_choose_kernel(const float *__restrict__ dists, uint32_t N,
                                                                  const double *__restrict__ bpre_local, uint32_t nb,
-                                                                 uint32_t ca, double cs, KmppTotals *__restrict__ out) {
+                                                                 double choice, uint32_t log2n, uint32_t step,
+                                                                 const float *__restrict__ samples,
+                                                                 float *__restrict__ centroids, uint32_t D,
+                                                                 uint32_t *__restrict__ fail,
+                                                                 KmppTotals *__restrict__ out) {
+  if (*fail) return;
+  {
+    // every partial sum of the distances (and of their butterfly sums) is exact in double iff
+    // (emax + 1 + log2 N) - (emin - 23) <= 53
+    const bool none = out->emin > out->emax;
+    const bool exact = !out->bad && (none || out->emax - out->emin + log2n <= 29u);
+    if (!exact) {
+      if (threadIdx.x == 0) *fail = step;
+      return;
+    }
+  }
+  const uint32_t ca = (uint32_t)(choice * (double)N);   // kmcuda.cc:301-302
+  const double cs = choice * out->sum_g;
   // exclusive prefix of block i (i <= nb): the chunk-local part + the chunk's carry (kmpp_reduce_*), stored behind
   // the nb local values: carry[c] = bpre_local[nb + c], carry[nchunks] = the total
   const uint32_t nchunks = (nb + 1023u) / 1024u;
@@ -579,32 +612,38 @@ __global__ __launch_bounds__(kKmppBlock) void kmpp_choose_kernel(const float *__
     j = max(2u, mp);
   }
   if (tid == 0) out->chosen = j;
+  if (j == 0u || j > N) {   // (the reference reports an internal bug here: so will the host)
+    if (tid == 0) *fail = step;
+    return;
+  }
+  for (uint32_t f = tid; f < D; f += kKmppBlock) centroids[(size_t)step * D + f] = samples[(size_t)(j - 1) * D + f];
 }
 
 // bpre: nb local prefixes, then nchunks + 1 carries, then (16-byte aligned) the nchunks chunk records
-static hipError_t launch_kmpp_reduce(const void *block_stats, uint32_t nb, double *bpre, void *totals, hipStream_t st) {
+static hipError_t launch_kmpp_reduce(const void *block_stats, uint32_t nb, double *bpre, void *totals,
+                                     const uint32_t *fail, hipStream_t st) {
   const uint32_t nchunks = (nb + 1023u) / 1024u;
   if (nchunks > 1024u) return hipErrorInvalidValue;   // (N > 2^28 rows: kmpp_supported() keeps such jobs on the host chooser)
   double *carry = bpre + nb;
   KmppChunk *aux = reinterpret_cast<KmppChunk *>(bpre + (((size_t)nb + nchunks + 1 + 1) & ~(size_t)1));
   hipLaunchKernelGGL(kmpp_reduce_a_kernel, dim3(nchunks), dim3(1024), 0, st,
-                     reinterpret_cast<const KmppBlockStat *>(block_stats), nb, bpre, aux);
+                     reinterpret_cast<const KmppBlockStat *>(block_stats), nb, bpre, aux, fail);
   hipLaunchKernelGGL(kmpp_reduce_b_kernel, dim3(1), dim3(1024), 0, st, aux, nchunks, carry,
-                     reinterpret_cast<KmppTotals *>(totals));
+                     reinterpret_cast<KmppTotals *>(totals), fail);
   return hipGetLastError();
 }
 
 hipError_t launch_kmpp_step2(int metric, const float *samples, uint32_t N, uint32_t D, const float *centroid,
                              uint32_t cc, float *dists, void *block_stats, double *bpre, void *totals_host,
-                             hipStream_t st) {
+                             const uint32_t *fail, hipStream_t st) {
   const uint32_t nb = (N + kKmppBlock - 1) / kKmppBlock;
   if (metric == 0)
     hipLaunchKernelGGL((kmpp_step2_kernel<0>), dim3(nb), dim3(kKmppBlock), 0, st, samples, N, D, centroid, cc, dists,
-                       reinterpret_cast<KmppBlockStat *>(block_stats), (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+                       reinterpret_cast<KmppBlockStat *>(block_stats), (const uint32_t *)nullptr, (const uint32_t *)nullptr, fail);
   else
     hipLaunchKernelGGL((kmpp_step2_kernel<1>), dim3(nb), dim3(kKmppBlock), 0, st, samples, N, D, centroid, cc, dists,
-                       reinterpret_cast<KmppBlockStat *>(block_stats), (const uint32_t *)nullptr, (const uint32_t *)nullptr);
-  return launch_kmpp_reduce(block_stats, nb, bpre, totals_host, st);
+                       reinterpret_cast<KmppBlockStat *>(block_stats), (const uint32_t *)nullptr, (const uint32_t *)nullptr, fail);
+  return launch_kmpp_reduce(block_stats, nb, bpre, totals_host, fail, st);
 }
 
 // The centred half copy of the rows for the filtered steps (L2): mu = column means of the first <= 65536 rows
@@ -626,14 +665,14 @@ hipError_t launch_kmpp_cache(const float *samples, uint32_t N, uint32_t D, uint3
 hipError_t launch_kmpp_step_filtered(const float *samples, uint32_t N, uint32_t D, uint32_t DP, const void *xs16,
                                      const float *n2c, const float *mu, uint32_t *stats, uint32_t *list,
                                      const float *centroid, uint32_t cc, float *dists, void *block_stats, double *bpre,
-                                     void *totals_host, hipStream_t st) {
+                                     void *totals_host, const uint32_t *fail, hipStream_t st) {
   const uint32_t nb = (N + kKmppBlock - 1) / kKmppBlock;
   const float eps = (float)(1.02 * ((double)D + 12.0) * 5.9604644775390625e-8);   // as the k-NN filter
   const uint32_t fgrid = (N + 127) / 128 < 1024u ? (N + 127) / 128 : 1024u;   // 16 waves per CU; one list atomic per wave
 #define KMX_KPP_FILTER(P)                                                                                           \
   hipLaunchKernelGGL((kmpp_filter_kernel<P>), dim3(fgrid), dim3(256), (size_t)DP * 2, st,                           \
                      reinterpret_cast<const _Float16 *>(xs16), n2c, mu, centroid, N, D, DP, stats, eps, dists, list, \
-                     stats + 1)
+                     stats + 1, fail)
   switch (DP / 64) {
     case 1: KMX_KPP_FILTER(1); break;
     case 2: KMX_KPP_FILTER(2); break;
@@ -646,17 +685,18 @@ hipError_t launch_kmpp_step_filtered(const float *samples, uint32_t N, uint32_t 
 #undef KMX_KPP_FILTER
   const uint32_t lgrid = nb < 1024u ? nb : 1024u;
   hipLaunchKernelGGL((kmpp_step2_kernel<0>), dim3(lgrid), dim3(kKmppBlock), 0, st, samples, N, D, centroid, cc, dists,
-                     (KmppBlockStat *)nullptr, list, stats + 1);
+                     (KmppBlockStat *)nullptr, list, stats + 1, fail);
   hipLaunchKernelGGL(kmpp_stats_kernel, dim3(nb < 4096u ? nb : 4096u), dim3(kKmppBlock), 0, st, dists, N,
-                     reinterpret_cast<KmppBlockStat *>(block_stats), stats + 1);
-  return launch_kmpp_reduce(block_stats, nb, bpre, totals_host, st);
+                     reinterpret_cast<KmppBlockStat *>(block_stats), stats + 1, fail);
+  return launch_kmpp_reduce(block_stats, nb, bpre, totals_host, fail, st);
 }
 
-hipError_t launch_kmpp_choose(const float *dists, uint32_t N, const double *bpre, uint32_t choice_approx,
-                              double choice_sum, void *totals_host, hipStream_t st) {
+hipError_t launch_kmpp_choose(const float *dists, uint32_t N, const double *bpre, double choice, uint32_t log2n,
+                              uint32_t step, const float *samples, float *centroids, uint32_t D, uint32_t *fail,
+                              void *totals, hipStream_t st) {
   const uint32_t nb = (N + kKmppBlock - 1) / kKmppBlock;
-  hipLaunchKernelGGL(kmpp_choose_kernel, dim3(1), dim3(kKmppBlock), 0, st, dists, N, bpre, nb, choice_approx, choice_sum,
-                     reinterpret_cast<KmppTotals *>(totals_host));
+  hipLaunchKernelGGL(kmpp_choose_kernel, dim3(1), dim3(kKmppBlock), 0, st, dists, N, bpre, nb, choice, log2n, step,
+                     samples, centroids, D, fail, reinterpret_cast<KmppTotals *>(totals));
   return hipGetLastError();
 }
 
