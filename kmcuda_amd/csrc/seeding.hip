@@ -351,7 +351,8 @@ __global__ __launch_bounds__(256) void kmpp_filter_kernel(const _Float16 *__rest
       const float score = acc - 0.5f * n2;
       const float T2 = T * T * 1.000001f;
       const float amin = 0.5f * (sn2 - T2 - E) - 1e-6f * (sn2 + T2);
-      need = !(usable && score < amin);   // NaN anywhere: not dropped
+      // (a row whose centred norm is beyond the half range may hold inf halves: never dropped; NaN anywhere: neither)
+      need = !(usable && n2 < 3.6e9f && score < amin);
     }
     // Survivors wait in the wave's LDS buffer: one global atomic per kBuf of them, not one per 8-row group (same-
     // address atomics are served one at a time by L2: 50 K of them per step were half of the kernel's time)

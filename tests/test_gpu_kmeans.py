@@ -508,7 +508,7 @@ def test_kmeanspp_device_chooser_equals_host(monkeypatch, case):
     assert (res[0][1] == res[1][1]).all()
 
 
-@pytest.mark.parametrize("case", ["uniform", "blobs", "duplicates", "wide", "ragged", "nan", "huge", "big", "fp16"])
+@pytest.mark.parametrize("case", ["uniform", "blobs", "duplicates", "wide", "ragged", "nan", "huge", "fewhuge", "big", "fp16"])
 def test_kmeanspp_filtered_steps_equal_plain_steps(monkeypatch, case):
     """k-means++ steps with the half-copy filter in front (seeding.hip: rows that provably are no closer to the new
     seed than to an earlier one are dropped, the exact chains run for the rest) against the plain steps
@@ -538,6 +538,12 @@ def test_kmeanspp_filtered_steps_equal_plain_steps(monkeypatch, case):
         x, k = rs.rand(20000, 24).astype(numpy.float32), 40
         x[::50] *= 1e6
         x[3::77, 2] = numpy.inf
+    elif case == "fewhuge":
+        # only a few rows are far beyond the half range (their centred norms overflow to inf and stay out of the
+        # maximum the bound uses): they must reach the exact chain, the others are filtered as usual
+        x, k = rs.rand(20000, 24).astype(numpy.float32), 40
+        x[7::1999] = 3e19
+        x[11::2999, 3] = -1e30
     elif case == "big":
         x, k, force = rs.rand(200000, 256).astype(numpy.float32), 48, "1"
     else:
