@@ -251,8 +251,8 @@ hipError_t launch_yy_local_filter(int metric, const float *samples, uint32_t len
 #define KNN16_PD 3              // candidate fragments in flight per wave
 #endif
 #define KNN16_PAD_ROWS 64   // rows of xs16 / entries of kbias the caller allocates (and the split zeroes) past N
-// rows wider than 256 features (DP = 512): ONE operand set per wave (a lane's half of a 512-feature row in halves
-// is 128 registers) and one 32-candidate sub-tile per staged tile (32 KB)
+// rows wider than 256 features (DP = 512 / 768 / 1024): ONE operand set per wave (a lane's half of a 512-feature row
+// in halves is 128 registers) and one 32-candidate sub-tile per staged tile (32 / 48 / 64 KB)
 constexpr int knn16_nset(int DP) { return DP > 256 ? 1 : KNN16_NSET; }
 constexpr int knn16_sub(int DP) { return DP > 256 ? 1 : KNN16_SUB; }
 constexpr uint32_t KNN_QPB_F32 = 128;

@@ -1296,8 +1296,10 @@ class KnnJob {
     const char *fenv = getenv("KMCUDA_AMD_FILTER");
     const bool want_f32 = fenv && strcmp(fenv, "f32") == 0;
     uint32_t dp_filter = ((force_exact && atoi(force_exact)) || strict_h2) ? 0 : filter_dp_for(D);
-    // 256 < D <= 512: the f16 filter's one-operand-set instantiation (knn_f16.hip; the f32 filter stops at 256)
-    if (!dp_filter && !(force_exact && atoi(force_exact)) && !strict_h2 && !want_f32 && D > 256 && D <= 512) dp_filter = 512;
+    // 256 < D <= 1024: the f16 filter's one-operand-set instantiations (knn_f16.hip: 512 with two blocks per CU;
+    // 768 / 1024 with one -- the queries' operands alone are 192 / 256 registers; the f32 filter stops at 256)
+    if (!dp_filter && !(force_exact && atoi(force_exact)) && !strict_h2 && !want_f32 && D > 256 && D <= 1024)
+      dp_filter = D <= 512 ? 512u : (D <= 768 ? 768u : 1024u);
     const uint32_t DP = dp_filter ? dp_filter : D;
     if (!dp_filter) INFO("k-NN: every candidate is evaluated with the exact arithmetic (no matrix-core filter)\n");
     // which matrix-core instruction filters the candidates: f16 on centred hi/lo-split rows (default,

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void knn_split_kernel(const float *__restrict_
 // Instrumented builds of the one-set kernel (per-phase s_memtime counters, per-wave timeline of one block):
 // profiles/r2e_knn_filter_phase_counters.log, r2e_knn_filter_block_timeline.log.
 template <int DP, int METRIC, bool FASTX>
-__global__ __launch_bounds__(KNN16_WAVES * 64, KNN16_BLOCKS_PER_CU) void knn_filter_f16_kernel(KnnArgs a) {
+__global__ __launch_bounds__(KNN16_WAVES * 64, (DP > 512 ? 1 : KNN16_BLOCKS_PER_CU)) void knn_filter_f16_kernel(KnnArgs a) {
   constexpr int WV = KNN16_WAVES, NSET = knn16_nset(DP);
   constexpr int NKH = DP / 2;   // features per half-wave
   constexpr int KS = NKH / 8;   // k-steps = 16-byte chunks per half row
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(KNN16_WAVES * 64, KNN16_BLOCKS_PER_CU) void knn_fil
     }
 #undef KMX_VM_CASE
   };
-  static_assert(PPW + 1 <= 9 && (NBUF - 2) * 9 < 64, "wait_tiles: DMAs per wave and tile");
+  static_assert(NBUF == 2 || (PPW + 1 <= 9 && (NBUF - 2) * 9 < 64), "wait_tiles: DMAs per wave and tile");
   static_assert(SUB == 1 || SUB == 2, "one 64-lane bias DMA per tile");
   static_assert(NBUF >= 2, "ring");
   const uint32_t fragbase = lds0 + (uint32_t)col * ROWB + (uint32_t)h * (KS * 16);
@@ -495,6 +495,8 @@ hipError_t launch_knn_filter_f16(int metric, const KnnArgs &a, uint32_t nblocks,
     KMX_KNN16_CASE(128);
     KMX_KNN16_CASE(256);
     KMX_KNN16_CASE(512);
+    KMX_KNN16_CASE(768);
+    KMX_KNN16_CASE(1024);
     default: return hipErrorInvalidValue;
   }
 #undef KMX_KNN16_CASE

@@ -99,7 +99,9 @@ def test_device_ptr(clustered13k):
 
 @pytest.mark.parametrize("n,d,K,k", [(8000, 48, 160, 10), (6000, 256, 64, 10), (5000, 7, 40, 3), (3000, 100, 20, 33),
                                      (2000, 300, 16, 5),            # 256 < D <= 512: the one-operand-set f16 filter
-                                     (3000, 512, 24, 10), (2500, 400, 300, 4), (1500, 640, 12, 6)])   # 640: exact search
+                                     (3000, 512, 24, 10), (2500, 400, 300, 4),
+                                     (1500, 640, 12, 6), (2200, 768, 20, 10), (2000, 1024, 16, 10),   # 513..1024: one block per CU
+                                     (900, 1100, 8, 5)])            # beyond 1024: the exact search
 @pytest.mark.parametrize("filt", ["f16", "f32"])
 def test_matches_oracle_bit_exact(n, d, K, k, filt, monkeypatch):
     from kmcuda_amd import knn_cuda
