@@ -154,12 +154,14 @@ hipError_t launch_kmpp_step2(int metric, const float *samples, uint32_t N, uint3
 hipError_t launch_kmpp_choose(const float *dists, uint32_t N, const double *bpre, double choice, uint32_t log2n,
                               uint32_t step, const float *samples, float *centroids, uint32_t D, uint32_t *fail,
                               void *totals, hipStream_t st);
-// filtered k-means++ steps (L2; seeding.hip): the centred half copy of the rows, then per step the survivors of
+// filtered k-means++ steps (seeding.hip): the centred half copy of the rows, then per step the survivors of
 // the k-NN candidate bound get the exact chain.  DP: D rounded up to 64; stats: 4 words ([2..3]: exact chains run so far, 64 bits); list: N words.
+// (mux: N floats, mu.(x - mu) per row: the angular metric's bias; nullptr for L2)
 hipError_t launch_kmpp_cache(const float *samples, uint32_t N, uint32_t D, uint32_t DP, double *part, float *mu,
-                             void *xs16, float *n2c, uint32_t *stats, hipStream_t st);
-hipError_t launch_kmpp_step_filtered(const float *samples, uint32_t N, uint32_t D, uint32_t DP, const void *xs16,
-                                     const float *n2c, const float *mu, uint32_t *stats, uint32_t *list,
+                             void *xs16, float *n2c, float *mux, uint32_t *stats, hipStream_t st);
+hipError_t launch_kmpp_step_filtered(int metric, const float *samples, uint32_t N, uint32_t D, uint32_t DP,
+                                     const void *xs16, const float *n2c, const float *mux, const float *mu,
+                                     uint32_t *stats, uint32_t *list,
                                      const float *centroid, uint32_t cc, float *dists, void *block_stats, double *bpre,
                                      void *totals, const uint32_t *fail, hipStream_t st);
 size_t kmpp_block_stat_bytes(uint32_t N);

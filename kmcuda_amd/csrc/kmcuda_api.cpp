@@ -521,17 +521,17 @@ class Job {
           if (hipHostMalloc(reinterpret_cast<void **>(&totals_host), sizeof(Totals), hipHostMallocDefault) != hipSuccess)
             return kmcudaMemoryAllocationFailure;
         }
-        // Filtered steps (L2, seeding.hip): a centred half copy of the rows; a step's first kernel drops every row
+        // Filtered steps (seeding.hip): a centred half copy of the rows; a step's first kernel drops every row
         // that provably is no closer to the new seed than to an earlier one, the exact chains run for the rest.
         // Needs 2 DP + 8 bytes per row beside the rows; without that memory (or KMCUDA_AMD_KMPP_FILTER=0) every
         // step is the plain one.  Same dists[] after every step either way, hence the same seeds.
         const uint32_t kpp_dp = ((uint32_t)D + 63u) / 64u * 64u;
         void *kpp_xs16 = nullptr;
-        float *kpp_n2c = nullptr, *kpp_mu = nullptr;
+        float *kpp_n2c = nullptr, *kpp_mu = nullptr, *kpp_mux = nullptr;
         uint32_t *kpp_stats = nullptr, *kpp_list = nullptr;
         double *kpp_part = nullptr;
         struct KppFree {
-          void **a; float **b, **c; uint32_t **d, **e; double **f;
+          void **a; float **b, **c; uint32_t **d, **e; double **f; float **g;
           ~KppFree() {
             if (*a) (void)hipFree(*a);
             if (*b) (void)hipFree(*b);
@@ -539,13 +539,14 @@ class Job {
             if (*d) (void)hipFree(*d);
             if (*e) (void)hipFree(*e);
             if (*f) (void)hipFree(*f);
+            if (*g) (void)hipFree(*g);
           }
-        } kpp_guard{&kpp_xs16, &kpp_n2c, &kpp_mu, &kpp_stats, &kpp_list, &kpp_part};
+        } kpp_guard{&kpp_xs16, &kpp_n2c, &kpp_mu, &kpp_stats, &kpp_list, &kpp_part, &kpp_mux};
         // (small jobs: the plain step is a few launches of nothing; KMCUDA_AMD_KMPP_FILTER=2 filters them too: tests)
-        bool kpp_filter = device_chooser && metric == 0 && K >= 8 && N >= 65536u && kpp_dp <= 16384u;
+        bool kpp_filter = device_chooser && K >= 8 && N >= 65536u && kpp_dp <= 16384u;
         if (const char *v = getenv("KMCUDA_AMD_KMPP_FILTER")) {
           const int f = atoi(v);
-          kpp_filter = f >= 2 ? (device_chooser && metric == 0 && K >= 3 && kpp_dp <= 16384u) : (kpp_filter && f != 0);
+          kpp_filter = f >= 2 ? (device_chooser && K >= 3 && kpp_dp <= 16384u) : (kpp_filter && f != 0);
         }
         if (kpp_filter) {
           Shard &s = *shards[0];
@@ -555,12 +556,13 @@ class Job {
                           hipMalloc(reinterpret_cast<void **>(&kpp_mu), (size_t)kpp_dp * sizeof(float)) == hipSuccess &&
                           hipMalloc(reinterpret_cast<void **>(&kpp_stats), 4 * sizeof(uint32_t)) == hipSuccess &&
                           hipMalloc(reinterpret_cast<void **>(&kpp_list), (size_t)N * sizeof(uint32_t)) == hipSuccess &&
-                          hipMalloc(reinterpret_cast<void **>(&kpp_part), (size_t)64 * D * sizeof(double)) == hipSuccess;
+                          hipMalloc(reinterpret_cast<void **>(&kpp_part), (size_t)64 * D * sizeof(double)) == hipSuccess &&
+                          (metric == 0 || hipMalloc(reinterpret_cast<void **>(&kpp_mux), (size_t)N * sizeof(float)) == hipSuccess);
           if (!ok) {
             (void)hipGetLastError();
             kpp_filter = false;
             DEBUG("k-means++: no memory for the half copy of the rows, plain steps\n");
-          } else if (launch_kmpp_cache(s.samples, N, D, kpp_dp, kpp_part, kpp_mu, kpp_xs16, kpp_n2c, kpp_stats,
+          } else if (launch_kmpp_cache(s.samples, N, D, kpp_dp, kpp_part, kpp_mu, kpp_xs16, kpp_n2c, kpp_mux, kpp_stats,
                                        s.eng->stream_) != hipSuccess) {
             return kmcudaRuntimeError;
           }
@@ -645,7 +647,7 @@ class Job {
               const float *newest = s.centroids + (size_t)(t - 1) * D;
               const hipError_t se =
                   (kpp_filter && t >= 2)
-                      ? launch_kmpp_step_filtered(s.samples, N, D, kpp_dp, kpp_xs16, kpp_n2c, kpp_mu, kpp_stats, kpp_list,
+                      ? launch_kmpp_step_filtered(metric, s.samples, N, D, kpp_dp, kpp_xs16, kpp_n2c, kpp_mux, kpp_mu, kpp_stats, kpp_list,
                                                   newest, t, s.dists, block_stats, bpre, totals_dev, fail_dev, st)
                       : launch_kmpp_step2(metric, s.samples, N, D, newest, t, s.dists, block_stats, bpre, totals_dev,
                                           fail_dev, st);

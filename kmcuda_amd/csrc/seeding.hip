@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kKmppBlock) void kmpp_stats_kernel(const float *__r
 }
 
 // ---------------------------------------------------------------------------------------
-// Filtered steps (L2).  A step only changes dists[s] where the new seed is CLOSER than the row's nearest seed so
+// Filtered steps.  A step only changes dists[s] where the new seed is CLOSER than the row's nearest seed so
 // far -- one row in i at step i on average -- but the plain step streams all N rows (4 D bytes each) to find out.
 // Here the rows are kept a second time as centred halves (2 DP bytes; kmpp_cache_kernel, once per call), a
 // step's first kernel forms hi(x').hi(s') per row (8 lanes per row, f32 accumulation) and drops every row whose
@@ -274,22 +274,28 @@ __global__ __launch_bounds__(256) void kmpp_mean_kernel(const double *__restrict
 __global__ __launch_bounds__(256) void kmpp_cache_kernel(const float *__restrict__ samples, uint32_t N, uint32_t D,
                                                          uint32_t DP, const float *__restrict__ mu,
                                                          _Float16 *__restrict__ xs16, float *__restrict__ n2c,
-                                                         uint32_t *__restrict__ stats) {
+                                                         float *__restrict__ mux, uint32_t *__restrict__ stats) {
   const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63;
   if (p >= N) return;
   const float *src = samples + (size_t)p * D;
   _Float16 *dst = xs16 + (size_t)p * DP;
-  float a = 0.f;
+  float a = 0.f, b = 0.f;
   for (uint32_t f = lane; f < DP; f += 64) {
-    const float v = f < D ? src[f] - mu[f] : 0.f;
+    const float m = f < D ? mu[f] : 0.f;
+    const float v = f < D ? src[f] - m : 0.f;
     dst[f] = (_Float16)v;
     a = fmaf(v, v, a);
+    b = fmaf(m, v, b);
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_xor(a, off);
+    b += __shfl_xor(b, off);
+  }
   if (lane == 0) {
     n2c[p] = a;
+    if (mux) mux[p] = b;   // angular: x.s = x'.s' + mu.x' + (mu.s' + ||mu||^2)
     if ((a - a) == 0.f && __float_as_uint(a) > *reinterpret_cast<volatile uint32_t *>(&stats[0]))
       atomicMax(&stats[0], __float_as_uint(a));
   }
@@ -297,8 +303,9 @@ __global__ __launch_bounds__(256) void kmpp_cache_kernel(const float *__restrict
 
 // PPL: 16-byte pieces per lane and row (DP = 64 PPL), 0 = any DP (rolled loops).  With PPL known a wave has the
 // pieces of 4 x 8 rows in flight before the first product (a 4-GB stream per step: bandwidth is the whole cost).
-template <int PPL>
+template <int PPL, int METRIC>
 __global__ __launch_bounds__(256) void kmpp_filter_kernel(const _Float16 *__restrict__ xs16, const float *__restrict__ n2c,
+                                                          const float *__restrict__ mux,
                                                           const float *__restrict__ mu, const float *__restrict__ seed,
                                                           uint32_t N, uint32_t D, uint32_t DP,
                                                           const uint32_t *__restrict__ stats, float eps,
@@ -306,26 +313,42 @@ __global__ __launch_bounds__(256) void kmpp_filter_kernel(const _Float16 *__rest
                                                           uint32_t *__restrict__ count, const uint32_t *__restrict__ fail) {
   extern __shared__ __attribute__((aligned(16))) _Float16 s16[];   // DP halves: hi(s - mu)
   if (*fail) return;
-  __shared__ float red[4];
+  __shared__ float red[3][4];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float part = 0.f;
+  float part = 0.f, pmus = 0.f, pmu2 = 0.f;
   for (uint32_t f = threadIdx.x; f < DP; f += 256) {
-    const float v = f < D ? seed[f] - mu[f] : 0.f;
+    const float m = f < D ? mu[f] : 0.f;
+    const float v = f < D ? seed[f] - m : 0.f;
     s16[f] = (_Float16)v;
     part = fmaf(v, v, part);
+    pmus = fmaf(m, v, pmus);
+    pmu2 = fmaf(m, m, pmu2);
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-  if (lane == 0) red[wave] = part;
+  for (int off = 32; off > 0; off >>= 1) {
+    part += __shfl_xor(part, off);
+    pmus += __shfl_xor(pmus, off);
+    pmu2 += __shfl_xor(pmu2, off);
+  }
+  if (lane == 0) { red[0][wave] = part; red[1][wave] = pmus; red[2][wave] = pmu2; }
   __syncthreads();
-  const float sn2 = (red[0] + red[1]) + (red[2] + red[3]);   // ||s'||^2 (the "query" of knn_f16.hip)
+  const float sn2 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);   // ||s'||^2 (the "query" of knn_f16.hip)
+  const float mus = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);   // mu.s'
+  const float mu2 = ((red[2][0] + red[2][1]) + (red[2][2] + red[2][3])) * 1.0001f;   // ||mu||^2, as knn_cuda inflates it
   // the k-NN filter's bound with one query: a row can only come closer than T = dists[s] if
   //   hi(x').hi(s') - ||x'||^2 / 2  >=  (||s'||^2 - T^2 - E) / 2 - 1e-6 (||s'||^2 + T^2)
   const float nmax2 = __uint_as_float(stats[0]);
   const float u = 5.9604645e-8f;
   const float qn = sqrtf(sn2) * 1.0001f, nmx = sqrtf(nmax2) * 1.0001f;
   const float e_round = 9.78e-4f * qn * nmx;
-  const float E = 4.04f * (3.0f * eps + 16.0f * u) * (sn2 + nmax2) + 6e-8f * sqrtf((float)DP) * (qn + nmx) + 2.0f * e_round;
+  // angular (knn_f16.hip's bound again): a row can only come closer than T if
+  //   hi(x').hi(s') + mu.x'  >=  cos(T) - (mu.s' + ||mu||^2) - E
+  const float mun = sqrtf(mu2) * 1.0001f;
+  const float kq = mus + mu2;
+  const float E = METRIC == 0
+      ? 4.04f * (3.0f * eps + 16.0f * u) * (sn2 + nmax2) + 6e-8f * sqrtf((float)DP) * (qn + nmx) + 2.0f * e_round
+      : 2.02f * (3.0f * eps + 16.0f * u) * (qn * nmx + mun * nmx) + 3e-8f * sqrtf((float)DP) * (qn + nmx) +
+            eps * (mun * qn + mu2) + 1e-6f + e_round;
   // operands near the half range could round to inf: then nothing is dropped
   const bool usable = (sn2 - sn2) == 0.f && qn < 6.0e4f && nmx < 6.0e4f && (E - E) == 0.f;
   const uint32_t l8 = lane & 7u, rsub = lane >> 3;
@@ -348,9 +371,15 @@ __global__ __launch_bounds__(256) void kmpp_filter_kernel(const _Float16 *__rest
     bool need = false;
     if (live && l8 == 0) {
       const float n2 = n2c[s], T = dists[s];
-      const float score = acc - 0.5f * n2;
-      const float T2 = T * T * 1.000001f;
-      const float amin = 0.5f * (sn2 - T2 - E) - 1e-6f * (sn2 + T2);
+      float score, amin;
+      if (METRIC == 0) {
+        score = acc - 0.5f * n2;
+        const float T2 = T * T * 1.000001f;
+        amin = 0.5f * (sn2 - T2 - E) - 1e-6f * (sn2 + T2);
+      } else {
+        score = acc + mux[s];
+        amin = T >= 3.1415925f ? -INFINITY : cosf(T) - kq - E;   // (NaN T: NaN amin: not dropped)
+      }
       // (a row whose centred norm is beyond the half range may hold inf halves: never dropped; NaN anywhere: neither)
       need = !(usable && n2 < 3.6e9f && score < amin);
     }
@@ -650,30 +679,35 @@ hipError_t launch_kmpp_step2(int metric, const float *samples, uint32_t N, uint3
 // The centred half copy of the rows for the filtered steps (L2): mu = column means of the first <= 65536 rows
 // (any vector is valid; a central one keeps the norms in the error bound small).  part: 64 x D doubles of scratch.
 hipError_t launch_kmpp_cache(const float *samples, uint32_t N, uint32_t D, uint32_t DP, double *part, float *mu,
-                             void *xs16, float *n2c, uint32_t *stats, hipStream_t st) {
+                             void *xs16, float *n2c, float *mux, uint32_t *stats, hipStream_t st) {
   const uint32_t rows = N < 65536u ? N : 65536u;
   hipError_t e = hipMemsetAsync(stats, 0, 4 * sizeof(uint32_t), st);   // [0] max ||x'||^2, [1] survivors of the step, [2..3] of all steps
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kmpp_colsum_kernel, dim3(64), dim3(256), 0, st, samples, rows, D, part);
   hipLaunchKernelGGL(kmpp_mean_kernel, dim3((DP + 255) / 256), dim3(256), 0, st, part, 64u, rows, D, DP, mu);
   hipLaunchKernelGGL(kmpp_cache_kernel, dim3((N + 3) / 4), dim3(256), 0, st, samples, N, D, DP, mu,
-                     reinterpret_cast<_Float16 *>(xs16), n2c, stats);
+                     reinterpret_cast<_Float16 *>(xs16), n2c, mux, stats);
   return hipGetLastError();
 }
 
 // One filtered step (cc >= 2; the first step has nothing to compare with: launch_kmpp_step2): survivors of the
 // bound -> exact chains -> block statistics -> totals, as launch_kmpp_step2 leaves them.
-hipError_t launch_kmpp_step_filtered(const float *samples, uint32_t N, uint32_t D, uint32_t DP, const void *xs16,
-                                     const float *n2c, const float *mu, uint32_t *stats, uint32_t *list,
+hipError_t launch_kmpp_step_filtered(int metric, const float *samples, uint32_t N, uint32_t D, uint32_t DP,
+                                     const void *xs16, const float *n2c, const float *mux, const float *mu,
+                                     uint32_t *stats, uint32_t *list,
                                      const float *centroid, uint32_t cc, float *dists, void *block_stats, double *bpre,
                                      void *totals_host, const uint32_t *fail, hipStream_t st) {
   const uint32_t nb = (N + kKmppBlock - 1) / kKmppBlock;
   const float eps = (float)(1.02 * ((double)D + 12.0) * 5.9604644775390625e-8);   // as the k-NN filter
   const uint32_t fgrid = (N + 127) / 128 < 1024u ? (N + 127) / 128 : 1024u;   // 16 waves per CU; one list atomic per wave
+#define KMX_KPP_FILTER1(P, M)                                                                                       \
+  hipLaunchKernelGGL((kmpp_filter_kernel<P, M>), dim3(fgrid), dim3(256), (size_t)DP * 2, st,                        \
+                     reinterpret_cast<const _Float16 *>(xs16), n2c, mux, mu, centroid, N, D, DP, stats, eps, dists,  \
+                     list, stats + 1, fail)
 #define KMX_KPP_FILTER(P)                                                                                           \
-  hipLaunchKernelGGL((kmpp_filter_kernel<P>), dim3(fgrid), dim3(256), (size_t)DP * 2, st,                           \
-                     reinterpret_cast<const _Float16 *>(xs16), n2c, mu, centroid, N, D, DP, stats, eps, dists, list, \
-                     stats + 1, fail)
+  do {                                                                                                              \
+    if (metric == 0) KMX_KPP_FILTER1(P, 0); else KMX_KPP_FILTER1(P, 1);                                             \
+  } while (0)
   switch (DP / 64) {
     case 1: KMX_KPP_FILTER(1); break;
     case 2: KMX_KPP_FILTER(2); break;
@@ -684,9 +718,14 @@ hipError_t launch_kmpp_step_filtered(const float *samples, uint32_t N, uint32_t 
     default: KMX_KPP_FILTER(0); break;
   }
 #undef KMX_KPP_FILTER
+#undef KMX_KPP_FILTER1
   const uint32_t lgrid = nb < 1024u ? nb : 1024u;
-  hipLaunchKernelGGL((kmpp_step2_kernel<0>), dim3(lgrid), dim3(kKmppBlock), 0, st, samples, N, D, centroid, cc, dists,
-                     (KmppBlockStat *)nullptr, list, stats + 1, fail);
+  if (metric == 0)
+    hipLaunchKernelGGL((kmpp_step2_kernel<0>), dim3(lgrid), dim3(kKmppBlock), 0, st, samples, N, D, centroid, cc, dists,
+                       (KmppBlockStat *)nullptr, list, stats + 1, fail);
+  else
+    hipLaunchKernelGGL((kmpp_step2_kernel<1>), dim3(lgrid), dim3(kKmppBlock), 0, st, samples, N, D, centroid, cc, dists,
+                       (KmppBlockStat *)nullptr, list, stats + 1, fail);
   hipLaunchKernelGGL(kmpp_stats_kernel, dim3(nb < 4096u ? nb : 4096u), dim3(kKmppBlock), 0, st, dists, N,
                      reinterpret_cast<KmppBlockStat *>(block_stats), stats + 1, fail);
   return launch_kmpp_reduce(block_stats, nb, bpre, totals_host, fail, st);

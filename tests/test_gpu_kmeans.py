@@ -508,7 +508,8 @@ def test_kmeanspp_device_chooser_equals_host(monkeypatch, case):
     assert (res[0][1] == res[1][1]).all()
 
 
-@pytest.mark.parametrize("case", ["uniform", "blobs", "duplicates", "wide", "ragged", "nan", "huge", "fewhuge", "big", "fp16"])
+@pytest.mark.parametrize("case", ["uniform", "blobs", "duplicates", "wide", "ragged", "nan", "huge", "fewhuge", "big", "fp16",
+                                  "cos", "cosblobs", "cos16"])
 def test_kmeanspp_filtered_steps_equal_plain_steps(monkeypatch, case):
     """k-means++ steps with the half-copy filter in front (seeding.hip: rows that provably are no closer to the new
     seed than to an earlier one are dropped, the exact chains run for the rest) against the plain steps
@@ -546,12 +547,24 @@ def test_kmeanspp_filtered_steps_equal_plain_steps(monkeypatch, case):
         x[11::2999, 3] = -1e30
     elif case == "big":
         x, k, force = rs.rand(200000, 256).astype(numpy.float32), 48, "1"
-    else:
+    elif case == "fp16":
         x, k = rs.rand(30000, 64).astype(numpy.float16), 100
+    elif case == "cos":        # the angular metric: rows on the unit sphere
+        x, k = rs.randn(30000, 48).astype(numpy.float32), 120
+    elif case == "cosblobs":   # ... in tight bunches: angles near 0, where acos is steep
+        cen = rs.randn(30, 100)
+        x, k = (cen[rs.randint(0, 30, 25000)] + 0.05 * rs.randn(25000, 100)).astype(numpy.float32), 64
+    else:
+        x, k = (rs.rand(30000, 64) - 0.3).astype(numpy.float32), 100
+    metric = "cos" if case.startswith("cos") else "L2"
+    if metric == "cos":
+        x = (x / numpy.linalg.norm(x, axis=1, keepdims=True)).astype(numpy.float32)
+        if case == "cos16":
+            x = x.astype(numpy.float16)
     res = []
     for filt in (force, "0"):
         monkeypatch.setenv("KMCUDA_AMD_KMPP_FILTER", filt)
-        c, a = kmeans_cuda(x, k, tolerance=0.5, init="k-means++", seed=11, yinyang_t=0, verbosity=0)
+        c, a = kmeans_cuda(x, k, tolerance=0.5, init="k-means++", seed=11, yinyang_t=0, verbosity=0, metric=metric)
         res.append((c.copy(), a.copy()))
     assert numpy.array_equal(res[0][0], res[1][0], equal_nan=True)   # after one update: same seeds
     assert (res[0][1] == res[1][1]).all()
