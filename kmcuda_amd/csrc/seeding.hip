@@ -218,21 +218,58 @@ __global__ __launch_bounds__(kKmppBlock) void kmpp_step2_kernel(const float *__r
   kmpp_block_stats(v, &stats[blockIdx.x]);
 }
 
-// block statistics of the distances as they stand (after a filtered step)
-__global__ __launch_bounds__(kKmppBlock) void kmpp_stats_kernel(const float *__restrict__ dists, uint32_t N,
-                                                                KmppBlockStat *__restrict__ stats,
-                                                                uint32_t *__restrict__ list_count,
-                                                                const uint32_t *__restrict__ fail) {
+// block statistics of the distances as they stand (after a filtered step): ONE WAVE per block of kKmppBlock rows, four
+// trips of 64 rows, no LDS, no barrier (kmpp_block_stats' shape -- four waves meeting in LDS -- is latency: 70 us for
+// 32 MB).  The same numbers: the butterfly sums are per 32 lanes, the double sums exact in any order.
+__global__ __launch_bounds__(256) void kmpp_stats_kernel(const float *__restrict__ dists, uint32_t N,
+                                                         KmppBlockStat *__restrict__ stats,
+                                                         uint32_t *__restrict__ list_count,
+                                                         const uint32_t *__restrict__ fail) {
   if (*fail) return;
   if (blockIdx.x == 0 && threadIdx.x == 0) {   // the step's survivor list has been consumed (stream order); [1..2] behind it: the running total
     *reinterpret_cast<unsigned long long *>(list_count + 1) += *list_count;
     *list_count = 0u;
   }
   const uint32_t nb = (N + kKmppBlock - 1) / kKmppBlock;
-  for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
-    const uint32_t s = b * kKmppBlock + threadIdx.x;
-    kmpp_block_stats(s < N ? dists[s] : 0.f, &stats[b]);
-    __syncthreads();   // kmpp_block_stats' shared words are read by thread 0 until here
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  for (uint32_t b = wave_global; b < nb; b += nwaves) {
+    float v[kKmppBlock / 64];
+#pragma unroll
+    for (int t = 0; t < kKmppBlock / 64; t++) {
+      const uint32_t s = b * kKmppBlock + t * 64 + lane;
+      v[t] = s < N ? dists[s] : 0.f;
+    }
+    double sd = 0.0, sg = 0.0;
+    uint32_t emin = 0xFFFFu, emax = 0u, bad = 0u;
+#pragma unroll
+    for (int t = 0; t < kKmppBlock / 64; t++) {
+      float g = v[t];   // warpReduceSum over 32 lanes (kmeans.cu:63-66)
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) g = g + __shfl_down(g, off, 32);
+      sd += (double)v[t];
+      if ((lane & 31) == 0) sg += (double)g;
+      const uint32_t bits = __float_as_uint(v[t]), ex = (bits >> 23) & 0xFFu;
+      const bool finite = ex != 0xFFu, nz = (bits & 0x7FFFFFFFu) != 0u;
+      if (finite && nz) {
+        emin = min(emin, ex ? ex : 1u);
+        emax = max(emax, ex ? ex : 1u);
+      }
+      bad |= finite ? 0u : 1u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sd += __shfl_xor(sd, off);
+      sg += __shfl_xor(sg, off);
+      emin = min(emin, (uint32_t)__shfl_xor((int)emin, off));
+      emax = max(emax, (uint32_t)__shfl_xor((int)emax, off));
+      bad |= (uint32_t)__shfl_xor((int)bad, off);
+    }
+    if (lane == 0) {
+      KmppBlockStat st;
+      st.sum_d = sd; st.sum_g = sg; st.emin = emin; st.emax = emax; st.bad = bad; st.pad = 0;
+      stats[b] = st;
+    }
   }
 }
 
@@ -602,8 +639,23 @@ __global__ __launch_bounds__(kKmppBlock) void kmpp_choose_kernel(const float *__
     if (tid == 0) best = 0xFFFFFFFFu;
     __syncthreads();
     if (0.0 - dca >= cs) return 0u;                               // prefix(0) = 0
-    for (uint32_t bi = tid; bi < nb; bi += kKmppBlock)            // smallest block whose END prefix qualifies
-      if (bpre[bi + 1] - dca >= cs) { atomicMin(&best, bi); break; }
+    // smallest block whose END prefix qualifies: the prefixes do not decrease (distances >= 0; a NaN has sent the step
+    // to the host), so two rounds of 256 probes find it: every stride-th block, then the blocks in between
+    const uint32_t stride = (nb + kKmppBlock - 1) / kKmppBlock;   // >= 1
+    {
+      const uint32_t probe = (tid + 1) * stride - 1;              // last block of my range
+      const uint32_t pb = probe < nb ? probe : nb - 1;
+      if (tid * stride < nb && bpre[pb + 1] - dca >= cs) atomicMin(&best, tid);
+    }
+    __syncthreads();
+    const uint32_t range = best;
+    __syncthreads();
+    if (tid == 0) best = 0xFFFFFFFFu;
+    __syncthreads();
+    if (range != 0xFFFFFFFFu) {
+      for (uint32_t bi = range * stride + tid; bi < nb && bi < (range + 1) * stride; bi += kKmppBlock)
+        if (bpre[bi + 1] - dca >= cs) { atomicMin(&best, bi); break; }
+    }
     __syncthreads();
     const uint32_t bi = best;
     __syncthreads();
@@ -726,7 +778,7 @@ hipError_t launch_kmpp_step_filtered(int metric, const float *samples, uint32_t 
   else
     hipLaunchKernelGGL((kmpp_step2_kernel<1>), dim3(lgrid), dim3(kKmppBlock), 0, st, samples, N, D, centroid, cc, dists,
                        (KmppBlockStat *)nullptr, list, stats + 1, fail);
-  hipLaunchKernelGGL(kmpp_stats_kernel, dim3(nb < 4096u ? nb : 4096u), dim3(kKmppBlock), 0, st, dists, N,
+  hipLaunchKernelGGL(kmpp_stats_kernel, dim3((nb + 3) / 4 < 2048u ? (nb + 3) / 4 : 2048u), dim3(256), 0, st, dists, N,
                      reinterpret_cast<KmppBlockStat *>(block_stats), stats + 1, fail);
   return launch_kmpp_reduce(block_stats, nb, bpre, totals_host, fail, st);
 }
