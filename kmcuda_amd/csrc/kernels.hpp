@@ -154,16 +154,15 @@ hipError_t launch_kmpp_step2(int metric, const float *samples, uint32_t N, uint3
 hipError_t launch_kmpp_choose(const float *dists, uint32_t N, const double *bpre, double choice, uint32_t log2n,
                               uint32_t step, const float *samples, float *centroids, uint32_t D, uint32_t *fail,
                               void *totals, hipStream_t st);
-// filtered k-means++ steps (seeding.hip): the centred half copy of the rows, then per step the survivors of
-// the k-NN candidate bound get the exact chain.  DP: D rounded up to 64; stats: 4 words ([2..3]: exact chains run so far, 64 bits); list: N words.
-// (mux: N floats, mu.(x - mu) per row: the angular metric's bias; nullptr for L2)
+// filtered k-means++ steps (seeding.hip): a centred BYTE copy of the rows (per-row scale and measured residual), then
+// per step the survivors of the k-NN candidate bound get the exact chain.  DP: D rounded up to 128; xs8: N x DP bytes;
+// meta: N x 4 floats; stats: 4 words ([2..3]: exact chains run so far, 64 bits); list: N words.
 hipError_t launch_kmpp_cache(const float *samples, uint32_t N, uint32_t D, uint32_t DP, double *part, float *mu,
-                             void *xs16, float *n2c, float *mux, uint32_t *stats, hipStream_t st);
+                             void *xs8, float *meta, uint32_t *stats, hipStream_t st);
 hipError_t launch_kmpp_step_filtered(int metric, const float *samples, uint32_t N, uint32_t D, uint32_t DP,
-                                     const void *xs16, const float *n2c, const float *mux, const float *mu,
-                                     uint32_t *stats, uint32_t *list,
-                                     const float *centroid, uint32_t cc, float *dists, void *block_stats, double *bpre,
-                                     void *totals, const uint32_t *fail, hipStream_t st);
+                                     const void *xs8, const float *meta, const float *mu, uint32_t *stats,
+                                     uint32_t *list, const float *centroid, uint32_t cc, float *dists,
+                                     void *block_stats, double *bpre, void *totals, const uint32_t *fail, hipStream_t st);
 size_t kmpp_block_stat_bytes(uint32_t N);
 size_t kmpp_blocks(uint32_t N);
 size_t kmpp_prefix_doubles(uint32_t N);   // doubles of `bpre`

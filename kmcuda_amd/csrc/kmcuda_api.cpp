@@ -521,11 +521,11 @@ class Job {
           if (hipHostMalloc(reinterpret_cast<void **>(&totals_host), sizeof(Totals), hipHostMallocDefault) != hipSuccess)
             return kmcudaMemoryAllocationFailure;
         }
-        // Filtered steps (seeding.hip): a centred half copy of the rows; a step's first kernel drops every row
+        // Filtered steps (seeding.hip): a centred byte copy of the rows (kpp_xs16; kpp_n2c: 4 floats per row); a step's first kernel drops every row
         // that provably is no closer to the new seed than to an earlier one, the exact chains run for the rest.
-        // Needs 2 DP + 8 bytes per row beside the rows; without that memory (or KMCUDA_AMD_KMPP_FILTER=0) every
+        // Needs DP + 20 bytes per row beside the rows; without that memory (or KMCUDA_AMD_KMPP_FILTER=0) every
         // step is the plain one.  Same dists[] after every step either way, hence the same seeds.
-        const uint32_t kpp_dp = ((uint32_t)D + 63u) / 64u * 64u;
+        const uint32_t kpp_dp = ((uint32_t)D + 127u) / 128u * 128u;
         void *kpp_xs16 = nullptr;
         float *kpp_n2c = nullptr, *kpp_mu = nullptr, *kpp_mux = nullptr;
         uint32_t *kpp_stats = nullptr, *kpp_list = nullptr;
@@ -543,26 +543,25 @@ class Job {
           }
         } kpp_guard{&kpp_xs16, &kpp_n2c, &kpp_mu, &kpp_stats, &kpp_list, &kpp_part, &kpp_mux};
         // (small jobs: the plain step is a few launches of nothing; KMCUDA_AMD_KMPP_FILTER=2 filters them too: tests)
-        bool kpp_filter = device_chooser && K >= 8 && N >= 65536u && kpp_dp <= 16384u;
+        bool kpp_filter = device_chooser && K >= 8 && N >= 65536u && kpp_dp <= 8192u;
         if (const char *v = getenv("KMCUDA_AMD_KMPP_FILTER")) {
           const int f = atoi(v);
-          kpp_filter = f >= 2 ? (device_chooser && K >= 3 && kpp_dp <= 16384u) : (kpp_filter && f != 0);
+          kpp_filter = f >= 2 ? (device_chooser && K >= 3 && kpp_dp <= 8192u) : (kpp_filter && f != 0);
         }
         if (kpp_filter) {
           Shard &s = *shards[0];
           (void)hipSetDevice(s.dev);
-          const bool ok = hipMalloc(&kpp_xs16, (size_t)N * kpp_dp * 2) == hipSuccess &&
-                          hipMalloc(reinterpret_cast<void **>(&kpp_n2c), (size_t)N * sizeof(float)) == hipSuccess &&
+          const bool ok = hipMalloc(&kpp_xs16, (size_t)N * kpp_dp) == hipSuccess &&   // (bytes)
+                          hipMalloc(reinterpret_cast<void **>(&kpp_n2c), (size_t)N * 4 * sizeof(float)) == hipSuccess &&
                           hipMalloc(reinterpret_cast<void **>(&kpp_mu), (size_t)kpp_dp * sizeof(float)) == hipSuccess &&
                           hipMalloc(reinterpret_cast<void **>(&kpp_stats), 4 * sizeof(uint32_t)) == hipSuccess &&
                           hipMalloc(reinterpret_cast<void **>(&kpp_list), (size_t)N * sizeof(uint32_t)) == hipSuccess &&
-                          hipMalloc(reinterpret_cast<void **>(&kpp_part), (size_t)64 * D * sizeof(double)) == hipSuccess &&
-                          (metric == 0 || hipMalloc(reinterpret_cast<void **>(&kpp_mux), (size_t)N * sizeof(float)) == hipSuccess);
+                          hipMalloc(reinterpret_cast<void **>(&kpp_part), (size_t)64 * D * sizeof(double)) == hipSuccess;
           if (!ok) {
             (void)hipGetLastError();
             kpp_filter = false;
-            DEBUG("k-means++: no memory for the half copy of the rows, plain steps\n");
-          } else if (launch_kmpp_cache(s.samples, N, D, kpp_dp, kpp_part, kpp_mu, kpp_xs16, kpp_n2c, kpp_mux, kpp_stats,
+            DEBUG("k-means++: no memory for the byte copy of the rows, plain steps\n");
+          } else if (launch_kmpp_cache(s.samples, N, D, kpp_dp, kpp_part, kpp_mu, kpp_xs16, kpp_n2c, kpp_stats,
                                        s.eng->stream_) != hipSuccess) {
             return kmcudaRuntimeError;
           }
@@ -647,7 +646,7 @@ class Job {
               const float *newest = s.centroids + (size_t)(t - 1) * D;
               const hipError_t se =
                   (kpp_filter && t >= 2)
-                      ? launch_kmpp_step_filtered(metric, s.samples, N, D, kpp_dp, kpp_xs16, kpp_n2c, kpp_mux, kpp_mu, kpp_stats, kpp_list,
+                      ? launch_kmpp_step_filtered(metric, s.samples, N, D, kpp_dp, kpp_xs16, kpp_n2c, kpp_mu, kpp_stats, kpp_list,
                                                   newest, t, s.dists, block_stats, bpre, totals_dev, fail_dev, st)
                       : launch_kmpp_step2(metric, s.samples, N, D, newest, t, s.dists, block_stats, bpre, totals_dev,
                                           fail_dev, st);

@@ -276,14 +276,21 @@ __global__ __launch_bounds__(256) void kmpp_stats_kernel(const float *__restrict
 // ---------------------------------------------------------------------------------------
 // Filtered steps.  A step only changes dists[s] where the new seed is CLOSER than the row's nearest seed so
 // far -- one row in i at step i on average -- but the plain step streams all N rows (4 D bytes each) to find out.
-// Here the rows are kept a second time as centred halves (2 DP bytes; kmpp_cache_kernel, once per call), a
-// step's first kernel forms hi(x').hi(s') per row (8 lanes per row, f32 accumulation) and drops every row whose
-// distance to the new seed provably is not below dists[s] -- the cluster-pruned k-NN search's candidate test with
-// one query, the seed, and a threshold per candidate (knn_f16.hip: same operands, same error bound E, DESIGN.md
-// 4.2 / 4.5) -- and only the survivors' exact chains run (kmpp_step2_kernel over the list).  dists[] afterwards is
-// the plain step's bit for bit: a dropped row keeps its value in both.
+// Here the rows are kept a second time as centred BYTES, x' = x - mu ~ a q with q in [-127, 127] and a = max |x'| /
+// 127 per row, beside (a, an upper bound of ||x' - a q||, ||x'||^2, mu.x') per row (DP + 16 bytes; kmpp_cache_kernel,
+// once per call).  A step's first kernel forms a (q . s') per row (8 lanes per row, the seed s' = s - mu in fp32,
+// fp32 accumulation) and drops every row whose distance to the new seed provably is not below dists[s]: the cluster-
+// pruned k-NN search's candidate test with one query, the seed, and a threshold per candidate (knn_f16.hip, DESIGN.md
+// 4.2 / 4.5), with that test's operand-rounding term (halves: 2^-10 ||x'|| ||s'||) replaced by the row's MEASURED
+// residual, |x'.s' - a q.s'| <= ||x' - a q|| ||s'||.  Only the survivors' exact chains run (kmpp_step2_kernel over
+// the list).  dists[] afterwards is the plain step's bit for bit: a dropped row keeps its value in both.
+// (Round 3 first kept the rows as halves: 0.62 % of the (row, step) pairs survived on 8M uniform rows in 256-D, and
+// the 4.1-GB stream was 87 % of the seeding.  Bytes halve the stream; the margin a new seed has to beat -- the gap
+// between a row's distance to a random point and to the nearest of i seeds -- is two orders of magnitude wider than
+// either rounding, so the survivors stay what they were.)
 // ---------------------------------------------------------------------------------------
-typedef _Float16 f16x8_kp __attribute__((ext_vector_type(8)));
+typedef float f32x4_kp __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_kp __attribute__((ext_vector_type(4)));
 
 // column sums of (up to) the first `rows` rows, one partial per block in fixed order: part[b][f]
 __global__ __launch_bounds__(256) void kmpp_colsum_kernel(const float *__restrict__ samples, uint32_t rows, uint32_t D,
@@ -307,48 +314,61 @@ __global__ __launch_bounds__(256) void kmpp_mean_kernel(const double *__restrict
   mu[f] = f < D ? (float)(acc / (double)rows) : 0.f;
 }
 
-// one wave per row: x' = x - mu as halves (zero padded to DP), ||x'||^2 of the fp32 values, the largest finite one
+// one wave per row: q = round(x' / a) as bytes (zero padded to DP), meta = (a, residual bound, ||x'||^2, mu.x')
 __global__ __launch_bounds__(256) void kmpp_cache_kernel(const float *__restrict__ samples, uint32_t N, uint32_t D,
                                                          uint32_t DP, const float *__restrict__ mu,
-                                                         _Float16 *__restrict__ xs16, float *__restrict__ n2c,
-                                                         float *__restrict__ mux, uint32_t *__restrict__ stats) {
+                                                         signed char *__restrict__ xs8, f32x4_kp *__restrict__ meta) {
   const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63;
   if (p >= N) return;
   const float *src = samples + (size_t)p * D;
-  _Float16 *dst = xs16 + (size_t)p * DP;
-  float a = 0.f, b = 0.f;
-  for (uint32_t f = lane; f < DP; f += 64) {
-    const float m = f < D ? mu[f] : 0.f;
-    const float v = f < D ? src[f] - m : 0.f;
-    dst[f] = (_Float16)v;
-    a = fmaf(v, v, a);
-    b = fmaf(m, v, b);
+  signed char *dst = xs8 + (size_t)p * DP;
+  float n2 = 0.f, mx = 0.f, mb = 0.f;
+  for (uint32_t f = lane; f < D; f += 64) {
+    const float m = mu[f], v = src[f] - m;
+    n2 = fmaf(v, v, n2);
+    mb = fmaf(m, v, mb);
+    mx = fmaxf(mx, fabsf(v));   // (fmaxf drops a NaN operand: a NaN row shows in n2)
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
-    a += __shfl_xor(a, off);
-    b += __shfl_xor(b, off);
+    n2 += __shfl_xor(n2, off);
+    mb += __shfl_xor(mb, off);
+    mx = fmaxf(mx, __shfl_xor(mx, off));
   }
+  const bool fin = (n2 - n2) == 0.f;
+  const float a = fin ? mx / 127.0f : 0.f, inv = (fin && a > 0.f) ? 1.0f / a : 0.f;
+  float r2 = 0.f;
+  for (uint32_t f = lane; f < DP; f += 64) {
+    float q = 0.f;
+    if (f < D && fin) {
+      const float v = src[f] - mu[f];
+      q = fminf(fmaxf(rintf(v * inv), -127.f), 127.f);
+      const float r = v - a * q;
+      r2 = fmaf(r, r, r2);
+    }
+    dst[f] = (signed char)(int)q;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) r2 += __shfl_xor(r2, off);
   if (lane == 0) {
-    n2c[p] = a;
-    if (mux) mux[p] = b;   // angular: x.s = x'.s' + mu.x' + (mu.s' + ||mu||^2)
-    if ((a - a) == 0.f && __float_as_uint(a) > *reinterpret_cast<volatile uint32_t *>(&stats[0]))
-      atomicMax(&stats[0], __float_as_uint(a));
+    // the residual's norm from above: its fp32 evaluation is off by a few ulps of ||x'|| at most
+    const float rn = (sqrtf(r2) + 1e-6f * sqrtf(n2)) * 1.001f;
+    // a row that is not finite keeps NaN in its record: the filter never drops it
+    meta[p] = f32x4_kp{fin ? a : __builtin_nanf(""), rn, n2, mb};
   }
 }
 
-// PPL: 16-byte pieces per lane and row (DP = 64 PPL), 0 = any DP (rolled loops).  With PPL known a wave has the
-// pieces of 4 x 8 rows in flight before the first product (a 4-GB stream per step: bandwidth is the whole cost).
+// PPL: 16-byte pieces per lane and row (DP = 128 PPL), 0 = any DP (rolled loops).  With PPL known a wave has the
+// pieces of 4 x 8 rows in flight before the first product (a 2-GB stream per step: bandwidth is the whole cost).
 template <int PPL, int METRIC>
-__global__ __launch_bounds__(256) void kmpp_filter_kernel(const _Float16 *__restrict__ xs16, const float *__restrict__ n2c,
-                                                          const float *__restrict__ mux,
+__global__ __launch_bounds__(256) void kmpp_filter_kernel(const signed char *__restrict__ xs8,
+                                                          const f32x4_kp *__restrict__ meta,
                                                           const float *__restrict__ mu, const float *__restrict__ seed,
-                                                          uint32_t N, uint32_t D, uint32_t DP,
-                                                          const uint32_t *__restrict__ stats, float eps,
+                                                          uint32_t N, uint32_t D, uint32_t DP, float eps,
                                                           const float *__restrict__ dists, uint32_t *__restrict__ list,
                                                           uint32_t *__restrict__ count, const uint32_t *__restrict__ fail) {
-  extern __shared__ __attribute__((aligned(16))) _Float16 s16[];   // DP halves: hi(s - mu)
+  extern __shared__ __attribute__((aligned(16))) float sfl[];   // DP floats: s' = s - mu
   if (*fail) return;
   __shared__ float red[3][4];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -356,7 +376,7 @@ __global__ __launch_bounds__(256) void kmpp_filter_kernel(const _Float16 *__rest
   for (uint32_t f = threadIdx.x; f < DP; f += 256) {
     const float m = f < D ? mu[f] : 0.f;
     const float v = f < D ? seed[f] - m : 0.f;
-    s16[f] = (_Float16)v;
+    sfl[f] = v;
     part = fmaf(v, v, part);
     pmus = fmaf(m, v, pmus);
     pmu2 = fmaf(m, m, pmu2);
@@ -372,22 +392,10 @@ __global__ __launch_bounds__(256) void kmpp_filter_kernel(const _Float16 *__rest
   const float sn2 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);   // ||s'||^2 (the "query" of knn_f16.hip)
   const float mus = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);   // mu.s'
   const float mu2 = ((red[2][0] + red[2][1]) + (red[2][2] + red[2][3])) * 1.0001f;   // ||mu||^2, as knn_cuda inflates it
-  // the k-NN filter's bound with one query: a row can only come closer than T = dists[s] if
-  //   hi(x').hi(s') - ||x'||^2 / 2  >=  (||s'||^2 - T^2 - E) / 2 - 1e-6 (||s'||^2 + T^2)
-  const float nmax2 = __uint_as_float(stats[0]);
   const float u = 5.9604645e-8f;
-  const float qn = sqrtf(sn2) * 1.0001f, nmx = sqrtf(nmax2) * 1.0001f;
-  const float e_round = 9.78e-4f * qn * nmx;
-  // angular (knn_f16.hip's bound again): a row can only come closer than T if
-  //   hi(x').hi(s') + mu.x'  >=  cos(T) - (mu.s' + ||mu||^2) - E
-  const float mun = sqrtf(mu2) * 1.0001f;
+  const float qn = sqrtf(sn2) * 1.0001f, mun = sqrtf(mu2) * 1.0001f;
   const float kq = mus + mu2;
-  const float E = METRIC == 0
-      ? 4.04f * (3.0f * eps + 16.0f * u) * (sn2 + nmax2) + 6e-8f * sqrtf((float)DP) * (qn + nmx) + 2.0f * e_round
-      : 2.02f * (3.0f * eps + 16.0f * u) * (qn * nmx + mun * nmx) + 3e-8f * sqrtf((float)DP) * (qn + nmx) +
-            eps * (mun * qn + mu2) + 1e-6f + e_round;
-  // operands near the half range could round to inf: then nothing is dropped
-  const bool usable = (sn2 - sn2) == 0.f && qn < 6.0e4f && nmx < 6.0e4f && (E - E) == 0.f;
+  const bool usable = (sn2 - sn2) == 0.f && (mu2 - mu2) == 0.f && qn < 1.0e18f;
   const uint32_t l8 = lane & 7u, rsub = lane >> 3;
   constexpr uint32_t kBuf = 128;
   __shared__ uint32_t buf[4][kBuf];
@@ -401,24 +409,36 @@ __global__ __launch_bounds__(256) void kmpp_filter_kernel(const _Float16 *__rest
     for (uint32_t i = lane; i < buffered; i += 64) list[base + i] = mine[i];
     buffered = 0;
   };
+  // knn_f16.hip's bound with one query (the seed) and this row as the candidate: the row can only come closer than
+  // T = dists[s] if   (L2)       a q.s' - ||x'||^2 / 2  >=  (||s'||^2 - T^2 - E) / 2 - 1e-6 (||s'||^2 + T^2)
+  //                   (angular)  a q.s' + mu.x'         >=  cos T - (mu.s' + ||mu||^2) - E
+  // E: the reference's own rounding + the centring in fp32 (the k-NN filter's terms, with this row's norm) + the
+  // quantisation, |x'.s' - a q.s'| <= rn ||s'||, + the fp32 accumulation of q.s' (gamma_D ||x'|| ||s'||)
   auto decide = [&](uint32_t s, bool live, float acc) {
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
     acc += __shfl_xor(acc, 4);
     bool need = false;
     if (live && l8 == 0) {
-      const float n2 = n2c[s], T = dists[s];
+      const f32x4_kp m = meta[s];
+      const float a = m.x, rn = m.y, n2 = m.z, T = dists[s];
+      const float xn = sqrtf(n2) * 1.0001f;
+      const float e_q = rn * qn * 1.001f + eps * xn * qn;
       float score, amin;
       if (METRIC == 0) {
-        score = acc - 0.5f * n2;
+        const float E = 4.04f * (3.0f * eps + 16.0f * u) * (sn2 + n2) + 6e-8f * sqrtf((float)DP) * (qn + xn) + 2.0f * e_q;
+        score = a * acc - 0.5f * n2;
         const float T2 = T * T * 1.000001f;
         amin = 0.5f * (sn2 - T2 - E) - 1e-6f * (sn2 + T2);
       } else {
-        score = acc + mux[s];
-        amin = T >= 3.1415925f ? -INFINITY : cosf(T) - kq - E;   // (NaN T: NaN amin: not dropped)
+        const float E = 2.02f * (3.0f * eps + 16.0f * u) * (qn * xn + mun * xn) + 3e-8f * sqrtf((float)DP) * (qn + xn) +
+                        eps * (mun * qn + mu2) + 1e-6f + e_q;
+        score = a * acc + m.w;
+        amin = T >= 3.1415925f ? -INFINITY : cosf(T) - kq - E;
       }
-      // (a row whose centred norm is beyond the half range may hold inf halves: never dropped; NaN anywhere: neither)
-      need = !(usable && n2 < 3.6e9f && score < amin);
+      // (a NaN anywhere -- a row that is not finite has NaN for a -- : not dropped; norms near the end of the float
+      //  range, where the bound's own products would overflow: neither)
+      need = !(usable && xn < 1.0e18f && score < amin);
     }
     // Survivors wait in the wave's LDS buffer: one global atomic per kBuf of them, not one per 8-row group (same-
     // address atomics are served one at a time by L2: 50 K of them per step were half of the kernel's time)
@@ -430,22 +450,31 @@ __global__ __launch_bounds__(256) void kmpp_filter_kernel(const _Float16 *__rest
       buffered += n;
     }
   };
-  auto dot8 = [](const f16x8_kp &xv, const f16x8_kp &sv, float acc) {
+  // 16 bytes of q against 16 floats of s'
+  auto dot16 = [](const u32x4_kp &xq, const float *sv, float acc) {
 #pragma unroll
-    for (int q = 0; q < 8; q++) acc = fmaf((float)xv[q], (float)sv[q], acc);   // products of halves: exact in fp32
+    for (int w = 0; w < 4; w++) {
+      const int x = (int)xq[w];
+      acc = fmaf((float)(signed char)(x & 0xFF), sv[4 * w + 0], acc);
+      acc = fmaf((float)(signed char)((x >> 8) & 0xFF), sv[4 * w + 1], acc);
+      acc = fmaf((float)(signed char)((x >> 16) & 0xFF), sv[4 * w + 2], acc);
+      acc = fmaf((float)(x >> 24), sv[4 * w + 3], acc);
+    }
     return acc;
   };
   if constexpr (PPL > 0) {
     constexpr int R = 4;   // 8-row groups in flight per wave
-    f16x8_kp sv[PPL];
+    float sv[PPL][16];
 #pragma unroll
-    for (int i = 0; i < PPL; i++) sv[i] = *reinterpret_cast<const f16x8_kp *>(&s16[(l8 + 8 * i) * 8]);
+    for (int i = 0; i < PPL; i++)
+#pragma unroll
+      for (int q = 0; q < 16; q++) sv[i][q] = sfl[(l8 + 8 * i) * 16 + q];
     for (uint32_t row0 = (blockIdx.x * 4 + wave) * (8 * R); row0 < N; row0 += gridDim.x * (32 * R)) {
-      f16x8_kp xv[R][PPL];
+      u32x4_kp xv[R][PPL];
 #pragma unroll
       for (int r = 0; r < R; r++) {
         const uint32_t s = row0 + 8 * r + rsub;
-        const f16x8_kp *xr = reinterpret_cast<const f16x8_kp *>(xs16 + (size_t)(s < N ? s : 0) * DP);
+        const u32x4_kp *xr = reinterpret_cast<const u32x4_kp *>(xs8 + (size_t)(s < N ? s : 0) * DP);
 #pragma unroll
         for (int i = 0; i < PPL; i++) xv[r][i] = __builtin_nontemporal_load(&xr[l8 + 8 * i]);
       }
@@ -454,19 +483,18 @@ __global__ __launch_bounds__(256) void kmpp_filter_kernel(const _Float16 *__rest
         const uint32_t s = row0 + 8 * r + rsub;
         float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < PPL; i++) acc = dot8(xv[r][i], sv[i], acc);
+        for (int i = 0; i < PPL; i++) acc = dot16(xv[r][i], sv[i], acc);
         decide(s, s < N, acc);
       }
     }
   } else {
-    const uint32_t npieces = DP / 8;   // 16-byte pieces per row; DP is a multiple of 64
+    const uint32_t npieces = DP / 16;   // 16-byte pieces per row; DP is a multiple of 128
     for (uint32_t row0 = (blockIdx.x * 4 + wave) * 8; row0 < N; row0 += gridDim.x * 32) {
       const uint32_t s = row0 + rsub;
       const bool live = s < N;
-      const f16x8_kp *xr = reinterpret_cast<const f16x8_kp *>(xs16 + (size_t)(live ? s : 0) * DP);
+      const u32x4_kp *xr = reinterpret_cast<const u32x4_kp *>(xs8 + (size_t)(live ? s : 0) * DP);
       float acc = 0.f;
-      for (uint32_t p = l8; p < npieces; p += 8)
-        acc = dot8(xr[p], *reinterpret_cast<const f16x8_kp *>(&s16[p * 8]), acc);
+      for (uint32_t p = l8; p < npieces; p += 8) acc = dot16(xr[p], &sfl[p * 16], acc);
       decide(s, live, acc);
     }
   }
@@ -728,45 +756,45 @@ hipError_t launch_kmpp_step2(int metric, const float *samples, uint32_t N, uint3
   return launch_kmpp_reduce(block_stats, nb, bpre, totals_host, fail, st);
 }
 
-// The centred half copy of the rows for the filtered steps (L2): mu = column means of the first <= 65536 rows
-// (any vector is valid; a central one keeps the norms in the error bound small).  part: 64 x D doubles of scratch.
+// The centred byte copy of the rows for the filtered steps: mu = column means of the first <= 65536 rows (any
+// vector is valid; a central one keeps the norms in the error bound small).  part: 64 x D doubles of scratch;
+// xs8: N x DP bytes (DP = D rounded up to 128); meta: N x 4 floats; stats: 4 words ([1] the step's survivor count,
+// [2..3] the run's).
 hipError_t launch_kmpp_cache(const float *samples, uint32_t N, uint32_t D, uint32_t DP, double *part, float *mu,
-                             void *xs16, float *n2c, float *mux, uint32_t *stats, hipStream_t st) {
+                             void *xs8, float *meta, uint32_t *stats, hipStream_t st) {
   const uint32_t rows = N < 65536u ? N : 65536u;
-  hipError_t e = hipMemsetAsync(stats, 0, 4 * sizeof(uint32_t), st);   // [0] max ||x'||^2, [1] survivors of the step, [2..3] of all steps
+  hipError_t e = hipMemsetAsync(stats, 0, 4 * sizeof(uint32_t), st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kmpp_colsum_kernel, dim3(64), dim3(256), 0, st, samples, rows, D, part);
   hipLaunchKernelGGL(kmpp_mean_kernel, dim3((DP + 255) / 256), dim3(256), 0, st, part, 64u, rows, D, DP, mu);
   hipLaunchKernelGGL(kmpp_cache_kernel, dim3((N + 3) / 4), dim3(256), 0, st, samples, N, D, DP, mu,
-                     reinterpret_cast<_Float16 *>(xs16), n2c, mux, stats);
+                     reinterpret_cast<signed char *>(xs8), reinterpret_cast<f32x4_kp *>(meta));
   return hipGetLastError();
 }
 
 // One filtered step (cc >= 2; the first step has nothing to compare with: launch_kmpp_step2): survivors of the
 // bound -> exact chains -> block statistics -> totals, as launch_kmpp_step2 leaves them.
 hipError_t launch_kmpp_step_filtered(int metric, const float *samples, uint32_t N, uint32_t D, uint32_t DP,
-                                     const void *xs16, const float *n2c, const float *mux, const float *mu,
-                                     uint32_t *stats, uint32_t *list,
-                                     const float *centroid, uint32_t cc, float *dists, void *block_stats, double *bpre,
-                                     void *totals_host, const uint32_t *fail, hipStream_t st) {
+                                     const void *xs8, const float *meta, const float *mu, uint32_t *stats,
+                                     uint32_t *list, const float *centroid, uint32_t cc, float *dists,
+                                     void *block_stats, double *bpre, void *totals_host, const uint32_t *fail,
+                                     hipStream_t st) {
   const uint32_t nb = (N + kKmppBlock - 1) / kKmppBlock;
   const float eps = (float)(1.02 * ((double)D + 12.0) * 5.9604644775390625e-8);   // as the k-NN filter
   const uint32_t fgrid = (N + 127) / 128 < 1024u ? (N + 127) / 128 : 1024u;   // 16 waves per CU; one list atomic per wave
 #define KMX_KPP_FILTER1(P, M)                                                                                       \
-  hipLaunchKernelGGL((kmpp_filter_kernel<P, M>), dim3(fgrid), dim3(256), (size_t)DP * 2, st,                        \
-                     reinterpret_cast<const _Float16 *>(xs16), n2c, mux, mu, centroid, N, D, DP, stats, eps, dists,  \
-                     list, stats + 1, fail)
+  hipLaunchKernelGGL((kmpp_filter_kernel<P, M>), dim3(fgrid), dim3(256), (size_t)DP * 4, st,                        \
+                     reinterpret_cast<const signed char *>(xs8), reinterpret_cast<const f32x4_kp *>(meta), mu, centroid, \
+                     N, D, DP, eps, dists, list, stats + 1, fail)
 #define KMX_KPP_FILTER(P)                                                                                           \
   do {                                                                                                              \
     if (metric == 0) KMX_KPP_FILTER1(P, 0); else KMX_KPP_FILTER1(P, 1);                                             \
   } while (0)
-  switch (DP / 64) {
+  switch (DP / 128) {
     case 1: KMX_KPP_FILTER(1); break;
     case 2: KMX_KPP_FILTER(2); break;
     case 3: KMX_KPP_FILTER(3); break;
     case 4: KMX_KPP_FILTER(4); break;
-    case 6: KMX_KPP_FILTER(6); break;
-    case 8: KMX_KPP_FILTER(8); break;
     default: KMX_KPP_FILTER(0); break;
   }
 #undef KMX_KPP_FILTER
