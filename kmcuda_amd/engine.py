@@ -40,6 +40,10 @@ class Engine:
         _lib.check(rc, "kmamd_engine_create")
         self.h = h
 
+    def stream_handle(self):
+        """The hipStream_t every step of this engine is enqueued on (kmamd_engine_stream)."""
+        return int(self.lib.kmamd_engine_stream(self.h) or 0)
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.kmamd_engine_destroy(self.h)
