@@ -276,6 +276,10 @@ struct KnnArgs {
   const float *mux;
   const float *kbias;       // N + KNN16_PAD_ROWS: -0.5 * centred squared norm (L2) / mu.(x - mu) (angular)
   float mu2;
+  // optional (L2, f16 filter): lb[c * lb_stride + (p - p_base)] <= d(x_p, centroid c) - R[c] in the reference's
+  // arithmetic (knn_centroid_bounds_kernel); nullptr: the reference's prune test alone
+  const float *lb = nullptr;
+  size_t lb_stride = 0;
   float *heaps;             // (p_end - p_base) x 2k
   uint32_t *out;            // (p_end - p_base) x k, sorted-position order
   unsigned long long *calced;
@@ -286,6 +290,10 @@ hipError_t launch_knn_prep(int metric, const float *xs, uint32_t N, uint32_t D, 
                            uint32_t K, const float *centroids, float *mydist, float *rdist, float *R, float *C,
                            bool strict_h2, hipStream_t st);
 hipError_t launch_knn_filter(int metric, const KnnArgs &a, uint32_t nblocks, hipStream_t st);
+// lb[c * stride + (p - p_base)] for the sorted positions [p_base, p_end) and all K centroids (L2, D <= 1024)
+hipError_t launch_knn_centroid_bounds(const float *xs, uint32_t D, uint32_t DP, uint32_t p_base, uint32_t p_end,
+                                      const float *centroids, uint32_t K, const float *R, float *lb, size_t stride,
+                                      hipStream_t st);
 // strict_h2 (both): the reference's half2 arithmetic on rows that hold half values (KMCUDA_AMD_FP16_STRICT)
 hipError_t launch_knn_exact(int metric, const KnnArgs &a, bool strict_h2, hipStream_t st);
 hipError_t launch_knn_split(int metric, const float *xs, uint32_t N, uint32_t D, uint32_t DP, const float *mu,

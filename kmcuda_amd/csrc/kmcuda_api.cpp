@@ -1460,6 +1460,25 @@ class KnnJob {
       a.eps = (float)(1.02 * ((double)D + 12.0) * ldexp(1.0, -24));  // as the Lloyd filter
       a.heaps = s.heaps; a.out = s.out; a.calced = s.calced;
       a.xs16 = s.xs16; a.mux = s.mux; a.kbias = s.kbias; a.mu2 = mu2;
+      // The tighter cluster test of the f16 search (knn_f16.hip: the query's own distance to every centroid instead of
+      // the triangle bound for it).  4 K bytes per query; without that memory, or with KMCUDA_AMD_KNN_TIGHT=0, the
+      // reference's prune test decides alone.  Same neighbour lists either way.
+      if (use_f16 && metric == 0 && D <= 1024 && len != 0) {
+        const char *tight = getenv("KMCUDA_AMD_KNN_TIGHT");
+        if (!(tight && atoi(tight) == 0)) {
+          float *lb = nullptr;
+          if (s.alloc(&lb, (size_t)K * len) == 0) {
+            if (launch_knn_centroid_bounds(s.xs, D, DP, s.p_base, s.p_end, s.centroids, K, s.R, lb, len, s.stream) !=
+                hipSuccess)
+              return kmcudaRuntimeError;
+            a.lb = lb;
+            a.lb_stride = len;
+          } else {
+            (void)hipGetLastError();
+            DEBUG("k-NN: no memory for the per-query centroid bounds, the reference's prune test alone\n");
+          }
+        }
+      }
       const hipError_t e = !dp_filter ? launch_knn_exact(metric, a, strict_h2, s.stream)
                            : use_f16 ? launch_knn_filter_f16(metric, a, s.nblocks, s.stream)
                                      : launch_knn_filter(metric, a, s.nblocks, s.stream);

@@ -438,6 +438,72 @@ __global__ __launch_bounds__(64) void knn_exact_kernel(KnnArgs a) {
   atomicAdd(a.calced, calced);
 }
 
+// ---------------------------------------------------------------------------------------
+// A lower bound of "distance to any member of cluster c" per (query, cluster): d(q, c) - R[c], from the query's own
+// distance to the centroid (the reference bounds that one by the triangle C[c][mine] - d(q, c_mine): knn.cu:222-225).
+// Plain fp32 sums of squared differences, a wave per four consecutive sorted rows, 4 features per lane and 256-feature
+// chunk; rounded DOWN past every error in sight: the fp32 sum ((D + 2) u relative), the reference's own candidate
+// distances (Kahan: a few u) and its radii (chunked float sums: ~1e-6) -- 1e-5 relative is taken for each.
+// 1M queries x 1024 centroids x 256 features: ~20 ms beside a search of seconds.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void knn_centroid_bounds_kernel(const float *__restrict__ xs, uint32_t D, uint32_t DP,
+                                                                  uint32_t p_base, uint32_t p_end,
+                                                                  const float *__restrict__ centroids, uint32_t K,
+                                                                  const float *__restrict__ R, float *__restrict__ lb,
+                                                                  size_t stride) {
+  constexpr int QW = 4, CH = 4;   // rows per wave, 256-feature chunks (D <= 1024)
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t p0 = p_base + (blockIdx.x * 4 + wave) * QW;
+  if (p0 >= p_end) return;
+  float4 xq[CH][QW];
+#pragma unroll
+  for (int ch = 0; ch < CH; ch++)
+#pragma unroll
+    for (int q = 0; q < QW; q++) {
+      const uint32_t f = ch * 256 + lane * 4, p = p0 + q < p_end ? p0 + q : p0;
+      // (xs rows are zero padded to DP, a multiple of 8; beyond DP: zeros against the centroid's zeros below)
+      xq[ch][q] = f + 3 < DP ? *reinterpret_cast<const float4 *>(xs + (size_t)p * DP + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  const int nch = (int)((D + 255) / 256);
+  for (uint32_t c = 0; c < K; c++) {
+    float acc[QW] = {0.f, 0.f, 0.f, 0.f};
+    const float *crow = centroids + (size_t)c * D;
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) {
+      if (ch >= nch) break;
+      const uint32_t f = ch * 256 + lane * 4;
+      float cv[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) cv[t] = f + t < D ? crow[f + t] : 0.f;
+#pragma unroll
+      for (int q = 0; q < QW; q++) {
+        const float d0 = xq[ch][q].x - cv[0], d1 = xq[ch][q].y - cv[1], d2 = xq[ch][q].z - cv[2], d3 = xq[ch][q].w - cv[3];
+        acc[q] = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, acc[q]))));
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int q = 0; q < QW; q++) acc[q] += __shfl_xor(acc[q], off);
+    if (lane < (uint32_t)QW && p0 + lane < p_end) {
+      const float d = sqrtf(acc[lane == 0 ? 0 : (lane == 1 ? 1 : (lane == 2 ? 2 : 3))]);
+      // NaN (a NaN row or centroid, an empty cluster's radius): compares false in the search, nothing is skipped
+      lb[(size_t)c * stride + (p0 + lane - p_base)] = (d * 0.99998f - R[c] * 1.00003f) * 0.99997f;
+    }
+  }
+}
+
+hipError_t launch_knn_centroid_bounds(const float *xs, uint32_t D, uint32_t DP, uint32_t p_base, uint32_t p_end,
+                                      const float *centroids, uint32_t K, const float *R, float *lb, size_t stride,
+                                      hipStream_t st) {
+  if (p_end <= p_base) return hipSuccess;
+  if (D > 1024 || (DP & 3u)) return hipErrorInvalidValue;
+  const uint32_t nrows = p_end - p_base;
+  hipLaunchKernelGGL(knn_centroid_bounds_kernel, dim3((nrows + 15) / 16), dim3(256), 0, st, xs, D, DP, p_base, p_end,
+                     centroids, K, R, lb, stride);
+  return hipGetLastError();
+}
+
 // neighbors[inv[p]][:] = sorted_out[p - p_base][:]
 __global__ void knn_scatter_kernel(const uint32_t *__restrict__ sorted_out, const uint32_t *__restrict__ inv,
                                    uint32_t p_base, uint32_t p_end, uint32_t k, uint32_t *__restrict__ neighbors) {
