@@ -442,8 +442,9 @@ __global__ __launch_bounds__(64) void knn_exact_kernel(KnnArgs a) {
 // A lower bound of "distance to any member of cluster c" per (query, cluster): d(q, c) - R[c], from the query's own
 // distance to the centroid (the reference bounds that one by the triangle C[c][mine] - d(q, c_mine): knn.cu:222-225).
 // Plain fp32 sums of squared differences, a wave per four consecutive sorted rows, 4 features per lane and 256-feature
-// chunk; rounded DOWN past every error in sight: the fp32 sum ((D + 2) u relative), the reference's own candidate
-// distances (Kahan: a few u) and its radii (chunked float sums: ~1e-6) -- 1e-5 relative is taken for each.
+// chunk; rounded DOWN past every error in sight: the fp32 sum ((D + 3) u relative on the square), the reference's own
+// candidate distances (Kahan + round-down products: ~2e-7) and its radii (round-down products, chunked float sums:
+// ~1e-6 up to 256 features, 4e-6 at 1024) -- 2e-5 or (D + 16) u, 3e-5 and 3e-5 relative are taken.
 // 1M queries x 1024 centroids x 256 features: ~20 ms beside a search of seconds.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void knn_centroid_bounds_kernel(const float *__restrict__ xs, uint32_t D, uint32_t DP,
@@ -465,6 +466,9 @@ __global__ __launch_bounds__(256) void knn_centroid_bounds_kernel(const float *_
       xq[ch][q] = f + 3 < DP ? *reinterpret_cast<const float4 *>(xs + (size_t)p * DP + f) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   const int nch = (int)((D + 255) / 256);
+  // the fp32 sum of D squared differences is off by (D + 3) u relative at worst, its root by half of that: the whole
+  // of it is taken off the root (2e-5 up to 256 features, as tested; more beyond)
+  const float sd = fminf(0.99998f, 1.0f - ((float)D + 16.0f) * 6.0e-8f);
   for (uint32_t c = 0; c < K; c++) {
     float acc[QW] = {0.f, 0.f, 0.f, 0.f};
     const float *crow = centroids + (size_t)c * D;
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(256) void knn_centroid_bounds_kernel(const float *_
     if (lane < (uint32_t)QW && p0 + lane < p_end) {
       const float d = sqrtf(acc[lane == 0 ? 0 : (lane == 1 ? 1 : (lane == 2 ? 2 : 3))]);
       // NaN (a NaN row or centroid, an empty cluster's radius): compares false in the search, nothing is skipped
-      lb[(size_t)c * stride + (p0 + lane - p_base)] = (d * 0.99998f - R[c] * 1.00003f) * 0.99997f;
+      lb[(size_t)c * stride + (p0 + lane - p_base)] = (d * sd - R[c] * 1.00003f) * 0.99997f;
     }
   }
 }
