@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PMC_SUMMARY = "r3y_pmc_summary.json"   # the rocprofv3 --pmc passes `roofline.traffic` is read from (profiles/)
 
 
 def pmc_traffic(rows_per_launch, filt="f32"):
@@ -33,7 +34,17 @@ def pmc_traffic(rows_per_launch, filt="f32"):
     process; None if no matching profile is committed."""
     import glob
     want = {"f16": ("lloyd_coarse2_kernel",), "f32": ("lloyd_filter_kernel",)}[filt]
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    # the pass named here (the counters of the build that is committed); any other summary only if it is gone --
+    # then the newest by its own "collected" stamp, by file time for the older ones that carry none
+    files = [os.path.join(ROOT, "profiles", PMC_SUMMARY)]
+    if not os.path.exists(files[0]):
+        def stamp(path):
+            try:
+                with open(path) as fin:
+                    return (json.load(fin).get("collected", ""), os.path.getmtime(path))
+            except Exception:
+                return ("", 0.0)
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), key=stamp)
     if files:
         with open(files[-1]) as fin:
             pmc = json.load(fin)
@@ -319,7 +330,15 @@ def main():
         raise SystemExit("the stop rule fired inside the timed region (%d iterations): the remaining steps were "
                          "no-ops -- use fewer steps or a smaller --step-tolerance" % loop.iterations)
     prof = backend.engine.profile_read()
-    # outside the timed region: the OTHER filter on the same state, for the side-by-side roofline entry
+    ctrs = backend.engine.counters()   # of the last timed step's assignment pass
+    flagged = ctrs[1]
+    pair_rows = ctrs[3]
+    # outside the timed region, and BEFORE anything else touches the state: the pass that follows the last timed
+    # update (it reassigns what a 21st step would: its change counter is checked on real moves)
+    verify = None
+    if rank == 0 and not args.no_verify:
+        verify = verify_state(backend, args.verify_rows)
+    # then the OTHER filter on the same state, for the side-by-side roofline entry
     other = "f32" if args.filter != "f32" else "f16"
     backend.engine.set_filter(other)
     backend.assign()
@@ -330,18 +349,12 @@ def main():
     prof_other = backend.engine.profile_read()
     backend.engine.set_filter(args.filter)
     backend.engine.profile(False)
-    ctrs = backend.engine.counters()
-    flagged = ctrs[1]
-    pair_rows = ctrs[3]
     changed_last = loop.changed_last()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    verify = None
-    if rank == 0 and not args.no_verify:
-        verify = verify_state(backend, args.verify_rows)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

@@ -119,6 +119,11 @@ int kmamd_stop_report(kmamd_engine *e, uint32_t seq, uint32_t *host_out6);
 int kmamd_reduce_apply_prepare(kmamd_engine *e, const double *buf, float *centroids, uint32_t *ccounts,
                                float stop_threshold, uint32_t seq);
 int kmamd_stop_clear(kmamd_engine *e);
+/* The caller has written `centroids` itself (new seeds, an imported set, a rounding pass) since the engine last
+ * saw them: whatever kmamd_reduce_apply_prepare prepared for that buffer is void.  (The engine recognises the
+ * buffer by its ADDRESS only; without this call the next kmamd_lloyd_assign would filter against the panels of
+ * the old values.) */
+int kmamd_centroids_written(kmamd_engine *e);
 /* Test / A-B hook for the update's host logic: 0 default, 1 radix path always, 2 always read the
  * counts before choosing (the pre-round-2 behaviour), 3 bucket path always without reading (exercises
  * the device-side fallback of oversized buckets).  Env KMCUDA_AMD_UPDATE=radix|sync|bucket sets it at

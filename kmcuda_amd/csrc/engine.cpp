@@ -837,6 +837,10 @@ int kmamd_reduce_apply_prepare(kmamd_engine *e, const double *buf, float *centro
 }
 int kmamd_stop_report(kmamd_engine *e, uint32_t seq, uint32_t *host_out6) { return e->e.stop_report(seq, host_out6); }
 int kmamd_stop_clear(kmamd_engine *e) { return e->e.stop_clear(); }
+int kmamd_centroids_written(kmamd_engine *e) {
+  e->e.prepared_for_ = nullptr;
+  return kmx::kSuccess;
+}
 int kmamd_set_update_mode(kmamd_engine *e, int mode) {
   if (mode < 0 || mode > 3) return kmx::kInvalidArguments;
   e->e.ms_.force = mode;

@@ -1595,10 +1595,6 @@ int virtual_shards() {
 
 }  // namespace
 
-// ---------------------------------------------------------------------------------------
-// Yinyang driver (reference: kmeans_cuda_yy, kmeans.cu:1028-1263) lives in yinyang.cpp
-// ---------------------------------------------------------------------------------------
-
 extern "C" {
 
 KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float tolerance, float yinyang_t,

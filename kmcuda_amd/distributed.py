@@ -76,6 +76,11 @@ class HipBackend:
         self.engine.stop_clear()
         self.engine.reset_counters(0)
 
+    def centroids_written(self):
+        """set_centroids() wrote self.centroids in place: the engine knows the buffer by address only, and a
+        preparation fused into the last update (apply_stop) would be taken for the new values' (ADVICE r3)."""
+        self.engine.centroids_written()
+
     def apply_stop(self, buf, threshold, seq):
         """The update, unless the reduced reassignment count is <= threshold (then nothing is touched and
         later assign() calls are no-ops).  Returns a handle for read_report()."""
@@ -133,10 +138,19 @@ class ShardedLloyd:
             dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
 
     def set_centroids(self, centroids):
-        """Replicated initial centroids (rank 0's are broadcast)."""
+        """Replicated initial centroids (rank 0's are broadcast).  Starts a new run: the stop state of an earlier
+        one is dropped."""
         self.b.centroids.copy_(centroids)
         if self.world > 1:
             dist.broadcast(self.b.centroids, src=0, group=self.group)
+        if hasattr(self.b, "centroids_written"):
+            self.b.centroids_written()
+        self._new_run()
+
+    def _new_run(self):
+        self.iterations = 0          # the next device-side step lowers the engine's stop flag (stop_clear)
+        self.stopped = False
+        self._pending = None
 
     def step(self, tolerance=None):
         """One Lloyd iteration: assign, reduce, (stop test), update.  With `tolerance` the reference's
@@ -194,6 +208,9 @@ class ShardedLloyd:
         return int(self.buf[kd + self.b.clusters].item())
 
     def run(self, tolerance, max_iter=10000, verbosity=0):
+        """Iterates from the current centroids until the stop rule fires.  Every call is a run of its own: a loop
+        that has stopped before starts again (flag lowered, counters reset), as a second kmeans_cuda() would."""
+        self._new_run()
         log = []
 
         def note(changed):

@@ -137,6 +137,10 @@ class Engine:
     def stop_clear(self):
         _lib.check(self.lib.kmamd_stop_clear(self.h), "kmamd_stop_clear")
 
+    def centroids_written(self):
+        """The caller wrote the centroid buffer itself: drop any preparation fused into the last update."""
+        _lib.check(self.lib.kmamd_centroids_written(self.h), "kmamd_centroids_written")
+
     def set_update_mode(self, mode):
         """"auto" | "radix" | "sync" | "bucket": the update's host logic (kmamd_set_update_mode); sums are
         bit-identical on every path."""

@@ -29,3 +29,18 @@ def reference_fixture():
 @pytest.fixture(scope="session")
 def fixture13k():
     return reference_fixture()
+
+
+def overflow_fixture(n=167772160):
+    """The reference's only N >> 8M case (src/test.py:307-326, test_kmeanspp_lloyd_uint32_overflow): the 13000x2
+    fixture stacked to 8 features and tiled to 167 772 160 rows -- 5.4 GB, past 2^32 BYTES."""
+    base = reference_fixture()
+    samples = numpy.empty((n, 8), dtype=numpy.float32)
+    tile = numpy.hstack((base,) * 4)
+    for i in range(0, n, base.shape[0]):
+        end = i + base.shape[0]
+        if end < n:
+            samples[i:end] = tile
+        else:
+            samples[i:] = tile[:n - i]
+    return samples

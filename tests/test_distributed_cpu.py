@@ -171,3 +171,37 @@ def test_sharded_lloyd_world2_matches_single(tmp_path, kind):
     ocen, oasg, olog = oracle.kmeans(x, 12, init=init, tolerance=0.005, yinyang_t=0)
     assert len(olog) == len(log)
     assert (oasg != loop.b.assignments).mean() < 0.002
+
+
+@pytest.mark.parametrize("kind", ["host-stop", "device-stop"])
+def test_loop_runs_again_after_a_stop(kind):
+    """a ShardedLloyd that has stopped must run again -- run() / set_centroids() start a new run (stop
+    flag lowered, lagged report dropped, iteration count from zero), and set_centroids() tells the backend that the
+    centroid buffer was written behind the engine's back (HipBackend: the fused preparation is void)."""
+    from kmcuda_amd.distributed import ShardedLloyd
+    x, init = _data()
+
+    class Backend(BACKENDS[kind]):
+        written = 0
+
+        def centroids_written(self):
+            self.written += 1
+
+    loop = ShardedLloyd(Backend(x, 12), len(x))
+    loop.set_centroids(torch.from_numpy(init))
+    assert loop.b.written == 1
+    first = loop.run(tolerance=0.005, max_iter=50)
+    assert len(first) > 3 and loop.stopped == (kind == "device-stop")
+    asg = loop.b.assignments.copy()
+    # again from where it stands: the stop test fires on the first pass (the converged state), nothing moves
+    again = loop.run(tolerance=0.005, max_iter=50)
+    assert len(again) >= 1 and again[-1] <= 0.005 * len(x) and len(again) < len(first)
+    # new seeds on the same loop: the same trajectory as a fresh loop's, counts and assignments
+    loop.b.assignments[:] = 0xFFFFFFFF
+    loop.b.assignments_prev[:] = 0xFFFFFFFF
+    loop.b.ccounts[:] = 0
+    loop.set_centroids(torch.from_numpy(init))
+    assert loop.b.written == 2 and loop.iterations == 0 and not loop.stopped
+    third = loop.run(tolerance=0.005, max_iter=50)
+    assert third == first
+    assert (loop.b.assignments == asg).all()

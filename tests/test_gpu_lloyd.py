@@ -166,7 +166,7 @@ def test_transpose_roundtrip():
     from kmcuda_amd.engine import Engine
     dev = _dev()
     rs = numpy.random.RandomState(3)
-    for rows, cols in [(1000, 256), (333, 77), (64, 64), (5, 1000)]:
+    for rows, cols in [(1000, 256), (333, 77), (64, 64), (5, 1000), (1028, 132), (4, 4), (260, 8), (1000, 254)]:   # 16-byte and 4-byte kernels
         a = rs.rand(rows, cols).astype(numpy.float32)
         src = torch.from_numpy(a).to(dev)
         dst = torch.empty(cols * rows, dtype=torch.float32, device=dev)

@@ -294,3 +294,43 @@ def test_config_d_shape_knn_8m_corpus_shard_vs_brute_force(monkeypatch):
     print("brute force: %d rows, %d differ only by an fp32 tie, %d wrong" % (rows.numel(), ties, wrong))
     assert wrong == 0
     del _DEVICE_ALLOCS[cptr], _DEVICE_ALLOCS[aptr]
+
+
+def test_kmeanspp_lloyd_uint32_overflow(monkeypatch):
+    """The reference's only N >> 8M case (src/test.py:307-326): 167 772 160 x 8 rows -- 5.4 GB, byte offsets pass
+    2^32 --, k-means++, seed 3, tolerance 0.142 -> it pins 2 iterations (the oracle's pin:
+    tests/test_oracle_pins.py::test_kmeanspp_lloyd_uint32_overflow_2).  Through kmeans_cuda() on a host array: the
+    two progress lines with the oracle's reassignment counts, and with the strict update (the oracle's centroid
+    arithmetic) the assignments of every row of 100 tiles spread over the whole matrix -- 1.3M rows, the last
+    tile included, i.e. rows whose byte offset is beyond 2^32 -- equal the oracle's."""
+    import psutil
+    if psutil.virtual_memory().available < 24 * 2**30:
+        pytest.skip("needs 24 GB of host memory")
+    from conftest import overflow_fixture
+    from kmcuda_amd import kmeans_cuda
+    from test_gpu_kmeans import StdoutListener
+    samples = overflow_fixture()
+    n = samples.shape[0]
+    _, oasg, olog = oracle.kmeans(samples, 50, init="kmeans++", seed=3, tolerance=0.142, yinyang_t=0)
+    assert list(olog) == [167772160, 23720437]
+    tiles = numpy.unique(numpy.linspace(0, n // 13000, 100).astype(numpy.int64))
+    rows = numpy.concatenate([numpy.arange(t * 13000, min((t + 1) * 13000, n)) for t in tiles])
+    assert rows.max() == n - 1 and rows.size > 1000000
+    for strict in ("0", "1"):
+        monkeypatch.setenv("KMCUDA_AMD_EXACT_UPDATE", strict)
+        out = StdoutListener()
+        with out:
+            centroids, assignments = kmeans_cuda(samples, 50, init="kmeans++", device=1, verbosity=2, seed=3,
+                                                 tolerance=0.142, yinyang_t=0)
+        assert out.iterations() == 2
+        assert centroids.shape == (50, 8) and assignments.shape == (n,)
+        reass = [int(l.split(":")[1].split()[0]) for l in out.text.split("\n") if l.startswith("iteration")]
+        assert reass[0] == n
+        if strict == "1":
+            assert reass == list(olog)
+            assert (assignments[rows] == oasg[rows]).all()
+        else:
+            # default update: fp64 sums rounded once instead of the reference's serial Kahan chain -- centroids
+            # agree to rounding, a row within rounding of a tie may land on its other side (in every tile at once)
+            assert abs(reass[1] - int(olog[1])) <= 0.001 * n
+            assert (assignments[rows] != oasg[rows]).mean() < 1e-3

@@ -91,6 +91,22 @@ def test_yinyang_equals_lloyd_outcome(fixture13k):
     assert (a1 != a2).mean() < 0.002
 
 
+def test_kmeanspp_lloyd_uint32_overflow_2():
+    """test.py:307-326: 167 772 160 x 8 rows (5.4 GB: byte offsets pass 2^32), k-means++, seed 3, tolerance 0.142
+    -> the reference pins 2 iterations.  The oracle reproduces the pin: the second pass reassigns 23 720 437 rows,
+    14.14 % of them, under the 14.2 % bar.  (~1.5 min on 8 cores; needs ~8 GB of host memory.)"""
+    import psutil
+    if psutil.virtual_memory().available < 10 * 2**30:
+        pytest.skip("needs 10 GB of host memory")
+    from conftest import overflow_fixture
+    samples = overflow_fixture()
+    c, a, log = oracle.kmeans(samples, 50, init="kmeans++", seed=3, tolerance=0.142, yinyang_t=0)
+    assert list(log) == [167772160, 23720437]
+    assert c.shape == (50, 8) and a.shape == (167772160,)
+    # every tile of the fixture carries the same assignments (the arithmetic is per row)
+    assert (a[:13000] == a[13000 * 5000:13000 * 5001]).all()
+
+
 def test_import_lloyd_8(fixture13k):
     # test.py:236-246
     c, a, log1 = oracle.kmeans(fixture13k, 50, init="random", seed=3, tolerance=0.25, yinyang_t=0)
