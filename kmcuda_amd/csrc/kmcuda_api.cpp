@@ -1371,7 +1371,7 @@ class KnnJob {
       if ((rc = sh->alloc(&sh->vals_tmp, N))) return rc;
       if ((rc = sh->alloc(&sh->keys_sorted, N))) return rc;
       if ((rc = sh->alloc(&sh->stats, 4))) return rc;
-      if ((rc = sh->alloc(&sh->calced, 1))) return rc;
+      if ((rc = sh->alloc(&sh->calced, KNN_STATS))) return rc;
       if (use_f16) {
         if ((rc = sh->alloc(&sh->xs16, ((size_t)N + KNN16_PAD_ROWS) * DP))) return rc;
         if ((rc = sh->alloc(&sh->kbias, (size_t)N + KNN16_PAD_ROWS))) return rc;
@@ -1389,7 +1389,7 @@ class KnnJob {
     INFO("initializing the inverse assignments...\n");
     for (auto &s : shards) {
       (void)hipSetDevice(s->dev);
-      if (hipMemsetAsync(s->calced, 0, sizeof(unsigned long long), s->stream) != hipSuccess) return kmcudaRuntimeError;
+      if (hipMemsetAsync(s->calced, 0, KNN_STATS * sizeof(unsigned long long), s->stream) != hipSuccess) return kmcudaRuntimeError;
       if (launch_inverse_assignments(s->assignments, N, K, s->keys_tmp, s->vals_tmp, s->keys_sorted, s->inv,
                                      s->offsets, s->sort_temp, sort_bytes, s->stream) != hipSuccess)
         return kmcudaRuntimeError;
@@ -1507,9 +1507,14 @@ class KnnJob {
         INFO("k-NN kernel failed: %s\n", hipGetErrorString(hipGetLastError()));
         return kmcudaRuntimeError;
       }
-      unsigned long long c = 0;
-      if (hipMemcpy(&c, s.calced, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess) return kmcudaMemoryCopyError;
+      unsigned long long cs[KNN_STATS] = {0, 0, 0, 0};
+      if (hipMemcpy(cs, s.calced, sizeof(cs), hipMemcpyDeviceToHost) != hipSuccess) return kmcudaMemoryCopyError;
+      const unsigned long long c = cs[0];
       DEBUG("#%d dists_calced: %llu\n", s.dev, c);
+      // what the f16 search actually did (knn_f16.hip; measurement: KMCUDA_AMD_KNN_STATS=1 prints it at any verbosity)
+      if (cs[1] && (verbosity > 1 || getenv("KMCUDA_AMD_KNN_STATS")))
+        printf("#%d k-NN filter: %llu pairs by the reference's prune rule, %llu scored on the matrix cores "
+               "(%llu of them live query x real candidate), %llu exact chains\n", s.dev, cs[0], cs[1], cs[2], cs[3]);
       dists_calced += c;
       const uint32_t len = s.p_end - s.p_base;
       if (!len) continue;

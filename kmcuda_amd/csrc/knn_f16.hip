@@ -244,6 +244,7 @@ __global__ __launch_bounds__(KNN16_WAVES * 64, (DP > 512 ? 1 : KNN16_BLOCKS_PER_
   // k <= 12 -- distances plus one-byte slots, the indices parked in global memory, so a push was LDS-only but
   // for one store -- with identical lists and NO gain: 2.72 s against 2.59 s for the config D share
   // (profiles/r3f_*).  The pushes were not what the other waves wait for at the barrier.)
+  uint32_t chains = 0;   // exact chains this lane's queries have paid for (statistics)
   auto flush = [&](int e) {  // wave-uniform call
     const uint32_t qq = live[e] ? qp[e] : p0;
     const float *xrow = a.xs + (size_t)qq * DP;   // original values (exact chains)
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(KNN16_WAVES * 64, (DP > 512 ? 1 : KNN16_BLOCKS_PER_
     for (int i = 0; i < 4; i++) crow[i] = a.xs + (size_t)(i < qn_[e] ? qc[e][i] : 0) * DP;
     float dist[4];
     const int nq = __ballot(qn_[e] >= 4) ? 4 : (__ballot(qn_[e] >= 3) ? 3 : (__ballot(qn_[e] >= 2) ? 2 : 1));
+    chains += h == 0 ? (uint32_t)qn_[e] : 0u;
     exact_distance4<NKH, METRIC, FASTX>(xrow, crow, D, h, col, dist, nq, qn_[e]);
     float mnd = mndist[e];
 #pragma unroll
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(KNN16_WAVES * 64, (DP > 512 ? 1 : KNN16_BLOCKS_PER_
     qn_[e] = 0;
   };
 
-  unsigned long long calced = 0;
+  unsigned long long calced = 0, scored = 0, useful = 0;   // wave-uniform (scalar registers)
   int ph = 0;
   for (uint32_t step = 0; step <= K; step++) {
     const uint32_t cls = step == 0 ? cls0 : step - 1;
@@ -304,8 +306,13 @@ __global__ __launch_bounds__(KNN16_WAVES * 64, (DP > 512 ? 1 : KNN16_BLOCKS_PER_
       for (int e = 0; e < NSET; e++)
         if (!pruned[e]) pruned[e] = a.lb[(size_t)cls * a.lb_stride + (qp[e] - a.p_base)] > mndist[e];
     }
+    uint32_t nvis_tight = 0;   // queries of the wave that visit the cluster after both tests
 #pragma unroll
-    for (int e = 0; e < NSET; e++) visiting |= __ballot(!pruned[e]);
+    for (int e = 0; e < NSET; e++) {
+      const unsigned long long b = __ballot(!pruned[e]);
+      visiting |= b;
+      nvis_tight += (uint32_t)__popcll(b & 0xFFFFFFFFull);
+    }
     const bool wave_need = visiting != 0ull;
     if (lane == 0) flags[ph * WV + wave] = wave_need ? 1u : 0u;
     __syncthreads();
@@ -430,6 +437,11 @@ __global__ __launch_bounds__(KNN16_WAVES * 64, (DP > 512 ? 1 : KNN16_BLOCKS_PER_
           // (a last tile of one sub-tile only has no tile NBUF - 1 ahead: no piece is lost by the break)
           if (sub > 0 && tile_base + 32u * sub >= end) break;   // block-uniform
           mfma_tile(buf, sub, dma, dma_base, dma_buf);
+          {   // statistics (wave-uniform)
+            scored += 1024ull * NSET;
+            const uint32_t left = end - (tile_base + 32u * sub);
+            useful += (unsigned long long)nvis_tight * (left < 32u ? left : 32u);
+          }
           if (sub == SUB - 1 && dma) {   // pieces the slots did not cover (very short rows)
 #pragma unroll
             for (int i = (SUB * KS - 1) / DSTR + 1; i <= PPW; i++) issue_piece(dma_base, dma_buf, i);
@@ -453,6 +465,13 @@ __global__ __launch_bounds__(KNN16_WAVES * 64, (DP > 512 ? 1 : KNN16_BLOCKS_PER_
     }
   }
   if (lane == 0 && calced) atomicAdd(a.calced, calced);
+  if (lane == 0 && scored) {
+    atomicAdd(a.calced + 1, scored);
+    atomicAdd(a.calced + 2, useful);
+  }
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) chains += __shfl_xor(chains, off);   // (the upper half-wave holds zeros)
+  if (lane == 0 && chains) atomicAdd(a.calced + 3, (unsigned long long)chains);
 }
 
 hipError_t launch_knn_split(int metric, const float *xs, uint32_t N, uint32_t D, uint32_t DP, const float *mu,
