@@ -124,6 +124,19 @@ int kmamd_stop_clear(kmamd_engine *e);
  * buffer by its ADDRESS only; without this call the next kmamd_lloyd_assign would filter against the panels of
  * the old values.) */
 int kmamd_centroids_written(kmamd_engine *e);
+/* Bounds carried from pass to pass (the Yinyang phase of kmeans_cuda()'s default schedule; lloyd_carry.hip).  on != 0:
+ * from the next kmamd_lloyd_assign on, a pass in the two-stage filter's steady state (L2, row cache valid) leaves per
+ * row an upper bound of the distance to its centroid and a lower bound of the distance to every other centroid --
+ * read off the coarse stage's best two scores, no extra distance work --, the next preparation measures how far every
+ * centroid has moved, and the next pass only looks at the rows whose bounds, moved by those drifts, no longer certify
+ * the assignment (Hamerly's test with the rounding of the reference's arithmetic as margin).  Assignments, previous
+ * assignments and counters are exactly those of plain passes.  Contract: between two passes the centroids change only
+ * through kmamd_reduce_apply* / kmamd_apply_delta or are announced with kmamd_centroids_written (which voids the
+ * bounds), and `assignments` / `assignments_prev` are the buffers of the previous pass, untouched.
+ * kmamd_carry_stats: rows_spared = row passes the bounds have decided since the engine was created (one stream
+ * synchronisation), last_list = the length of the newest list the host has heard of (0xFFFFFFFF: none yet). */
+int kmamd_set_carry(kmamd_engine *e, int on);
+int kmamd_carry_stats(kmamd_engine *e, uint64_t *rows_spared, uint32_t *last_list);
 /* Test / A-B hook for the update's host logic: 0 default, 1 radix path always, 2 always read the
  * counts before choosing (the pre-round-2 behaviour), 3 bucket path always without reading (exercises
  * the device-side fallback of oversized buckets).  Env KMCUDA_AMD_UPDATE=radix|sync|bucket sets it at

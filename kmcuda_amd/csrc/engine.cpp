@@ -52,6 +52,7 @@ Engine::~Engine() {
   for (void *p : owned_) (void)hipFree(p);
   if (host_counters_) (void)hipHostFree(host_counters_);
   if (host_move_count_) (void)hipHostFree(host_move_count_);
+  if (host_carry_) (void)hipHostFree(host_carry_);
   if (side_stream_) {
     (void)hipStreamDestroy(side_stream_);
     (void)hipEventDestroy(ev_fork_);
@@ -447,12 +448,16 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
       uint32_t *next = stats_;
       stats_ = stats_ == stats_base_ ? stats_base_ + 8 : stats_base_;
       KMX_HIP(launch_centroid_prep_frozen(metric_, centroids, K_, D_, K_pad_, DP_, mu_, finite_, bias_, bias2_, cfil_,
-                                          panelhi_, stats_, next, counters_ + 1, counters_ + 3, counters_ + 4, stream_),
+                                          panelhi_, stats_, next, counters_ + 1, counters_ + 3, counters_ + 4,
+                                          carry_on_ ? drift_ : nullptr, carry_on_ && drift_ ? counters_ + kCarryCursor : nullptr,
+                                          stream_),
               kRuntimeError);
+      carry_preps_++;
     }
   } else {
     int rc = prepare_centroids(centroids);
     if (rc) return rc;
+    carry_valid_ = false;   // (the panel was rebuilt outside the steady state: no drift for it)
   }
   LloydArgs a;
   a.samples = samples; a.N = N_; a.D = D_; a.K = K_; a.K_pad = K_pad_; a.DP = DP_; a.Kt = Kt_;
@@ -501,10 +506,56 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
       }
     }
     const bool cached = row_cache_on_ && row_cache_valid_;
+    // Carried bounds (lloyd_carry.hip): in the steady state the pass can leave per-row distance bounds behind and the
+    // next one only looks at the rows they do not decide.  The drift of this pass's centroids against the last pass's
+    // is the preparation kernel's (exactly one preparation since: anything else voids the bounds).
+    const bool carry = carry_on_ && steady && cached && metric_ == 0;
+    if (carry && !ub_) {
+      // (no memory: not an error, plain passes)
+      if (alloc(&ub_, N_) != kSuccess || alloc(&lb_, N_) != kSuccess || alloc(&drift_, K_) != kSuccess ||
+          alloc(&carry_list_, N_) != kSuccess ||
+          hipHostMalloc(reinterpret_cast<void **>(&host_carry_), 2 * sizeof(uint32_t), hipHostMallocCoherent) != hipSuccess) {
+        (void)hipGetLastError();
+        carry_on_ = false;
+      } else {
+        host_carry_[0] = 0xFFFFFFFFu;
+        host_carry_[1] = 0;
+        void *dp = nullptr;
+        KMX_HIP(hipHostGetDevicePointer(&dp, host_carry_, 0), kRuntimeError);
+        host_carry_dev_ = static_cast<uint32_t *>(dp);
+        if (const char *v = getenv("KMCUDA_AMD_CARRY_MAX")) carry_list_max_ = (float)atof(v);
+      }
+      carry_valid_ = false;   // (this pass's preparation ran without a drift buffer)
+    }
     span_begin(3);  // the dominant kernel on its own, inside the filter span
-    KMX_HIP(launch_lloyd_coarse(a, rows, half, cached ? xcache_ : nullptr, xmeta_, panelhi_, undecided_, und_thr_,
-                                stream_),
-            kRuntimeError);
+    if (carry && carry_on_) {
+      CarryArgs cy;
+      cy.ub = ub_; cy.lb = lb_; cy.host_report = host_carry_dev_; cy.seq = ++carry_seq_;
+      const bool moved = carry_valid_ && carry_preps_ == 1;   // drift_ / stats_[6] belong to the bounds
+      uint32_t hint = 0xFFFFFFFFu;
+      bool listed = false;
+      if (moved) {
+        // what the host knows of an EARLIER pass's list (a pinned word the coarse kernel writes; only speed depends
+        // on it): a short list -> the listed pass; else every row from the row cache, the list only counted
+        const uint32_t last = host_carry_[0];
+        listed = last != 0xFFFFFFFFu && (float)last <= carry_list_max_ * (float)N_;
+        if (listed) hint = last;
+        KMX_HIP(launch_carry_skip(N_, K_, assignments, assignments_prev, ub_, lb_, xmeta_, drift_, stats_, tie_slack_,
+                                  carry_list_, counters_, !listed, stream_),
+                kRuntimeError);
+        cy.n_list = counters_ + kCarryCursor;
+      }
+      if (listed) cy.row_list = carry_list_;
+      KMX_HIP(launch_lloyd_coarse_carry(a, rows, half, xcache_, xmeta_, panelhi_, undecided_, und_thr_, cy, hint, stream_),
+              kRuntimeError);
+      carry_valid_ = true;
+    } else {
+      carry_valid_ = false;
+      KMX_HIP(launch_lloyd_coarse(a, rows, half, cached ? xcache_ : nullptr, xmeta_, panelhi_, undecided_, und_thr_,
+                                  stream_),
+              kRuntimeError);
+    }
+    carry_preps_ = 0;
     span_end();
     // stage 2's grid follows an EARLIER pass's list length (whatever the update's async copy has
     // delivered to the pinned word; the kernel strides over the device-side count, so only speed
@@ -701,16 +752,29 @@ int Engine::apply_prepare(const double *delta, const double *dcount_d, float *ce
   span_begin(2);
   KMX_HIP(launch_apply_prep_frozen(delta, dcount_d, centroids, ccounts, ctl, K_, D_, K_pad_, DP_, mu_, finite_, bias_,
                                    bias2_, cfil_, panelhi_, stats_, next, counters_ + 1, counters_ + 3, counters_ + 4,
+                                   carry_on_ ? drift_ : nullptr, carry_on_ && drift_ ? counters_ + kCarryCursor : nullptr,
                                    stream_),
           kRuntimeError);
+  carry_preps_++;
   span_end();
   if (report) KMX_HIP(hipEventRecord(ev_report_[seq & 1u], stream_), kRuntimeError);
   prepared_for_ = centroids;
   return kSuccess;
 }
 
+int Engine::carry_stats(unsigned long long *rows_spared, uint32_t *last_list) {
+  KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  unsigned long long v = 0;
+  KMX_HIP(hipMemcpyAsync(&v, counters_ + kCarrySkipped, sizeof(v), hipMemcpyDeviceToHost, stream_), kMemoryCopyError);
+  KMX_HIP(hipStreamSynchronize(stream_), kRuntimeError);
+  if (rows_spared) *rows_spared = v;
+  if (last_list) *last_list = host_carry_ ? host_carry_[0] : 0xFFFFFFFFu;
+  return kSuccess;
+}
+
 int Engine::stop_clear() {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  carry_valid_ = false;   // (a pass enqueued behind a raised flag wrote no bounds: start over)
   KMX_HIP(hipMemsetAsync(counters_ + kStopFlag, 0, sizeof(uint32_t), stream_), kRuntimeError);
   return kSuccess;
 }
@@ -839,7 +903,19 @@ int kmamd_stop_report(kmamd_engine *e, uint32_t seq, uint32_t *host_out6) { retu
 int kmamd_stop_clear(kmamd_engine *e) { return e->e.stop_clear(); }
 int kmamd_centroids_written(kmamd_engine *e) {
   e->e.prepared_for_ = nullptr;
+  e->e.carry_valid_ = false;
   return kmx::kSuccess;
+}
+int kmamd_set_carry(kmamd_engine *e, int on) {
+  e->e.carry_on_ = on != 0;
+  e->e.carry_valid_ = false;
+  return kmx::kSuccess;
+}
+int kmamd_carry_stats(kmamd_engine *e, uint64_t *rows_spared, uint32_t *last_list) {
+  unsigned long long v = 0;
+  const int rc = e->e.carry_stats(&v, last_list);
+  if (rows_spared) *rows_spared = v;
+  return rc;
 }
 int kmamd_set_update_mode(kmamd_engine *e, int mode) {
   if (mode < 0 || mode > 3) return kmx::kInvalidArguments;

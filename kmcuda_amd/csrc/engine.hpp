@@ -122,6 +122,19 @@ class Engine {
   bool row_cache_on_ = false, row_cache_valid_ = false, mu_frozen_ = false;
   void *xcache_ = nullptr;
   float *xmeta_ = nullptr;
+  // Bounds carried from pass to pass (lloyd_carry.hip; kmamd_set_carry): per-row upper / lower distance bounds read
+  // off the coarse stage's best two scores, moved by the centroids' drifts, sparing the rows they still decide.
+  // L2, two-stage filter with a valid row cache only; any other state runs plain passes.
+  bool carry_on_ = false;        // the caller wants it
+  bool carry_valid_ = false;     // ub_ / lb_ describe the assignments and the centroids of the last pass
+  uint32_t carry_preps_ = 0;     // centroid preparations since the last pass (exactly 1: drift_ is that update's)
+  uint32_t carry_seq_ = 0;
+  float carry_list_max_ = 0.5f;  // a listed pass when at most this share of the rows is on the list (KMCUDA_AMD_CARRY_MAX)
+  float *ub_ = nullptr, *lb_ = nullptr, *drift_ = nullptr;
+  uint32_t *carry_list_ = nullptr;
+  uint32_t *host_carry_ = nullptr, *host_carry_dev_ = nullptr;   // 2 pinned words: [0] the last list's length, [1] seq
+  bool carry_usable() const;     // the state in which a pass can carry bounds
+  int carry_stats(unsigned long long *rows_spared, uint32_t *last_list);
   // stats_: the ACTIVE half of a double-buffered 2 x 8 words (stats_base_): every preparation flips to
   // the other half, which the invariant keeps zero (memset, or zeroed by centroid_prep_frozen_kernel)
   uint32_t *stats_base_ = nullptr, *stats_ = nullptr, *flagged_ = nullptr, *pairs_ = nullptr, *counters_ = nullptr;

@@ -29,6 +29,18 @@ struct LloydArgs {
 // counters[kStopFlag] != 0: the stop rule fired ON THE DEVICE (apply_delta_kernel with a threshold): the kernels
 // that assign every row return at once, so iterations enqueued past the stop leave the state untouched
 constexpr uint32_t kStopFlag = 8;
+// counters[kCarryCursor]: length of the carried-bounds pass's row list (zeroed by the preparation kernel);
+// counters[kCarrySkipped], [kCarrySkipped + 1]: one 64-bit total of the rows the bounds have spared since the engine was made
+constexpr uint32_t kCarryCursor = 9, kCarrySkipped = 10;
+// Bounds carried from one Lloyd pass to the next (lloyd_carry.hip): per row an upper bound of the distance to its
+// centroid and a lower bound of the distance to every other finite centroid.
+struct CarryArgs {
+  float *ub = nullptr, *lb = nullptr;
+  const uint32_t *row_list = nullptr;   // CARRY == 2: the rows of this pass (carry_skip_kernel's survivors) ...
+  const uint32_t *n_list = nullptr;     // ... and their number, on the device
+  uint32_t *host_report = nullptr;      // device address of 2 pinned words: [0] <- the list's length (N for a whole pass), [1] <- seq
+  uint32_t seq = 0;
+};
 // the device-side stop rule of launch_apply_delta (reference: check_changed, kmeans.cu:697-717)
 struct StopCtl {
   float threshold = -1.f;         // stop when (float)reassigned <= threshold (= tolerance * N in float); < 0: no test
@@ -65,14 +77,26 @@ hipError_t launch_centroid_panelhi(const float *centroids, uint32_t K, uint32_t 
 hipError_t launch_centroid_prep_frozen(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t K_pad,
                                        uint32_t DP, const float *mu, uint32_t *finite, float *bias, float *bias2,
                                        float *cfil, void *panelhi, uint32_t *stats, uint32_t *stats_next,
-                                       uint32_t *zero_a, uint32_t *zero_b, uint32_t *zero_c, hipStream_t st);
+                                       uint32_t *zero_a, uint32_t *zero_b, uint32_t *zero_c,
+                                       float *drift /* K: ||c - c of the previous pass||, or null; its maximum -> stats[6] */,
+                                       uint32_t *zero_d /* or null */, hipStream_t st);
 // L2 metric: the centroid update of launch_apply_delta (same formula, same StopCtl) fused in front of that
 // preparation -- one launch between the all-reduce and stage 1
 hipError_t launch_apply_prep_frozen(const double *delta, const double *dcount_d, float *centroids, uint32_t *ccounts,
                                     const StopCtl &stop, uint32_t K, uint32_t D, uint32_t K_pad, uint32_t DP,
                                     const float *mu, uint32_t *finite, float *bias, float *bias2, float *cfil,
                                     void *panelhi, uint32_t *stats, uint32_t *stats_next, uint32_t *zero_a,
-                                    uint32_t *zero_b, uint32_t *zero_c, hipStream_t st);
+                                    uint32_t *zero_b, uint32_t *zero_c, float *drift, uint32_t *zero_d, hipStream_t st);
+// lloyd_carry.hip -- passes that carry per-row distance bounds (CarryArgs): the coarse stage over every row
+// (cy.row_list == nullptr: from the row cache) or over the listed rows, leaving fresh bounds; carry_skip moves the
+// bounds by the drifts (launch_centroid_prep_frozen) and lists the rows they no longer decide into row_list /
+// counters[kCarryCursor] (probe: only counts them)
+hipError_t launch_lloyd_coarse_carry(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
+                                     const float *xmeta, const void *panelhi, uint32_t *undecided, float *und_thr,
+                                     const CarryArgs &cy, uint32_t rows_hint, hipStream_t st);
+hipError_t launch_carry_skip(uint32_t N, uint32_t K, const uint32_t *assignments, uint32_t *assignments_prev, float *ub,
+                             float *lb, const float *xmeta, const float *drift, const uint32_t *stats, float tie_slack,
+                             uint32_t *row_list, uint32_t *counters, bool probe, hipStream_t st);
 // the reference's exact sum_squares (csqr) + the transposed panel (ct) alone: what the pair / exact kernels read
 hipError_t launch_centroid_rows(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t Kt, float *csqr,
                                 float *ct, hipStream_t st);

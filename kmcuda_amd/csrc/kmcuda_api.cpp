@@ -1558,39 +1558,20 @@ class KnnJob {
   }
 };
 
-// When do Yinyang's bounds pay?  (measured on MI355X at 8M x 256, K = 1024, G = 102.)  In units of
-// one Lloyd assignment pass per row, t_L = 2 D K flop at ~1 PFLOP/s algorithmic on the f16 matrix cores:
-//   bounds refresh (kmeans_yy_init: >= G exact chains per row)       ~38 t_L
-//   global filter (streams 2 (G + 1) floats + the row)                (8 (G + 1) + 4 D + 12) B at 4.8 TB/s
-//   local filter per PASSED row (estimate + candidate sweeps)         ~2.9 t_L
-// so an iteration with bounds beats a plain pass only while few rows pass the global filter, and the refresh needs
-// that saving many times over.  The forecast: reassignments decay geometrically (ratio fitted to the last four
-// counts), the passed fraction is taken as 8 x the reassigned fraction.  It is a schedule, not a semantic: every
-// step either way is the reference's arithmetic.  KMCUDA_AMD_YY_SWITCH=<fraction> forces the hand-over at that
-// reassignment fraction instead (0.11 = the reference's).
-struct BoundsModel {
-  double N, D, K, G, target, force = -1.0;
-  bool wide = false;   // D > 512: the bounds kernels have no matrix-core filter there (exact VALU chains against a
-                       // GEMM-filtered Lloyd pass): they never pay
-  std::vector<double> hist;
-  BoundsModel(uint32_t n, uint32_t d, uint32_t k, uint32_t g, float tolerance)
-      : N(n), D(d), K(k), G(g), target(std::max((double)(tolerance * n), 0.5)) {
+// The Yinyang phase of the default schedule.  The reference hands over from Lloyd to its bounds at 11 %
+// reassignments whatever the data; its bounds refresh (kmeans_yy_init: >= G exact chains per row) costs 38 assignment
+// passes on this hardware and its filters more than a pass per row that passes them (profiles/r2n_*, r3y_*): measured on
+// both benchmark data sets it never pays.  The default keeps the reference's sequence up to and including the hand-over
+// point (group clustering, its progress lines, its srand(0)) and then goes on with assignment passes that CARRY
+// per-row bounds from pass to pass at no refresh cost (lloyd_carry.hip).  Every pass either way is the reference's
+// arithmetic.  KMCUDA_AMD_YY=reference: the reference's own schedule and kernels.  KMCUDA_AMD_YY_SWITCH=<fraction>
+// (tests): hand over to the reference's bounds once the reassigned fraction is at most that.
+struct SwitchRule {
+  double N, force = -1.0;
+  explicit SwitchRule(uint32_t n) : N(n) {
     if (const char *v = getenv("KMCUDA_AMD_YY_SWITCH")) force = atof(v);
   }
-  bool pays(uint32_t changed) {
-    hist.push_back((double)changed);
-    if (force >= 0) return (double)changed <= force * N;
-    if (wide || hist.size() < 4) return false;
-    const double a = hist[hist.size() - 4], b = hist.back();
-    if (!(b > target) || !(a > b)) return false;   // about to stop, or not decaying: no forecast
-    const double rho = std::min(std::pow(b / a, 1.0 / 3.0), 0.995);
-    const double remaining = std::min(std::log(target / b) / std::log(rho), 1.0e4);
-    const double t_l = 2.0 * D * K / 1.0e15;
-    const double t_g = (8.0 * (G + 1.0) + 4.0 * D + 12.0) / 4.8e12;
-    const double passed = std::min(1.0, 8.0 * b / N);
-    const double gain = t_l - (t_g + 2.9 * passed * t_l);
-    return gain > 0 && remaining * gain > 38.0 * t_l;
-  }
+  bool now(uint32_t changed) const { return force >= 0 && (double)changed <= force * N; }
 };
 
 int virtual_shards() {
@@ -1658,20 +1639,17 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
     else INFO("tolerance is too high (>= %.2f) => Lloyd\n", kYinyangDraftReassignments);
     RETERR(job.lloyd(tolerance, nullptr));
   } else {
-    // KMCUDA_AMD_YY=reference: the reference's fixed schedule (Lloyd down to 11 % reassignments, then bounds).
-    // Default: the same hand-over, but only when the bounds can pay for their refresh on this hardware
-    // (BoundsModel) -- an assignment pass costs 0.5 ns per row here, a bounds refresh 38 of them.  The strict
-    // parity modes keep the reference's schedule.
+    // KMCUDA_AMD_YY=reference: the reference's fixed schedule (Lloyd down to 11 % reassignments, then its bounds).
+    // Default: the same hand-over point, then assignment passes that carry per-sample bounds (SwitchRule above).
+    // The strict parity modes keep the reference's schedule.
     const char *yym = getenv("KMCUDA_AMD_YY");
     const bool wide = job.shards[0]->eng->DP_ == 0 && job.shards[0]->eng->gemm_dp_ != 0;   // D > 512: lloyd_gemm.hip
     const bool adaptive = !(yym && strcmp(yym, "reference") == 0) && !job.exact_update &&
                           ((job.shards[0]->eng->DP_ != 0 && job.shards[0]->eng->filter_mode_ == 0) || wide);
     INFO("running Lloyd until reassignments drop below %u\n", (uint32_t)(kYinyangDraftReassignments * samples_size));
-    BoundsModel model(samples_size, feats, clusters_size, yy_groups_size, tolerance);
-    model.wide = wide;
-    const Job::LeaveFn record = [&model](int, uint32_t changed) { (void)model.pays(changed); return false; };
+    const SwitchRule rule(samples_size);
     int iter = 0;
-    RETERR(job.lloyd((float)kYinyangDraftReassignments, &iter, adaptive ? &record : nullptr));
+    RETERR(job.lloyd((float)kYinyangDraftReassignments, &iter));
     const int st = job.check_changed(iter, tolerance, false);  // kmeans.cu:1058
     if (st < 0) return static_cast<KMCUDAResult>(-st);
     if (st == 0) {
@@ -1681,9 +1659,24 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
       RETERR(job.cluster_groups(yy_groups_size, &groups));
       bool bounds = !adaptive;
       if (adaptive) {
-        INFO("Lloyd goes on; Yinyang's bounds take over when they can pay for their refresh\n");
-        const Job::LeaveFn leave = [&model](int, uint32_t changed) { return model.pays(changed); };
-        RETERR(job.lloyd(tolerance, &iter, &leave, &bounds, iter));
+        const char *cv = getenv("KMCUDA_AMD_CARRY");
+        const bool carry = !(cv && atoi(cv) == 0) && metric == kmcudaDistanceMetricL2 && !wide;
+        INFO(carry ? "Lloyd goes on, carrying per-sample distance bounds from pass to pass\n" : "Lloyd goes on\n");
+        for (auto &s : job.shards) {
+          s->eng->carry_on_ = carry;
+          s->eng->carry_valid_ = false;
+        }
+        const Job::LeaveFn leave = [&rule](int, uint32_t changed) { return rule.now(changed); };
+        RETERR(job.lloyd(tolerance, &iter, rule.force >= 0 ? &leave : nullptr, &bounds, iter));
+        if (carry && verbosity > 1) {
+          unsigned long long spared = 0;
+          for (auto &s : job.shards) {
+            unsigned long long v = 0;
+            if (s->eng->carry_stats(&v, nullptr) == 0) spared += v;
+          }
+          printf("carried bounds: %llu sample passes decided without looking at the sample\n", spared);
+        }
+        for (auto &s : job.shards) s->eng->carry_on_ = false;
       }
       if (bounds) RETERR(job.yinyang(tolerance, yy_groups_size, iter, groups));
     }

@@ -1,0 +1,159 @@
+// lloyd_carry.hip -- Lloyd passes that CARRY distance bounds from one iteration to the next, the Yinyang phase of
+// the default schedule (reference: kmeans_cuda_yy, src/kmeans.cu:1028-1263, whose purpose -- not recomputing
+// distances the triangle inequality already decides -- this serves; its own kernels, kmeans.cu:431-672, stay
+// available bit for bit as KMCUDA_AMD_YY=reference).
+//
+// The reference refreshes its G + 1 bounds per row with >= G exact distance chains per row (kmeans_yy_init): 38
+// assignment passes' worth of time on this hardware, which no run of the benchmark data sets ever earns back.  The
+// two-stage assignment filter, on the other hand, ends every pass knowing each row's best and second-best coarse
+// score with a rigorous error bound.  That is one upper bound u(x) >= d(x, c_a) and one lower bound
+// l(x) <= min_{c != a} d(x, c) per row (Hamerly's pair) AT NO COST.  After the update the centroids have moved by
+// drift(c) = ||c_new - c_old||; by the triangle inequality u + drift(a) and l - max_c drift(c) bound the same two
+// distances for the new centroids, and a row with
+//     (l' - u') (l' + u') > 4 E_ref        (E_ref: the rounding of the reference's own score)
+// keeps its centroid in the reference's arithmetic, strictly: the pass does not look at it.  The other rows go
+// through the filter as a LIST (lloyd_coarse2_kernel<..., CARRY = 2>), stage 2 and the settle kernel as ever, and
+// come out with fresh bounds.  Assignments, previous assignments and the reassignment counter are therefore what a
+// plain pass produces, row for row -- tests/test_gpu_carry.py runs the two side by side; the inequality itself is
+// checked in float64 in tests/test_carry_bound_model.py.
+//
+// drift(c) comes out of the preparation kernel (centroid_prep_frozen_kernel: the centred panel it overwrites IS the
+// previous pass's centroid, the mean being frozen), max drift in stats[6].  L2 only.
+#include "lloyd_coarse.hpp"
+
+namespace kmx {
+
+// One pass over (assignment, u, l): moves the bounds by the drifts, keeps the rows they still decide (whose previous
+// assignment becomes the assignment, kmeans.cu:285-286 / :358-359: "assignments_prev[sample] = ass" for every row of
+// a pass) and lists the others.  probe: count only (the host wants to know what a listed pass would cover; a whole
+// pass follows and rewrites every bound).
+constexpr int kSkipRowsPerThread = 8, kSkipBlock = 256;
+__global__ __launch_bounds__(kSkipBlock) void carry_skip_kernel(
+    uint32_t N, uint32_t K, const uint32_t *__restrict__ assignments, uint32_t *__restrict__ assignments_prev,
+    float *__restrict__ ub, float *__restrict__ lb, const float2 *__restrict__ xmeta, float mu_norm_at,
+    const float *__restrict__ drift, const uint32_t *__restrict__ stats, float tie_slack, uint32_t *__restrict__ row_list,
+    uint32_t *__restrict__ counters, int probe) {
+  if (counters[kStopFlag] != 0u) return;   // the run has stopped on the device: touch nothing
+  (void)mu_norm_at;
+  const float maxdrift = __uint_as_float(stats[6]);                       // +inf if any drift is not finite
+  const float cmaxo = sqrtf(__uint_as_float(stats[2])) * 1.000001f;       // max ||c|| of THIS pass's centroids
+  const float mu_norm = reinterpret_cast<const float *>(xmeta)[2 * (((size_t)N + 255) / 256 * 256)];
+  const float u = 5.9604645e-8f;
+  const uint32_t chunk = kSkipBlock * kSkipRowsPerThread;
+  const uint32_t base = blockIdx.x * chunk;
+  __shared__ uint32_t wave_cnt[kSkipBlock / 64], blk_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t skipped_here = 0;
+#pragma unroll 1
+  for (int it = 0; it < kSkipRowsPerThread; it++) {
+    const uint32_t s = base + it * kSkipBlock + threadIdx.x;
+    bool keep = false, live = s < N;
+    if (live) {
+      const uint32_t a = assignments[s];
+      if (a < K) {
+        // (rounded away from the certificate: the sums up, the differences down)
+        const float un = (ub[s] + drift[a]) * 1.0000005f, ln = (lb[s] - maxdrift) * 0.9999995f;
+        const float xo = (sqrtf(xmeta[s].x) * 1.0001f + mu_norm) * 1.0001f;
+        const float e_ref = u * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
+        keep = (ln > un) && ((ln - un) * (ln + un) > 4.1f * e_ref + 2.0f * tie_slack);   // a NaN anywhere: false
+        if (keep && !probe) {
+          ub[s] = un;
+          lb[s] = ln;
+          if (assignments_prev[s] != a) assignments_prev[s] = a;
+        }
+      }
+    }
+    const bool list = live && !keep;
+    const unsigned long long lm = __ballot(list);
+    skipped_here += (uint32_t)__popcll(__ballot(live && keep));
+    if (probe) continue;   // (block-uniform; the would-be list length is counted below)
+    if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(lm);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t t = 0;
+#pragma unroll
+      for (int w = 0; w < kSkipBlock / 64; w++) t += wave_cnt[w];
+      blk_base = t ? atomicAdd(&counters[kCarryCursor], t) : 0u;
+    }
+    __syncthreads();
+    if (list) {
+      uint32_t at = blk_base + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull));
+      for (int w = 0; w < wave; w++) at += wave_cnt[w];
+      row_list[at] = s;
+    }
+    __syncthreads();   // wave_cnt / blk_base are reused by the next round
+  }
+  // per wave: every lane holds the wave's count (ballots); one atomic per block
+  __shared__ uint32_t wave_skip[kSkipBlock / 64];
+  if (lane == 0) wave_skip[wave] = skipped_here;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < kSkipBlock / 64; w++) t += wave_skip[w];
+    if (probe) {
+      // the would-be list: live rows of the chunk that are not kept
+      const uint32_t rows_here = base >= N ? 0u : (N - base < chunk ? N - base : chunk);
+      if (rows_here > t) atomicAdd(&counters[kCarryCursor], rows_here - t);
+    } else if (t) {
+      atomicAdd(reinterpret_cast<unsigned long long *>(counters + kCarrySkipped), (unsigned long long)t);
+    }
+  }
+}
+
+hipError_t launch_carry_skip(uint32_t N, uint32_t K, const uint32_t *assignments, uint32_t *assignments_prev, float *ub,
+                             float *lb, const float *xmeta, const float *drift, const uint32_t *stats, float tie_slack,
+                             uint32_t *row_list, uint32_t *counters, bool probe, hipStream_t st) {
+  const uint32_t chunk = kSkipBlock * kSkipRowsPerThread;
+  hipLaunchKernelGGL(carry_skip_kernel, dim3((N + chunk - 1) / chunk), dim3(kSkipBlock), 0, st, N, K, assignments,
+                     assignments_prev, ub, lb, reinterpret_cast<const float2 *>(xmeta), 0.f, drift, stats, tie_slack,
+                     row_list, counters, probe ? 1 : 0);
+  return hipGetLastError();
+}
+
+template <int DP>
+static hipError_t launch_coarse_carry_dp(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
+                                         const float *xmeta, const void *panelhi, uint32_t *undecided, float *und_thr,
+                                         const CarryArgs &cy, uint32_t rows_hint, hipStream_t st) {
+  constexpr int NSET = DP <= 256 ? 2 : 1;
+  const size_t lds_bytes = 2 * 64 * (size_t)(DP * 2) + 512 + 64 + (size_t)DP * 4;
+  const uint32_t rows_per_block = 128u * NSET;
+  uint32_t grid = (a.N + rows_per_block - 1) / rows_per_block;
+  const bool fast = a.D == (uint32_t)DP;
+#define KMX_CARRY_LAUNCH(H, F, C, MODE, SRC)                                                                          \
+  hipLaunchKernelGGL((lloyd_coarse2_kernel<DP, H, F, C, NSET, MODE>), dim3(grid), dim3(256), lds_bytes, st, SRC,      \
+                     xmeta, a.N, a.D, reinterpret_cast<const float *>(panelhi), a.bias, a.mu, a.K_pad, a.K, a.stats,   \
+                     a.eps, a.tie_slack, a.assignments, a.assignments_prev, undecided, und_thr, a.counters, cy)
+  if (!cy.row_list) {   // every row, streamed from the row cache
+    KMX_CARRY_LAUNCH(false, true, true, 1, xcache);
+    return hipGetLastError();
+  }
+  // the listed rows: blocks past the (device-side) end of the list leave at once; the grid follows the host's
+  // estimate of the list so that a short list does not dispatch N / 256 of them
+  if (rows_hint != 0xFFFFFFFFu) {
+    const uint32_t want = rows_hint / rows_per_block + rows_hint / (4 * rows_per_block) + 64;
+    if (want < grid) grid = want;
+  }
+  if (half_rows) {
+    if (fast) KMX_CARRY_LAUNCH(true, true, false, 2, rows); else KMX_CARRY_LAUNCH(true, false, false, 2, rows);
+  } else {
+    if (fast) KMX_CARRY_LAUNCH(false, true, false, 2, rows); else KMX_CARRY_LAUNCH(false, false, false, 2, rows);
+  }
+#undef KMX_CARRY_LAUNCH
+  return hipGetLastError();
+}
+
+// cy.row_list == nullptr: a whole pass from the row cache (xcache) that leaves bounds; else the listed rows
+hipError_t launch_lloyd_coarse_carry(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
+                                     const float *xmeta, const void *panelhi, uint32_t *undecided, float *und_thr,
+                                     const CarryArgs &cy, uint32_t rows_hint, hipStream_t st) {
+  switch (a.DP) {
+#define KMX_CARRY_CASE(dp) \
+    case dp: return launch_coarse_carry_dp<dp>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, und_thr, cy, rows_hint, st)
+    KMX_CARRY_CASE(16); KMX_CARRY_CASE(32); KMX_CARRY_CASE(64); KMX_CARRY_CASE(128); KMX_CARRY_CASE(256); KMX_CARRY_CASE(512);
+#undef KMX_CARRY_CASE
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace kmx

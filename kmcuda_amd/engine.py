@@ -81,6 +81,18 @@ class Engine:
         Assignments are unchanged.  Calling it again drops the copy."""
         _lib.check(self.lib.kmamd_set_row_cache(self.h, 1 if on else 0), "kmamd_set_row_cache")
 
+    def set_carry(self, on=True):
+        """Carry per-row distance bounds from pass to pass (kmamd_set_carry): in the two-stage filter's steady state
+        (L2, row cache valid) a pass only looks at the rows whose bounds -- read off the last pass's coarse scores,
+        moved by the centroids' drifts -- no longer certify their assignment.  Results are those of plain passes."""
+        _lib.check(self.lib.kmamd_set_carry(self.h, 1 if on else 0), "kmamd_set_carry")
+
+    def carry_stats(self):
+        """(row passes the carried bounds have decided so far, length of the newest row list the host knows)."""
+        spared, last = ctypes.c_uint64(0), ctypes.c_uint32(0)
+        _lib.check(self.lib.kmamd_carry_stats(self.h, ctypes.byref(spared), ctypes.byref(last)), "kmamd_carry_stats")
+        return int(spared.value), int(last.value)
+
     def counters(self):
         out = (ctypes.c_uint32 * 4)()
         _lib.check(self.lib.kmamd_counters_read(self.h, out), "kmamd_counters_read")

@@ -1,0 +1,138 @@
+"""Bounds carried from pass to pass (kmcuda_amd/csrc/lloyd_carry.hip; the Yinyang phase of kmeans_cuda()'s default
+schedule; the reference's purpose: src/kmeans.cu:1028-1263).
+
+Bar: a loop whose passes spare the rows their bounds decide is INDISTINGUISHABLE from the loop of plain passes --
+assignments, previous assignments, reassignment counters and (hence) centroids bit for bit after every iteration,
+on clustered data (where most rows are spared), unstructured data (where nearly none is), with NaN rows, clusters
+that die, rows as halves, through both update paths (apply alone; the update fused with the next preparation) and
+through kmeans_cuda(yinyang_t > 0) as a whole.  The first pass of every run is also checked against the oracle."""
+import os
+
+import numpy
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _blobs(n, d, k, seed, spread=6.0):
+    rs = numpy.random.RandomState(seed)
+    centres = rs.rand(k, d) * spread
+    lab = rs.randint(0, k, n)
+    x = (centres[lab] + rs.randn(n, d)).astype(numpy.float32)
+    return x
+
+
+def _uniform(n, d, seed):
+    return numpy.random.RandomState(seed).rand(n, d).astype(numpy.float32)
+
+
+def _run_pair(x, k, iters, carry_from, fused, half=False, seed=5, monkeypatch=None, list_max=None):
+    """Two loops over the same rows and seeds, one carrying bounds from iteration `carry_from` on; yields per
+    iteration (changed_plain, changed_carry) after asserting the states equal.  Returns the carry engine's stats."""
+    from kmcuda_amd.distributed import HipBackend, ShardedLloyd
+    dev = torch.device("cuda", 0)
+    rs = numpy.random.RandomState(seed)
+    if half:
+        x = x.astype(numpy.float16).astype(numpy.float32)
+    init = x[rs.choice(len(x), k, replace=False)].copy()
+    finite_rows = numpy.isfinite(init).all(axis=1)
+    if not finite_rows.all():   # never seed from a NaN row
+        good = numpy.nonzero(numpy.isfinite(x).all(axis=1))[0]
+        init[~finite_rows] = x[good[:int((~finite_rows).sum())]]
+    xs = torch.from_numpy(x).to(dev)
+    loops = []
+    for which in range(2):
+        h = xs.to(torch.float16) if half else None
+        b = HipBackend(xs, k, "L2", device_index=0, half_rows=h)
+        loop = ShardedLloyd(b, len(x))
+        loop.set_centroids(torch.from_numpy(init).to(dev))
+        loops.append(loop)
+    plain, carry = loops
+    if list_max is not None:
+        os.environ["KMCUDA_AMD_CARRY_MAX"] = str(list_max)
+    try:
+        log = []
+        for it in range(iters):
+            if it == carry_from:
+                carry.b.engine.set_carry(True)
+            for loop in loops:
+                if fused:
+                    loop.step(tolerance=0.0)      # device-side stop rule + update fused with the next preparation
+                else:
+                    loop.step()                    # plain apply; the preparation runs inside the next pass
+            for loop in loops:
+                loop.b.synchronize()
+            a0, a1 = plain.b.assignments.cpu().numpy(), carry.b.assignments.cpu().numpy()
+            p0, p1 = plain.b.assignments_prev.cpu().numpy(), carry.b.assignments_prev.cpu().numpy()
+            assert (a0 == a1).all(), "iteration %d: %d assignments differ" % (it, int((a0 != a1).sum()))
+            assert (p0 == p1).all(), "iteration %d: %d previous assignments differ" % (it, int((p0 != p1).sum()))
+            c0, c1 = plain.b.centroids.cpu().numpy(), carry.b.centroids.cpu().numpy()
+            assert (c0.view(numpy.uint32) == c1.view(numpy.uint32)).all(), "iteration %d: centroids differ" % it
+            if it == 0:
+                ref, _, _ = oracle.lloyd_assign(x, init)
+                assert (a0.view(numpy.uint32) == ref).all()
+            log.append(int((a0 != p0).sum()))
+        spared, last = carry.b.engine.carry_stats()
+        return log, spared, last
+    finally:
+        if list_max is not None:
+            del os.environ["KMCUDA_AMD_CARRY_MAX"]
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["apply", "apply+prepare"])
+@pytest.mark.parametrize("shape", [(60000, 64, 64), (50000, 256, 200), (30000, 24, 40), (40000, 100, 33)],
+                         ids=lambda s: "%dx%d@%d" % s)
+def test_carried_passes_equal_plain_passes_on_clustered_rows(shape, fused):
+    n, d, k = shape
+    x = _blobs(n, d, max(8, k // 2), seed=n + d)
+    log, spared, last = _run_pair(x, k, iters=14, carry_from=3, fused=fused)
+    # most rows of late iterations are decided by their bounds
+    assert spared > 3 * n, (log, spared, last)
+    assert last < n // 2, (log, spared, last)
+
+
+@pytest.mark.parametrize("list_max", [None, 1.0, 0.0], ids=["default", "always-listed", "never-listed"])
+def test_carried_passes_equal_plain_passes_on_unstructured_rows(list_max):
+    # uniform rows: the bounds spare next to nothing -- the listed pass (forced: KMCUDA_AMD_CARRY_MAX=1) then covers
+    # nearly every row from the rows themselves, the whole pass (=0) only counts the list
+    x = _uniform(60000, 256, seed=3)
+    log, spared, last = _run_pair(x, 300, iters=9, carry_from=2, fused=True, list_max=list_max)
+    assert last > 0
+
+
+def test_carried_passes_with_nan_rows_dead_clusters_and_halves():
+    x = _blobs(40000, 64, 20, seed=77)
+    x[5, 0] = numpy.nan          # kmeans.cu:312: assignment K
+    x[9, 7] = numpy.nan          # a NaN elsewhere: the row is never touched ("search failed")
+    x[100:110] = 1.0e4           # far rows: one cluster of their own, then another seed dies
+    _run_pair(x, 48, iters=10, carry_from=2, fused=True)
+    _run_pair(x, 48, iters=10, carry_from=2, fused=False)
+    xh = _blobs(40000, 64, 20, seed=78)
+    log, spared, _ = _run_pair(xh, 48, iters=10, carry_from=2, fused=True, half=True)
+    assert spared > 0
+
+
+def test_kmeans_cuda_default_schedule_carries_and_equals_the_plain_schedule(monkeypatch):
+    """kmeans_cuda(yinyang_t = 0.1): after the reference's hand-over point the default schedule carries bounds;
+    KMCUDA_AMD_CARRY=0 runs the same passes plain.  Same progress lines, same results."""
+    from kmcuda_amd import kmeans_cuda
+    from test_gpu_kmeans import StdoutListener
+    x = _blobs(120000, 64, 60, seed=9)
+    outs = []
+    for carry in ("1", "0"):
+        monkeypatch.setenv("KMCUDA_AMD_CARRY", carry)
+        out = StdoutListener()
+        with out:
+            cen, asg = kmeans_cuda(x, 100, init="random", seed=3, tolerance=0.0005, yinyang_t=0.1, device=1, verbosity=2)
+        text = out.text
+        lines = [l for l in text.split("\n") if l.startswith("iteration")]
+        outs.append((cen, asg, lines, text))
+    assert outs[0][2] == outs[1][2]
+    assert (outs[0][1] == outs[1][1]).all()
+    assert (outs[0][0].view(numpy.uint32) == outs[1][0].view(numpy.uint32)).all()
+    assert "carrying per-sample distance bounds" in outs[0][3]
+    spared = [l for l in outs[0][3].split("\n") if l.startswith("carried bounds:")]
+    assert spared and int(spared[0].split()[2]) > len(x), spared
