@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "../../include/kmcuda_amd.h"
@@ -26,39 +27,82 @@ struct Rocblas {
   int (*set_stream)(void *, hipStream_t) = nullptr;
   int (*gemm_ex)(void *, int, int, int, int, int, const void *, const void *, int, int, const void *, int, int,
                  const void *, const void *, int, int, void *, int, int, int, int, int32_t, uint32_t) = nullptr;
+  std::once_flag once;
+  bool ok = false;
+  // (called from every shard's worker thread: once, and nobody sees half-filled pointers -- ADVICE r3)
   bool load() {
-    if (tried) return gemm_ex != nullptr;
-    tried = true;
-    for (const char *name : {"librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so.5", "/opt/rocm/lib/librocblas.so"}) {
-      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (lib) break;
-    }
-    if (!lib) return false;
-    create_handle = (decltype(create_handle))dlsym(lib, "rocblas_create_handle");
-    destroy_handle = (decltype(destroy_handle))dlsym(lib, "rocblas_destroy_handle");
-    set_stream = (decltype(set_stream))dlsym(lib, "rocblas_set_stream");
-    gemm_ex = (decltype(gemm_ex))dlsym(lib, "rocblas_gemm_ex");
-    if (!(create_handle && destroy_handle && set_stream && gemm_ex)) gemm_ex = nullptr;
-    return gemm_ex != nullptr;
+    std::call_once(once, [this] {
+      for (const char *name : {"librocblas.so.5", "librocblas.so.4", "librocblas.so", "/opt/rocm/lib/librocblas.so.5",
+                               "/opt/rocm/lib/librocblas.so.4", "/opt/rocm/lib/librocblas.so"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (lib) break;
+      }
+      if (lib) {
+        create_handle = (decltype(create_handle))dlsym(lib, "rocblas_create_handle");
+        destroy_handle = (decltype(destroy_handle))dlsym(lib, "rocblas_destroy_handle");
+        set_stream = (decltype(set_stream))dlsym(lib, "rocblas_set_stream");
+        gemm_ex = (decltype(gemm_ex))dlsym(lib, "rocblas_gemm_ex");
+        ok = create_handle && destroy_handle && set_stream && gemm_ex;
+      }
+      if (!ok && g_verbosity > 0)
+        printf("rows wider than 512 features: no usable librocblas.so -- the exact kernels serve them (slowly)\n");
+    });
+    return ok;
   }
 };
 Rocblas g_rocblas;
 constexpr int kRbOpNone = 111, kRbOpTrans = 112, kRbF16 = 150, kRbF32 = 151;   // rocblas-types.h
 }  // namespace
 
+void *Engine::alloc_bytes(size_t bytes) {
+  const size_t rounded = (bytes + 255u) & ~(size_t)255u;
+  if (rounded <= kSlabMaxItem) {
+    if (slab_used_ + rounded > kSlabBytes) {
+      void *q = nullptr;
+      if (hipMalloc(&q, kSlabBytes) != hipSuccess) return nullptr;
+      owned_.push_back(q);
+      slab_ = static_cast<char *>(q);
+      slab_used_ = 0;
+    }
+    void *r = slab_ + slab_used_;
+    slab_used_ += rounded;
+    return r;
+  }
+  void *q = nullptr;
+  if (hipMalloc(&q, bytes) != hipSuccess) return nullptr;
+  owned_.push_back(q);
+  return q;
+}
+
+uint32_t *Engine::pinned_words(size_t n, uint32_t **dev_addr) {
+  if (!pinned_) {
+    if (hipHostMalloc(reinterpret_cast<void **>(&pinned_), kPinnedWords * sizeof(uint32_t), hipHostMallocCoherent) != hipSuccess) {
+      pinned_ = nullptr;
+      return nullptr;
+    }
+    memset(pinned_, 0, kPinnedWords * sizeof(uint32_t));
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, pinned_, 0) != hipSuccess) return nullptr;
+    pinned_dev_ = static_cast<uint32_t *>(dp);
+  }
+  n = (n + 3u) & ~(size_t)3u;   // 16-byte granules
+  if (pinned_used_ + n > kPinnedWords) return nullptr;
+  uint32_t *r = pinned_ + pinned_used_;
+  if (dev_addr) *dev_addr = pinned_dev_ + pinned_used_;
+  pinned_used_ += n;
+  return r;
+}
+
 Engine::~Engine() {
   if (device_ >= 0) (void)hipSetDevice(device_);
   for (auto &s : spans_) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (void *p : owned_) (void)hipFree(p);
-  if (host_counters_) (void)hipHostFree(host_counters_);
-  if (host_move_count_) (void)hipHostFree(host_move_count_);
-  if (host_carry_) (void)hipHostFree(host_carry_);
+  if (pinned_) (void)hipHostFree(pinned_);
   if (side_stream_) {
     (void)hipStreamDestroy(side_stream_);
     (void)hipEventDestroy(ev_fork_);
     (void)hipEventDestroy(ev_join_);
   }
-  if (host_report_) (void)hipHostFree(host_report_);
   for (hipEvent_t e : ev_report_)
     if (e) (void)hipEventDestroy(e);
   if (rb_handle_ && g_rocblas.destroy_handle) (void)g_rocblas.destroy_handle(rb_handle_);
@@ -130,15 +174,10 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   bucket_cap_ = move_bucket_cap(n_rows, K);
   if ((rc = alloc(&bucket_rows_, 2 * (size_t)K * bucket_cap_))) return rc;
   KMX_HIP(hipMemsetAsync(stats_base_, 0, 16 * sizeof(uint32_t), stream_), kRuntimeError);
-  KMX_HIP(hipHostMalloc(reinterpret_cast<void **>(&host_move_count_), 4 * sizeof(uint32_t), hipHostMallocCoherent), kMemoryAllocationFailure);
-  memset(host_move_count_, 0, 4 * sizeof(uint32_t));
+  host_move_count_ = pinned_words(4, &ms_.host_dev);
+  if (!host_move_count_) return kMemoryAllocationFailure;
   host_move_count_[2] = 0xFFFFFFFFu;   // undecided rows: not known yet
   ms_.host = host_move_count_;
-  {
-    void *dp = nullptr;
-    KMX_HIP(hipHostGetDevicePointer(&dp, host_move_count_, 0), kRuntimeError);
-    ms_.host_dev = static_cast<uint32_t *>(dp);
-  }
   KMX_HIP(hipEventCreateWithFlags(&ev_rows_, hipEventDisableTiming), kRuntimeError);
   sort_temp_bytes_ = sort_temp_bytes(2 * (size_t)n_rows, 2 * K);
   {
@@ -150,7 +189,8 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
     if ((rc = alloc(&t, sort_temp_bytes_ + 16))) return rc;
     sort_temp_ = t;
   }
-  KMX_HIP(hipHostMalloc((void **)&host_counters_, 8 * sizeof(uint32_t), hipHostMallocDefault), kMemoryAllocationFailure);
+  host_counters_ = pinned_words(8, nullptr);
+  if (!host_counters_) return kMemoryAllocationFailure;
   KMX_HIP(hipMemsetAsync(counters_, 0, 16 * sizeof(uint32_t), stream_), kRuntimeError);
   return kSuccess;
 }
@@ -466,7 +506,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   a.assignments = assignments; a.assignments_prev = assignments_prev;
   a.flagged = flagged_; a.pairs = pairs_; a.counters = counters_;
   if (N_ == 0) return kSuccess;
-  if (!exact_only && DP_ == 0 && gemm_dp_ != 0) {
+  if (!exact_only && DP_ == 0 && gemm_dp_ != 0 && !gemm_failed_) {
     const int rc = lloyd_assign_gemm(a, centroids);
     if (rc != kNoSuchDevice + 100) return rc;   // (that code: rocBLAS is not there -- the exact kernel below serves the shape)
   }
@@ -509,20 +549,21 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
     // Carried bounds (lloyd_carry.hip): in the steady state the pass can leave per-row distance bounds behind and the
     // next one only looks at the rows they do not decide.  The drift of this pass's centroids against the last pass's
     // is the preparation kernel's (exactly one preparation since: anything else voids the bounds).
-    const bool carry = carry_on_ && steady && cached && metric_ == 0;
+    bool carry = carry_on_ && steady && cached && metric_ == 0;
+    if (carry && carry_pause_ > 0) {   // the bounds decided next to nothing lately: plain passes for a while
+      carry_pause_--;
+      carry = false;
+    }
     if (carry && !ub_) {
       // (no memory: not an error, plain passes)
       if (alloc(&ub_, N_) != kSuccess || alloc(&lb_, N_) != kSuccess || alloc(&drift_, K_) != kSuccess ||
-          alloc(&carry_list_, N_) != kSuccess ||
-          hipHostMalloc(reinterpret_cast<void **>(&host_carry_), 2 * sizeof(uint32_t), hipHostMallocCoherent) != hipSuccess) {
+          alloc(&carry_list_, N_) != kSuccess || !(host_carry_ = pinned_words(2, &host_carry_dev_))) {
         (void)hipGetLastError();
         carry_on_ = false;
+        ub_ = nullptr;
       } else {
         host_carry_[0] = 0xFFFFFFFFu;
         host_carry_[1] = 0;
-        void *dp = nullptr;
-        KMX_HIP(hipHostGetDevicePointer(&dp, host_carry_, 0), kRuntimeError);
-        host_carry_dev_ = static_cast<uint32_t *>(dp);
         if (const char *v = getenv("KMCUDA_AMD_CARRY_MAX")) carry_list_max_ = (float)atof(v);
       }
       carry_valid_ = false;   // (this pass's preparation ran without a drift buffer)
@@ -537,8 +578,21 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
       if (moved) {
         // what the host knows of an EARLIER pass's list (a pinned word the coarse kernel writes; only speed depends
         // on it): a short list -> the listed pass; else every row from the row cache, the list only counted
-        const uint32_t last = host_carry_[0];
+        const uint32_t last = host_carry_[0], last_seq = host_carry_[1];
         listed = last != 0xFFFFFFFFu && (float)last <= carry_list_max_ * (float)N_;
+        if (last != 0xFFFFFFFFu && last_seq != carry_seen_seq_) {   // a report not judged yet
+          carry_seen_seq_ = last_seq;
+          if ((float)last > 0.9f * (float)N_ && carry_list_max_ < 1.0f) {
+            if (++carry_hopeless_ >= 2) {
+              carry_pause_ = carry_backoff_;
+              carry_backoff_ = carry_backoff_ < 64 ? 2 * carry_backoff_ : 64;
+              carry_hopeless_ = 0;
+            }
+          } else {
+            carry_hopeless_ = 0;
+            carry_backoff_ = 8;
+          }
+        }
         if (listed) hint = last;
         KMX_HIP(launch_carry_skip(N_, K_, assignments, assignments_prev, ub_, lb_, xmeta_, drift_, stats_, tie_slack_,
                                   carry_list_, counters_, !listed, stream_),
@@ -601,23 +655,30 @@ int Engine::lloyd_assign_gemm(const LloydArgs &a0, const float *centroids) {
   LloydArgs a = a0;
   const uint32_t DG = gemm_dp_;
   const uint32_t k_pad64 = (K_pad_ + 63u) / 64u * 64u;
-  int rc;
+  // This path's own memory (half copy of the rows, a chunk of scores, the contender tables) is an optimisation: a job
+  // whose rows fit but whose copies do not runs on the exact kernels, as it did before this path existed
+  auto no_memory = [&]() {
+    (void)hipGetLastError();
+    if (g_verbosity > 0) printf("rows wider than 512 features: no memory for the GEMM filter's buffers -- exact kernels\n");
+    gemm_failed_ = true;   // (gemm_dp_ stays: the preparation's buffers are sized by it)
+    return kNoRocblas;
+  };
   if (!panelhi_) {
     uint16_t *phi = nullptr;
-    if ((rc = alloc(&phi, (size_t)k_pad64 * (DG + 2)))) return rc;
+    if (alloc(&phi, (size_t)k_pad64 * (DG + 2))) return no_memory();
     panelhi_ = phi;
   }
   const uint32_t chunk = gemm_chunk_rows(N_, K_pad_);
   if (!gscores_) {
-    if ((rc = alloc(&gscores_, (size_t)chunk * K_pad_))) return rc;
-    if ((rc = alloc(&gund_rows_, gemm_rows_words(N_)))) return rc;
-    if ((rc = alloc(&gund_cont_, gemm_cont_words(N_)))) return rc;
-    if ((rc = alloc(&gcursors_, 64 * 32))) return rc;
+    if (alloc(&gscores_, (size_t)chunk * K_pad_) || alloc(&gund_rows_, gemm_rows_words(N_)) ||
+        alloc(&gund_cont_, gemm_cont_words(N_)) || alloc(&gcursors_, 64 * 32)) {
+      gscores_ = nullptr;
+      return no_memory();
+    }
   }
   if (!xg16_) {
     uint16_t *xg = nullptr;
-    if ((rc = alloc(&xg, (size_t)N_ * DG))) return rc;
-    if ((rc = alloc(&xgmeta_, (size_t)N_ * 4))) return rc;
+    if (alloc(&xg, (size_t)N_ * DG) || alloc(&xgmeta_, (size_t)N_ * 4)) return no_memory();
     xg16_ = xg;
   }
   span_begin(0);
@@ -705,12 +766,9 @@ int Engine::stop_ctl(float stop_threshold, bool report, uint32_t seq, StopCtl *c
   ctl->seq = seq;
   if (report) {
     if (!host_report_) {
-      KMX_HIP(hipHostMalloc(reinterpret_cast<void **>(&host_report_), 16 * sizeof(uint32_t), hipHostMallocCoherent),
-              kMemoryAllocationFailure);
+      host_report_ = pinned_words(16, &host_report_dev_);
+      if (!host_report_) return kMemoryAllocationFailure;
       memset(host_report_, 0xFF, 16 * sizeof(uint32_t));
-      void *dp = nullptr;
-      KMX_HIP(hipHostGetDevicePointer(&dp, host_report_, 0), kRuntimeError);
-      host_report_dev_ = static_cast<uint32_t *>(dp);
       for (hipEvent_t &e : ev_report_) KMX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming), kRuntimeError);
     }
     ctl->host_tail = host_report_dev_ + 8 * (seq & 1u);

@@ -72,14 +72,19 @@ class Engine {
   int counters_reset(int which);
   int sync();
 
+  // Device memory of the engine's lifetime.  Small buffers (most of them: a job has ~40, the nested job that
+  // clusters the centroids into Yinyang groups has nothing else) are carved out of 4-MB slabs -- a hipMalloc costs
+  // 0.1-0.2 ms whatever its size, which was 5 ms of set-up per job --, 256-byte aligned; large ones are their own.
   template <typename T>
   int alloc(T **p, size_t count) {
-    void *q = nullptr;
-    if (hipMalloc(&q, count ? count * sizeof(T) : sizeof(T)) != hipSuccess) return kMemoryAllocationFailure;
-    owned_.push_back(q);
+    void *q = alloc_bytes(count ? count * sizeof(T) : sizeof(T));
+    if (!q) return kMemoryAllocationFailure;
     *p = static_cast<T *>(q);
     return kSuccess;
   }
+  void *alloc_bytes(size_t bytes);
+  // pinned words of the engine's lifetime, from ONE pinned block (device-visible, coherent)
+  uint32_t *pinned_words(size_t n, uint32_t **dev_addr);
 
   int device_ = -1;
   hipStream_t stream_ = nullptr;
@@ -111,6 +116,7 @@ class Engine {
   // (0: not this path); KMCUDA_AMD_GEMM=0 leaves such shapes to the exact kernels (the cross-check)
   uint32_t gemm_dp_ = 0;
   bool gemm_ok_ = true;
+  bool gemm_failed_ = false;   // its buffers could not be allocated: the exact kernels serve the shape
   void *rb_handle_ = nullptr;
   void *xg16_ = nullptr;          // N x gemm_dp_ halves: x - mu, row-major (this path's row cache)
   float *xgmeta_ = nullptr;       // 4 floats per row
@@ -130,6 +136,9 @@ class Engine {
   uint32_t carry_preps_ = 0;     // centroid preparations since the last pass (exactly 1: drift_ is that update's)
   uint32_t carry_seq_ = 0;
   float carry_list_max_ = 0.5f;  // a listed pass when at most this share of the rows is on the list (KMCUDA_AMD_CARRY_MAX)
+  // rows the bounds cannot decide (unstructured data): after two lists in a row beyond 90 % of the rows the passes
+  // go plain for carry_backoff_ iterations (8, doubling up to 64), then the bounds are tried again
+  uint32_t carry_pause_ = 0, carry_backoff_ = 8, carry_hopeless_ = 0, carry_seen_seq_ = 0;
   float *ub_ = nullptr, *lb_ = nullptr, *drift_ = nullptr;
   uint32_t *carry_list_ = nullptr;
   uint32_t *host_carry_ = nullptr, *host_carry_dev_ = nullptr;   // 2 pinned words: [0] the last list's length, [1] seq
@@ -178,6 +187,12 @@ class Engine {
 
  private:
   std::vector<void *> owned_;
+  static constexpr size_t kSlabBytes = 4u << 20, kSlabMaxItem = 512u << 10;
+  char *slab_ = nullptr;
+  size_t slab_used_ = kSlabBytes;
+  static constexpr size_t kPinnedWords = 64;
+  uint32_t *pinned_ = nullptr, *pinned_dev_ = nullptr;
+  size_t pinned_used_ = 0;
 };
 
 }  // namespace kmx

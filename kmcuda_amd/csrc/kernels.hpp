@@ -304,6 +304,9 @@ struct KnnArgs {
   // arithmetic (knn_centroid_bounds_kernel); nullptr: the reference's prune test alone
   const float *lb = nullptr;
   size_t lb_stride = 0;
+  // optional (f16 filter): slot i of the launch's block plan (sorted position p_base + i) handles the query at sorted
+  // position qperm[i] of the same cluster (launch_knn_query_order); nullptr: i itself
+  const uint32_t *qperm = nullptr;
   float *heaps;             // (p_end - p_base) x 2k
   uint32_t *out;            // (p_end - p_base) x k, sorted-position order
   unsigned long long *calced;  // [0] pairs the REFERENCE's prune rule visits (knn.cu:228); knn_f16.hip also: [1] pairs
@@ -321,6 +324,9 @@ hipError_t launch_knn_filter(int metric, const KnnArgs &a, uint32_t nblocks, hip
 hipError_t launch_knn_centroid_bounds(const float *xs, uint32_t D, uint32_t DP, uint32_t p_base, uint32_t p_end,
                                       const float *centroids, uint32_t K, const float *R, float *lb, size_t stride,
                                       hipStream_t st);
+bool launch_knn_query_order(const float *lb, size_t stride, const uint32_t *offsets, uint32_t K, uint32_t p_base,
+                            uint32_t p_end, uint32_t *keys_tmp, uint32_t *vals_tmp, uint32_t *keys_sorted,
+                            uint32_t *qperm, void *temp, size_t temp_bytes, hipStream_t st);
 // strict_h2 (both): the reference's half2 arithmetic on rows that hold half values (KMCUDA_AMD_FP16_STRICT)
 hipError_t launch_knn_exact(int metric, const KnnArgs &a, bool strict_h2, hipStream_t st);
 hipError_t launch_knn_split(int metric, const float *xs, uint32_t N, uint32_t D, uint32_t DP, const float *mu,

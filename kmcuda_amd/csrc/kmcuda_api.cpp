@@ -228,7 +228,8 @@ struct Shard {
     for (void *p : owned) (void)hipFree(p);
   }
   template <typename T>
-  int alloc(T **p, size_t count) {
+  int alloc(T **p, size_t count) {   // (through the engine once it exists: small buffers share its slabs)
+    if (eng) return eng->alloc(p, count);
     void *q = nullptr;
     if (hipMalloc(&q, count ? count * sizeof(T) : sizeof(T)) != hipSuccess) return kmcudaMemoryAllocationFailure;
     owned.push_back(q);
@@ -855,7 +856,7 @@ class Job {
 
   // the same test from the REDUCED buffer's tail (the counters rode along in the iteration's all-reduce):
   // one 32-byte read on the first shard instead of a synchronisation per GPU
-  int check_changed_reduced(int iter, float tolerance, bool print) {
+  int check_changed_reduced(int iter, float tolerance, bool print, uint32_t *passed_total = nullptr) {
     Shard &f = *shards[0];
     (void)hipSetDevice(f.dev);
     double tail[4];
@@ -863,7 +864,7 @@ class Job {
         hipStreamSynchronize(f.eng->stream_) != hipSuccess)
       return -kmcudaMemoryCopyError;
     return judge_changed(iter, tolerance, print, (uint32_t)tail[0], (uint32_t)tail[2], (uint32_t)tail[3], (uint32_t)tail[1],
-                         nullptr);
+                         passed_total);
   }
 
   int judge_changed(int iter, float tolerance, bool print, uint32_t overall_changed, uint32_t overall_passed,
@@ -1056,15 +1057,27 @@ class Job {
   int cluster_groups(uint32_t G, std::vector<uint32_t> *groups) {
     Shard &first = *shards[0];
     RETERR(first.eng->sync());
+    const bool timing = getenv("KMCUDA_AMD_TIMING") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+      if (!timing) return;
+      const auto t1 = std::chrono::steady_clock::now();
+      fprintf(stderr, "[timing] group clustering, %s: %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+      t0 = t1;
+    };
     Job gjob;
     gjob.strict_h2 = strict_h2;   // (before setup: the engines take the flag there)
     std::vector<int> one{first.dev};
     RETERR(gjob.setup(one, 0, K, D, G, metric, verbosity, first.centroids, first.dev));  // fp32 replica in place
+    lap("setup");
     gjob.exact_update = exact_update;
     gjob.fp16 = fp16;  // centroids_yy is half2 in the reference too (kmeans.cu:1084-1091)
     RETERR(gjob.init_centroids(kmcudaInitMethodPlusPlus, 0, nullptr, first.dev));
+    if (timing) RETERR(gjob.sync_all());
+    lap("k-means++");
     RETERR(gjob.lloyd((float)kYinyangGroupTolerance, nullptr));
     RETERR(gjob.sync_all());
+    lap("Lloyd");
     groups->resize(K);
     (void)hipSetDevice(first.dev);
     if (hipMemcpy(groups->data(), gjob.shards[0]->assignments, K * sizeof(uint32_t), hipMemcpyDeviceToHost) !=
@@ -1087,10 +1100,21 @@ class Job {
     RETERR(sync_all());  // host vectors above go out of use
     RETERR(prepare_mem(true));
     bool refresh = true;
+    // Per iteration (kmeans.cu:1112-1260): stop test on the filters' counters, bounds refresh when nearly every row
+    // passed, the update, the drifts, the two filters.  With several shards the counters (reassigned, passed) ride
+    // in the update's ONE all-reduce -- the shards' move sums are formed and reduced BEFORE the test, which then is
+    // one 32-byte read on the first shard instead of a stream synchronisation per GPU (round 3: check_changed) --
+    // and every shard's kernels are enqueued by its own worker thread (for_shards), as in lloyd().  The strict
+    // update (one serial chain over all rows, single shard) has no reduce buffer and keeps the plain sequence.
     for (;; iter++) {
+      if (!exact_update) {
+        RETERR(fill_deltas());
+        RETERR(allreduce_fused());
+      }
       if (!refresh) {
         uint32_t passed_total = 0;
-        const int status = check_changed(iter, tolerance, true, &passed_total);
+        const int status = exact_update ? check_changed(iter, tolerance, true, &passed_total)
+                                        : check_changed_reduced(iter, tolerance, true, &passed_total);
         if (status < 0) return -status;
         if (status == 1) {
           if (verbosity > 1) {
@@ -1110,28 +1134,24 @@ class Job {
       }
       if (refresh) {
         INFO("refreshing Yinyang bounds...\n");
-        for (auto &s : shards) {
-          (void)hipSetDevice(s->dev);
-          RETERR(s->eng->yy_init(s->samples, s->centroids, s->assignments, s->bounds));
-        }
+        RETERR(for_shards([](Shard &s) { return s.eng->yy_init(s.samples, s.centroids, s.assignments, s.bounds); }));
         refresh = false;
       }
-      for (auto &s : shards) {  // kmeans.cu:1159: keep the old centroids for the drifts
-        (void)hipSetDevice(s->dev);
-        if (hipMemcpyAsync(s->drifts, s->centroids, (size_t)K * D * sizeof(float), hipMemcpyDeviceToDevice,
-                           s->eng->stream_) != hipSuccess)
-          return kmcudaMemoryCopyError;
-      }
-      RETERR(adjust());
-      for (auto &s : shards) {
-        (void)hipSetDevice(s->dev);
-        RETERR(s->eng->yy_drifts(s->centroids, s->drifts, s->gdrifts));
-        RETERR(s->eng->counters_reset(2));  // d_passed_number = 0, kmeans.cu:1225-1229
-        RETERR(s->eng->counters_reset(1));  // statistics of the local filter (flushes, exact distances)
-        RETERR(s->eng->counters_reset(3));
-        RETERR(s->eng->yy_filters(s->samples, s->centroids, s->drifts, s->gdrifts, s->assignments, s->prev, s->bounds,
-                                  s->passed));
-      }
+      const size_t kd_bytes = (size_t)K * D * sizeof(float);
+      RETERR(for_shards([kd_bytes](Shard &s) {   // kmeans.cu:1159: keep the old centroids for the drifts
+        return hipMemcpyAsync(s.drifts, s.centroids, kd_bytes, hipMemcpyDeviceToDevice, s.eng->stream_) == hipSuccess
+                   ? 0 : (int)kmcudaMemoryCopyError;
+      }));
+      if (exact_update) RETERR(adjust());
+      else RETERR(apply_deltas());
+      RETERR(for_shards([](Shard &s) {
+        int rc = s.eng->yy_drifts(s.centroids, s.drifts, s.gdrifts);
+        if (rc) return rc;
+        if ((rc = s.eng->counters_reset(2))) return rc;  // d_passed_number = 0, kmeans.cu:1225-1229
+        if ((rc = s.eng->counters_reset(1))) return rc;  // statistics of the local filter (flushes, exact distances)
+        if ((rc = s.eng->counters_reset(3))) return rc;
+        return s.eng->yy_filters(s.samples, s.centroids, s.drifts, s.gdrifts, s.assignments, s.prev, s.bounds, s.passed);
+      }));
       stats.iterations++;
     }
   }
@@ -1473,6 +1493,17 @@ class KnnJob {
               return kmcudaRuntimeError;
             a.lb = lb;
             a.lb_stride = len;
+            // queries that want the same clusters into the same waves (update.hip: launch_knn_query_order);
+            // KMCUDA_AMD_KNN_ORDER=0: sorted-position order (A/B)
+            const char *ord = getenv("KMCUDA_AMD_KNN_ORDER");
+            uint32_t *qperm = nullptr;
+            if (!(ord && atoi(ord) == 0) && s.alloc(&qperm, len) == 0) {
+              if (launch_knn_query_order(lb, len, s.offsets, K, s.p_base, s.p_end, s.keys_tmp, s.vals_tmp, s.keys_sorted,
+                                         qperm, s.sort_temp, sort_bytes, s.stream))
+                a.qperm = qperm;
+              else
+                (void)hipGetLastError();
+            }
           } else {
             (void)hipGetLastError();
             DEBUG("k-NN: no memory for the per-query centroid bounds, the reference's prune test alone\n");
@@ -1613,7 +1644,17 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
   // default stream's implicit synchronisation
   if (device_ptrs >= 0 && hipSetDevice(device_ptrs) == hipSuccess) (void)hipDeviceSynchronize();
   const auto t_begin = std::chrono::steady_clock::now();
+  // KMCUDA_AMD_TIMING=1: wall-clock laps of the call's phases on stderr (a measurement aid; each lap waits for the GPUs)
+  const bool timing = getenv("KMCUDA_AMD_TIMING") != nullptr;
+  auto t_lap = t_begin;
   Job job;
+  auto lap = [&](const char *what) {
+    if (!timing) return;
+    (void)job.sync_all();
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[timing] %s: %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t_lap).count());
+    t_lap = t1;
+  };
   job.fp16 = fp16x2 != 0;
   if (const char *v = getenv("KMCUDA_AMD_FP16_STRICT")) job.strict_h2 = job.fp16 && atoi(v) != 0;
   // fp16x2: features_size counts half2 pairs (kmcuda.h:107-108); internally one feature per half
@@ -1622,6 +1663,7 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
                    device_ptrs));
   if (const char *v = getenv("KMCUDA_AMD_EXACT_UPDATE")) job.exact_update = atoi(v) != 0;
   if (job.strict_h2) job.exact_update = true;   // the reference's serial update, in half2 arithmetic
+  lap("set-up (engines, uploads)");
   if (job.exact_update && job.shards.size() > 1) {
     INFO("KMCUDA_AMD_EXACT_UPDATE needs all rows on one GPU (the reference's update order is global)\n");
     return kmcudaInvalidArguments;
@@ -1629,6 +1671,7 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
   const uint32_t afk_m = (init == kmcudaInitMethodAFKMC2 && init_params) ? *reinterpret_cast<const uint32_t *>(init_params) : 0;
   RETERR(job.init_centroids(init, seed, centroids, device_ptrs, afk_m));
   RETERR(job.sync_all());
+  lap("seeding");
   const auto t_loop = std::chrono::steady_clock::now();
   job.stats.setup_seconds = std::chrono::duration<double>(t_loop - t_begin).count();
   job.stats.shards = (uint32_t)job.shards.size();
@@ -1650,6 +1693,7 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
     const SwitchRule rule(samples_size);
     int iter = 0;
     RETERR(job.lloyd((float)kYinyangDraftReassignments, &iter));
+    lap("Lloyd down to 11 % reassignments");
     const int st = job.check_changed(iter, tolerance, false);  // kmeans.cu:1058
     if (st < 0) return static_cast<KMCUDAResult>(-st);
     if (st == 0) {
@@ -1657,6 +1701,7 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
       // part of what a caller sees, its srand(0) of what a caller's rand() sees) -- whichever schedule follows
       std::vector<uint32_t> groups;
       RETERR(job.cluster_groups(yy_groups_size, &groups));
+      lap("group clustering, whole");
       bool bounds = !adaptive;
       if (adaptive) {
         const char *cv = getenv("KMCUDA_AMD_CARRY");
@@ -1677,8 +1722,10 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
           printf("carried bounds: %llu sample passes decided without looking at the sample\n", spared);
         }
         for (auto &s : job.shards) s->eng->carry_on_ = false;
+        lap("Lloyd after the hand-over point");
       }
       if (bounds) RETERR(job.yinyang(tolerance, yy_groups_size, iter, groups));
+      if (bounds) lap("Yinyang");
     }
   }
   RETERR(job.sync_all());
@@ -1687,8 +1734,10 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
     std::lock_guard<std::mutex> lock(g_last_run_mutex);
     g_last_run = job.stats;
   }
+  lap("loop end");
   if (average_distance) RETERR(job.average_distance(average_distance));
   RETERR(job.gather_outputs(centroids, assignments, device_ptrs));
+  lap("outputs");
   DEBUG("return kmcudaSuccess\n");
   return kmcudaSuccess;
 }

@@ -146,8 +146,9 @@ __global__ __launch_bounds__(KNN16_WAVES * 64, (DP > 512 ? 1 : KNN16_BLOCKS_PER_
   };
 #pragma unroll
   for (int e = 0; e < NSET; e++) {
-    qp[e] = p0 + (uint32_t)wave * (32u * NSET) + 32u * e + col;
+    qp[e] = p0 + (uint32_t)wave * (32u * NSET) + 32u * e + col;   // my slot of the block plan ...
     live[e] = qp[e] < own_end;
+    if (a.qperm && live[e]) qp[e] = a.qperm[qp[e] - a.p_base];     // ... and the query of this cluster it stands for
     const uint32_t qq = live[e] ? qp[e] : p0;
     const _Float16 *src = reinterpret_cast<const _Float16 *>(a.xs16) + (size_t)qq * DP + h * NKH;
 #pragma unroll

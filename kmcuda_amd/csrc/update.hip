@@ -92,6 +92,56 @@ hipError_t launch_inverse_assignments(const uint32_t *assignments, uint32_t N, u
   return hipGetLastError();
 }
 
+// ---- k-NN: the order in which a cluster's queries are grouped into blocks -------------------------------------
+// Every query of the f16 search (knn_f16.hip) decides per cluster whether to visit it, but a tile of candidates is
+// scored by a whole wave (64 queries) and staged for a whole block (256) if ANY of them visits: queries taken in
+// sorted-position order -- sample order inside a cluster, i.e. spatially random -- make the union of 64 visit sets a
+// third larger than one set (profiles/r4a_*: 1.98e12 pairs scored for 1.44e12 wanted).  Queries that lie on the same
+// side of their cluster want the same clusters: key = (own cluster, the OTHER cluster whose members can come closest,
+// argmin_c lb[c][q]); sorting the positions by it groups them.  Only the grouping of queries into waves changes:
+// every query still scans all clusters in the reference's order against its own heap.
+__global__ void knn_query_keys_kernel(const float *__restrict__ lb, size_t stride, const uint32_t *__restrict__ offsets,
+                                      uint32_t K, uint32_t p_base, uint32_t p_end, uint32_t *__restrict__ keys,
+                                      uint32_t *__restrict__ vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p_end - p_base) return;
+  const uint32_t p = p_base + i;
+  uint32_t lo = 0, hi = K;   // the cluster of sorted position p: offsets[cls] <= p < offsets[cls + 1]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) / 2;
+    if (offsets[mid] <= p) lo = mid; else hi = mid;
+  }
+  const uint32_t cls = lo;
+  float best = INFINITY;
+  uint32_t arg = 0;
+  for (uint32_t c = 0; c < K; c++) {
+    const float v = lb[(size_t)c * stride + i];   // coalesced across the block's queries
+    if (c != cls && v < best) { best = v; arg = c; }
+  }
+  keys[i] = cls * K + arg;
+  vals[i] = p;
+}
+
+// qperm[i] = the sorted position of the query that slot p_base + i of the block plan handles.  false: not possible
+// here (K * K does not fit the key, or the sort's scratch is too small): the caller keeps the identity order
+bool launch_knn_query_order(const float *lb, size_t stride, const uint32_t *offsets, uint32_t K, uint32_t p_base,
+                            uint32_t p_end, uint32_t *keys_tmp, uint32_t *vals_tmp, uint32_t *keys_sorted,
+                            uint32_t *qperm, void *temp, size_t temp_bytes, hipStream_t st) {
+  if (p_end <= p_base || K > 65535u) return false;
+  const uint32_t n = p_end - p_base;
+  size_t need = 0;
+  if (rocprim::radix_sort_pairs(nullptr, need, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
+                                (uint32_t *)nullptr, (size_t)n, 0u, bits_for((uint64_t)K * K), st) != hipSuccess ||
+      need > temp_bytes)
+    return false;
+  hipLaunchKernelGGL(knn_query_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, lb, stride, offsets, K, p_base,
+                     p_end, keys_tmp, vals_tmp);
+  size_t bytes = temp_bytes;
+  return rocprim::radix_sort_pairs(temp, bytes, (const uint32_t *)keys_tmp, keys_sorted, (const uint32_t *)vals_tmp,
+                                   qperm, (size_t)n, 0u, bits_for((uint64_t)K * K), st) == hipSuccess &&
+         hipGetLastError() == hipSuccess;
+}
+
 // ---- move events --------------------------------------------------------------------------
 // uncompacted form (two slots per row, sentinel keys): the strict-parity update sorts all of them
 __global__ void move_events_kernel(const uint32_t *__restrict__ prev, const uint32_t *__restrict__ cur, uint32_t N,
@@ -546,7 +596,7 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
   hipError_t e = hipSuccess;
   // (the mapping depends on D and the rows' alignment only, never on the path: the two paths stay bit-identical)
   const bool vec4 = (D & 3u) == 0 && (((uintptr_t)samples) & 15u) == 0;
-  const size_t sums_lds = kSumThreads * 4 * sizeof(double) + 2 * kBucketCapMax * sizeof(uint32_t) + 64;
+  const size_t sums_lds = kSumThreads * 4 * sizeof(double) + 2 * kBucketCapMax * sizeof(uint32_t);   // 64 KB
   auto launch_sums = [&](bool direct) {
     const void *fn = direct ? (vec4 ? (const void *)cluster_sums_kernel<true, true> : (const void *)cluster_sums_kernel<true, false>)
                             : (vec4 ? (const void *)cluster_sums_kernel<false, true> : (const void *)cluster_sums_kernel<false, false>);

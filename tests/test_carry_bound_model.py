@@ -1,0 +1,118 @@
+"""Model check (CPU, numpy) of the carried bounds (kmcuda_amd/csrc/lloyd_carry.hip, lloyd_coarse.hpp CARRY != 0,
+centroid_prep_frozen_kernel's drift): the float32 formulas restated exactly as the kernels form them, against
+float64 ground truth.
+
+Claim: a row the skip test keeps has, in exact arithmetic, d(x, c)^2 - d(x, a)^2 > 4 E_ref for EVERY other centroid c
+of the NEW centroid set, E_ref being the bound on the reference's own rounding -- so the reference's
+scan (kmeans.cu:293-364), whose computed score is within 2 E_ref (in squared-distance units) of the exact one, keeps
+a, strictly.  The coarse scores the bounds are read from are modelled adversarially: any value within +-e_c of the
+exact score, including the extremes that make the upper bound as small and the lower bound as large as e_c allows.
+(The GPU tests compare whole loops with and without the bounds; this pins the inequality.)"""
+import numpy
+import pytest
+
+F = numpy.float32
+U = F(5.9604645e-8)
+
+
+def _bounds_from_scores(xn2, v1, v2, e_c, eps, xn, cmaxc):
+    """lloyd_coarse.hpp, finish(), CARRY != 0 (a row the stage decided)."""
+    e = (e_c * F(1.001)).astype(F)
+    d2u = numpy.maximum(xn2 * (F(1.0) + F(2.0) * eps) - F(2.0) * (v1 - e), F(0.0)).astype(F)
+    d2l = (xn2 * (F(1.0) - F(2.0) * eps) - F(2.0) * (v2 + e)).astype(F)
+    geo = (F(2.4e-7) * (xn + cmaxc)).astype(F)
+    ub = (numpy.sqrt(d2u).astype(F) * F(1.000001) + geo).astype(F)
+    lb = numpy.where(d2l > 0, numpy.maximum(numpy.sqrt(numpy.maximum(d2l, 0)).astype(F) * F(0.999999) - geo, F(0.0)), F(0.0)).astype(F)
+    return ub, lb
+
+
+def _drift(cnew_c, cold_c):
+    """centroid_prep_frozen_kernel: from the centred fp32 panels of the two passes."""
+    d = (cnew_c - cold_c).astype(F)
+    dr2 = (d * d).sum(axis=1, dtype=F)
+    n2 = (cnew_c * cnew_c).sum(axis=1, dtype=F)
+    o2 = (cold_c * cold_c).sum(axis=1, dtype=F)
+    return (numpy.sqrt(dr2).astype(F) * F(1.0002) + F(2.4e-7) * (numpy.sqrt(n2) + numpy.sqrt(o2)).astype(F) + F(1e-37)).astype(F)
+
+
+def _skip(ub, lb, drift_a, maxdrift, xn2, mu_norm, cmaxo, tie_slack=F(0.0)):
+    """carry_skip_kernel."""
+    un = ((ub + drift_a) * F(1.0000005)).astype(F)
+    ln = ((lb - maxdrift) * F(0.9999995)).astype(F)
+    xo = ((numpy.sqrt(xn2).astype(F) * F(1.0001) + mu_norm) * F(1.0001)).astype(F)
+    e_ref = (U * (F(12.0) * xo * cmaxo + F(4.0) * cmaxo * cmaxo)).astype(F)
+    keep = (ln > un) & (((ln - un) * (ln + un)).astype(F) > F(4.1) * e_ref + F(2.0) * tie_slack)
+    return keep, e_ref
+
+
+@pytest.mark.parametrize("case", ["blobs", "uniform", "offset", "tight", "tiny-drift", "big-drift"])
+def test_a_spared_row_keeps_its_centroid_in_the_references_arithmetic(case):
+    rs = numpy.random.RandomState(len(case) + 17)
+    n, d, k = 4000, 48, 40
+    if case in ("blobs", "tiny-drift", "big-drift"):
+        cen = rs.rand(k // 2, d) * 6
+        x = cen[rs.randint(0, k // 2, n)] + rs.randn(n, d)
+    elif case == "uniform":
+        x = rs.rand(n, d)
+    elif case == "offset":
+        x = rs.rand(n, d) * 3 + 200.0
+    else:   # near-duplicate centroids: gaps of the order of the roundings
+        base = rs.rand(8, d) * 4
+        x = base[rs.randint(0, 8, n)] + 0.05 * rs.randn(n, d)
+    x = x.astype(F)
+    c_old = x[rs.choice(n, k, replace=False)].astype(F) + (F(1e-3) * rs.randn(k, d)).astype(F)
+    if case == "tight":
+        c_old[1] = c_old[0] + F(1e-5)
+    scale = {"tiny-drift": 1e-6, "big-drift": 0.5}.get(case, 0.02)
+    c_new = (c_old + (scale * rs.randn(k, d)).astype(F)).astype(F)
+    mu = c_old.mean(axis=0, dtype=numpy.float64).astype(F)            # frozen mean
+    eps = F(1.02 * (d + 12.0) * 5.9604644775390625e-8)
+    x64, co64, cn64 = x.astype(numpy.float64), c_old.astype(numpy.float64), c_new.astype(numpy.float64)
+    # --- the pass over the OLD centroids: exact scores of the centred operands, then +- e_c ---
+    xc = (x - mu[None, :]).astype(F)
+    cc_old = (c_old - mu[None, :]).astype(F)
+    cc_new = (c_new - mu[None, :]).astype(F)
+    xn2 = (xc * xc).sum(axis=1, dtype=F)
+    xn = (numpy.sqrt(xn2).astype(F) * F(1.0001)).astype(F)
+    cmaxc = F(numpy.sqrt((cc_old.astype(numpy.float64) ** 2).sum(axis=1).max()) * 1.000001)
+    bmaxc = F(0.5 * (cc_old.astype(numpy.float64) ** 2).sum(axis=1).max())
+    d2_old = ((x64[:, None, :] - co64[None, :, :]) ** 2).sum(axis=2)
+    xm2 = ((x64 - mu.astype(numpy.float64)) ** 2).sum(axis=1)
+    s_exact = 0.5 * (xm2[:, None] - d2_old)                            # s(c) = (||x - mu||^2 - d^2) / 2
+    order = numpy.argsort(-s_exact, axis=1)
+    a = order[:, 0]
+    s1 = s_exact[numpy.arange(n), a]
+    s2 = s_exact[numpy.arange(n), order[:, 1]]
+    # a coarse bound of realistic size (hi.hi products: ~2^-11 relative operand rounding) -- any e_c works as long as
+    # |v - s| <= e_c, which is what the coarse stage guarantees
+    e_c = (F(2.0) * eps * (xn * cmaxc + bmaxc) + F(2.0 ** -10) * xn * cmaxc).astype(F)
+    mu_norm = F(numpy.sqrt((mu.astype(numpy.float64) ** 2).sum()) * 1.00001)
+    cmaxo = F(numpy.sqrt((cn64 ** 2).sum(axis=1).max()) * 1.000001)
+    drift = _drift(cc_new, cc_old)
+    # the true drifts never exceed the modelled ones
+    true_drift = numpy.sqrt(((cn64 - co64) ** 2).sum(axis=1))
+    assert (true_drift <= drift.astype(numpy.float64)).all()
+    maxdrift = drift.max()
+    d2_new = ((x64[:, None, :] - cn64[None, :, :]) ** 2).sum(axis=2)
+    kept_total = 0
+    for sign1, sign2 in ((+1, -1), (-1, +1), (0, 0), (+1, +1), (-1, -1)):
+        v1 = (s1 + sign1 * e_c.astype(numpy.float64) * 0.999).astype(F)
+        v2 = (s2 + sign2 * e_c.astype(numpy.float64) * 0.999).astype(F)
+        ub, lb = _bounds_from_scores(xn2, v1, v2, e_c, eps, xn, cmaxc)
+        # the bounds hold for the OLD centroids
+        d_a = numpy.sqrt(d2_old[numpy.arange(n), a])
+        d_o = numpy.sqrt(numpy.partition(d2_old, 1, axis=1)[:, 1])
+        assert (ub.astype(numpy.float64) >= d_a).all()
+        assert (lb.astype(numpy.float64) <= d_o).all()
+        keep, e_ref = _skip(ub, lb, drift[a], maxdrift, xn2, mu_norm, cmaxo)
+        kept_total += int(keep.sum())
+        # ground truth over the NEW centroids
+        da2 = d2_new[numpy.arange(n), a]
+        others = d2_new.copy()
+        others[numpy.arange(n), a] = numpy.inf
+        gap = others.min(axis=1) - da2
+        assert (gap[keep] > 4.0 * e_ref[keep].astype(numpy.float64)).all()
+    if case in ("blobs", "tiny-drift"):
+        assert kept_total > n          # the test is not vacuous: most rows are spared in most variants
+    if case == "big-drift":
+        assert kept_total < 5 * n
