@@ -165,6 +165,8 @@ def api_bench(args):
     (device_ptrs = 0), init=random, Lloyd (yinyang_t = 0).  value = N x iterations / the library's own
     clock around its iteration loop (kmamd_last_run_stats); the call's wall time is reported beside it."""
     import ctypes
+    if int(os.environ.get("RANK", "0")) != 0:
+        return   # started under torch.distributed.run: ONE process drives every GPU here, the other ranks have nothing to do
     import torch
     from kmcuda_amd import _lib
     L = _lib.lib()
@@ -209,11 +211,17 @@ def api_bench(args):
                                   "K=%d, uniform[0,1) rows on GPU 0 (device_ptrs=0), init=random seed 777, tolerance %g, "
                                   "yinyang_t=0" % (mask, N, D, K, args.tolerance),
                       "samples": N, "features": D, "clusters": K, "parallelism": "rows/%d" % timed[0]["shards"],
+                      # (the same keys as the one-process-per-GPU line: a scaling run can take either loop)
+                      "ranks_seen_by_communicator": max(1, timed[0]["rccl_ranks"]),
+                      "collective": ("ncclAllReduce inside the library (ncclCommInitAll over the device mask), one fused "
+                                     "fp64 buffer per iteration" if timed[0]["rccl_ranks"] else
+                                     ("none" if timed[0]["shards"] == 1 else "sum kernel on one device (KMCUDA_AMD_VIRTUAL_SHARDS)")),
+                      "filter": "f16", "row_cache": True,
                       "rccl_ranks_in_library": timed[0]["rccl_ranks"]},
            "calls": runs,
            "note": "value = N x iterations / seconds the library spent in its iteration loop (after upload and "
-                   "seeding); wall_s is the whole call incl. the peer copies of the row shards, std::random_shuffle "
-                   "over N indices for init=random and the output gather"}
+                   "seeding); wall_s is the whole call incl. the peer copies of the row shards, the reference's shuffle "
+                   "draws for init=random and the output gather"}
     print(json.dumps(out))
 
 

@@ -28,6 +28,14 @@ struct LloydArgs {
 };
 // counters[kStopFlag] != 0: the stop rule fired ON THE DEVICE (apply_delta_kernel with a threshold): the kernels
 // that assign every row return at once, so iterations enqueued past the stop leave the state untouched
+// Kernels with one wave per row (four rows per 256-thread block) stride over the rows from a bounded grid: a grid of
+// N / 4 blocks x 256 threads passes 2^32 threads at N = 2^26 rows, which the runtime does not launch as asked (found by
+// the reference's 167 772 160-row case, test.py:307-326: the k-means++ byte copy was only partly written)
+constexpr uint32_t kWaveRowGridMax = 1u << 20;
+inline uint32_t wave_row_grid(uint32_t n_rows) {
+  const uint32_t g = (n_rows + 3u) / 4u;
+  return g < kWaveRowGridMax ? (g ? g : 1u) : kWaveRowGridMax;
+}
 constexpr uint32_t kStopFlag = 8;
 // counters[kCarryCursor]: length of the carried-bounds pass's row list (zeroed by the preparation kernel);
 // counters[kCarrySkipped], [kCarrySkipped + 1]: one 64-bit total of the rows the bounds have spared since the engine was made

@@ -238,6 +238,65 @@ struct Shard {
   }
 };
 
+// glibc's rand() (random_r, TYPE_3: 31 words, r[k] = r[k - 31] + r[k - 3], output r[k] >> 1) restated, for the one place
+// that draws N numbers (init = "random").  attach(seed): called right after srand(seed); checks the restatement against
+// the library's own first draws (false: not this generator -- the caller uses rand()), then moves the library onto a
+// state buffer of ours (initstate), which detach() overwrites with the restated generator's state (setstate): the
+// library's rand() goes on exactly where the same number of rand() calls would have left it.
+class GlibcRand {
+ public:
+  bool attach(uint32_t seed) {
+    seed_ = seed;
+    reseed();
+    uint32_t mine[4];
+    for (uint32_t &v : mine) v = next();
+    bool same = true;
+    for (uint32_t v : mine) same = same && (uint32_t)rand() == v;
+    srand(seed);   // back to the start for either path
+    if (!same) return false;
+    reseed();
+    return true;
+  }
+  uint32_t next() {
+    s_[f_] += s_[r_];
+    const uint32_t out = s_[f_] >> 1;
+    f_ = f_ + 1 == 31 ? 0 : f_ + 1;
+    r_ = r_ + 1 == 31 ? 0 : r_ + 1;
+    return out;
+  }
+  void detach() {
+    // (two buffers in turn: setstate() first stores the CURRENT buffer's position word, which must not be the one
+    //  being installed; the library keeps pointing at the installed one: process lifetime)
+    static int32_t lib_state[2][32];
+    static int turn = 0;
+    static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    int32_t *st = lib_state[turn];
+    turn ^= 1;
+    for (int i = 0; i < 31; i++) st[1 + i] = (int32_t)s_[i];
+    st[0] = (int32_t)(r_ * 5 + 3);   // glibc: rear * MAX_TYPES + TYPE_3
+    (void)setstate(reinterpret_cast<char *>(st));
+  }
+
+ private:
+  void reseed() {   // srandom_r: 16807 LCG fills the table, 310 outputs are discarded
+    int32_t word = seed_ ? (int32_t)seed_ : 1;
+    s_[0] = (uint32_t)word;
+    for (int i = 1; i < 31; i++) {
+      const long hi = word / 127773, lo = word % 127773;
+      long w = 16807 * lo - 2836 * hi;
+      if (w < 0) w += 2147483647;
+      word = (int32_t)w;
+      s_[i] = (uint32_t)word;
+    }
+    f_ = 3;
+    r_ = 0;
+    for (int i = 0; i < 310; i++) (void)next();
+  }
+  uint32_t s_[31], seed_ = 0;
+  int f_ = 3, r_ = 0;
+};
+
 // what the last kmeans_cuda() call did (kmamd_last_run_stats): iterations of the Lloyd / Yinyang loops and
 // the wall time spent in them (everything after seeding), for drivers that time the drop-in entry point
 struct RunStats { uint32_t iterations = 0; double loop_seconds = 0, setup_seconds = 0; uint32_t shards = 0, rccl = 0; };
@@ -477,10 +536,30 @@ class Job {
       }
       case kmcudaInitMethodRandom: {
         INFO("randomly picking initial centroids...\n");
-        // libstdc++'s std::random_shuffle over rand() (kmcuda.cc:245-253): the first K entries
-        std::vector<uint32_t> chosen(N);
-        for (uint32_t s = 0; s < N; s++) chosen[s] = s;
-        for (uint32_t i = 1; i < N; i++) std::swap(chosen[i], chosen[rand() % (i + 1)]);
+        // The reference shuffles ALL N indices with libstdc++'s std::random_shuffle over rand() and takes the first K
+        // (kmcuda.cc:245-253): for i = 1 .. N-1: swap(a[i], a[rand() % (i + 1)]).  Position i is untouched before its
+        // own step and a value that leaves the first K never returns, so the first K entries follow from a K-entry
+        // array: steps i < K swap inside it, a step i >= K whose draw j falls below K puts i at j.  Same draws, same
+        // rows, no N-entry array; with glibc's generator restated (GlibcRand: a rand() call is 10-20 ns behind its
+        // lock -- 45 ms of a 4M-row call, 90 ms at 8M rows) the N - 1 draws take a few ms, and rand()'s own state is
+        // set to what N - 1 calls would have left.
+        std::vector<uint32_t> chosen(K);
+        for (uint32_t c = 0; c < K; c++) chosen[c] = c;
+        GlibcRand fast;
+        if (fast.attach(seed)) {
+          for (uint32_t i = 1; i < N && i < K; i++) std::swap(chosen[i], chosen[fast.next() % (i + 1)]);
+          for (uint32_t i = K; i < N; i++) {
+            const uint32_t j = fast.next() % (i + 1);
+            if (j < K) chosen[j] = i;
+          }
+          fast.detach();
+        } else {   // another C library: its rand(), call by call
+          for (uint32_t i = 1; i < N && i < K; i++) std::swap(chosen[i], chosen[rand() % (i + 1)]);
+          for (uint32_t i = K; i < N; i++) {
+            const uint32_t j = rand() % (i + 1);
+            if (j < K) chosen[j] = i;
+          }
+        }
         DEBUG("shuffle complete, copying to device(s)...\n");
         for (uint32_t c = 0; c < K; c++) RETERR(copy_sample_to_centroid(chosen[c], c));
         return sync_all();

@@ -45,25 +45,25 @@ __global__ __launch_bounds__(256) void knn_gather_kernel(const float *__restrict
                                                          uint32_t DP, const uint32_t *__restrict__ inv,
                                                          float *__restrict__ xs, float *__restrict__ n2s,
                                                          uint32_t *__restrict__ stats) {
-  const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63;
-  if (p >= N) return;
-  const float *src = samples + (size_t)inv[p] * D;
-  float *dst = xs + (size_t)p * DP;
-  float a = 0.f;
-  for (uint32_t f = lane; f < DP; f += 64) {
-    const float v = f < D ? src[f] : 0.f;
-    dst[f] = v;
-    a = fmaf(v, v, a);
-  }
+  for (uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6); p < N; p += gridDim.x * 4) {   // (kernels.hpp: wave_row_grid)
+    const float *src = samples + (size_t)inv[p] * D;
+    float *dst = xs + (size_t)p * DP;
+    float a = 0.f;
+    for (uint32_t f = lane; f < DP; f += 64) {
+      const float v = f < D ? src[f] : 0.f;
+      dst[f] = v;
+      a = fmaf(v, v, a);
+    }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
-  if (lane == 0) {
-    n2s[p] = a;
-    // finite, non-negative: bits order like values.  Look before the atomic: N of them on one address serialise
-    // in L2 (8M rows: 90 ms for a kernel that moves 16 GB), and the running maximum rarely moves
-    if ((a - a) == 0.f && __float_as_uint(a) > *reinterpret_cast<volatile uint32_t *>(&stats[0]))
-      atomicMax(&stats[0], __float_as_uint(a));
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+    if (lane == 0) {
+      n2s[p] = a;
+      // finite, non-negative: bits order like values.  Look before the atomic: N of them on one address serialise
+      // in L2 (8M rows: 90 ms for a kernel that moves 16 GB), and the running maximum rarely moves
+      if ((a - a) == 0.f && __float_as_uint(a) > *reinterpret_cast<volatile uint32_t *>(&stats[0]))
+        atomicMax(&stats[0], __float_as_uint(a));
+    }
   }
 }
 
@@ -525,7 +525,7 @@ hipError_t launch_knn_gather(const float *samples, uint32_t N, uint32_t D, uint3
                              float *xs, float *n2s, uint32_t *stats, hipStream_t st) {
   hipError_t e = hipMemsetAsync(stats, 0, sizeof(uint32_t), st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(knn_gather_kernel, dim3((N + 3) / 4), dim3(256), 0, st, samples, N, D, DP, inv, xs, n2s, stats);
+  hipLaunchKernelGGL(knn_gather_kernel, dim3(wave_row_grid(N)), dim3(256), 0, st, samples, N, D, DP, inv, xs, n2s, stats);
   return hipGetLastError();
 }
 

@@ -54,32 +54,32 @@ __global__ __launch_bounds__(256) void knn_split_kernel(const float *__restrict_
                                                         _Float16 *__restrict__ xs16, float *__restrict__ n2c,
                                                         float *__restrict__ mux, float *__restrict__ kbias,
                                                         uint32_t *__restrict__ stats) {
-  const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63;
-  if (p >= N) return;
-  const float *src = xs + (size_t)p * DP;
-  _Float16 *dst = xs16 + (size_t)p * DP;
-  float a = 0.f, b = 0.f;
-  for (uint32_t f = lane; f < DP; f += 64) {
-    const float m = f < D ? mu[f] : 0.f;
-    const float v = f < D ? src[f] - m : 0.f;
-    dst[f] = (_Float16)v;
-    a = fmaf(v, v, a);
-    b = fmaf(m, v, b);
-  }
+  for (uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6); p < N; p += gridDim.x * 4) {   // (kernels.hpp: wave_row_grid)
+    const float *src = xs + (size_t)p * DP;
+    _Float16 *dst = xs16 + (size_t)p * DP;
+    float a = 0.f, b = 0.f;
+    for (uint32_t f = lane; f < DP; f += 64) {
+      const float m = f < D ? mu[f] : 0.f;
+      const float v = f < D ? src[f] - m : 0.f;
+      dst[f] = (_Float16)v;
+      a = fmaf(v, v, a);
+      b = fmaf(m, v, b);
+    }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    a += __shfl_xor(a, off);
-    b += __shfl_xor(b, off);
-  }
-  if (lane == 0) {
-    n2c[p] = a;
-    mux[p] = b;
-    kbias[p] = METRIC == 0 ? -0.5f * a : b;   // what a candidate adds to the matrix-core score
-    // finite, non-negative: bits order like values.  Look before the atomic: N of them on one address serialise
-    // in L2 (8M rows: 90 ms for a kernel that moves 16 GB), and the running maximum rarely moves
-    if ((a - a) == 0.f && __float_as_uint(a) > *reinterpret_cast<volatile uint32_t *>(&stats[0]))
-      atomicMax(&stats[0], __float_as_uint(a));
+    for (int off = 32; off > 0; off >>= 1) {
+      a += __shfl_xor(a, off);
+      b += __shfl_xor(b, off);
+    }
+    if (lane == 0) {
+      n2c[p] = a;
+      mux[p] = b;
+      kbias[p] = METRIC == 0 ? -0.5f * a : b;   // what a candidate adds to the matrix-core score
+      // finite, non-negative: bits order like values.  Look before the atomic: N of them on one address serialise
+      // in L2 (8M rows: 90 ms for a kernel that moves 16 GB), and the running maximum rarely moves
+      if ((a - a) == 0.f && __float_as_uint(a) > *reinterpret_cast<volatile uint32_t *>(&stats[0]))
+        atomicMax(&stats[0], __float_as_uint(a));
+    }
   }
   (void)METRIC;
 }
@@ -485,10 +485,10 @@ hipError_t launch_knn_split(int metric, const float *xs, uint32_t N, uint32_t D,
   e = hipMemsetAsync(kbias + N, 0, (size_t)KNN16_PAD_ROWS * sizeof(float), st);
   if (e != hipSuccess) return e;
   if (metric == 0)
-    hipLaunchKernelGGL((knn_split_kernel<0>), dim3((N + 3) / 4), dim3(256), 0, st, xs, N, D, DP, mu,
+    hipLaunchKernelGGL((knn_split_kernel<0>), dim3(wave_row_grid(N)), dim3(256), 0, st, xs, N, D, DP, mu,
                        reinterpret_cast<_Float16 *>(xs16), n2c, mux, kbias, stats);
   else
-    hipLaunchKernelGGL((knn_split_kernel<1>), dim3((N + 3) / 4), dim3(256), 0, st, xs, N, D, DP, mu,
+    hipLaunchKernelGGL((knn_split_kernel<1>), dim3(wave_row_grid(N)), dim3(256), 0, st, xs, N, D, DP, mu,
                        reinterpret_cast<_Float16 *>(xs16), n2c, mux, kbias, stats);
   return hipGetLastError();
 }

@@ -33,30 +33,30 @@ __global__ __launch_bounds__(256) void row_halves_kernel(const void *__restrict_
                                                          uint32_t DG, const float *__restrict__ mu,
                                                          _Float16 *__restrict__ xg, float4 *__restrict__ meta) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t r = blockIdx.x * 4 + wave;
-  if (r >= N) return;
-  float n2 = 0.f, d2 = 0.f, o2 = 0.f, x0 = 0.f;
-  for (uint32_t f = lane; f < DG; f += 64) {
-    float x = 0.f;
-    if (f < D) x = HALF_ROWS ? (float)reinterpret_cast<const _Float16 *>(rows)[(size_t)r * D + f]
-                             : reinterpret_cast<const float *>(rows)[(size_t)r * D + f];
-    const float xc = f < D ? x - mu[f] : 0.f;
-    const _Float16 hi = (_Float16)xc;
-    const float res = xc - (float)hi;
-    xg[(size_t)r * DG + f] = hi;
-    n2 = fmaf(xc, xc, n2);
-    d2 = fmaf(res, res, d2);
-    o2 = fmaf(x, x, o2);
-    if (f == 0) x0 = x;
-  }
+  for (uint32_t r = blockIdx.x * 4 + wave; r < N; r += gridDim.x * 4) {   // (kernels.hpp: wave_row_grid)
+    float n2 = 0.f, d2 = 0.f, o2 = 0.f, x0 = 0.f;
+    for (uint32_t f = lane; f < DG; f += 64) {
+      float x = 0.f;
+      if (f < D) x = HALF_ROWS ? (float)reinterpret_cast<const _Float16 *>(rows)[(size_t)r * D + f]
+                               : reinterpret_cast<const float *>(rows)[(size_t)r * D + f];
+      const float xc = f < D ? x - mu[f] : 0.f;
+      const _Float16 hi = (_Float16)xc;
+      const float res = xc - (float)hi;
+      xg[(size_t)r * DG + f] = hi;
+      n2 = fmaf(xc, xc, n2);
+      d2 = fmaf(res, res, d2);
+      o2 = fmaf(x, x, o2);
+      if (f == 0) x0 = x;
+    }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    n2 += __shfl_xor(n2, off);
-    d2 += __shfl_xor(d2, off);
-    o2 += __shfl_xor(o2, off);
+    for (int off = 32; off > 0; off >>= 1) {
+      n2 += __shfl_xor(n2, off);
+      d2 += __shfl_xor(d2, off);
+      o2 += __shfl_xor(o2, off);
+    }
+    x0 = __shfl(x0, 0);
+    if (lane == 0) meta[r] = make_float4(n2, d2, x0, o2);
   }
-  x0 = __shfl(x0, 0);
-  if (lane == 0) meta[r] = make_float4(n2, d2, x0, o2);
 }
 
 // One wave per row, 4 rows per wave, 16 rows per block.  scores: rows [row0, row0 + nrows) x ld floats.
@@ -341,10 +341,10 @@ hipError_t launch_row_halves(const void *rows, bool half_rows, uint32_t N, uint3
                              void *xg, float *meta, hipStream_t st) {
   if (N == 0) return hipSuccess;
   if (half_rows)
-    hipLaunchKernelGGL((row_halves_kernel<true>), dim3((N + 3) / 4), dim3(256), 0, st, rows, N, D, DG, mu,
+    hipLaunchKernelGGL((row_halves_kernel<true>), dim3(wave_row_grid(N)), dim3(256), 0, st, rows, N, D, DG, mu,
                        reinterpret_cast<_Float16 *>(xg), reinterpret_cast<float4 *>(meta));
   else
-    hipLaunchKernelGGL((row_halves_kernel<false>), dim3((N + 3) / 4), dim3(256), 0, st, rows, N, D, DG, mu,
+    hipLaunchKernelGGL((row_halves_kernel<false>), dim3(wave_row_grid(N)), dim3(256), 0, st, rows, N, D, DG, mu,
                        reinterpret_cast<_Float16 *>(xg), reinterpret_cast<float4 *>(meta));
   return hipGetLastError();
 }

@@ -318,44 +318,44 @@ __global__ __launch_bounds__(256) void kmpp_mean_kernel(const double *__restrict
 __global__ __launch_bounds__(256) void kmpp_cache_kernel(const float *__restrict__ samples, uint32_t N, uint32_t D,
                                                          uint32_t DP, const float *__restrict__ mu,
                                                          signed char *__restrict__ xs8, f32x4_kp *__restrict__ meta) {
-  const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63;
-  if (p >= N) return;
-  const float *src = samples + (size_t)p * D;
-  signed char *dst = xs8 + (size_t)p * DP;
-  float n2 = 0.f, mx = 0.f, mb = 0.f;
-  for (uint32_t f = lane; f < D; f += 64) {
-    const float m = mu[f], v = src[f] - m;
-    n2 = fmaf(v, v, n2);
-    mb = fmaf(m, v, mb);
-    mx = fmaxf(mx, fabsf(v));   // (fmaxf drops a NaN operand: a NaN row shows in n2)
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    n2 += __shfl_xor(n2, off);
-    mb += __shfl_xor(mb, off);
-    mx = fmaxf(mx, __shfl_xor(mx, off));
-  }
-  const bool fin = (n2 - n2) == 0.f;
-  const float a = fin ? mx / 127.0f : 0.f, inv = (fin && a > 0.f) ? 1.0f / a : 0.f;
-  float r2 = 0.f;
-  for (uint32_t f = lane; f < DP; f += 64) {
-    float q = 0.f;
-    if (f < D && fin) {
-      const float v = src[f] - mu[f];
-      q = fminf(fmaxf(rintf(v * inv), -127.f), 127.f);
-      const float r = v - a * q;
-      r2 = fmaf(r, r, r2);
+  for (uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6); p < N; p += gridDim.x * 4) {   // (kernels.hpp: wave_row_grid)
+    const float *src = samples + (size_t)p * D;
+    signed char *dst = xs8 + (size_t)p * DP;
+    float n2 = 0.f, mx = 0.f, mb = 0.f;
+    for (uint32_t f = lane; f < D; f += 64) {
+      const float m = mu[f], v = src[f] - m;
+      n2 = fmaf(v, v, n2);
+      mb = fmaf(m, v, mb);
+      mx = fmaxf(mx, fabsf(v));   // (fmaxf drops a NaN operand: a NaN row shows in n2)
     }
-    dst[f] = (signed char)(int)q;
-  }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) r2 += __shfl_xor(r2, off);
-  if (lane == 0) {
-    // the residual's norm from above: its fp32 evaluation is off by a few ulps of ||x'|| at most
-    const float rn = (sqrtf(r2) + 1e-6f * sqrtf(n2)) * 1.001f;
-    // a row that is not finite keeps NaN in its record: the filter never drops it
-    meta[p] = f32x4_kp{fin ? a : __builtin_nanf(""), rn, n2, mb};
+    for (int off = 32; off > 0; off >>= 1) {
+      n2 += __shfl_xor(n2, off);
+      mb += __shfl_xor(mb, off);
+      mx = fmaxf(mx, __shfl_xor(mx, off));
+    }
+    const bool fin = (n2 - n2) == 0.f;
+    const float a = fin ? mx / 127.0f : 0.f, inv = (fin && a > 0.f) ? 1.0f / a : 0.f;
+    float r2 = 0.f;
+    for (uint32_t f = lane; f < DP; f += 64) {
+      float q = 0.f;
+      if (f < D && fin) {
+        const float v = src[f] - mu[f];
+        q = fminf(fmaxf(rintf(v * inv), -127.f), 127.f);
+        const float r = v - a * q;
+        r2 = fmaf(r, r, r2);
+      }
+      dst[f] = (signed char)(int)q;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) r2 += __shfl_xor(r2, off);
+    if (lane == 0) {
+      // the residual's norm from above: its fp32 evaluation is off by a few ulps of ||x'|| at most
+      const float rn = (sqrtf(r2) + 1e-6f * sqrtf(n2)) * 1.001f;
+      // a row that is not finite keeps NaN in its record: the filter never drops it
+      meta[p] = f32x4_kp{fin ? a : __builtin_nanf(""), rn, n2, mb};
+    }
   }
 }
 
@@ -767,7 +767,7 @@ hipError_t launch_kmpp_cache(const float *samples, uint32_t N, uint32_t D, uint3
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kmpp_colsum_kernel, dim3(64), dim3(256), 0, st, samples, rows, D, part);
   hipLaunchKernelGGL(kmpp_mean_kernel, dim3((DP + 255) / 256), dim3(256), 0, st, part, 64u, rows, D, DP, mu);
-  hipLaunchKernelGGL(kmpp_cache_kernel, dim3((N + 3) / 4), dim3(256), 0, st, samples, N, D, DP, mu,
+  hipLaunchKernelGGL(kmpp_cache_kernel, dim3(wave_row_grid(N)), dim3(256), 0, st, samples, N, D, DP, mu,
                      reinterpret_cast<signed char *>(xs8), reinterpret_cast<f32x4_kp *>(meta));
   return hipGetLastError();
 }
