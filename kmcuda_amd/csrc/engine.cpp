@@ -51,8 +51,36 @@ struct Rocblas {
   }
 };
 Rocblas g_rocblas;
+std::mutex g_stream_pool_mutex;
+std::vector<std::vector<hipStream_t>> g_stream_pool;   // [device] -> idle streams
 constexpr int kRbOpNone = 111, kRbOpTrans = 112, kRbF16 = 150, kRbF32 = 151;   // rocblas-types.h
 }  // namespace
+
+hipStream_t pooled_stream_acquire(int device) {
+  {
+    std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
+    if ((size_t)device < g_stream_pool.size() && !g_stream_pool[device].empty()) {
+      hipStream_t s = g_stream_pool[device].back();
+      g_stream_pool[device].pop_back();
+      return s;
+    }
+  }
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  return s;
+}
+void pooled_stream_release(int device, hipStream_t s) {
+  if (!s) return;
+  if (hipStreamSynchronize(s) != hipSuccess) {   // (a stream in an error state is not worth keeping)
+    (void)hipGetLastError();
+    (void)hipStreamDestroy(s);
+    return;
+  }
+  std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
+  if (g_stream_pool.size() <= (size_t)device) g_stream_pool.resize(device + 1);
+  if (g_stream_pool[device].size() < 32) g_stream_pool[device].push_back(s);
+  else (void)hipStreamDestroy(s);
+}
 
 void *Engine::alloc_bytes(size_t bytes) {
   const size_t rounded = (bytes + 255u) & ~(size_t)255u;
@@ -98,16 +126,17 @@ Engine::~Engine() {
   for (auto &s : spans_) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (void *p : owned_) (void)hipFree(p);
   if (pinned_) (void)hipHostFree(pinned_);
-  if (side_stream_) {
-    (void)hipStreamDestroy(side_stream_);
-    (void)hipEventDestroy(ev_fork_);
-    (void)hipEventDestroy(ev_join_);
-  }
+  if (side_stream_ && own_side_stream_) pooled_stream_release(device_, side_stream_);
+  if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+  if (ev_join_) (void)hipEventDestroy(ev_join_);
   for (hipEvent_t e : ev_report_)
     if (e) (void)hipEventDestroy(e);
   if (rb_handle_ && g_rocblas.destroy_handle) (void)g_rocblas.destroy_handle(rb_handle_);
   if (ev_rows_) (void)hipEventDestroy(ev_rows_);
-  if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+  if (own_stream_ && stream_) {
+    if (blocking_stream_) (void)hipStreamDestroy(stream_);
+    else pooled_stream_release(device_, stream_);
+  }
 }
 
 int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric, int fp16x2, hipStream_t stream) {
@@ -133,7 +162,8 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   } else if (stream) {
     stream_ = stream;
   } else {
-    KMX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), kRuntimeError);
+    stream_ = pooled_stream_acquire(device);
+    if (!stream_) return kRuntimeError;
     own_stream_ = true;
   }
   N_ = n_rows; D_ = D; K_ = K; metric_ = metric; fp16x2_ = fp16x2;
@@ -459,7 +489,11 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   if (build_cache) mu_frozen_ = false;  // take the mean of THESE centroids
   if (!side_stream_) {
     // (non-blocking even beside a blocking main stream: fork / join events order it completely)
-    KMX_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking), kRuntimeError);
+    side_stream_ = pooled_stream_acquire(device_);
+    if (!side_stream_) return kRuntimeError;
+    own_side_stream_ = true;
+  }
+  if (!ev_fork_) {   // (a borrowed side stream -- the nested group-clustering job's -- comes without events)
     KMX_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming), kRuntimeError);
     KMX_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming), kRuntimeError);
   }

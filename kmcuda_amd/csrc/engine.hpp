@@ -28,6 +28,12 @@ enum Result {  // == KMCUDAResult (include/kmcuda.h)
 
 extern int g_verbosity;
 
+// Non-blocking streams of the library's own making are kept for the process: creating one and launching on it for
+// the first time costs ~5 ms (kmeans_cuda() on 100 000 x 256 rows is 13 ms of work), so an engine takes an idle
+// one from a per-device pool and hands it back, drained, when it goes.
+hipStream_t pooled_stream_acquire(int device);
+void pooled_stream_release(int device, hipStream_t s);
+
 class Engine {
  public:
   Engine() = default;
@@ -90,6 +96,7 @@ class Engine {
   hipStream_t stream_ = nullptr;
   bool own_stream_ = false, blocking_stream_ = false;
   hipStream_t side_stream_ = nullptr;   // the full-scan refine kernel beside the pair kernel
+  bool own_side_stream_ = false;
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   hipEvent_t ev_rows_ = nullptr;        // csqr / ct ready on the side stream (steady-state preparation)
   uint32_t N_ = 0, D_ = 0, K_ = 0, K_pad_ = 0, Kt_ = 0, DP_ = 0;

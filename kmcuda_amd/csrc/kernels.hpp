@@ -170,6 +170,7 @@ hipError_t launch_apply_delta(int metric, const double *delta, const int32_t *dc
 // all-reduce: KMCUDA_AMD_VIRTUAL_SHARDS)
 hipError_t launch_sum_buffers(double *const *bufs_dev, uint32_t nbuf, size_t len, hipStream_t st);
 
+hipError_t launch_gather_rows(const float *samples, const uint32_t *idx, uint32_t K, uint32_t D, float *out, hipStream_t st);
 // seeding.hip (reference: kmeans.cu:42-67 kmeans_plus_plus, transpose.cu:6-14 copy_sample_t,
 // kmeans.cu:674-691 kmeans_calc_average_distance)
 hipError_t launch_kmpp_step(int metric, const float *samples, uint32_t N, uint32_t D, const float *centroid,

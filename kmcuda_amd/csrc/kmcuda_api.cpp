@@ -330,8 +330,10 @@ class Job {
     if (ev_summed) (void)hipEventDestroy(ev_summed);
   }
 
+  // on_stream: the (single) shard's engine works on this existing stream instead of creating one -- the nested job
+  // that clusters the centroids into groups rides on its parent's: a stream's first launches cost milliseconds
   int setup(const std::vector<int> &devs, int nvirtual, uint32_t N_, uint32_t D_, uint32_t K_, int metric_,
-            int verbosity_, const float *samples, int32_t device_ptrs) {
+            int verbosity_, const float *samples, int32_t device_ptrs, hipStream_t on_stream = nullptr) {
     N = N_; D = D_; K = K_; metric = metric_; verbosity = verbosity_;
     std::vector<int> shard_devs = devs;
     if (nvirtual > 1 && devs.size() == 1) shard_devs.assign(nvirtual, devs[0]);  // test hook
@@ -343,7 +345,7 @@ class Job {
       sh->length = plan[i].second;
       if (hipSetDevice(sh->dev) != hipSuccess) return kmcudaNoSuchDevice;
       sh->eng = std::make_unique<Engine>();
-      int rc = sh->eng->init(sh->dev, sh->length, D, K, metric, 0, nullptr);
+      int rc = sh->eng->init(sh->dev, sh->length, D, K, metric, 0, shard_devs.size() == 1 ? on_stream : nullptr);
       if (rc) return rc;
       sh->eng->strict_h2_ = strict_h2;
       const float *src = samples + (size_t)sh->offset * D;
@@ -561,6 +563,15 @@ class Job {
           }
         }
         DEBUG("shuffle complete, copying to device(s)...\n");
+        if (shards.size() == 1) {   // one gather launch (the index list rides in the dists buffer: N >= K floats)
+          Shard &s = *shards[0];
+          (void)hipSetDevice(s.dev);
+          uint32_t *idx = reinterpret_cast<uint32_t *>(s.dists);
+          if (hipMemcpyAsync(idx, chosen.data(), K * sizeof(uint32_t), hipMemcpyHostToDevice, s.eng->stream_) != hipSuccess)
+            return kmcudaMemoryCopyError;
+          if (launch_gather_rows(s.samples, idx, K, D, s.centroids, s.eng->stream_) != hipSuccess) return kmcudaRuntimeError;
+          return sync_all();   // (chosen[] must outlive the copy)
+        }
         for (uint32_t c = 0; c < K; c++) RETERR(copy_sample_to_centroid(chosen[c], c));
         return sync_all();
       }
@@ -954,12 +965,21 @@ class Job {
       DEBUG("local filter: %u exact distances queued, %u wave flushes\n", pair_rows, scan_rows);
     if (passed_total) *passed_total = overall_passed;
     if (print) INFO("iteration %d: %u reassignments\n", iter, overall_changed);
+    stamp(iter);
     if (overall_changed <= tolerance * N) return 1;  // counters are NOT zeroed on stop (kmeans.cu:707-709)
     for (auto &s : shards)
       if (s->eng->counters_reset(0) != 0) return -kmcudaRuntimeError;
     return 0;
   }
 
+  // KMCUDA_AMD_TIMING: when the host learned an iteration's outcome (ms since the job was made; a measurement aid)
+  const bool timing_ = getenv("KMCUDA_AMD_TIMING") != nullptr;
+  const std::chrono::steady_clock::time_point born_ = std::chrono::steady_clock::now();
+  void stamp(int iter) const {
+    if (timing_)
+      fprintf(stderr, "[timing]   iteration %d judged at %.3f ms\n", iter,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - born_).count());
+  }
   bool exact_update = false;  // KMCUDA_AMD_EXACT_UPDATE=1: the reference's serial Kahan chain (single shard)
 
   // the update in three stream-ordered phases (reference: kmeans_adjust launch + peer exchange,
@@ -1124,6 +1144,7 @@ class Job {
     }
     DEBUG("filter: %u rows settled by two exact chains, %u by a full exact scan\n", t[3], t[1]);
     INFO("iteration %d: %u reassignments\n", iter, t[0]);
+    stamp(iter);
     if (changed) *changed = t[0];
     stats.iterations++;
     return t[4] ? 1 : 0;
@@ -1147,7 +1168,8 @@ class Job {
     Job gjob;
     gjob.strict_h2 = strict_h2;   // (before setup: the engines take the flag there)
     std::vector<int> one{first.dev};
-    RETERR(gjob.setup(one, 0, K, D, G, metric, verbosity, first.centroids, first.dev));  // fp32 replica in place
+    RETERR(gjob.setup(one, 0, K, D, G, metric, verbosity, first.centroids, first.dev, first.eng->stream_));  // fp32 replica in place
+    gjob.shards[0]->eng->side_stream_ = first.eng->side_stream_;   // (borrowed with the main one; may be null)
     lap("setup");
     gjob.exact_update = exact_update;
     gjob.fp16 = fp16;  // centroids_yy is half2 in the reference too (kmeans.cu:1084-1091)
@@ -1162,6 +1184,24 @@ class Job {
     if (hipMemcpy(groups->data(), gjob.shards[0]->assignments, K * sizeof(uint32_t), hipMemcpyDeviceToHost) !=
         hipSuccess)
       return kmcudaMemoryCopyError;
+    return 0;
+  }
+
+  // rand() as cluster_groups() leaves it: srand(0) (kmeans.cu:1081-1084 passes seed 0 to the nested k-means++), the
+  // draws for its first seed -- a centroid whose first feature is not NaN, kmcuda.cc:265-270 -- and one draw per further
+  // seed (kmcuda.cc:300)
+  int replay_group_seeding_draws(uint32_t G) {
+    Shard &first = *shards[0];
+    srand(0);
+    float smoke = NAN;
+    while (smoke != smoke) {
+      const uint32_t idx = rand() % K;
+      (void)hipSetDevice(first.dev);
+      RETERR(first.eng->sync());
+      if (hipMemcpy(&smoke, first.centroids + (size_t)idx * D, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+        return kmcudaMemoryCopyError;
+    }
+    for (uint32_t t = 1; t < G; t++) (void)rand();
     return 0;
   }
 
@@ -1317,7 +1357,7 @@ struct KnnShard {
   ~KnnShard() {
     (void)hipSetDevice(dev);
     for (void *p : owned) (void)hipFree(p);
-    if (stream) (void)hipStreamDestroy(stream);
+    pooled_stream_release(dev, stream);
   }
   template <typename T>
   int alloc(T **p, size_t count) {
@@ -1448,7 +1488,7 @@ class KnnJob {
       auto sh = std::make_unique<KnnShard>();
       sh->dev = dev;
       if (hipSetDevice(dev) != hipSuccess) return kmcudaNoSuchDevice;
-      if (hipStreamCreateWithFlags(&sh->stream, hipStreamNonBlocking) != hipSuccess) return kmcudaRuntimeError;
+      if (!(sh->stream = pooled_stream_acquire(dev))) return kmcudaRuntimeError;
       if (fp16) {  // half buffers -> fp32 working copies (fp32 arithmetic on the half values)
         RETERR(stage_in_half(*sh, samples, (size_t)N * D, device_ptrs, &sh->samples));
         RETERR(stage_in_half(*sh, centroids, (size_t)K * D, device_ptrs, &sh->centroids));
@@ -1779,7 +1819,15 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
       // the reference's hand-over point: the K centroids are clustered into groups here (its progress lines are
       // part of what a caller sees, its srand(0) of what a caller's rand() sees) -- whichever schedule follows
       std::vector<uint32_t> groups;
-      RETERR(job.cluster_groups(yy_groups_size, &groups));
+      // The groups are only ever USED by the reference's bounds (KMCUDA_AMD_YY=reference / the forced switch).  What a
+      // caller can observe of their clustering besides -- its progress lines, and the C library's rand() state after
+      // its srand(0) and draws -- is kept either way: a silent call (verbosity 0) that will not use the groups only
+      // replays the draws (13 ms -> 0.05 ms at K = 1024, G = 102).
+      if (!adaptive || rule.force >= 0 || verbosity > 0) {
+        RETERR(job.cluster_groups(yy_groups_size, &groups));
+      } else {
+        RETERR(job.replay_group_seeding_draws(yy_groups_size));
+      }
       lap("group clustering, whole");
       bool bounds = !adaptive;
       if (adaptive) {

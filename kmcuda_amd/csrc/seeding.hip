@@ -501,6 +501,21 @@ __global__ __launch_bounds__(256) void kmpp_filter_kernel(const signed char *__r
   flush();
 }
 
+// out[c][:] = samples[idx[c]][:] for c < K: the K seed rows of init = "random" in one launch (1024 separate
+// device-to-device copies were 2 ms of a 20-ms call)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ samples, const uint32_t *__restrict__ idx,
+                                                          uint32_t K, uint32_t D, float *__restrict__ out) {
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6); c < K; c += gridDim.x * 4) {
+    const float *src = samples + (size_t)idx[c] * D;
+    for (uint32_t f = lane; f < D; f += 64) out[(size_t)c * D + f] = src[f];
+  }
+}
+hipError_t launch_gather_rows(const float *samples, const uint32_t *idx, uint32_t K, uint32_t D, float *out, hipStream_t st) {
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(wave_row_grid(K)), dim3(256), 0, st, samples, idx, K, D, out);
+  return hipGetLastError();
+}
+
 struct KmppTotals {   // pinned host memory
   double sum_g, sum_d;
   uint32_t emin, emax, bad, chosen;

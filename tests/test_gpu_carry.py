@@ -138,3 +138,33 @@ def test_kmeans_cuda_default_schedule_carries_and_equals_the_plain_schedule(monk
     assert "carrying per-sample distance bounds" in outs[0][3]
     spared = [l for l in outs[0][3].split("\n") if l.startswith("carried bounds:")]
     assert spared and int(spared[0].split()[2]) > len(x), spared
+
+
+def test_random_init_and_silent_group_clustering_leave_rand_where_the_reference_does():
+    """init="random" draws the reference's N - 1 shuffle numbers from a restatement of glibc's generator and then sets
+    rand()'s state (kmcuda_api.cpp: GlibcRand); a silent yinyang_t > 0 call on the default schedule replays the group
+    clustering's draws instead of clustering (replay_group_seeding_draws).  What a caller's next rand() returns must
+    be what it returns after the plain sequences."""
+    import ctypes
+    from kmcuda_amd import kmeans_cuda
+    libc = ctypes.CDLL(None)
+    x = _blobs(30000, 16, 12, seed=4)
+    n, k = x.shape[0], 24
+    # the reference's own sequence for init = "random": srand(seed), one draw per shuffle step
+    libc.srand(11)
+    chosen = list(range(n))
+    for i in range(1, n):
+        j = libc.rand() % (i + 1)
+        chosen[i], chosen[j] = chosen[j], chosen[i]
+    after_shuffle = libc.rand()
+    cen, _ = kmeans_cuda(x, k, init="random", seed=11, tolerance=1.0, yinyang_t=0, device=1, verbosity=0)
+    assert libc.rand() == after_shuffle
+    assert (cen.view(numpy.uint32) == x[chosen[:k]].view(numpy.uint32)).all()   # tolerance 1: no update, centroids = seeds
+    # yinyang_t > 0: silent (draws replayed) against verbose (groups clustered for their progress lines)
+    nxt = []
+    for verbosity in (0, 1):
+        from test_gpu_kmeans import StdoutListener
+        with StdoutListener():
+            kmeans_cuda(x, k, init="random", seed=11, tolerance=0.001, yinyang_t=0.25, device=1, verbosity=verbosity)
+        nxt.append(libc.rand())
+    assert nxt[0] == nxt[1]
