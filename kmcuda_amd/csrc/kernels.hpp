@@ -320,9 +320,10 @@ struct KnnArgs {
   uint32_t *out;            // (p_end - p_base) x k, sorted-position order
   unsigned long long *calced;  // [0] pairs the REFERENCE's prune rule visits (knn.cu:228); knn_f16.hip also: [1] pairs
                                // scored on the matrix cores (32 x 32 per wave, operand set and sub-tile), [2] of those:
-                               // live, unpruned query x real candidate, [3] exact chains evaluated
+                               // live, unpruned query x real candidate, [3] exact chains evaluated, [4] what [1] would
+                               // be if an operand set without a visiting query were not scored
 };
-constexpr int KNN_STATS = 4;
+constexpr int KNN_STATS = 5;
 hipError_t launch_knn_gather(const float *samples, uint32_t N, uint32_t D, uint32_t DP, const uint32_t *inv,
                              float *xs, float *n2s, uint32_t *stats, hipStream_t st);
 hipError_t launch_knn_prep(int metric, const float *xs, uint32_t N, uint32_t D, uint32_t DP, const uint32_t *offsets,

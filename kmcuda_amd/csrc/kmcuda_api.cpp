@@ -1657,14 +1657,15 @@ class KnnJob {
         INFO("k-NN kernel failed: %s\n", hipGetErrorString(hipGetLastError()));
         return kmcudaRuntimeError;
       }
-      unsigned long long cs[KNN_STATS] = {0, 0, 0, 0};
+      unsigned long long cs[KNN_STATS] = {0, 0, 0, 0, 0};
       if (hipMemcpy(cs, s.calced, sizeof(cs), hipMemcpyDeviceToHost) != hipSuccess) return kmcudaMemoryCopyError;
       const unsigned long long c = cs[0];
       DEBUG("#%d dists_calced: %llu\n", s.dev, c);
       // what the f16 search actually did (knn_f16.hip; measurement: KMCUDA_AMD_KNN_STATS=1 prints it at any verbosity)
       if (cs[1] && (verbosity > 1 || getenv("KMCUDA_AMD_KNN_STATS")))
         printf("#%d k-NN filter: %llu pairs by the reference's prune rule, %llu scored on the matrix cores "
-               "(%llu of them live query x real candidate), %llu exact chains\n", s.dev, cs[0], cs[1], cs[2], cs[3]);
+               "(%llu of them live query x real candidate; %llu if an operand set nobody visits with were skipped), "
+               "%llu exact chains\n", s.dev, cs[0], cs[1], cs[2], cs[4], cs[3]);
       dists_calced += c;
       const uint32_t len = s.p_end - s.p_base;
       if (!len) continue;

@@ -447,53 +447,69 @@ __global__ __launch_bounds__(64) void knn_exact_kernel(KnnArgs a) {
 // ~1e-6 up to 256 features, 4e-6 at 1024) -- 2e-5 or (D + 16) u, 3e-5 and 3e-5 relative are taken.
 // 1M queries x 1024 centroids x 256 features: ~20 ms beside a search of seconds.
 // ---------------------------------------------------------------------------------------
+// (Round 4: 64 queries per block -- a lane per query, a wave per quarter of the features, the queries' values in
+// registers, the centroid's values broadcast from LDS -- instead of a wave per four rows with a 6-step butterfly per
+// (row, centroid) and 16-byte writes: 63 -> see profiles/README.md for the 1M x 1024 x 256 case of config D.)
+constexpr int kCbQ = 64, kCbTile = 16;   // queries per block; centroids staged per round
 __global__ __launch_bounds__(256) void knn_centroid_bounds_kernel(const float *__restrict__ xs, uint32_t D, uint32_t DP,
                                                                   uint32_t p_base, uint32_t p_end,
                                                                   const float *__restrict__ centroids, uint32_t K,
                                                                   const float *__restrict__ R, float *__restrict__ lb,
                                                                   size_t stride) {
-  constexpr int QW = 4, CH = 4;   // rows per wave, 256-feature chunks (D <= 1024)
+  // features in chunks of 256: wave w owns features [64 w, 64 w + 64) of the chunk
+  __shared__ __attribute__((aligned(16))) float ctile[kCbTile][256];
+  __shared__ float part[4][kCbTile][kCbQ];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t p0 = p_base + (blockIdx.x * 4 + wave) * QW;
-  if (p0 >= p_end) return;
-  float4 xq[CH][QW];
-#pragma unroll
-  for (int ch = 0; ch < CH; ch++)
-#pragma unroll
-    for (int q = 0; q < QW; q++) {
-      const uint32_t f = ch * 256 + lane * 4, p = p0 + q < p_end ? p0 + q : p0;
-      // (xs rows are zero padded to DP, a multiple of 8; beyond DP: zeros against the centroid's zeros below)
-      xq[ch][q] = f + 3 < DP ? *reinterpret_cast<const float4 *>(xs + (size_t)p * DP + f) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+  const uint32_t q0 = p_base + blockIdx.x * kCbQ;
+  const uint32_t p = q0 + lane < p_end ? q0 + lane : q0;   // (lanes past the end repeat a row; their results are not written)
   const int nch = (int)((D + 255) / 256);
-  // the fp32 sum of D squared differences is off by (D + 3) u relative at worst, its root by half of that: the whole
-  // of it is taken off the root (2e-5 up to 256 features, as tested; more beyond)
   const float sd = fminf(0.99998f, 1.0f - ((float)D + 16.0f) * 6.0e-8f);
-  for (uint32_t c = 0; c < K; c++) {
-    float acc[QW] = {0.f, 0.f, 0.f, 0.f};
-    const float *crow = centroids + (size_t)c * D;
+  for (uint32_t c0 = 0; c0 < K; c0 += kCbTile) {
+    float acc[kCbTile];
 #pragma unroll
-    for (int ch = 0; ch < CH; ch++) {
-      if (ch >= nch) break;
-      const uint32_t f = ch * 256 + lane * 4;
-      float cv[4];
+    for (int t = 0; t < kCbTile; t++) acc[t] = 0.f;
+    for (int ch = 0; ch < nch; ch++) {
+      __syncthreads();   // the previous chunk's tile has been consumed
+      // stage 16 centroids x 256 features of this chunk (zeros beyond D / beyond K)
+      for (uint32_t i = threadIdx.x; i < kCbTile * 256; i += 256) {
+        const uint32_t t = i >> 8, f = ch * 256 + (i & 255u);
+        ctile[t][i & 255u] = (c0 + t < K && f < D) ? centroids[(size_t)(c0 + t) * D + f] : 0.f;
+      }
+      // my 64 features of my query (xs rows are zero padded to DP; beyond DP: zeros against the tile's zeros)
+      float xv[64];
 #pragma unroll
-      for (int t = 0; t < 4; t++) cv[t] = f + t < D ? crow[f + t] : 0.f;
+      for (int f4 = 0; f4 < 16; f4++) {
+        const uint32_t f = ch * 256 + wave * 64 + f4 * 4;
+        const float4 v = f + 3 < DP ? *reinterpret_cast<const float4 *>(xs + (size_t)p * DP + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xv[4 * f4 + 0] = v.x; xv[4 * f4 + 1] = v.y; xv[4 * f4 + 2] = v.z; xv[4 * f4 + 3] = v.w;
+      }
+      __syncthreads();
 #pragma unroll
-      for (int q = 0; q < QW; q++) {
-        const float d0 = xq[ch][q].x - cv[0], d1 = xq[ch][q].y - cv[1], d2 = xq[ch][q].z - cv[2], d3 = xq[ch][q].w - cv[3];
-        acc[q] = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, acc[q]))));
+      for (int t = 0; t < kCbTile; t++) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int f4 = 0; f4 < 16; f4++) {
+          const float4 cv = *reinterpret_cast<const float4 *>(&ctile[t][wave * 64 + f4 * 4]);   // same address in every lane: a broadcast
+          const float d0 = xv[4 * f4 + 0] - cv.x, d1 = xv[4 * f4 + 1] - cv.y, d2 = xv[4 * f4 + 2] - cv.z, d3 = xv[4 * f4 + 3] - cv.w;
+          a0 = fmaf(d0, d0, a0); a1 = fmaf(d1, d1, a1); a2 = fmaf(d2, d2, a2); a3 = fmaf(d3, d3, a3);
+        }
+        acc[t] += (a0 + a1) + (a2 + a3);
       }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-      for (int q = 0; q < QW; q++) acc[q] += __shfl_xor(acc[q], off);
-    if (lane < (uint32_t)QW && p0 + lane < p_end) {
-      const float d = sqrtf(acc[lane == 0 ? 0 : (lane == 1 ? 1 : (lane == 2 ? 2 : 3))]);
-      // NaN (a NaN row or centroid, an empty cluster's radius): compares false in the search, nothing is skipped
-      lb[(size_t)c * stride + (p0 + lane - p_base)] = (d * sd - R[c] * 1.00003f) * 0.99997f;
+    for (int t = 0; t < kCbTile; t++) part[wave][t][lane] = acc[t];
+    __syncthreads();
+    // 16 centroids x 64 queries = 1024 results, four per thread: thread -> (centroid t, query)
+    for (uint32_t i = threadIdx.x; i < kCbTile * kCbQ; i += 256) {
+      const uint32_t t = i >> 6, q = i & 63u;
+      const uint32_t c = c0 + t;
+      if (c < K && q0 + q < p_end) {
+        const float d = sqrtf((part[0][t][q] + part[1][t][q]) + (part[2][t][q] + part[3][t][q]));
+        // NaN (a NaN row or centroid, an empty cluster's radius): compares false in the search, nothing is skipped
+        lb[(size_t)c * stride + (q0 + q - p_base)] = (d * sd - R[c] * 1.00003f) * 0.99997f;
+      }
     }
+    __syncthreads();   // part[] is reused by the next round
   }
 }
 
@@ -503,8 +519,8 @@ hipError_t launch_knn_centroid_bounds(const float *xs, uint32_t D, uint32_t DP, 
   if (p_end <= p_base) return hipSuccess;
   if (D > 1024 || (DP & 3u)) return hipErrorInvalidValue;
   const uint32_t nrows = p_end - p_base;
-  hipLaunchKernelGGL(knn_centroid_bounds_kernel, dim3((nrows + 15) / 16), dim3(256), 0, st, xs, D, DP, p_base, p_end,
-                     centroids, K, R, lb, stride);
+  hipLaunchKernelGGL(knn_centroid_bounds_kernel, dim3((nrows + kCbQ - 1) / kCbQ), dim3(256), 0, st, xs, D, DP, p_base,
+                     p_end, centroids, K, R, lb, stride);
   return hipGetLastError();
 }
 

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(KNN16_WAVES * 64, (DP > 512 ? 1 : KNN16_BLOCKS_PER_
     qn_[e] = 0;
   };
 
-  unsigned long long calced = 0, scored = 0, useful = 0;   // wave-uniform (scalar registers)
+  unsigned long long calced = 0, scored = 0, useful = 0, scored_sets = 0;   // wave-uniform (scalar registers)
   int ph = 0;
   for (uint32_t step = 0; step <= K; step++) {
     const uint32_t cls = step == 0 ? cls0 : step - 1;
@@ -307,12 +307,13 @@ __global__ __launch_bounds__(KNN16_WAVES * 64, (DP > 512 ? 1 : KNN16_BLOCKS_PER_
       for (int e = 0; e < NSET; e++)
         if (!pruned[e]) pruned[e] = a.lb[(size_t)cls * a.lb_stride + (qp[e] - a.p_base)] > mndist[e];
     }
-    uint32_t nvis_tight = 0;   // queries of the wave that visit the cluster after both tests
+    uint32_t nvis_tight = 0, nsets_live = 0;   // queries / operand sets of the wave that visit the cluster after both tests
 #pragma unroll
     for (int e = 0; e < NSET; e++) {
       const unsigned long long b = __ballot(!pruned[e]);
       visiting |= b;
       nvis_tight += (uint32_t)__popcll(b & 0xFFFFFFFFull);
+      nsets_live += b ? 1u : 0u;
     }
     const bool wave_need = visiting != 0ull;
     if (lane == 0) flags[ph * WV + wave] = wave_need ? 1u : 0u;
@@ -440,6 +441,7 @@ __global__ __launch_bounds__(KNN16_WAVES * 64, (DP > 512 ? 1 : KNN16_BLOCKS_PER_
           mfma_tile(buf, sub, dma, dma_base, dma_buf);
           {   // statistics (wave-uniform)
             scored += 1024ull * NSET;
+            scored_sets += 1024ull * nsets_live;
             const uint32_t left = end - (tile_base + 32u * sub);
             useful += (unsigned long long)nvis_tight * (left < 32u ? left : 32u);
           }
@@ -469,6 +471,7 @@ __global__ __launch_bounds__(KNN16_WAVES * 64, (DP > 512 ? 1 : KNN16_BLOCKS_PER_
   if (lane == 0 && scored) {
     atomicAdd(a.calced + 1, scored);
     atomicAdd(a.calced + 2, useful);
+    atomicAdd(a.calced + 4, scored_sets);
   }
 #pragma unroll
   for (int off = 16; off > 0; off >>= 1) chains += __shfl_xor(chains, off);   // (the upper half-wave holds zeros)
