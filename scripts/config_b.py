@@ -56,7 +56,12 @@ def main():
                              device=1, verbosity=args.verbosity)
     dt = time.perf_counter() - t0
     asg = _DEVICE_ALLOCS[aptr]
-    print("kmeans_cuda wall: %.3f s; clusters used: %d" % (dt, int(torch.unique(asg).numel())), flush=True)
+    import ctypes
+    from kmcuda_amd import _lib
+    it, loop_s = ctypes.c_uint32(), ctypes.c_double()
+    _lib.lib().kmamd_last_run_stats(ctypes.byref(it), ctypes.byref(loop_s), None, None, None)
+    print("kmeans_cuda wall: %.3f s (%d iterations, %.3f s in the iteration loop); clusters used: %d" %
+          (dt, it.value, loop_s.value, int(torch.unique(asg).numel())), flush=True)
 
 
 if __name__ == "__main__":

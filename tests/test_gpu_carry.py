@@ -168,3 +168,24 @@ def test_random_init_and_silent_group_clustering_leave_rand_where_the_reference_
             kmeans_cuda(x, k, init="random", seed=11, tolerance=0.001, yinyang_t=0.25, device=1, verbosity=verbosity)
         nxt.append(libc.rand())
     assert nxt[0] == nxt[1]
+
+
+def test_carried_bounds_over_virtual_shards(monkeypatch):
+    """Three row shards on one GPU (KMCUDA_AMD_VIRTUAL_SHARDS: every shard its own engine, bounds, drifts and row
+    list; the centroids replicated): the carried schedule equals the plain one there too, and both equal one shard."""
+    from kmcuda_amd import kmeans_cuda
+    x = _blobs(90000, 32, 50, seed=21, spread=8.0)
+    res = {}
+    for shards, carry in ((1, "1"), (3, "1"), (3, "0")):
+        monkeypatch.setenv("KMCUDA_AMD_CARRY", carry)
+        if shards > 1:
+            monkeypatch.setenv("KMCUDA_AMD_VIRTUAL_SHARDS", str(shards))
+        else:
+            monkeypatch.delenv("KMCUDA_AMD_VIRTUAL_SHARDS", raising=False)
+        res[(shards, carry)] = kmeans_cuda(x, 50, init="random", seed=3, tolerance=0.0002, yinyang_t=0.1, device=1, verbosity=0)
+    a = res[(3, "1")]
+    b = res[(3, "0")]
+    assert (a[1] == b[1]).all() and (a[0].view(numpy.uint32) == b[0].view(numpy.uint32)).all()
+    # one shard against three: the same assignments (the deltas are fp64 sums of fp32 values: the split moves
+    # the centroids by rounding at most, which this well-separated data does not notice)
+    assert (res[(1, "1")][1] == a[1]).mean() > 0.9999
