@@ -128,6 +128,73 @@ __global__ void knn_member_kernel(const float *__restrict__ xs, uint32_t N, uint
   rdist[p] = finalize<METRIC>(sd);
 }
 
+// The same two chains per member with the rows coming in through LDS (D % 32 == 0, 16-byte aligned rows): a thread
+// walking its own 1-KB row makes every load of a wave touch 64 different lines (27 ms for 8M x 256: 0.3 TB/s); 8 lanes
+// fetch a row's 128-byte line per 32-feature chunk, the tile has a 36-float row stride (conflict-free 16-byte reads),
+// the next chunk's loads fly during the chains -- seeding.hip's kmpp_step2_kernel, with a centroid per row (the rows
+// are cluster-sorted: a block's threads share one or two centroid rows, served by L1).  A 32-feature chunk is two of
+// the reference's 16-feature partials.
+constexpr int kMemberBlock = 256;
+template <int METRIC>
+__global__ __launch_bounds__(kMemberBlock) void knn_member_tiled_kernel(const float *__restrict__ xs, uint32_t N, uint32_t D,
+                                                                        uint32_t DP, const uint32_t *__restrict__ offsets,
+                                                                        uint32_t K, const float *__restrict__ centroids,
+                                                                        float *__restrict__ mydist, float *__restrict__ rdist) {
+  __shared__ __attribute__((aligned(16))) float tile[kMemberBlock * 36];
+  const uint32_t p = blockIdx.x * kMemberBlock + threadIdx.x;
+  const uint32_t c = p < N ? cluster_of(offsets, K, p) : K;
+  const float *cen = centroids + (size_t)(c < K ? c : 0) * D;
+  const uint32_t nchunk = D / 32;
+  float4 stage[8];
+  auto fetch = [&](uint32_t ch) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const uint32_t i = threadIdx.x + kMemberBlock * q, r = i >> 3, c4 = i & 7u;
+      const uint32_t row = blockIdx.x * kMemberBlock + r;
+      stage[q] = row < N ? *reinterpret_cast<const float4 *>(xs + (size_t)row * DP + ch * 32 + c4 * 4)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  float acc = 0.f, corr = 0.f, sd = 0.f;
+  fetch(0);
+  for (uint32_t ch = 0; ch < nchunk; ch++) {
+    __syncthreads();   // the previous chunk has been consumed
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const uint32_t i = threadIdx.x + kMemberBlock * q, r = i >> 3, c4 = i & 7u;
+      *reinterpret_cast<float4 *>(&tile[r * 36 + c4 * 4]) = stage[q];
+    }
+    __syncthreads();
+    if (ch + 1 < nchunk) fetch(ch + 1);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {   // one 16-feature partial of the radius distance (knn.cu:31-45)
+      float pacc = 0.f, pcorr = 0.f;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; c4++) {
+        const float4 xv = *reinterpret_cast<const float4 *>(&tile[threadIdx.x * 36 + half * 16 + c4 * 4]);
+        const float4 cv = *reinterpret_cast<const float4 *>(cen + ch * 32 + half * 16 + c4 * 4);
+        const float aa[4] = {xv.x, xv.y, xv.z, xv.w}, bb[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if (METRIC == 0) {
+            const float d = aa[q] - bb[q];
+            kahan_fold(fma_rd(d, d, corr), acc, corr);      // the one chain over all features (distance_t)
+            kahan_fold(fma_rd(d, d, pcorr), pacc, pcorr);   // the partial's own chain
+          } else {
+            kahan_fold(fma_rd(aa[q], bb[q], corr), acc, corr);
+            kahan_fold(fma_rd(aa[q], bb[q], pcorr), pacc, pcorr);
+          }
+        }
+      }
+      sd += pacc;
+    }
+  }
+  if (p < N) {
+    mydist[p] = c < K ? finalize<METRIC>(acc) : NAN;
+    rdist[p] = c < K ? finalize<METRIC>(sd) : NAN;
+  }
+}
+
 // knn.cu:46-57: radius = max member distance, NaN for an empty cluster.  One wave per cluster.
 __global__ __launch_bounds__(64) void knn_radii_kernel(const float *__restrict__ rdist,
                                                        const uint32_t *__restrict__ offsets, uint32_t K,
@@ -548,10 +615,17 @@ hipError_t launch_knn_gather(const float *samples, uint32_t N, uint32_t D, uint3
 hipError_t launch_knn_prep(int metric, const float *xs, uint32_t N, uint32_t D, uint32_t DP, const uint32_t *offsets,
                            uint32_t K, const float *centroids, float *mydist, float *rdist, float *R, float *C,
                            bool strict_h2, hipStream_t st) {
+  // (the tiled member kernel: whole 32-feature chunks, 16-byte aligned rows and centroids; else, and for the half2
+  //  arithmetic, a thread per row)
+  const bool tiled = !strict_h2 && D >= 32 && (D & 31u) == 0 && (DP & 3u) == 0 && (((uintptr_t)xs | (uintptr_t)centroids) & 15u) == 0;
 #define KMX_KNN_PREP(M, H)                                                                                          \
   do {                                                                                                              \
-    hipLaunchKernelGGL((knn_member_kernel<M, H>), dim3((N + 127) / 128), dim3(128), 0, st, xs, N, D, DP, offsets, K, \
-                       centroids, mydist, rdist);                                                                   \
+    if (tiled)                                                                                                      \
+      hipLaunchKernelGGL((knn_member_tiled_kernel<M>), dim3((N + kMemberBlock - 1) / kMemberBlock), dim3(kMemberBlock), 0, \
+                         st, xs, N, D, DP, offsets, K, centroids, mydist, rdist);                                   \
+    else                                                                                                            \
+      hipLaunchKernelGGL((knn_member_kernel<M, H>), dim3((N + 127) / 128), dim3(128), 0, st, xs, N, D, DP, offsets, K, \
+                         centroids, mydist, rdist);                                                                 \
     hipLaunchKernelGGL((knn_cdist_kernel<M, H>), dim3(((K + 127) / 128) * K), dim3(128), 0, st, centroids, K, D, C); \
   } while (0)
   if (metric == 0) {
