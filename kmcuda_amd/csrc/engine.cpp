@@ -413,6 +413,7 @@ int Engine::yy_drifts(const float *centroids, float *drifts, float *gdrifts) {
 int Engine::yy_filters(const float *samples, const float *centroids, const float *drifts, const float *gdrifts,
                        uint32_t *assignments, uint32_t *assignments_prev, float *bounds, uint32_t *passed) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  carry_valid_ = false;   // (the reference's filters move assignments behind the carried bounds' back)
   if (N_ == 0) return kSuccess;
   if (strict_h2_) {
     KMX_HIP(launch_h2_yy_global(metric_, samples, N_, D_, K_, G_, centroids, drifts, gdrifts, assignments,
@@ -468,6 +469,10 @@ int Engine::yy_filters(const float *samples, const float *centroids, const float
 int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t *assignments,
                          uint32_t *assignments_prev, bool exact_only) {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  // carried bounds describe the assignments of the LAST pass: whatever this pass turns out to be, they hold afterwards
+  // only if it was a carried pass itself (set at its end) -- an exact pass, the f32 filter, a rebuilt panel void them
+  const bool carry_was_valid = carry_valid_;
+  carry_valid_ = false;
   if (strict_h2_) {
     if (!h2_sq_) {
       int rc = alloc(&h2_sq_, 2 * (size_t)K_);
@@ -531,7 +536,6 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   } else {
     int rc = prepare_centroids(centroids);
     if (rc) return rc;
-    carry_valid_ = false;   // (the panel was rebuilt outside the steady state: no drift for it)
   }
   LloydArgs a;
   a.samples = samples; a.N = N_; a.D = D_; a.K = K_; a.K_pad = K_pad_; a.DP = DP_; a.Kt = Kt_;
@@ -600,13 +604,12 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
         host_carry_[1] = 0;
         if (const char *v = getenv("KMCUDA_AMD_CARRY_MAX")) carry_list_max_ = (float)atof(v);
       }
-      carry_valid_ = false;   // (this pass's preparation ran without a drift buffer)
     }
     span_begin(3);  // the dominant kernel on its own, inside the filter span
     if (carry && carry_on_) {
       CarryArgs cy;
       cy.ub = ub_; cy.lb = lb_; cy.host_report = host_carry_dev_; cy.seq = ++carry_seq_;
-      const bool moved = carry_valid_ && carry_preps_ == 1;   // drift_ / stats_[6] belong to the bounds
+      const bool moved = carry_was_valid && carry_preps_ == 1;   // drift_ / stats_[6] belong to the bounds
       uint32_t hint = 0xFFFFFFFFu;
       bool listed = false;
       if (moved) {
@@ -638,7 +641,6 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
               kRuntimeError);
       carry_valid_ = true;
     } else {
-      carry_valid_ = false;
       KMX_HIP(launch_lloyd_coarse(a, rows, half, cached ? xcache_ : nullptr, xmeta_, panelhi_, undecided_, und_thr_,
                                   stream_),
               kRuntimeError);

@@ -189,3 +189,41 @@ def test_carried_bounds_over_virtual_shards(monkeypatch):
     # one shard against three: the same assignments (the deltas are fp64 sums of fp32 values: the split moves
     # the centroids by rounding at most, which this well-separated data does not notice)
     assert (res[(1, "1")][1] == a[1]).mean() > 0.9999
+
+
+def test_an_exact_pass_or_a_filter_change_between_carried_passes_voids_the_bounds():
+    """The bounds describe the last pass's assignments: a pass of another kind in between (the exact kernels, the f32
+    filter) must not leave stale bounds behind for the next carried pass."""
+    from kmcuda_amd.distributed import HipBackend, ShardedLloyd
+    dev = torch.device("cuda", 0)
+    x = _blobs(50000, 64, 30, seed=13, spread=9.0)
+    init = x[numpy.random.RandomState(2).choice(len(x), 30, replace=False)].copy()
+    xs = torch.from_numpy(x).to(dev)
+    loops = []
+    for which in range(2):
+        b = HipBackend(xs, 30, "L2", device_index=0)
+        loop = ShardedLloyd(b, len(x))
+        loop.set_centroids(torch.from_numpy(init).to(dev))
+        loops.append(loop)
+    plain, carry = loops
+    carry.b.engine.set_carry(True)
+    for it in range(12):
+        for loop in loops:
+            loop.step()
+        if it in (4, 8):   # scramble the carry engine's state with a pass of another kind, then restore the assignments
+            e = carry.b.engine
+            keep_a, keep_p = carry.b.assignments.clone(), carry.b.assignments_prev.clone()
+            if it == 4:
+                e.lloyd_assign(carry.b.samples, carry.b.centroids, carry.b.assignments, carry.b.assignments_prev, exact=True)
+            else:
+                e.set_filter("f32")
+                e.lloyd_assign(carry.b.samples, carry.b.centroids, carry.b.assignments, carry.b.assignments_prev)
+                e.set_filter("f16")
+            # pretend the caller moved rows in between as well: bounds that survived would now be wrong
+            carry.b.assignments.copy_(keep_a)
+            carry.b.assignments_prev.copy_(keep_p)
+            e.reset_counters(0)
+        for loop in loops:
+            loop.b.synchronize()
+        assert (plain.b.assignments == carry.b.assignments).all(), it
+        assert (plain.b.centroids.view(torch.int32) == carry.b.centroids.view(torch.int32)).all(), it
