@@ -170,6 +170,13 @@ hipError_t launch_apply_delta(int metric, const double *delta, const int32_t *dc
 // all-reduce: KMCUDA_AMD_VIRTUAL_SHARDS)
 hipError_t launch_sum_buffers(double *const *bufs_dev, uint32_t nbuf, size_t len, hipStream_t st);
 
+// Code objects load on the first use of a kernel of their translation unit: ~24 ms per process in front of the first
+// iteration's kernels (16 of them the update's radix sort).  kmeans_cuda() touches them from a helper thread while its
+// own thread uploads and seeds (kmcuda_api.cpp: preload_code_objects).
+hipError_t preload_update_code();
+hipError_t preload_lloyd_f16_code();
+hipError_t preload_lloyd_code();
+hipError_t preload_lloyd_carry_code();
 hipError_t launch_gather_rows(const float *samples, const uint32_t *idx, uint32_t K, uint32_t D, float *out, hipStream_t st);
 // seeding.hip (reference: kmeans.cu:42-67 kmeans_plus_plus, transpose.cu:6-14 copy_sample_t,
 // kmeans.cu:674-691 kmeans_calc_average_distance)

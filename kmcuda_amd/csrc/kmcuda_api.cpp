@@ -1725,6 +1725,39 @@ struct SwitchRule {
   bool now(uint32_t changed) const { return force >= 0 && (double)changed <= force * N; }
 };
 
+// Once per process and device: the iteration kernels' code objects are loaded by a helper thread while the calling
+// thread uploads the rows and seeds (they would otherwise load one by one in front of the first iteration: 24 ms of a
+// 45-ms call on 4M rows).  Fire and forget: a launch that needs a code object the helper is still loading waits for it
+// inside the runtime; the caller joins the helper before it returns (never a thread inside the runtime at process
+// exit).  KMCUDA_AMD_PRELOAD=0: off (A/B).
+struct PreloadThreads {
+  std::vector<std::thread> threads;
+  ~PreloadThreads() {
+    for (auto &t : threads)
+      if (t.joinable()) t.join();
+  }
+};
+void preload_code_objects(int dev, PreloadThreads *keep) {
+  static std::mutex m;
+  static std::vector<bool> done;
+  {
+    std::lock_guard<std::mutex> lock(m);
+    if (done.size() <= (size_t)dev) done.resize(dev + 1, false);
+    if (done[dev]) return;
+    done[dev] = true;
+  }
+  if (const char *v = getenv("KMCUDA_AMD_PRELOAD"))
+    if (atoi(v) == 0) return;
+  keep->threads.emplace_back([dev] {
+    if (hipSetDevice(dev) != hipSuccess) return;
+    (void)preload_update_code();
+    (void)preload_lloyd_f16_code();
+    (void)preload_lloyd_code();
+    (void)preload_lloyd_carry_code();
+    (void)hipGetLastError();
+  });
+}
+
 int virtual_shards() {
   const char *v = getenv("KMCUDA_AMD_VIRTUAL_SHARDS");
   return v ? atoi(v) : 0;
@@ -1763,6 +1796,8 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
   // landed before our own non-blocking streams read it -- the reference got this from the legacy
   // default stream's implicit synchronisation
   if (device_ptrs >= 0 && hipSetDevice(device_ptrs) == hipSuccess) (void)hipDeviceSynchronize();
+  PreloadThreads preload;   // (joined when this call returns, whichever way)
+  for (int d : devs) preload_code_objects(d, &preload);
   const auto t_begin = std::chrono::steady_clock::now();
   // KMCUDA_AMD_TIMING=1: wall-clock laps of the call's phases on stderr (a measurement aid; each lap waits for the GPUs)
   const bool timing = getenv("KMCUDA_AMD_TIMING") != nullptr;

@@ -926,4 +926,9 @@ hipError_t launch_lloyd_exact(int metric, const LloydArgs &a, const uint32_t *ro
   return hipGetLastError();
 }
 
+hipError_t preload_lloyd_code() {   // (kernels.hpp: preload_code_objects)
+  hipFuncAttributes at;
+  return hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&centroid_rows_kernel<0>));
+}
+
 }  // namespace kmx

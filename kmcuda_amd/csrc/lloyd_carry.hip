@@ -156,4 +156,9 @@ hipError_t launch_lloyd_coarse_carry(const LloydArgs &a, const void *rows, bool 
   }
 }
 
+hipError_t preload_lloyd_carry_code() {   // (kernels.hpp: preload_code_objects)
+  hipFuncAttributes at;
+  return hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&carry_skip_kernel));
+}
+
 }  // namespace kmx

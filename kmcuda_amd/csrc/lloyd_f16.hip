@@ -790,4 +790,9 @@ hipError_t launch_row_cache(const void *rows, bool half_rows, uint32_t N, uint32
   }
 }
 
+hipError_t preload_lloyd_f16_code() {   // (kernels.hpp: preload_code_objects)
+  hipFuncAttributes at;
+  return hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&centroid_panelhi_kernel));
+}
+
 }  // namespace kmx

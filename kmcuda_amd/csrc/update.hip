@@ -861,4 +861,11 @@ hipError_t launch_adjust_exact(int metric, const float *samples, uint32_t N, uin
   return hipGetLastError();
 }
 
+// (kernels.hpp: preload_code_objects) touches one kernel of this translation unit: its code object -- with the radix
+// sort's instantiations the largest of the library -- is loaded now instead of at the first update
+hipError_t preload_update_code() {
+  hipFuncAttributes at;
+  return hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&move_count_kernel));
+}
+
 }  // namespace kmx
