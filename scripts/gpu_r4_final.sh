@@ -46,6 +46,7 @@ run "4M-row mixture tol 1e-4: yinyang_t=0" timeout 300 python scripts/config_b.p
 run "config C shape: fp16 angular, 8 virtual 1M-row shards: default" env KMCUDA_AMD_VIRTUAL_SHARDS=8 timeout 300 python scripts/config_b.py --metric cos --dtype f16 --yinyang 0.1 --verbosity 0
 run "config C shape: reference schedule" env KMCUDA_AMD_YY=reference KMCUDA_AMD_VIRTUAL_SHARDS=8 timeout 300 python scripts/config_b.py --metric cos --dtype f16 --yinyang 0.1 --verbosity 0
 run "config D share: 1M queries of rank 0 of 8 against the 8Mx256 corpus" env KMCUDA_AMD_KNN_STATS=1 timeout 300 python scripts/config_d.py --samples 8000000 --shard 0/8
+echo "## transpose against HBM" | tee -a $OUT/configs_$TAG.log; timeout 300 python scripts/transpose_bench.py 2>&1 | grep transpose | tee -a $OUT/configs_$TAG.log
 echo "## config A: 100000 x 256 host arrays, K = 1024, tolerance 0.002, five calls in one process" | tee -a $OUT/configs_$TAG.log
 timeout 300 python - <<'PY' 2>&1 | grep "kmeans_cuda(" | tee -a $OUT/configs_$TAG.log
 import time, numpy
