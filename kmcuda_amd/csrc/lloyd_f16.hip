@@ -706,8 +706,8 @@ __global__ __launch_bounds__(256) void row_cache_kernel(const void *__restrict__
                                                         float2 *__restrict__ xmeta, uint32_t nblocks32) {
   constexpr int NKH = DP / 2, KS = NKH / 8;
   const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
-  const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (b >= nblocks32) return;
+  // (a wave per 32-row block, strided from a bounded grid: kernels.hpp, wave_row_grid)
+  for (uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6); b < nblocks32; b += gridDim.x * 4u) {
   if (b == 0) {  // ||mu|| behind the per-row records: ||x|| <= ||x'|| + ||mu|| in the coarse kernel's bound
     float m2 = 0.f;
     for (uint32_t f = lane; f < (uint32_t)DP; f += 64) m2 = fmaf(mu[f], mu[f], m2);
@@ -758,6 +758,7 @@ __global__ __launch_bounds__(256) void row_cache_kernel(const void *__restrict__
   dx2 += __shfl_xor(dx2, 32);
   // record = (||x'||^2, ||x' - hi(x')||^2); a NaN first feature (kmeans.cu:312) is flagged by -1
   if (h == 0) xmeta[s] = make_float2(xn2, (x0 != x0) ? -1.f : dx2 * 1.0001f);   // xmeta covers the padded row count
+  }
 }
 
 template <int DP>
@@ -766,7 +767,7 @@ static hipError_t launch_row_cache_dp(const void *rows, bool half_rows, uint32_t
   const uint32_t nblocks32 = (N + 255u) / 256u * 8u;
   const bool fast = D == (uint32_t)DP;
 #define KMX_RC_LAUNCH(H, F)                                                                                       \
-  hipLaunchKernelGGL((row_cache_kernel<DP, H, F>), dim3(nblocks32 / 4), dim3(256), 0, st, rows, N, D, mu,          \
+  hipLaunchKernelGGL((row_cache_kernel<DP, H, F>), dim3(wave_row_grid(nblocks32)), dim3(256), 0, st, rows, N, D, mu, \
                      reinterpret_cast<f16x8 *>(xcache), reinterpret_cast<float2 *>(xmeta), nblocks32)
   if (half_rows) {
     if (fast) KMX_RC_LAUNCH(true, true); else KMX_RC_LAUNCH(true, false);

@@ -963,18 +963,20 @@ hipError_t launch_member_distances(int metric, const float *samples, uint32_t N,
 // as half2 -- instead of accumulating in half2 like the reference (tolerance).
 // ---------------------------------------------------------------------------------------
 __global__ void half_to_float_kernel(const __half *__restrict__ src, size_t n, float *__restrict__ dst) {
-  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
-  if (i + 8 <= n) {
-    const uint4 raw = *reinterpret_cast<const uint4 *>(src + i);
-    const __half2 *h2 = reinterpret_cast<const __half2 *>(&raw);
-    float4 lo, hi;
-    float2 a = __half22float2(h2[0]), b = __half22float2(h2[1]), c = __half22float2(h2[2]), d = __half22float2(h2[3]);
-    lo.x = a.x; lo.y = a.y; lo.z = b.x; lo.w = b.y;
-    hi.x = c.x; hi.y = c.y; hi.z = d.x; hi.w = d.y;
-    *reinterpret_cast<float4 *>(dst + i) = lo;
-    *reinterpret_cast<float4 *>(dst + i + 4) = hi;
-  } else {
-    for (size_t j = i; j < n; j++) dst[j] = __half2float(src[j]);
+  // (strided from a bounded grid: n / 8 threads pass 2^32 for buffers beyond 32 G halves -- kernels.hpp: wave_row_grid)
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += (size_t)gridDim.x * blockDim.x * 8) {
+    if (i + 8 <= n) {
+      const uint4 raw = *reinterpret_cast<const uint4 *>(src + i);
+      const __half2 *h2 = reinterpret_cast<const __half2 *>(&raw);
+      float4 lo, hi;
+      float2 a = __half22float2(h2[0]), b = __half22float2(h2[1]), c = __half22float2(h2[2]), d = __half22float2(h2[3]);
+      lo.x = a.x; lo.y = a.y; lo.z = b.x; lo.w = b.y;
+      hi.x = c.x; hi.y = c.y; hi.z = d.x; hi.w = d.y;
+      *reinterpret_cast<float4 *>(dst + i) = lo;
+      *reinterpret_cast<float4 *>(dst + i + 4) = hi;
+    } else {
+      for (size_t j = i; j < n; j++) dst[j] = __half2float(src[j]);
+    }
   }
 }
 
@@ -991,8 +993,8 @@ __global__ void quantize_half_kernel(float *__restrict__ v, size_t n) {
 
 hipError_t launch_half_to_float(const void *src, size_t n, float *dst, hipStream_t st) {
   if (n == 0) return hipSuccess;
-  const size_t threads = (n + 7) / 8;
-  hipLaunchKernelGGL(half_to_float_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, st,
+  const size_t blocks = ((n + 7) / 8 + 255) / 256;
+  hipLaunchKernelGGL(half_to_float_kernel, dim3((uint32_t)(blocks < (1u << 22) ? blocks : (1u << 22))), dim3(256), 0, st,
                      reinterpret_cast<const __half *>(src), n, dst);
   return hipGetLastError();
 }
