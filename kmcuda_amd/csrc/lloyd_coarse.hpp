@@ -15,7 +15,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // ---------------------------------------------------------------------------------------
-// Stage 1: ONE f16 MFMA per 16 features (hi.hi only).  What shaped the kernel (DESIGN.md 4.6,
+// Stage 1: ONE f16 MFMA per 16 features (hi.hi only).  What shaped the kernel (DESIGN.md 4.5,
 // profiles/r1e..r1k): a wave owns 64 rows (two B-operand sets) so each A fragment read from LDS feeds
 // two MFMAs; blocks are 4 waves, one per SIMD, two blocks per CU, so one block's bookkeeping runs under
 // the other's MFMAs; the accumulator register number travels in the low 4 mantissa bits of the score

@@ -6,7 +6,7 @@
 // of the f16 rate).  Two stages:
 //   1. lloyd_coarse2_kernel: operands CENTRED in fp32 (x' = x - mu, c' = c - mu) and rounded to halves;
 //      hi(x').hi(c') with ONE v_mfma_f32_32x32x16_f16 per 16 features, products exact in the fp32
-//      accumulator, the operand rounding carried explicitly in the bound (DESIGN.md 4.6).  Decides the
+//      accumulator, the operand rounding carried explicitly in the bound (DESIGN.md 4.5).  Decides the
 //      rows whose best / second-best gap exceeds the bound (the large majority).
 //   2. lloyd_refine_kernel: the others -- contenders above the row's cut-off, scored in fp32.
 // (Round 1 also had a single-stage three-product pass, x_hi.c_hi + x_hi.c_lo + x_lo.c_hi; it was a third

@@ -2,7 +2,7 @@
 // (D > 512: lloyd_f16.hip keeps a wave's rows in registers as the matrix-core B operand, which stops at 512
 // features), reference: kmeans_assign_lloyd, src/kmeans.cu:293-364.
 //
-// Same decision chain as the two-stage filter (DESIGN.md 4.6), with stage 1's scores coming out of ONE plain
+// Same decision chain as the two-stage filter (DESIGN.md 4.5), with stage 1's scores coming out of ONE plain
 // library GEMM -- rocBLAS, f16 operands, f32 accumulation: S = hi(X - mu) . hi(C - mu)^T, the product the coarse
 // kernel forms tile by tile -- into a chunk-sized score matrix:
 //   row_halves      x' = x - mu as halves, row-major (the GEMM's operand; the engine's row cache for this path)

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void yy_hint_kernel(YyArgs a) {
 // the local filter against the estimate
 // ---------------------------------------------------------------------------------------
 // The candidate sweep runs on the f16 matrix cores (hi halves only, like the estimate) with the coarse Lloyd
-// stage's rigorous bound on the dropped parts (lloyd_f16.hip, DESIGN.md 4.6): the measured ||x' - hi(x')|| of the
+// stage's rigorous bound on the dropped parts (lloyd_f16.hip, DESIGN.md 4.5): the measured ||x' - hi(x')|| of the
 // row and max ||c' - hi(c')|| of the panel (stats[5]).  The panel streams like the Lloyd coarse stage's: 64-centroid
 // super-tiles by LDS-DMA (bank-swizzled by source address, biases behind the panel), double buffered, the next
 // super-tile's pieces issued between this one's matrix products, fragments read by hand with counted waits --
