@@ -83,7 +83,8 @@ def _run_pair(x, k, iters, carry_from, fused, half=False, seed=5, monkeypatch=No
 
 
 @pytest.mark.parametrize("fused", [False, True], ids=["apply", "apply+prepare"])
-@pytest.mark.parametrize("shape", [(60000, 64, 64), (50000, 256, 200), (30000, 24, 40), (40000, 100, 33)],
+@pytest.mark.parametrize("shape", [(60000, 64, 64), (50000, 256, 200), (30000, 24, 40), (40000, 100, 33),
+                                   (30000, 512, 48), (20000, 300, 24), (25000, 7, 12)],
                          ids=lambda s: "%dx%d@%d" % s)
 def test_carried_passes_equal_plain_passes_on_clustered_rows(shape, fused):
     n, d, k = shape
