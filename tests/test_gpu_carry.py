@@ -84,16 +84,16 @@ def _run_pair(x, k, iters, carry_from, fused, half=False, seed=5, monkeypatch=No
 
 @pytest.mark.parametrize("fused", [False, True], ids=["apply", "apply+prepare"])
 @pytest.mark.parametrize("shape", [(60000, 64, 64), (50000, 256, 200), (30000, 24, 40), (40000, 100, 33),
-                                   (30000, 512, 48), (20000, 300, 24), (25000, 7, 12)],
+                                   (30000, 512, 48), (20000, 300, 24), (25000, 12, 12)],
                          ids=lambda s: "%dx%d@%d" % s)
 def test_carried_passes_equal_plain_passes_on_clustered_rows(shape, fused):
     n, d, k = shape
     # half as many blobs as centroids: most blobs are shared by two centroids, whose rows the bounds rarely decide;
     # as many blobs as centroids (the first shape): most rows are decided by their bounds from the first carried pass on
     x = _blobs(n, d, k if n == 60000 else max(8, k // 2), seed=n + d, spread=10.0 if n == 60000 else 6.0)
-    # (the padded shapes -- 300 -> 512, 7 -> 16 features -- always take the LISTED pass, whatever the list's length:
+    # (the padded shapes -- 300 -> 512, 12 -> 16 features -- always take the LISTED pass, whatever the list's length:
     #  the gathered, zero-padding instantiations of the coarse stage are the ones to exercise there)
-    padded = d in (300, 7)
+    padded = d in (300, 12)
     log, spared, last = _run_pair(x, k, iters=14, carry_from=3, fused=fused, list_max=1.0 if padded else None)
     assert spared > 0, (log, spared, last)
     if n == 60000:
