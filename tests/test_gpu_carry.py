@@ -231,3 +231,34 @@ def test_an_exact_pass_or_a_filter_change_between_carried_passes_voids_the_bound
             loop.b.synchronize()
         assert (plain.b.assignments == carry.b.assignments).all(), it
         assert (plain.b.centroids.view(torch.int32) == carry.b.centroids.view(torch.int32)).all(), it
+
+
+def test_carried_passes_at_shard_scale():
+    """One rank's share of the benchmark's shape -- 1M x 256 rows, K = 1024 -- on a mixture of 1024 Gaussians: 16
+    iterations with and without the bounds, compared on the device after every iteration."""
+    from kmcuda_amd.distributed import HipBackend, ShardedLloyd
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    n, d, k = 1000000, 256, 1024
+    centres = torch.rand((k, d), device=dev, generator=g) * 10.0
+    x = torch.randn((n, d), device=dev, generator=g) + centres[torch.randint(0, k, (n,), device=dev, generator=g)]
+    init = x[torch.randperm(n, device=dev, generator=g)[:k]].clone()
+    loops = []
+    for which in range(2):
+        loop = ShardedLloyd(HipBackend(x, k, "L2", device_index=0), n)
+        loop.set_centroids(init)
+        loops.append(loop)
+    plain, carry = loops
+    for it in range(16):
+        if it == 3:
+            carry.b.engine.set_carry(True)
+        for loop in loops:
+            loop.step(tolerance=0.0)
+        for loop in loops:
+            loop.b.synchronize()
+        assert torch.equal(plain.b.assignments, carry.b.assignments), it
+        assert torch.equal(plain.b.assignments_prev, carry.b.assignments_prev), it
+        assert torch.equal(plain.b.centroids.view(torch.int32), carry.b.centroids.view(torch.int32)), it
+    spared, last = carry.b.engine.carry_stats()
+    assert spared > 4 * n and last < n // 2, (spared, last)
