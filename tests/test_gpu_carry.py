@@ -262,3 +262,17 @@ def test_carried_passes_at_shard_scale():
         assert torch.equal(plain.b.centroids.view(torch.int32), carry.b.centroids.view(torch.int32)), it
     spared, last = carry.b.engine.carry_stats()
     assert spared > 4 * n and last < n // 2, (spared, last)
+
+
+def test_kmeans_cuda_fp16_l2_carries_and_equals_the_plain_schedule(monkeypatch):
+    """The fp16x2 path (half rows at the boundary, centroids rounded to half after every update): carried bounds
+    against plain passes through kmeans_cuda()."""
+    from kmcuda_amd import kmeans_cuda
+    x = _blobs(100000, 64, 40, seed=31, spread=9.0).astype(numpy.float16)
+    res = []
+    for carry in ("1", "0"):
+        monkeypatch.setenv("KMCUDA_AMD_CARRY", carry)
+        res.append(kmeans_cuda(x, 40, init="random", seed=5, tolerance=0.0002, yinyang_t=0.1, device=1, verbosity=0))
+    assert res[0][0].dtype == numpy.float16
+    assert (res[0][1] == res[1][1]).all()
+    assert (res[0][0].view(numpy.uint16) == res[1][0].view(numpy.uint16)).all()
