@@ -210,6 +210,19 @@ def test_cosine_metric_5():
     assert assignments.min() == 0 and assignments.max() == 3
 
 
+def test_cosine_metric2_centroids_stay_on_the_unit_sphere():
+    """test.py:450-457: 16000 x 4 unit rows, K = 50, every default (k-means++, yinyang_t = 0.1, tolerance 0.01):
+    the centroids come out with unit norm."""
+    from kmcuda_amd import kmeans_cuda
+    numpy.random.seed(0)
+    samples = numpy.random.random((16000, 4)).astype(numpy.float32)
+    samples /= numpy.linalg.norm(samples, axis=1)[:, numpy.newaxis]
+    centroids, assignments = kmeans_cuda(samples, 50, metric="cos", verbosity=0, seed=3, device=1)
+    assert centroids.shape == (50, 4) and assignments.shape == (16000,)
+    for c in centroids:
+        assert 0.9999 < numpy.linalg.norm(c) < 1.0001
+
+
 def test_cosine_rejects_unnormalised():
     from kmcuda_amd import kmeans_cuda
     arr = numpy.random.RandomState(0).rand(1000, 8).astype(numpy.float32)
