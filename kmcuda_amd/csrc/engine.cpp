@@ -587,7 +587,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
     // Carried bounds (lloyd_carry.hip): in the steady state the pass can leave per-row distance bounds behind and the
     // next one only looks at the rows they do not decide.  The drift of this pass's centroids against the last pass's
     // is the preparation kernel's (exactly one preparation since: anything else voids the bounds).
-    bool carry = carry_on_ && steady && cached && metric_ == 0;
+    bool carry = carry_on_ && steady && cached;
     if (carry && carry_pause_ > 0) {   // the bounds decided next to nothing lately: plain passes for a while
       carry_pause_--;
       carry = false;
@@ -609,6 +609,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
     if (carry && carry_on_) {
       CarryArgs cy;
       cy.ub = ub_; cy.lb = lb_; cy.host_report = host_carry_dev_; cy.seq = ++carry_seq_;
+      cy.angular = metric_ != 0;
       const bool moved = carry_was_valid && carry_preps_ == 1;   // drift_ / stats_[6] belong to the bounds
       uint32_t hint = 0xFFFFFFFFu;
       bool listed = false;
@@ -632,7 +633,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
         }
         if (listed) hint = last;
         KMX_HIP(launch_carry_skip(N_, K_, assignments, assignments_prev, ub_, lb_, xmeta_, drift_, stats_, tie_slack_,
-                                  carry_list_, counters_, !listed, stream_),
+                                  carry_list_, counters_, !listed, metric_ != 0, stream_),
                 kRuntimeError);
         cy.n_list = counters_ + kCarryCursor;
       }

@@ -48,6 +48,9 @@ struct CarryArgs {
   const uint32_t *n_list = nullptr;     // ... and their number, on the device
   uint32_t *host_report = nullptr;      // device address of 2 pinned words: [0] <- the list's length (N for a whole pass), [1] <- seq
   uint32_t seq = 0;
+  // angular metric: ub[] holds the certified SCORE gap between the row's centroid and every other one instead (the
+  // reference decides on products there; |x.(c_new - c_old)| <= ||x|| ||c_new - c_old|| moves it), lb[] is unused
+  int angular = 0;
 };
 // the device-side stop rule of launch_apply_delta (reference: check_changed, kmeans.cu:697-717)
 struct StopCtl {
@@ -104,7 +107,7 @@ hipError_t launch_lloyd_coarse_carry(const LloydArgs &a, const void *rows, bool 
                                      const CarryArgs &cy, uint32_t rows_hint, hipStream_t st);
 hipError_t launch_carry_skip(uint32_t N, uint32_t K, const uint32_t *assignments, uint32_t *assignments_prev, float *ub,
                              float *lb, const float *xmeta, const float *drift, const uint32_t *stats, float tie_slack,
-                             uint32_t *row_list, uint32_t *counters, bool probe, hipStream_t st);
+                             uint32_t *row_list, uint32_t *counters, bool probe, bool angular, hipStream_t st);
 // the reference's exact sum_squares (csqr) + the transposed panel (ct) alone: what the pair / exact kernels read
 hipError_t launch_centroid_rows(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t Kt, float *csqr,
                                 float *ct, hipStream_t st);

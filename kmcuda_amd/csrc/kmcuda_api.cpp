@@ -1868,7 +1868,7 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
       bool bounds = !adaptive;
       if (adaptive) {
         const char *cv = getenv("KMCUDA_AMD_CARRY");
-        const bool carry = !(cv && atoi(cv) == 0) && metric == kmcudaDistanceMetricL2 && !wide;
+        const bool carry = !(cv && atoi(cv) == 0) && !wide;
         INFO(carry ? "Lloyd goes on, carrying per-sample distance bounds from pass to pass\n" : "Lloyd goes on\n");
         for (auto &s : job.shards) {
           s->eng->carry_on_ = carry;

@@ -18,7 +18,13 @@
 // checked in float64 in tests/test_carry_bound_model.py.
 //
 // drift(c) comes out of the preparation kernel (centroid_prep_frozen_kernel: the centred panel it overwrites IS the
-// previous pass's centroid, the mean being frozen), max drift in stats[6].  L2 only.
+// previous pass's centroid, the mean being frozen), max drift in stats[6].
+//
+// Angular metric: the reference decides on PRODUCTS there (acos is monotone; its plateaus are the filter's tie slack),
+// and the score s(c) = x.(c - mu) moves by at most ||x|| ||c_new - c_old|| whatever the norms are -- no angles, no unit
+// length assumed.  One number per row then: the certified gap (v1 - e_c) - (v2 + e_c) between the row's centroid and the
+// best of the others, shrunk every pass by ||x|| (drift(a) + max drift); the row is spared while it exceeds 4 E_ref +
+// the tie slack.
 #include "lloyd_coarse.hpp"
 
 namespace kmx {
@@ -32,7 +38,7 @@ __global__ __launch_bounds__(kSkipBlock) void carry_skip_kernel(
     uint32_t N, uint32_t K, const uint32_t *__restrict__ assignments, uint32_t *__restrict__ assignments_prev,
     float *__restrict__ ub, float *__restrict__ lb, const float2 *__restrict__ xmeta, float mu_norm_at,
     const float *__restrict__ drift, const uint32_t *__restrict__ stats, float tie_slack, uint32_t *__restrict__ row_list,
-    uint32_t *__restrict__ counters, int probe) {
+    uint32_t *__restrict__ counters, int probe, int angular) {
   if (counters[kStopFlag] != 0u) return;   // the run has stopped on the device: touch nothing
   (void)mu_norm_at;
   const float maxdrift = __uint_as_float(stats[6]);                       // +inf if any drift is not finite
@@ -51,15 +57,26 @@ __global__ __launch_bounds__(kSkipBlock) void carry_skip_kernel(
     if (live) {
       const uint32_t a = assignments[s];
       if (a < K) {
-        // (rounded away from the certificate: the sums up, the differences down)
-        const float un = (ub[s] + drift[a]) * 1.0000005f, ln = (lb[s] - maxdrift) * 0.9999995f;
-        const float xo = (sqrtf(xmeta[s].x) * 1.0001f + mu_norm) * 1.0001f;
+        const float xo = (sqrtf(xmeta[s].x) * 1.0001f + mu_norm) * 1.0001f;   // ||x|| <= ||x - mu|| + ||mu||
         const float e_ref = u * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
-        keep = (ln > un) && ((ln - un) * (ln + un) > 4.1f * e_ref + 2.0f * tie_slack);   // a NaN anywhere: false
-        if (keep && !probe) {
-          ub[s] = un;
-          lb[s] = ln;
-          if (assignments_prev[s] != a) assignments_prev[s] = a;
+        if (angular) {
+          // score space: s(c) = x.(c - mu) moves by at most ||x|| ||c_new - c_old||; the certified gap shrinks by that
+          // for the row's centroid and for the best of the others
+          const float g = ub[s] - xo * (drift[a] + maxdrift) * 1.000001f;
+          keep = g > 4.1f * e_ref + 2.0f * tie_slack;   // (-inf, NaN: false)
+          if (keep && !probe) {
+            ub[s] = g * 0.999999f;
+            if (assignments_prev[s] != a) assignments_prev[s] = a;
+          }
+        } else {
+          // (rounded away from the certificate: the sums up, the differences down)
+          const float un = (ub[s] + drift[a]) * 1.0000005f, ln = (lb[s] - maxdrift) * 0.9999995f;
+          keep = (ln > un) && ((ln - un) * (ln + un) > 4.1f * e_ref + 2.0f * tie_slack);   // a NaN anywhere: false
+          if (keep && !probe) {
+            ub[s] = un;
+            lb[s] = ln;
+            if (assignments_prev[s] != a) assignments_prev[s] = a;
+          }
         }
       }
     }
@@ -103,11 +120,11 @@ __global__ __launch_bounds__(kSkipBlock) void carry_skip_kernel(
 
 hipError_t launch_carry_skip(uint32_t N, uint32_t K, const uint32_t *assignments, uint32_t *assignments_prev, float *ub,
                              float *lb, const float *xmeta, const float *drift, const uint32_t *stats, float tie_slack,
-                             uint32_t *row_list, uint32_t *counters, bool probe, hipStream_t st) {
+                             uint32_t *row_list, uint32_t *counters, bool probe, bool angular, hipStream_t st) {
   const uint32_t chunk = kSkipBlock * kSkipRowsPerThread;
   hipLaunchKernelGGL(carry_skip_kernel, dim3((N + chunk - 1) / chunk), dim3(kSkipBlock), 0, st, N, K, assignments,
                      assignments_prev, ub, lb, reinterpret_cast<const float2 *>(xmeta), 0.f, drift, stats, tie_slack,
-                     row_list, counters, probe ? 1 : 0);
+                     row_list, counters, probe ? 1 : 0, angular ? 1 : 0);
   return hipGetLastError();
 }
 

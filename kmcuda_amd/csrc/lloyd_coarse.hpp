@@ -364,7 +364,14 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
       // Every centroid other than i1 scored <= v2.  A row that stage 2 / the settle kernels decide may end on another
       // contender than i1: its lower bound is void (0: the next pass looks at it again); ub stays valid, the final
       // centroid being the reference's nearest (carried bounds).
-      if (mine) {
+      if (mine && cy.angular) {
+        // the certified gap of the scores (= products up to a term constant in c): what is left of it after the
+        // centroids' moves is what carry_skip_kernel tests
+        const float e = e_c * 1.001f;
+        float gapv = (certain && !insane && in_range) ? ((v1 - e) - (v2 + e)) * 0.999999f : -INFINITY;
+        if (!(gapv == gapv)) gapv = -INFINITY;
+        cy.ub[s] = gapv;
+      } else if (mine) {
         float ubv = INFINITY, lbv = 0.f;
         if (!insane && in_range) {
           const float e = e_c * 1.001f;

@@ -116,3 +116,65 @@ def test_a_spared_row_keeps_its_centroid_in_the_references_arithmetic(case):
         assert kept_total > n          # the test is not vacuous: most rows are spared in most variants
     if case == "big-drift":
         assert kept_total < 5 * n
+
+
+@pytest.mark.parametrize("case", ["unit-blobs", "unit-uniform", "not-unit"])
+def test_a_spared_row_keeps_its_centroid_under_the_angular_metric(case):
+    """Angular metric: the certified SCORE gap s(a) - s(c), s(c) = x.(c - mu), shrunk by ||x|| (drift(a) + max drift)
+    per pass (carry_skip_kernel, angular branch).  A kept row must have x.c_a - x.c_c > 4 E_ref + 2 tie for every other
+    NEW centroid in exact arithmetic -- for rows and centroids of any norm."""
+    rs = numpy.random.RandomState(len(case) + 5)
+    n, d, k = 4000, 48, 40
+    if case == "unit-blobs":
+        cen = rs.randn(k, d)
+        x = cen[rs.randint(0, k, n)] + 0.1 * rs.randn(n, d)
+    else:
+        x = rs.rand(n, d)
+    x = x / numpy.linalg.norm(x, axis=1, keepdims=True)
+    if case == "not-unit":
+        x = x * (0.5 + rs.rand(n, 1))
+    x = x.astype(F)
+    c_old = x[rs.choice(n, k, replace=False)].astype(F)
+    c_new = (c_old + (0.003 * rs.randn(k, d)).astype(F)).astype(F)
+    c_new = (c_new / numpy.linalg.norm(c_new.astype(numpy.float64), axis=1, keepdims=True)).astype(F)
+    mu = c_old.mean(axis=0, dtype=numpy.float64).astype(F)
+    eps = F(1.02 * (d + 12.0) * 5.9604644775390625e-8)
+    tie = F(1e-6)
+    x64, co64, cn64, mu64 = (a.astype(numpy.float64) for a in (x, c_old, c_new, mu))
+    xc = (x - mu[None, :]).astype(F)
+    cc_old = (c_old - mu[None, :]).astype(F)
+    cc_new = (c_new - mu[None, :]).astype(F)
+    xn2 = (xc * xc).sum(axis=1, dtype=F)
+    xn = (numpy.sqrt(xn2).astype(F) * F(1.0001)).astype(F)
+    cmaxc = F(numpy.sqrt((cc_old.astype(numpy.float64) ** 2).sum(axis=1).max()) * 1.000001)
+    bmaxc = F(numpy.abs(cc_old.astype(numpy.float64) @ mu64).max())
+    s_old = x64 @ (co64 - mu64).T                       # exact scores of the old centroids
+    order = numpy.argsort(-s_old, axis=1)
+    a = order[:, 0]
+    s1 = s_old[numpy.arange(n), a]
+    s2 = s_old[numpy.arange(n), order[:, 1]]
+    e_c = (F(2.0) * eps * (xn * cmaxc + bmaxc) + F(2.0 ** -10) * xn * cmaxc).astype(F)
+    mu_norm = F(numpy.sqrt((mu64 ** 2).sum()) * 1.00001)
+    cmaxo = F(numpy.sqrt((cn64 ** 2).sum(axis=1).max()) * 1.000001)
+    drift = _drift(cc_new, cc_old)
+    maxdrift = drift.max()
+    xo = ((numpy.sqrt(xn2).astype(F) * F(1.0001) + mu_norm) * F(1.0001)).astype(F)
+    assert (xo.astype(numpy.float64) >= numpy.linalg.norm(x64, axis=1)).all()
+    e_ref = (U * (F(12.0) * xo * cmaxo + F(4.0) * cmaxo * cmaxo)).astype(F)
+    p_new = x64 @ cn64.T                                # what the reference compares (up to its rounding)
+    kept_total = 0
+    for sign1, sign2 in ((+1, -1), (-1, +1), (0, 0)):
+        v1 = (s1 + sign1 * e_c.astype(numpy.float64) * 0.999).astype(F)
+        v2 = (s2 + sign2 * e_c.astype(numpy.float64) * 0.999).astype(F)
+        e = (e_c * F(1.001)).astype(F)
+        gap = (((v1 - e) - (v2 + e)) * F(0.999999)).astype(F)
+        g = (gap - xo * (drift[a] + maxdrift) * F(1.000001)).astype(F)
+        keep = g > F(4.1) * e_ref + F(2.0) * tie
+        kept_total += int(keep.sum())
+        pa = p_new[numpy.arange(n), a]
+        others = p_new.copy()
+        others[numpy.arange(n), a] = -numpy.inf
+        true_gap = pa - others.max(axis=1)
+        assert (true_gap[keep] > 4.0 * e_ref[keep].astype(numpy.float64) + 2.0 * float(tie)).all()
+    if case == "unit-blobs":
+        assert kept_total > n
