@@ -25,6 +25,8 @@
 // length assumed.  One number per row then: the certified gap (v1 - e_c) - (v2 + e_c) between the row's centroid and the
 // best of the others, shrunk every pass by ||x|| (drift(a) + max drift); the row is spared while it exceeds 4 E_ref +
 // the tie slack.
+#include <cstdlib>
+
 #include "lloyd_coarse.hpp"
 
 namespace kmx {
@@ -147,9 +149,15 @@ static hipError_t launch_coarse_carry_dp(const LloydArgs &a, const void *rows, b
   }
   // the listed rows: blocks past the (device-side) end of the list leave at once; the grid follows the host's
   // estimate of the list so that a short list does not dispatch N / 256 of them
+  // (the kernel strides: a list longer than the estimate costs time, never rows.  KMCUDA_AMD_CARRY_GRID caps the
+  // grid -- the tests' way of making every block take several trips)
   if (rows_hint != 0xFFFFFFFFu) {
     const uint32_t want = rows_hint / rows_per_block + rows_hint / (4 * rows_per_block) + 64;
     if (want < grid) grid = want;
+  }
+  if (const char *v = getenv("KMCUDA_AMD_CARRY_GRID")) {
+    const long cap = atol(v);
+    if (cap > 0 && (uint32_t)cap < grid) grid = (uint32_t)cap;
   }
   if (half_rows) {
     if (fast) KMX_CARRY_LAUNCH(true, true, false, 2, rows); else KMX_CARRY_LAUNCH(true, false, false, 2, rows);

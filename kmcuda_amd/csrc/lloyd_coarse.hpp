@@ -73,10 +73,9 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 31, h = lane >> 5;
   constexpr int WV = 4;
   constexpr bool TWO = NSET == 2;
-  const uint32_t posA = blockIdx.x * (128u * NSET) + wave * (32u * NSET) + col, posB = posA + 32u;
   uint32_t total = N;
   if constexpr (CARRY == 2) {
-    total = *cy.n_list;
+    total = __builtin_amdgcn_readfirstlane(*cy.n_list);
     if (blockIdx.x * (128u * NSET) >= total) return;   // (block-uniform, in front of every barrier and DMA)
   }
   if constexpr (CARRY != 0) {   // how long this pass's list was: the host sizes later passes by it
@@ -86,6 +85,12 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
       hr[1] = cy.seq;
     }
   }
+  // The listed pass's grid follows the host's ESTIMATE of the list (an earlier pass's length): the blocks stride over
+  // the list, whose length only the device knows -- a cluster that dies, say, turns every drift bound into +inf and
+  // lists every row.  Every other instantiation makes one trip (its block index is its 128 NSET rows).
+  for (uint32_t blk = blockIdx.x;;) {
+  blk = __builtin_amdgcn_readfirstlane(blk);
+  const uint32_t posA = blk * (128u * NSET) + wave * (32u * NSET) + col, posB = posA + 32u;
   const bool liveA = posA < total, liveB = TWO && posB < total;
   uint32_t sA = posA, sB = posB;
   if constexpr (CARRY == 2) {
@@ -440,6 +445,14 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
       undecided[at] = sB;
       und_thr[at] = cutb;
     }
+  }
+  if constexpr (CARRY != 2) {
+    break;
+  } else {
+    blk += gridDim.x;
+    if ((uint64_t)blk * (128u * NSET) >= total) break;   // (block-uniform)
+    __syncthreads();   // the tiles, the mean and the block sums in LDS belong to the next trip from here on
+  }
   }
 }
 

@@ -101,6 +101,23 @@ def test_carried_passes_equal_plain_passes_on_clustered_rows(shape, fused):
         assert spared > 3 * n and last < n // 2, (log, spared, last)
 
 
+@pytest.mark.parametrize("metric", ["L2", "cos"])
+def test_a_list_longer_than_the_listed_pass_s_grid_is_strided_over(metric, monkeypatch):
+    """The listed pass is launched for the host's ESTIMATE of the list; the device-side list can be any length (a
+    cluster that dies makes every drift bound +inf: every row is listed).  KMCUDA_AMD_CARRY_GRID=3: every block takes
+    dozens of trips over the list."""
+    monkeypatch.setenv("KMCUDA_AMD_CARRY_GRID", "3")
+    x = _blobs(60000, 64, 64, seed=60064, spread=10.0)
+    if metric == "cos":
+        x /= numpy.linalg.norm(x, axis=1, keepdims=True)
+    log, spared, last = _run_pair(x, 64, iters=12, carry_from=3, fused=True, metric=metric, list_max=1.0)
+    assert spared > 0 and last > 3 * 256, (log, spared, last)
+    y = _uniform(30000, 200, seed=4)   # (padded rows, next to nothing spared: ~117 trips per block)
+    if metric == "cos":
+        y /= numpy.linalg.norm(y, axis=1, keepdims=True)
+    _run_pair(y, 100, iters=6, carry_from=2, fused=False, metric=metric, list_max=1.0)
+
+
 @pytest.mark.parametrize("list_max", [None, 1.0, 0.0], ids=["default", "always-listed", "never-listed"])
 def test_carried_passes_equal_plain_passes_on_unstructured_rows(list_max):
     # uniform rows: the bounds spare next to nothing -- the listed pass (forced: KMCUDA_AMD_CARRY_MAX=1) then covers
