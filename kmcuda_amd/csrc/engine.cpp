@@ -591,10 +591,12 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
     if (carry && carry_pause_ > 0) {   // the bounds decided next to nothing lately: plain passes for a while
       carry_pause_--;
       carry = false;
+      if (getenv("KMCUDA_AMD_CARRY_TRACE")) fprintf(stderr, "[carry] paused (%u more)\n", carry_pause_);
     }
     if (carry && !ub_) {
       // (no memory: not an error, plain passes)
-      if (alloc(&ub_, N_) != kSuccess || alloc(&lb_, N_) != kSuccess || alloc(&drift_, K_) != kSuccess ||
+      if (alloc(&ub_, N_) != kSuccess || alloc(&lb_, N_) != kSuccess || alloc(&drift_, 2 * (size_t)K_) != kSuccess ||   // (+ K bias changes: the angular metric)
+         
           alloc(&carry_list_, N_) != kSuccess || !(host_carry_ = pinned_words(2, &host_carry_dev_))) {
         (void)hipGetLastError();
         carry_on_ = false;
@@ -618,17 +620,18 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
         // on it): a short list -> the listed pass; else every row from the row cache, the list only counted
         const uint32_t last = host_carry_[0], last_seq = host_carry_[1];
         listed = last != 0xFFFFFFFFu && (float)last <= carry_list_max_ * (float)N_;
-        if (last != 0xFFFFFFFFu && last_seq != carry_seen_seq_) {   // a report not judged yet
+        if (last != 0xFFFFFFFFu && (int32_t)(last_seq - carry_seen_seq_) > 0) {   // a report not judged yet
           carry_seen_seq_ = last_seq;
           if ((float)last > 0.9f * (float)N_ && carry_list_max_ < 1.0f) {
             if (++carry_hopeless_ >= 2) {
               carry_pause_ = carry_backoff_;
-              carry_backoff_ = carry_backoff_ < 64 ? 2 * carry_backoff_ : 64;
+              carry_backoff_ = carry_backoff_ < 32 ? 2 * carry_backoff_ : 32;
               carry_hopeless_ = 0;
+              carry_seen_seq_ = carry_seq_;   // what the passes up to this one report describes the drifts before the pause
             }
           } else {
             carry_hopeless_ = 0;
-            carry_backoff_ = 8;
+            carry_backoff_ = 4;
           }
         }
         if (listed) hint = last;
@@ -638,6 +641,20 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
         cy.n_list = counters_ + kCarryCursor;
       }
       if (listed) cy.row_list = carry_list_;
+      static const bool trace = getenv("KMCUDA_AMD_CARRY_TRACE") != nullptr;
+      if (trace) {   // (debugging aid: synchronises)
+        uint32_t w[8] = {0};
+        (void)hipStreamSynchronize(stream_);
+        (void)hipMemcpy(w, stats_, sizeof(w), hipMemcpyDeviceToHost);
+        float f[8];
+        memcpy(f, w, sizeof(f));
+        fprintf(stderr, "[carry] stats: max ||c'||^2 %g, max |bias| %g, max ||c||^2 %g, max residual^2 %g, max drift %g, max bias change %g\n",
+                f[0], f[1], f[2], f[5], f[6], f[7]);
+      }
+      if (trace)
+        fprintf(stderr, "[carry] pass %u: bounds %s, %u preparation(s) since, last reported list %u (pass %u), %s\n",
+                carry_seq_, carry_was_valid ? "valid" : "void", carry_preps_, host_carry_[0], host_carry_[1],
+                listed ? "listed pass" : (moved ? "whole pass, list counted" : "whole pass"));
       KMX_HIP(launch_lloyd_coarse_carry(a, rows, half, xcache_, xmeta_, panelhi_, undecided_, und_thr_, cy, hint, stream_),
               kRuntimeError);
       carry_valid_ = true;

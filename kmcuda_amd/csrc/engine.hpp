@@ -137,15 +137,16 @@ class Engine {
   float *xmeta_ = nullptr;
   // Bounds carried from pass to pass (lloyd_carry.hip; kmamd_set_carry): per-row upper / lower distance bounds read
   // off the coarse stage's best two scores, moved by the centroids' drifts, sparing the rows they still decide.
-  // L2, two-stage filter with a valid row cache only; any other state runs plain passes.
+  // (Angular metric: one number per row, the certified gap of the scores, in ub_; the centroids' bias changes behind
+  // the drifts in drift_.)  Two-stage filter with a valid row cache only; any other state runs plain passes.
   bool carry_on_ = false;        // the caller wants it
   bool carry_valid_ = false;     // ub_ / lb_ describe the assignments and the centroids of the last pass
   uint32_t carry_preps_ = 0;     // centroid preparations since the last pass (exactly 1: drift_ is that update's)
   uint32_t carry_seq_ = 0;
   float carry_list_max_ = 0.5f;  // a listed pass when at most this share of the rows is on the list (KMCUDA_AMD_CARRY_MAX)
   // rows the bounds cannot decide (unstructured data): after two lists in a row beyond 90 % of the rows the passes
-  // go plain for carry_backoff_ iterations (8, doubling up to 64), then the bounds are tried again
-  uint32_t carry_pause_ = 0, carry_backoff_ = 8, carry_hopeless_ = 0, carry_seen_seq_ = 0;
+  // go plain for carry_backoff_ iterations (4, doubling up to 32), then the bounds are tried again
+  uint32_t carry_pause_ = 0, carry_backoff_ = 4, carry_hopeless_ = 0, carry_seen_seq_ = 0;
   float *ub_ = nullptr, *lb_ = nullptr, *drift_ = nullptr;
   uint32_t *carry_list_ = nullptr;
   uint32_t *host_carry_ = nullptr, *host_carry_dev_ = nullptr;   // 2 pinned words: [0] the last list's length, [1] seq

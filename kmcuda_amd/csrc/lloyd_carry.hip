@@ -21,10 +21,13 @@
 // previous pass's centroid, the mean being frozen), max drift in stats[6].
 //
 // Angular metric: the reference decides on PRODUCTS there (acos is monotone; its plateaus are the filter's tie slack),
-// and the score s(c) = x.(c - mu) moves by at most ||x|| ||c_new - c_old|| whatever the norms are -- no angles, no unit
-// length assumed.  One number per row then: the certified gap (v1 - e_c) - (v2 + e_c) between the row's centroid and the
-// best of the others, shrunk every pass by ||x|| (drift(a) + max drift); the row is spared while it exceeds 4 E_ref +
-// the tie slack.
+// and the score s(c) = x'.c' + mu.c' (primes: centred by the frozen mean mu) moves by at most ||x'|| ||c_new - c_old||
+// plus the change db(c) of its second term -- which is the filter's bias, known per centroid -- whatever the norms are:
+// no angles, no unit length assumed.  One number per row then: the certified gap (v1 - e_c) - (v2 + e_c) between the
+// row's centroid and the best of the others, shrunk every pass by ||x'|| (drift(a) + max drift) + max_c db(c) - db(a);
+// the row is spared while it exceeds 4 E_ref + the tie slack.  (Charging ||x|| ||c_new - c_old|| instead -- the rows
+// as they are -- spares nothing on rows that share a direction, the usual case for unit rows with positive entries:
+// ||x'|| is a fraction of ||x|| there.)
 #include <cstdlib>
 
 #include "lloyd_coarse.hpp"
@@ -47,6 +50,11 @@ __global__ __launch_bounds__(kSkipBlock) void carry_skip_kernel(
   const float cmaxo = sqrtf(__uint_as_float(stats[2])) * 1.000001f;       // max ||c|| of THIS pass's centroids
   const float mu_norm = reinterpret_cast<const float *>(xmeta)[2 * (((size_t)N + 255) / 256 * 256)];
   const float u = 5.9604645e-8f;
+  // angular: max(0, max_c db(c)) and the rounding of the four fp32 sums mu.c' behind two differences of them (each
+  // within (DP + 2) u ||mu|| ||c'||, DP <= 512; ||c'_old|| <= ||c'_new|| + drift)
+  const float maxdb = __uint_as_float(stats[7]);
+  const float cmaxc = sqrtf(__uint_as_float(stats[0])) * 1.000001f;
+  const float eb = 4.0f * 520.0f * u * mu_norm * (cmaxc + maxdrift);
   const uint32_t chunk = kSkipBlock * kSkipRowsPerThread;
   const uint32_t base = blockIdx.x * chunk;
   __shared__ uint32_t wave_cnt[kSkipBlock / 64], blk_base;
@@ -62,9 +70,11 @@ __global__ __launch_bounds__(kSkipBlock) void carry_skip_kernel(
         const float xo = (sqrtf(xmeta[s].x) * 1.0001f + mu_norm) * 1.0001f;   // ||x|| <= ||x - mu|| + ||mu||
         const float e_ref = u * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
         if (angular) {
-          // score space: s(c) = x.(c - mu) moves by at most ||x|| ||c_new - c_old||; the certified gap shrinks by that
-          // for the row's centroid and for the best of the others
-          const float g = ub[s] - xo * (drift[a] + maxdrift) * 1.000001f;
+          // score space: s(c) = x'.c' + mu.c' moves by at most ||x'|| ||c_new - c_old|| plus the change db(c) of its
+          // second term, known per centroid: the certified gap shrinks by the first for the row's centroid and for the
+          // best of the others, and by max_c db(c) - db(a)
+          const float xn = sqrtf(xmeta[s].x) * 1.0001f;
+          const float g = ub[s] - (xn * (drift[a] + maxdrift) + (maxdb - drift[K + a]) + eb) * 1.000001f;
           keep = g > 4.1f * e_ref + 2.0f * tie_slack;   // (-inf, NaN: false)
           if (keep && !probe) {
             ub[s] = g * 0.999999f;

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   if constexpr (CARRY != 0) {   // how long this pass's list was: the host sizes later passes by it
     if (blockIdx.x == 0 && threadIdx.x == 0 && cy.host_report) {
       volatile uint32_t *hr = cy.host_report;
-      hr[0] = cy.n_list ? *cy.n_list : N;
+      hr[0] = cy.n_list ? *cy.n_list : 0xFFFFFFFFu;   // (a pass without bounds to move has no list to report)
       hr[1] = cy.seq;
     }
   }

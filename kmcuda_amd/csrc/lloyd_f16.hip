@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void centroid_prep_frozen_kernel(
     }
     update = !stop;
   }
-  uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0;
+  uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
   for (uint32_t i = 0; i < 4; i++) {
     const uint32_t c = blockIdx.x * 16 + wave * 4 + i;
     if (c >= K_pad64) break;
@@ -183,14 +183,22 @@ __global__ __launch_bounds__(256) void centroid_prep_frozen_kernel(
     }
     s5 = max(s5, ((res2 - res2) == 0.f) ? __float_as_uint(res2 * 1.0001f) : 0x7F800000u);
     if (lane == 0) {
+      if (METRIC != 0 && drift && c < K) {
+        // angular: the score x'.c' + mu.c' moves by at most ||x'|| drift(c) PLUS this, known per centroid (the bias
+        // is mu.c', the mean being frozen): carry_skip_kernel charges a row max_c(db) - db(its centroid)
+        const float db = b - bias[c];
+        drift[K + c] = db;
+        if (ok && (db - db) == 0.f && db > 0.f) s7 = max(s7, __float_as_uint(db * 1.000001f));
+        else if (ok && !((db - db) == 0.f)) s7 = 0x7F800000u;
+      }
       if (real) { bias[c] = b; bias2[c] = b2; }
       reinterpret_cast<float *>(panelhi + (size_t)K_pad64 * DP)[c] = real ? fmaxf(b, -3.0e38f) : -3.0e38f;
     }
   }
-  __shared__ uint32_t red[4][7];
-  if (lane == 0) { red[wave][0] = s0; red[wave][1] = s1; red[wave][2] = s2; red[wave][3] = s3; red[wave][4] = s4; red[wave][5] = s5; red[wave][6] = s6; }
+  __shared__ uint32_t red[4][8];
+  if (lane == 0) { red[wave][0] = s0; red[wave][1] = s1; red[wave][2] = s2; red[wave][3] = s3; red[wave][4] = s4; red[wave][5] = s5; red[wave][6] = s6; red[wave][7] = s7; }
   __syncthreads();
-  if (threadIdx.x < 7) {
+  if (threadIdx.x < 8) {
     const uint32_t m = max(max(red[0][threadIdx.x], red[1][threadIdx.x]), max(red[2][threadIdx.x], red[3][threadIdx.x]));
     if (m) atomicMax(&stats[threadIdx.x], m);
   }

@@ -120,8 +120,8 @@ def test_a_spared_row_keeps_its_centroid_in_the_references_arithmetic(case):
 
 @pytest.mark.parametrize("case", ["unit-blobs", "unit-uniform", "not-unit"])
 def test_a_spared_row_keeps_its_centroid_under_the_angular_metric(case):
-    """Angular metric: the certified SCORE gap s(a) - s(c), s(c) = x.(c - mu), shrunk by ||x|| (drift(a) + max drift)
-    per pass (carry_skip_kernel, angular branch).  A kept row must have x.c_a - x.c_c > 4 E_ref + 2 tie for every other
+    """Angular metric: the certified SCORE gap s(a) - s(c), s(c) = x'.c' + mu.c', shrunk per pass by
+    ||x'|| (drift(a) + max drift) + max_c db(c) - db(a), db the change of mu.c' (carry_skip_kernel, angular branch).  A kept row must have x.c_a - x.c_c > 4 E_ref + 2 tie for every other
     NEW centroid in exact arithmetic -- for rows and centroids of any norm."""
     rs = numpy.random.RandomState(len(case) + 5)
     n, d, k = 4000, 48, 40
@@ -162,13 +162,20 @@ def test_a_spared_row_keeps_its_centroid_under_the_angular_metric(case):
     assert (xo.astype(numpy.float64) >= numpy.linalg.norm(x64, axis=1)).all()
     e_ref = (U * (F(12.0) * xo * cmaxo + F(4.0) * cmaxo * cmaxo)).astype(F)
     p_new = x64 @ cn64.T                                # what the reference compares (up to its rounding)
+    # the second term of the score, mu.c', as the preparation kernel sums it (fp32), and its change per centroid
+    b_old = (cc_old * mu[None, :]).sum(axis=1, dtype=F)
+    b_new = (cc_new * mu[None, :]).sum(axis=1, dtype=F)
+    db = (b_new - b_old).astype(F)
+    maxdb = F(max(0.0, float(db.max()) * 1.000001))
+    cmaxc_new = F(numpy.sqrt((cc_new.astype(numpy.float64) ** 2).sum(axis=1).max()) * 1.000001)
+    eb = F(4.0) * F(520.0) * U * mu_norm * (cmaxc_new + maxdrift)
     kept_total = 0
     for sign1, sign2 in ((+1, -1), (-1, +1), (0, 0)):
         v1 = (s1 + sign1 * e_c.astype(numpy.float64) * 0.999).astype(F)
         v2 = (s2 + sign2 * e_c.astype(numpy.float64) * 0.999).astype(F)
         e = (e_c * F(1.001)).astype(F)
         gap = (((v1 - e) - (v2 + e)) * F(0.999999)).astype(F)
-        g = (gap - xo * (drift[a] + maxdrift) * F(1.000001)).astype(F)
+        g = (gap - (xn * (drift[a] + maxdrift) + (maxdb - db[a]) + eb) * F(1.000001)).astype(F)
         keep = g > F(4.1) * e_ref + F(2.0) * tie
         kept_total += int(keep.sum())
         pa = p_new[numpy.arange(n), a]
