@@ -192,11 +192,14 @@ def test_random_init_and_silent_group_clustering_leave_rand_where_the_reference_
     assert nxt[0] == nxt[1]
 
 
-def test_carried_bounds_over_virtual_shards(monkeypatch):
+@pytest.mark.parametrize("metric", ["L2", "cos"])
+def test_carried_bounds_over_virtual_shards(metric, monkeypatch):
     """Three row shards on one GPU (KMCUDA_AMD_VIRTUAL_SHARDS: every shard its own engine, bounds, drifts and row
     list; the centroids replicated): the carried schedule equals the plain one there too, and both equal one shard."""
     from kmcuda_amd import kmeans_cuda
     x = _blobs(90000, 32, 50, seed=21, spread=8.0)
+    if metric == "cos":
+        x /= numpy.linalg.norm(x, axis=1, keepdims=True)
     res = {}
     for shards, carry in ((1, "1"), (3, "1"), (3, "0")):
         monkeypatch.setenv("KMCUDA_AMD_CARRY", carry)
@@ -204,7 +207,8 @@ def test_carried_bounds_over_virtual_shards(monkeypatch):
             monkeypatch.setenv("KMCUDA_AMD_VIRTUAL_SHARDS", str(shards))
         else:
             monkeypatch.delenv("KMCUDA_AMD_VIRTUAL_SHARDS", raising=False)
-        res[(shards, carry)] = kmeans_cuda(x, 50, init="random", seed=3, tolerance=0.0002, yinyang_t=0.1, device=1, verbosity=0)
+        res[(shards, carry)] = kmeans_cuda(x, 50, init="random", seed=3, tolerance=0.0002, yinyang_t=0.1, metric=metric,
+                                           device=1, verbosity=0)
     a = res[(3, "1")]
     b = res[(3, "0")]
     assert (a[1] == b[1]).all() and (a[0].view(numpy.uint32) == b[0].view(numpy.uint32)).all()
@@ -317,9 +321,16 @@ def test_kmeans_cuda_angular_carries_and_equals_the_plain_schedule(monkeypatch):
     cen = rs.randn(30, 32)
     x = cen[rs.randint(0, 30, 80000)] + 0.2 * rs.randn(80000, 32)
     x = (x / numpy.linalg.norm(x, axis=1, keepdims=True)).astype(numpy.float32)
+    from test_gpu_kmeans import StdoutListener
     res = []
     for carry in ("1", "0"):
         monkeypatch.setenv("KMCUDA_AMD_CARRY", carry)
-        res.append(kmeans_cuda(x, 30, init="random", seed=5, tolerance=0.0002, yinyang_t=0.1, metric="cos", device=1, verbosity=0))
+        out = StdoutListener()
+        with out:
+            res.append(kmeans_cuda(x, 30, init="random", seed=5, tolerance=0.0002, yinyang_t=0.1, metric="cos", device=1,
+                                   verbosity=2))
+        if carry == "1":   # the bounds did decide rows (a report judged late or twice once paused them for good)
+            spared = [l for l in out.text.split("\n") if l.startswith("carried bounds:")]
+            assert spared and int(spared[0].split()[2]) > len(x), out.text[-600:]
     assert (res[0][1] == res[1][1]).all()
     assert (res[0][0].view(numpy.uint32) == res[1][0].view(numpy.uint32)).all()
