@@ -1,0 +1,77 @@
+"""Randomised side-by-side runs of carried and plain passes (GPU): shapes, metrics, row types, update paths, list
+policies and grid caps drawn at random; every iteration of every trial must leave identical assignments, previous
+assignments and centroids (tests/test_gpu_carry.py::_run_pair).   python scripts/stress_carry.py [seconds] [seed]"""
+import os, sys, time, traceback
+import numpy
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import test_gpu_carry as tc
+
+
+def make(rs, n, d, k, metric):
+    kind = rs.choice(["blobs", "blobs-few", "blobs-many", "uniform", "duplicates", "outliers", "nan"])
+    if kind.startswith("blobs") or kind in ("outliers", "nan"):
+        nb = {"blobs": k, "blobs-few": max(2, k // 3), "blobs-many": 2 * k}.get(kind, k)
+        cen = rs.rand(nb, d) * rs.choice([3.0, 6.0, 10.0]) if rs.rand() < 0.5 else rs.randn(nb, d) * rs.choice([1.0, 4.0])
+        x = cen[rs.randint(0, nb, n)] + rs.choice([0.1, 0.5, 1.0]) * rs.randn(n, d)
+    elif kind == "uniform":
+        x = rs.rand(n, d)
+    else:
+        base = rs.rand(max(k, n // 50), d)
+        x = base[rs.randint(0, len(base), n)]          # many identical rows: ties everywhere
+    x = x.astype(numpy.float64)
+    if metric == "cos":
+        nr = numpy.linalg.norm(x, axis=1, keepdims=True)
+        x = x / numpy.maximum(nr, 1e-12)
+    x = x.astype(numpy.float32)
+    if kind == "outliers":
+        x[rs.randint(0, n, 5)] *= 50.0 if metric == "L2" else 1.0
+    if kind == "nan":
+        x[rs.randint(0, n, 3), rs.randint(0, d, 3)] = numpy.nan
+    return kind, x
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rs = numpy.random.RandomState(seed)
+    t0 = time.time()
+    trials = failures = 0
+    while time.time() - t0 < budget:
+        n = int(rs.choice([1500, 7000, 30000, 90000, 250000]))
+        d = int(rs.choice([12, 16, 24, 32, 48, 64, 100, 128, 200, 256, 300, 512]))
+        k = int(rs.choice([3, 17, 40, 64, 130, 300, 600]))
+        k = min(k, n // 8)
+        metric = str(rs.choice(["L2", "cos"]))
+        half = bool(rs.rand() < 0.3)
+        fused = bool(rs.rand() < 0.5)
+        list_max = [None, 0.0, 1.0, 0.2][rs.randint(0, 4)]
+        grid = [None, 1, 7][rs.randint(0, 3)]
+        iters = int(rs.randint(5, 15))
+        carry_from = int(rs.randint(1, 4))
+        kind, x = make(rs, n, d, k, metric)
+        if grid is None:
+            os.environ.pop("KMCUDA_AMD_CARRY_GRID", None)
+        else:
+            os.environ["KMCUDA_AMD_CARRY_GRID"] = str(grid)
+        os.environ.pop("KMCUDA_AMD_CARRY_MAX", None)
+        desc = "%dx%d@%d %s %s %s %s list_max=%s grid=%s iters=%d from=%d" % (
+            n, d, k, metric, "fp16" if half else "fp32", "fused" if fused else "plain-apply", kind, list_max, grid, iters, carry_from)
+        try:
+            log, spared, last = tc._run_pair(x, k, iters=iters, carry_from=carry_from, fused=fused, half=half,
+                                             seed=int(rs.randint(0, 1000)), list_max=list_max, metric=metric)
+            print("ok   %s: spared %d" % (desc, spared), flush=True)
+        except AssertionError as e:
+            failures += 1
+            print("FAIL %s: %s" % (desc, str(e).split("\n")[0]), flush=True)
+        except Exception:
+            failures += 1
+            print("ERR  %s" % desc, flush=True)
+            traceback.print_exc()
+        trials += 1
+    print("%d trials, %d failures, %.0f s" % (trials, failures, time.time() - t0), flush=True)
+    sys.exit(1 if failures else 0)
+
+
+if __name__ == "__main__":
+    main()
