@@ -648,8 +648,8 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
         (void)hipMemcpy(w, stats_, sizeof(w), hipMemcpyDeviceToHost);
         float f[8];
         memcpy(f, w, sizeof(f));
-        fprintf(stderr, "[carry] stats: max ||c'||^2 %g, max |bias| %g, max ||c||^2 %g, max residual^2 %g, max drift %g, max bias change %g\n",
-                f[0], f[1], f[2], f[5], f[6], f[7]);
+        fprintf(stderr, "[carry] stats: max ||c'||^2 %g, max |bias| %g, max ||c||^2 %g, max residual^2 %g, max drift %g, max bias change %g; "
+                "stage 2 took %u rows of an earlier pass\n", f[0], f[1], f[2], f[5], f[6], f[7], host_move_count_[2]);
       }
       if (trace)
         fprintf(stderr, "[carry] pass %u: bounds %s, %u preparation(s) since, last reported list %u (pass %u), %s\n",

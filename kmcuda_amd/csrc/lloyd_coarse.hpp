@@ -74,16 +74,20 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   constexpr int WV = 4;
   constexpr bool TWO = NSET == 2;
   uint32_t total = N;
-  if constexpr (CARRY == 2) {
-    total = __builtin_amdgcn_readfirstlane(*cy.n_list);
-    if (blockIdx.x * (128u * NSET) >= total) return;   // (block-uniform, in front of every barrier and DMA)
-  }
-  if constexpr (CARRY != 0) {   // how long this pass's list was: the host sizes later passes by it
-    if (blockIdx.x == 0 && threadIdx.x == 0 && cy.host_report) {
-      volatile uint32_t *hr = cy.host_report;
-      hr[0] = cy.n_list ? *cy.n_list : 0xFFFFFFFFu;   // (a pass without bounds to move has no list to report)
-      hr[1] = cy.seq;
+  if constexpr (CARRY == 2) total = __builtin_amdgcn_readfirstlane(*cy.n_list);
+  if constexpr (CARRY != 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (cy.host_report) {   // how long this pass's list was: the host sizes later passes by it
+        volatile uint32_t *hr = cy.host_report;
+        hr[0] = cy.n_list ? *cy.n_list : 0xFFFFFFFFu;   // (a pass without bounds to move has no list to report)
+        hr[1] = cy.seq;
+      }
+      if constexpr (CARRY == 2)   // the rows this pass does not look at (statistics: kmamd_carry_stats)
+        *reinterpret_cast<unsigned long long *>(counters + kCarrySkipped) += (unsigned long long)(N - total);
     }
+  }
+  if constexpr (CARRY == 2) {
+    if (blockIdx.x * (128u * NSET) >= total) return;   // (block-uniform, in front of every barrier and DMA)
   }
   // The listed pass's grid follows the host's ESTIMATE of the list (an earlier pass's length): the blocks stride over
   // the list, whose length only the device knows -- a cluster that dies, say, turns every drift bound into +inf and
