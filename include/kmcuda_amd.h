@@ -137,6 +137,12 @@ int kmamd_centroids_written(kmamd_engine *e);
  * synchronisation), last_list = the length of the newest list the host has heard of (0xFFFFFFFF: none yet). */
 int kmamd_set_carry(kmamd_engine *e, int on);
 int kmamd_carry_stats(kmamd_engine *e, uint64_t *rows_spared, uint32_t *last_list);
+/* L2: a row that stage 2 settles between two contenders carries the pair, an upper bound of both distances and a lower
+ * bound of every other centroid's; while the drifts leave the latter above the former the row goes straight to the
+ * two-contender kernel (the reference's arithmetic and tie rule: kmeans.cu:214-364 restricted to the two) instead of
+ * through the filter.  rows_paired = such row passes since the engine was created (they are not in rows_spared).
+ * KMCUDA_AMD_CARRY_PAIRS=0 in the environment: without (A/B). */
+int kmamd_carry_pair_stats(kmamd_engine *e, uint64_t *rows_paired);
 /* Test / A-B hook for the update's host logic: 0 default, 1 radix path always, 2 always read the
  * counts before choosing (the pre-round-2 behaviour), 3 bucket path always without reading (exercises
  * the device-side fallback of oversized buckets).  Env KMCUDA_AMD_UPDATE=radix|sync|bucket sets it at

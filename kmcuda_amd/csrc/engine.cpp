@@ -143,6 +143,7 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if (getenv("KMCUDA_AMD_DEBUG")) g_verbosity = atoi(getenv("KMCUDA_AMD_DEBUG"));
   if (const char *f = getenv("KMCUDA_AMD_FILTER")) filter_mode_ = strcmp(f, "f32") == 0 ? 1 : 0;
   if (const char *c = getenv("KMCUDA_AMD_ROW_CACHE")) row_cache_allowed_ = atoi(c) != 0;
+  if (const char *c = getenv("KMCUDA_AMD_CARRY_PAIRS")) carry_pairs_ = atoi(c) != 0;
   if (const char *c = getenv("KMCUDA_AMD_SETTLE")) settle_ = atoi(c) != 0;
   if (const char *c = getenv("KMCUDA_AMD_GEMM")) gemm_ok_ = atoi(c) != 0;
   if (const char *u = getenv("KMCUDA_AMD_UPDATE"))
@@ -595,7 +596,8 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
     }
     if (carry && !ub_) {
       // (no memory: not an error, plain passes)
-      if (alloc(&ub_, N_) != kSuccess || alloc(&lb_, N_) != kSuccess || alloc(&drift_, 2 * (size_t)K_) != kSuccess ||   // (+ K bias changes: the angular metric)
+      if (alloc(&ub_, N_) != kSuccess || alloc(&lb_, N_) != kSuccess ||
+          (metric_ == 0 && carry_pairs_ && (alloc(&l3_, N_) != kSuccess || alloc(&p1_, N_) != kSuccess || alloc(&p2_, N_) != kSuccess)) || alloc(&drift_, 2 * (size_t)K_) != kSuccess ||   // (+ K bias changes: the angular metric)
          
           alloc(&carry_list_, N_) != kSuccess || !(host_carry_ = pinned_words(2, &host_carry_dev_))) {
         (void)hipGetLastError();
@@ -605,13 +607,17 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
         host_carry_[0] = 0xFFFFFFFFu;
         host_carry_[1] = 0;
         if (const char *v = getenv("KMCUDA_AMD_CARRY_MAX")) carry_list_max_ = (float)atof(v);
+        if (metric_ != 0 || !carry_pairs_) l3_ = nullptr;
       }
     }
     span_begin(3);  // the dominant kernel on its own, inside the filter span
+    CarryArgs cy_refine;   // (stage 2 leaves bounds only in a carried pass)
     if (carry && carry_on_) {
       CarryArgs cy;
       cy.ub = ub_; cy.lb = lb_; cy.host_report = host_carry_dev_; cy.seq = ++carry_seq_;
       cy.angular = metric_ != 0;
+      cy.l3 = l3_; cy.p1 = p1_; cy.p2 = p2_;
+      cy_refine = cy;
       const bool moved = carry_was_valid && carry_preps_ == 1;   // drift_ / stats_[6] belong to the bounds
       uint32_t hint = 0xFFFFFFFFu;
       bool listed = false;
@@ -635,8 +641,8 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
           }
         }
         if (listed) hint = last;
-        KMX_HIP(launch_carry_skip(N_, K_, assignments, assignments_prev, ub_, lb_, xmeta_, drift_, stats_, tie_slack_,
-                                  carry_list_, counters_, !listed, metric_ != 0, stream_),
+        KMX_HIP(launch_carry_skip(N_, K_, assignments, assignments_prev, cy, xmeta_, drift_, stats_, tie_slack_,
+                                  carry_list_, finite_, pairs_, counters_, !listed, stream_),
                 kRuntimeError);
         cy.n_list = counters_ + kCarryCursor;
       }
@@ -669,9 +675,15 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
     // delivered to the pinned word; the kernel strides over the device-side count, so only speed
     // depends on it)
     last_undecided_ = host_move_count_[2];
-    KMX_HIP(launch_lloyd_refine(a, rows, half, panelhi_, undecided_, und_thr_, counters_ + 4, last_undecided_,
-                                stream_),
-            kRuntimeError);
+    if (cy_refine.l3) {
+      KMX_HIP(launch_lloyd_refine_carry(a, rows, half, panelhi_, undecided_, und_thr_, counters_ + 4, last_undecided_,
+                                        cy_refine, stream_),
+              kRuntimeError);
+    } else {
+      KMX_HIP(launch_lloyd_refine(a, rows, half, panelhi_, undecided_, und_thr_, counters_ + 4, last_undecided_,
+                                  stream_),
+              kRuntimeError);
+    }
   } else {
     KMX_HIP(launch_lloyd_filter(a, stream_), kRuntimeError);
   }
@@ -884,6 +896,15 @@ int Engine::carry_stats(unsigned long long *rows_spared, uint32_t *last_list) {
   return kSuccess;
 }
 
+int Engine::carry_pair_stats(unsigned long long *rows_paired) {
+  KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  unsigned long long v = 0;
+  KMX_HIP(hipMemcpyAsync(&v, counters_ + kCarryPaired, sizeof(v), hipMemcpyDeviceToHost, stream_), kMemoryCopyError);
+  KMX_HIP(hipStreamSynchronize(stream_), kRuntimeError);
+  if (rows_paired) *rows_paired = v;
+  return kSuccess;
+}
+
 int Engine::stop_clear() {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   carry_valid_ = false;   // (a pass enqueued behind a raised flag wrote no bounds: start over)
@@ -1027,6 +1048,12 @@ int kmamd_carry_stats(kmamd_engine *e, uint64_t *rows_spared, uint32_t *last_lis
   unsigned long long v = 0;
   const int rc = e->e.carry_stats(&v, last_list);
   if (rows_spared) *rows_spared = v;
+  return rc;
+}
+int kmamd_carry_pair_stats(kmamd_engine *e, uint64_t *rows_paired) {
+  unsigned long long v = 0;
+  const int rc = e->e.carry_pair_stats(&v);
+  if (rows_paired) *rows_paired = v;
   return rc;
 }
 int kmamd_set_update_mode(kmamd_engine *e, int mode) {

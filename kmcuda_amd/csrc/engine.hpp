@@ -148,10 +148,15 @@ class Engine {
   // go plain for carry_backoff_ iterations (4, doubling up to 32), then the bounds are tried again
   uint32_t carry_pause_ = 0, carry_backoff_ = 4, carry_hopeless_ = 0, carry_seen_seq_ = 0;
   float *ub_ = nullptr, *lb_ = nullptr, *drift_ = nullptr;
+  // the pair certificates (L2; CarryArgs::l3 / p1 / p2).  KMCUDA_AMD_CARRY_PAIRS=0: without (A/B, tests)
+  bool carry_pairs_ = true;
+  float *l3_ = nullptr;
+  uint32_t *p1_ = nullptr, *p2_ = nullptr;
   uint32_t *carry_list_ = nullptr;
   uint32_t *host_carry_ = nullptr, *host_carry_dev_ = nullptr;   // 2 pinned words: [0] the last list's length, [1] seq
   bool carry_usable() const;     // the state in which a pass can carry bounds
   int carry_stats(unsigned long long *rows_spared, uint32_t *last_list);
+  int carry_pair_stats(unsigned long long *rows_paired);
   // stats_: the ACTIVE half of a double-buffered 2 x 8 words (stats_base_): every preparation flips to
   // the other half, which the invariant keeps zero (memset, or zeroed by centroid_prep_frozen_kernel)
   uint32_t *stats_base_ = nullptr, *stats_ = nullptr, *flagged_ = nullptr, *pairs_ = nullptr, *counters_ = nullptr;

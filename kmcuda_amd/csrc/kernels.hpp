@@ -40,6 +40,9 @@ constexpr uint32_t kStopFlag = 8;
 // counters[kCarryCursor]: length of the carried-bounds pass's row list (zeroed by the preparation kernel);
 // counters[kCarrySkipped], [kCarrySkipped + 1]: one 64-bit total of the rows the bounds have spared since the engine was made
 constexpr uint32_t kCarryCursor = 9, kCarrySkipped = 10;
+// counters[kCarryPaired], [kCarryPaired + 1]: 64-bit total of the rows the carried PAIR certificates have sent straight to
+// the two-contender kernel (lloyd_carry.hip)
+constexpr uint32_t kCarryPaired = 12;
 // Bounds carried from one Lloyd pass to the next (lloyd_carry.hip): per row an upper bound of the distance to its
 // centroid and a lower bound of the distance to every other finite centroid.
 struct CarryArgs {
@@ -51,6 +54,12 @@ struct CarryArgs {
   // angular metric: ub[] holds the certified SCORE gap between the row's centroid and every other one instead (the
   // reference decides on products there; |x.(c_new - c_old)| <= ||x|| ||c_new - c_old|| moves it), lb[] is unused
   int angular = 0;
+  // L2: the rows stage 2 decides between two contenders (p1, p2) come out of it with an upper bound of BOTH distances
+  // in ub[], lb[] void and l3[] > 0, a lower bound of the distance to every other finite centroid: while l3 stays above
+  // ub under the drifts, the reference's nearest is one of the two and the pair kernel alone looks at the row.
+  // l3[] == 0: no such statement (stage 1 writes that for every row it sees)
+  float *l3 = nullptr;
+  uint32_t *p1 = nullptr, *p2 = nullptr;
 };
 // the device-side stop rule of launch_apply_delta (reference: check_changed, kmeans.cu:697-717)
 struct StopCtl {
@@ -105,9 +114,11 @@ hipError_t launch_apply_prep_frozen(const double *delta, const double *dcount_d,
 hipError_t launch_lloyd_coarse_carry(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
                                      const float *xmeta, const void *panelhi, uint32_t *undecided, float *und_thr,
                                      const CarryArgs &cy, uint32_t rows_hint, hipStream_t st);
-hipError_t launch_carry_skip(uint32_t N, uint32_t K, const uint32_t *assignments, uint32_t *assignments_prev, float *ub,
-                             float *lb, const float *xmeta, const float *drift, const uint32_t *stats, float tie_slack,
-                             uint32_t *row_list, uint32_t *counters, bool probe, bool angular, hipStream_t st);
+// (cy.l3 / p1 / p2 / finite / pairs: the pair certificates, L2 only; pairs[3 counters[3]++] = (row, p1, p2))
+hipError_t launch_carry_skip(uint32_t N, uint32_t K, const uint32_t *assignments, uint32_t *assignments_prev,
+                             const CarryArgs &cy, const float *xmeta, const float *drift, const uint32_t *stats,
+                             float tie_slack, uint32_t *row_list, const uint32_t *finite, uint32_t *pairs,
+                             uint32_t *counters, bool probe, hipStream_t st);
 // the reference's exact sum_squares (csqr) + the transposed panel (ct) alone: what the pair / exact kernels read
 hipError_t launch_centroid_rows(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t Kt, float *csqr,
                                 float *ct, hipStream_t st);
@@ -120,6 +131,10 @@ hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_r
 hipError_t launch_lloyd_refine(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
                                const uint32_t *row_list, const float *thr_list, const uint32_t *n_list,
                                uint32_t rows_hint /* expected list length, 0xFFFFFFFF = unknown */, hipStream_t st);
+// the same in a carried L2 pass (lloyd_carry.hip): the rows it settles leave with bounds and pair certificates (cy.l3)
+hipError_t launch_lloyd_refine_carry(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
+                                     const uint32_t *row_list, const float *thr_list, const uint32_t *n_list,
+                                     uint32_t rows_hint, const CarryArgs &cy, hipStream_t st);
 // x' = x - mu as halves in the coarse kernel's operand order (N rounded up to 256 rows: DP*2 bytes per
 // row) + (||x'||^2, x_0) per row (8 bytes); valid while mu is unchanged
 hipError_t launch_row_cache(const void *rows, bool half_rows, uint32_t N, uint32_t D, uint32_t DP, const float *mu,

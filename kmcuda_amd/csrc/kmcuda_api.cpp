@@ -1877,12 +1877,14 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
         const Job::LeaveFn leave = [&rule](int, uint32_t changed) { return rule.now(changed); };
         RETERR(job.lloyd(tolerance, &iter, rule.force >= 0 ? &leave : nullptr, &bounds, iter));
         if (carry && verbosity > 1) {
-          unsigned long long spared = 0;
+          unsigned long long spared = 0, paired = 0;
           for (auto &s : job.shards) {
             unsigned long long v = 0;
             if (s->eng->carry_stats(&v, nullptr) == 0) spared += v;
+            if (s->eng->carry_pair_stats(&v) == 0) paired += v;
           }
           printf("carried bounds: %llu sample passes decided without looking at the sample\n", spared);
+          if (paired) printf("carried pairs: %llu sample passes settled between two carried contenders\n", paired);
         }
         for (auto &s : job.shards) s->eng->carry_on_ = false;
         lap("Lloyd after the hand-over point");

@@ -31,6 +31,7 @@
 #include <cstdlib>
 
 #include "lloyd_coarse.hpp"
+#include "lloyd_refine.hpp"
 
 namespace kmx {
 
@@ -42,11 +43,12 @@ namespace kmx {
 constexpr int kSkipRowsPerThread = 8, kSkipBlock = 256;
 __global__ __launch_bounds__(kSkipBlock) void carry_skip_kernel(
     uint32_t N, uint32_t K, const uint32_t *__restrict__ assignments, uint32_t *__restrict__ assignments_prev,
-    float *__restrict__ ub, float *__restrict__ lb, const float2 *__restrict__ xmeta, float mu_norm_at,
-    const float *__restrict__ drift, const uint32_t *__restrict__ stats, float tie_slack, uint32_t *__restrict__ row_list,
-    uint32_t *__restrict__ counters, int probe, int angular) {
+    CarryArgs cy, const float2 *__restrict__ xmeta, const float *__restrict__ drift, const uint32_t *__restrict__ stats,
+    float tie_slack, uint32_t *__restrict__ row_list, const uint32_t *__restrict__ finite, uint32_t *__restrict__ pairs,
+    uint32_t *__restrict__ counters, int probe) {
   if (counters[kStopFlag] != 0u) return;   // the run has stopped on the device: touch nothing
-  (void)mu_norm_at;
+  float *__restrict__ ub = cy.ub, *__restrict__ lb = cy.lb, *__restrict__ l3 = cy.l3;
+  const int angular = cy.angular;
   const float maxdrift = __uint_as_float(stats[6]);                       // +inf if any drift is not finite
   const float cmaxo = sqrtf(__uint_as_float(stats[2])) * 1.000001f;       // max ||c|| of THIS pass's centroids
   const float mu_norm = reinterpret_cast<const float *>(xmeta)[2 * (((size_t)N + 255) / 256 * 256)];
@@ -58,15 +60,16 @@ __global__ __launch_bounds__(kSkipBlock) void carry_skip_kernel(
   const float eb = 4.0f * 520.0f * u * mu_norm * (cmaxc + maxdrift);
   const uint32_t chunk = kSkipBlock * kSkipRowsPerThread;
   const uint32_t base = blockIdx.x * chunk;
-  // ONE cursor atomic per block: same-address atomics are served one at a time by L2 (~11 ns each), and a cursor
-  // advanced once per 256-row round made this kernel 0.19 ms per 4M rows where its 100 MB of traffic take 0.03
-  __shared__ uint32_t wave_cnt[kSkipRowsPerThread][kSkipBlock / 64], blk_base;
+  // ONE cursor atomic per block and list: same-address atomics are served one at a time by L2 (~11 ns each), and a
+  // cursor advanced once per 256-row round made this kernel 0.19 ms per 4M rows where its 100 MB of traffic take 0.03
+  __shared__ uint32_t wave_cnt[kSkipRowsPerThread][kSkipBlock / 64], pair_cnt[kSkipRowsPerThread][kSkipBlock / 64];
+  __shared__ uint32_t blk_base, blk_pair_base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t listbits = 0;
+  uint32_t listbits = 0, pairbits = 0;
 #pragma unroll
   for (int it = 0; it < kSkipRowsPerThread; it++) {
     const uint32_t s = base + it * kSkipBlock + threadIdx.x;
-    bool keep = false, live = s < N;
+    bool keep = false, pair = false, live = s < N;
     if (live) {
       const uint32_t a = assignments[s];
       if (a < K) {
@@ -85,52 +88,87 @@ __global__ __launch_bounds__(kSkipBlock) void carry_skip_kernel(
           }
         } else {
           // (rounded away from the certificate: the sums up, the differences down)
-          const float un = (ub[s] + drift[a]) * 1.0000005f, ln = (lb[s] - maxdrift) * 0.9999995f;
+          const float ubs = ub[s];
+          const float un = (ubs + drift[a]) * 1.0000005f, ln = (lb[s] - maxdrift) * 0.9999995f;
           keep = (ln > un) && ((ln - un) * (ln + un) > 4.1f * e_ref + 2.0f * tie_slack);   // a NaN anywhere: false
           if (keep && !probe) {
             ub[s] = un;
             lb[s] = ln;
             if (assignments_prev[s] != a) assignments_prev[s] = a;
+          } else if (!keep && l3) {
+            // the pair certificate (stage 2 left it: ub bounds the distances to BOTH p1 and p2, l3 every other
+            // centroid's; lb is void for such a row, so the test above has failed): while l3 - max drift stays above
+            // ub + the larger of the two drifts by the same margin, the reference's nearest is p1 or p2, and which
+            // of the two the pair kernel finds out in the reference's arithmetic
+            const float l3s = l3[s];
+            if (l3s > 0.f) {
+              const uint32_t q1 = cy.p1[s], q2 = cy.p2[s];
+              if ((a == q1 || a == q2) && q1 < K && q2 < K && q1 != q2 && finite[q1] != 0u && finite[q2] != 0u) {
+                const float up = (ubs + fmaxf(drift[q1], drift[q2])) * 1.0000005f, lp = (l3s - maxdrift) * 0.9999995f;
+                pair = (lp > up) && ((lp - up) * (lp + up) > 4.1f * e_ref + 2.0f * tie_slack);
+                if (pair && !probe) {
+                  ub[s] = up;
+                  l3[s] = lp;
+                }
+              }
+            }
           }
         }
       }
     }
-    const bool list = live && !keep;
-    const unsigned long long lm = __ballot(list);
+    const bool list = live && !keep && !pair;
+    const unsigned long long lm = __ballot(list), pm = __ballot(pair);
     if (list) listbits |= 1u << it;
-    if (lane == 0) wave_cnt[it][wave] = (uint32_t)__popcll(lm);
+    if (pair) pairbits |= 1u << it;
+    if (lane == 0) {
+      wave_cnt[it][wave] = (uint32_t)__popcll(lm);
+      pair_cnt[it][wave] = (uint32_t)__popcll(pm);
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {   // the counts become offsets, round by round, wave by wave: the list keeps the rows' order
-    uint32_t t = 0;
+    uint32_t t = 0, tp = 0;
 #pragma unroll
     for (int it = 0; it < kSkipRowsPerThread; it++)
 #pragma unroll
       for (int w = 0; w < kSkipBlock / 64; w++) {
-        const uint32_t c = wave_cnt[it][w];
+        const uint32_t c = wave_cnt[it][w], cp = pair_cnt[it][w];
         wave_cnt[it][w] = t;
+        pair_cnt[it][w] = tp;
         t += c;
+        tp += cp;
       }
-    // (probe: the would-be list is only counted; the whole pass that follows rewrites every bound)
+    // (probe: the would-be list is only counted; the whole pass that follows looks at every row and rewrites every
+    // bound and pair)
     blk_base = t ? atomicAdd(&counters[kCarryCursor], t) : 0u;
+    blk_pair_base = (tp && !probe) ? atomicAdd(&counters[3], tp) : 0u;
   }
   if (probe) return;
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < kSkipRowsPerThread; it++) {
-    const bool list = (listbits >> it) & 1u;
-    const unsigned long long lm = __ballot(list);
-    if (list) row_list[blk_base + wave_cnt[it][wave] + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull))] = base + it * kSkipBlock + threadIdx.x;
+    const bool list = (listbits >> it) & 1u, pair = (pairbits >> it) & 1u;
+    const unsigned long long lm = __ballot(list), pm = __ballot(pair);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t s = base + it * kSkipBlock + threadIdx.x;
+    if (list) row_list[blk_base + wave_cnt[it][wave] + (uint32_t)__popcll(lm & below)] = s;
+    if (pair) {
+      const size_t at = blk_pair_base + pair_cnt[it][wave] + (uint32_t)__popcll(pm & below);
+      pairs[3 * at + 0] = s;
+      pairs[3 * at + 1] = cy.p1[s];
+      pairs[3 * at + 2] = cy.p2[s];
+    }
   }
 }
 
-hipError_t launch_carry_skip(uint32_t N, uint32_t K, const uint32_t *assignments, uint32_t *assignments_prev, float *ub,
-                             float *lb, const float *xmeta, const float *drift, const uint32_t *stats, float tie_slack,
-                             uint32_t *row_list, uint32_t *counters, bool probe, bool angular, hipStream_t st) {
+hipError_t launch_carry_skip(uint32_t N, uint32_t K, const uint32_t *assignments, uint32_t *assignments_prev,
+                             const CarryArgs &cy, const float *xmeta, const float *drift, const uint32_t *stats,
+                             float tie_slack, uint32_t *row_list, const uint32_t *finite, uint32_t *pairs,
+                             uint32_t *counters, bool probe, hipStream_t st) {
   const uint32_t chunk = kSkipBlock * kSkipRowsPerThread;
   hipLaunchKernelGGL(carry_skip_kernel, dim3((N + chunk - 1) / chunk), dim3(kSkipBlock), 0, st, N, K, assignments,
-                     assignments_prev, ub, lb, reinterpret_cast<const float2 *>(xmeta), 0.f, drift, stats, tie_slack,
-                     row_list, counters, probe ? 1 : 0, angular ? 1 : 0);
+                     assignments_prev, cy, reinterpret_cast<const float2 *>(xmeta), drift, stats, tie_slack, row_list,
+                     finite, pairs, counters, probe ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -183,6 +221,13 @@ hipError_t launch_lloyd_coarse_carry(const LloydArgs &a, const void *rows, bool 
 #undef KMX_CARRY_CASE
     default: return hipErrorInvalidValue;
   }
+}
+
+// stage 2 of a carried L2 pass: as launch_lloyd_refine, and the rows leave with bounds / pair certificates (cy)
+hipError_t launch_lloyd_refine_carry(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
+                                     const uint32_t *row_list, const float *thr_list, const uint32_t *n_list,
+                                     uint32_t rows_hint, const CarryArgs &cy, hipStream_t st) {
+  return launch_lloyd_refine_t<true>(a, rows, half_rows, panelhi, row_list, thr_list, n_list, rows_hint, cy, st);
 }
 
 hipError_t preload_lloyd_carry_code() {   // (kernels.hpp: preload_code_objects)

@@ -82,8 +82,12 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
         hr[0] = cy.n_list ? *cy.n_list : 0xFFFFFFFFu;   // (a pass without bounds to move has no list to report)
         hr[1] = cy.seq;
       }
-      if constexpr (CARRY == 2)   // the rows this pass does not look at (statistics: kmamd_carry_stats)
-        *reinterpret_cast<unsigned long long *>(counters + kCarrySkipped) += (unsigned long long)(N - total);
+      if constexpr (CARRY == 2) {   // the rows this pass does not look at (statistics: kmamd_carry_stats)
+        // counters[3]: the pairs carry_skip_kernel has queued (stage 2 has not added its own yet)
+        const uint32_t paired = cy.l3 ? counters[3] : 0u;
+        *reinterpret_cast<unsigned long long *>(counters + kCarrySkipped) += (unsigned long long)(N - total - paired);
+        *reinterpret_cast<unsigned long long *>(counters + kCarryPaired) += (unsigned long long)paired;
+      }
     }
   }
   if constexpr (CARRY == 2) {
@@ -394,6 +398,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
         }
         cy.ub[s] = ubv;
         cy.lb[s] = lbv;
+        if (cy.l3) cy.l3[s] = 0.f;   // (no pair statement; stage 2 writes one for the rows it settles between two)
       }
     }
     // what the refine stage may drop: a centroid whose coarse score is below best - thr cannot be the

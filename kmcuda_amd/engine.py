@@ -93,6 +93,12 @@ class Engine:
         _lib.check(self.lib.kmamd_carry_stats(self.h, ctypes.byref(spared), ctypes.byref(last)), "kmamd_carry_stats")
         return int(spared.value), int(last.value)
 
+    def carry_pair_stats(self):
+        """Row passes the carried pair certificates have sent straight to the two-contender kernel so far (L2)."""
+        paired = ctypes.c_uint64(0)
+        _lib.check(self.lib.kmamd_carry_pair_stats(self.h, ctypes.byref(paired)), "kmamd_carry_pair_stats")
+        return int(paired.value)
+
     def counters(self):
         out = (ctypes.c_uint32 * 4)()
         _lib.check(self.lib.kmamd_counters_read(self.h, out), "kmamd_counters_read")

@@ -60,7 +60,7 @@ def main():
         try:
             log, spared, last = tc._run_pair(x, k, iters=iters, carry_from=carry_from, fused=fused, half=half,
                                              seed=int(rs.randint(0, 1000)), list_max=list_max, metric=metric)
-            print("ok   %s: spared %d" % (desc, spared), flush=True)
+            print("ok   %s: spared %d paired %d" % (desc, spared, tc._run_pair.paired), flush=True)
         except AssertionError as e:
             failures += 1
             print("FAIL %s: %s" % (desc, str(e).split("\n")[0]), flush=True)

@@ -185,3 +185,96 @@ def test_a_spared_row_keeps_its_centroid_under_the_angular_metric(case):
         assert (true_gap[keep] > 4.0 * e_ref[keep].astype(numpy.float64) + 2.0 * float(tie)).all()
     if case == "unit-blobs":
         assert kept_total > n
+
+
+@pytest.mark.parametrize("case", ["shared-blobs", "shared-blobs-drift", "uniform", "three-close"])
+def test_a_pair_certificate_leaves_only_the_two_contenders(case):
+    """Stage 2's pair state (lloyd_refine.hpp, PAIRS) and carry_skip_kernel's pair test: fp32 contender scores within
+    e_mfma of the exact ones, every other centroid's coarse score (within e_c of exact) at most `rest`; u bounds the
+    distances to BOTH contenders, l3 every other centroid's.  A row whose certificate survives the drifts must have, for
+    the NEW centroids and in exact arithmetic, d(x, c)^2 - d(x, p)^2 > 4 E_ref for p in {p1, p2} and every other c: the
+    reference's scan ends on p1 or p2, and the pair kernel finds out which in the reference's own arithmetic."""
+    rs = numpy.random.RandomState(len(case) + 3)
+    n, d, k = 4000, 48, 40
+    if case.startswith("shared-blobs"):
+        cen = rs.rand(k // 2, d) * 8
+        x = cen[rs.randint(0, k // 2, n)] + rs.randn(n, d)
+        c_old = numpy.concatenate([cen + 0.4 * rs.randn(k // 2, d), cen + 0.4 * rs.randn(k // 2, d)])   # two per blob
+    elif case == "three-close":
+        cen = rs.rand(k // 4, d) * 8
+        x = cen[rs.randint(0, k // 4, n)] + rs.randn(n, d)
+        c_old = numpy.concatenate([cen + 0.3 * rs.randn(k // 4, d) for _ in range(4)])                    # four per blob
+    else:
+        x = rs.rand(n, d)
+        c_old = x[rs.choice(n, k, replace=False)]
+    x = x.astype(F)
+    c_old = c_old.astype(F)
+    scale = 0.2 if case == "shared-blobs-drift" else 0.01
+    c_new = (c_old + (scale * rs.randn(k, d)).astype(F)).astype(F)
+    mu = c_old.mean(axis=0, dtype=numpy.float64).astype(F)
+    eps = F(1.02 * (d + 12.0) * 5.9604644775390625e-8)
+    x64, co64, cn64, mu64 = (v.astype(numpy.float64) for v in (x, c_old, c_new, mu))
+    xc = (x - mu[None, :]).astype(F)
+    cc_old = (c_old - mu[None, :]).astype(F)
+    cc_new = (c_new - mu[None, :]).astype(F)
+    xn2 = (xc * xc).sum(axis=1, dtype=F)
+    xn = (numpy.sqrt(xn2).astype(F) * F(1.0001)).astype(F)
+    cmaxc = F(numpy.sqrt((cc_old.astype(numpy.float64) ** 2).sum(axis=1).max()) * 1.000001)
+    bmaxc = F(0.5 * (cc_old.astype(numpy.float64) ** 2).sum(axis=1).max())
+    d2_old = ((x64[:, None, :] - co64[None, :, :]) ** 2).sum(axis=2)
+    d2_new = ((x64[:, None, :] - cn64[None, :, :]) ** 2).sum(axis=2)
+    xm2 = ((x64 - mu64) ** 2).sum(axis=1)
+    s_exact = 0.5 * (xm2[:, None] - d2_old)
+    order = numpy.argsort(-s_exact, axis=1)
+    rows = numpy.arange(n)
+    p1, p2 = order[:, 0], order[:, 1]
+    s1, s2, s3 = s_exact[rows, p1], s_exact[rows, p2], s_exact[rows, order[:, 2]]
+    e_mfma = (F(2.0) * eps * (xn * cmaxc + bmaxc)).astype(F)
+    dcmax = F(2.0 ** -11) * cmaxc
+    dxw = (F(4.8829e-4) * xn).astype(F)
+    e_c = (F(2.0) * eps * (xn * cmaxc + bmaxc) + (xn * dcmax + dxw * cmaxc + dxw * dcmax) * F(1.001) +
+           F(6e-8) * F(numpy.sqrt(64.0)) * (xn + cmaxc) + F(2.0e-6) * (F(1.001) * xn * cmaxc + bmaxc)).astype(F)
+    geo = (F(2.4e-7) * (xn + cmaxc)).astype(F)
+    mu_norm = F(numpy.sqrt((mu64 ** 2).sum()) * 1.00001)
+    cmaxo = F(numpy.sqrt((cn64 ** 2).sum(axis=1).max()) * 1.000001)
+    drift = _drift(cc_new, cc_old)
+    maxdrift = drift.max()
+    xo = ((numpy.sqrt(xn2).astype(F) * F(1.0001) + mu_norm) * F(1.0001)).astype(F)
+    e_ref = (U * (F(12.0) * xo * cmaxo + F(4.0) * cmaxo * cmaxo)).astype(F)
+    certified = 0
+    # two contenders (the third centroid is the best of the rest), or three (v3 a contender's fp32 score); the scores at
+    # the extremes of their error bands that make u small and l3 large
+    for three in (False, True):
+        e = (e_mfma * F(1.001)).astype(F)
+        v2 = (s2 + 0.999 * e_mfma.astype(numpy.float64)).astype(F)             # high v2: small u
+        if three:
+            v3 = (s3 - 0.999 * e_mfma.astype(numpy.float64)).astype(F)         # low third contender
+            rest = (s_exact[rows, order[:, 3]] - 0.999 * e_c.astype(numpy.float64)).astype(F)
+        else:
+            v3 = numpy.full(n, -numpy.inf, dtype=F)
+            rest = (s3 - 0.999 * e_c.astype(numpy.float64)).astype(F)          # low coarse score of the best of the rest
+        w = numpy.maximum(rest + e_c * F(1.001), v3 + e).astype(F)
+        d2l = (xn2 * (F(1.0) - F(2.0) * eps) - F(2.0) * w).astype(F)
+        l3 = numpy.where(d2l > 0, numpy.maximum(numpy.sqrt(numpy.maximum(d2l, 0)).astype(F) * F(0.999999) - geo, F(0.0)), F(0.0)).astype(F)
+        ub = (numpy.sqrt(numpy.maximum(xn2 * (F(1.0) + F(2.0) * eps) - F(2.0) * (v2 - e), F(0.0))).astype(F) * F(1.000001) + geo).astype(F)
+        # the statements hold for the OLD centroids
+        d_pair = numpy.sqrt(numpy.maximum(d2_old[rows, p1], d2_old[rows, p2]))
+        others = d2_old.copy()
+        others[rows, p1] = numpy.inf
+        others[rows, p2] = numpy.inf
+        assert (ub.astype(numpy.float64) >= d_pair).all()
+        assert (l3.astype(numpy.float64) <= numpy.sqrt(others.min(axis=1))).all()
+        # carry_skip_kernel's pair test
+        up = ((ub + numpy.maximum(drift[p1], drift[p2])) * F(1.0000005)).astype(F)
+        lp = ((l3 - maxdrift) * F(0.9999995)).astype(F)
+        ok = (l3 > 0) & (lp > up) & (((lp - up) * (lp + up)).astype(F) > F(4.1) * e_ref)
+        certified += int(ok.sum())
+        on = d2_new.copy()
+        on[rows, p1] = numpy.inf
+        on[rows, p2] = numpy.inf
+        worst_pair = numpy.maximum(d2_new[rows, p1], d2_new[rows, p2])
+        assert ((on.min(axis=1) - worst_pair)[ok] > 4.0 * e_ref[ok].astype(numpy.float64)).all()
+    if case == "shared-blobs":
+        assert certified > n        # not vacuous: nearly every row's third centroid is another blob's
+    if case == "uniform":
+        assert certified < n // 2
