@@ -42,3 +42,5 @@ rm -rf $OUT/prof_mix_$TAG
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_mix_$TAG -o p -- python scripts/config_b.py --samples 4000000 --data gaussian --yinyang 0.1 --tolerance 0.0001 --verbosity 0 > $OUT/prof_mix_$TAG.log 2>&1; echo "rocprof rc=$?"
 python scripts/rocpd_stats.py $OUT/prof_mix_$TAG/p_results.db $OUT/kernel_stats_mixture_$TAG.csv | head -14 | cut -c1-150
 rm -rf $OUT/prof_mix_$TAG
+echo "== whole calls at random: default schedule against KMCUDA_AMD_CARRY=0"
+timeout 200 python scripts/stress_carry_api.py 70 11 > $OUT/stress_carry_api_$TAG.log 2>&1; tail -1 $OUT/stress_carry_api_$TAG.log; grep -E "^FAIL|^ERR" $OUT/stress_carry_api_$TAG.log | head
