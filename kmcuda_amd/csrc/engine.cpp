@@ -596,18 +596,19 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
     }
     if (carry && !ub_) {
       // (no memory: not an error, plain passes)
+      const bool pairs = metric_ == 0 && carry_pairs_;   // (the pair certificates: L2)
       if (alloc(&ub_, N_) != kSuccess || alloc(&lb_, N_) != kSuccess ||
-          (metric_ == 0 && carry_pairs_ && (alloc(&l3_, N_) != kSuccess || alloc(&p1_, N_) != kSuccess || alloc(&p2_, N_) != kSuccess)) || alloc(&drift_, 2 * (size_t)K_) != kSuccess ||   // (+ K bias changes: the angular metric)
-         
+          alloc(&drift_, 2 * (size_t)K_) != kSuccess ||   // (+ K bias changes: the angular metric)
+          (pairs && (alloc(&l3_, N_) != kSuccess || alloc(&p1_, N_) != kSuccess || alloc(&p2_, N_) != kSuccess)) ||
           alloc(&carry_list_, N_) != kSuccess || !(host_carry_ = pinned_words(2, &host_carry_dev_))) {
         (void)hipGetLastError();
         carry_on_ = false;
         ub_ = nullptr;
+        l3_ = nullptr;
       } else {
         host_carry_[0] = 0xFFFFFFFFu;
         host_carry_[1] = 0;
         if (const char *v = getenv("KMCUDA_AMD_CARRY_MAX")) carry_list_max_ = (float)atof(v);
-        if (metric_ != 0 || !carry_pairs_) l3_ = nullptr;
       }
     }
     span_begin(3);  // the dominant kernel on its own, inside the filter span
