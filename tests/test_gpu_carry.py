@@ -120,6 +120,17 @@ def test_pair_certificates_send_shared_blob_rows_to_the_pair_kernel(fused, half,
     assert _run_pair.paired == 0 and log0 == log
 
 
+@pytest.mark.parametrize("d", [50, 30, 18])
+def test_pair_certificates_with_feature_counts_the_settle_kernel_does_not_take(d):
+    """D % 4 != 0: the pairs go to lloyd_pair_kernel, the scans to lloyd_exact_kernel (two streams) -- the carried
+    pairs arrive there like stage 2's own."""
+    rs = numpy.random.RandomState(d)
+    cen = rs.rand(20, d) * 9.0
+    x = (cen[rs.randint(0, 20, 50000)] + rs.randn(50000, d)).astype(numpy.float32)
+    log, spared, last = _run_pair(x, 40, iters=12, carry_from=3, fused=(d != 30), list_max=1.0)
+    assert _run_pair.paired > 0, (log, spared, last)
+
+
 @pytest.mark.parametrize("metric", ["L2", "cos"])
 def test_a_list_longer_than_the_listed_pass_s_grid_is_strided_over(metric, monkeypatch):
     """The listed pass is launched for the host's ESTIMATE of the list; the device-side list can be any length (a
