@@ -137,8 +137,9 @@ int kmamd_centroids_written(kmamd_engine *e);
  * synchronisation), last_list = the length of the newest list the host has heard of (0xFFFFFFFF: none yet). */
 int kmamd_set_carry(kmamd_engine *e, int on);
 int kmamd_carry_stats(kmamd_engine *e, uint64_t *rows_spared, uint32_t *last_list);
-/* L2: a row that stage 2 settles between two contenders carries the pair, an upper bound of both distances and a lower
- * bound of every other centroid's; while the drifts leave the latter above the former the row goes straight to the
+/* A row that stage 2 settles between two contenders carries the pair, an upper bound of both distances and a lower
+ * bound of every other centroid's (angular: the gap by which both scores exceed every other centroid's); while the
+ * drifts leave the latter above the former (the gap positive) the row goes straight to the
  * two-contender kernel (the reference's arithmetic and tie rule: kmeans.cu:214-364 restricted to the two) instead of
  * through the filter.  rows_paired = such row passes since the engine was created (they are not in rows_spared).
  * KMCUDA_AMD_CARRY_PAIRS=0 in the environment: without (A/B). */

@@ -596,7 +596,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
     }
     if (carry && !ub_) {
       // (no memory: not an error, plain passes)
-      const bool pairs = metric_ == 0 && carry_pairs_;   // (the pair certificates: L2)
+      const bool pairs = carry_pairs_;   // (the pair certificates)
       if (alloc(&ub_, N_) != kSuccess || alloc(&lb_, N_) != kSuccess ||
           alloc(&drift_, 2 * (size_t)K_) != kSuccess ||   // (+ K bias changes: the angular metric)
           (pairs && (alloc(&l3_, N_) != kSuccess || alloc(&p1_, N_) != kSuccess || alloc(&p2_, N_) != kSuccess)) ||

@@ -148,7 +148,7 @@ class Engine {
   // go plain for carry_backoff_ iterations (4, doubling up to 32), then the bounds are tried again
   uint32_t carry_pause_ = 0, carry_backoff_ = 4, carry_hopeless_ = 0, carry_seen_seq_ = 0;
   float *ub_ = nullptr, *lb_ = nullptr, *drift_ = nullptr;
-  // the pair certificates (L2; CarryArgs::l3 / p1 / p2).  KMCUDA_AMD_CARRY_PAIRS=0: without (A/B, tests)
+  // the pair certificates (CarryArgs::l3 / p1 / p2).  KMCUDA_AMD_CARRY_PAIRS=0: without (A/B, tests)
   bool carry_pairs_ = true;
   float *l3_ = nullptr;
   uint32_t *p1_ = nullptr, *p2_ = nullptr;

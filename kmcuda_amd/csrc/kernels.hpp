@@ -54,9 +54,10 @@ struct CarryArgs {
   // angular metric: ub[] holds the certified SCORE gap between the row's centroid and every other one instead (the
   // reference decides on products there; |x.(c_new - c_old)| <= ||x|| ||c_new - c_old|| moves it), lb[] is unused
   int angular = 0;
-  // L2: the rows stage 2 decides between two contenders (p1, p2) come out of it with an upper bound of BOTH distances
-  // in ub[], lb[] void and l3[] > 0, a lower bound of the distance to every other finite centroid: while l3 stays above
-  // ub under the drifts, the reference's nearest is one of the two and the pair kernel alone looks at the row.
+  // The rows stage 2 decides between two contenders (p1, p2) come out of it with l3[] > 0.  L2: an upper bound of BOTH
+  // distances in ub[], lb[] void, l3[] a lower bound of the distance to every other finite centroid: while l3 stays
+  // above ub under the drifts, the reference's nearest is one of the two and the pair kernel alone looks at the row.
+  // Angular: l3[] = the gap by which both contenders' scores exceed every other centroid's, shrunk by the drifts.
   // l3[] == 0: no such statement (stage 1 writes that for every row it sees)
   float *l3 = nullptr;
   uint32_t *p1 = nullptr, *p2 = nullptr;
@@ -114,7 +115,7 @@ hipError_t launch_apply_prep_frozen(const double *delta, const double *dcount_d,
 hipError_t launch_lloyd_coarse_carry(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
                                      const float *xmeta, const void *panelhi, uint32_t *undecided, float *und_thr,
                                      const CarryArgs &cy, uint32_t rows_hint, hipStream_t st);
-// (cy.l3 / p1 / p2 / finite / pairs: the pair certificates, L2 only; pairs[3 counters[3]++] = (row, p1, p2))
+// (cy.l3 / p1 / p2 / finite / pairs: the pair certificates; pairs[3 counters[3]++] = (row, p1, p2))
 hipError_t launch_carry_skip(uint32_t N, uint32_t K, const uint32_t *assignments, uint32_t *assignments_prev,
                              const CarryArgs &cy, const float *xmeta, const float *drift, const uint32_t *stats,
                              float tie_slack, uint32_t *row_list, const uint32_t *finite, uint32_t *pairs,
@@ -131,7 +132,7 @@ hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_r
 hipError_t launch_lloyd_refine(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
                                const uint32_t *row_list, const float *thr_list, const uint32_t *n_list,
                                uint32_t rows_hint /* expected list length, 0xFFFFFFFF = unknown */, hipStream_t st);
-// the same in a carried L2 pass (lloyd_carry.hip): the rows it settles leave with bounds and pair certificates (cy.l3)
+// the same in a carried pass (lloyd_carry.hip): the rows it settles leave with bounds and pair certificates (cy.l3)
 hipError_t launch_lloyd_refine_carry(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
                                      const uint32_t *row_list, const float *thr_list, const uint32_t *n_list,
                                      uint32_t rows_hint, const CarryArgs &cy, hipStream_t st);

@@ -85,6 +85,19 @@ __global__ __launch_bounds__(kSkipBlock) void carry_skip_kernel(
           if (keep && !probe) {
             ub[s] = g * 0.999999f;
             if (assignments_prev[s] != a) assignments_prev[s] = a;
+          } else if (!keep && l3) {
+            // the pair certificate in score space: l3 = the gap by which both p1's and p2's scores exceed every other
+            // centroid's; it shrinks by ||x'|| (the larger of the two drifts + max drift) + max_c db(c) - the smaller db
+            const float l3s = l3[s];
+            if (l3s > 0.f) {
+              const uint32_t q1 = cy.p1[s], q2 = cy.p2[s];
+              if ((a == q1 || a == q2) && q1 < K && q2 < K && q1 != q2 && finite[q1] != 0u && finite[q2] != 0u) {
+                const float g2 = l3s - (xn * (fmaxf(drift[q1], drift[q2]) + maxdrift) +
+                                        (maxdb - fminf(drift[K + q1], drift[K + q2])) + eb) * 1.000001f;
+                pair = g2 > 4.1f * e_ref + 2.0f * tie_slack;
+                if (pair && !probe) l3[s] = g2 * 0.999999f;
+              }
+            }
           }
         } else {
           // (rounded away from the certificate: the sums up, the differences down)

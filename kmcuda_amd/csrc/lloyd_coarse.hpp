@@ -384,6 +384,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
         float gapv = (certain && !insane && in_range) ? ((v1 - e) - (v2 + e)) * 0.999999f : -INFINITY;
         if (!(gapv == gapv)) gapv = -INFINITY;
         cy.ub[s] = gapv;
+        if (cy.l3) cy.l3[s] = 0.f;   // (no pair statement)
       } else if (mine) {
         float ubv = INFINITY, lbv = 0.f;
         if (!insane && in_range) {

@@ -348,7 +348,29 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
       //   two or more:     the row ends on i1 or i2 (here, or in the pair kernel): u = an upper bound of BOTH
       //                    distances (from v2 <= v1), l3 = a lower bound for every centroid but the two, l void
       rest = fmaxf(rest, __shfl_xor(rest, 32));
-      if (mine) {
+      if (mine && cy.angular) {
+        // angular: the same statements in score space (lloyd_carry.hip).  One contender: the certified gap between its
+        // score and every other centroid's (ub[], Hamerly's test there); two or more: l3[] = the gap by which BOTH
+        // i1's and i2's scores exceed every other centroid's
+        float gapv = -INFINITY, pairg = 0.f;
+        if (!insane && in_range && (certain || two)) {
+          const float e = e_mfma * 1.001f;
+          const float dcmax = sqrtf(__uint_as_float(stats[5])) * 1.000001f, dxw = 4.8829e-4f * xn;
+          const float e_c = 2.0f * eps * (xn * cmaxc + bmaxc) + (xn * dcmax + dxw * cmaxc + dxw * dcmax) * 1.001f +
+                            6e-8f * sqrtf((float)DP) * (xn + cmaxc) + 2.0e-6f * (1.001f * xn * cmaxc + bmaxc);
+          const float w = fmaxf(rest + e_c * 1.001f, v3 + e);
+          if (n == 1) gapv = ((v1 - e) - w) * 0.999999f;
+          else if (i2 < K) pairg = ((v2 - e) - w) * 0.999999f;
+          if (!(gapv == gapv)) gapv = -INFINITY;
+          if (!(pairg > 0.f)) pairg = 0.f;   // (NaN too)
+        }
+        cy.ub[s] = gapv;
+        cy.l3[s] = pairg;
+        if (pairg > 0.f) {
+          cy.p1[s] = i1;
+          cy.p2[s] = i2;
+        }
+      } else if (mine) {
         float ubv = INFINITY, lbv = 0.f, l3v = 0.f;
         if (!insane && in_range && (certain || two)) {
           const float e = e_mfma * 1.001f;

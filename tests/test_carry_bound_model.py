@@ -278,3 +278,75 @@ def test_a_pair_certificate_leaves_only_the_two_contenders(case):
         assert certified > n        # not vacuous: nearly every row's third centroid is another blob's
     if case == "uniform":
         assert certified < n // 2
+
+
+@pytest.mark.parametrize("case", ["unit-shared-blobs", "unit-uniform", "not-unit"])
+def test_an_angular_pair_certificate_leaves_only_the_two_contenders(case):
+    """The pair certificate in score space (lloyd_refine.hpp PAIRS with cy.angular, carry_skip_kernel's angular pair test):
+    l3 = the gap by which both contenders' scores exceed every other centroid's, shrunk per pass by
+    ||x'|| (max(drift(p1), drift(p2)) + max drift) + max_c db(c) - min(db(p1), db(p2)).  A row that keeps it has
+    x.c_p - x.c_c > 4 E_ref + 2 tie for p in {p1, p2} and every other NEW centroid, in exact arithmetic."""
+    rs = numpy.random.RandomState(len(case) + 11)
+    n, d, k = 4000, 48, 40
+    if case == "unit-shared-blobs":
+        cen = rs.rand(k // 2, d) * 8
+        x = cen[rs.randint(0, k // 2, n)] + rs.randn(n, d)
+        c_old = numpy.concatenate([cen + 0.4 * rs.randn(k // 2, d), cen + 0.4 * rs.randn(k // 2, d)])
+        c_old = c_old / numpy.linalg.norm(c_old, axis=1, keepdims=True)
+    else:
+        x = rs.rand(n, d)
+        c_old = None
+    x = x / numpy.linalg.norm(x, axis=1, keepdims=True)
+    if case == "not-unit":
+        x = x * (0.5 + rs.rand(n, 1))
+    x = x.astype(F)
+    if c_old is None:
+        c_old = x[rs.choice(n, k, replace=False)]
+    c_old = c_old.astype(F)
+    c_new = (c_old + (0.002 * rs.randn(k, d)).astype(F)).astype(F)
+    c_new = (c_new / numpy.linalg.norm(c_new.astype(numpy.float64), axis=1, keepdims=True)).astype(F)
+    mu = c_old.mean(axis=0, dtype=numpy.float64).astype(F)
+    eps = F(1.02 * (d + 12.0) * 5.9604644775390625e-8)
+    tie = F(1e-6)
+    x64, co64, cn64, mu64 = (v.astype(numpy.float64) for v in (x, c_old, c_new, mu))
+    xc = (x - mu[None, :]).astype(F)
+    cc_old = (c_old - mu[None, :]).astype(F)
+    cc_new = (c_new - mu[None, :]).astype(F)
+    xn2 = (xc * xc).sum(axis=1, dtype=F)
+    xn = (numpy.sqrt(xn2).astype(F) * F(1.0001)).astype(F)
+    cmaxc = F(numpy.sqrt((cc_old.astype(numpy.float64) ** 2).sum(axis=1).max()) * 1.000001)
+    bmaxc = F(numpy.abs(cc_old.astype(numpy.float64) @ mu64).max())
+    s_old = x64 @ (co64 - mu64).T
+    order = numpy.argsort(-s_old, axis=1)
+    rows = numpy.arange(n)
+    p1, p2 = order[:, 0], order[:, 1]
+    s2, s3 = s_old[rows, p2], s_old[rows, order[:, 2]]
+    e_mfma = (F(2.0) * eps * (xn * cmaxc + bmaxc)).astype(F)
+    e_c = (e_mfma + F(2.0 ** -10) * xn * cmaxc).astype(F)
+    mu_norm = F(numpy.sqrt((mu64 ** 2).sum()) * 1.00001)
+    cmaxo = F(numpy.sqrt((cn64 ** 2).sum(axis=1).max()) * 1.000001)
+    drift = _drift(cc_new, cc_old)
+    maxdrift = drift.max()
+    xo = ((numpy.sqrt(xn2).astype(F) * F(1.0001) + mu_norm) * F(1.0001)).astype(F)
+    e_ref = (U * (F(12.0) * xo * cmaxo + F(4.0) * cmaxo * cmaxo)).astype(F)
+    b_old = (cc_old * mu[None, :]).sum(axis=1, dtype=F)
+    b_new = (cc_new * mu[None, :]).sum(axis=1, dtype=F)
+    db = (b_new - b_old).astype(F)
+    maxdb = F(max(0.0, float(db.max()) * 1.000001))
+    cmaxc_new = F(numpy.sqrt((cc_new.astype(numpy.float64) ** 2).sum(axis=1).max()) * 1.000001)
+    eb = F(4.0) * F(520.0) * U * mu_norm * (cmaxc_new + maxdrift)
+    p_new = x64 @ cn64.T
+    e = (e_mfma * F(1.001)).astype(F)
+    v2 = (s2 + 0.999 * e_mfma.astype(numpy.float64)).astype(F)          # high: the largest gap the band allows
+    rest = (s3 - 0.999 * e_c.astype(numpy.float64)).astype(F)           # low coarse score of the best of the rest
+    w = (rest + e_c * F(1.001)).astype(F)
+    pairg = (((v2 - e) - w) * F(0.999999)).astype(F)
+    g2 = (pairg - (xn * (numpy.maximum(drift[p1], drift[p2]) + maxdrift) + (maxdb - numpy.minimum(db[p1], db[p2])) + eb) * F(1.000001)).astype(F)
+    ok = (pairg > 0) & (g2 > F(4.1) * e_ref + F(2.0) * tie)
+    others = p_new.copy()
+    others[rows, p1] = -numpy.inf
+    others[rows, p2] = -numpy.inf
+    worst = numpy.minimum(p_new[rows, p1], p_new[rows, p2])
+    assert ((worst - others.max(axis=1))[ok] > 4.0 * e_ref[ok].astype(numpy.float64) + 2.0 * float(tie)).all()
+    if case == "unit-shared-blobs":
+        assert int(ok.sum()) > n // 2

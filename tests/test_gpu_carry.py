@@ -102,21 +102,25 @@ def test_carried_passes_equal_plain_passes_on_clustered_rows(shape, fused):
         assert spared > 3 * n and last < n // 2, (log, spared, last)
 
 
+@pytest.mark.parametrize("metric", ["L2", "cos"])
 @pytest.mark.parametrize("half", [False, True], ids=["fp32", "fp16x2"])
 @pytest.mark.parametrize("fused", [False, True], ids=["apply", "apply+prepare"])
-def test_pair_certificates_send_shared_blob_rows_to_the_pair_kernel(fused, half, monkeypatch):
+def test_pair_certificates_send_shared_blob_rows_to_the_pair_kernel(fused, half, metric, monkeypatch):
     """Two centroids per blob: a third of the rows sit too close to the border between the two for stage 1 to decide,
     pass after pass.  Stage 2 leaves them a pair certificate (the two contenders, an upper bound of both distances, a
     lower bound of every other centroid's); while it survives the drifts the pair kernel alone looks at the row.
     Same states as plain passes, iteration by iteration; KMCUDA_AMD_CARRY_PAIRS=0 is the A/B."""
     rs = numpy.random.RandomState(12)
     cen = rs.rand(48, 128) * 9.0
-    x = (cen[rs.randint(0, 48, 80000)] + rs.randn(80000, 128)).astype(numpy.float32)
-    log, spared, last = _run_pair(x, 96, iters=14, carry_from=3, fused=fused, half=half, list_max=1.0)
+    x = cen[rs.randint(0, 48, 80000)] + rs.randn(80000, 128)
+    if metric == "cos":   # (the same statements in score space)
+        x /= numpy.linalg.norm(x, axis=1, keepdims=True)
+    x = x.astype(numpy.float32)
+    log, spared, last = _run_pair(x, 96, iters=14, carry_from=3, fused=fused, half=half, list_max=1.0, metric=metric)
     paired = _run_pair.paired
     assert paired > len(x) // 2, (log, spared, last, paired)
     monkeypatch.setenv("KMCUDA_AMD_CARRY_PAIRS", "0")
-    log0, spared0, last0 = _run_pair(x, 96, iters=14, carry_from=3, fused=fused, half=half, list_max=1.0)
+    log0, spared0, last0 = _run_pair(x, 96, iters=14, carry_from=3, fused=fused, half=half, list_max=1.0, metric=metric)
     assert _run_pair.paired == 0 and log0 == log
 
 
