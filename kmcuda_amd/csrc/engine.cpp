@@ -589,10 +589,9 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
     // next one only looks at the rows they do not decide.  The drift of this pass's centroids against the last pass's
     // is the preparation kernel's (exactly one preparation since: anything else voids the bounds).
     bool carry = carry_on_ && steady && cached;
-    if (carry && carry_pause_ > 0) {   // the bounds decided next to nothing lately: plain passes for a while
-      carry_pause_--;
+    if (carry && carry_policy_.paused()) {   // the bounds decided next to nothing lately: plain passes for a while
       carry = false;
-      if (getenv("KMCUDA_AMD_CARRY_TRACE")) fprintf(stderr, "[carry] paused (%u more)\n", carry_pause_);
+      if (getenv("KMCUDA_AMD_CARRY_TRACE")) fprintf(stderr, "[carry] paused (%u more)\n", carry_policy_.pause);
     }
     if (carry && !ub_) {
       // (no memory: not an error, plain passes)
@@ -608,7 +607,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
       } else {
         host_carry_[0] = 0xFFFFFFFFu;
         host_carry_[1] = 0;
-        if (const char *v = getenv("KMCUDA_AMD_CARRY_MAX")) carry_list_max_ = (float)atof(v);
+        if (const char *v = getenv("KMCUDA_AMD_CARRY_MAX")) carry_policy_.list_max = (float)atof(v);
       }
     }
     span_begin(3);  // the dominant kernel on its own, inside the filter span
@@ -626,21 +625,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
         // what the host knows of an EARLIER pass's list (a pinned word the coarse kernel writes; only speed depends
         // on it): a short list -> the listed pass; else every row from the row cache, the list only counted
         const uint32_t last = host_carry_[0], last_seq = host_carry_[1];
-        listed = last != 0xFFFFFFFFu && (float)last <= carry_list_max_ * (float)N_;
-        if (last != 0xFFFFFFFFu && (int32_t)(last_seq - carry_seen_seq_) > 0) {   // a report not judged yet
-          carry_seen_seq_ = last_seq;
-          if ((float)last > 0.9f * (float)N_ && carry_list_max_ < 1.0f) {
-            if (++carry_hopeless_ >= 2) {
-              carry_pause_ = carry_backoff_;
-              carry_backoff_ = carry_backoff_ < 32 ? 2 * carry_backoff_ : 32;
-              carry_hopeless_ = 0;
-              carry_seen_seq_ = carry_seq_;   // what the passes up to this one report describes the drifts before the pause
-            }
-          } else {
-            carry_hopeless_ = 0;
-            carry_backoff_ = 4;
-          }
-        }
+        listed = carry_policy_.decide(last, last_seq, carry_seq_, N_);
         if (listed) hint = last;
         KMX_HIP(launch_carry_skip(N_, K_, assignments, assignments_prev, cy, xmeta_, drift_, stats_, tie_slack_,
                                   carry_list_, finite_, pairs_, counters_, !listed, stream_),
@@ -1050,6 +1035,41 @@ int kmamd_carry_stats(kmamd_engine *e, uint64_t *rows_spared, uint32_t *last_lis
   const int rc = e->e.carry_stats(&v, last_list);
   if (rows_spared) *rows_spared = v;
   return rc;
+}
+// The carried-bounds host policy replayed without a device (CarryPolicy, engine.hpp): pass i + 1 would count
+// list_len[i] rows if it counts a list; a pass's report reaches the host `lag` passes later.  out[i]: 0 a plain pass
+// (paused), 1 a whole pass that leaves bounds (none were valid: nothing to count), 2 a whole pass that counts its
+// would-be list, 3 a listed pass.
+int kmamd_carry_policy_sim(uint32_t n_passes, uint32_t n_rows, float list_max, const uint32_t *list_len, uint32_t lag,
+                           uint8_t *out) {
+  if (!list_len || !out || lag == 0) return kmx::kInvalidArguments;
+  kmx::CarryPolicy policy;
+  policy.list_max = list_max;
+  std::vector<uint32_t> reported(n_passes + 1, kmx::CarryPolicy::kNoList);   // by sequence number (1-based)
+  std::vector<bool> has_report(n_passes + 1, false);
+  bool valid = false;
+  for (uint32_t i = 0; i < n_passes; i++) {
+    const uint32_t seq = i + 1;
+    if (policy.paused()) {
+      out[i] = 0;
+      valid = false;
+      continue;
+    }
+    if (!valid) {
+      out[i] = 1;
+      reported[seq] = kmx::CarryPolicy::kNoList;
+    } else {
+      // the newest report that has landed: of a pass at least `lag` passes back
+      uint32_t last = kmx::CarryPolicy::kNoList, last_seq = 0;
+      for (uint32_t q = seq > lag ? seq - lag : 0; q >= 1; q--)
+        if (has_report[q]) { last = reported[q]; last_seq = q; break; }
+      out[i] = policy.decide(last, last_seq, seq, n_rows) ? 3 : 2;
+      reported[seq] = list_len[i];
+    }
+    has_report[seq] = true;
+    valid = true;
+  }
+  return kmx::kSuccess;
 }
 int kmamd_carry_pair_stats(kmamd_engine *e, uint64_t *rows_paired) {
   unsigned long long v = 0;

@@ -34,6 +34,48 @@ extern int g_verbosity;
 hipStream_t pooled_stream_acquire(int device);
 void pooled_stream_release(int device, hipStream_t s);
 
+// The host's part in the carried-bounds passes (lloyd_carry.hip): pure bookkeeping over what the device REPORTS, one or
+// two passes late, through a pinned pair of words (the length of a pass's row list and the pass's sequence number).
+// Only speed depends on it -- the device-side list decides what a pass looks at -- but a wrong judgement here can switch
+// the bounds off for a whole run (round 4: a stale report judged after a pause did).  kmamd_carry_policy_sim replays
+// it on the CPU (tests/test_boundary_cpu.py).
+struct CarryPolicy {
+  float list_max = 0.5f;   // a listed pass when at most this share of the rows is on the list (KMCUDA_AMD_CARRY_MAX)
+  // rows the bounds cannot decide (unstructured data): after two COUNTED lists in a row beyond 90 % of the rows the
+  // passes go plain for `backoff` iterations (4, doubling up to 32), then the bounds are tried again
+  uint32_t pause = 0, backoff = 4, hopeless = 0, seen_seq = 0;
+  static constexpr uint32_t kNoList = 0xFFFFFFFFu;   // the report of a pass that had no list to count
+
+  // A pass is about to run with carrying switched on: true = it runs plain (one pass of a pause is used up).
+  bool paused() {
+    if (pause == 0) return false;
+    pause--;
+    return true;
+  }
+  // A pass whose bounds are valid and have been moved once.  (last, last_seq): whatever report has landed; this_seq: the
+  // sequence number this pass will report under.  Returns true for a LISTED pass (the list an earlier pass counted is
+  // short enough), false for a whole pass that only counts its would-be list.  A report is judged once, by sequence
+  // number, and never across a pause: what the passes before it reported describes drifts the pause was the answer to.
+  bool decide(uint32_t last, uint32_t last_seq, uint32_t this_seq, uint32_t n_rows) {
+    const bool listed = last != kNoList && (float)last <= list_max * (float)n_rows;
+    if (last != kNoList && (int32_t)(last_seq - seen_seq) > 0) {
+      seen_seq = last_seq;
+      if ((float)last > 0.9f * (float)n_rows && list_max < 1.0f) {
+        if (++hopeless >= 2) {
+          pause = backoff;
+          backoff = backoff < 32 ? 2 * backoff : 32;
+          hopeless = 0;
+          seen_seq = this_seq;
+        }
+      } else {
+        hopeless = 0;
+        backoff = 4;
+      }
+    }
+    return listed;
+  }
+};
+
 class Engine {
  public:
   Engine() = default;
@@ -143,10 +185,7 @@ class Engine {
   bool carry_valid_ = false;     // ub_ / lb_ describe the assignments and the centroids of the last pass
   uint32_t carry_preps_ = 0;     // centroid preparations since the last pass (exactly 1: drift_ is that update's)
   uint32_t carry_seq_ = 0;
-  float carry_list_max_ = 0.5f;  // a listed pass when at most this share of the rows is on the list (KMCUDA_AMD_CARRY_MAX)
-  // rows the bounds cannot decide (unstructured data): after two lists in a row beyond 90 % of the rows the passes
-  // go plain for carry_backoff_ iterations (4, doubling up to 32), then the bounds are tried again
-  uint32_t carry_pause_ = 0, carry_backoff_ = 4, carry_hopeless_ = 0, carry_seen_seq_ = 0;
+  CarryPolicy carry_policy_;
   float *ub_ = nullptr, *lb_ = nullptr, *drift_ = nullptr;
   // the pair certificates (CarryArgs::l3 / p1 / p2).  KMCUDA_AMD_CARRY_PAIRS=0: without (A/B, tests)
   bool carry_pairs_ = true;

@@ -149,3 +149,42 @@ def test_native_cpython_module_in_the_library():
     from kmcuda_amd import _lib
     syms = subprocess.check_output(["nm", "-D", "--undefined-only", _lib.LIB_PATH]).decode()
     assert not [l for l in syms.splitlines() if " Py" in l or "_Py" in l]
+
+
+def _policy(list_len, n_rows=1000, list_max=0.5, lag=1):
+    import ctypes
+    from kmcuda_amd import _lib
+    L = _lib.lib()
+    n = len(list_len)
+    arr = (ctypes.c_uint32 * n)(*list_len)
+    out = (ctypes.c_uint8 * n)()
+    assert L.kmamd_carry_policy_sim(n, n_rows, ctypes.c_float(list_max), arr, lag, out) == 0
+    return list(out)
+
+
+def test_carried_bounds_host_policy_without_gpu():
+    """CarryPolicy (engine.hpp): what kind of pass the host launches from the list lengths the device reports one or
+    two passes late.  0 plain (paused), 1 whole pass without bounds to move, 2 whole pass counting its would-be list,
+    3 listed pass."""
+    # clustered rows: short lists from the first count on -> listed as soon as a count has landed
+    assert _policy([0, 100, 100, 100, 100, 100], lag=1) == [1, 2, 3, 3, 3, 3]
+    assert _policy([0, 100, 100, 100, 100, 100], lag=2) == [1, 2, 2, 3, 3, 3]
+    # unstructured rows: two counted lists beyond 90 % -> four plain passes, a whole pass, counts again; twice hopeless
+    # again -> eight plain passes
+    out = _policy([1000] * 30, lag=1)
+    assert out[:4] == [1, 2, 2, 2]          # the third moved pass judges the second count: pause from the next pass on
+    assert out[4:8] == [0, 0, 0, 0] and out[8] == 1
+    assert out[9:12] == [2, 2, 2] and out[12:20] == [0] * 8 and out[20] == 1
+    # the bug of round 4: large drifts right after the hand-over point (two hopeless counts), then lists of 12 % -- the
+    # reports from before the pause, and the "no list" report of the whole pass after it, must not start another pause
+    lens = [0, 1000, 1000] + [120] * 20
+    for lag in (1, 2):
+        out = _policy(lens, lag=lag)
+        assert out.count(0) == 4, (lag, out)                       # one pause, of four passes
+        assert out[-8:] == [3] * 8, (lag, out)                     # and listed passes from then on
+    # a single hopeless count between good ones (a cluster died: every row listed once) pauses nothing
+    out = _policy([0, 100, 100, 1000, 100, 100, 100, 100], lag=1)
+    assert 0 not in out and out[-2:] == [3, 3]
+    # list_max = 1 (tests): always listed once a count is known, never paused; list_max = 0: never listed
+    assert 0 not in _policy([1000] * 12, list_max=1.0) and _policy([1000] * 12, list_max=1.0)[-1] == 3
+    assert 3 not in _policy([10] * 12, list_max=0.0)
