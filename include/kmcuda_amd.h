@@ -125,11 +125,12 @@ int kmamd_stop_clear(kmamd_engine *e);
  * the old values.) */
 int kmamd_centroids_written(kmamd_engine *e);
 /* Bounds carried from pass to pass (the Yinyang phase of kmeans_cuda()'s default schedule; lloyd_carry.hip).  on != 0:
- * from the next kmamd_lloyd_assign on, a pass in the two-stage filter's steady state (L2, row cache valid) leaves per
+ * from the next kmamd_lloyd_assign on, a pass in the two-stage filter's steady state (row cache valid) leaves per
  * row an upper bound of the distance to its centroid and a lower bound of the distance to every other centroid --
  * read off the coarse stage's best two scores, no extra distance work --, the next preparation measures how far every
  * centroid has moved, and the next pass only looks at the rows whose bounds, moved by those drifts, no longer certify
- * the assignment (Hamerly's test with the rounding of the reference's arithmetic as margin).  Assignments, previous
+ * the assignment (Hamerly's test with the rounding of the reference's arithmetic as margin; angular metric: one number
+ * per row, the certified gap of the scores).  Assignments, previous
  * assignments and counters are exactly those of plain passes.  Contract: between two passes the centroids change only
  * through kmamd_reduce_apply* / kmamd_apply_delta or are announced with kmamd_centroids_written (which voids the
  * bounds), and `assignments` / `assignments_prev` are the buffers of the previous pass, untouched.

@@ -83,7 +83,7 @@ class Engine:
 
     def set_carry(self, on=True):
         """Carry per-row distance bounds from pass to pass (kmamd_set_carry): in the two-stage filter's steady state
-        (L2, row cache valid) a pass only looks at the rows whose bounds -- read off the last pass's coarse scores,
+        (row cache valid; both metrics) a pass only looks at the rows whose bounds -- read off the last pass's coarse scores,
         moved by the centroids' drifts -- no longer certify their assignment.  Results are those of plain passes."""
         _lib.check(self.lib.kmamd_set_carry(self.h, 1 if on else 0), "kmamd_set_carry")
 
