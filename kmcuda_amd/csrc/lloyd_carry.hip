@@ -28,6 +28,14 @@
 // the row is spared while it exceeds 4 E_ref + the tie slack.  (Charging ||x|| ||c_new - c_old|| instead -- the rows
 // as they are -- spares nothing on rows that share a direction, the usual case for unit rows with positive entries:
 // ||x'|| is a fraction of ||x|| there.)
+//
+// Pair certificates: on clustered data the listed rows are mostly the same ones every pass -- rows of a blob that two
+// centroids share, too close to the border between them for stage 1's operand-rounding bound -- and stage 2 settles
+// them between the same two contenders again and again.  It leaves them (lloyd_refine.hpp, PAIRS) the pair, an upper
+// bound of BOTH distances and a lower bound l3 of every other centroid's (angular: the gap by which both scores exceed
+// every other centroid's); carry_skip_kernel moves those like the other bounds and, while l3 stays above the upper
+// bound by the same margin, queues (row, p1, p2) for the two-contender kernel (lloyd_settle_kernel: the reference's
+// arithmetic and tie rule over the two).  The row is on neither the spared side nor the list.
 #include <cstdlib>
 
 #include "lloyd_coarse.hpp"
