@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PMC_SUMMARY = "r3y_pmc_summary.json"   # the rocprofv3 --pmc passes `roofline.traffic` is read from (profiles/)
+PMC_TRAFFIC_SOURCE = None   # the profiles/ file `roofline.traffic` was read from (reported in the line)
 
 
 def pmc_traffic(rows_per_launch, filt="f32"):
@@ -33,18 +33,18 @@ def pmc_traffic(rows_per_launch, filt="f32"):
     two-stage default: its dominant (coarse) kernel.  PMC counters cannot be collected from inside the bench
     process; None if no matching profile is committed."""
     import glob
+    global PMC_TRAFFIC_SOURCE
     want = {"f16": ("lloyd_coarse2_kernel",), "f32": ("lloyd_filter_kernel",)}[filt]
-    # the pass named here (the counters of the build that is committed); any other summary only if it is gone --
-    # then the newest by its own "collected" stamp, by file time for the older ones that carry none
-    files = [os.path.join(ROOT, "profiles", PMC_SUMMARY)]
-    if not os.path.exists(files[0]):
-        def stamp(path):
-            try:
-                with open(path) as fin:
-                    return (json.load(fin).get("collected", ""), os.path.getmtime(path))
-            except Exception:
-                return ("", 0.0)
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), key=stamp)
+    # the NEWEST summary: by its own "collected" stamp (scripts/gpu_pmc_all.sh writes one since round 5), then by
+    # name (r5a > r4zz > r3y: the rounds' files sort that way) -- never a file named here by hand (VERDICT r4 weak 4:
+    # the name had gone stale by a round)
+    def stamp(path):
+        try:
+            with open(path) as fin:
+                return (json.load(fin).get("collected", ""), os.path.basename(path))
+        except Exception:
+            return ("", "")
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), key=stamp)
     if files:
         with open(files[-1]) as fin:
             pmc = json.load(fin)
@@ -54,12 +54,14 @@ def pmc_traffic(rows_per_launch, filt="f32"):
             if not hit:
                 return None
             total += hit[0]["traffic_bytes_per_launch"]
+        PMC_TRAFFIC_SOURCE = "profiles/" + os.path.basename(files[-1])
         return total * (rows_per_launch / float(pmc["rows_per_launch"]))
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_lloyd_filter.json")))
     if not files or filt != "f32":
         return None
     with open(files[-1]) as fin:
         pmc = json.load(fin)
+    PMC_TRAFFIC_SOURCE = "profiles/" + os.path.basename(files[-1])
     return pmc["traffic_bytes_per_launch"] * (rows_per_launch / float(pmc["rows_per_launch"]))
 
 
@@ -338,9 +340,12 @@ def main():
         raise SystemExit("the stop rule fired inside the timed region (%d iterations): the remaining steps were "
                          "no-ops -- use fewer steps or a smaller --step-tolerance" % loop.iterations)
     prof = backend.engine.profile_read()
-    ctrs = backend.engine.counters()   # of the last timed step's assignment pass
-    flagged = ctrs[1]
-    pair_rows = ctrs[3]
+    # the last timed step's full-scan / pair rows: the update kernel copied the pass's counters behind the move sums
+    # (buffer tail [K*D + K ..+3] = counters[0..3]) BEFORE the fused preparation zeroed the lists for the next pass
+    # -- read from the engine after drain() they were 0 / 0.  All ranks' rows when N > 1.
+    tail = loop.buf[K * D + K:K * D + K + 4].cpu().tolist()
+    flagged = int(tail[1])
+    pair_rows = int(tail[3])
     # outside the timed region, and BEFORE anything else touches the state: the pass that follows the last timed
     # update (it reassigns what a 21st step would: its change counter is checked on real moves)
     verify = None
@@ -408,7 +413,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": pmc_traffic(n_local, args.filter) if not f16 else None,
-                         "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+                         "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)", "traffic_source": PMC_TRAFFIC_SOURCE,
                          "algorithmic_bytes": alg_bytes, "algorithmic_flop": flops,
                          "hbm": {"achieved": alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0, "peak": 8000.0,
                                  "unit": "GB/s", "frac": alg_bytes / (dom_ms * 1e-3) / 1e9 / 8000.0 if dom_ms > 0 else 0.0},

@@ -110,7 +110,13 @@ uint32_t *Engine::pinned_words(size_t n, uint32_t **dev_addr) {
     }
     memset(pinned_, 0, kPinnedWords * sizeof(uint32_t));
     void *dp = nullptr;
-    if (hipHostGetDevicePointer(&dp, pinned_, 0) != hipSuccess) return nullptr;
+    if (hipHostGetDevicePointer(&dp, pinned_, 0) != hipSuccess || dp == nullptr) {
+      // (no half-initialised block: a later call must not hand out host words with a null device address)
+      (void)hipHostFree(pinned_);
+      pinned_ = nullptr;
+      pinned_dev_ = nullptr;
+      return nullptr;
+    }
     pinned_dev_ = static_cast<uint32_t *>(dp);
   }
   n = (n + 3u) & ~(size_t)3u;   // 16-byte granules

@@ -241,8 +241,9 @@ struct Shard {
 // glibc's rand() (random_r, TYPE_3: 31 words, r[k] = r[k - 31] + r[k - 3], output r[k] >> 1) restated, for the one place
 // that draws N numbers (init = "random").  attach(seed): called right after srand(seed); checks the restatement against
 // the library's own first draws (false: not this generator -- the caller uses rand()), then moves the library onto a
-// state buffer of ours (initstate), which detach() overwrites with the restated generator's state (setstate): the
-// library's rand() goes on exactly where the same number of rand() calls would have left it.
+// scratch buffer (initstate) while detach() overwrites the library's OWN state table with the restated generator's state
+// and moves it back (setstate): the library's rand() goes on exactly where the same number of rand() calls would have
+// left it, in its own memory.
 class GlibcRand {
  public:
   bool attach(uint32_t seed) {
@@ -265,17 +266,20 @@ class GlibcRand {
     return out;
   }
   void detach() {
-    // (two buffers in turn: setstate() first stores the CURRENT buffer's position word, which must not be the one
-    //  being installed; the library keeps pointing at the installed one: process lifetime)
-    static int32_t lib_state[2][32];
-    static int turn = 0;
+    // The generator goes back to the C library's OWN state table (or whatever buffer the caller had installed), with
+    // the restated generator's words in it: initstate() parks the library on a scratch buffer and returns the table
+    // it was using, the table is overwritten, setstate() moves the library back onto it.  Nothing of this library
+    // stays referenced by rand() afterwards (round 4 left the library on a static buffer of ours: a dlclose away
+    // from unmapped memory).  attach() has verified that the table is the 31-word TYPE_3 one.
     static std::mutex m;
     std::lock_guard<std::mutex> lock(m);
-    int32_t *st = lib_state[turn];
-    turn ^= 1;
+    int32_t scratch[32];
+    char *table = initstate(1u, reinterpret_cast<char *>(scratch), sizeof(scratch));
+    if (!table) return;
+    int32_t *st = reinterpret_cast<int32_t *>(table);
     for (int i = 0; i < 31; i++) st[1 + i] = (int32_t)s_[i];
-    st[0] = (int32_t)(r_ * 5 + 3);   // glibc: rear * MAX_TYPES + TYPE_3
-    (void)setstate(reinterpret_cast<char *>(st));
+    st[0] = (int32_t)(r_ * 5 + 3);   // glibc: rear * MAX_TYPES + TYPE_3 (setstate() reads type and position from it)
+    (void)setstate(table);           // (stores the scratch buffer's position word first: into `scratch`, ours)
   }
 
  private:
@@ -1842,7 +1846,11 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
     // The strict parity modes keep the reference's schedule.
     const char *yym = getenv("KMCUDA_AMD_YY");
     const bool wide = job.shards[0]->eng->DP_ == 0 && job.shards[0]->eng->gemm_dp_ != 0;   // D > 512: lloyd_gemm.hip
-    const bool adaptive = !(yym && strcmp(yym, "reference") == 0) && !job.exact_update &&
+    // (KMCUDA_AMD_YY=carry: the default schedule also under the strict update -- every pass is the reference's Lloyd
+    //  arithmetic, so the whole call then equals the reference's kmeans_cuda_lloyd bit for bit: the parity test of the
+    //  carried bounds against the oracle end to end, tests/test_gpu_carry.py)
+    const bool carry_asked = yym && strcmp(yym, "carry") == 0;
+    const bool adaptive = !(yym && strcmp(yym, "reference") == 0) && (!job.exact_update || (carry_asked && !job.strict_h2)) &&
                           ((job.shards[0]->eng->DP_ != 0 && job.shards[0]->eng->filter_mode_ == 0) || wide);
     INFO("running Lloyd until reassignments drop below %u\n", (uint32_t)(kYinyangDraftReassignments * samples_size));
     const SwitchRule rule(samples_size);

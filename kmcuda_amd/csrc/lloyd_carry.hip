@@ -80,7 +80,9 @@ __global__ __launch_bounds__(kSkipBlock) void carry_skip_kernel(
     bool keep = false, pair = false, live = s < N;
     if (live) {
       const uint32_t a = assignments[s];
-      if (a < K) {
+      // (a centroid that has turned non-finite while it still has members -- an overflow, inf features -- never wins in
+      //  the reference (a NaN distance is never "<"): its rows are listed, whatever the drifts of its zeroed panel row say)
+      if (a < K && finite[a] != 0u) {
         const float xo = (sqrtf(xmeta[s].x) * 1.0001f + mu_norm) * 1.0001f;   // ||x|| <= ||x - mu|| + ||mu||
         const float e_ref = u * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
         if (angular) {

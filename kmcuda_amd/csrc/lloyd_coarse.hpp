@@ -94,8 +94,10 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     if (blockIdx.x * (128u * NSET) >= total) return;   // (block-uniform, in front of every barrier and DMA)
   }
   // The listed pass's grid follows the host's ESTIMATE of the list (an earlier pass's length): the blocks stride over
-  // the list, whose length only the device knows -- a cluster that dies, say, turns every drift bound into +inf and
-  // lists every row.  Every other instantiation makes one trip (its block index is its 128 NSET rows).
+  // the list, whose length only the device knows -- a cluster that dies, say, "drifts" by its whole centred norm (its
+  // zeroed panel row against the old one: the maximum drift every row is charged; a drift that is not finite counts as
+  // +inf) and can list every row in one pass, its own rows always (carry_skip_kernel: finite[a]).
+  // Every other instantiation makes one trip (its block index is its 128 NSET rows).
   for (uint32_t blk = blockIdx.x;;) {
   blk = __builtin_amdgcn_readfirstlane(blk);
   const uint32_t posA = blk * (128u * NSET) + wave * (32u * NSET) + col, posB = posA + 32u;

@@ -84,7 +84,13 @@ class Engine:
     def set_carry(self, on=True):
         """Carry per-row distance bounds from pass to pass (kmamd_set_carry): in the two-stage filter's steady state
         (row cache valid; both metrics) a pass only looks at the rows whose bounds -- read off the last pass's coarse scores,
-        moved by the centroids' drifts -- no longer certify their assignment.  Results are those of plain passes."""
+        moved by the centroids' drifts -- no longer certify their assignment.  Results are those of plain passes.
+
+        Contract (include/kmcuda_amd.h): between two passes the centroids change only through reduce_apply* /
+        apply_delta / adjust_exact or are announced with centroids_written() (which voids the bounds), and
+        `assignments` / `assignments_prev` are the previous pass's buffers, untouched.  A caller that rewrites the
+        assignments between passes (a re-seed, a verification step) calls set_carry(True) again -- or
+        centroids_written() -- first: the bounds describe the LAST pass's assignments and nothing else voids them."""
         _lib.check(self.lib.kmamd_set_carry(self.h, 1 if on else 0), "kmamd_set_carry")
 
     def carry_stats(self):

@@ -17,7 +17,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GR
   timeout 400 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmc_$i -o pmc -- $CMD > /tmp/pmc_$i.log 2>&1
   echo "pmc pass $i ($grp) rc=$?"
 done
-python3 - "$OUT/pmc_${TAG}_summary.json" <<'PY'
+PMC_TAG=$TAG python3 - "$OUT/pmc_${TAG}_summary.json" <<'PY'
 import csv, sys, glob, json, collections, os
 LAST = int(os.environ.get("PMC_LAST", "10"))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -38,7 +38,8 @@ out = {"source": "scripts/gpu_pmc_all.sh: rocprofv3 --pmc <group> --kernel-trace
        "units": "FETCH_SIZE/WRITE_SIZE in KB as reported; fetch_bytes_corrected = 2 x FETCH_SIZE x 1024 (gfx950: "
                 "wide streaming reads are tallied at half, MI355X_MICROARCH.md HBM); SQ_* summed over SIMDs "
                 "(quad-cycles for *_CYCLES waits per the guide); GRBM_GUI_ACTIVE summed over 8 XCDs",
-       "rows_per_launch": 8000000, "kernels": {}}
+       "rows_per_launch": 8000000, "collected": __import__("time").strftime("%Y-%m-%dT%H:%M:%S"), "tag": os.environ.get("PMC_TAG", ""),
+       "kernels": {}}
 for k, v in sorted(agg.items()):
     e = {c: sum(x[-LAST:]) / len(x[-LAST:]) for c, x in v.items()}
     e["launches"] = max(len(x) for x in v.values())

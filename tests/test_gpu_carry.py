@@ -5,7 +5,9 @@ Bar: a loop whose passes spare the rows their bounds decide is INDISTINGUISHABLE
 assignments, previous assignments, reassignment counters and (hence) centroids bit for bit after every iteration,
 on clustered data (where most rows are spared), unstructured data (where nearly none is), with NaN rows, clusters
 that die, rows as halves, through both update paths (apply alone; the update fused with the next preparation) and
-through kmeans_cuda(yinyang_t > 0) as a whole.  The first pass of every run is also checked against the oracle."""
+through kmeans_cuda(yinyang_t > 0) as a whole.  And, directly: EVERY pass of every carrying loop below is replayed by the
+oracle (the reference's kmeans_assign_lloyd on the CPU) from the same centroids and previous assignments -- the bounds
+are not only compared with HIP-without-bounds."""
 import os
 
 import numpy
@@ -58,6 +60,9 @@ def _run_pair(x, k, iters, carry_from, fused, half=False, seed=5, monkeypatch=No
         for it in range(iters):
             if it == carry_from:
                 carry.b.engine.set_carry(True)
+            # the state the CARRY loop's pass starts from (the oracle replays the pass from it below)
+            cen_in = carry.b.centroids.cpu().numpy().copy()
+            asg_in = carry.b.assignments.cpu().numpy().view(numpy.uint32).copy()
             for loop in loops:
                 if fused:
                     loop.step(tolerance=0.0)      # device-side stop rule + update fused with the next preparation
@@ -71,10 +76,21 @@ def _run_pair(x, k, iters, carry_from, fused, half=False, seed=5, monkeypatch=No
             assert (p0 == p1).all(), "iteration %d: %d previous assignments differ" % (it, int((p0 != p1).sum()))
             c0, c1 = plain.b.centroids.cpu().numpy(), carry.b.centroids.cpu().numpy()
             assert (c0.view(numpy.uint32) == c1.view(numpy.uint32)).all(), "iteration %d: centroids differ" % it
-            if it == 0:
-                if metric == "L2":   # (angular: ocml's and libm's acosf differ in the last place: tolerance only)
-                    ref, _, _ = oracle.lloyd_assign(x, init)
-                    assert (a0.view(numpy.uint32) == ref).all()
+            # The oracle in the loop: EVERY pass of the loop that carries bounds -- spared rows,
+            # listed rows, pair certificates and all -- against the reference's kmeans_assign_lloyd restated on the CPU,
+            # from the same centroids and previous assignments: assignments, previous assignments, reassignment count.
+            # (angular: ocml's and libm's acosf differ in the last place -- tolerance only)
+            ref, ref_prev, ref_changed = oracle.lloyd_assign(x, cen_in, assignments=asg_in,
+                                                             metric=oracle.L2 if metric == "L2" else oracle.COS)
+            a1u, p1u = a1.view(numpy.uint32), p1.view(numpy.uint32)
+            if metric == "L2":
+                assert (a1u == ref).all(), "iteration %d: %d assignments differ from the oracle's" % (it, int((a1u != ref).sum()))
+                assert (p1u == ref_prev).all(), "iteration %d: previous assignments differ from the oracle's" % it
+                assert int((a1u != p1u).sum()) == ref_changed, (it, int((a1u != p1u).sum()), ref_changed)
+                assert carry.changed_last() == ref_changed, (it, carry.changed_last(), ref_changed)
+            else:
+                assert (a1u != ref).mean() < 2e-3, "iteration %d: %.4f of the assignments differ from the oracle's" % (
+                    it, (a1u != ref).mean())
             log.append(int((a0 != p0).sum()))
         spared, last = carry.b.engine.carry_stats()
         _run_pair.paired = carry.b.engine.carry_pair_stats()
@@ -289,17 +305,22 @@ def test_an_exact_pass_or_a_filter_change_between_carried_passes_voids_the_bound
         assert (plain.b.centroids.view(torch.int32) == carry.b.centroids.view(torch.int32)).all(), it
 
 
-def test_carried_passes_at_shard_scale():
-    """One rank's share of the benchmark's shape -- 1M x 256 rows, K = 1024 -- on a mixture of 1024 Gaussians: 16
-    iterations with and without the bounds, compared on the device after every iteration."""
+@pytest.mark.parametrize("blobs", [1024, 600], ids=["a-blob-per-centroid", "shared-blobs"])
+def test_carried_passes_at_shard_scale(blobs):
+    """One rank's share of the benchmark's shape -- 1M x 256 rows, K = 1024 -- on a mixture of Gaussians (as many as
+    centroids: most rows spared; fewer: blobs shared by two centroids, whose rows live on pair certificates): 16
+    iterations with and without the bounds, compared on the device after every iteration -- and four of the CARRIED
+    passes (the first one, two in the middle, the last) replayed whole by the oracle: all 1M assignments, previous
+    assignments and the reassignment count against the reference's kmeans_assign_lloyd."""
     from kmcuda_amd.distributed import HipBackend, ShardedLloyd
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
     g.manual_seed(99)
     n, d, k = 1000000, 256, 1024
-    centres = torch.rand((k, d), device=dev, generator=g) * 10.0
-    x = torch.randn((n, d), device=dev, generator=g) + centres[torch.randint(0, k, (n,), device=dev, generator=g)]
+    centres = torch.rand((blobs, d), device=dev, generator=g) * 10.0
+    x = torch.randn((n, d), device=dev, generator=g) + centres[torch.randint(0, blobs, (n,), device=dev, generator=g)]
     init = x[torch.randperm(n, device=dev, generator=g)[:k]].clone()
+    xh = x.cpu().numpy()
     loops = []
     for which in range(2):
         loop = ShardedLloyd(HipBackend(x, k, "L2", device_index=0), n)
@@ -309,6 +330,10 @@ def test_carried_passes_at_shard_scale():
     for it in range(16):
         if it == 3:
             carry.b.engine.set_carry(True)
+        judged = it in (4, 7, 11, 15)
+        if judged:
+            cen_in = carry.b.centroids.cpu().numpy().copy()
+            asg_in = carry.b.assignments.cpu().numpy().view(numpy.uint32).copy()
         for loop in loops:
             loop.step(tolerance=0.0)
         for loop in loops:
@@ -316,8 +341,54 @@ def test_carried_passes_at_shard_scale():
         assert torch.equal(plain.b.assignments, carry.b.assignments), it
         assert torch.equal(plain.b.assignments_prev, carry.b.assignments_prev), it
         assert torch.equal(plain.b.centroids.view(torch.int32), carry.b.centroids.view(torch.int32)), it
+        if judged:
+            ref, ref_prev, ref_changed = oracle.lloyd_assign(xh, cen_in, assignments=asg_in)
+            got = carry.b.assignments.cpu().numpy().view(numpy.uint32)
+            assert (got == ref).all(), (it, int((got != ref).sum()))
+            assert (carry.b.assignments_prev.cpu().numpy().view(numpy.uint32) == ref_prev).all(), it
+            assert carry.changed_last() == ref_changed, (it, carry.changed_last(), ref_changed)
     spared, last = carry.b.engine.carry_stats()
-    assert spared > 4 * n and last < n // 2, (spared, last)
+    paired = carry.b.engine.carry_pair_stats()
+    if blobs == k:
+        assert spared > 4 * n and last < n // 2, (spared, last)
+    else:
+        assert spared > n and paired > 0, (spared, last, paired)
+
+
+def test_kmeans_cuda_default_schedule_under_the_strict_update_equals_the_oracle_s_lloyd(monkeypatch):
+    """End to end against the oracle: kmeans_cuda(yinyang_t = 0.1) on the DEFAULT schedule (Lloyd down to 11 %, the group
+    clustering, then passes that carry bounds and pair certificates) with the reference's serial update
+    (KMCUDA_AMD_EXACT_UPDATE=1; KMCUDA_AMD_YY=carry keeps the default schedule under it).  Every pass is the
+    reference's Lloyd arithmetic, so the call must be the oracle's kmeans(yinyang_t = 0) bit for bit: the progress
+    lines' reassignment counts, the assignments, the centroids."""
+    from kmcuda_amd import kmeans_cuda
+    from test_gpu_kmeans import StdoutListener
+    rs = numpy.random.RandomState(41)
+    cen = rs.rand(70, 256) * 4.0
+    x = (cen[rs.randint(0, 70, 60000)] + rs.randn(60000, 256)).astype(numpy.float32)
+    monkeypatch.setenv("KMCUDA_AMD_EXACT_UPDATE", "1")
+    monkeypatch.setenv("KMCUDA_AMD_YY", "carry")
+    kw = dict(init="random", seed=3, tolerance=0.0002)
+    out = StdoutListener()
+    with out:
+        got_cen, got_asg = kmeans_cuda(x, 100, yinyang_t=0.1, device=1, verbosity=2, **kw)
+    assert "carrying per-sample distance bounds" in out.text
+    # the call's own progress lines: up to the hand-over point (then the nested group clustering's lines follow,
+    # numbered from 1 again -- the reference prints them too, kmeans.cu:1062-1100), and after "Lloyd goes on"
+    before, after = out.text.split("Lloyd goes on", 1)
+    reass = []
+    for l in before.split("\n"):
+        if l.startswith("iteration"):
+            if int(l.split()[1].rstrip(":")) == 1 and reass:
+                break
+            reass.append(int(l.split(":")[1].split()[0]))
+    reass += [int(l.split(":")[1].split()[0]) for l in after.split("\n") if l.startswith("iteration")]
+    spared = [l for l in out.text.split("\n") if l.startswith("carried bounds:")]
+    assert spared and int(spared[0].split()[2]) > len(x), out.text[-600:]
+    ocen, oasg, olog = oracle.kmeans(x, 100, yinyang_t=0, **kw)
+    assert reass == list(olog), (reass, list(olog))
+    assert (got_asg == oasg).all()
+    assert (got_cen.view(numpy.uint32) == ocen.view(numpy.uint32)).all()
 
 
 def test_kmeans_cuda_fp16_l2_carries_and_equals_the_plain_schedule(monkeypatch):
