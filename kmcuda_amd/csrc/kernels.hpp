@@ -208,11 +208,23 @@ hipError_t launch_kmpp_step(int metric, const float *samples, uint32_t N, uint32
 hipError_t launch_kmpp_step2(int metric, const float *samples, uint32_t N, uint32_t D, const float *centroid,
                              uint32_t cc, float *dists, void *block_stats, double *bpre, void *totals,
                              const uint32_t *fail, hipStream_t st);
-// the reference's chooser (kmcuda.cc:300-326) for step `step` with random number `choice`, on the device: the
-// totals the step left in `totals`; copies the chosen row into centroid slot `step`, or raises *fail = step
-hipError_t launch_kmpp_choose(const float *dists, uint32_t N, const double *bpre, double choice, uint32_t log2n,
-                              uint32_t step, const float *samples, float *centroids, uint32_t D, uint32_t *fail,
-                              void *totals, hipStream_t st);
+// the reference's chooser (kmcuda.cc:300-326) for step `step` with random number `choice`, on the device, over the
+// concatenation of `nshards` row shards (1: the whole job on one GPU): every shard has run the step on its rows
+// (launch_kmpp_step2 / _filtered with its own length and buffers); the kernel runs on shards[0]'s device, reads the
+// other shards' totals / prefixes / distances in place (peer access), copies the chosen row from its owner into
+// centroid slot `step` of EVERY shard, or raises every shard's *fail = step.  offset % 256 == 0 for every shard.
+constexpr int kKmppMaxShards = 16;
+struct KmppShardPtrs {
+  const float *dists;
+  const double *bpre;
+  void *totals;
+  const float *samples;
+  float *centroids;
+  uint32_t *fail;
+  uint32_t offset, length;
+};
+hipError_t launch_kmpp_choose(const KmppShardPtrs *shards, uint32_t nshards, uint32_t N, double choice, uint32_t log2n,
+                              uint32_t step, uint32_t D, hipStream_t st);
 // filtered k-means++ steps (seeding.hip): a centred BYTE copy of the rows (per-row scale and measured residual), then
 // per step the survivors of the k-NN candidate bound get the exact chain.  DP: D rounded up to 128; xs8: N x DP bytes;
 // meta: N x 4 floats; stats: 4 words ([2..3]: exact chains run so far, 64 bits); list: N words.

@@ -89,14 +89,18 @@ std::vector<int> setup_devices(uint32_t device, int verbosity) {
 
 // contiguous row blocks, one per shard (the reference's distribute(), private.h:240-273,
 // aligns to 512 B; rows here are whole samples so plain balanced blocks do)
+// Shards of at least 1024 rows start on multiples of 256 rows: the k-means++ chooser's exact block sums (256 rows) and
+// the reference's butterfly sums (aligned groups of 32 rows, kmeans.cu:63-66) then never straddle two shards, and the
+// per-shard sums concatenate into the one-shard sums (seeding.hip: kmpp_choose_kernel).
 std::vector<std::pair<uint32_t, uint32_t>> row_plan(uint32_t N, size_t nshards) {
   std::vector<std::pair<uint32_t, uint32_t>> plan;
-  uint32_t offset = 0;
-  for (size_t i = 0; i < nshards; i++) {
-    const uint32_t len = (uint32_t)(((uint64_t)N * (i + 1)) / nshards - ((uint64_t)N * i) / nshards);
-    plan.emplace_back(offset, len);
-    offset += len;
-  }
+  const bool align = nshards > 1 && (uint64_t)N / nshards >= 1024u;
+  auto start = [&](size_t i) -> uint32_t {
+    if (i >= nshards) return N;
+    const uint32_t o = (uint32_t)(((uint64_t)N * i) / nshards);
+    return align ? (o & ~255u) : o;
+  };
+  for (size_t i = 0; i < nshards; i++) plan.emplace_back(start(i), start(i + 1) - start(i));
   return plan;
 }
 
@@ -596,47 +600,80 @@ class Job {
         // holds a NaN / inf distance) takes the host way.
         float *host_dists = nullptr;
         struct HostFree { float **p; ~HostFree() { if (*p) (void)hipHostFree(*p); } } host_dists_guard{&host_dists};
-        const bool device_chooser = shards.size() == 1 && !strict_h2 && getenv("KMCUDA_AMD_KMPP_HOST") == nullptr &&
-                                    kmpp_blocks(N) <= (1u << 20);   // (two-level prefix: 1024 x 1024 blocks of 256 rows)
+        // Several row shards (round 5): every shard runs the step on its rows and leaves its own exact block sums; ONE
+        // chooser kernel on the first shard's device reads them where they lie (peer access) as the concatenation
+        // they are and copies the seed's row into every replica (seeding.hip: kmpp_choose_kernel) -- no N-sized
+        // transfer, no host in the loop.  Needs whole 256-row blocks on every shard but the last (row_plan()) and
+        // peer access from the first shard's device to the others'; otherwise the host chooser below.
+        bool device_chooser = !strict_h2 && getenv("KMCUDA_AMD_KMPP_HOST") == nullptr && shards.size() <= (size_t)kKmppMaxShards;
+        for (auto &s : shards) {
+          device_chooser = device_chooser && kmpp_blocks(s->length) <= (1u << 20) &&   // (two-level prefix: 1024 x 1024 blocks of 256 rows)
+                           (s->offset % 256u == 0u) && s->length != 0;
+          if (device_chooser && s->dev != shards[0]->dev) {
+            int can = 0;
+            (void)hipSetDevice(shards[0]->dev);
+            if (hipDeviceCanAccessPeer(&can, shards[0]->dev, s->dev) != hipSuccess || !can) {
+              device_chooser = false;
+            } else {
+              const hipError_t pe = hipDeviceEnablePeerAccess(s->dev, 0);
+              if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) device_chooser = false;
+            }
+            (void)hipGetLastError();
+          }
+        }
         struct Totals { double sum_g, sum_d; uint32_t emin, emax, bad, chosen; };
         Totals *totals_host = nullptr;
         struct TotalsFree { Totals **p; ~TotalsFree() { if (*p) (void)hipHostFree(*p); } } totals_guard{&totals_host};
-        void *block_stats = nullptr, *totals_dev = nullptr;
-        double *bpre = nullptr;
+        // Per shard: block statistics, local prefixes, totals, the fail flag, an event behind its step -- and for the
+        // filtered steps (seeding.hip) a centred byte copy of its rows (xs8; n2c: 4 floats per row): a step's first kernel
+        // drops every row that provably is no closer to the new seed than to an earlier one, the exact chains run for
+        // the rest.  Needs DP + 20 bytes per row beside the rows; without that memory (or KMCUDA_AMD_KMPP_FILTER=0) every
+        // step is the plain one.  Same dists[] after every step either way, hence the same seeds.
+        struct KppShard {
+          int dev = 0;
+          void *block_stats = nullptr, *totals = nullptr;
+          double *bpre = nullptr;
+          uint32_t *fail = nullptr;
+          hipEvent_t ev_step = nullptr;
+          void *xs8 = nullptr;
+          float *n2c = nullptr, *mu = nullptr;
+          uint32_t *stats = nullptr, *list = nullptr;
+          double *part = nullptr;
+          void release() {
+            (void)hipSetDevice(dev);
+            if (ev_step) (void)hipEventDestroy(ev_step);
+            for (void *q : {xs8, (void *)n2c, (void *)mu, (void *)stats, (void *)list, (void *)part})
+              if (q) (void)hipFree(q);
+            ev_step = nullptr; xs8 = nullptr; n2c = nullptr; mu = nullptr; stats = nullptr; list = nullptr; part = nullptr;
+          }
+        };
+        std::vector<KppShard> kpp(shards.size());
+        struct KppFree { std::vector<KppShard> *v; ~KppFree() { for (auto &k : *v) k.release(); } } kpp_guard{&kpp};
+        hipEvent_t ev_chosen = nullptr;
+        struct EvFree { hipEvent_t *e; int dev; ~EvFree() { if (*e) { (void)hipSetDevice(dev); (void)hipEventDestroy(*e); } } } ev_guard{&ev_chosen, shards[0]->dev};
         if (device_chooser) {
-          Shard &s = *shards[0];
-          (void)hipSetDevice(s.dev);
-          unsigned char *bs = nullptr, *td = nullptr;
-          int rc;
-          if ((rc = s.alloc(&bs, kmpp_block_stat_bytes(N)))) return rc;
-          if ((rc = s.alloc(&td, sizeof(Totals)))) return rc;
-          if ((rc = s.alloc(&bpre, kmpp_prefix_doubles(N)))) return rc;
-          block_stats = bs;
-          totals_dev = td;
+          for (size_t q = 0; q < shards.size(); q++) {
+            Shard &s = *shards[q];
+            KppShard &k = kpp[q];
+            k.dev = s.dev;
+            (void)hipSetDevice(s.dev);
+            unsigned char *bs = nullptr, *td = nullptr;
+            int rc;
+            if ((rc = s.alloc(&bs, kmpp_block_stat_bytes(s.length)))) return rc;
+            if ((rc = s.alloc(&td, sizeof(Totals)))) return rc;
+            if ((rc = s.alloc(&k.bpre, kmpp_prefix_doubles(s.length)))) return rc;
+            if ((rc = s.alloc(&k.fail, 1))) return rc;
+            k.block_stats = bs;
+            k.totals = td;
+            if (hipMemsetAsync(k.fail, 0, sizeof(uint32_t), s.eng->stream_) != hipSuccess) return kmcudaRuntimeError;
+            if (shards.size() > 1 && hipEventCreateWithFlags(&k.ev_step, hipEventDisableTiming) != hipSuccess) return kmcudaRuntimeError;
+          }
+          (void)hipSetDevice(shards[0]->dev);
+          if (shards.size() > 1 && hipEventCreateWithFlags(&ev_chosen, hipEventDisableTiming) != hipSuccess) return kmcudaRuntimeError;
           if (hipHostMalloc(reinterpret_cast<void **>(&totals_host), sizeof(Totals), hipHostMallocDefault) != hipSuccess)
             return kmcudaMemoryAllocationFailure;
         }
-        // Filtered steps (seeding.hip): a centred byte copy of the rows (kpp_xs16; kpp_n2c: 4 floats per row); a step's first kernel drops every row
-        // that provably is no closer to the new seed than to an earlier one, the exact chains run for the rest.
-        // Needs DP + 20 bytes per row beside the rows; without that memory (or KMCUDA_AMD_KMPP_FILTER=0) every
-        // step is the plain one.  Same dists[] after every step either way, hence the same seeds.
         const uint32_t kpp_dp = ((uint32_t)D + 127u) / 128u * 128u;
-        void *kpp_xs16 = nullptr;
-        float *kpp_n2c = nullptr, *kpp_mu = nullptr, *kpp_mux = nullptr;
-        uint32_t *kpp_stats = nullptr, *kpp_list = nullptr;
-        double *kpp_part = nullptr;
-        struct KppFree {
-          void **a; float **b, **c; uint32_t **d, **e; double **f; float **g;
-          ~KppFree() {
-            if (*a) (void)hipFree(*a);
-            if (*b) (void)hipFree(*b);
-            if (*c) (void)hipFree(*c);
-            if (*d) (void)hipFree(*d);
-            if (*e) (void)hipFree(*e);
-            if (*f) (void)hipFree(*f);
-            if (*g) (void)hipFree(*g);
-          }
-        } kpp_guard{&kpp_xs16, &kpp_n2c, &kpp_mu, &kpp_stats, &kpp_list, &kpp_part, &kpp_mux};
         // (small jobs: the plain step is a few launches of nothing; KMCUDA_AMD_KMPP_FILTER=2 filters them too: tests)
         bool kpp_filter = device_chooser && K >= 8 && N >= 65536u && kpp_dp <= 8192u;
         if (const char *v = getenv("KMCUDA_AMD_KMPP_FILTER")) {
@@ -644,21 +681,36 @@ class Job {
           kpp_filter = f >= 2 ? (device_chooser && K >= 3 && kpp_dp <= 8192u) : (kpp_filter && f != 0);
         }
         if (kpp_filter) {
-          Shard &s = *shards[0];
-          (void)hipSetDevice(s.dev);
-          const bool ok = hipMalloc(&kpp_xs16, (size_t)N * kpp_dp) == hipSuccess &&   // (bytes)
-                          hipMalloc(reinterpret_cast<void **>(&kpp_n2c), (size_t)N * 4 * sizeof(float)) == hipSuccess &&
-                          hipMalloc(reinterpret_cast<void **>(&kpp_mu), (size_t)kpp_dp * sizeof(float)) == hipSuccess &&
-                          hipMalloc(reinterpret_cast<void **>(&kpp_stats), 4 * sizeof(uint32_t)) == hipSuccess &&
-                          hipMalloc(reinterpret_cast<void **>(&kpp_list), (size_t)N * sizeof(uint32_t)) == hipSuccess &&
-                          hipMalloc(reinterpret_cast<void **>(&kpp_part), (size_t)64 * D * sizeof(double)) == hipSuccess;
+          bool ok = true;
+          for (size_t q = 0; q < shards.size() && ok; q++) {
+            Shard &s = *shards[q];
+            KppShard &k = kpp[q];
+            (void)hipSetDevice(s.dev);
+            ok = hipMalloc(&k.xs8, (size_t)s.length * kpp_dp) == hipSuccess &&   // (bytes)
+                 hipMalloc(reinterpret_cast<void **>(&k.n2c), (size_t)s.length * 4 * sizeof(float)) == hipSuccess &&
+                 hipMalloc(reinterpret_cast<void **>(&k.mu), (size_t)kpp_dp * sizeof(float)) == hipSuccess &&
+                 hipMalloc(reinterpret_cast<void **>(&k.stats), 4 * sizeof(uint32_t)) == hipSuccess &&
+                 hipMalloc(reinterpret_cast<void **>(&k.list), (size_t)s.length * sizeof(uint32_t)) == hipSuccess &&
+                 hipMalloc(reinterpret_cast<void **>(&k.part), (size_t)64 * D * sizeof(double)) == hipSuccess;
+          }
           if (!ok) {
             (void)hipGetLastError();
             kpp_filter = false;
+            for (auto &k : kpp) {   // (the events stay: release() is the end of the seeding)
+              (void)hipSetDevice(k.dev);
+              for (void *q : {k.xs8, (void *)k.n2c, (void *)k.mu, (void *)k.stats, (void *)k.list, (void *)k.part})
+                if (q) (void)hipFree(q);
+              k.xs8 = nullptr; k.n2c = nullptr; k.mu = nullptr; k.stats = nullptr; k.list = nullptr; k.part = nullptr;
+            }
             DEBUG("k-means++: no memory for the byte copy of the rows, plain steps\n");
-          } else if (launch_kmpp_cache(s.samples, N, D, kpp_dp, kpp_part, kpp_mu, kpp_xs16, kpp_n2c, kpp_stats,
-                                       s.eng->stream_) != hipSuccess) {
-            return kmcudaRuntimeError;
+          } else {
+            for (size_t q = 0; q < shards.size(); q++) {
+              Shard &s = *shards[q];
+              KppShard &k = kpp[q];
+              (void)hipSetDevice(s.dev);
+              if (launch_kmpp_cache(s.samples, s.length, D, kpp_dp, k.part, k.mu, k.xs8, k.n2c, k.stats, s.eng->stream_) != hipSuccess)
+                return kmcudaRuntimeError;
+            }
           }
         }
         uint32_t log2n = 0;
@@ -713,15 +765,19 @@ class Job {
           // (seeding.hip).  A step the device cannot decide raises a flag that turns the rest of the enqueued
           // kernels into no-ops; the host looks after every batch of steps, chooses that seed the reference's way from the
           // distances as that step left them, lowers the flag and goes on behind it.
-          Shard &s = *shards[0];
-          (void)hipSetDevice(s.dev);
-          hipStream_t st = s.eng->stream_;
-          uint32_t *fail_dev = nullptr;
-          {
-            int rc = s.alloc(&fail_dev, 1);
-            if (rc) return rc;
+          // Several shards: one host thread enqueues every shard's step, the chooser on the first shard's stream behind
+          // events of the others' steps, and the others' next steps behind an event of the chooser (the events must be
+          // RECORDED before they are waited for: one thread, in order).
+          Shard &lead = *shards[0];
+          const bool many = shards.size() > 1;
+          std::vector<KmppShardPtrs> views(shards.size());
+          for (size_t q = 0; q < shards.size(); q++) {
+            Shard &s = *shards[q];
+            views[q].dists = s.dists; views[q].bpre = kpp[q].bpre; views[q].totals = kpp[q].totals;
+            views[q].samples = s.samples; views[q].centroids = s.centroids; views[q].fail = kpp[q].fail;
+            views[q].offset = s.offset; views[q].length = s.length;
           }
-          if (hipMemsetAsync(fail_dev, 0, sizeof(uint32_t), st) != hipSuccess) return kmcudaRuntimeError;
+          if (many) RETERR(sync_all());   // (the first seed's peer copies and the flags' memsets have landed everywhere)
           std::vector<double> choices(K, 0.0);
           // (steps enqueued behind an undecided one are wasted launches: the batch starts small, doubles while the
           //  device decides, and falls back to one step after a hand-over -- a data set whose distances span too many
@@ -738,21 +794,38 @@ class Job {
                 choices[t] = ((rand() + .0) / RAND_MAX);   // kmcuda.cc:300
                 drawn = t + 1;
               }
-              const float *newest = s.centroids + (size_t)(t - 1) * D;
-              const hipError_t se =
-                  (kpp_filter && t >= 2)
-                      ? launch_kmpp_step_filtered(metric, s.samples, N, D, kpp_dp, kpp_xs16, kpp_n2c, kpp_mu, kpp_stats, kpp_list,
-                                                  newest, t, s.dists, block_stats, bpre, totals_dev, fail_dev, st)
-                      : launch_kmpp_step2(metric, s.samples, N, D, newest, t, s.dists, block_stats, bpre, totals_dev,
-                                          fail_dev, st);
-              if (se != hipSuccess) return kmcudaRuntimeError;
-              if (launch_kmpp_choose(s.dists, N, bpre, choices[t], log2n, t, s.samples, s.centroids, D, fail_dev,
-                                     totals_dev, st) != hipSuccess)
+              for (size_t q = 0; q < shards.size(); q++) {
+                Shard &s = *shards[q];
+                KppShard &k = kpp[q];
+                (void)hipSetDevice(s.dev);
+                hipStream_t st = s.eng->stream_;
+                const float *newest = s.centroids + (size_t)(t - 1) * D;
+                const hipError_t se =
+                    (kpp_filter && t >= 2)
+                        ? launch_kmpp_step_filtered(metric, s.samples, s.length, D, kpp_dp, k.xs8, k.n2c, k.mu, k.stats, k.list,
+                                                    newest, t, s.dists, k.block_stats, k.bpre, k.totals, k.fail, st)
+                        : launch_kmpp_step2(metric, s.samples, s.length, D, newest, t, s.dists, k.block_stats, k.bpre, k.totals,
+                                            k.fail, st);
+                if (se != hipSuccess) return kmcudaRuntimeError;
+                if (many && q != 0 && hipEventRecord(k.ev_step, st) != hipSuccess) return kmcudaRuntimeError;
+              }
+              (void)hipSetDevice(lead.dev);
+              for (size_t q = 1; q < shards.size(); q++)
+                if (hipStreamWaitEvent(lead.eng->stream_, kpp[q].ev_step, 0) != hipSuccess) return kmcudaRuntimeError;
+              if (launch_kmpp_choose(views.data(), (uint32_t)views.size(), N, choices[t], log2n, t, D, lead.eng->stream_) != hipSuccess)
                 return kmcudaRuntimeError;
+              if (many) {
+                if (hipEventRecord(ev_chosen, lead.eng->stream_) != hipSuccess) return kmcudaRuntimeError;
+                for (size_t q = 1; q < shards.size(); q++) {
+                  (void)hipSetDevice(shards[q]->dev);
+                  if (hipStreamWaitEvent(shards[q]->eng->stream_, ev_chosen, 0) != hipSuccess) return kmcudaRuntimeError;
+                }
+              }
             }
             uint32_t failed = 0;
-            if (hipMemcpyAsync(totals_host, fail_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipStreamSynchronize(st) != hipSuccess)
+            (void)hipSetDevice(lead.dev);
+            if (hipMemcpyAsync(totals_host, kpp[0].fail, sizeof(uint32_t), hipMemcpyDeviceToHost, lead.eng->stream_) != hipSuccess ||
+                hipStreamSynchronize(lead.eng->stream_) != hipSuccess)
               return kmcudaMemoryCopyError;
             memcpy(&failed, totals_host, sizeof(uint32_t));
             if (failed == 0) {
@@ -762,8 +835,12 @@ class Job {
             }
             batch = 1;
             if (failed < i || failed >= end) return kmcudaRuntimeError;
-            RETERR(host_choose(failed, choices[failed]));
-            if (hipMemsetAsync(fail_dev, 0, sizeof(uint32_t), st) != hipSuccess) return kmcudaRuntimeError;
+            RETERR(host_choose(failed, choices[failed]));   // (waits for every shard: sync_all)
+            for (size_t q = 0; q < shards.size(); q++) {
+              (void)hipSetDevice(shards[q]->dev);
+              if (hipMemsetAsync(kpp[q].fail, 0, sizeof(uint32_t), shards[q]->eng->stream_) != hipSuccess) return kmcudaRuntimeError;
+            }
+            if (many) RETERR(sync_all());   // (the seed's peer copies and the lowered flags, before the chooser reads across shards)
             i = failed + 1;
           }
         } else {
@@ -785,7 +862,14 @@ class Job {
         RETERR(sync_all());
         if (kpp_filter) {
           unsigned long long chains = 0;
-          if (hipMemcpy(&chains, kpp_stats + 2, sizeof(chains), hipMemcpyDeviceToHost) == hipSuccess)
+          bool read = true;
+          for (auto &k : kpp) {
+            unsigned long long v = 0;
+            (void)hipSetDevice(k.dev);
+            read = read && hipMemcpy(&v, k.stats + 2, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess;
+            chains += v;
+          }
+          if (read)
             DEBUG("k-means++: the filtered steps ran %llu exact chains for %llu (row, step) pairs\n", chains,
                   (unsigned long long)N * (K - 2));
         }

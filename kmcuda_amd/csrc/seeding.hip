@@ -634,42 +634,91 @@ __global__ __launch_bounds__(1024) void kmpp_reduce_b_kernel(const KmppChunk *__
 // NaN / inf distance, an exponent range too wide for exact sums, an index out of range) raises *fail = step: every
 // later kmpp kernel of the run returns at once, and the host chooses that seed the reference's way before it goes on.
 // Otherwise the chosen row is copied into centroid slot `step` here.
-__global__ __launch_bounds__(kKmppBlock) void kmpp_choose_kernel(const float *__restrict__ dists, uint32_t N,
-                                                                 const double *__restrict__ bpre_local, uint32_t nb,
-                                                                 double choice, uint32_t log2n, uint32_t step,
-                                                                 const float *__restrict__ samples,
-                                                                 float *__restrict__ centroids, uint32_t D,
-                                                                 uint32_t *__restrict__ fail,
-                                                                 KmppTotals *__restrict__ out) {
-  if (*fail) return;
-  {
+//
+// ROW SHARDS (round 5; kmeans.cu:774-828 runs the step on every device, kmcuda.cc:286-326 chooses on the host from all
+// N distances): every shard runs the step on its own rows and leaves its own block sums, local prefixes and totals
+// (launch_kmpp_step2 / _filtered with the shard's length); ONE chooser -- this kernel, on the first shard's device --
+// reads them where they lie (peer access; a few KB per step) as the concatenation they are: the exact prefix of global
+// block i is  (the exact sum of the earlier shards' totals) + (the owning shard's local prefix).  Exact sums are
+// order free, so every number the chooser compares is the one-shard chooser's, bit for bit, and so is the seed; the
+// seed's row is copied from its owner into slot `step` of EVERY shard's centroid replica by this kernel.  No
+// N-sized transfer, no host in the loop.  Needs every shard but the last to hold whole blocks of kKmppBlock rows
+// (row_plan() aligns the shards that way): the reference's butterfly sums are over aligned groups of 32 rows.
+struct KmppShardView {
+  const float *dists;        // the shard's distances (its rows in order)
+  const double *bpre;        // its local block prefixes + carries (launch_kmpp_reduce)
+  const KmppTotals *totals;  // its totals
+  const float *samples;      // its rows
+  float *centroids;          // its centroid replica (slot `step` is written)
+  uint32_t *fail;            // its fail flag (raised on every shard together)
+  uint32_t offset, length;   // its rows: [offset, offset + length) of the N; offset % kKmppBlock == 0
+};
+struct KmppShards {
+  KmppShardView s[kKmppMaxShards];
+  uint32_t n;
+};
+__global__ __launch_bounds__(kKmppBlock) void kmpp_choose_kernel(KmppShards sh, uint32_t N, double choice, uint32_t log2n,
+                                                                 uint32_t step, uint32_t D, KmppTotals *__restrict__ out) {
+  if (*sh.s[0].fail) return;
+  const uint32_t tid = threadIdx.x, S = sh.n;
+  __shared__ double base[kKmppMaxShards + 1];    // exact sum of the distances of the shards before s; [S] = of all
+  __shared__ uint32_t blk0[kKmppMaxShards + 1];  // first global block of shard s; [S] = the number of blocks
+  __shared__ double sum_g_s;
+  __shared__ uint32_t exact_s;
+  if (tid == 0) {
+    double b = 0.0, g = 0.0;
+    uint32_t emin = 0xFFFFu, emax = 0u, bad = 0u;
+    for (uint32_t i = 0; i < S; i++) {
+      const KmppTotals *t = sh.s[i].totals;
+      base[i] = b;
+      blk0[i] = sh.s[i].offset / kKmppBlock;
+      b += t->sum_d;
+      g += t->sum_g;
+      emin = min(emin, t->emin);
+      emax = max(emax, t->emax);
+      bad |= t->bad;
+    }
+    base[S] = b;
+    blk0[S] = (N + kKmppBlock - 1) / kKmppBlock;
+    sum_g_s = g;
     // every partial sum of the distances (and of their butterfly sums) is exact in double iff
     // (emax + 1 + log2 N) - (emin - 23) <= 53
-    const bool none = out->emin > out->emax;
-    const bool exact = !out->bad && (none || out->emax - out->emin + log2n <= 29u);
-    if (!exact) {
-      if (threadIdx.x == 0) *fail = step;
-      return;
-    }
+    const bool none = emin > emax;
+    exact_s = (!bad && (none || emax - emin + log2n <= 29u)) ? 1u : 0u;
+    if (!exact_s)
+      for (uint32_t i = 0; i < S; i++) *sh.s[i].fail = step;
   }
+  __syncthreads();
+  if (!exact_s) return;
+  const uint32_t nb = blk0[S];
   const uint32_t ca = (uint32_t)(choice * (double)N);   // kmcuda.cc:301-302
-  const double cs = choice * out->sum_g;
-  // exclusive prefix of block i (i <= nb): the chunk-local part + the chunk's carry (kmpp_reduce_*), stored behind
-  // the nb local values: carry[c] = bpre_local[nb + c], carry[nchunks] = the total
-  const uint32_t nchunks = (nb + 1023u) / 1024u;
-  struct Pre {
-    const double *local, *carry;
-    uint32_t nb, nchunks;
-    __device__ double operator[](uint32_t i) const { return i >= nb ? carry[nchunks] : local[i] + carry[i >> 10]; }
-  } bpre{bpre_local, bpre_local + nb, nb, nchunks};
+  const double cs = choice * sum_g_s;
+  // exclusive prefix of global block i (i <= nb): the owner's chunk-local part + its chunk's carry (kmpp_reduce_*,
+  // stored behind the shard's local values) + the exact sum of the shards before it; bpre[nb] = the total
+  auto shard_of_block = [&](uint32_t i) -> uint32_t {
+    uint32_t o = 0;
+    for (uint32_t q = 1; q < S; q++)
+      if (i >= blk0[q]) o = q;
+    return o;
+  };
+  auto bpre = [&](uint32_t i) -> double {
+    if (i >= nb) return base[S];
+    const uint32_t o = shard_of_block(i), li = i - blk0[o];
+    const uint32_t nbl = (sh.s[o].length + kKmppBlock - 1) / kKmppBlock;
+    const double *loc = sh.s[o].bpre;
+    return base[o] + (loc[li] + loc[nbl + (li >> 10)]);
+  };
+  auto dist_at = [&](uint32_t row) -> float {   // row < N
+    const uint32_t o = shard_of_block(row / kKmppBlock);
+    return sh.s[o].dists[row - sh.s[o].offset];
+  };
   __shared__ double incl[kKmppBlock];
   __shared__ uint32_t best;
   __shared__ double pca_s;
-  const uint32_t tid = threadIdx.x;
   // inclusive exact prefix of block bi into incl[] (Hillis-Steele; any order is exact)
   auto scan_block = [&](uint32_t bi) {
     const uint32_t s = bi * kKmppBlock + tid;
-    incl[tid] = s < N ? (double)dists[s] : 0.0;
+    incl[tid] = s < N ? (double)dist_at(s) : 0.0;
     __syncthreads();
     for (int o = 1; o < kKmppBlock; o <<= 1) {
       const double t = tid >= (uint32_t)o ? incl[tid - o] : 0.0;
@@ -688,7 +737,7 @@ __global__ __launch_bounds__(kKmppBlock) void kmpp_choose_kernel(const float *__
     {
       const uint32_t probe = (tid + 1) * stride - 1;              // last block of my range
       const uint32_t pb = probe < nb ? probe : nb - 1;
-      if (tid * stride < nb && bpre[pb + 1] - dca >= cs) atomicMin(&best, tid);
+      if (tid * stride < nb && bpre(pb + 1) - dca >= cs) atomicMin(&best, tid);
     }
     __syncthreads();
     const uint32_t range = best;
@@ -697,7 +746,7 @@ __global__ __launch_bounds__(kKmppBlock) void kmpp_choose_kernel(const float *__
     __syncthreads();
     if (range != 0xFFFFFFFFu) {
       for (uint32_t bi = range * stride + tid; bi < nb && bi < (range + 1) * stride; bi += kKmppBlock)
-        if (bpre[bi + 1] - dca >= cs) { atomicMin(&best, bi); break; }
+        if (bpre(bi + 1) - dca >= cs) { atomicMin(&best, bi); break; }
     }
     __syncthreads();
     const uint32_t bi = best;
@@ -706,8 +755,8 @@ __global__ __launch_bounds__(kKmppBlock) void kmpp_choose_kernel(const float *__
     scan_block(bi);
     if (tid == 0) best = 0xFFFFFFFFu;
     __syncthreads();
-    const uint32_t m = bi * kKmppBlock + tid + 1;                  // prefix(m) = bpre[bi] + incl[tid]
-    if (m <= N && (bpre[bi] + incl[tid]) - dca >= cs) atomicMin(&best, m);
+    const uint32_t m = bi * kKmppBlock + tid + 1;                  // prefix(m) = bpre(bi) + incl[tid]
+    if (m <= N && (bpre(bi) + incl[tid]) - dca >= cs) atomicMin(&best, m);
     __syncthreads();
     const uint32_t r = best;
     __syncthreads();
@@ -718,10 +767,10 @@ __global__ __launch_bounds__(kKmppBlock) void kmpp_choose_kernel(const float *__
   if (!forward) {   // prefix(ca), exact
     const uint32_t bi = ca / kKmppBlock, r = ca % kKmppBlock;
     double pca;
-    if (bi >= nb) pca = bpre[nb];
+    if (bi >= nb) pca = bpre(nb);
     else {
       scan_block(bi);
-      pca = bpre[bi] + (r ? incl[r - 1] : 0.0);
+      pca = bpre(bi) + (r ? incl[r - 1] : 0.0);
     }
     if (tid == 0) pca_s = pca;
     __syncthreads();
@@ -731,17 +780,24 @@ __global__ __launch_bounds__(kKmppBlock) void kmpp_choose_kernel(const float *__
   if (forward) {
     j = first_m(0.0);
   } else {
-    const double dca = ca < N ? (double)dists[ca] : 0.0;
+    const double dca = ca < N ? (double)dist_at(ca) : 0.0;
     const uint32_t m0 = first_m(dca);
     const uint32_t mp = m0 == 0u ? 0u : min(m0 - 1u, ca + 1u);
     j = max(2u, mp);
   }
   if (tid == 0) out->chosen = j;
   if (j == 0u || j > N) {   // (the reference reports an internal bug here: so will the host)
-    if (tid == 0) *fail = step;
+    if (tid == 0)
+      for (uint32_t i = 0; i < S; i++) *sh.s[i].fail = step;
     return;
   }
-  for (uint32_t f = tid; f < D; f += kKmppBlock) centroids[(size_t)step * D + f] = samples[(size_t)(j - 1) * D + f];
+  // the seed's row, from its owner into every shard's replica
+  const uint32_t o = shard_of_block((j - 1u) / kKmppBlock);
+  const float *src = sh.s[o].samples + (size_t)(j - 1u - sh.s[o].offset) * D;
+  for (uint32_t f = tid; f < D; f += kKmppBlock) {
+    const float v = src[f];
+    for (uint32_t i = 0; i < S; i++) sh.s[i].centroids[(size_t)step * D + f] = v;
+  }
 }
 
 // bpre: nb local prefixes, then nchunks + 1 carries, then (16-byte aligned) the nchunks chunk records
@@ -826,12 +882,24 @@ hipError_t launch_kmpp_step_filtered(int metric, const float *samples, uint32_t 
   return launch_kmpp_reduce(block_stats, nb, bpre, totals_host, fail, st);
 }
 
-hipError_t launch_kmpp_choose(const float *dists, uint32_t N, const double *bpre, double choice, uint32_t log2n,
-                              uint32_t step, const float *samples, float *centroids, uint32_t D, uint32_t *fail,
-                              void *totals, hipStream_t st) {
-  const uint32_t nb = (N + kKmppBlock - 1) / kKmppBlock;
-  hipLaunchKernelGGL(kmpp_choose_kernel, dim3(1), dim3(kKmppBlock), 0, st, dists, N, bpre, nb, choice, log2n, step,
-                     samples, centroids, D, fail, reinterpret_cast<KmppTotals *>(totals));
+hipError_t launch_kmpp_choose(const KmppShardPtrs *shards, uint32_t nshards, uint32_t N, double choice, uint32_t log2n,
+                              uint32_t step, uint32_t D, hipStream_t st) {
+  if (nshards == 0 || nshards > (uint32_t)kKmppMaxShards) return hipErrorInvalidValue;
+  KmppShards sh;
+  sh.n = nshards;
+  for (uint32_t i = 0; i < nshards; i++) {
+    sh.s[i].dists = shards[i].dists;
+    sh.s[i].bpre = shards[i].bpre;
+    sh.s[i].totals = reinterpret_cast<const KmppTotals *>(shards[i].totals);
+    sh.s[i].samples = shards[i].samples;
+    sh.s[i].centroids = shards[i].centroids;
+    sh.s[i].fail = shards[i].fail;
+    sh.s[i].offset = shards[i].offset;
+    sh.s[i].length = shards[i].length;
+    if (i && shards[i].offset % kKmppBlock != 0) return hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(kmpp_choose_kernel, dim3(1), dim3(kKmppBlock), 0, st, sh, N, choice, log2n, step, D,
+                     reinterpret_cast<KmppTotals *>(shards[0].totals));
   return hipGetLastError();
 }
 
