@@ -186,6 +186,7 @@ def api_bench(args):
     asg = torch.empty(N, dtype=torch.int32, device=dev)
     torch.cuda.synchronize(dev)
     mask = (1 << ngpu) - 1 if not os.environ.get("KMCUDA_AMD_VIRTUAL_SHARDS") else 1
+    os.environ["KMCUDA_AMD_TIME_COLLECTIVE"] = "1"   # events around every iteration's all-reduce inside the library
     runs = []
     calls = max(args.warmup > 0, 0) + max(args.steps // 10, 1)   # one warm-up call, then ~steps/10 timed calls
     for i in range(calls):
@@ -200,8 +201,11 @@ def api_bench(args):
         loop_s, setup_s = ctypes.c_double(), ctypes.c_double()
         L.kmamd_last_run_stats(ctypes.byref(it), ctypes.byref(loop_s), ctypes.byref(setup_s), ctypes.byref(shards),
                                ctypes.byref(rccl))
+        cms, cn = ctypes.c_double(), ctypes.c_uint32()
+        L.kmamd_last_run_collective(ctypes.byref(cms), ctypes.byref(cn))
         runs.append({"wall_s": wall, "loop_s": loop_s.value, "setup_s": setup_s.value, "iterations": it.value,
-                     "shards": shards.value, "rccl_ranks": rccl.value})
+                     "shards": shards.value, "rccl_ranks": rccl.value, "collective_ms": cms.value,
+                     "collectives": cn.value})
     timed = runs[1:] if len(runs) > 1 else runs
     iters = sum(r["iterations"] for r in timed)
     loop = sum(r["loop_s"] for r in timed)
@@ -214,7 +218,12 @@ def api_bench(args):
                                   "yinyang_t=0" % (mask, N, D, K, args.tolerance),
                       "samples": N, "features": D, "clusters": K, "parallelism": "rows/%d" % timed[0]["shards"],
                       # (the same keys as the one-process-per-GPU line: a scaling run can take either loop)
+                      # ranks of the communicator the library created (ncclCommInitAll over the mask); 1: none
                       "ranks_seen_by_communicator": max(1, timed[0]["rccl_ranks"]),
+                      # the library's own events around every iteration's all-reduce on the first shard's stream (its
+                      # one-device stand-in under KMCUDA_AMD_VIRTUAL_SHARDS); null: one shard
+                      "collective_ms_per_step": (sum(r["collective_ms"] for r in timed) / sum(r["collectives"] for r in timed))
+                      if sum(r["collectives"] for r in timed) else None,
                       "collective": ("ncclAllReduce inside the library (ncclCommInitAll over the device mask), one fused "
                                      "fp64 buffer per iteration" if timed[0]["rccl_ranks"] else
                                      ("none" if timed[0]["shards"] == 1 else "sum kernel on one device (KMCUDA_AMD_VIRTUAL_SHARDS)")),
@@ -290,7 +299,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend_name)
-        ranks_seen = dist.get_world_size()
+        ranks_seen = dist.get_world_size(dist.group.WORLD)   # (the group ShardedLloyd reduces over)
         if not os.environ.get("KMCUDA_AMD_BENCH_SINGLE_DEVICE") and torch.cuda.device_count() < world:
             raise SystemExit("--gpus %d but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
 
@@ -329,12 +338,15 @@ def main():
     for _ in range(args.warmup):
         loop.step(args.step_tolerance)
     backend.engine.profile(True)
+    loop.time_collective = world > 1   # a pair of events around every timed step's all-reduce, on its stream
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loop.step(args.step_tolerance)
     barrier()
     elapsed = time.perf_counter() - t0
+    loop.time_collective = False
+    coll_ms, coll_n = loop.collective_ms()
     loop.drain()
     if loop.stopped:
         raise SystemExit("the stop rule fired inside the timed region (%d iterations): the remaining steps were "
@@ -405,10 +417,15 @@ def main():
             "config": {"workload": "%dx%d %s L2 Lloyd iteration, K=%d, uniform[0,1) rows, init=random; "
                                    "rows sharded %d-way" % (N, D, "fp16x2" if f16 else "fp32", K, world),
                        "samples": N, "features": D, "clusters": K, "parallelism": "rows/%d" % world,
+                       # the communicator the timed steps' all-reduce ran on, asked itself (not WORLD_SIZE)
                        "ranks_seen_by_communicator": ranks_seen,
                        "collective": ("one all-reduce of %d doubles per iteration (%s)" %
                                       (K * D + K + 4, os.environ.get("KMCUDA_AMD_BENCH_BACKEND", "nccl = RCCL")))
                        if world > 1 else "none",
+                       # rank 0's events around the all-reduce on its stream: the exchange + the wait for the slowest
+                       # rank's move sums (null: one rank, no collective)
+                       "collective_ms_per_step": (coll_ms / coll_n) if coll_n else None,
+                       "collectives_timed": coll_n,
                        "filter": args.filter, "row_cache": bool(cached)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak,

@@ -202,6 +202,12 @@ int kmamd_profile_enable(kmamd_engine *e, int on);
 int kmamd_last_run_stats(uint32_t *iterations, double *loop_seconds, double *setup_seconds, uint32_t *shards,
                          uint32_t *rccl_ranks);
 
+/* With KMCUDA_AMD_TIME_COLLECTIVE=1 in the environment of that call (several row shards): the summed duration of its
+ * per-iteration all-reduces -- ncclAllReduce over the device mask, or the one-device stand-in under
+ * KMCUDA_AMD_VIRTUAL_SHARDS -- as HIP events on the first shard's stream bracketed them (the wait for the slowest
+ * shard's move sums is inside: that is what an iteration pays), and their number.  0 / 0 otherwise. */
+int kmamd_last_run_collective(double *milliseconds, uint32_t *count);
+
 /* host -> raw device pointer copy on `device` (what python.cc:330-345 does with cudaMemcpy for imported
  * centroids in device-pointer mode; lets a binding without a HIP runtime of its own fill caller-owned memory). */
 int kmamd_copy_to_device(int device, void *dst, const void *host_src, size_t bytes);

@@ -307,7 +307,11 @@ class GlibcRand {
 
 // what the last kmeans_cuda() call did (kmamd_last_run_stats): iterations of the Lloyd / Yinyang loops and
 // the wall time spent in them (everything after seeding), for drivers that time the drop-in entry point
-struct RunStats { uint32_t iterations = 0; double loop_seconds = 0, setup_seconds = 0; uint32_t shards = 0, rccl = 0; };
+struct RunStats {
+  uint32_t iterations = 0; double loop_seconds = 0, setup_seconds = 0; uint32_t shards = 0, rccl = 0;
+  // kmamd_last_run_collective: the per-iteration all-reduce as HIP events on the first shard's stream saw it
+  double collective_ms = 0; uint32_t collectives = 0;
+};
 RunStats g_last_run;        // published once per kmeans_cuda() call, under g_last_run_mutex (the Python module
 std::mutex g_last_run_mutex;  // releases the GIL around the call: two threads may be inside the library)
 
@@ -329,6 +333,36 @@ class Job {
   double **reduce_ptrs_dev = nullptr;
   hipEvent_t ev_summed = nullptr;
   bool speculate = true;   // KMCUDA_AMD_SPECULATE=0: every iteration waits for its stop test before its update
+  // KMCUDA_AMD_TIME_COLLECTIVE=1 (bench.py --api): a pair of HIP events around every iteration's all-reduce (its
+  // stand-in under KMCUDA_AMD_VIRTUAL_SHARDS) on the first shard's stream, read when the loops are over -- so that a
+  // multi-GPU run says by itself how long the collective takes (kmamd_last_run_collective)
+  bool time_collective = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> coll_events;
+  size_t coll_used = 0;
+  int collective_mark(bool begin) {
+    if (!time_collective) return 0;
+    (void)hipSetDevice(shards[0]->dev);
+    if (begin) {
+      if (coll_used == coll_events.size()) {
+        if (coll_events.size() >= 4096) { time_collective = false; return 0; }   // (enough of a sample)
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return kmcudaRuntimeError;
+        coll_events.emplace_back(a, b);
+      }
+      return hipEventRecord(coll_events[coll_used].first, shards[0]->eng->stream_) == hipSuccess ? 0 : (int)kmcudaRuntimeError;
+    }
+    return hipEventRecord(coll_events[coll_used++].second, shards[0]->eng->stream_) == hipSuccess ? 0 : (int)kmcudaRuntimeError;
+  }
+  void collective_collect() {   // after sync_all()
+    for (size_t i = 0; i < coll_used; i++) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, coll_events[i].first, coll_events[i].second) == hipSuccess) {
+        stats.collective_ms += ms;
+        stats.collectives++;
+      }
+    }
+    coll_used = 0;
+  }
 
   ~Job() {
     for (void *c : comms)
@@ -336,6 +370,7 @@ class Job {
     if (!shards.empty()) (void)hipSetDevice(shards[0]->dev);
     if (reduce_ptrs_dev) (void)hipFree(reduce_ptrs_dev);
     if (ev_summed) (void)hipEventDestroy(ev_summed);
+    for (auto &e : coll_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   }
 
   // on_stream: the (single) shard's engine works on this existing stream instead of creating one -- the nested job
@@ -433,6 +468,7 @@ class Job {
       if (hipEventCreateWithFlags(&ev_summed, hipEventDisableTiming) != hipSuccess) return kmcudaRuntimeError;
     }
     if (const char *v = getenv("KMCUDA_AMD_SPECULATE")) speculate = atoi(v) != 0;
+    if (const char *v = getenv("KMCUDA_AMD_TIME_COLLECTIVE")) time_collective = atoi(v) != 0 && (shards.size() > 1 || !comms.empty());
     return sync_all();  // uploads complete: later cross-stream reads of the samples are safe
   }
 
@@ -990,6 +1026,7 @@ class Job {
     if (shards.size() == 1 && comms.empty()) return 0;
     const size_t len = (size_t)K * D + K + 4;
     if (!comms.empty()) {
+      RETERR(collective_mark(true));
       if (rccl.GroupStart() != 0) return kmcudaRuntimeError;
       for (size_t i = 0; i < shards.size(); i++) {
         auto &s = shards[i];
@@ -998,7 +1035,7 @@ class Job {
           return kmcudaRuntimeError;
       }
       if (rccl.GroupEnd() != 0) return kmcudaRuntimeError;
-      return 0;
+      return collective_mark(false);
     }
     // several shards on ONE device (test hook KMCUDA_AMD_VIRTUAL_SHARDS): a fixed-order sum kernel on the first
     // shard's stream once every shard's buffer is written; the other streams go on when it is done.  No host wait:
@@ -1009,8 +1046,10 @@ class Job {
       if (hipEventRecord(s->ev_filled, s->eng->stream_) != hipSuccess) return kmcudaRuntimeError;
       if (s.get() != &f && hipStreamWaitEvent(f.eng->stream_, s->ev_filled, 0) != hipSuccess) return kmcudaRuntimeError;
     }
+    RETERR(collective_mark(true));   // (behind the waits: the stand-in's own time, not the slowest shard's lag)
     if (launch_sum_buffers(reduce_ptrs_dev, (uint32_t)shards.size(), len, f.eng->stream_) != hipSuccess)
       return kmcudaRuntimeError;
+    RETERR(collective_mark(false));
     if (hipEventRecord(ev_summed, f.eng->stream_) != hipSuccess) return kmcudaRuntimeError;
     for (auto &s : shards)
       if (s.get() != &f && hipStreamWaitEvent(s->eng->stream_, ev_summed, 0) != hipSuccess) return kmcudaRuntimeError;
@@ -1987,6 +2026,7 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
   }
   RETERR(job.sync_all());
   job.stats.loop_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
+  job.collective_collect();
   {
     std::lock_guard<std::mutex> lock(g_last_run_mutex);
     g_last_run = job.stats;
@@ -2034,6 +2074,13 @@ int kmamd_last_run_stats(uint32_t *iterations, double *loop_seconds, double *set
   if (setup_seconds) *setup_seconds = g_last_run.setup_seconds;
   if (shards) *shards = g_last_run.shards;
   if (rccl_ranks) *rccl_ranks = g_last_run.rccl;
+  return kmcudaSuccess;
+}
+
+int kmamd_last_run_collective(double *milliseconds, uint32_t *count) {
+  std::lock_guard<std::mutex> lock(g_last_run_mutex);
+  if (milliseconds) *milliseconds = g_last_run.collective_ms;
+  if (count) *count = g_last_run.collectives;
   return kmcudaSuccess;
 }
 

@@ -118,6 +118,8 @@ class ShardedLloyd:
         self.buf = backend.new_reduce_buffer()
         self.iterations = 0
         self.stopped = False
+        self.time_collective = False   # bench.py: bracket every all-reduce with events (collective_ms())
+        self._collective_events = []
         # The collective is enqueued with the ENGINE's stream as torch's current stream: RCCL then orders with the
         # iteration's kernels through two events on the device.  On torch's default stream -- the legacy NULL stream,
         # which orders with the engine's blocking stream implicitly -- the same call cost 110 us per iteration on a
@@ -131,11 +133,34 @@ class ShardedLloyd:
             self._collective_stream = torch.cuda.ExternalStream(handle, device=backend.device)
 
     def _all_reduce(self):
-        if self._collective_stream is not None:
-            with torch.cuda.stream(self._collective_stream):
-                dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
-        else:
+        stream = self._collective_stream
+        ctx = torch.cuda.stream(stream) if stream is not None else None
+        timed = self.time_collective and self.buf.is_cuda
+        if ctx is not None:
+            ctx.__enter__()
+        try:
+            if timed:   # a pair of events on the stream the collective is enqueued on (collective_ms())
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(torch.cuda.current_stream(self.buf.device))
             dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
+            if timed:
+                b.record(torch.cuda.current_stream(self.buf.device))
+                self._collective_events.append((a, b))
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+
+    def collective_ms(self):
+        """(summed milliseconds, number) of the all-reduces enqueued while `time_collective` was set, as events on their
+        stream bracketed them -- the wait for the slowest rank's move sums included: what an iteration pays for the
+        exchange.  Waits for the device; clears the record."""
+        if not self._collective_events:
+            return 0.0, 0
+        torch.cuda.synchronize(self.buf.device)
+        total = sum(a.elapsed_time(b) for a, b in self._collective_events)
+        n = len(self._collective_events)
+        self._collective_events = []
+        return total, n
 
     def set_centroids(self, centroids):
         """Replicated initial centroids (rank 0's are broadcast).  Starts a new run: the stop state of an earlier

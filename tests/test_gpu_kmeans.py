@@ -583,6 +583,61 @@ def test_kmeanspp_filtered_steps_equal_plain_steps(monkeypatch, case):
     assert (res[0][1] == res[1][1]).all()
 
 
+@pytest.mark.parametrize("filt", ["2", "0"], ids=["filtered", "plain"])
+@pytest.mark.parametrize("case", ["uniform", "blobs", "duplicates", "wide", "ragged", "nan", "cos"])
+def test_kmeanspp_over_row_shards_equals_one_shard_and_the_oracle(monkeypatch, case, filt):
+    """k-means++ over several row shards (KMCUDA_AMD_VIRTUAL_SHARDS: every shard its own engine, distances, block
+    sums and byte copy; ONE chooser kernel reading the shards' exact sums as the concatenation they are,
+    seeding.hip): the SEEDS -- tolerance 1 stops the run before its first update, so the centroids that come back
+    are the seeds -- equal the one-shard seeds bit for bit, with 3 and with 8 shards (the last one ragged), and the
+    oracle's (kmcuda.cc:262-336 restated: N distances, butterfly sum, sequential double prefix sums).  The device
+    chooser must really have run ('wide' spans so many binades that every step goes to the host chooser; 'cos'
+    hands over once a seed's own angle sits binades under the bulk)."""
+    from kmcuda_amd import kmeans_cuda
+    rs = numpy.random.RandomState(sum(map(ord, case)))
+    if case == "uniform":
+        x, k = rs.rand(30000, 64).astype(numpy.float32), 200
+    elif case == "blobs":
+        cen = rs.rand(40, 32) * 20
+        x, k = (cen[rs.randint(0, 40, 25000)] + rs.randn(25000, 32)).astype(numpy.float32), 64
+    elif case == "duplicates":
+        base = rs.rand(500, 16).astype(numpy.float32)
+        x, k = base[rs.randint(0, 500, 20000)].copy(), 100
+    elif case == "wide":
+        x, k = (rs.rand(20000, 8) * numpy.exp(rs.uniform(-12, 12, (20000, 1)))).astype(numpy.float32), 50
+    elif case == "ragged":
+        x, k = rs.rand(10007, 33).astype(numpy.float32), 257
+    elif case == "nan":
+        x, k = rs.rand(20000, 48).astype(numpy.float32), 60
+        x[::97, 0] = numpy.nan
+        x[5::101, 7] = numpy.nan
+    else:
+        x, k = rs.randn(30000, 48).astype(numpy.float32), 120
+    metric = "cos" if case == "cos" else "L2"
+    if metric == "cos":
+        x = (x / numpy.linalg.norm(x, axis=1, keepdims=True)).astype(numpy.float32)
+    monkeypatch.setenv("KMCUDA_AMD_KMPP_FILTER", filt)
+    seeds = {}
+    for shards in (1, 3, 8):
+        if shards > 1:
+            monkeypatch.setenv("KMCUDA_AMD_VIRTUAL_SHARDS", str(shards))
+        else:
+            monkeypatch.delenv("KMCUDA_AMD_VIRTUAL_SHARDS", raising=False)
+        out = StdoutListener()
+        with out:
+            c, a = kmeans_cuda(x, k, tolerance=1.0, init="k-means++", seed=11, yinyang_t=0, verbosity=2, metric=metric)
+        seeds[shards] = c.copy()
+        import re
+        took = re.search(r"k-means\+\+: (\d+) of (\d+) steps took the host chooser", out.text)
+        assert took, "the device chooser did not run with %d shard(s)" % shards   # (only printed on that path)
+        if case not in ("wide", "cos", "nan"):   # (a NaN distance sends the step to the host chooser as well)
+            assert int(took.group(1)) == 0, took.group(0)
+    ref = oracle.init_centroids(x, k, "kmeans++", seed=11, metric=oracle.COS if metric == "cos" else oracle.L2)
+    for shards in (1, 3, 8):
+        assert (seeds[shards].view(numpy.uint32) == ref.view(numpy.uint32)).all(), \
+            "%d shard(s): %d seeds differ from the oracle's" % (shards, int((seeds[shards] != ref).any(axis=1).sum()))
+
+
 def test_native_module_equals_ctypes_mirror(fixture13k):
     """The CPython module inside libKMCUDA.so (`import libKMCUDA`, python.cc's counterpart) against the
     ctypes mirror: same centroids / assignments / average distance, result arrays referenced by the caller

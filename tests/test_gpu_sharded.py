@@ -123,10 +123,12 @@ def _rccl_worker(rank, port, out):
     x, init = _data()
     loop = ShardedLloyd(HipBackend(torch.from_numpy(x).to(dev), len(init), "L2", device_index=0), len(x), reduce_always=True)
     loop.set_centroids(torch.from_numpy(init).to(dev))
+    loop.time_collective = True   # (bench.py's collective_ms_per_step: a pair of events around every all-reduce)
     log = loop.run(tolerance=0.002, max_iter=60)
     torch.cuda.synchronize(dev)
+    coll_ms, coll_n = loop.collective_ms()
     numpy.savez(out, log=numpy.array(log), asg=loop.b.assignments.cpu().numpy().view(numpy.uint32),
-                cen=loop.b.centroids.cpu().numpy())
+                cen=loop.b.centroids.cpu().numpy(), coll=numpy.array([coll_ms, coll_n]))
     dist.destroy_process_group()
 
 
@@ -151,6 +153,8 @@ def test_rccl_one_rank_all_reduce_in_the_loop(tmp_path):
     assert list(got["log"]) == log
     assert (got["asg"] == loop.b.assignments.cpu().numpy().view(numpy.uint32)).all()
     assert numpy.array_equal(got["cen"], loop.b.centroids.cpu().numpy(), equal_nan=True)
+    # every enqueued iteration's all-reduce was bracketed (the speculative loop enqueues one pass past the stop)
+    assert got["coll"][1] >= len(log) and 0.0 < got["coll"][0] < 1000.0, got["coll"]
 
 
 def test_rccl_one_rank_inside_kmeans_cuda(monkeypatch):
@@ -161,6 +165,36 @@ def test_rccl_one_rank_inside_kmeans_cuda(monkeypatch):
     x, _ = _data()
     c0, a0 = kmeans_cuda(x, 24, init="k-means++", seed=5, tolerance=0.002, yinyang_t=0, device=1)
     monkeypatch.setenv("KMCUDA_AMD_FORCE_RCCL", "1")
+    monkeypatch.setenv("KMCUDA_AMD_TIME_COLLECTIVE", "1")
     c1, a1 = kmeans_cuda(x, 24, init="k-means++", seed=5, tolerance=0.002, yinyang_t=0, device=1)
     assert (a0 == a1).all()
     assert numpy.array_equal(c0, c1, equal_nan=True)
+    # the library's own clock around its grouped ncclAllReduce (kmamd_last_run_collective; bench.py --api reports it)
+    import ctypes
+    from kmcuda_amd import _lib
+    it, ranks, ms, n = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_double(), ctypes.c_uint32()
+    _lib.lib().kmamd_last_run_stats(ctypes.byref(it), None, None, None, ctypes.byref(ranks))
+    _lib.lib().kmamd_last_run_collective(ctypes.byref(ms), ctypes.byref(n))
+    assert ranks.value == 1 and n.value >= it.value > 0 and 0.0 < ms.value < 1000.0, (ranks.value, n.value, it.value, ms.value)
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_on_one_gpu_reports_its_communicator_and_collective():
+    """bench.py --gpus 2 as the driver starts it (python bench.py --gpus N: it becomes the launcher of N ranks), with the
+    test hooks that put both ranks on GPU 0 over gloo: the line must say how many ranks the communicator of the timed
+    steps really had and how long the all-reduce took per step, by events on its stream -- so that the first real
+    multi-GPU run explains itself -- and the timed state must verify against the oracle."""
+    import json
+    import subprocess
+    env = dict(os.environ, KMCUDA_AMD_BENCH_SINGLE_DEVICE="1", KMCUDA_AMD_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--samples", "200000", "--clusters",
+                          "256", "--steps", "4", "--warmup", "3", "--no-cpu-baseline", "--verify-rows", "20000"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen_by_communicator"] == 2
+    assert d["config"]["collectives_timed"] == 4 and d["config"]["collective_ms_per_step"] > 0.0
+    assert d["verify"]["ok"], d["verify"]
+    assert d["rows_pair_refined_last_step"] + d["rows_full_exact_scan_last_step"] >= 0 and d["reassigned_last_step"] > 0
+
