@@ -1,7 +1,6 @@
 // engine.cpp -- Engine implementation + the step-level C ABI of include/kmcuda_amd.h.
 #include "engine.hpp"
 
-#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -16,44 +15,9 @@ namespace kmx {
 
 int g_verbosity = 0;
 
-// rocBLAS, loaded on first use (lloyd_gemm.hip's stage 1: one plain library GEMM per row chunk); a process that
-// never clusters rows wider than 512 features never loads it
 namespace {
-struct Rocblas {
-  void *lib = nullptr;
-  bool tried = false;
-  int (*create_handle)(void **) = nullptr;
-  int (*destroy_handle)(void *) = nullptr;
-  int (*set_stream)(void *, hipStream_t) = nullptr;
-  int (*gemm_ex)(void *, int, int, int, int, int, const void *, const void *, int, int, const void *, int, int,
-                 const void *, const void *, int, int, void *, int, int, int, int, int32_t, uint32_t) = nullptr;
-  std::once_flag once;
-  bool ok = false;
-  // (called from every shard's worker thread: once, and nobody sees half-filled pointers -- ADVICE r3)
-  bool load() {
-    std::call_once(once, [this] {
-      for (const char *name : {"librocblas.so.5", "librocblas.so.4", "librocblas.so", "/opt/rocm/lib/librocblas.so.5",
-                               "/opt/rocm/lib/librocblas.so.4", "/opt/rocm/lib/librocblas.so"}) {
-        lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (lib) break;
-      }
-      if (lib) {
-        create_handle = (decltype(create_handle))dlsym(lib, "rocblas_create_handle");
-        destroy_handle = (decltype(destroy_handle))dlsym(lib, "rocblas_destroy_handle");
-        set_stream = (decltype(set_stream))dlsym(lib, "rocblas_set_stream");
-        gemm_ex = (decltype(gemm_ex))dlsym(lib, "rocblas_gemm_ex");
-        ok = create_handle && destroy_handle && set_stream && gemm_ex;
-      }
-      if (!ok && g_verbosity > 0)
-        printf("rows wider than 512 features: no usable librocblas.so -- the exact kernels serve them (slowly)\n");
-    });
-    return ok;
-  }
-};
-Rocblas g_rocblas;
 std::mutex g_stream_pool_mutex;
 std::vector<std::vector<hipStream_t>> g_stream_pool;   // [device] -> idle streams
-constexpr int kRbOpNone = 111, kRbOpTrans = 112, kRbF16 = 150, kRbF32 = 151;   // rocblas-types.h
 }  // namespace
 
 hipStream_t pooled_stream_acquire(int device) {
@@ -137,7 +101,6 @@ Engine::~Engine() {
   if (ev_join_) (void)hipEventDestroy(ev_join_);
   for (hipEvent_t e : ev_report_)
     if (e) (void)hipEventDestroy(e);
-  if (rb_handle_ && g_rocblas.destroy_handle) (void)g_rocblas.destroy_handle(rb_handle_);
   if (ev_rows_) (void)hipEventDestroy(ev_rows_);
   if (own_stream_ && stream_) {
     if (blocking_stream_) (void)hipStreamDestroy(stream_);
@@ -151,7 +114,8 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if (const char *c = getenv("KMCUDA_AMD_ROW_CACHE")) row_cache_allowed_ = atoi(c) != 0;
   if (const char *c = getenv("KMCUDA_AMD_CARRY_PAIRS")) carry_pairs_ = atoi(c) != 0;
   if (const char *c = getenv("KMCUDA_AMD_SETTLE")) settle_ = atoi(c) != 0;
-  if (const char *c = getenv("KMCUDA_AMD_GEMM")) gemm_ok_ = atoi(c) != 0;
+  if (const char *c = getenv("KMCUDA_AMD_WIDE")) gemm_ok_ = atoi(c) != 0;
+  if (const char *c = getenv("KMCUDA_AMD_GEMM")) gemm_ok_ = atoi(c) != 0;   // (the switch's name while stage 1 was a library GEMM)
   if (const char *u = getenv("KMCUDA_AMD_UPDATE"))
     ms_.force = strcmp(u, "radix") == 0 ? 1 : (strcmp(u, "sync") == 0 ? 2 : (strcmp(u, "bucket") == 0 ? 3 : 0));
   if (D == 0 || K < 1 || K >= 0x7FFFFFFFu) return kInvalidArguments;  // K == 1: Yinyang group clustering with one group
@@ -184,8 +148,9 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   // same angle, so near-ties go to the exact kernel which applies acosf like the reference.
   tie_slack_ = metric == 0 ? 0.f : 1e-6f;
 
-  // no register-resident filter for this D: stage 1 through a library GEMM (lloyd_gemm.hip), operands padded to 32
-  gemm_dp_ = (DP_ == 0 && gemm_ok_) ? (D + 31) / 32 * 32 : 0;
+  // no register-resident filter for this D: stage 1 streams both operands through LDS (lloyd_wide.hip), in 64-feature
+  // chunks: operands padded to 64
+  gemm_dp_ = (DP_ == 0 && gemm_ok_) ? (D + 63) / 64 * 64 : 0;
   const uint32_t dp = DP_ ? DP_ : (gemm_dp_ ? gemm_dp_ : 8);
   int rc;
   if ((rc = alloc(&csqr_, K))) return rc;
@@ -553,7 +518,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   if (N_ == 0) return kSuccess;
   if (!exact_only && DP_ == 0 && gemm_dp_ != 0 && !gemm_failed_) {
     const int rc = lloyd_assign_gemm(a, centroids);
-    if (rc != kNoSuchDevice + 100) return rc;   // (that code: rocBLAS is not there -- the exact kernel below serves the shape)
+    if (rc != kNoSuchDevice + 100) return rc;   // (that code: no memory for its buffers -- the exact kernel below serves the shape)
   }
   if (exact_only || DP_ == 0 || (DP_ > 256 && filter_mode_ != 0)) {
     span_begin(1);
@@ -703,34 +668,29 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   return kSuccess;
 }
 
-// D beyond the register-resident filters: lloyd_gemm.hip.  prepare_centroids() has run (csqr, ct, mean -- frozen
+// D beyond the register-resident filters: lloyd_wide.hip.  prepare_centroids() has run (csqr, ct, mean -- frozen
 // while a row copy is alive --, centred fp32 panel, biases, statistics, list counters zeroed).
 int Engine::lloyd_assign_gemm(const LloydArgs &a0, const float *centroids) {
-  constexpr int kNoRocblas = kNoSuchDevice + 100;
-  if (!g_rocblas.load()) return kNoRocblas;
-  if (!rb_handle_ && g_rocblas.create_handle(&rb_handle_) != 0) { rb_handle_ = nullptr; return kNoRocblas; }
-  if (g_rocblas.set_stream(rb_handle_, stream_) != 0) return kRuntimeError;
+  constexpr int kNoFilter = kNoSuchDevice + 100;
   LloydArgs a = a0;
   const uint32_t DG = gemm_dp_;
   const uint32_t k_pad64 = (K_pad_ + 63u) / 64u * 64u;
-  // This path's own memory (half copy of the rows, a chunk of scores, the contender tables) is an optimisation: a job
-  // whose rows fit but whose copies do not runs on the exact kernels, as it did before this path existed
+  // This path's own memory (half copy of the rows, the listed rows' contender table) is an optimisation: a job whose
+  // rows fit but whose copies do not runs on the exact kernels, as it did before this path existed
   auto no_memory = [&]() {
     (void)hipGetLastError();
-    if (g_verbosity > 0) printf("rows wider than 512 features: no memory for the GEMM filter's buffers -- exact kernels\n");
+    if (g_verbosity > 0) printf("rows wider than 512 features: no memory for the matrix-core filter's buffers -- exact kernels\n");
     gemm_failed_ = true;   // (gemm_dp_ stays: the preparation's buffers are sized by it)
-    return kNoRocblas;
+    return kNoFilter;
   };
   if (!panelhi_) {
     uint16_t *phi = nullptr;
     if (alloc(&phi, (size_t)k_pad64 * (DG + 2))) return no_memory();
     panelhi_ = phi;
   }
-  const uint32_t chunk = gemm_chunk_rows(N_, K_pad_);
-  if (!gscores_) {
-    if (alloc(&gscores_, (size_t)chunk * K_pad_) || alloc(&gund_rows_, gemm_rows_words(N_)) ||
-        alloc(&gund_cont_, gemm_cont_words(N_)) || alloc(&gcursors_, 64 * 32)) {
-      gscores_ = nullptr;
+  if (!gund_cont_) {
+    if (alloc(&undecided_, N_) || alloc(&und_thr_, N_) || alloc(&gund_cont_, wide_cont_words(N_))) {
+      gund_cont_ = nullptr;
       return no_memory();
     }
   }
@@ -753,24 +713,10 @@ int Engine::lloyd_assign_gemm(const LloydArgs &a0, const float *centroids) {
       mu_frozen_ = true;
     }
   }
-  KMX_HIP(hipMemsetAsync(gcursors_, 0, 64 * 32 * sizeof(uint32_t), stream_), kRuntimeError);
-  const float one = 1.f, zero = 0.f;
-  for (uint32_t r0 = 0; r0 < N_; r0 += chunk) {
-    const uint32_t nr = N_ - r0 < chunk ? N_ - r0 : chunk;
-    // row-major S (nr x K_pad) = Xhi (nr x DG) . Chi^T, i.e. column-major S^T (K_pad x nr) = op(A) op(B) with
-    // A = Chi seen column-major as DG x K_pad (transposed), B = Xhi seen column-major as DG x nr
-    const int st = g_rocblas.gemm_ex(rb_handle_, kRbOpTrans, kRbOpNone, (int)K_pad_, (int)nr, (int)DG, &one, panelhi_,
-                                     kRbF16, (int)DG, reinterpret_cast<const uint16_t *>(xg16_) + (size_t)r0 * DG, kRbF16,
-                                     (int)DG, &zero, gscores_, kRbF32, (int)K_pad_, gscores_, kRbF32, (int)K_pad_, kRbF32,
-                                     0 /* rocblas_gemm_algo_standard */, 0, 0);
-    if (st != 0) {
-      if (g_verbosity > 0) printf("rocblas_gemm_ex -> %d\n", st);
-      return kRuntimeError;
-    }
-    KMX_HIP(launch_gemm_decide(a, gscores_, K_pad_, r0, nr, DG, xgmeta_, gund_rows_, gund_cont_, gcursors_, stream_),
-            kRuntimeError);
-  }
-  KMX_HIP(launch_gemm_contenders(metric_, a, centroids, DG, gund_rows_, gund_cont_, gcursors_, stream_), kRuntimeError);
+  span_begin(3);   // the dominant kernels on their own, inside the filter span
+  KMX_HIP(launch_lloyd_wide(a, xg16_, xgmeta_, DG, panelhi_, undecided_, und_thr_, gund_cont_, stream_), kRuntimeError);
+  span_end();
+  KMX_HIP(launch_wide_contenders(metric_, a, centroids, DG, undecided_, gund_cont_, stream_), kRuntimeError);
   span_end();
   span_begin(1);
   if (settle_ && lloyd_settle_supported(a, centroids)) {

@@ -161,16 +161,14 @@ class Engine {
   // 1: f32 matrix-core filter (KMCUDA_AMD_FILTER=f32; cross-check)
   int filter_mode_ = 0;
   bool settle_ = true;   // KMCUDA_AMD_SETTLE=0: lloyd_pair + lloyd_exact instead of the one-launch lloyd_settle
-  // D beyond the register-resident filters (lloyd_gemm.hip): stage 1 through rocBLAS.  gemm_dp_ = D rounded up to 32
-  // (0: not this path); KMCUDA_AMD_GEMM=0 leaves such shapes to the exact kernels (the cross-check)
+  // D beyond the register-resident filters (lloyd_wide.hip): both operands streamed through LDS.  gemm_dp_ = D rounded
+  // up to 64 (0: not this path); KMCUDA_AMD_WIDE=0 leaves such shapes to the exact kernels (the cross-check)
   uint32_t gemm_dp_ = 0;
   bool gemm_ok_ = true;
   bool gemm_failed_ = false;   // its buffers could not be allocated: the exact kernels serve the shape
-  void *rb_handle_ = nullptr;
   void *xg16_ = nullptr;          // N x gemm_dp_ halves: x - mu, row-major (this path's row cache)
   float *xgmeta_ = nullptr;       // 4 floats per row
-  float *gscores_ = nullptr;      // chunk x K_pad
-  uint32_t *gund_rows_ = nullptr, *gund_cont_ = nullptr, *gcursors_ = nullptr;
+  uint32_t *gund_cont_ = nullptr; // per listed row: the number of its contenders, then up to 16 of them
   int lloyd_assign_gemm(const LloydArgs &a, const float *centroids);
   // row cache of the coarse filter stage (lloyd_f16.hip: row_cache_kernel); set_row_cache()
   bool row_cache_allowed_ = true;   // KMCUDA_AMD_ROW_CACHE=0 vetoes it

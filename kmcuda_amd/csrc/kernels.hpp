@@ -141,20 +141,17 @@ hipError_t launch_lloyd_refine_carry(const LloydArgs &a, const void *rows, bool 
 hipError_t launch_row_cache(const void *rows, bool half_rows, uint32_t N, uint32_t D, uint32_t DP, const float *mu,
                             void *xcache, float *xmeta, hipStream_t st);
 
-// lloyd_gemm.hip -- the assignment filter for D beyond the register-resident kernels: stage 1's scores from one
-// library GEMM per row chunk (f16 operands, f32 accumulation), contenders read off the score matrix
+// lloyd_wide.hip -- the assignment filter for D beyond the register-resident kernels: both operands streamed through
+// LDS (256 rows x 256 centroids per block, 64-feature chunks), best / second-best per row in registers, no score ever
+// written; then the same sweep over the rows it listed for their contenders
 hipError_t launch_row_halves(const void *rows, bool half_rows, uint32_t N, uint32_t D, uint32_t DG, const float *mu,
                              void *xg, float *meta /* 4 floats per row */, hipStream_t st);
-uint32_t gemm_list_cap(uint32_t N);
-uint32_t gemm_chunk_rows(uint32_t N, uint32_t K_pad);
-size_t gemm_cont_words(uint32_t N);   // contender table: 64 lists x cap x (1 + 16) words
-size_t gemm_rows_words(uint32_t N);   // row lists: 64 x cap words
-hipError_t launch_gemm_decide(const LloydArgs &a, const float *scores, uint32_t ld, uint32_t row0, uint32_t nrows,
-                              uint32_t DG, const float *meta, uint32_t *und_rows, uint32_t *und_cont,
-                              uint32_t *cursors /* 64 x 32 words, zero on entry of a pass */, hipStream_t st);
-hipError_t launch_gemm_contenders(int metric, const LloydArgs &a, const float *centroids, uint32_t DG,
-                                  const uint32_t *und_rows, const uint32_t *und_cont, const uint32_t *cursors,
-                                  hipStream_t st);
+size_t wide_cont_words(uint32_t N);   // contender table: (1 + 16) words per row
+// commits / lists (undecided, und_thr, counters[4]) every row, then writes the listed rows' contenders (und_cont)
+hipError_t launch_lloyd_wide(const LloydArgs &a, const void *xg, const float *meta, uint32_t DG /* % 64 == 0 */,
+                             const void *panelhi, uint32_t *undecided, float *und_thr, uint32_t *und_cont, hipStream_t st);
+hipError_t launch_wide_contenders(int metric, const LloydArgs &a, const float *centroids, uint32_t DG,
+                                  const uint32_t *und_rows, const uint32_t *und_cont, hipStream_t st);
 
 // update.hip -- centroid update (reference: kmeans.cu:366-429 kmeans_adjust)
 size_t sort_temp_bytes(size_t n, uint32_t max_key);

@@ -188,3 +188,13 @@ def test_carried_bounds_host_policy_without_gpu():
     # list_max = 1 (tests): always listed once a count is known, never paused; list_max = 0: never listed
     assert 0 not in _policy([1000] * 12, list_max=1.0) and _policy([1000] * 12, list_max=1.0)[-1] == 3
     assert 3 not in _policy([10] * 12, list_max=0.0)
+
+
+def test_no_vendor_gemm_on_the_assignment_path():
+    """Round 5: the D > 512 filter is a hand-written kernel (lloyd_wide.hip); the library neither links nor dlopens
+    rocBLAS / hipBLASLt any more."""
+    import os
+    from kmcuda_amd import _lib
+    path = os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), "libKMCUDA.so")
+    blob = open(path, "rb").read().lower()
+    assert b"rocblas" not in blob and b"hipblas" not in blob

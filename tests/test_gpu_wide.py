@@ -1,7 +1,9 @@
-"""Feature counts beyond the register-resident filters (D > 512): stage 1's scores come out of one library GEMM
-per row chunk (kmcuda_amd/csrc/lloyd_gemm.hip; rocBLAS, f16 operands, f32 accumulation), contenders are read off
-the score matrix, the exact kernels settle the rest.  Bar, as everywhere: assignments, previous assignments and the
-reassignment counter BIT-EXACT against the oracle (kmeans_assign_lloyd, kmeans.cu:293-364) for any input."""
+"""Feature counts beyond the register-resident filters (D > 512): stage 1 streams BOTH operands through LDS
+(kmcuda_amd/csrc/lloyd_wide.hip: 256 rows x 256 centroids per block, f16 matrix cores, best / second-best per row in
+registers -- no score is ever written; a library GEMM into a score matrix until round 4), the same sweep over the rows
+it lists collects their contenders, the exact kernels settle the rest.  Bar, as everywhere: assignments, previous
+assignments and the reassignment counter BIT-EXACT against the oracle (kmeans_assign_lloyd, kmeans.cu:293-364) for any
+input."""
 import numpy
 import pytest
 
@@ -37,7 +39,7 @@ def _passes(x, cs, metric="L2", cached=False, half=False):
 
 @pytest.mark.parametrize("cached", [False, True])
 @pytest.mark.parametrize("n,d,k", [(3000, 1024, 1024), (1500, 600, 64), (2000, 520, 100), (900, 2048, 33),
-                                   (4097, 768, 257), (50, 1536, 7)])
+                                   (4097, 768, 257), (50, 1536, 7), (20000, 640, 300), (70000, 576, 1100)])
 def test_wide_rows_bit_exact(n, d, k, cached):
     rs = numpy.random.RandomState(n + d + k)
     x = rs.rand(n, d).astype(numpy.float32)
@@ -55,8 +57,9 @@ def test_wide_rows_bit_exact(n, d, k, cached):
     assert got[0][2][1] < n // 4
 
 
-def test_wide_rows_gemm_off_is_the_exact_kernel(monkeypatch):
-    monkeypatch.setenv("KMCUDA_AMD_GEMM", "0")
+@pytest.mark.parametrize("switch", ["KMCUDA_AMD_WIDE", "KMCUDA_AMD_GEMM"])
+def test_wide_rows_filter_off_is_the_exact_kernel(monkeypatch, switch):
+    monkeypatch.setenv(switch, "0")
     rs = numpy.random.RandomState(3)
     x = rs.rand(700, 640).astype(numpy.float32)
     c = x[rs.choice(700, 40, replace=False)].copy()
@@ -96,7 +99,7 @@ def test_wide_rows_angular_and_half_rows():
     (asg, _, _), = _passes(x, [c], metric="cos")
     ref, _, _ = oracle.lloyd_assign(x, c, metric=oracle.COS)
     assert (asg != ref).mean() < 1e-3     # acosf: libm vs ocml (tests/test_gpu_lloyd.py::test_assign_angular)
-    # fp16x2 path: the rows as halves feed the GEMM operand; results as on the widened values
+    # fp16x2 path: the rows as halves feed the row operand; results as on the widened values
     xh = x.astype(numpy.float16).astype(numpy.float32)
     ch = c.astype(numpy.float16).astype(numpy.float32)
     (asg, prev, counters), = _passes(xh, [ch], half=True)
@@ -121,7 +124,7 @@ def test_wide_rows_whole_run_through_the_boundary():
 
 
 def test_wide_rows_yinyang_schedules(monkeypatch):
-    """yinyang_t > 0 on 768-feature rows: the default schedule keeps running Lloyd passes through the GEMM filter (the
+    """yinyang_t > 0 on 768-feature rows: the default schedule keeps running Lloyd passes through the wide filter (the
     bounds kernels have no matrix-core filter at this width); the reference schedule runs the exact Yinyang kernels.
     Same hand-over point and lines up to it; equally good clusterings."""
     from kmcuda_amd import kmeans_cuda
