@@ -1714,10 +1714,48 @@ class KnnJob {
       int rc;
       if ((rc = s.alloc(&s.heaps, (size_t)len * 2 * k))) return rc;
       if ((rc = s.alloc(&s.out, (size_t)len * k))) return rc;
-      if ((rc = s.alloc(&s.blocks, 2 * (size_t)(s.nblocks ? s.nblocks : 1)))) return rc;
-      if (s.nblocks &&
-          hipMemcpyAsync(s.blocks, blocks.data() + 2 * (size_t)s.first_block, 2 * (size_t)s.nblocks * sizeof(uint32_t),
-                         hipMemcpyHostToDevice, s.stream) != hipSuccess)
+      // The dispatch order of the f16 search (round 5).  Every block of one query cluster visits the same candidate
+      // clusters in the same order, 512 bytes per candidate and block -- 4.3 TB of fetches for config D's share, the
+      // kernel HBM co-bound (profiles/r4a_pmc_knn_*).  Workgroups go to the XCDs round-robin by index and every XCD has
+      // its own L2, so consecutive indices -- the blocks of ONE cluster -- were spread over all eight and each XCD held
+      // ~16 clusters' streams at once, none of which found the others' tiles still in its 4 MB.  Now the blocks of a
+      // cluster go to ONE XCD (indices congruent mod 8), cluster after cluster: an XCD holds two or three streams, the
+      // followers of a stream hit the tiles its leader has just fetched (and catch up with it: they wait less).  Slots a
+      // shorter list leaves empty carry the marker 0xFFFFFFFF (the kernel returns at once).  KMCUDA_AMD_KNN_XCD=0: plain
+      // order (A/B).  Only the order of independent blocks changes: the lists are the same.
+      std::vector<uint32_t> plan(blocks.begin() + 2 * (size_t)s.first_block,
+                                 blocks.begin() + 2 * (size_t)(s.first_block + s.nblocks));
+      uint32_t launch_blocks = s.nblocks;
+      {
+        const char *xe = getenv("KMCUDA_AMD_KNN_XCD");
+        if (use_f16 && s.nblocks >= 64 && !(xe && atoi(xe) == 0)) {
+          constexpr uint32_t kXcds = 8;
+          std::vector<std::vector<uint32_t>> lists(kXcds);   // block numbers (into plan) per XCD
+          uint32_t b = 0;
+          while (b < s.nblocks) {
+            uint32_t e = b;
+            while (e < s.nblocks && plan[2 * (size_t)e] == plan[2 * (size_t)b]) e++;   // one cluster's blocks
+            uint32_t best = 0;
+            for (uint32_t x = 1; x < kXcds; x++)
+              if (lists[x].size() < lists[best].size()) best = x;
+            for (uint32_t q = b; q < e; q++) lists[best].push_back(q);
+            b = e;
+          }
+          size_t longest = 0;
+          for (auto &l : lists) longest = l.size() > longest ? l.size() : longest;
+          std::vector<uint32_t> ordered(2 * kXcds * longest, 0xFFFFFFFFu);
+          for (uint32_t x = 0; x < kXcds; x++)
+            for (size_t i = 0; i < lists[x].size(); i++) {
+              ordered[2 * (kXcds * i + x)] = plan[2 * (size_t)lists[x][i]];
+              ordered[2 * (kXcds * i + x) + 1] = plan[2 * (size_t)lists[x][i] + 1];
+            }
+          plan.swap(ordered);
+          launch_blocks = (uint32_t)(kXcds * longest);
+        }
+      }
+      if ((rc = s.alloc(&s.blocks, plan.size() ? plan.size() : 2))) return rc;
+      if (!plan.empty() &&
+          hipMemcpy(s.blocks, plan.data(), plan.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
         return kmcudaMemoryCopyError;
       KnnArgs a;
       a.xs = s.xs; a.n2s = s.n2s; a.inv = s.inv; a.offsets = s.offsets; a.mydist = s.mydist; a.R = s.R; a.C = s.C;
@@ -1757,7 +1795,7 @@ class KnnJob {
         }
       }
       const hipError_t e = !dp_filter ? launch_knn_exact(metric, a, strict_h2, s.stream)
-                           : use_f16 ? launch_knn_filter_f16(metric, a, s.nblocks, s.stream)
+                           : use_f16 ? launch_knn_filter_f16(metric, a, launch_blocks, s.stream)
                                      : launch_knn_filter(metric, a, s.nblocks, s.stream);
       if (e != hipSuccess) return kmcudaRuntimeError;
     }

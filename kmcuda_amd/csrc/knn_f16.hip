@@ -126,6 +126,7 @@ __global__ __launch_bounds__(KNN16_WAVES * 64, (DP > 512 ? 1 : KNN16_BLOCKS_PER_
   const uint32_t K = a.K, k = a.k, D = a.D;
 
   const uint32_t cls0 = a.blocks[2 * (size_t)blockIdx.x], p0 = a.blocks[2 * (size_t)blockIdx.x + 1];
+  if (cls0 == 0xFFFFFFFFu) return;   // an empty slot of the dispatch plan (kmcuda_api.cpp: one cluster's blocks per XCD)
   const uint32_t own_end = a.offsets[cls0 + 1];
   uint32_t qp[NSET];
   bool live[NSET];

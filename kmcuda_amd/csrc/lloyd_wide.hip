@@ -468,7 +468,9 @@ __global__ __launch_bounds__(256) void wide_contenders_kernel(
     for (uint32_t f = lane * 4; f < DG; f += 256) {
       float x4[4], m4[4];
       if (FAST) {
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + f), b = *reinterpret_cast<const f32x4 *>(mu + f);
+        // (the row is read once: streamed past the caches, which the contenders' centroid rows -- a 4-MB panel at
+        //  1024 x 1024 -- need)
+        const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(xr + f)), b = *reinterpret_cast<const f32x4 *>(mu + f);
         x4[0] = a.x; x4[1] = a.y; x4[2] = a.z; x4[3] = a.w;
         m4[0] = b.x; m4[1] = b.y; m4[2] = b.z; m4[3] = b.w;
       } else {
