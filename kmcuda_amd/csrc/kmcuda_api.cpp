@@ -1093,6 +1093,7 @@ class Job {
     if (passed_total) *passed_total = overall_passed;
     if (print) INFO("iteration %d: %u reassignments\n", iter, overall_changed);
     stamp(iter);
+    note_changed(iter, overall_changed);
     if (overall_changed <= tolerance * N) return 1;  // counters are NOT zeroed on stop (kmeans.cu:707-709)
     for (auto &s : shards)
       if (s->eng->counters_reset(0) != 0) return -kmcudaRuntimeError;
@@ -1108,6 +1109,30 @@ class Job {
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - born_).count());
   }
   bool exact_update = false;  // KMCUDA_AMD_EXACT_UPDATE=1: the reference's serial Kahan chain (single shard)
+
+  // The reassignment counts of the run's iterations as the host has judged them (iteration i at [i - 1]), for one
+  // decision: whether carrying bounds after the hand-over point can pay.  A carried schedule spends its first pass
+  // after the hand-over on LEAVING bounds (a whole pass that writes 8 bytes per row more, an allocation of 24 bytes
+  // per row in front of it) and only spares rows from the second pass on: a run that will stop within a pass or two
+  // loses (round 4: the 4M-row mixture at tolerance 0.01 -- ONE iteration after the hand-over -- 0.051 s against
+  // 0.044).  The counts fall roughly geometrically; with the ratio r of the last two and the stop threshold the
+  // remaining iterations are ln(threshold / last) / ln(r).  Speed only: every pass is the reference's either way.
+  std::vector<uint32_t> changed_log;
+  void note_changed(int iter, uint32_t changed) {
+    if (iter < 1) return;
+    if (changed_log.size() < (size_t)iter) changed_log.resize(iter, 0u);
+    changed_log[iter - 1] = changed;
+  }
+  // iterations the run still has in front of it after iteration `iter` (did not stop), by that extrapolation; a
+  // large number when the history says nothing
+  double iterations_left(int iter, float tolerance) const {
+    if (iter < 2 || changed_log.size() < (size_t)iter) return 1e9;
+    const double last = changed_log[iter - 1], before = changed_log[iter - 2], thr = (double)tolerance * N;
+    if (!(last > 0) || !(before > last)) return 1e9;        // not falling: no statement
+    if (thr < 1.0) return std::log(last) / std::log(before / last) + 1.0;   // down to (next to) no reassignment
+    if (last <= thr) return 0.0;
+    return std::log(last / thr) / std::log(before / last);
+  }
 
   // the update in three stream-ordered phases (reference: kmeans_adjust launch + peer exchange,
   // kmeans.cu:1002-1024): fill every shard's reduce buffer, ONE all-reduce, apply on every shard
@@ -1272,6 +1297,7 @@ class Job {
     DEBUG("filter: %u rows settled by two exact chains, %u by a full exact scan\n", t[3], t[1]);
     INFO("iteration %d: %u reassignments\n", iter, t[0]);
     stamp(iter);
+    note_changed(iter, t[0]);
     if (changed) *changed = t[0];
     stats.iterations++;
     return t[4] ? 1 : 0;
@@ -1714,21 +1740,20 @@ class KnnJob {
       int rc;
       if ((rc = s.alloc(&s.heaps, (size_t)len * 2 * k))) return rc;
       if ((rc = s.alloc(&s.out, (size_t)len * k))) return rc;
-      // The dispatch order of the f16 search (round 5).  Every block of one query cluster visits the same candidate
-      // clusters in the same order, 512 bytes per candidate and block -- 4.3 TB of fetches for config D's share, the
-      // kernel HBM co-bound (profiles/r4a_pmc_knn_*).  Workgroups go to the XCDs round-robin by index and every XCD has
-      // its own L2, so consecutive indices -- the blocks of ONE cluster -- were spread over all eight and each XCD held
-      // ~16 clusters' streams at once, none of which found the others' tiles still in its 4 MB.  Now the blocks of a
-      // cluster go to ONE XCD (indices congruent mod 8), cluster after cluster: an XCD holds two or three streams, the
-      // followers of a stream hit the tiles its leader has just fetched (and catch up with it: they wait less).  Slots a
-      // shorter list leaves empty carry the marker 0xFFFFFFFF (the kernel returns at once).  KMCUDA_AMD_KNN_XCD=0: plain
-      // order (A/B).  Only the order of independent blocks changes: the lists are the same.
+      // KMCUDA_AMD_KNN_XCD=1 (an experiment of round 5, off by default): the blocks of one query cluster -- which visit
+      // the same candidate clusters in the same order, 512 bytes per candidate and block: 4.3 TB of fetches for config
+      // D's share -- dispatched to ONE XCD (workgroup indices congruent mod 8), cluster after cluster, so that an XCD's
+      // L2 holds two or three such streams instead of sixteen and a stream's followers hit the tiles its leader has
+      // just fetched.  Measured: FETCH_SIZE 4.17 TB against 4.27, knn_cuda 1.13-1.15 s against 1.11-1.13
+      // (profiles/r5d_knn_dispatch_order_ab.log): the blocks of a stream drift further apart than an L2 holds (a
+      // cluster's slab alone is 4 MB).  Slots a shorter list leaves empty carry the marker 0xFFFFFFFF (the kernel
+      // returns at once).  Only the order of independent blocks changes: the lists are the same.
       std::vector<uint32_t> plan(blocks.begin() + 2 * (size_t)s.first_block,
                                  blocks.begin() + 2 * (size_t)(s.first_block + s.nblocks));
       uint32_t launch_blocks = s.nblocks;
       {
         const char *xe = getenv("KMCUDA_AMD_KNN_XCD");
-        if (use_f16 && s.nblocks >= 64 && !(xe && atoi(xe) == 0)) {
+        if (use_f16 && s.nblocks >= 64 && xe && atoi(xe) != 0) {
           constexpr uint32_t kXcds = 8;
           std::vector<std::vector<uint32_t>> lists(kXcds);   // block numbers (into plan) per XCD
           uint32_t b = 0;
@@ -2037,7 +2062,11 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
       bool bounds = !adaptive;
       if (adaptive) {
         const char *cv = getenv("KMCUDA_AMD_CARRY");
-        const bool carry = !(cv && atoi(cv) == 0) && !wide;
+        // (KMCUDA_AMD_CARRY=1 carries whatever the extrapolation says: tests; unset: only when the run is expected to
+        //  last at least three more iterations -- Job::iterations_left)
+        const double left = job.iterations_left(iter, tolerance);
+        const bool carry = !(cv && atoi(cv) == 0) && !wide && ((cv && atoi(cv) != 0) || left >= 3.0);
+        DEBUG("about %.1f more iterations by the last two counts\n", left < 1e8 ? left : -1.0);
         INFO(carry ? "Lloyd goes on, carrying per-sample distance bounds from pass to pass\n" : "Lloyd goes on\n");
         for (auto &s : job.shards) {
           s->eng->carry_on_ = carry;

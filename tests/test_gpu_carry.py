@@ -368,6 +368,7 @@ def test_kmeans_cuda_default_schedule_under_the_strict_update_equals_the_oracle_
     x = (cen[rs.randint(0, 70, 60000)] + rs.randn(60000, 256)).astype(numpy.float32)
     monkeypatch.setenv("KMCUDA_AMD_EXACT_UPDATE", "1")
     monkeypatch.setenv("KMCUDA_AMD_YY", "carry")
+    monkeypatch.setenv("KMCUDA_AMD_CARRY", "1")   # (whatever the run's expected length: kmcuda_api.cpp, iterations_left)
     kw = dict(init="random", seed=3, tolerance=0.0002)
     out = StdoutListener()
     with out:
@@ -439,3 +440,26 @@ def test_kmeans_cuda_angular_carries_and_equals_the_plain_schedule(monkeypatch):
             assert spared and int(spared[0].split()[2]) > len(x), out.text[-600:]
     assert (res[0][1] == res[1][1]).all()
     assert (res[0][0].view(numpy.uint32) == res[1][0].view(numpy.uint32)).all()
+
+
+def test_a_run_about_to_stop_does_not_start_carrying(monkeypatch):
+    """The first pass after the hand-over point only LEAVES bounds; a run that the last two reassignment counts say
+    will stop within a pass or two goes on with plain passes (round 4: such calls lost 12-16 % to the bounds they
+    never used).  Same lines but the announcement, same results; a long run of the same data does carry."""
+    from kmcuda_amd import kmeans_cuda
+    from test_gpu_kmeans import StdoutListener
+    monkeypatch.delenv("KMCUDA_AMD_CARRY", raising=False)
+    x = _blobs(200000, 64, 100, seed=19, spread=10.0)
+    outs = {}
+    for tol in (0.03, 0.00002):
+        out = StdoutListener()
+        with out:
+            cen, asg = kmeans_cuda(x, 100, init="random", seed=3, tolerance=tol, yinyang_t=0.1, device=1, verbosity=2)
+        outs[tol] = (out.text, cen, asg)
+    short, long_ = outs[0.03][0], outs[0.00002][0]
+    assert "Lloyd goes on" in short, short[-800:]   # (the hand-over point was reached ...)
+    assert "carrying per-sample distance bounds" not in short   # (... and the bounds were not started)
+    assert "carrying per-sample distance bounds" in long_
+    monkeypatch.setenv("KMCUDA_AMD_CARRY", "0")
+    cen0, asg0 = kmeans_cuda(x, 100, init="random", seed=3, tolerance=0.03, yinyang_t=0.1, device=1, verbosity=0)
+    assert (asg0 == outs[0.03][2]).all() and (cen0.view(numpy.uint32) == outs[0.03][1].view(numpy.uint32)).all()
