@@ -304,11 +304,16 @@ hipError_t launch_yy_local_filter(int metric, const float *samples, uint32_t len
 
 // knn.hip (reference: knn.cu)
 // queries (consecutive sorted positions of one cluster) per block: f32 filter 4 waves x 32, f16 filter
-// KNN16_WAVES x KNN16_NSET x 32
-#ifndef KNN16_WAVES
-#define KNN16_WAVES 4           // waves per block
-#define KNN16_NSET 2            // 32-query operand sets per wave
-#define KNN16_BLOCKS_PER_CU 2
+// knn16_waves(DP) x knn16_nset(DP) x 32
+// Rows up to 256 features: 8 waves x 2 operand sets = 512 queries share every staged candidate tile, ONE block per CU
+// (round 5: 4 waves x 2 sets, two blocks per CU, until then -- 2 bytes fetched per scored pair, 4.3 TB for config D's
+// share, the kernel HBM co-bound; 8-wave blocks halve the fetches -- 2.27 TB by FETCH_SIZE -- and take 1.02 s against
+// 1.10, profiles/r5e_knn_filter_8wave_blocks_ab.log).  Wider rows (DP = 512 / 768 / 1024): ONE operand set per wave (a
+// lane's half of a 512-feature row in halves is 128 registers) and four waves (768 / 1024: a wave needs its SIMD to
+// itself, 512 registers), one 32-candidate sub-tile per staged tile (32 / 48 / 64 KB).
+#ifndef KNN16_WAVES_NARROW
+#define KNN16_WAVES_NARROW 8    // waves per block, DP <= 256
+#define KNN16_NSET 2            // 32-query operand sets per wave, DP <= 256
 #endif
 #ifndef KNN16_SUB
 #define KNN16_SUB 2             // 32-candidate sub-tiles per staged tile (per barrier)
@@ -320,12 +325,12 @@ hipError_t launch_yy_local_filter(int metric, const float *samples, uint32_t len
 #define KNN16_PD 3              // candidate fragments in flight per wave
 #endif
 #define KNN16_PAD_ROWS 64   // rows of xs16 / entries of kbias the caller allocates (and the split zeroes) past N
-// rows wider than 256 features (DP = 512 / 768 / 1024): ONE operand set per wave (a lane's half of a 512-feature row
-// in halves is 128 registers) and one 32-candidate sub-tile per staged tile (32 / 48 / 64 KB)
+constexpr int knn16_waves(int DP) { return DP > 256 ? 4 : KNN16_WAVES_NARROW; }
+constexpr int knn16_blocks_per_cu(int DP) { return DP > 512 ? 1 : (DP > 256 ? 2 : (KNN16_WAVES_NARROW > 4 ? 1 : 2)); }
 constexpr int knn16_nset(int DP) { return DP > 256 ? 1 : KNN16_NSET; }
 constexpr int knn16_sub(int DP) { return DP > 256 ? 1 : KNN16_SUB; }
 constexpr uint32_t KNN_QPB_F32 = 128;
-constexpr uint32_t knn_qpb_f16(uint32_t DP) { return KNN16_WAVES * (uint32_t)knn16_nset((int)DP) * 32u; }
+constexpr uint32_t knn_qpb_f16(uint32_t DP) { return (uint32_t)knn16_waves((int)DP) * (uint32_t)knn16_nset((int)DP) * 32u; }
 struct KnnArgs {
   const float *xs;          // N x DP cluster-sorted rows (zero padded to DP)
   const float *n2s;         // N plain squared norms of the sorted rows

@@ -1093,7 +1093,6 @@ class Job {
     if (passed_total) *passed_total = overall_passed;
     if (print) INFO("iteration %d: %u reassignments\n", iter, overall_changed);
     stamp(iter);
-    note_changed(iter, overall_changed);
     if (overall_changed <= tolerance * N) return 1;  // counters are NOT zeroed on stop (kmeans.cu:707-709)
     for (auto &s : shards)
       if (s->eng->counters_reset(0) != 0) return -kmcudaRuntimeError;
@@ -1110,28 +1109,17 @@ class Job {
   }
   bool exact_update = false;  // KMCUDA_AMD_EXACT_UPDATE=1: the reference's serial Kahan chain (single shard)
 
-  // The reassignment counts of the run's iterations as the host has judged them (iteration i at [i - 1]), for one
-  // decision: whether carrying bounds after the hand-over point can pay.  A carried schedule spends its first pass
-  // after the hand-over on LEAVING bounds (a whole pass that writes 8 bytes per row more, an allocation of 24 bytes
-  // per row in front of it) and only spares rows from the second pass on: a run that will stop within a pass or two
-  // loses (round 4: the 4M-row mixture at tolerance 0.01 -- ONE iteration after the hand-over -- 0.051 s against
-  // 0.044).  The counts fall roughly geometrically; with the ratio r of the last two and the stop threshold the
-  // remaining iterations are ln(threshold / last) / ln(r).  Speed only: every pass is the reference's either way.
-  std::vector<uint32_t> changed_log;
-  void note_changed(int iter, uint32_t changed) {
-    if (iter < 1) return;
-    if (changed_log.size() < (size_t)iter) changed_log.resize(iter, 0u);
-    changed_log[iter - 1] = changed;
-  }
-  // iterations the run still has in front of it after iteration `iter` (did not stop), by that extrapolation; a
-  // large number when the history says nothing
-  double iterations_left(int iter, float tolerance) const {
-    if (iter < 2 || changed_log.size() < (size_t)iter) return 1e9;
-    const double last = changed_log[iter - 1], before = changed_log[iter - 2], thr = (double)tolerance * N;
-    if (!(last > 0) || !(before > last)) return 1e9;        // not falling: no statement
-    if (thr < 1.0) return std::log(last) / std::log(before / last) + 1.0;   // down to (next to) no reassignment
-    if (last <= thr) return 0.0;
-    return std::log(last / thr) / std::log(before / last);
+  // Default schedule: iteration number from which on a judged "goes on" starts the carried bounds (0: no such
+  // start pending; kmeans_cuda sets it at the hand-over point)
+  int carry_after = 0;
+  void maybe_start_carry(int judged_iter) {
+    if (carry_after == 0 || judged_iter < carry_after) return;
+    carry_after = 0;
+    INFO("carrying per-sample distance bounds from pass to pass\n");
+    for (auto &s : shards) {
+      s->eng->carry_on_ = true;
+      s->eng->carry_valid_ = false;
+    }
   }
 
   // the update in three stream-ordered phases (reference: kmeans_adjust launch + peer exchange,
@@ -1240,6 +1228,7 @@ class Job {
           if (iterations) *iterations = iter;
           return 0;
         }
+        maybe_start_carry(iter);
         RETERR(adjust());
       }
     }
@@ -1269,6 +1258,7 @@ class Job {
           return 0;
         }
         if (leave && (*leave)(unjudged, changed)) leave_next = true;
+        maybe_start_carry(unjudged);   // (the run has gone on past iteration `unjudged`)
         unjudged = 0;
       }
       if (spec) {
@@ -1283,6 +1273,7 @@ class Job {
         if (iterations) *iterations = iter;
         return 0;
       }
+      maybe_start_carry(iter);
       RETERR(apply_deltas(threshold));   // (the same decision once more on the device; zeroes the counter)
     }
   }
@@ -1297,7 +1288,6 @@ class Job {
     DEBUG("filter: %u rows settled by two exact chains, %u by a full exact scan\n", t[3], t[1]);
     INFO("iteration %d: %u reassignments\n", iter, t[0]);
     stamp(iter);
-    note_changed(iter, t[0]);
     if (changed) *changed = t[0];
     stats.iterations++;
     return t[4] ? 1 : 0;
@@ -2062,16 +2052,22 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
       bool bounds = !adaptive;
       if (adaptive) {
         const char *cv = getenv("KMCUDA_AMD_CARRY");
-        // (KMCUDA_AMD_CARRY=1 carries whatever the extrapolation says: tests; unset: only when the run is expected to
-        //  last at least three more iterations -- Job::iterations_left)
-        const double left = job.iterations_left(iter, tolerance);
-        const bool carry = !(cv && atoi(cv) == 0) && !wide && ((cv && atoi(cv) != 0) || left >= 3.0);
-        DEBUG("about %.1f more iterations by the last two counts\n", left < 1e8 ? left : -1.0);
-        INFO(carry ? "Lloyd goes on, carrying per-sample distance bounds from pass to pass\n" : "Lloyd goes on\n");
+        const bool carry = !(cv && atoi(cv) == 0) && !wide;
+        // The first carried pass only LEAVES bounds (and allocates them: 24 bytes per row); rows are spared from the
+        // second one on.  A run that stops within a pass or two of the hand-over point never earns that back (round 4:
+        // the 4M-row mixture at tolerance 0.01, one iteration after the hand-over, +12-16 %), and how long a run will
+        // last cannot be read off its first counts (they fall by a factor of 4-8 per iteration, the tail by 1.1: an
+        // extrapolation tried in round 5 switched the bounds off for the 37-iteration run,
+        // profiles/r5e_configs_carry_extrapolation_rule_misfires.log).  So the bounds start once the host has SEEN the
+        // run go on past an iteration after the hand-over (Job::lloyd, carry_after).  KMCUDA_AMD_CARRY=1: at once
+        // (tests: every pass after the hand-over is then a carried one).
+        const bool at_once = carry && cv && atoi(cv) != 0;
+        INFO(at_once ? "Lloyd goes on, carrying per-sample distance bounds from pass to pass\n" : "Lloyd goes on\n");
         for (auto &s : job.shards) {
-          s->eng->carry_on_ = carry;
+          s->eng->carry_on_ = at_once;
           s->eng->carry_valid_ = false;
         }
+        job.carry_after = (carry && !at_once) ? iter + 1 : 0;
         const Job::LeaveFn leave = [&rule](int, uint32_t changed) { return rule.now(changed); };
         RETERR(job.lloyd(tolerance, &iter, rule.force >= 0 ? &leave : nullptr, &bounds, iter));
         if (carry && verbosity > 1) {
@@ -2085,6 +2081,7 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
           if (paired) printf("carried pairs: %llu sample passes settled between two carried contenders\n", paired);
         }
         for (auto &s : job.shards) s->eng->carry_on_ = false;
+        job.carry_after = 0;
         lap("Lloyd after the hand-over point");
       }
       if (bounds) RETERR(job.yinyang(tolerance, yy_groups_size, iter, groups));

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void knn_split_kernel(const float *__restrict_
 // filter of knn.hip and the unfiltered exact search are the two that remain.)
 //
 // Shape (round 2, each step measured on BASELINE config D, 8M x 256 corpus, 1M queries: 3.72 s -> see
-// profiles/README.md): a block is KNN16_WAVES waves x KNN16_NSET operand sets of 32 queries of ONE cluster
+// profiles/README.md): a block is knn16_waves(DP) waves x knn16_nset(DP) operand sets of 32 queries of ONE cluster
 // sharing every candidate tile it visits.
 //   * 256 queries per tile fetch (was 128): the 4-wave / one-set kernel pulled 3.5 TB/s through L2 with the
 //     matrix pipe busy 26 %.
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256) void knn_split_kernel(const float *__restrict_
 // Instrumented builds of the one-set kernel (per-phase s_memtime counters, per-wave timeline of one block):
 // profiles/r2e_knn_filter_phase_counters.log, r2e_knn_filter_block_timeline.log.
 template <int DP, int METRIC, bool FASTX>
-__global__ __launch_bounds__(KNN16_WAVES * 64, (DP > 512 ? 1 : KNN16_BLOCKS_PER_CU)) void knn_filter_f16_kernel(KnnArgs a) {
-  constexpr int WV = KNN16_WAVES, NSET = knn16_nset(DP);
+__global__ __launch_bounds__(knn16_waves(DP) * 64, knn16_blocks_per_cu(DP)) void knn_filter_f16_kernel(KnnArgs a) {
+  constexpr int WV = knn16_waves(DP), NSET = knn16_nset(DP);
   constexpr int NKH = DP / 2;   // features per half-wave
   constexpr int KS = NKH / 8;   // k-steps = 16-byte chunks per half row
   constexpr int ROWB = DP * 2;  // bytes of one candidate row (DP halves)
@@ -499,7 +499,7 @@ hipError_t launch_knn_split(int metric, const float *xs, uint32_t N, uint32_t D,
 
 template <int DP, int METRIC>
 static hipError_t launch_knn_f16_t(const KnnArgs &a, uint32_t nblocks, hipStream_t st) {
-  const size_t lds_bytes = (size_t)KNN16_NBUF * (32 * knn16_sub(DP) * DP * 2) + KNN16_NBUF * 256 + 2 * KNN16_WAVES * 4;
+  const size_t lds_bytes = (size_t)KNN16_NBUF * (32 * knn16_sub(DP) * DP * 2) + KNN16_NBUF * 256 + 2 * knn16_waves(DP) * 4;
   if (lds_bytes > 65536) {   // (per launch: the attribute belongs to the current device's copy of the kernel)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_filter_f16_kernel<DP, METRIC, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -509,9 +509,9 @@ static hipError_t launch_knn_f16_t(const KnnArgs &a, uint32_t nblocks, hipStream
     if (e != hipSuccess) return e;
   }
   if (a.D == (uint32_t)DP)
-    hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, true>), dim3(nblocks), dim3(KNN16_WAVES * 64), lds_bytes, st, a);
+    hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, true>), dim3(nblocks), dim3(knn16_waves(DP) * 64), lds_bytes, st, a);
   else
-    hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, false>), dim3(nblocks), dim3(KNN16_WAVES * 64), lds_bytes, st, a);
+    hipLaunchKernelGGL((knn_filter_f16_kernel<DP, METRIC, false>), dim3(nblocks), dim3(knn16_waves(DP) * 64), lds_bytes, st, a);
   return hipGetLastError();
 }
 

@@ -443,9 +443,10 @@ def test_kmeans_cuda_angular_carries_and_equals_the_plain_schedule(monkeypatch):
 
 
 def test_a_run_about_to_stop_does_not_start_carrying(monkeypatch):
-    """The first pass after the hand-over point only LEAVES bounds; a run that the last two reassignment counts say
-    will stop within a pass or two goes on with plain passes (round 4: such calls lost 12-16 % to the bounds they
-    never used).  Same lines but the announcement, same results; a long run of the same data does carry."""
+    """The first pass after the hand-over point only LEAVES bounds (and allocates them); the default schedule starts
+    them once the host has seen the run go on past an iteration after the hand-over -- a run that stops within a pass
+    or two never starts them (round 4: such calls lost 12-16 % to bounds they never used).  Same iteration lines and
+    results as plain passes either way; a long run of the same data does carry."""
     from kmcuda_amd import kmeans_cuda
     from test_gpu_kmeans import StdoutListener
     monkeypatch.delenv("KMCUDA_AMD_CARRY", raising=False)
@@ -458,8 +459,13 @@ def test_a_run_about_to_stop_does_not_start_carrying(monkeypatch):
         outs[tol] = (out.text, cen, asg)
     short, long_ = outs[0.03][0], outs[0.00002][0]
     assert "Lloyd goes on" in short, short[-800:]   # (the hand-over point was reached ...)
-    assert "carrying per-sample distance bounds" not in short   # (... and the bounds were not started)
+    after = [l for l in short.split("Lloyd goes on", 1)[1].split("\n") if l.startswith("iteration")]
+    assert len(after) <= 2, after                    # (... the run stopped within two iterations of it ...)
+    assert "carrying per-sample distance bounds" not in short   # (... and the bounds were never started)
     assert "carrying per-sample distance bounds" in long_
+    spared = [l for l in long_.split("\n") if l.startswith("carried bounds:")]
+    assert spared and int(spared[0].split()[2]) > len(x), long_[-600:]
     monkeypatch.setenv("KMCUDA_AMD_CARRY", "0")
-    cen0, asg0 = kmeans_cuda(x, 100, init="random", seed=3, tolerance=0.03, yinyang_t=0.1, device=1, verbosity=0)
-    assert (asg0 == outs[0.03][2]).all() and (cen0.view(numpy.uint32) == outs[0.03][1].view(numpy.uint32)).all()
+    for tol in (0.03, 0.00002):
+        cen0, asg0 = kmeans_cuda(x, 100, init="random", seed=3, tolerance=tol, yinyang_t=0.1, device=1, verbosity=0)
+        assert (asg0 == outs[tol][2]).all() and (cen0.view(numpy.uint32) == outs[tol][1].view(numpy.uint32)).all()
