@@ -202,9 +202,19 @@ hipError_t launch_kmpp_step(int metric, const float *samples, uint32_t N, uint32
 // range; totals_host = pinned { double sum_g, sum_d; uint32 emin, emax, bad, chosen } (32 bytes)
 // fail (one device word, 0 while all is well): raised by launch_kmpp_choose's kernel at a step the device cannot
 // decide; every kmpp kernel launched with it returns at once while it is set (the host enqueues steps ahead)
+// out: the step's exponent cut (one device word, read; zero-initialised by the owner, written by launch_kmpp_choose)
+// and where the non-zero distances below it are listed instead of summed (kmpp_outlier_bytes() + one count word,
+// zero on entry, zeroed again by launch_kmpp_choose) -- seeding.hip: KmppOutlier
+struct KmppOutlierBuf {
+  uint32_t *ecut = nullptr;
+  void *outl = nullptr;
+  uint32_t *outl_count = nullptr;
+};
+size_t kmpp_outlier_bytes();
+size_t kmpp_totals_bytes();
 hipError_t launch_kmpp_step2(int metric, const float *samples, uint32_t N, uint32_t D, const float *centroid,
                              uint32_t cc, float *dists, void *block_stats, double *bpre, void *totals,
-                             const uint32_t *fail, hipStream_t st);
+                             const uint32_t *fail, const KmppOutlierBuf &out, hipStream_t st);
 // the reference's chooser (kmcuda.cc:300-326) for step `step` with random number `choice`, on the device, over the
 // concatenation of `nshards` row shards (1: the whole job on one GPU): every shard has run the step on its rows
 // (launch_kmpp_step2 / _filtered with its own length and buffers); the kernel runs on shards[0]'s device, reads the
@@ -219,6 +229,7 @@ struct KmppShardPtrs {
   float *centroids;
   uint32_t *fail;
   uint32_t offset, length;
+  KmppOutlierBuf out;
 };
 hipError_t launch_kmpp_choose(const KmppShardPtrs *shards, uint32_t nshards, uint32_t N, double choice, uint32_t log2n,
                               uint32_t step, uint32_t D, hipStream_t st);
@@ -230,7 +241,8 @@ hipError_t launch_kmpp_cache(const float *samples, uint32_t N, uint32_t D, uint3
 hipError_t launch_kmpp_step_filtered(int metric, const float *samples, uint32_t N, uint32_t D, uint32_t DP,
                                      const void *xs8, const float *meta, const float *mu, uint32_t *stats,
                                      uint32_t *list, const float *centroid, uint32_t cc, float *dists,
-                                     void *block_stats, double *bpre, void *totals, const uint32_t *fail, hipStream_t st);
+                                     void *block_stats, double *bpre, void *totals, const uint32_t *fail,
+                                     const KmppOutlierBuf &out, hipStream_t st);
 size_t kmpp_block_stat_bytes(uint32_t N);
 size_t kmpp_blocks(uint32_t N);
 size_t kmpp_prefix_doubles(uint32_t N);   // doubles of `bpre`

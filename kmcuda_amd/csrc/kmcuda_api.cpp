@@ -670,6 +670,7 @@ class Job {
           void *block_stats = nullptr, *totals = nullptr;
           double *bpre = nullptr;
           uint32_t *fail = nullptr;
+          KmppOutlierBuf out;   // the step's exponent cut, the distances below it (seeding.hip: KmppOutlier)
           hipEvent_t ev_step = nullptr;
           void *xs8 = nullptr;
           float *n2c = nullptr, *mu = nullptr;
@@ -696,12 +697,18 @@ class Job {
             unsigned char *bs = nullptr, *td = nullptr;
             int rc;
             if ((rc = s.alloc(&bs, kmpp_block_stat_bytes(s.length)))) return rc;
-            if ((rc = s.alloc(&td, sizeof(Totals)))) return rc;
+            if ((rc = s.alloc(&td, kmpp_totals_bytes()))) return rc;
             if ((rc = s.alloc(&k.bpre, kmpp_prefix_doubles(s.length)))) return rc;
-            if ((rc = s.alloc(&k.fail, 1))) return rc;
+            if ((rc = s.alloc(&k.fail, 4))) return rc;   // [0] the flag, [1] the exponent cut, [2] the listed values' number
+            unsigned char *ob = nullptr;
+            if ((rc = s.alloc(&ob, kmpp_outlier_bytes()))) return rc;
             k.block_stats = bs;
             k.totals = td;
-            if (hipMemsetAsync(k.fail, 0, sizeof(uint32_t), s.eng->stream_) != hipSuccess) return kmcudaRuntimeError;
+            k.out.ecut = k.fail + 1;
+            k.out.outl_count = k.fail + 2;
+            k.out.outl = ob;
+            if (hipMemsetAsync(k.fail, 0, 4 * sizeof(uint32_t), s.eng->stream_) != hipSuccess) return kmcudaRuntimeError;
+            if (hipMemsetAsync(td, 0, kmpp_totals_bytes(), s.eng->stream_) != hipSuccess) return kmcudaRuntimeError;
             if (shards.size() > 1 && hipEventCreateWithFlags(&k.ev_step, hipEventDisableTiming) != hipSuccess) return kmcudaRuntimeError;
           }
           (void)hipSetDevice(shards[0]->dev);
@@ -812,6 +819,7 @@ class Job {
             views[q].dists = s.dists; views[q].bpre = kpp[q].bpre; views[q].totals = kpp[q].totals;
             views[q].samples = s.samples; views[q].centroids = s.centroids; views[q].fail = kpp[q].fail;
             views[q].offset = s.offset; views[q].length = s.length;
+            views[q].out = kpp[q].out;
           }
           if (many) RETERR(sync_all());   // (the first seed's peer copies and the flags' memsets have landed everywhere)
           std::vector<double> choices(K, 0.0);
@@ -839,9 +847,9 @@ class Job {
                 const hipError_t se =
                     (kpp_filter && t >= 2)
                         ? launch_kmpp_step_filtered(metric, s.samples, s.length, D, kpp_dp, k.xs8, k.n2c, k.mu, k.stats, k.list,
-                                                    newest, t, s.dists, k.block_stats, k.bpre, k.totals, k.fail, st)
+                                                    newest, t, s.dists, k.block_stats, k.bpre, k.totals, k.fail, k.out, st)
                         : launch_kmpp_step2(metric, s.samples, s.length, D, newest, t, s.dists, k.block_stats, k.bpre, k.totals,
-                                            k.fail, st);
+                                            k.fail, k.out, st);
                 if (se != hipSuccess) return kmcudaRuntimeError;
                 if (many && q != 0 && hipEventRecord(k.ev_step, st) != hipSuccess) return kmcudaRuntimeError;
               }

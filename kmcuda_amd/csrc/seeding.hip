@@ -45,49 +45,30 @@ hipError_t launch_kmpp_step(int metric, const float *samples, uint32_t N, uint32
 constexpr int kKmppBlock = 256;   // rows per block of the step kernel = granularity of the exact prefix sums
 
 struct KmppBlockStat {   // one per block of kKmppBlock rows
-  double sum_d;          // exact sum of the block's distances
-  double sum_g;          // exact sum of its per-32 butterfly float sums
-  uint32_t emin, emax;   // biased exponent range of its finite non-zero distances (emin > emax: none)
+  double sum_d;          // exact sum of the block's BULK distances (biased exponent >= the step's cut, below)
+  double sum_g;          // exact sum of its per-32 butterfly float sums (over all its distances, as the reference)
+  uint32_t emin, emax;   // biased exponent range of its bulk distances (emin > emax: none)
   uint32_t bad;          // a NaN or inf distance
-  uint32_t pad;
+  uint32_t grange;       // (max << 16) | min biased exponent of its non-zero butterfly sums (min 0xFFFF: none)
 };
 
-// the reference's warpReduceSum over 32 lanes (kmeans.cu:63-66) + the block's exact double sums / exponent range
-// of its kKmppBlock values v (rows past N: 0)
-__device__ __forceinline__ void kmpp_block_stats(float v, KmppBlockStat *__restrict__ out) {
-  // a lane past the group reads itself
-  float g = v;
-#pragma unroll
-  for (int off = 16; off > 0; off >>= 1) g = g + __shfl_down(g, off, 32);
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double sd = (double)v, sg = ((threadIdx.x & 31) == 0) ? (double)g : 0.0;
-  const uint32_t bits = __float_as_uint(v), ex = (bits >> 23) & 0xFFu;
-  const bool finite = ex != 0xFFu, nz = (bits & 0x7FFFFFFFu) != 0u;
-  uint32_t emin = (finite && nz) ? (ex ? ex : 1u) : 0xFFFFu, emax = (finite && nz) ? (ex ? ex : 1u) : 0u;
-  uint32_t bad = finite ? 0u : 1u;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    sd += __shfl_xor(sd, off);
-    sg += __shfl_xor(sg, off);
-    emin = min(emin, (uint32_t)__shfl_xor((int)emin, off));
-    emax = max(emax, (uint32_t)__shfl_xor((int)emax, off));
-    bad |= (uint32_t)__shfl_xor((int)bad, off);
-  }
-  __shared__ double wd[4], wg[4];
-  __shared__ uint32_t wmin[4], wmax[4], wbad[4];
-  if (lane == 0) { wd[wave] = sd; wg[wave] = sg; wmin[wave] = emin; wmax[wave] = emax; wbad[wave] = bad; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    KmppBlockStat st;
-    st.sum_d = (wd[0] + wd[1]) + (wd[2] + wd[3]);
-    st.sum_g = (wg[0] + wg[1]) + (wg[2] + wg[3]);
-    st.emin = min(min(wmin[0], wmin[1]), min(wmin[2], wmin[3]));
-    st.emax = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
-    st.bad = wbad[0] | wbad[1] | wbad[2] | wbad[3];
-    st.pad = 0;
-    *out = st;
-  }
-}
+// Round 5: BULK and OUTLIERS.  The chooser's sums are exact -- order free -- only while every partial sum fits a
+// double, i.e. while the distances span few enough binades; the angular metric breaks that from the second or third
+// seed on (a seed's own row sits at acos(fl(x.x)) = 3.5e-4, twelve binades under the bulk of the angles) and every
+// step went to the host chooser (4 ms per step at 8M rows).  Now the non-zero distances below the step's exponent cut
+// -- a handful: the seeds' own rows, duplicates of them -- are kept OUT of the exact sums and listed (index, value, the
+// exact sum of the bulk distances in front of them in their block), and the chooser replays the host's SEQUENTIAL
+// double sum over that list: between two listed values the running sum moves by an exact bulk sum, at a listed value
+// it is rounded as the host's addition rounds it, and when it enters a new binade the residue of the listed values
+// loses one bit, to even (kmpp_settle).  The cut is the previous step's largest exponent + log2 N - 27: two binades
+// inside the window in which bulk sums are exact, so that every bulk partial sum is a multiple of four grid steps of
+// the running sum wherever that stands.
+struct KmppOutlier {
+  uint32_t idx;   // row (in its shard)
+  float val;
+  double pre;     // exact sum of the bulk distances of its 256-row block in front of it
+};
+constexpr uint32_t kKmppOutCap = 2048;   // listed values a step may have (more: the host chooser takes the step)
 
 // list != nullptr: the rows list[0 .. *count) only (kmpp_filter_kernel's survivors), blocks striding over the
 // list, no block statistics (kmpp_stats_kernel follows)
@@ -215,21 +196,26 @@ __global__ __launch_bounds__(kKmppBlock) void kmpp_step2_kernel(const float *__r
     if (cc == 1 || dist < dists[s]) dists[s] = dist; else dist = dists[s];   // :57-62
     v = dist;
   }
-  kmpp_block_stats(v, &stats[blockIdx.x]);
+  (void)v;
+  (void)stats;   // (the block statistics are kmpp_stats_kernel's, which follows every step)
 }
 
-// block statistics of the distances as they stand (after a filtered step): ONE WAVE per block of kKmppBlock rows, four
-// trips of 64 rows, no LDS, no barrier (kmpp_block_stats' shape -- four waves meeting in LDS -- is latency: 70 us for
-// 32 MB).  The same numbers: the butterfly sums are per 32 lanes, the double sums exact in any order.
+// block statistics of the distances as they stand (after a step): ONE WAVE per block of kKmppBlock rows, four trips
+// of 64 rows, no LDS, no barrier (four waves meeting in LDS was latency: 70 us for 32 MB).  The butterfly sums are per
+// 32 lanes, the double sums exact in any order.  *ecut (0 counts as 1): the step's exponent cut; the non-zero
+// distances below it are listed in outl / *outl_count instead of summed (KmppOutlier).
 __global__ __launch_bounds__(256) void kmpp_stats_kernel(const float *__restrict__ dists, uint32_t N,
                                                          KmppBlockStat *__restrict__ stats,
                                                          uint32_t *__restrict__ list_count,
-                                                         const uint32_t *__restrict__ fail) {
+                                                         const uint32_t *__restrict__ fail,
+                                                         const uint32_t *__restrict__ ecut_ptr,
+                                                         KmppOutlier *__restrict__ outl, uint32_t *__restrict__ outl_count) {
   if (*fail) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {   // the step's survivor list has been consumed (stream order); [1..2] behind it: the running total
+  if (list_count && blockIdx.x == 0 && threadIdx.x == 0) {   // the step's survivor list has been consumed (stream order); [1..2] behind it: the running total
     *reinterpret_cast<unsigned long long *>(list_count + 1) += *list_count;
     *list_count = 0u;
   }
+  const uint32_t ecut = max(*ecut_ptr, 1u);
   const uint32_t nb = (N + kKmppBlock - 1) / kKmppBlock;
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
@@ -241,21 +227,62 @@ __global__ __launch_bounds__(256) void kmpp_stats_kernel(const float *__restrict
       v[t] = s < N ? dists[s] : 0.f;
     }
     double sd = 0.0, sg = 0.0;
-    uint32_t emin = 0xFFFFu, emax = 0u, bad = 0u;
+    uint32_t emin = 0xFFFFu, emax = 0u, bad = 0u, gmin = 0xFFFFu, gmax = 0u;
+    bool isbulk[kKmppBlock / 64], isout[kKmppBlock / 64];
+    unsigned long long any_out = 0ull;
 #pragma unroll
     for (int t = 0; t < kKmppBlock / 64; t++) {
       float g = v[t];   // warpReduceSum over 32 lanes (kmeans.cu:63-66)
 #pragma unroll
       for (int off = 16; off > 0; off >>= 1) g = g + __shfl_down(g, off, 32);
-      sd += (double)v[t];
-      if ((lane & 31) == 0) sg += (double)g;
       const uint32_t bits = __float_as_uint(v[t]), ex = (bits >> 23) & 0xFFu;
       const bool finite = ex != 0xFFu, nz = (bits & 0x7FFFFFFFu) != 0u;
-      if (finite && nz) {
-        emin = min(emin, ex ? ex : 1u);
-        emax = max(emax, ex ? ex : 1u);
+      const uint32_t ee = ex ? ex : 1u;
+      isbulk[t] = finite && nz && ee >= ecut;
+      isout[t] = finite && nz && ee < ecut;
+      if (isbulk[t]) {
+        sd += (double)v[t];
+        emin = min(emin, ee);
+        emax = max(emax, ee);
+      }
+      if ((lane & 31) == 0) {
+        sg += (double)g;
+        const uint32_t gb = __float_as_uint(g), gx = (gb >> 23) & 0xFFu;
+        if (gx != 0xFFu && (gb & 0x7FFFFFFFu) != 0u) {
+          gmin = min(gmin, gx ? gx : 1u);
+          gmax = max(gmax, gx ? gx : 1u);
+        }
       }
       bad |= finite ? 0u : 1u;
+      any_out |= __ballot(isout[t]);
+    }
+    if (any_out) {   // (wave-uniform; rare) the listed values with the exact bulk sum in front of each
+      double carry = 0.0;
+#pragma unroll
+      for (int t = 0; t < kKmppBlock / 64; t++) {
+        const double bv = isbulk[t] ? (double)v[t] : 0.0;
+        double inc = bv;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const double up = __shfl_up(inc, o);
+          if ((int)lane >= o) inc += up;
+        }
+        const unsigned long long m = __ballot(isout[t]);
+        if (m) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(outl_count, (uint32_t)__popcll(m));
+          base = __shfl(base, 0);
+          const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          if (isout[t] && at < kKmppOutCap) {
+            KmppOutlier o;
+            o.idx = b * kKmppBlock + t * 64 + lane;
+            o.val = v[t];
+            o.pre = carry + (inc - bv);
+            outl[at] = o;
+          }
+        }
+        carry += __shfl(inc, 63);
+      }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -263,11 +290,13 @@ __global__ __launch_bounds__(256) void kmpp_stats_kernel(const float *__restrict
       sg += __shfl_xor(sg, off);
       emin = min(emin, (uint32_t)__shfl_xor((int)emin, off));
       emax = max(emax, (uint32_t)__shfl_xor((int)emax, off));
+      gmin = min(gmin, (uint32_t)__shfl_xor((int)gmin, off));
+      gmax = max(gmax, (uint32_t)__shfl_xor((int)gmax, off));
       bad |= (uint32_t)__shfl_xor((int)bad, off);
     }
     if (lane == 0) {
       KmppBlockStat st;
-      st.sum_d = sd; st.sum_g = sg; st.emin = emin; st.emax = emax; st.bad = bad; st.pad = 0;
+      st.sum_d = sd; st.sum_g = sg; st.emin = emin; st.emax = emax; st.bad = bad; st.grange = (gmax << 16) | gmin;
       stats[b] = st;
     }
   }
@@ -516,9 +545,10 @@ hipError_t launch_gather_rows(const float *samples, const uint32_t *idx, uint32_
   return hipGetLastError();
 }
 
-struct KmppTotals {   // pinned host memory
+struct KmppTotals {   // device memory, one per shard (kmcuda_api.cpp mirrors the size)
   double sum_g, sum_d;
   uint32_t emin, emax, bad, chosen;
+  uint32_t grange, pad;   // exponent range of the non-zero butterfly sums ((max << 16) | min)
 };
 
 // Exclusive prefix of the block sums in two launches.  (a) every 1024 block statistics: their local exclusive
@@ -527,20 +557,24 @@ struct KmppTotals {   // pinned host memory
 // partial sum is exact (caller's exponent-range test), so the association does not matter.
 struct KmppChunk {
   double sum, sg;
-  uint32_t emin, emax, bad, pad;
+  uint32_t emin, emax, bad, grange;
 };
+__device__ __forceinline__ uint32_t kmpp_grange_join(uint32_t a, uint32_t b) {
+  return (max(a >> 16, b >> 16) << 16) | min(a & 0xFFFFu, b & 0xFFFFu);
+}
 __global__ __launch_bounds__(1024) void kmpp_reduce_a_kernel(const KmppBlockStat *__restrict__ stats, uint32_t nb,
                                                              double *__restrict__ bpre, KmppChunk *__restrict__ aux,
                                                              const uint32_t *__restrict__ fail) {
   if (fail && *fail) return;
   __shared__ double wsum[16], wsg[16];
-  __shared__ uint32_t wmin[16], wmax[16], wbad[16];
+  __shared__ uint32_t wmin[16], wmax[16], wbad[16], wgr[16];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
   const bool in = i < nb;
   const double v = in ? stats[i].sum_d : 0.0;
   double sg = in ? stats[i].sum_g : 0.0;
   uint32_t emin = in ? stats[i].emin : 0xFFFFu, emax = in ? stats[i].emax : 0u, bad = in ? stats[i].bad : 0u;
+  uint32_t gr = in ? stats[i].grange : 0xFFFFu;
   double inc = v;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -553,9 +587,10 @@ __global__ __launch_bounds__(1024) void kmpp_reduce_a_kernel(const KmppBlockStat
     emin = min(emin, (uint32_t)__shfl_xor((int)emin, o));
     emax = max(emax, (uint32_t)__shfl_xor((int)emax, o));
     bad |= (uint32_t)__shfl_xor((int)bad, o);
+    gr = kmpp_grange_join(gr, (uint32_t)__shfl_xor((int)gr, o));
   }
   if (lane == 63) wsum[wave] = inc;
-  if (lane == 0) { wsg[wave] = sg; wmin[wave] = emin; wmax[wave] = emax; wbad[wave] = bad; }
+  if (lane == 0) { wsg[wave] = sg; wmin[wave] = emin; wmax[wave] = emax; wbad[wave] = bad; wgr[wave] = gr; }
   __syncthreads();
   double wbase = 0.0, all = 0.0;
 #pragma unroll
@@ -569,9 +604,9 @@ __global__ __launch_bounds__(1024) void kmpp_reduce_a_kernel(const KmppBlockStat
     KmppChunk c;
     c.sum = all;
     double g = 0.0;
-    uint32_t mn = 0xFFFFu, mx = 0u, bd = 0u;
-    for (uint32_t k = 0; k < 16; k++) { g += wsg[k]; mn = min(mn, wmin[k]); mx = max(mx, wmax[k]); bd |= wbad[k]; }
-    c.sg = g; c.emin = mn; c.emax = mx; c.bad = bd; c.pad = 0;
+    uint32_t mn = 0xFFFFu, mx = 0u, bd = 0u, gg = 0xFFFFu;
+    for (uint32_t k = 0; k < 16; k++) { g += wsg[k]; mn = min(mn, wmin[k]); mx = max(mx, wmax[k]); bd |= wbad[k]; gg = kmpp_grange_join(gg, wgr[k]); }
+    c.sg = g; c.emin = mn; c.emax = mx; c.bad = bd; c.grange = gg;
     aux[blockIdx.x] = c;
   }
 }
@@ -581,13 +616,13 @@ __global__ __launch_bounds__(1024) void kmpp_reduce_b_kernel(const KmppChunk *__
                                                              const uint32_t *__restrict__ fail) {
   if (fail && *fail) return;
   __shared__ double wsum[16], wsg[16];
-  __shared__ uint32_t wmin[16], wmax[16], wbad[16];
+  __shared__ uint32_t wmin[16], wmax[16], wbad[16], wgr[16];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool in = threadIdx.x < nchunks;
   const double v = in ? aux[threadIdx.x].sum : 0.0;
   double sg = in ? aux[threadIdx.x].sg : 0.0;
   uint32_t emin = in ? aux[threadIdx.x].emin : 0xFFFFu, emax = in ? aux[threadIdx.x].emax : 0u,
-           bad = in ? aux[threadIdx.x].bad : 0u;
+           bad = in ? aux[threadIdx.x].bad : 0u, gr = in ? aux[threadIdx.x].grange : 0xFFFFu;
   double inc = v;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -600,9 +635,10 @@ __global__ __launch_bounds__(1024) void kmpp_reduce_b_kernel(const KmppChunk *__
     emin = min(emin, (uint32_t)__shfl_xor((int)emin, o));
     emax = max(emax, (uint32_t)__shfl_xor((int)emax, o));
     bad |= (uint32_t)__shfl_xor((int)bad, o);
+    gr = kmpp_grange_join(gr, (uint32_t)__shfl_xor((int)gr, o));
   }
   if (lane == 63) wsum[wave] = inc;
-  if (lane == 0) { wsg[wave] = sg; wmin[wave] = emin; wmax[wave] = emax; wbad[wave] = bad; }
+  if (lane == 0) { wsg[wave] = sg; wmin[wave] = emin; wmax[wave] = emax; wbad[wave] = bad; wgr[wave] = gr; }
   __syncthreads();
   double wbase = 0.0, all = 0.0;
 #pragma unroll
@@ -615,13 +651,14 @@ __global__ __launch_bounds__(1024) void kmpp_reduce_b_kernel(const KmppChunk *__
   if (threadIdx.x == 0) {
     carry[nchunks] = all;
     double g = 0.0;
-    uint32_t mn = 0xFFFFu, mx = 0u, bd = 0u;
-    for (uint32_t k = 0; k < 16; k++) { g += wsg[k]; mn = min(mn, wmin[k]); mx = max(mx, wmax[k]); bd |= wbad[k]; }
+    uint32_t mn = 0xFFFFu, mx = 0u, bd = 0u, gg = 0xFFFFu;
+    for (uint32_t k = 0; k < 16; k++) { g += wsg[k]; mn = min(mn, wmin[k]); mx = max(mx, wmax[k]); bd |= wbad[k]; gg = kmpp_grange_join(gg, wgr[k]); }
     out->sum_g = g;
     out->sum_d = all;
     out->emin = mn;
     out->emax = mx;
     out->bad = bd;
+    out->grange = gg;
   }
 }
 
@@ -651,49 +688,103 @@ struct KmppShardView {
   const float *samples;      // its rows
   float *centroids;          // its centroid replica (slot `step` is written)
   uint32_t *fail;            // its fail flag (raised on every shard together)
+  uint32_t *ecut;            // its exponent cut: read (this step's), then written (the next step's)
+  const KmppOutlier *outl;   // its listed values ...
+  uint32_t *outl_count;      // ... and their number (zeroed here for the next step)
   uint32_t offset, length;   // its rows: [offset, offset + length) of the N; offset % kKmppBlock == 0
 };
 struct KmppShards {
   KmppShardView s[kKmppMaxShards];
   uint32_t n;
 };
+
+__device__ __forceinline__ int kmpp_ilogb(double x) {   // floor(log2 |x|), x finite, normal, non-zero
+  return (int)(((unsigned long long)__double_as_longlong(x) >> 52) & 0x7FFull) - 1023;
+}
+__device__ __forceinline__ int kmpp_lowbit(double r) {  // exponent of r's lowest set bit (r normal, non-zero)
+  const unsigned long long m = ((unsigned long long)__double_as_longlong(r) & 0xFFFFFFFFFFFFFull) | 0x10000000000000ull;
+  return kmpp_ilogb(r) - 52 + (__ffsll((long long)m) - 1);
+}
+// The host's running sum, in double, is (exact bulk sum so far) + r, r being what the listed values have left in
+// it.  While bulk values are added that stays exact until the sum enters a binade whose grid is coarser than r's
+// lowest bit; there the addition rounds, and what it drops is exactly that one bit (r is a multiple of the old grid,
+// the bulk part a multiple of four new grid steps: the caller's range test): a tie, to even, decided by r's own next
+// bit.  One bit per binade entered, in this order -- not the same as one rounding to the final grid.
+__device__ double kmpp_settle(double r, double B) {
+  for (int guard = 0; guard < 80 && r != 0.0; guard++) {
+    const double x = B + r;   // (only its binade is used)
+    if (x == 0.0) break;
+    const int lb = kmpp_lowbit(r);
+    if (lb >= kmpp_ilogb(x) - 52) break;
+    const double C = ldexp(1.5, 52 + lb + 1);   // (r + C) - C: r to a multiple of 2^(lb + 1), ties to even
+    const double t = r + C;
+    r = t - C;
+  }
+  return r;
+}
+
 __global__ __launch_bounds__(kKmppBlock) void kmpp_choose_kernel(KmppShards sh, uint32_t N, double choice, uint32_t log2n,
                                                                  uint32_t step, uint32_t D, KmppTotals *__restrict__ out) {
   if (*sh.s[0].fail) return;
   const uint32_t tid = threadIdx.x, S = sh.n;
-  __shared__ double base[kKmppMaxShards + 1];    // exact sum of the distances of the shards before s; [S] = of all
+  __shared__ double base[kKmppMaxShards + 1];    // exact sum of the bulk distances of the shards before s; [S] = of all
   __shared__ uint32_t blk0[kKmppMaxShards + 1];  // first global block of shard s; [S] = the number of blocks
+  __shared__ uint32_t obase[kKmppMaxShards + 1]; // listed values of the shards before s
   __shared__ double sum_g_s;
-  __shared__ uint32_t exact_s;
+  __shared__ uint32_t exact_s, ecut_s;
+  // the listed values of all shards, by global row (sorted below): 32 KB
+  __shared__ uint32_t o_idx[kKmppOutCap];
+  __shared__ float o_val[kKmppOutCap];
+  __shared__ double o_bulk[kKmppOutCap];          // exact sum of the bulk distances in front of the row
+  auto fail_all = [&]() {
+    for (uint32_t i = 0; i < S; i++) {
+      *sh.s[i].fail = step;
+      *sh.s[i].outl_count = 0u;   // (the host chooser takes the step from dists[]; the next step lists afresh)
+    }
+  };
   if (tid == 0) {
     double b = 0.0, g = 0.0;
-    uint32_t emin = 0xFFFFu, emax = 0u, bad = 0u;
+    uint32_t emin = 0xFFFFu, emax = 0u, bad = 0u, gr = 0xFFFFu, no = 0u;
     for (uint32_t i = 0; i < S; i++) {
       const KmppTotals *t = sh.s[i].totals;
       base[i] = b;
       blk0[i] = sh.s[i].offset / kKmppBlock;
+      obase[i] = no;
       b += t->sum_d;
       g += t->sum_g;
       emin = min(emin, t->emin);
       emax = max(emax, t->emax);
       bad |= t->bad;
+      gr = kmpp_grange_join(gr, t->grange);
+      no += *sh.s[i].outl_count;   // (counts every attempt: beyond the capacity = too many)
     }
     base[S] = b;
     blk0[S] = (N + kKmppBlock - 1) / kKmppBlock;
+    obase[S] = no;
     sum_g_s = g;
-    // every partial sum of the distances (and of their butterfly sums) is exact in double iff
-    // (emax + 1 + log2 N) - (emin - 23) <= 53
+    ecut_s = max(*sh.s[0].ecut, 1u);   // (the same on every shard: written below)
+    // every partial sum of the bulk distances is exact in double iff (emax + 1 + log2 N) - (emin - 23) <= 53; with
+    // listed values two binades more are asked for (kmpp_settle: the bulk part a multiple of four grid steps); the
+    // butterfly sums of 32 likewise (N / 32 of them)
     const bool none = emin > emax;
-    exact_s = (!bad && (none || emax - emin + log2n <= 29u)) ? 1u : 0u;
-    if (!exact_s)
-      for (uint32_t i = 0; i < S; i++) *sh.s[i].fail = step;
+    const uint32_t window = no ? 27u : 29u;
+    const uint32_t gmin = gr & 0xFFFFu, gmax = gr >> 16;
+    const bool gnone = gmin > gmax;
+    const bool ok = !bad && (none || emax - emin + log2n <= window) &&
+                    (gnone || gmax - gmin + (log2n > 5u ? log2n - 5u : 0u) <= 29u) && no <= kKmppOutCap;
+    exact_s = ok ? 1u : 0u;
+    if (!ok) fail_all();
+    // the next step's cut, also behind a step that goes to the host (the first angular step does: nothing is listed
+    // yet): distances only shrink from step to step, so this step's largest exponent bounds the next's
+    const uint32_t next = (none || bad) ? 1u : (emax + log2n > 27u ? emax + log2n - 27u : 1u);
+    for (uint32_t i = 0; i < S; i++) *sh.s[i].ecut = next;
   }
   __syncthreads();
   if (!exact_s) return;
-  const uint32_t nb = blk0[S];
+  const uint32_t nb = blk0[S], nout = obase[S], ecut = ecut_s;
   const uint32_t ca = (uint32_t)(choice * (double)N);   // kmcuda.cc:301-302
   const double cs = choice * sum_g_s;
-  // exclusive prefix of global block i (i <= nb): the owner's chunk-local part + its chunk's carry (kmpp_reduce_*,
+  // exclusive BULK prefix of global block i (i <= nb): the owner's chunk-local part + its chunk's carry (kmpp_reduce_*,
   // stored behind the shard's local values) + the exact sum of the shards before it; bpre[nb] = the total
   auto shard_of_block = [&](uint32_t i) -> uint32_t {
     uint32_t o = 0;
@@ -712,13 +803,54 @@ __global__ __launch_bounds__(kKmppBlock) void kmpp_choose_kernel(KmppShards sh, 
     const uint32_t o = shard_of_block(row / kKmppBlock);
     return sh.s[o].dists[row - sh.s[o].offset];
   };
+  auto bulk_of = [&](float v) -> double {       // v as the bulk sums count it (a listed value, a zero: nothing)
+    const uint32_t bits = __float_as_uint(v), ex = (bits >> 23) & 0xFFu;
+    return ((bits & 0x7FFFFFFFu) != 0u && (ex ? ex : 1u) >= ecut) ? (double)v : 0.0;
+  };
+  // ---- the listed values, by global row ----
+  if (nout) {
+    uint32_t n2 = 1;
+    while (n2 < nout) n2 <<= 1;
+    for (uint32_t i = tid; i < n2; i += kKmppBlock) {
+      uint32_t gi = 0xFFFFFFFFu;
+      float v = 0.f;
+      double bk = 0.0;
+      if (i < nout) {
+        uint32_t o = 0;
+        for (uint32_t q = 1; q < S; q++)
+          if (i >= obase[q]) o = q;
+        const KmppOutlier rec = sh.s[o].outl[i - obase[o]];
+        gi = sh.s[o].offset + rec.idx;
+        v = rec.val;
+        bk = bpre(gi / kKmppBlock) + rec.pre;
+      }
+      o_idx[i] = gi; o_val[i] = v; o_bulk[i] = bk;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= n2; k <<= 1) {       // bitonic sort by row (rows are distinct)
+      for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
+        for (uint32_t i = tid; i < n2; i += kKmppBlock) {
+          const uint32_t l = i ^ jj;
+          if (l > i) {
+            const uint32_t x = o_idx[i], y = o_idx[l];
+            const bool up = (i & k) == 0;
+            if ((x > y) == up) {
+              o_idx[i] = y; o_idx[l] = x;
+              const float fv = o_val[i]; o_val[i] = o_val[l]; o_val[l] = fv;
+              const double dv = o_bulk[i]; o_bulk[i] = o_bulk[l]; o_bulk[l] = dv;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
   __shared__ double incl[kKmppBlock];
   __shared__ uint32_t best;
-  __shared__ double pca_s;
-  // inclusive exact prefix of block bi into incl[] (Hillis-Steele; any order is exact)
+  // inclusive exact BULK prefix of block bi into incl[] (Hillis-Steele; any order is exact)
   auto scan_block = [&](uint32_t bi) {
     const uint32_t s = bi * kKmppBlock + tid;
-    incl[tid] = s < N ? (double)dist_at(s) : 0.0;
+    incl[tid] = s < N ? bulk_of(dist_at(s)) : 0.0;
     __syncthreads();
     for (int o = 1; o < kKmppBlock; o <<= 1) {
       const double t = tid >= (uint32_t)o ? incl[tid - o] : 0.0;
@@ -727,17 +859,19 @@ __global__ __launch_bounds__(kKmppBlock) void kmpp_choose_kernel(KmppShards sh, 
       __syncthreads();
     }
   };
-  auto first_m = [&](double dca) -> uint32_t {   // block-uniform result
+  // m0 = min { m in [0, N] : (Bulk(m) - c1) + c2 >= cs }  (N when there is none); Bulk(m) = the exact sum of the bulk
+  // distances of the rows below m.  Block-uniform result.
+  auto first_m = [&](double c1, double c2) -> uint32_t {
     if (tid == 0) best = 0xFFFFFFFFu;
     __syncthreads();
-    if (0.0 - dca >= cs) return 0u;                               // prefix(0) = 0
+    if ((0.0 - c1) + c2 >= cs) return 0u;                          // Bulk(0) = 0
     // smallest block whose END prefix qualifies: the prefixes do not decrease (distances >= 0; a NaN has sent the step
     // to the host), so two rounds of 256 probes find it: every stride-th block, then the blocks in between
     const uint32_t stride = (nb + kKmppBlock - 1) / kKmppBlock;   // >= 1
     {
       const uint32_t probe = (tid + 1) * stride - 1;              // last block of my range
       const uint32_t pb = probe < nb ? probe : nb - 1;
-      if (tid * stride < nb && bpre(pb + 1) - dca >= cs) atomicMin(&best, tid);
+      if (tid * stride < nb && (bpre(pb + 1) - c1) + c2 >= cs) atomicMin(&best, tid);
     }
     __syncthreads();
     const uint32_t range = best;
@@ -746,7 +880,7 @@ __global__ __launch_bounds__(kKmppBlock) void kmpp_choose_kernel(KmppShards sh, 
     __syncthreads();
     if (range != 0xFFFFFFFFu) {
       for (uint32_t bi = range * stride + tid; bi < nb && bi < (range + 1) * stride; bi += kKmppBlock)
-        if (bpre(bi + 1) - dca >= cs) { atomicMin(&best, bi); break; }
+        if ((bpre(bi + 1) - c1) + c2 >= cs) { atomicMin(&best, bi); break; }
     }
     __syncthreads();
     const uint32_t bi = best;
@@ -755,40 +889,123 @@ __global__ __launch_bounds__(kKmppBlock) void kmpp_choose_kernel(KmppShards sh, 
     scan_block(bi);
     if (tid == 0) best = 0xFFFFFFFFu;
     __syncthreads();
-    const uint32_t m = bi * kKmppBlock + tid + 1;                  // prefix(m) = bpre(bi) + incl[tid]
-    if (m <= N && (bpre(bi) + incl[tid]) - dca >= cs) atomicMin(&best, m);
+    const uint32_t m = bi * kKmppBlock + tid + 1;                  // Bulk(m) = bpre(bi) + incl[tid]
+    if (m <= N && ((bpre(bi) + incl[tid]) - c1) + c2 >= cs) atomicMin(&best, m);
     __syncthreads();
     const uint32_t r = best;
     __syncthreads();
     return r == 0xFFFFFFFFu ? N : r;
   };
-  uint32_t j;
-  bool forward = ca < 100u;
-  if (!forward) {   // prefix(ca), exact
-    const uint32_t bi = ca / kKmppBlock, r = ca % kKmppBlock;
-    double pca;
-    if (bi >= nb) pca = bpre(nb);
+  // ---- the host's walk (kmcuda.cc:300-326) over the listed values: which way, which residue, which stretch ----
+  // what thread 0 leaves for everybody: mode 0 = j is known (w_j), 1 = forward search first_m(0, w_r) in a stretch
+  // whose residue (as of cs's binade) is w_r, 2 = backward search first_m(w_c1, w_r) -> j = max(2, m0 - 1), 3 = the host's turn
+  __shared__ uint32_t w_mode, w_j;
+  __shared__ double w_r, w_c1;
+  double bulk_ca = 0.0;
+  float dca_f = 0.f;
+  if (ca >= 100u) {   // Bulk(ca), exact (block-uniform)
+    const uint32_t bi = ca / kKmppBlock, rr = ca % kKmppBlock;
+    if (bi >= nb) bulk_ca = bpre(nb);
     else {
       scan_block(bi);
-      pca = bpre(bi) + (r ? incl[r - 1] : 0.0);
+      bulk_ca = bpre(bi) + (rr ? incl[rr - 1] : 0.0);
     }
-    if (tid == 0) pca_s = pca;
     __syncthreads();
-    forward = pca_s < cs;
-    __syncthreads();
+    dca_f = ca < N ? dist_at(ca) : 0.f;
   }
-  if (forward) {
-    j = first_m(0.0);
-  } else {
-    const double dca = ca < N ? (double)dist_at(ca) : 0.0;
-    const uint32_t m0 = first_m(dca);
+  if (tid == 0) {
+    uint32_t mode = 1, jfix = 0;
+    double r = 0.0, c1 = 0.0;
+    uint32_t i = 0;
+    bool forward = true;
+    if (ca >= 100u) {
+      for (; i < nout && o_idx[i] < ca; i++) {      // the sum over the rows below ca, rounded where the host's is
+        r = kmpp_settle(r, o_bulk[i]);
+        const double sb = o_bulk[i] + r;
+        r = (sb + (double)o_val[i]) - o_bulk[i];
+      }
+      r = kmpp_settle(r, bulk_ca);
+      forward = (bulk_ca + r) < cs;
+    }
+    if (forward) {
+      // for (j = start; j < N && sum < cs; j++) sum += d[j]: j = the first m >= start with S(m) >= cs
+      if (ca < 100u && 0.0 >= cs) { mode = 0; jfix = 0; }
+      else {
+        bool found = false;
+        for (; i < nout; i++) {
+          const double rs = kmpp_settle(r, o_bulk[i]);
+          const double sb = o_bulk[i] + rs;         // S(p): every row below the listed row p added
+          if (sb >= cs) {                           // reached inside the bulk stretch in front of p
+            mode = 1;
+            found = true;
+            break;
+          }
+          const double s2 = sb + (double)o_val[i];
+          r = s2 - o_bulk[i];
+          if (s2 >= cs) { mode = 0; jfix = o_idx[i] + 1u; found = true; break; }
+        }
+        if (!found) {
+          const double rs = kmpp_settle(r, base[S]);
+          if (base[S] + rs >= cs) mode = 1;
+          else { mode = 0; jfix = N; }
+        }
+      }
+    } else {
+      // for (j = ca; j > 1 && sum >= cs; j--) sum -= d[j]; j++  -- going down the grid only gets finer: the listed
+      // values are the only roundings.  T(j) = (Bulk(j + 1) - bulk part of d[ca]) + r before d[j] is subtracted.
+      c1 = bulk_of(dca_f);
+      mode = 2;
+      // the listed rows <= ca, downwards
+      uint32_t t = i;
+      while (t < nout && o_idx[t] <= ca) t++;
+      while (t > 0) {
+        t--;
+        const uint32_t p = o_idx[t];
+        const double tlow = (o_bulk[t] - c1) + r;   // T(p): Bulk(p + 1) = Bulk(p), p being listed
+        if (tlow < cs || p <= 1u) break;            // the loop ends in the stretch above p (or at its j > 1 test)
+        const double tnew = tlow - (double)o_val[t];   // d[p] subtracted: T(p - 1), rounded as the host's subtraction
+        if (tnew < cs) { mode = 0; jfix = p; break; }  // the loop ends at j = p - 1 (>= 1), then j++
+        r = tnew - (o_bulk[t] - c1);
+      }
+    }
+    if (mode == 1u) {
+      // Inside the stretch the sum may enter new binades (its residue losing a bit each time) before it reaches cs.
+      // Every sum >= cs has been through all of them up to cs's own binade, every sum of a lower binade is < cs: the
+      // first row at which the sum reaches cs is the first at which Bulk + (the residue as of cs's binade) does --
+      // unless cs IS a power of two (a sum rounded up onto it from below would be taken for reaching it): the host's turn.
+      const unsigned long long cb = (unsigned long long)__double_as_longlong(cs);
+      if ((cb & 0xFFFFFFFFFFFFFull) == 0ull) mode = 3;
+      else {
+        for (int guard = 0; guard < 80 && r != 0.0; guard++) {
+          const int lb = kmpp_lowbit(r);
+          if (lb >= kmpp_ilogb(cs) - 52) break;
+          const double C = ldexp(1.5, 52 + lb + 1);
+          const double t = r + C;
+          r = t - C;
+        }
+      }
+    }
+    w_mode = mode; w_j = jfix; w_r = r; w_c1 = c1;
+  }
+  __syncthreads();
+  if (w_mode == 3u) {
+    if (tid == 0) fail_all();
+    return;
+  }
+  uint32_t j;
+  if (w_mode == 0u) j = w_j;
+  else if (w_mode == 1u) j = first_m(0.0, w_r);
+  else {
+    const uint32_t m0 = first_m(w_c1, w_r);
     const uint32_t mp = m0 == 0u ? 0u : min(m0 - 1u, ca + 1u);
     j = max(2u, mp);
   }
-  if (tid == 0) out->chosen = j;
+  if (tid == 0) {
+    out->chosen = j;
+    for (uint32_t i = 0; i < S; i++) *sh.s[i].outl_count = 0u;   // consumed: the next step lists afresh
+  }
   if (j == 0u || j > N) {   // (the reference reports an internal bug here: so will the host)
-    if (tid == 0)
-      for (uint32_t i = 0; i < S; i++) *sh.s[i].fail = step;
+    if (tid == 0) fail_all();
     return;
   }
   // the seed's row, from its owner into every shard's replica
@@ -816,7 +1033,7 @@ static hipError_t launch_kmpp_reduce(const void *block_stats, uint32_t nb, doubl
 
 hipError_t launch_kmpp_step2(int metric, const float *samples, uint32_t N, uint32_t D, const float *centroid,
                              uint32_t cc, float *dists, void *block_stats, double *bpre, void *totals_host,
-                             const uint32_t *fail, hipStream_t st) {
+                             const uint32_t *fail, const KmppOutlierBuf &out, hipStream_t st) {
   const uint32_t nb = (N + kKmppBlock - 1) / kKmppBlock;
   if (metric == 0)
     hipLaunchKernelGGL((kmpp_step2_kernel<0>), dim3(nb), dim3(kKmppBlock), 0, st, samples, N, D, centroid, cc, dists,
@@ -824,6 +1041,9 @@ hipError_t launch_kmpp_step2(int metric, const float *samples, uint32_t N, uint3
   else
     hipLaunchKernelGGL((kmpp_step2_kernel<1>), dim3(nb), dim3(kKmppBlock), 0, st, samples, N, D, centroid, cc, dists,
                        reinterpret_cast<KmppBlockStat *>(block_stats), (const uint32_t *)nullptr, (const uint32_t *)nullptr, fail);
+  hipLaunchKernelGGL(kmpp_stats_kernel, dim3((nb + 3) / 4 < 2048u ? (nb + 3) / 4 : 2048u), dim3(256), 0, st, dists, N,
+                     reinterpret_cast<KmppBlockStat *>(block_stats), (uint32_t *)nullptr, fail, out.ecut,
+                     reinterpret_cast<KmppOutlier *>(out.outl), out.outl_count);
   return launch_kmpp_reduce(block_stats, nb, bpre, totals_host, fail, st);
 }
 
@@ -849,7 +1069,7 @@ hipError_t launch_kmpp_step_filtered(int metric, const float *samples, uint32_t 
                                      const void *xs8, const float *meta, const float *mu, uint32_t *stats,
                                      uint32_t *list, const float *centroid, uint32_t cc, float *dists,
                                      void *block_stats, double *bpre, void *totals_host, const uint32_t *fail,
-                                     hipStream_t st) {
+                                     const KmppOutlierBuf &out, hipStream_t st) {
   const uint32_t nb = (N + kKmppBlock - 1) / kKmppBlock;
   const float eps = (float)(1.02 * ((double)D + 12.0) * 5.9604644775390625e-8);   // as the k-NN filter
   const uint32_t fgrid = (N + 127) / 128 < 1024u ? (N + 127) / 128 : 1024u;   // 16 waves per CU; one list atomic per wave
@@ -878,7 +1098,8 @@ hipError_t launch_kmpp_step_filtered(int metric, const float *samples, uint32_t 
     hipLaunchKernelGGL((kmpp_step2_kernel<1>), dim3(lgrid), dim3(kKmppBlock), 0, st, samples, N, D, centroid, cc, dists,
                        (KmppBlockStat *)nullptr, list, stats + 1, fail);
   hipLaunchKernelGGL(kmpp_stats_kernel, dim3((nb + 3) / 4 < 2048u ? (nb + 3) / 4 : 2048u), dim3(256), 0, st, dists, N,
-                     reinterpret_cast<KmppBlockStat *>(block_stats), stats + 1, fail);
+                     reinterpret_cast<KmppBlockStat *>(block_stats), stats + 1, fail, out.ecut,
+                     reinterpret_cast<KmppOutlier *>(out.outl), out.outl_count);
   return launch_kmpp_reduce(block_stats, nb, bpre, totals_host, fail, st);
 }
 
@@ -894,6 +1115,9 @@ hipError_t launch_kmpp_choose(const KmppShardPtrs *shards, uint32_t nshards, uin
     sh.s[i].samples = shards[i].samples;
     sh.s[i].centroids = shards[i].centroids;
     sh.s[i].fail = shards[i].fail;
+    sh.s[i].ecut = shards[i].out.ecut;
+    sh.s[i].outl = reinterpret_cast<const KmppOutlier *>(shards[i].out.outl);
+    sh.s[i].outl_count = shards[i].out.outl_count;
     sh.s[i].offset = shards[i].offset;
     sh.s[i].length = shards[i].length;
     if (i && shards[i].offset % kKmppBlock != 0) return hipErrorInvalidValue;
@@ -903,6 +1127,8 @@ hipError_t launch_kmpp_choose(const KmppShardPtrs *shards, uint32_t nshards, uin
   return hipGetLastError();
 }
 
+size_t kmpp_outlier_bytes() { return (size_t)kKmppOutCap * sizeof(KmppOutlier); }
+size_t kmpp_totals_bytes() { return sizeof(KmppTotals); }
 size_t kmpp_block_stat_bytes(uint32_t N) { return (size_t)((N + kKmppBlock - 1) / kKmppBlock) * sizeof(KmppBlockStat); }
 size_t kmpp_blocks(uint32_t N) { return (N + kKmppBlock - 1) / kKmppBlock; }
 // doubles the caller allocates for bpre (local prefixes + carries + chunk records)

@@ -583,6 +583,62 @@ def test_kmeanspp_filtered_steps_equal_plain_steps(monkeypatch, case):
     assert (res[0][1] == res[1][1]).all()
 
 
+@pytest.mark.parametrize("shards", [1, 3])
+@pytest.mark.parametrize("case", ["cos", "cosblobs", "cos16", "cosbig", "cosdup", "l2tiny"])
+def test_kmeanspp_chooser_replays_the_host_s_roundings_on_the_device(monkeypatch, case, shards):
+    """Angular k-means++ (round 5).  A seed's own row sits at acos(fl(x.x)) = 3.5e-4 -- twelve binades under the bulk of
+    the angles --, the host's sequential double sums are no longer exact, and until round 4 every step from the second
+    or third seed on went to the host chooser.  Now the few distances under the step's exponent cut are listed and the
+    chooser replays the host's roundings over them (seeding.hip: KmppOutlier, kmpp_settle).  Bar: the SEEDS (tolerance
+    1: the call returns them) equal the host chooser's bit for bit -- same distances, the host's own sequential sums
+    -- and the oracle's, with next to no step handed to the host.  'cosdup': duplicated rows (zero and tiny distances
+    in runs); 'l2tiny': the L2 metric with a few rows a hair's breadth from their seeds."""
+    from kmcuda_amd import kmeans_cuda
+    rs = numpy.random.RandomState(sum(map(ord, case)))
+    metric = "cos"
+    if case == "cos":
+        x, k = rs.randn(30000, 48), 120
+    elif case == "cosblobs":
+        cen = rs.randn(30, 100)
+        x, k = cen[rs.randint(0, 30, 25000)] + 0.05 * rs.randn(25000, 100), 64
+    elif case == "cos16":
+        x, k = rs.rand(30000, 64) - 0.3, 100
+    elif case == "cosbig":
+        x, k = rs.randn(200000, 64), 400
+    elif case == "cosdup":
+        basis = rs.randn(8000, 32)
+        x, k = basis[rs.randint(0, 8000, 40000)], 150
+    else:
+        metric = "L2"
+        x, k = rs.rand(40000, 16) * 8.0, 90
+        x[1::40] = x[0::40][:len(x[1::40])] + 1e-6   # rows next to other rows: distances twenty binades down
+    if metric == "cos":
+        x = x / numpy.linalg.norm(x, axis=1, keepdims=True)
+    x = x.astype(numpy.float16 if case == "cos16" else numpy.float32)
+    if shards > 1:
+        monkeypatch.setenv("KMCUDA_AMD_VIRTUAL_SHARDS", str(shards))
+    res = {}
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("KMCUDA_AMD_KMPP_HOST", "1")
+        else:
+            monkeypatch.delenv("KMCUDA_AMD_KMPP_HOST", raising=False)
+        out = StdoutListener()
+        with out:
+            c, a = kmeans_cuda(x, k, tolerance=1.0, init="k-means++", seed=11, yinyang_t=0, verbosity=2, metric=metric)
+        res[host] = (c.copy(), out.text)
+    import re
+    took = re.search(r"k-means\+\+: (\d+) of (\d+) steps took the host chooser", res[False][1])
+    assert took, "the device chooser did not run"
+    assert int(took.group(1)) <= 4, took.group(0)    # (the first angular step: nothing is listed yet)
+    bits = numpy.uint16 if case == "cos16" else numpy.uint32
+    diff = (res[False][0].view(bits) != res[True][0].view(bits)).any(axis=1)
+    assert not diff.any(), "seeds %s differ from the host chooser's" % numpy.nonzero(diff)[0][:8]
+    if case != "cos16":
+        ref = oracle.init_centroids(x, k, "kmeans++", seed=11, metric=oracle.COS if metric == "cos" else oracle.L2)
+        assert (res[False][0].view(numpy.uint32) == ref.view(numpy.uint32)).all()
+
+
 @pytest.mark.parametrize("filt", ["2", "0"], ids=["filtered", "plain"])
 @pytest.mark.parametrize("case", ["uniform", "blobs", "duplicates", "wide", "ragged", "nan", "cos"])
 def test_kmeanspp_over_row_shards_equals_one_shard_and_the_oracle(monkeypatch, case, filt):
