@@ -435,7 +435,7 @@ __global__ __launch_bounds__(512) void lloyd_wide_kernel(
 // the row's contenders idle: such rows are rare, and the alternative is a full scan of all K).  Only rows without a
 // usable list (more than kGemmCap contenders, operands out of the half range, NaN scores) go to the full scan.
 template <int METRIC, bool FAST>
-__global__ __launch_bounds__(256) void wide_contenders_kernel(
+__global__ __launch_bounds__(256, 4) void wide_contenders_kernel(
     const float *__restrict__ samples, uint32_t D, uint32_t DG, uint32_t K, const float *__restrict__ centroids,
     const float *__restrict__ csqr, const float *__restrict__ cfil,
     const float *__restrict__ bias, const float *__restrict__ mu, const uint32_t *__restrict__ stats, float eps,
@@ -465,34 +465,46 @@ __global__ __launch_bounds__(256) void wide_contenders_kernel(
     for (int i = 0; i < kGemmCap; i++) acc[i] = 0.f;
     float xn2 = 0.f, xo2 = 0.f, x0 = 0.f;
     const float *xr = samples + (size_t)s * D;
-    for (uint32_t f = lane * 4; f < DG; f += 256) {
-      float x4[4], m4[4];
-      if (FAST) {
-        // (the row is read once: streamed past the caches, which the contenders' centroid rows -- a 4-MB panel at
-        //  1024 x 1024 -- need)
-        const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(xr + f)), b = *reinterpret_cast<const f32x4 *>(mu + f);
-        x4[0] = a.x; x4[1] = a.y; x4[2] = a.z; x4[3] = a.w;
-        m4[0] = b.x; m4[1] = b.y; m4[2] = b.z; m4[3] = b.w;
-      } else {
+    // two 256-feature slices per trip, both slices' loads in flight before the first product: the stage is a chain
+    // of round trips to L2 / the Infinity Cache (a 4-MB fp32 panel does not stay in L2), not arithmetic
+    for (uint32_t f0 = lane * 4; f0 < DG; f0 += 512) {
+      float xc[2][4];
+      const bool second = f0 + 256 < DG;   // (DG is a multiple of 64: a lane's slice is whole or absent)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; h2++) {
+        const uint32_t f = f0 + 256u * h2;
+        float x4[4] = {0.f, 0.f, 0.f, 0.f}, m4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (h2 == 0 || second) {
+          if (FAST) {
+            // (the row is read once: streamed past the caches, which the contenders' centroid rows need)
+            const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(xr + f)), b = *reinterpret_cast<const f32x4 *>(mu + f);
+            x4[0] = a.x; x4[1] = a.y; x4[2] = a.z; x4[3] = a.w;
+            m4[0] = b.x; m4[1] = b.y; m4[2] = b.z; m4[3] = b.w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              x4[e] = (f + e) < D ? xr[f + e] : 0.f;
+              m4[e] = mu[f + e];   // DG floats, zero beyond D
+            }
+          }
+        }
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-          x4[e] = (f + e) < D ? xr[f + e] : 0.f;
-          m4[e] = mu[f + e];   // DG floats, zero beyond D
+          xc[h2][e] = x4[e] - m4[e];
+          xn2 = fmaf(xc[h2][e], xc[h2][e], xn2);
+          xo2 = fmaf(x4[e], x4[e], xo2);
         }
+        if (f == 0) x0 = x4[0];
       }
-      float xc[4];
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        xc[e] = x4[e] - m4[e];
-        xn2 = fmaf(xc[e], xc[e], xn2);
-        xo2 = fmaf(x4[e], x4[e], xo2);
-      }
-      if (f == 0) x0 = x4[0];
 #pragma unroll
       for (int i = 0; i < kGemmCap; i++) {
         if ((uint32_t)i < n && usable) {   // wave-uniform
-          const f32x4 c4 = *reinterpret_cast<const f32x4 *>(cfil + (size_t)cid[i] * DG + f);
-          acc[i] = fmaf(xc[0], c4.x, fmaf(xc[1], c4.y, fmaf(xc[2], c4.z, fmaf(xc[3], c4.w, acc[i]))));
+          const float *cr = cfil + (size_t)cid[i] * DG + f0;
+          const f32x4 ca = *reinterpret_cast<const f32x4 *>(cr);
+          f32x4 cb = {0.f, 0.f, 0.f, 0.f};
+          if (second) cb = *reinterpret_cast<const f32x4 *>(cr + 256);
+          acc[i] = fmaf(xc[0][0], ca.x, fmaf(xc[0][1], ca.y, fmaf(xc[0][2], ca.z, fmaf(xc[0][3], ca.w, acc[i]))));
+          acc[i] = fmaf(xc[1][0], cb.x, fmaf(xc[1][1], cb.y, fmaf(xc[1][2], cb.z, fmaf(xc[1][3], cb.w, acc[i]))));
         }
       }
     }

@@ -615,7 +615,7 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
   // Lists shrink from iteration to iteration, so an older figure errs towards the radix path, which takes any
   // size; after a radix call only the count is known yet and the largest list is taken as twice the average.
   // A list beyond the bucket capacity would still be summed correctly (rebuilt from (prev, cur)), only slowly.
-  const uint32_t est_max = std::max((uint32_t)ms->host[1] /* whatever has landed; 0xFFFFFFFF: not known yet */, ms->last_events / K);
+  const uint32_t est_max = std::max((uint32_t)ms->host[1] /* whatever has landed */, ms->last_events / K);
   const bool radix = N != 0 && !force_direct &&
                      (force_radix || ms->last_events > N / 2 || est_max > cap - cap / 4);
   if (N == 0) {
@@ -644,11 +644,13 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
     // (written BEFORE the kernel that reports is launched -- the stream is idle here, nothing else writes these words --
     //  so that its report, whenever it lands, is the last word)
     ms->host[0] = m;    // (the kernel's report will say the same)
-    // the largest list is NOT known until this update's kernel has reported it: until then the next update takes this
-    // path again.  (Round 4 assumed twice the average: the pass enqueued behind the stop at the hand-over point repeats
-    // that iteration's events, and on skewed clusters -- a 4M-row mixture after three iterations -- the direct path then
-    // rebuilt dozens of overflowing buckets from all N rows: 5.3 ms of a 27-ms call, profiles/r5g_handover_*.)
-    ms->host[1] = 0xFFFFFFFFu;
+    // (the largest list: whatever an EARLIER update has reported stays in host[1] until this one's report lands --
+    //  lists shrink from iteration to iteration, so the older figure errs towards this path.  Round 4 zeroed the word
+    //  here and took twice the average: the pass enqueued behind the stop at the hand-over point repeats that
+    //  iteration's events, and on skewed clusters -- a 4M-row mixture after three iterations -- the direct path then
+    //  rebuilt dozens of overflowing buckets from all N rows: 5.3 ms of a 27-ms call, profiles/r5g_handover_*.  A
+    //  marker "not known yet" written here instead kept every later update on this path -- the host runs one pass ahead
+    //  of the reports: kmeans_cuda's 46-iteration loop 0.28-0.40 s instead of 0.21, profiles/r5k_bench_api_*.)
     launch_sums(false);
   } else {
     hipLaunchKernelGGL(move_scatter_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, bucket_work,
