@@ -167,6 +167,7 @@ struct MoveState {
   uint32_t *host_dev = nullptr;        //   [2] undecided rows of the last assignment pass; host_dev: their device address
   uint32_t last_events = 0xFFFFFFFFu;  // newest event count the host knows
   int force = 0;                       // kmamd_set_update_mode
+  uint32_t n_radix = 0, n_direct = 0;  // calls by path (KMCUDA_AMD_UPDATE_TRACE: kmeans_cuda prints them at its end)
 };
 hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint32_t K, const uint32_t *prev,
                               const uint32_t *cur, uint32_t *keys_tmp, uint32_t *vals_tmp, uint32_t *keys_sorted,

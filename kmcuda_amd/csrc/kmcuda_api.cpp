@@ -2099,6 +2099,10 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
   RETERR(job.sync_all());
   job.stats.loop_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
   job.collective_collect();
+  if (getenv("KMCUDA_AMD_UPDATE_TRACE"))   // (a measurement aid: which way the updates went; nothing is printed inside the loop)
+    for (auto &s : job.shards)
+      fprintf(stderr, "[update] shard on device %d: %u radix, %u direct; loop %.4f s\n", s->dev, s->eng->ms_.n_radix, s->eng->ms_.n_direct,
+              job.stats.loop_seconds);
   {
     std::lock_guard<std::mutex> lock(g_last_run_mutex);
     g_last_run = job.stats;

@@ -623,6 +623,7 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
     if (e != hipSuccess) return e;
     launch_sums(false);
   } else if (radix) {
+    ms->n_radix++;
     const uint32_t nb = (N + kMoveRows - 1) / kMoveRows;
     hipLaunchKernelGGL(move_count_kernel, dim3(nb), dim3(256), 0, st, prev, cur, N, K, blockoff);
     hipLaunchKernelGGL(move_scan_kernel, dim3(1), dim3(1024), 0, st, blockoff, nb, blockoff + nb + 1);
@@ -653,6 +654,7 @@ hipError_t launch_move_deltas(const float *samples, uint32_t N, uint32_t D, uint
     //  of the reports: kmeans_cuda's 46-iteration loop 0.28-0.40 s instead of 0.21, profiles/r5k_bench_api_*.)
     launch_sums(false);
   } else {
+    ms->n_direct++;
     hipLaunchKernelGGL(move_scatter_kernel, dim3((N + 255) / 256), dim3(256), 0, st, prev, cur, N, K, bucket_work,
                        stride, bucket_rows, cap);
     launch_sums(true);
