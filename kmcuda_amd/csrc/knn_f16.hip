@@ -336,6 +336,11 @@ __global__ __launch_bounds__(knn16_waves(DP) * 64, knn16_blocks_per_cu(DP)) void
     constexpr int DSTR = (SUB * KS) / (PPW + 1) > 0 ? (SUB * KS) / (PPW + 1) : 1;
     // scores of one sub-tile: the biases seed the accumulators, KS k-steps on hand-issued fragment reads, every
     // fragment feeding the NSET operand sets
+    // (an operand set none of whose 32 queries visits the cluster is not multiplied: 3.4 % of the scored pairs of
+    //  config D's share, KnnArgs::calced[4]; wave-uniform)
+    bool set_live[NSET];
+#pragma unroll
+    for (int e = 0; e < NSET; e++) set_live[e] = __ballot(!pruned[e]) != 0ull;
     auto mfma_tile = [&](int buf, int sub, bool dma, uint32_t dma_base, int dma_buf) {
       const uint32_t tb = fragbase + (uint32_t)buf * TILEB + (uint32_t)sub * (32 * ROWB);
       const uint32_t bb = bias0 + (uint32_t)buf * 256u + (uint32_t)sub * 128u + 16u * h;
@@ -365,7 +370,8 @@ __global__ __launch_bounds__(knn16_waves(DP) * 64, knn16_blocks_per_cu(DP)) void
         else if (behind == 1) knn_frag_wait<1>(f);
         else knn_frag_wait<0>(f);
 #pragma unroll
-        for (int e = 0; e < NSET; e++) acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, xhi[e][j], acc[e], 0, 0, 0);
+        for (int e = 0; e < NSET; e++)
+          if (NSET == 1 || set_live[e]) acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, xhi[e][j], acc[e], 0, 0, 0);
         {
           const int slot = sub * KS + j;   // compile-time after unrolling
           if (dma && slot % DSTR == 0 && slot / DSTR <= PPW) issue_piece(dma_base, dma_buf, slot / DSTR);
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(knn16_waves(DP) * 64, knn16_blocks_per_cu(DP)) void
           if (sub > 0 && tile_base + 32u * sub >= end) break;   // block-uniform
           mfma_tile(buf, sub, dma, dma_base, dma_buf);
           {   // statistics (wave-uniform)
-            scored += 1024ull * NSET;
+            scored += 1024ull * (NSET == 1 ? 1u : nsets_live);
             scored_sets += 1024ull * nsets_live;
             const uint32_t left = end - (tile_base + 32u * sub);
             useful += (unsigned long long)nvis_tight * (left < 32u ? left : 32u);
