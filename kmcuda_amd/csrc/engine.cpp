@@ -693,12 +693,6 @@ int Engine::lloyd_assign_gemm(const LloydArgs &a0, const float *centroids) {
       gund_cont_ = nullptr;
       return no_memory();
     }
-    if (const char *v = getenv("KMCUDA_AMD_WIDE_SORT")) wide_sort_ = atoi(v) != 0;
-    if (wide_sort_ && (alloc(&gund_key_, N_) || alloc(&gsort_hist_, wide_sort_words(K_)) || alloc(&gund_rows_sorted_, N_) ||
-                       alloc(&gund_thr_sorted_, N_))) {
-      (void)hipGetLastError();
-      wide_sort_ = false;   // (no memory for the ordering: list order)
-    }
   }
   if (!xg16_) {
     uint16_t *xg = nullptr;
@@ -720,12 +714,9 @@ int Engine::lloyd_assign_gemm(const LloydArgs &a0, const float *centroids) {
     }
   }
   span_begin(3);   // the dominant kernels on their own, inside the filter span
-  KMX_HIP(launch_lloyd_wide(a, xg16_, xgmeta_, DG, panelhi_, undecided_, und_thr_, gund_cont_, wide_sort_ ? gund_key_ : nullptr,
-                            gsort_hist_, gund_rows_sorted_, gund_thr_sorted_, stream_),
-          kRuntimeError);
+  KMX_HIP(launch_lloyd_wide(a, xg16_, xgmeta_, DG, panelhi_, undecided_, und_thr_, gund_cont_, stream_), kRuntimeError);
   span_end();
-  KMX_HIP(launch_wide_contenders(metric_, a, centroids, DG, wide_sort_ ? gund_rows_sorted_ : undecided_, gund_cont_, stream_),
-          kRuntimeError);
+  KMX_HIP(launch_wide_contenders(metric_, a, centroids, DG, undecided_, gund_cont_, stream_), kRuntimeError);
   span_end();
   span_begin(1);
   if (settle_ && lloyd_settle_supported(a, centroids)) {

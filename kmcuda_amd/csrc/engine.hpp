@@ -169,10 +169,6 @@ class Engine {
   void *xg16_ = nullptr;          // N x gemm_dp_ halves: x - mu, row-major (this path's row cache)
   float *xgmeta_ = nullptr;       // 4 floats per row
   uint32_t *gund_cont_ = nullptr; // per listed row: the number of its contenders, then up to 16 of them
-  // the listed rows ordered by their best coarse centroid (KMCUDA_AMD_WIDE_SORT=0: list order, the A/B)
-  bool wide_sort_ = true;
-  uint32_t *gund_key_ = nullptr, *gsort_hist_ = nullptr, *gund_rows_sorted_ = nullptr;
-  float *gund_thr_sorted_ = nullptr;
   int lloyd_assign_gemm(const LloydArgs &a, const float *centroids);
   // row cache of the coarse filter stage (lloyd_f16.hip: row_cache_kernel); set_row_cache()
   bool row_cache_allowed_ = true;   // KMCUDA_AMD_ROW_CACHE=0 vetoes it

@@ -148,12 +148,8 @@ hipError_t launch_row_halves(const void *rows, bool half_rows, uint32_t N, uint3
                              void *xg, float *meta /* 4 floats per row */, hipStream_t st);
 size_t wide_cont_words(uint32_t N);   // contender table: (1 + 16) words per row
 // commits / lists (undecided, und_thr, counters[4]) every row, then writes the listed rows' contenders (und_cont)
-// und_key / hist / rows_sorted / thr_sorted (all or none): the listed rows are handed on ordered by their best coarse
-// centroid (rows_sorted / thr_sorted: what launch_wide_contenders then reads as und_rows); hist: wide_sort_words(K) words
-size_t wide_sort_words(uint32_t K);
 hipError_t launch_lloyd_wide(const LloydArgs &a, const void *xg, const float *meta, uint32_t DG /* % 64 == 0 */,
-                             const void *panelhi, uint32_t *undecided, float *und_thr, uint32_t *und_cont, uint32_t *und_key,
-                             uint32_t *hist, uint32_t *rows_sorted, float *thr_sorted, hipStream_t st);
+                             const void *panelhi, uint32_t *undecided, float *und_thr, uint32_t *und_cont, hipStream_t st);
 hipError_t launch_wide_contenders(int metric, const LloydArgs &a, const float *centroids, uint32_t DG,
                                   const uint32_t *und_rows, const uint32_t *und_cont, hipStream_t st);
 

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(512) void lloyd_wide_kernel(
     const _Float16 *__restrict__ panelhi, uint32_t K_pad64, uint32_t K, const uint32_t *__restrict__ stats, float eps,
     float tie_slack, uint32_t *__restrict__ assignments, uint32_t *__restrict__ assignments_prev,
     uint32_t *__restrict__ undecided, float *__restrict__ und_thr, uint32_t *__restrict__ und_cont,
-    uint32_t *__restrict__ und_key, uint32_t *__restrict__ counters) {
+    uint32_t *__restrict__ counters) {
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
   extern __shared__ __attribute__((aligned(1024))) unsigned char ldsw[];
   if (counters[kStopFlag] != 0u) return;   // the run has stopped on the device: touch nothing
@@ -362,7 +362,6 @@ __global__ __launch_bounds__(512) void lloyd_wide_kernel(
   uint32_t und_count = 0, changed_count = 0;
   unsigned long long um[2] = {0ull, 0ull};
   bool und[2] = {false, false};
-  uint32_t ikey[2] = {0u, 0u};   // the row's best coarse centroid: what the listed rows are ordered by
   if (wn == 0) {
 #pragma unroll
     for (int s = 0; s < 2; s++) {
@@ -389,7 +388,6 @@ __global__ __launch_bounds__(512) void lloyd_wide_kernel(
       bool changed = false;
       if (mine && certain) changed = commit_row(srow[s], insane ? K : i1, assignments, assignments_prev);
       und[s] = mine && !certain;
-      ikey[s] = i1 < K ? i1 : K;
       cut[s] = in_range ? b1 - thr : __builtin_nanf("");
       um[s] = __ballot(und[s]);
       changed_count += (uint32_t)__popcll(__ballot(changed));
@@ -422,73 +420,12 @@ __global__ __launch_bounds__(512) void lloyd_wide_kernel(
       const uint32_t at = base + (uint32_t)__popcll(um[0] & below);
       undecided[at] = srow[0];
       und_thr[at] = cut[0];
-      if (und_key) und_key[at] = ikey[0];
     }
     if (und[1]) {
       const uint32_t at = base + (uint32_t)__popcll(um[0]) + (uint32_t)__popcll(um[1] & below);
       undecided[at] = srow[1];
       und_thr[at] = cut[1];
-      if (und_key) und_key[at] = ikey[1];
     }
-  }
-}
-
-// The listed rows in the order of their best coarse centroid (a counting sort: histogram, scan, scatter; the order
-// inside a key is whatever the atomics make it -- nothing downstream depends on it).  Rows of one cluster share most of
-// their contenders, and the contender stage reads 4 KB of centred fp32 centroid per contender from a panel (4 MB at
-// 1024 x 1024) that does not stay in L2 under the rows streaming through: in list order every row's contenders came
-// from the Infinity Cache or HBM, in key order a block's consecutive rows find them in its L1 / L2.  hist: (K + 2)
-// counters `stride` words apart (one cache line each while that stays small), zero on entry.
-__global__ __launch_bounds__(256) void wide_sort_count_kernel(const uint32_t *__restrict__ key, const uint32_t *__restrict__ n,
-                                                              uint32_t *__restrict__ hist, uint32_t stride,
-                                                              const uint32_t *__restrict__ counters) {
-  if (counters[kStopFlag] != 0u) return;
-  const uint32_t total = *n;
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) atomicAdd(&hist[(size_t)key[i] * stride], 1u);
-}
-__global__ __launch_bounds__(1024) void wide_sort_scan_kernel(uint32_t *__restrict__ hist, uint32_t stride, uint32_t nkeys,
-                                                              const uint32_t *__restrict__ counters) {
-  if (counters[kStopFlag] != 0u) return;
-  __shared__ uint32_t wsum[16];
-  __shared__ uint32_t carry_s;
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) carry_s = 0u;
-  __syncthreads();
-  for (uint32_t base = 0; base < nkeys; base += 1024u) {   // exclusive prefix, 1024 keys per round
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t v = i < nkeys ? hist[(size_t)i * stride] : 0u;
-    uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t t = (uint32_t)__shfl_up((int)inc, o);
-      if ((int)lane >= o) inc += t;
-    }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    uint32_t wbase = carry_s, all = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 16; k++) {
-      const uint32_t t = wsum[k];
-      if (k < wave) wbase += t;
-      all += t;
-    }
-    if (i < nkeys) hist[(size_t)i * stride] = wbase + inc - v;
-    __syncthreads();
-    if (threadIdx.x == 0) carry_s += all;
-    __syncthreads();
-  }
-}
-__global__ __launch_bounds__(256) void wide_sort_scatter_kernel(const uint32_t *__restrict__ key, const uint32_t *__restrict__ rows,
-                                                                const float *__restrict__ thr, const uint32_t *__restrict__ n,
-                                                                uint32_t *__restrict__ hist, uint32_t stride,
-                                                                uint32_t *__restrict__ rows_out, float *__restrict__ thr_out,
-                                                                const uint32_t *__restrict__ counters) {
-  if (counters[kStopFlag] != 0u) return;
-  const uint32_t total = *n;
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
-    const uint32_t at = atomicAdd(&hist[(size_t)key[i] * stride], 1u);
-    rows_out[at] = rows[i];
-    thr_out[at] = thr[i];
   }
 }
 
@@ -513,12 +450,9 @@ __global__ __launch_bounds__(256, 4) void wide_contenders_kernel(
   const float cmaxo = sqrtf(__uint_as_float(stats[2])) * 1.000001f;
   const float u = 5.9604645e-8f;
   __shared__ uint32_t sh_pair[4], sh_flag[4], sh_chg[4], sh_pbase, sh_fbase;
-  // a block takes a CONTIGUOUS stretch of the list (rows ordered by their best centroid share contenders: L1 / L2)
-  const uint32_t chunk = ((total + gridDim.x - 1) / gridDim.x + 3u) / 4u * 4u;
-  const uint32_t lo = blockIdx.x * chunk, hi = min(total, lo + chunk);
-  for (uint32_t p0 = lo; p0 < hi; p0 += 4) {   // block-uniform trip count
+  for (uint32_t p0 = blockIdx.x * 4; p0 < total; p0 += gridDim.x * 4) {   // block-uniform trip count
     const uint32_t p = p0 + wave;
-    const bool live = p < hi;
+    const bool live = p < total;
     const size_t slot = live ? p : 0;
     const uint32_t s = und_rows[slot];
     const uint32_t n = live ? und_cont[slot * (kGemmCap + 1)] : 0u;
@@ -679,14 +613,8 @@ hipError_t launch_row_halves(const void *rows, bool half_rows, uint32_t N, uint3
 size_t wide_cont_words(uint32_t N) { return (size_t)N * (kGemmCap + 1); }
 
 // stage 1 over every row, then over the rows it listed (their contenders); DG: a multiple of 64
-uint32_t wide_sort_stride(uint32_t K) { return (size_t)(K + 2) * 16 * 4 <= (4u << 20) ? 16u : 1u; }
-size_t wide_sort_words(uint32_t K) { return (size_t)(K + 2) * wide_sort_stride(K); }
-
-// sort: {und_key, hist, rows_sorted, thr_sorted} or all null (list order).  Returns through *rows_out / *thr_out the
-// arrays the later stages read.
 hipError_t launch_lloyd_wide(const LloydArgs &a, const void *xg, const float *meta, uint32_t DG, const void *panelhi,
-                             uint32_t *undecided, float *und_thr, uint32_t *und_cont, uint32_t *und_key, uint32_t *hist,
-                             uint32_t *rows_sorted, float *thr_sorted, hipStream_t st) {
+                             uint32_t *undecided, float *und_thr, uint32_t *und_cont, hipStream_t st) {
   if (a.N == 0) return hipSuccess;
   if (DG % kWideBK != 0) return hipErrorInvalidValue;
   const uint32_t k_pad64 = (a.K_pad + 63u) / 64u * 64u;
@@ -700,27 +628,11 @@ hipError_t launch_lloyd_wide(const LloydArgs &a, const void *xg, const float *me
   }
   hipLaunchKernelGGL((lloyd_wide_kernel<0>), dim3(grid), dim3(512), kWideLds0, st, reinterpret_cast<const _Float16 *>(xg),
                      reinterpret_cast<const float4 *>(meta), a.N, DG, reinterpret_cast<const _Float16 *>(panelhi), k_pad64, a.K,
-                     a.stats, a.eps, a.tie_slack, a.assignments, a.assignments_prev, undecided, und_thr, und_cont, und_key,
-                     a.counters);
-  uint32_t *rows = undecided;
-  float *thr = und_thr;
-  if (und_key) {
-    const uint32_t stride = wide_sort_stride(a.K);
-    hipError_t e = hipMemsetAsync(hist, 0, wide_sort_words(a.K) * sizeof(uint32_t), st);
-    if (e != hipSuccess) return e;
-    const uint32_t sgrid = (a.N + 255) / 256 < 1024u ? (a.N + 255) / 256 : 1024u;
-    hipLaunchKernelGGL(wide_sort_count_kernel, dim3(sgrid), dim3(256), 0, st, und_key, a.counters + 4, hist, stride, a.counters);
-    hipLaunchKernelGGL(wide_sort_scan_kernel, dim3(1), dim3(1024), 0, st, hist, stride, a.K + 1, a.counters);
-    hipLaunchKernelGGL(wide_sort_scatter_kernel, dim3(sgrid), dim3(256), 0, st, und_key, undecided, und_thr, a.counters + 4, hist,
-                       stride, rows_sorted, thr_sorted, a.counters);
-    rows = rows_sorted;
-    thr = thr_sorted;
-  }
+                     a.stats, a.eps, a.tie_slack, a.assignments, a.assignments_prev, undecided, und_thr, und_cont, a.counters);
   // the listed rows: the grid covers the worst case, blocks past the (device-side) end of the list leave at once
   hipLaunchKernelGGL((lloyd_wide_kernel<1>), dim3(grid), dim3(512), kWideLds1, st, reinterpret_cast<const _Float16 *>(xg),
                      reinterpret_cast<const float4 *>(meta), a.N, DG, reinterpret_cast<const _Float16 *>(panelhi), k_pad64, a.K,
-                     a.stats, a.eps, a.tie_slack, a.assignments, a.assignments_prev, rows, thr, und_cont, (uint32_t *)nullptr,
-                     a.counters);
+                     a.stats, a.eps, a.tie_slack, a.assignments, a.assignments_prev, undecided, und_thr, und_cont, a.counters);
   return hipGetLastError();
 }
 
