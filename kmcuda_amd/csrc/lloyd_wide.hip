@@ -449,11 +449,33 @@ __global__ __launch_bounds__(256, 4) void wide_contenders_kernel(
   const float bmaxc = __uint_as_float(stats[1]);
   const float cmaxo = sqrtf(__uint_as_float(stats[2])) * 1.000001f;
   const float u = 5.9604645e-8f;
-  __shared__ uint32_t sh_pair[4], sh_flag[4], sh_chg[4], sh_pbase, sh_fbase;
-  for (uint32_t p0 = blockIdx.x * 4; p0 < total; p0 += gridDim.x * 4) {   // block-uniform trip count
-    const uint32_t p = p0 + wave;
-    const bool live = p < total;
-    const size_t slot = live ? p : 0;
+  // Every wave works through its rows on its own: no block barrier per row (round 5: three of them per row made the
+  // four waves of a block wait for the slowest -- a row settled by exact chains takes microseconds).  The pair / full-
+  // scan records wait in the wave's LDS buffer, one global atomic per kPend of them; the reassignments are counted in
+  // lane 0 and added once.
+  constexpr uint32_t kPend = 16;
+  __shared__ uint32_t pbuf[4][kPend * 3], fbuf[4][kPend];
+  volatile uint32_t *mypairs = pbuf[wave], *myflags = fbuf[wave];
+  uint32_t np = 0, nf = 0, nchg = 0;   // (np, nf wave-uniform; nchg lane 0's)
+  auto flush_pairs = [&]() {
+    if (np == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&counters[3], np);
+    base = __shfl(base, 0);
+    for (uint32_t i = lane; i < np * 3; i += 64) pairs[3 * (size_t)base + i] = mypairs[i];
+    np = 0;
+  };
+  auto flush_flags = [&]() {
+    if (nf == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&counters[1], nf);
+    base = __shfl(base, 0);
+    for (uint32_t i = lane; i < nf; i += 64) flagged[base + i] = myflags[i];
+    nf = 0;
+  };
+  for (uint32_t p = blockIdx.x * 4 + wave; p < total; p += gridDim.x * 4) {
+    const bool live = true;
+    const size_t slot = p;
     const uint32_t s = und_rows[slot];
     const uint32_t n = live ? und_cont[slot * (kGemmCap + 1)] : 0u;
     const bool usable = n >= 1 && n <= (uint32_t)kGemmCap;
@@ -574,28 +596,19 @@ __global__ __launch_bounds__(256, 4) void wide_contenders_kernel(
       }
       if (lane == 0 && best != 0xFFFFFFFFu) changed = commit_row(s, best, assignments, assignments_prev);
     }
-    if (lane == 0) { sh_pair[wave] = pair_now ? 1u : 0u; sh_flag[wave] = flag_now ? 1u : 0u; sh_chg[wave] = changed ? 1u : 0u; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const uint32_t np = sh_pair[0] + sh_pair[1] + sh_pair[2] + sh_pair[3];
-      const uint32_t nf = sh_flag[0] + sh_flag[1] + sh_flag[2] + sh_flag[3];
-      const uint32_t nc = sh_chg[0] + sh_chg[1] + sh_chg[2] + sh_chg[3];
-      sh_pbase = np ? atomicAdd(&counters[3], np) : 0u;
-      sh_fbase = nf ? atomicAdd(&counters[1], nf) : 0u;
-      if (nc) atomicAdd(&counters[0], nc);
+    if (lane == 0 && changed) nchg++;
+    if (pair_now) {   // wave-uniform
+      if (lane == 0) { mypairs[3 * np + 0] = s; mypairs[3 * np + 1] = i1; mypairs[3 * np + 2] = i2; }
+      if (++np == kPend) flush_pairs();
     }
-    __syncthreads();
-    if (lane == 0) {
-      uint32_t pb = 0, fb = 0;
-      for (uint32_t w = 0; w < wave; w++) { pb += sh_pair[w]; fb += sh_flag[w]; }
-      if (pair_now) {
-        const size_t at = (size_t)sh_pbase + pb;
-        pairs[3 * at + 0] = s; pairs[3 * at + 1] = i1; pairs[3 * at + 2] = i2;
-      }
-      if (flag_now) flagged[sh_fbase + fb] = s;
+    if (flag_now) {   // wave-uniform
+      if (lane == 0) myflags[nf] = s;
+      if (++nf == kPend) flush_flags();
     }
-    __syncthreads();
   }
+  flush_pairs();
+  flush_flags();
+  if (lane == 0 && nchg) atomicAdd(&counters[0], nchg);
 }
 
 hipError_t launch_row_halves(const void *rows, bool half_rows, uint32_t N, uint32_t D, uint32_t DG, const float *mu,
