@@ -114,8 +114,8 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if (const char *c = getenv("KMCUDA_AMD_ROW_CACHE")) row_cache_allowed_ = atoi(c) != 0;
   if (const char *c = getenv("KMCUDA_AMD_CARRY_PAIRS")) carry_pairs_ = atoi(c) != 0;
   if (const char *c = getenv("KMCUDA_AMD_SETTLE")) settle_ = atoi(c) != 0;
-  if (const char *c = getenv("KMCUDA_AMD_WIDE")) gemm_ok_ = atoi(c) != 0;
-  if (const char *c = getenv("KMCUDA_AMD_GEMM")) gemm_ok_ = atoi(c) != 0;   // (the switch's name while stage 1 was a library GEMM)
+  if (const char *c = getenv("KMCUDA_AMD_WIDE")) wide_ok_ = atoi(c) != 0;
+  if (const char *c = getenv("KMCUDA_AMD_GEMM")) wide_ok_ = atoi(c) != 0;   // (the switch's name while stage 1 was a library GEMM)
   if (const char *u = getenv("KMCUDA_AMD_UPDATE"))
     ms_.force = strcmp(u, "radix") == 0 ? 1 : (strcmp(u, "sync") == 0 ? 2 : (strcmp(u, "bucket") == 0 ? 3 : 0));
   if (D == 0 || K < 1 || K >= 0x7FFFFFFFu) return kInvalidArguments;  // K == 1: Yinyang group clustering with one group
@@ -150,8 +150,8 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
 
   // no register-resident filter for this D: stage 1 streams both operands through LDS (lloyd_wide.hip), in 64-feature
   // chunks: operands padded to 64
-  gemm_dp_ = (DP_ == 0 && gemm_ok_) ? (D + 63) / 64 * 64 : 0;
-  const uint32_t dp = DP_ ? DP_ : (gemm_dp_ ? gemm_dp_ : 8);
+  wide_dp_ = (DP_ == 0 && wide_ok_) ? (D + 63) / 64 * 64 : 0;
+  const uint32_t dp = DP_ ? DP_ : (wide_dp_ ? wide_dp_ : 8);
   int rc;
   if ((rc = alloc(&csqr_, K))) return rc;
   if ((rc = alloc(&bias_, K_pad_))) return rc;
@@ -234,7 +234,7 @@ void Engine::profile_reset() {
 }
 
 int Engine::prepare_centroids(const float *centroids) {
-  const uint32_t dp = DP_ ? DP_ : (gemm_dp_ ? gemm_dp_ : 8);
+  const uint32_t dp = DP_ ? DP_ : (wide_dp_ ? wide_dp_ : 8);
   prepared_for_ = nullptr;
   // this preparation's statistics go to the other half; both halves are zeroed here, which also leaves
   // the half after this one zero (the invariant centroid_prep_frozen_kernel relies on)
@@ -516,8 +516,8 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   a.assignments = assignments; a.assignments_prev = assignments_prev;
   a.flagged = flagged_; a.pairs = pairs_; a.counters = counters_;
   if (N_ == 0) return kSuccess;
-  if (!exact_only && DP_ == 0 && gemm_dp_ != 0 && !gemm_failed_) {
-    const int rc = lloyd_assign_gemm(a, centroids);
+  if (!exact_only && DP_ == 0 && wide_dp_ != 0 && !wide_failed_) {
+    const int rc = lloyd_assign_wide(a, centroids);
     if (rc != kNoSuchDevice + 100) return rc;   // (that code: no memory for its buffers -- the exact kernel below serves the shape)
   }
   if (exact_only || DP_ == 0 || (DP_ > 256 && filter_mode_ != 0)) {
@@ -670,17 +670,17 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
 
 // D beyond the register-resident filters: lloyd_wide.hip.  prepare_centroids() has run (csqr, ct, mean -- frozen
 // while a row copy is alive --, centred fp32 panel, biases, statistics, list counters zeroed).
-int Engine::lloyd_assign_gemm(const LloydArgs &a0, const float *centroids) {
+int Engine::lloyd_assign_wide(const LloydArgs &a0, const float *centroids) {
   constexpr int kNoFilter = kNoSuchDevice + 100;
   LloydArgs a = a0;
-  const uint32_t DG = gemm_dp_;
+  const uint32_t DG = wide_dp_;
   const uint32_t k_pad64 = (K_pad_ + 63u) / 64u * 64u;
   // This path's own memory (half copy of the rows, the listed rows' contender table) is an optimisation: a job whose
   // rows fit but whose copies do not runs on the exact kernels, as it did before this path existed
   auto no_memory = [&]() {
     (void)hipGetLastError();
     if (g_verbosity > 0) printf("rows wider than 512 features: no memory for the matrix-core filter's buffers -- exact kernels\n");
-    gemm_failed_ = true;   // (gemm_dp_ stays: the preparation's buffers are sized by it)
+    wide_failed_ = true;   // (wide_dp_ stays: the preparation's buffers are sized by it)
     return kNoFilter;
   };
   if (!panelhi_) {
@@ -688,16 +688,16 @@ int Engine::lloyd_assign_gemm(const LloydArgs &a0, const float *centroids) {
     if (alloc(&phi, (size_t)k_pad64 * (DG + 2))) return no_memory();
     panelhi_ = phi;
   }
-  if (!gund_cont_) {
-    if (alloc(&undecided_, N_) || alloc(&und_thr_, N_) || alloc(&gund_cont_, wide_cont_words(N_))) {
-      gund_cont_ = nullptr;
+  if (!wide_cont_) {
+    if (alloc(&undecided_, N_) || alloc(&und_thr_, N_) || alloc(&wide_cont_, wide_cont_words(N_))) {
+      wide_cont_ = nullptr;
       return no_memory();
     }
   }
-  if (!xg16_) {
+  if (!wide_rows16_) {
     uint16_t *xg = nullptr;
-    if (alloc(&xg, (size_t)N_ * DG) || alloc(&xgmeta_, (size_t)N_ * 4)) return no_memory();
-    xg16_ = xg;
+    if (alloc(&xg, (size_t)N_ * DG) || alloc(&wide_meta_, (size_t)N_ * 4)) return no_memory();
+    wide_rows16_ = xg;
   }
   span_begin(0);
   // hi halves of the centred centroids (+ their residual maximum, stats[5])
@@ -707,16 +707,16 @@ int Engine::lloyd_assign_gemm(const LloydArgs &a0, const float *centroids) {
   // being valid), otherwise rebuilt for this pass's mean
   if (!(row_cache_on_ && row_cache_valid_)) {
     const void *rows = half_rows_ ? half_rows_ : (const void *)a.samples;
-    KMX_HIP(launch_row_halves(rows, half_rows_ != nullptr, N_, D_, DG, mu_, xg16_, xgmeta_, stream_), kRuntimeError);
+    KMX_HIP(launch_row_halves(rows, half_rows_ != nullptr, N_, D_, DG, mu_, wide_rows16_, wide_meta_, stream_), kRuntimeError);
     if (row_cache_on_) {
       row_cache_valid_ = true;
       mu_frozen_ = true;
     }
   }
   span_begin(3);   // the dominant kernels on their own, inside the filter span
-  KMX_HIP(launch_lloyd_wide(a, xg16_, xgmeta_, DG, panelhi_, undecided_, und_thr_, gund_cont_, stream_), kRuntimeError);
+  KMX_HIP(launch_lloyd_wide(a, wide_rows16_, wide_meta_, DG, panelhi_, undecided_, und_thr_, wide_cont_, stream_), kRuntimeError);
   span_end();
-  KMX_HIP(launch_wide_contenders(metric_, a, centroids, DG, undecided_, gund_cont_, stream_), kRuntimeError);
+  KMX_HIP(launch_wide_contenders(metric_, a, centroids, DG, undecided_, wide_cont_, stream_), kRuntimeError);
   span_end();
   span_begin(1);
   if (settle_ && lloyd_settle_supported(a, centroids)) {

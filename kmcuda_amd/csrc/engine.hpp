@@ -161,15 +161,15 @@ class Engine {
   // 1: f32 matrix-core filter (KMCUDA_AMD_FILTER=f32; cross-check)
   int filter_mode_ = 0;
   bool settle_ = true;   // KMCUDA_AMD_SETTLE=0: lloyd_pair + lloyd_exact instead of the one-launch lloyd_settle
-  // D beyond the register-resident filters (lloyd_wide.hip): both operands streamed through LDS.  gemm_dp_ = D rounded
+  // D beyond the register-resident filters (lloyd_wide.hip): both operands streamed through LDS.  wide_dp_ = D rounded
   // up to 64 (0: not this path); KMCUDA_AMD_WIDE=0 leaves such shapes to the exact kernels (the cross-check)
-  uint32_t gemm_dp_ = 0;
-  bool gemm_ok_ = true;
-  bool gemm_failed_ = false;   // its buffers could not be allocated: the exact kernels serve the shape
-  void *xg16_ = nullptr;          // N x gemm_dp_ halves: x - mu, row-major (this path's row cache)
-  float *xgmeta_ = nullptr;       // 4 floats per row
-  uint32_t *gund_cont_ = nullptr; // per listed row: the number of its contenders, then up to 16 of them
-  int lloyd_assign_gemm(const LloydArgs &a, const float *centroids);
+  uint32_t wide_dp_ = 0;
+  bool wide_ok_ = true;
+  bool wide_failed_ = false;   // its buffers could not be allocated: the exact kernels serve the shape
+  void *wide_rows16_ = nullptr;          // N x wide_dp_ halves: x - mu, row-major (this path's row cache)
+  float *wide_meta_ = nullptr;       // 4 floats per row
+  uint32_t *wide_cont_ = nullptr; // per listed row: the number of its contenders, then up to 16 of them
+  int lloyd_assign_wide(const LloydArgs &a, const float *centroids);
   // row cache of the coarse filter stage (lloyd_f16.hip: row_cache_kernel); set_row_cache()
   bool row_cache_allowed_ = true;   // KMCUDA_AMD_ROW_CACHE=0 vetoes it
   bool row_cache_on_ = false, row_cache_valid_ = false, mu_frozen_ = false;

@@ -2029,7 +2029,7 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
     // Default: the same hand-over point, then assignment passes that carry per-sample bounds (SwitchRule above).
     // The strict parity modes keep the reference's schedule.
     const char *yym = getenv("KMCUDA_AMD_YY");
-    const bool wide = job.shards[0]->eng->DP_ == 0 && job.shards[0]->eng->gemm_dp_ != 0;   // D > 512: lloyd_gemm.hip
+    const bool wide = job.shards[0]->eng->DP_ == 0 && job.shards[0]->eng->wide_dp_ != 0;   // D > 512: lloyd_wide.hip
     // (KMCUDA_AMD_YY=carry: the default schedule also under the strict update -- every pass is the reference's Lloyd
     //  arithmetic, so the whole call then equals the reference's kmeans_cuda_lloyd bit for bit: the parity test of the
     //  carried bounds against the oracle end to end, tests/test_gpu_carry.py)

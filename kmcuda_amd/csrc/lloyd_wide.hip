@@ -31,7 +31,7 @@
 
 namespace kmx {
 
-constexpr int kGemmCap = 16;       // contenders kept per row
+constexpr int kWideCap = 16;       // contenders kept per row
 
 // x' = x - mu as halves (DG per row, zero padded) + the row's record
 template <bool HALF_ROWS>
@@ -83,8 +83,8 @@ constexpr int kWideTileB = 256 * kWideRowB;         // one operand tile: 32 KB
 constexpr int kWideOffA = 0, kWideOffB = 2 * kWideTileB, kWideOffBias = 4 * kWideTileB;
 constexpr int kWideOffMerge = kWideOffBias + 1024;  // 4 x 64 rows x (v1, v2, i1)
 constexpr int kWideOffCnt = kWideOffMerge + 4 * 64 * 12;
-constexpr int kWideOffCont = kWideOffCnt + 1024;    // MODE 1: 256 rows x kGemmCap contenders
-constexpr size_t kWideLds0 = kWideOffCnt, kWideLds1 = kWideOffCont + 256 * kGemmCap * 4;
+constexpr int kWideOffCont = kWideOffCnt + 1024;    // MODE 1: 256 rows x kWideCap contenders
+constexpr size_t kWideLds0 = kWideOffCnt, kWideLds1 = kWideOffCont + 256 * kWideCap * 4;
 
 template <int OFF>
 __device__ __forceinline__ f16x8 lds_frag_issue_at(uint32_t addr) {
@@ -98,7 +98,7 @@ __device__ __forceinline__ void lds_frag_wait6(f16x8 &a0, f16x8 &a1, f16x8 &a2, 
 }
 
 // MODE 0: every row; commits the rows the bound decides, lists the others (undecided / und_thr, counters[4]).
-// MODE 1: the listed rows; writes their contenders (und_cont: kGemmCap + 1 words per listed row: the count, the ids).
+// MODE 1: the listed rows; writes their contenders (und_cont: kWideCap + 1 words per listed row: the count, the ids).
 template <int MODE>
 __global__ __launch_bounds__(512) void lloyd_wide_kernel(
     const _Float16 *__restrict__ xg, const float4 *__restrict__ meta, uint32_t N, uint32_t DG,
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(512) void lloyd_wide_kernel(
               if (acc[s][t][r] >= cutv[s]) {
                 const uint32_t c = gt * 32u + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * h);
                 const uint32_t at = atomicAdd(&cnt[rl], 1u);
-                if (at < (uint32_t)kGemmCap) cont[rl * kGemmCap + at] = c;
+                if (at < (uint32_t)kWideCap) cont[rl * kWideCap + at] = c;
               }
             }
           }
@@ -320,9 +320,9 @@ __global__ __launch_bounds__(512) void lloyd_wide_kernel(
       const uint32_t p = blk * kWideRows + (uint32_t)tid;
       if (p < total) {
         const uint32_t n = cnt[tid];
-        uint32_t *out = und_cont + (size_t)p * (kGemmCap + 1);
+        uint32_t *out = und_cont + (size_t)p * (kWideCap + 1);
         out[0] = n;
-        for (uint32_t i = 0; i < n && i < (uint32_t)kGemmCap; i++) out[1 + i] = cont[(uint32_t)tid * kGemmCap + i];
+        for (uint32_t i = 0; i < n && i < (uint32_t)kWideCap; i++) out[1 + i] = cont[(uint32_t)tid * kWideCap + i];
       }
     }
     return;
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(512) void lloyd_wide_kernel(
 // whose best three are still within the f32 bound is settled HERE with the reference's exact chains over its
 // contenders only -- every other centroid is already ruled out by the cut-off -- one chain per lane (lanes beyond
 // the row's contenders idle: such rows are rare, and the alternative is a full scan of all K).  Only rows without a
-// usable list (more than kGemmCap contenders, operands out of the half range, NaN scores) go to the full scan.
+// usable list (more than kWideCap contenders, operands out of the half range, NaN scores) go to the full scan.
 template <int METRIC, bool FAST>
 __global__ __launch_bounds__(256, 4) void wide_contenders_kernel(
     const float *__restrict__ samples, uint32_t D, uint32_t DG, uint32_t K, const float *__restrict__ centroids,
@@ -477,14 +477,14 @@ __global__ __launch_bounds__(256, 4) void wide_contenders_kernel(
     const bool live = true;
     const size_t slot = p;
     const uint32_t s = und_rows[slot];
-    const uint32_t n = live ? und_cont[slot * (kGemmCap + 1)] : 0u;
-    const bool usable = n >= 1 && n <= (uint32_t)kGemmCap;
-    uint32_t cid[kGemmCap];
+    const uint32_t n = live ? und_cont[slot * (kWideCap + 1)] : 0u;
+    const bool usable = n >= 1 && n <= (uint32_t)kWideCap;
+    uint32_t cid[kWideCap];
 #pragma unroll
-    for (int i = 0; i < kGemmCap; i++) cid[i] = (usable && (uint32_t)i < n) ? und_cont[slot * (kGemmCap + 1) + 1 + i] : 0u;
-    float acc[kGemmCap];
+    for (int i = 0; i < kWideCap; i++) cid[i] = (usable && (uint32_t)i < n) ? und_cont[slot * (kWideCap + 1) + 1 + i] : 0u;
+    float acc[kWideCap];
 #pragma unroll
-    for (int i = 0; i < kGemmCap; i++) acc[i] = 0.f;
+    for (int i = 0; i < kWideCap; i++) acc[i] = 0.f;
     float xn2 = 0.f, xo2 = 0.f, x0 = 0.f;
     const float *xr = samples + (size_t)s * D;
     // two 256-feature slices per trip, both slices' loads in flight before the first product: the stage is a chain
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256, 4) void wide_contenders_kernel(
         if (f == 0) x0 = x4[0];
       }
 #pragma unroll
-      for (int i = 0; i < kGemmCap; i++) {
+      for (int i = 0; i < kWideCap; i++) {
         if ((uint32_t)i < n && usable) {   // wave-uniform
           const float *cr = cfil + (size_t)cid[i] * DG + f0;
           const f32x4 ca = *reinterpret_cast<const f32x4 *>(cr);
@@ -535,13 +535,13 @@ __global__ __launch_bounds__(256, 4) void wide_contenders_kernel(
       xn2 += __shfl_xor(xn2, off);
       xo2 += __shfl_xor(xo2, off);
 #pragma unroll
-      for (int i = 0; i < kGemmCap; i++) acc[i] += __shfl_xor(acc[i], off);
+      for (int i = 0; i < kWideCap; i++) acc[i] += __shfl_xor(acc[i], off);
     }
     x0 = __shfl(x0, 0);
     float v1 = -INFINITY, v2 = -INFINITY, v3 = -INFINITY;
     uint32_t i1 = 0xFFFFFFFFu, i2 = 0xFFFFFFFFu;
 #pragma unroll
-    for (int i = 0; i < kGemmCap; i++) {
+    for (int i = 0; i < kWideCap; i++) {
       if (usable && (uint32_t)i < n) {
         const uint32_t c = cid[i];
         const float v = acc[i] + bias[c];
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256, 4) void wide_contenders_kernel(
     if (multi) {   // wave-uniform
       uint32_t mine = 0;
 #pragma unroll
-      for (int i = 0; i < kGemmCap; i++) mine = ((int)lane == i) ? cid[i] : mine;
+      for (int i = 0; i < kWideCap; i++) mine = ((int)lane == i) ? cid[i] : mine;
       const bool on = lane < n;
       const float *cr = centroids + (size_t)(on ? mine : 0) * D;
       const float *xs = samples + (size_t)__builtin_amdgcn_readfirstlane(s) * D;   // wave-uniform: scalar loads
@@ -623,7 +623,7 @@ hipError_t launch_row_halves(const void *rows, bool half_rows, uint32_t N, uint3
   return hipGetLastError();
 }
 
-size_t wide_cont_words(uint32_t N) { return (size_t)N * (kGemmCap + 1); }
+size_t wide_cont_words(uint32_t N) { return (size_t)N * (kWideCap + 1); }
 
 // stage 1 over every row, then over the rows it listed (their contenders); DG: a multiple of 64
 hipError_t launch_lloyd_wide(const LloydArgs &a, const void *xg, const float *meta, uint32_t DG, const void *panelhi,
