@@ -140,7 +140,21 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   N_ = n_rows; D_ = D; K_ = K; metric_ = metric; fp16x2_ = fp16x2;
   K_pad_ = (K + 31) / 32 * 32;
   Kt_ = (K + 63) / 64 * 64;
-  DP_ = lloyd_dp_for(D);   // > 256: only the two-stage f16 Lloyd filter is instantiated that wide
+  DP_ = reg_dp_ = lloyd_dp_for(D);   // 0 beyond 512 features: no register-resident instantiation
+  // 257..512 features: the register-resident filter exists (one operand set per wave, rows padded to 512) but the
+  // LDS-streamed one of lloyd_wide.hip (rows padded to 64) is 14-33 % faster per pass (4M rows @ 1024: 512 features
+  // 7.52 -> 6.49 ms, 384 6.95 -> 4.96, 320 5.88 -> 3.96; at <= 256 features the register-resident one wins, 2.20
+  // against 3.17 ms: profiles/r5s_*, r5t_*).  Only the register-resident filter carries bounds between passes: such an
+  // engine has both, plain passes streamed, carried ones not (select_filter).  KMCUDA_AMD_WIDE_MIN_D=d moves the
+  // border: rows of at least d features are streamed (513: the register-resident filter alone up to 512 features).
+  long wide_min_d = 257;
+  if (const char *c = getenv("KMCUDA_AMD_WIDE_MIN_D")) {
+    const long d = atol(c);
+    if (d > 0) wide_min_d = d;
+  }
+  const bool streamed = wide_ok_ && (long)D >= wide_min_d;
+  if (streamed) DP_ = 0;
+  if (streamed && reg_dp_ <= 256) reg_dp_ = 0;   // (a measurement aid below 257 features: the streamed filter alone)
   // Filter error bound coefficient (DESIGN.md "error bound"): gamma_D + (kappa + 3) u with
   // u = 2^-24, gamma_D <= 1.01 D u, kappa = 8 for the reference's Kahan chain; +2% margin.
   eps_ = (float)(1.02 * ((double)D + 12.0) * ldexp(1.0, -24));
@@ -151,7 +165,17 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   // no register-resident filter for this D: stage 1 streams both operands through LDS (lloyd_wide.hip), in 64-feature
   // chunks: operands padded to 64
   wide_dp_ = (DP_ == 0 && wide_ok_) ? (D + 63) / 64 * 64 : 0;
-  const uint32_t dp = DP_ ? DP_ : (wide_dp_ ? wide_dp_ : 8);
+  if (wide_dp_ == 0) reg_dp_ = DP_;
+  // (both filters: the streamed pass is ~0.35 + DG / 1024 of a register-resident one -- the measurements above --, so a
+  //  list beyond that share of the rows, less a margin for the skip kernel, is not worth a carried pass; and every
+  //  attempt costs two of the slower passes: one such list is enough, the pauses start at 8 passes)
+  if (both_filters()) {
+    carry_policy_.hopeless_share = 0.30f + (float)wide_dp_ / 1024.f;
+    carry_policy_.hopeless_needed = 1;
+    carry_policy_.backoff = carry_policy_.first_backoff = 8;
+  }
+  dp_alloc_ = reg_dp_ > wide_dp_ ? reg_dp_ : (wide_dp_ ? wide_dp_ : 8);
+  const uint32_t dp = dp_alloc_;
   int rc;
   if ((rc = alloc(&csqr_, K))) return rc;
   if ((rc = alloc(&bias_, K_pad_))) return rc;
@@ -161,6 +185,7 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if ((rc = alloc(&stats_base_, 16))) return rc;
   stats_ = stats_base_;
   if ((rc = alloc(&mu_, dp))) return rc;
+  KMX_HIP(hipMemsetAsync(mu_, 0, dp * sizeof(float), stream_), kRuntimeError);   // (zero beyond D whichever filter froze it)
   if ((rc = alloc(&finite_, Kt_))) return rc;
   if ((rc = alloc(&flagged_, n_rows))) return rc;
   if ((rc = alloc(&pairs_, 3 * (size_t)n_rows))) return rc;
@@ -231,6 +256,16 @@ void Engine::profile_reset() {
   profile_collect();
   filter_ms_ = exact_ms_ = update_ms_ = coarse_ms_ = 0;
   filter_launches_ = 0;
+}
+
+// An engine with both filters (engine.hpp: both_filters): which one the next passes run.  The row copies of both stay
+// valid (same frozen mean); a preparation done for the other one and any carried bounds do not.
+void Engine::select_filter(bool streamed) {
+  if (!both_filters() || (DP_ == 0) == streamed) return;
+  DP_ = streamed ? 0 : reg_dp_;
+  std::swap(row_cache_valid_, other_cache_valid_);
+  prepared_for_ = nullptr;
+  carry_valid_ = false;
 }
 
 int Engine::prepare_centroids(const float *centroids) {
@@ -443,6 +478,15 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   // carried bounds describe the assignments of the LAST pass: whatever this pass turns out to be, they hold afterwards
   // only if it was a carried pass itself (set at its end) -- an exact pass, the f32 filter, a rebuilt panel void them
+  if (both_filters() && !exact_only && !strict_h2_) {
+    // plain passes -- no bounds asked for, or a pause of the carry policy -- are the streamed filter's
+    bool streamed = !wide_failed_;   // (no memory for the streamed filter's buffers: the other one serves every pass)
+    if (streamed && carry_on_ && filter_mode_ == 0) {
+      if (carry_policy_.pause) carry_policy_.pause--;
+      else streamed = false;
+    }
+    select_filter(streamed);
+  }
   const bool carry_was_valid = carry_valid_;
   carry_valid_ = false;
   if (strict_h2_) {
@@ -463,7 +507,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   const bool two_stage = !exact_only && DP_ != 0 && filter_mode_ == 0 && lloyd_filter_f16_supported(D_, DP_);
   const bool want_cache = row_cache_on_ && two_stage && N_ != 0;
   const bool build_cache = want_cache && !row_cache_valid_;
-  if (build_cache) mu_frozen_ = false;  // take the mean of THESE centroids
+  if (build_cache && !other_cache_valid_) mu_frozen_ = false;  // take the mean of THESE centroids
   if (!side_stream_) {
     // (non-blocking even beside a blocking main stream: fork / join events order it completely)
     side_stream_ = pooled_stream_acquire(device_);
@@ -476,10 +520,9 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   }
   if (two_stage && !panelhi_) {
     uint16_t *phi = nullptr;
-    int rc = alloc(&phi, (size_t)((K_pad_ + 63u) / 64u * 64u) * (DP_ + 2));  // whole 64-row super-tiles + their biases
+    int rc = alloc(&phi, (size_t)((K_pad_ + 63u) / 64u * 64u) * (dp_alloc_ + 2));  // whole 64-row super-tiles + their biases
     if (rc) return rc;
-    if ((rc = alloc(&undecided_, N_))) return rc;
-    if ((rc = alloc(&und_thr_, N_))) return rc;
+    if (!undecided_ && ((rc = alloc(&undecided_, N_)) || (rc = alloc(&und_thr_, N_)))) return rc;
     panelhi_ = phi;
   }
   // Steady state of the two-stage filter (mean frozen, cache valid): ONE preparation kernel in front of
@@ -679,17 +722,17 @@ int Engine::lloyd_assign_wide(const LloydArgs &a0, const float *centroids) {
   // rows fit but whose copies do not runs on the exact kernels, as it did before this path existed
   auto no_memory = [&]() {
     (void)hipGetLastError();
-    if (g_verbosity > 0) printf("rows wider than 512 features: no memory for the matrix-core filter's buffers -- exact kernels\n");
+    if (g_verbosity > 0) printf("rows wider than 256 features: no memory for the streamed filter's buffers -- exact kernels\n");
     wide_failed_ = true;   // (wide_dp_ stays: the preparation's buffers are sized by it)
     return kNoFilter;
   };
   if (!panelhi_) {
     uint16_t *phi = nullptr;
-    if (alloc(&phi, (size_t)k_pad64 * (DG + 2))) return no_memory();
+    if (alloc(&phi, (size_t)k_pad64 * (dp_alloc_ + 2))) return no_memory();
     panelhi_ = phi;
   }
   if (!wide_cont_) {
-    if (alloc(&undecided_, N_) || alloc(&und_thr_, N_) || alloc(&wide_cont_, wide_cont_words(N_))) {
+    if ((!undecided_ && (alloc(&undecided_, N_) || alloc(&und_thr_, N_))) || alloc(&wide_cont_, wide_cont_words(N_))) {
       wide_cont_ = nullptr;
       return no_memory();
     }
@@ -1043,12 +1086,12 @@ int kmamd_set_filter(kmamd_engine *e, int mode) {
 int kmamd_set_half_rows(kmamd_engine *e, const void *rows16) {
   e->e.half_rows_ = rows16;
   e->e.prepared_for_ = nullptr;
-  e->e.row_cache_valid_ = false;  // a cache built from other rows is stale
+  e->e.drop_row_copies();  // a cache built from other rows is stale
   return kmx::kSuccess;
 }
 int kmamd_set_row_cache(kmamd_engine *e, int on) {
   e->e.row_cache_on_ = on != 0 && e->e.row_cache_allowed_;
-  e->e.row_cache_valid_ = false;  // (re)built by the next kmamd_lloyd_assign
+  e->e.drop_row_copies();  // (re)built by the next kmamd_lloyd_assign
   e->e.prepared_for_ = nullptr;
   if (!e->e.row_cache_on_) e->e.mu_frozen_ = false;
   return kmx::kSuccess;
@@ -1075,6 +1118,12 @@ int kmamd_yy_filters(kmamd_engine *e, const float *samples, const float *centroi
                      const float *gdrifts, uint32_t *assignments, uint32_t *assignments_prev, float *bounds,
                      uint32_t *passed) {
   return e->e.yy_filters(samples, centroids, drifts, gdrifts, assignments, assignments_prev, bounds, passed);
+}
+int kmamd_filter_kind(kmamd_engine *e, uint32_t *padded_width) {
+  const kmx::Engine &g = e->e;
+  const bool streamed = g.DP_ == 0 && g.wide_dp_ != 0 && !g.wide_failed_;
+  if (padded_width) *padded_width = g.DP_ ? g.DP_ : (streamed ? g.wide_dp_ : 0);
+  return g.DP_ ? 1 : (streamed ? 2 : 0);
 }
 int kmamd_profile_enable(kmamd_engine *e, int on) {
   e->e.profile_collect();

@@ -44,6 +44,10 @@ struct CarryPolicy {
   // rows the bounds cannot decide (unstructured data): after two COUNTED lists in a row beyond 90 % of the rows the
   // passes go plain for `backoff` iterations (4, doubling up to 32), then the bounds are tried again
   uint32_t pause = 0, backoff = 4, hopeless = 0, seen_seq = 0;
+  // (an engine whose plain passes have a faster filter than the carried ones -- 257..512 features -- gives up earlier:
+  //  Engine::init)
+  float hopeless_share = 0.9f;
+  uint32_t hopeless_needed = 2, first_backoff = 4;
   static constexpr uint32_t kNoList = 0xFFFFFFFFu;   // the report of a pass that had no list to count
 
   // A pass is about to run with carrying switched on: true = it runs plain (one pass of a pause is used up).
@@ -60,8 +64,8 @@ struct CarryPolicy {
     const bool listed = last != kNoList && (float)last <= list_max * (float)n_rows;
     if (last != kNoList && (int32_t)(last_seq - seen_seq) > 0) {
       seen_seq = last_seq;
-      if ((float)last > 0.9f * (float)n_rows && list_max < 1.0f) {
-        if (++hopeless >= 2) {
+      if ((float)last > hopeless_share * (float)n_rows && list_max < 1.0f) {
+        if (++hopeless >= hopeless_needed) {
           pause = backoff;
           backoff = backoff < 32 ? 2 * backoff : 32;
           hopeless = 0;
@@ -69,7 +73,7 @@ struct CarryPolicy {
         }
       } else {
         hopeless = 0;
-        backoff = 4;
+        backoff = first_backoff;
       }
     }
     return listed;
@@ -164,6 +168,14 @@ class Engine {
   // D beyond the register-resident filters (lloyd_wide.hip): both operands streamed through LDS.  wide_dp_ = D rounded
   // up to 64 (0: not this path); KMCUDA_AMD_WIDE=0 leaves such shapes to the exact kernels (the cross-check)
   uint32_t wide_dp_ = 0;
+  // 257..512 features have BOTH filters: plain passes take the streamed one (faster there), carried passes the
+  // register-resident one (reg_dp_ = 512: the only one that leaves / reads bounds).  DP_ says which is selected (0:
+  // streamed); each keeps its own row copy over the same frozen mean (other_cache_valid_: the unselected one's).
+  uint32_t reg_dp_ = 0, dp_alloc_ = 0;
+  bool other_cache_valid_ = false;
+  bool both_filters() const { return reg_dp_ != 0 && wide_dp_ != 0; }
+  void select_filter(bool streamed);
+  void drop_row_copies() { row_cache_valid_ = other_cache_valid_ = false; }
   bool wide_ok_ = true;
   bool wide_failed_ = false;   // its buffers could not be allocated: the exact kernels serve the shape
   void *wide_rows16_ = nullptr;          // N x wide_dp_ halves: x - mu, row-major (this path's row cache)

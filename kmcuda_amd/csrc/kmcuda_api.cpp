@@ -1220,7 +1220,7 @@ class Job {
     for (auto &s : shards) {
       if (after == 0) {
         s->eng->row_cache_on_ = s->eng->row_cache_allowed_;
-        s->eng->row_cache_valid_ = false;
+        s->eng->drop_row_copies();
       }
       RETERR(s->eng->stop_clear());
     }
@@ -2029,7 +2029,7 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
     // Default: the same hand-over point, then assignment passes that carry per-sample bounds (SwitchRule above).
     // The strict parity modes keep the reference's schedule.
     const char *yym = getenv("KMCUDA_AMD_YY");
-    const bool wide = job.shards[0]->eng->DP_ == 0 && job.shards[0]->eng->wide_dp_ != 0;   // D > 512: lloyd_wide.hip
+    const bool wide = job.shards[0]->eng->DP_ == 0 && job.shards[0]->eng->wide_dp_ != 0;   // D > 256: lloyd_wide.hip
     // (KMCUDA_AMD_YY=carry: the default schedule also under the strict update -- every pass is the reference's Lloyd
     //  arithmetic, so the whole call then equals the reference's kmeans_cuda_lloyd bit for bit: the parity test of the
     //  carried bounds against the oracle end to end, tests/test_gpu_carry.py)
@@ -2060,7 +2060,8 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
       bool bounds = !adaptive;
       if (adaptive) {
         const char *cv = getenv("KMCUDA_AMD_CARRY");
-        const bool carry = !(cv && atoi(cv) == 0) && !wide;
+        // (rows of 257..512 features: streamed plain passes, register-resident carried ones -- engine.hpp: both_filters)
+        const bool carry = !(cv && atoi(cv) == 0) && (!wide || job.shards[0]->eng->both_filters());
         // The first carried pass only LEAVES bounds (and allocates them: 24 bytes per row); rows are spared from the
         // second one on.  A run that stops within a pass or two of the hand-over point never earns that back (round 4:
         // the 4M-row mixture at tolerance 0.01, one iteration after the hand-over, +12-16 %), and how long a run will

@@ -57,6 +57,7 @@ def _run_pair(x, k, iters, carry_from, fused, half=False, seed=5, monkeypatch=No
         os.environ["KMCUDA_AMD_CARRY_MAX"] = str(list_max)
     try:
         log = []
+        _run_pair.kinds = []
         for it in range(iters):
             if it == carry_from:
                 carry.b.engine.set_carry(True)
@@ -92,6 +93,7 @@ def _run_pair(x, k, iters, carry_from, fused, half=False, seed=5, monkeypatch=No
                 assert (a1u != ref).mean() < 2e-3, "iteration %d: %.4f of the assignments differ from the oracle's" % (
                     it, (a1u != ref).mean())
             log.append(int((a0 != p0).sum()))
+            _run_pair.kinds.append(carry.b.engine.filter_kind())
         spared, last = carry.b.engine.carry_stats()
         _run_pair.paired = carry.b.engine.carry_pair_stats()
         return log, spared, last
@@ -104,8 +106,10 @@ def _run_pair(x, k, iters, carry_from, fused, half=False, seed=5, monkeypatch=No
 @pytest.mark.parametrize("shape", [(60000, 64, 64), (50000, 256, 200), (30000, 24, 40), (40000, 100, 33),
                                    (30000, 512, 48), (20000, 300, 24), (25000, 12, 12)],
                          ids=lambda s: "%dx%d@%d" % s)
-def test_carried_passes_equal_plain_passes_on_clustered_rows(shape, fused):
+def test_carried_passes_equal_plain_passes_on_clustered_rows(shape, fused, monkeypatch):
     n, d, k = shape
+    # (257..512 features: plain passes take the streamed filter, the carried ones change to the register-resident one
+    #  -- the engine keeps both row copies over one frozen mean, engine.hpp: both_filters; log of kinds below)
     # half as many blobs as centroids: most blobs are shared by two centroids, whose rows the bounds rarely decide;
     # as many blobs as centroids (the first shape): most rows are decided by their bounds from the first carried pass on
     x = _blobs(n, d, k if n == 60000 else max(8, k // 2), seed=n + d, spread=10.0 if n == 60000 else 6.0)
@@ -114,6 +118,8 @@ def test_carried_passes_equal_plain_passes_on_clustered_rows(shape, fused):
     padded = d in (300, 12)
     log, spared, last = _run_pair(x, k, iters=14, carry_from=3, fused=fused, list_max=1.0 if padded else None)
     assert spared > 0, (log, spared, last)
+    if 256 < d <= 512:
+        assert _run_pair.kinds[:3] == [(2, (d + 63) // 64 * 64)] * 3 and _run_pair.kinds[-1] == (1, 512), _run_pair.kinds
     if n == 60000:
         assert spared > 3 * n and last < n // 2, (log, spared, last)
 
@@ -175,6 +181,19 @@ def test_carried_passes_equal_plain_passes_on_unstructured_rows(list_max):
     x = _uniform(60000, 256, seed=3)
     log, spared, last = _run_pair(x, 300, iters=9, carry_from=2, fused=True, list_max=list_max)
     assert last > 0
+
+
+def test_unstructured_rows_of_384_features_go_back_to_the_streamed_filter_while_the_bounds_pause():
+    """257..512 features: a carried pass costs more than a plain one there (the register-resident filter against the
+    streamed one), so lists beyond ~2/3 of the rows pause the bounds, the pause's passes are streamed ones, then the
+    bounds are tried again -- same states as plain passes throughout (and the oracle's, _run_pair)."""
+    x = _uniform(30000, 384, seed=8)
+    log, spared, last = _run_pair(x, 200, iters=19, carry_from=2, fused=True)
+    kinds = [k[0] for k in _run_pair.kinds]
+    assert kinds[:2] == [2, 2] and kinds[2] == 1, kinds
+    assert 2 in kinds[3:], kinds              # a pause ...
+    first_pause = 3 + kinds[3:].index(2)
+    assert 1 in kinds[first_pause:], kinds    # ... and the next attempt behind it
 
 
 def test_carried_passes_with_nan_rows_dead_clusters_and_halves():

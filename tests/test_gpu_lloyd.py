@@ -30,6 +30,7 @@ def _assign(x, c, metric="L2", exact=False, asg0=None, filt="f16"):
     asg = torch.from_numpy(init.view(numpy.int32).copy()).to(dev)
     prev = torch.full((n,), -1, dtype=torch.int32, device=dev)
     eng = Engine(n, d, k, metric, device=0)
+    _assign.kind = eng.filter_kind()
     eng.set_filter(filt)
     eng.lloyd_assign(xs, cs, asg, prev, exact=exact)
     counters = eng.counters()
@@ -52,6 +53,21 @@ def test_assign_bit_exact(n, d, k, mode):
     assert (got == ref).all()
     assert (prev == ref_prev).all()
     assert counters[0] == ref_changed
+
+
+@pytest.mark.parametrize("n,d,k", [(777, 300, 40), (3000, 384, 500), (2500, 512, 1024)])
+def test_assign_bit_exact_register_resident_filter_at_its_widest(n, d, k, monkeypatch):
+    """257..512 features take the LDS-streamed filter by default (tests/test_gpu_wide.py); the register-resident
+    filter's one-operand-set instantiation for these widths stays reachable (KMCUDA_AMD_WIDE_MIN_D=513: carried bounds
+    at these widths) and stays exact."""
+    monkeypatch.setenv("KMCUDA_AMD_WIDE_MIN_D", "513")
+    rs = numpy.random.RandomState(n + d + k)
+    x = rs.rand(n, d).astype(numpy.float32)
+    c = x[rs.choice(n, k, replace=False)].copy()
+    got, prev, counters = _assign(x, c)
+    assert _assign.kind == (1, 512)
+    ref, ref_prev, ref_changed = oracle.lloyd_assign(x, c)
+    assert (got == ref).all() and (prev == ref_prev).all() and counters[0] == ref_changed
 
 
 @pytest.mark.parametrize("filt", ["f16", "f32"])

@@ -43,7 +43,9 @@ def _run_passes(x, cs, cached, rebuild_at=None):
 
 @pytest.mark.parametrize("n,d,k", [(5000, 256, 1024), (3001, 64, 100), (2000, 16, 33), (4100, 100, 257), (300, 256, 64),
                                    (2600, 512, 300), (1900, 300, 70)])
-def test_cached_passes_match_oracle(n, d, k):
+def test_cached_passes_match_oracle(n, d, k, monkeypatch):
+    if 256 < d <= 512:   # the register-resident filter's widest instantiation (the default there is the streamed
+        monkeypatch.setenv("KMCUDA_AMD_WIDE_MIN_D", "513")   # filter: tests/test_gpu_wide.py)
     rs = numpy.random.RandomState(n + k)
     x = rs.rand(n, d).astype(numpy.float32)
     c0 = x[rs.choice(n, k, replace=False)].copy()
@@ -140,9 +142,11 @@ def test_kmeans_cuda_iterations_unchanged_by_cache(monkeypatch):
 @pytest.mark.parametrize("n,d,k", [(1, 256, 1), (31, 256, 2), (33, 64, 3), (129, 512, 5), (257, 16, 2), (1000, 256, 1000),
                                    (65, 300, 65)])
 @pytest.mark.parametrize("cached", [False, True])
-def test_tiny_and_ragged_shapes(n, d, k, cached):
+def test_tiny_and_ragged_shapes(n, d, k, cached, monkeypatch):
     """row counts around the 32 / 64 / 128 / 256-row tiling steps, K around the 32 / 64-centroid tiles,
     K == N, a single row; with and without the row cache."""
+    if 256 < d <= 512:   # (the register-resident filter: see test_cached_passes_match_oracle)
+        monkeypatch.setenv("KMCUDA_AMD_WIDE_MIN_D", "513")
     rs = numpy.random.RandomState(n * 7 + d + k)
     x = rs.rand(n, d).astype(numpy.float32)
     c0 = x[rs.choice(n, k, replace=False)].copy()
