@@ -236,12 +236,15 @@ __global__ __launch_bounds__(512) void lloyd_wide_kernel(
           acc[1][t] = acc[0][t];
         }
       }
-      // the next chunk goes into the other buffer, piece by piece between the products below
-      const bool more = it + 1 < nit;
+      // The next chunk goes into the other buffer between the products below, and EARLY: the rows' four pieces behind
+      // the first k-step's products, the panel's behind the second's.  (Two pieces per k-step, the rows' last, left the
+      // late ones ~0.2 us to land before the wait at the top: 5.55 -> 5.03 ms for both sweeps at 2M x 1024 @ 1024,
+      // profiles/r5x_*.)  No branch inside the products -- with one, the compiler spills 140 registers once four
+      // pieces share a k-step: behind the last chunk the first one is staged once more, into the free buffer.
       uint32_t nkc = kc + 1;
       if (nkc == NC) {
         nkc = 0;
-        if (more) set_aoff(pass + 1);
+        set_aoff(it + 1 < nit ? pass + 1 : 0);
       }
       uint32_t fa = fbA + (uint32_t)buf * kWideTileB, fb = fbB + (uint32_t)buf * kWideTileB;
       asm volatile("" : "+v"(fa), "+v"(fb));
@@ -269,9 +272,9 @@ __global__ __launch_bounds__(512) void lloyd_wide_kernel(
         for (int t = 0; t < 4; t++) {
           acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][t], b[cur][0], acc[0][t], 0, 0, 0);
           acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][t], b[cur][1], acc[1][t], 0, 0, 0);
-          if (more && (t == 1 || t == 3)) {   // two pieces per k-step: A 0..3 in steps 0, 1; B 0..3 in steps 2, 3
-            const int piece = 2 * j + (t == 3 ? 1 : 0);
-            stage_piece(piece >= 4, piece & 3, nkc, buf ^ 1);
+          if (j < 2) {
+            stage_piece(j == 0, t, nkc, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
@@ -314,6 +317,7 @@ __global__ __launch_bounds__(512) void lloyd_wide_kernel(
     }
   }
 
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the spare pieces staged behind the last chunk)
   if (MODE == 1) {
     __syncthreads();
     if (tid < 256) {
