@@ -166,11 +166,9 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   // chunks: operands padded to 64
   wide_dp_ = (DP_ == 0 && wide_ok_) ? (D + 63) / 64 * 64 : 0;
   if (wide_dp_ == 0) reg_dp_ = DP_;
-  // (both filters: the streamed pass is ~0.35 + DG / 1024 of a register-resident one -- the measurements above --, so a
-  //  list beyond that share of the rows, less a margin for the skip kernel, is not worth a carried pass; and every
-  //  attempt costs two of the slower passes: one such list is enough, the pauses start at 8 passes)
+  // (both filters: every attempt of the bounds costs two of the slower passes and the second row copy: one counted
+  //  list beyond the listed passes' limit is enough to give up, the pauses start at 8 passes)
   if (both_filters()) {
-    carry_policy_.hopeless_share = 0.30f + (float)wide_dp_ / 1024.f;
     carry_policy_.hopeless_needed = 1;
     carry_policy_.backoff = carry_policy_.first_backoff = 8;
   }

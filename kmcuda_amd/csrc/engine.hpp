@@ -41,12 +41,13 @@ void pooled_stream_release(int device, hipStream_t s);
 // it on the CPU (tests/test_boundary_cpu.py).
 struct CarryPolicy {
   float list_max = 0.5f;   // a listed pass when at most this share of the rows is on the list (KMCUDA_AMD_CARRY_MAX)
-  // rows the bounds cannot decide (unstructured data): after two COUNTED lists in a row beyond 90 % of the rows the
-  // passes go plain for `backoff` iterations (4, doubling up to 32), then the bounds are tried again
+  // A counted list beyond that share makes the next pass a whole one too -- the skip kernel and the bounds' bookkeeping
+  // for nothing -- so two such counts in a row pause the bounds: `backoff` plain passes (4, doubling up to 32), then
+  // they are tried again.  (Round 4 only gave up beyond 90 %: config B's lists hover at 65-80 % from iteration 27 on and
+  // twenty whole passes paid 0.5 ms each for bounds that spared nothing, profiles/r5ac_carry_trace_config_b.log.)
   uint32_t pause = 0, backoff = 4, hopeless = 0, seen_seq = 0;
-  // (an engine whose plain passes have a faster filter than the carried ones -- 257..512 features -- gives up earlier:
-  //  Engine::init)
-  float hopeless_share = 0.9f;
+  // (an engine whose plain passes have a faster filter than the carried ones -- 257..512 features, Engine::init -- gives
+  //  up after one such count and pauses longer)
   uint32_t hopeless_needed = 2, first_backoff = 4;
   static constexpr uint32_t kNoList = 0xFFFFFFFFu;   // the report of a pass that had no list to count
 
@@ -64,7 +65,8 @@ struct CarryPolicy {
     const bool listed = last != kNoList && (float)last <= list_max * (float)n_rows;
     if (last != kNoList && (int32_t)(last_seq - seen_seq) > 0) {
       seen_seq = last_seq;
-      if ((float)last > hopeless_share * (float)n_rows && list_max < 1.0f) {
+      const float give_up = list_max > 0.f && list_max < 0.9f ? list_max : 0.9f;
+      if ((float)last > give_up * (float)n_rows && list_max < 1.0f) {
         if (++hopeless >= hopeless_needed) {
           pause = backoff;
           backoff = backoff < 32 ? 2 * backoff : 32;

@@ -169,12 +169,16 @@ def test_carried_bounds_host_policy_without_gpu():
     # clustered rows: short lists from the first count on -> listed as soon as a count has landed
     assert _policy([0, 100, 100, 100, 100, 100], lag=1) == [1, 2, 3, 3, 3, 3]
     assert _policy([0, 100, 100, 100, 100, 100], lag=2) == [1, 2, 2, 3, 3, 3]
-    # unstructured rows: two counted lists beyond 90 % -> four plain passes, a whole pass, counts again; twice hopeless
-    # again -> eight plain passes
+    # unstructured rows: two counted lists beyond the listed passes' limit (list_max: whole passes that gain nothing)
+    # -> four plain passes, a whole pass, counts again; twice hopeless again -> eight plain passes
     out = _policy([1000] * 30, lag=1)
     assert out[:4] == [1, 2, 2, 2]          # the third moved pass judges the second count: pause from the next pass on
     assert out[4:8] == [0, 0, 0, 0] and out[8] == 1
     assert out[9:12] == [2, 2, 2] and out[12:20] == [0] * 8 and out[20] == 1
+    # ... and lists of 70 % are no better than lists of 100 %: not one of those passes would be a listed one (round 5:
+    # config B's lists at 65-80 % of the rows kept twenty whole passes paying for bounds that spared nothing)
+    assert _policy([700] * 30, lag=1) == out
+    assert 0 not in _policy([450] * 30, lag=1)      # 45 % < list_max: listed passes, no pause
     # the bug of round 4: large drifts right after the hand-over point (two hopeless counts), then lists of 12 % -- the
     # reports from before the pause, and the "no list" report of the whole pass after it, must not start another pause
     lens = [0, 1000, 1000] + [120] * 20
