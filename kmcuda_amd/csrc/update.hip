@@ -532,10 +532,15 @@ __global__ __launch_bounds__(kSumThreads) void cluster_sums_kernel(SumArgs a) {
     __threadfence();
     const uint32_t ticket = atomicAdd(&a.res[2], 1u);
     if (ticket == gridDim.x - 1) {   // the last block: report to the host's pinned words, reset for the next update
-      volatile uint32_t *h = a.host;
-      h[0] = atomicAdd(&a.res[0], 0u);
-      h[1] = atomicAdd(&a.res[1], 0u);
-      h[2] = a.counters[4];
+      // (not from a pass behind the device-side stop: it touched nothing, and its zeros would size the NEXT run's
+      //  first update and stage 2 -- the default schedule's first pass behind the hand-over point ran stage 2 on a
+      //  64-block grid, 2.16 ms instead of 0.47 at 4M rows, profiles/r5af_*)
+      if (a.counters[kStopFlag] == 0u) {
+        volatile uint32_t *h = a.host;
+        h[0] = atomicAdd(&a.res[0], 0u);
+        h[1] = atomicAdd(&a.res[1], 0u);
+        h[2] = a.counters[4];
+      }
       a.res[0] = 0u; a.res[1] = 0u; a.res[2] = 0u; a.res[3] = 0u;
     }
   }
