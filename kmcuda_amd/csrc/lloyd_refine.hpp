@@ -439,7 +439,10 @@ static hipError_t launch_refine_dp_n(const LloydArgs &a, const void *rows, bool 
   // 2k long is not free: the grid follows the caller's estimate of the list (the kernel strides)
   uint32_t grid = (a.N + rows_per_block - 1) / rows_per_block;
   if (rows_hint != 0xFFFFFFFFu) {
-    const uint32_t want = rows_hint / rows_per_block + rows_hint / (4 * rows_per_block) + 64;
+    // (never less than one round of resident blocks, 2 per CU: a report that undercounts -- a pass that listed few rows
+    //  followed by one that lists many -- then costs strides of a full machine, not of 64 blocks)
+    uint32_t want = rows_hint / rows_per_block + rows_hint / (4 * rows_per_block) + 64;
+    if (want < 512u) want = 512u;
     if (want < grid) grid = want;
   }
   const bool fast = a.D == (uint32_t)DP;

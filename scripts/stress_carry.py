@@ -39,7 +39,7 @@ def main():
     trials = failures = 0
     while time.time() - t0 < budget:
         n = int(rs.choice([1500, 7000, 30000, 90000, 250000]))
-        d = int(rs.choice([12, 16, 24, 32, 48, 64, 100, 128, 200, 256, 300, 512]))
+        d = int(rs.choice([12, 16, 24, 32, 48, 64, 100, 128, 200, 256, 300, 320, 384, 448, 512]))   # (257..512: both filters)
         k = int(rs.choice([3, 17, 40, 64, 130, 300, 600]))
         k = min(k, n // 8)
         metric = str(rs.choice(["L2", "cos"]))
@@ -47,7 +47,7 @@ def main():
         fused = bool(rs.rand() < 0.5)
         list_max = [None, 0.0, 1.0, 0.2][rs.randint(0, 4)]
         grid = [None, 1, 7][rs.randint(0, 3)]
-        iters = int(rs.randint(5, 15))
+        iters = int(rs.randint(5, 15)) if rs.rand() < 0.7 else int(rs.randint(15, 26))   # (long ones: across a pause)
         carry_from = int(rs.randint(1, 4))
         kind, x = make(rs, n, d, k, metric)
         if grid is None:
@@ -59,7 +59,11 @@ def main():
             n, d, k, metric, "fp16" if half else "fp32", "fused" if fused else "plain-apply", kind, list_max, grid, iters, carry_from)
         try:
             log, spared, last = tc._run_pair(x, k, iters=iters, carry_from=carry_from, fused=fused, half=half,
-                                             seed=int(rs.randint(0, 1000)), list_max=list_max, metric=metric)
+                                             seed=int(rs.randint(0, 1000)), list_max=list_max, metric=metric,
+                                             # (angular against the oracle: libm's and ocml's acosf differ in the last
+                                             #  place, and half rows of 12..32 features tie in droves -- 0.4 % of the
+                                             #  rows in two of round 5's 367 trials; carried == plain is exact above)
+                                             cos_tol=1e-2)
             print("ok   %s: spared %d paired %d" % (desc, spared, tc._run_pair.paired), flush=True)
         except AssertionError as e:
             failures += 1

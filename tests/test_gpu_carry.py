@@ -31,7 +31,8 @@ def _uniform(n, d, seed):
     return numpy.random.RandomState(seed).rand(n, d).astype(numpy.float32)
 
 
-def _run_pair(x, k, iters, carry_from, fused, half=False, seed=5, monkeypatch=None, list_max=None, metric="L2"):
+def _run_pair(x, k, iters, carry_from, fused, half=False, seed=5, monkeypatch=None, list_max=None, metric="L2",
+              cos_tol=2e-3):
     """Two loops over the same rows and seeds, one carrying bounds from iteration `carry_from` on; yields per
     iteration (changed_plain, changed_carry) after asserting the states equal.  Returns the carry engine's stats."""
     from kmcuda_amd.distributed import HipBackend, ShardedLloyd
@@ -90,7 +91,7 @@ def _run_pair(x, k, iters, carry_from, fused, half=False, seed=5, monkeypatch=No
                 assert int((a1u != p1u).sum()) == ref_changed, (it, int((a1u != p1u).sum()), ref_changed)
                 assert carry.changed_last() == ref_changed, (it, carry.changed_last(), ref_changed)
             else:
-                assert (a1u != ref).mean() < 2e-3, "iteration %d: %.4f of the assignments differ from the oracle's" % (
+                assert (a1u != ref).mean() < cos_tol, "iteration %d: %.4f of the assignments differ from the oracle's" % (
                     it, (a1u != ref).mean())
             log.append(int((a0 != p0).sum()))
             _run_pair.kinds.append(carry.b.engine.filter_kind())
