@@ -189,10 +189,8 @@ int kmamd_transpose(kmamd_engine *e, const float *in, uint32_t rows, uint32_t co
 /* Which filter kmamd_lloyd_assign runs in front of the exact kernels for this engine's shape: 1 the register-resident
  * ones (features <= 256: lloyd.hip / lloyd_f16.hip), 2 the LDS-streamed one (features > 256: lloyd_wide.hip), 0 none
  * (the exact kernels alone: the streamed filter switched off or out of memory).  *padded_width: the feature count the
- * filter's operands are padded to (0 with no filter).  Only kind 1 carries bounds (kmamd_set_carry).  Rows of 257..512
- * features have both: the answer is the filter the LAST pass ran (plain passes -- kind 2, faster there --, carried
- * passes -- kind 1, padded to 512; a pause of the carry policy goes back to kind 2); beyond 512 features
- * kmamd_set_carry is accepted and every pass is a plain one. */
+ * filter's operands are padded to (0 with no filter).  Both kinds carry bounds (kmamd_set_carry; kind 2 up to 4096
+ * features and without pair certificates). */
 int kmamd_filter_kind(kmamd_engine *e, uint32_t *padded_width);
 
 /* Timing of the dominant kernel on the engine's own stream (HIP events): start/stop bracket

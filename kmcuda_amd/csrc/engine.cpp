@@ -140,21 +140,20 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   N_ = n_rows; D_ = D; K_ = K; metric_ = metric; fp16x2_ = fp16x2;
   K_pad_ = (K + 31) / 32 * 32;
   Kt_ = (K + 63) / 64 * 64;
-  DP_ = reg_dp_ = lloyd_dp_for(D);   // 0 beyond 512 features: no register-resident instantiation
+  DP_ = lloyd_dp_for(D);   // 0 beyond 512 features: no register-resident instantiation
   // 257..512 features: the register-resident filter exists (one operand set per wave, rows padded to 512) but the
-  // LDS-streamed one of lloyd_wide.hip (rows padded to 64) is 14-33 % faster per pass (4M rows @ 1024: 512 features
-  // 7.52 -> 6.49 ms, 384 6.95 -> 4.96, 320 5.88 -> 3.96; at <= 256 features the register-resident one wins, 2.20
-  // against 3.17 ms: profiles/r5s_*, r5t_*).  Only the register-resident filter carries bounds between passes: such an
-  // engine has both, plain passes streamed, carried ones not (select_filter).  KMCUDA_AMD_WIDE_MIN_D=d moves the
-  // border: rows of at least d features are streamed (513: the register-resident filter alone up to 512 features).
+  // LDS-streamed one of lloyd_wide.hip (rows padded to 64) is 14-33 % faster per plain pass (4M rows @ 1024: 512
+  // features 7.52 -> 6.49 ms, 384 6.95 -> 4.96, 320 5.88 -> 3.96; at <= 256 features the register-resident one wins,
+  // 2.20 against 3.17 ms: profiles/r5s_*, r5t_*) and carries bounds as well (whole calls on 2M-row mixtures at
+  // tolerance 1e-4: 384 features 0.041 s against 0.048 s with the bounds on the register-resident filter, 512 features
+  // 0.048 against 0.053: profiles/r5aj_*).  KMCUDA_AMD_WIDE_MIN_D=d moves the border: rows of at least d features are
+  // streamed (513: the register-resident filter up to 512 features, the cross-check).
   long wide_min_d = 257;
   if (const char *c = getenv("KMCUDA_AMD_WIDE_MIN_D")) {
     const long d = atol(c);
     if (d > 0) wide_min_d = d;
   }
-  const bool streamed = wide_ok_ && (long)D >= wide_min_d;
-  if (streamed) DP_ = 0;
-  if (streamed && reg_dp_ <= 256) reg_dp_ = 0;   // (a measurement aid below 257 features: the streamed filter alone)
+  if (wide_ok_ && (long)D >= wide_min_d) DP_ = 0;
   // Filter error bound coefficient (DESIGN.md "error bound"): gamma_D + (kappa + 3) u with
   // u = 2^-24, gamma_D <= 1.01 D u, kappa = 8 for the reference's Kahan chain; +2% margin.
   eps_ = (float)(1.02 * ((double)D + 12.0) * ldexp(1.0, -24));
@@ -165,15 +164,7 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   // no register-resident filter for this D: stage 1 streams both operands through LDS (lloyd_wide.hip), in 64-feature
   // chunks: operands padded to 64
   wide_dp_ = (DP_ == 0 && wide_ok_) ? (D + 63) / 64 * 64 : 0;
-  if (wide_dp_ == 0) reg_dp_ = DP_;
-  // (both filters: every attempt of the bounds costs two of the slower passes and the second row copy: one counted
-  //  list beyond the listed passes' limit is enough to give up, the pauses start at 8 passes)
-  if (both_filters()) {
-    carry_policy_.hopeless_needed = 1;
-    carry_policy_.backoff = carry_policy_.first_backoff = 8;
-  }
-  dp_alloc_ = reg_dp_ > wide_dp_ ? reg_dp_ : (wide_dp_ ? wide_dp_ : 8);
-  const uint32_t dp = dp_alloc_;
+  const uint32_t dp = DP_ ? DP_ : (wide_dp_ ? wide_dp_ : 8);
   int rc;
   if ((rc = alloc(&csqr_, K))) return rc;
   if ((rc = alloc(&bias_, K_pad_))) return rc;
@@ -183,7 +174,6 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if ((rc = alloc(&stats_base_, 16))) return rc;
   stats_ = stats_base_;
   if ((rc = alloc(&mu_, dp))) return rc;
-  KMX_HIP(hipMemsetAsync(mu_, 0, dp * sizeof(float), stream_), kRuntimeError);   // (zero beyond D whichever filter froze it)
   if ((rc = alloc(&finite_, Kt_))) return rc;
   if ((rc = alloc(&flagged_, n_rows))) return rc;
   if ((rc = alloc(&pairs_, 3 * (size_t)n_rows))) return rc;
@@ -254,16 +244,6 @@ void Engine::profile_reset() {
   profile_collect();
   filter_ms_ = exact_ms_ = update_ms_ = coarse_ms_ = 0;
   filter_launches_ = 0;
-}
-
-// An engine with both filters (engine.hpp: both_filters): which one the next passes run.  The row copies of both stay
-// valid (same frozen mean); a preparation done for the other one and any carried bounds do not.
-void Engine::select_filter(bool streamed) {
-  if (!both_filters() || (DP_ == 0) == streamed) return;
-  DP_ = streamed ? 0 : reg_dp_;
-  std::swap(row_cache_valid_, other_cache_valid_);
-  prepared_for_ = nullptr;
-  carry_valid_ = false;
 }
 
 int Engine::prepare_centroids(const float *centroids) {
@@ -476,15 +456,6 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   // carried bounds describe the assignments of the LAST pass: whatever this pass turns out to be, they hold afterwards
   // only if it was a carried pass itself (set at its end) -- an exact pass, the f32 filter, a rebuilt panel void them
-  if (both_filters() && !exact_only && !strict_h2_) {
-    // plain passes -- no bounds asked for, or a pause of the carry policy -- are the streamed filter's
-    bool streamed = !wide_failed_;   // (no memory for the streamed filter's buffers: the other one serves every pass)
-    if (streamed && carry_on_ && filter_mode_ == 0) {
-      if (carry_policy_.pause) carry_policy_.pause--;
-      else streamed = false;
-    }
-    select_filter(streamed);
-  }
   const bool carry_was_valid = carry_valid_;
   carry_valid_ = false;
   if (strict_h2_) {
@@ -505,7 +476,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   const bool two_stage = !exact_only && DP_ != 0 && filter_mode_ == 0 && lloyd_filter_f16_supported(D_, DP_);
   const bool want_cache = row_cache_on_ && two_stage && N_ != 0;
   const bool build_cache = want_cache && !row_cache_valid_;
-  if (build_cache && !other_cache_valid_) mu_frozen_ = false;  // take the mean of THESE centroids
+  if (build_cache) mu_frozen_ = false;  // take the mean of THESE centroids
   if (!side_stream_) {
     // (non-blocking even beside a blocking main stream: fork / join events order it completely)
     side_stream_ = pooled_stream_acquire(device_);
@@ -518,7 +489,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   }
   if (two_stage && !panelhi_) {
     uint16_t *phi = nullptr;
-    int rc = alloc(&phi, (size_t)((K_pad_ + 63u) / 64u * 64u) * (dp_alloc_ + 2));  // whole 64-row super-tiles + their biases
+    int rc = alloc(&phi, (size_t)((K_pad_ + 63u) / 64u * 64u) * (DP_ + 2));  // whole 64-row super-tiles + their biases
     if (rc) return rc;
     if (!undecided_ && ((rc = alloc(&undecided_, N_)) || (rc = alloc(&und_thr_, N_)))) return rc;
     panelhi_ = phi;
@@ -527,10 +498,14 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   // stage 1; the reference's serial sum_squares chain and the transposed panel, which only the pair /
   // exact kernels read, are computed beside stage 1 on the side stream.
   const bool steady = steady_state(exact_only);
+  // (the streamed filter's steady state: the same ONE preparation kernel, operands padded to wide_dp_)
+  const bool wide_sel = !exact_only && DP_ == 0 && wide_dp_ != 0 && !wide_failed_;
+  const bool wide_steady = wide_sel && mu_frozen_ && row_cache_on_ && row_cache_valid_ && N_ != 0 && panelhi_ != nullptr &&
+                           wide_rows16_ != nullptr && !strict_h2_;
   const bool prepared = steady && prepared_for_ == centroids;   // apply_prepare() has done this pass's preparation
   prepared_for_ = nullptr;
   bool rows_on_side = false;
-  if (steady) {
+  if (steady || wide_steady) {
     KMX_HIP(hipEventRecord(ev_fork_, stream_), kRuntimeError);   // the centroids are final here
     KMX_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0), kRuntimeError);
     KMX_HIP(launch_centroid_rows(metric_, centroids, K_, D_, Kt_, csqr_, ct_, side_stream_), kRuntimeError);
@@ -539,8 +514,8 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
     if (!prepared) {
       uint32_t *next = stats_;
       stats_ = stats_ == stats_base_ ? stats_base_ + 8 : stats_base_;
-      KMX_HIP(launch_centroid_prep_frozen(metric_, centroids, K_, D_, K_pad_, DP_, mu_, finite_, bias_, bias2_, cfil_,
-                                          panelhi_, stats_, next, counters_ + 1, counters_ + 3, counters_ + 4,
+      KMX_HIP(launch_centroid_prep_frozen(metric_, centroids, K_, D_, K_pad_, DP_ ? DP_ : wide_dp_, mu_, finite_, bias_,
+                                          bias2_, cfil_, panelhi_, stats_, next, counters_ + 1, counters_ + 3, counters_ + 4,
                                           carry_on_ ? drift_ : nullptr, carry_on_ && drift_ ? counters_ + kCarryCursor : nullptr,
                                           stream_),
               kRuntimeError);
@@ -557,8 +532,8 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   a.assignments = assignments; a.assignments_prev = assignments_prev;
   a.flagged = flagged_; a.pairs = pairs_; a.counters = counters_;
   if (N_ == 0) return kSuccess;
-  if (!exact_only && DP_ == 0 && wide_dp_ != 0 && !wide_failed_) {
-    const int rc = lloyd_assign_wide(a, centroids);
+  if (wide_sel) {
+    const int rc = lloyd_assign_wide(a, centroids, wide_steady, rows_on_side, carry_was_valid);
     if (rc != kNoSuchDevice + 100) return rc;   // (that code: no memory for its buffers -- the exact kernel below serves the shape)
   }
   if (exact_only || DP_ == 0 || (DP_ > 256 && filter_mode_ != 0)) {
@@ -711,7 +686,8 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
 
 // D beyond the register-resident filters: lloyd_wide.hip.  prepare_centroids() has run (csqr, ct, mean -- frozen
 // while a row copy is alive --, centred fp32 panel, biases, statistics, list counters zeroed).
-int Engine::lloyd_assign_wide(const LloydArgs &a0, const float *centroids) {
+int Engine::lloyd_assign_wide(const LloydArgs &a0, const float *centroids, bool steady, bool rows_on_side,
+                              bool carry_was_valid) {
   constexpr int kNoFilter = kNoSuchDevice + 100;
   LloydArgs a = a0;
   const uint32_t DG = wide_dp_;
@@ -726,7 +702,7 @@ int Engine::lloyd_assign_wide(const LloydArgs &a0, const float *centroids) {
   };
   if (!panelhi_) {
     uint16_t *phi = nullptr;
-    if (alloc(&phi, (size_t)k_pad64 * (dp_alloc_ + 2))) return no_memory();
+    if (alloc(&phi, (size_t)k_pad64 * (DG + 2))) return no_memory();
     panelhi_ = phi;
   }
   if (!wide_cont_) {
@@ -737,13 +713,15 @@ int Engine::lloyd_assign_wide(const LloydArgs &a0, const float *centroids) {
   }
   if (!wide_rows16_) {
     uint16_t *xg = nullptr;
-    if (alloc(&xg, (size_t)N_ * DG) || alloc(&wide_meta_, (size_t)N_ * 4)) return no_memory();
+    if (alloc(&xg, (size_t)N_ * DG) || alloc(&wide_meta_, ((size_t)N_ + 1) * 4)) return no_memory();
     wide_rows16_ = xg;
   }
   span_begin(0);
-  // hi halves of the centred centroids (+ their residual maximum, stats[5])
-  KMX_HIP(launch_centroid_panelhi(centroids, K_, D_, K_pad_, DG, finite_, mu_, bias_, panelhi_, stats_, stream_),
-          kRuntimeError);
+  // hi halves of the centred centroids (+ their residual maximum, stats[5]); the steady state's one preparation
+  // kernel has written them
+  if (!steady)
+    KMX_HIP(launch_centroid_panelhi(centroids, K_, D_, K_pad_, DG, finite_, mu_, bias_, panelhi_, stats_, stream_),
+            kRuntimeError);
   // the rows as centred halves: kept while the caller has promised fixed rows (the mean is then frozen, any mean
   // being valid), otherwise rebuilt for this pass's mean
   if (!(row_cache_on_ && row_cache_valid_)) {
@@ -754,9 +732,55 @@ int Engine::lloyd_assign_wide(const LloydArgs &a0, const float *centroids) {
       mu_frozen_ = true;
     }
   }
+  // Carried bounds, as in the register-resident filter's steady state (lloyd_assign): the pass leaves per-row bounds,
+  // the next one only looks at the rows they do not decide.  No pair certificates here: a row the later stages settle
+  // is listed again.  (The drift bound's rounding allowance covers fp32 sums of up to ~6000 terms.)
+  bool carry = carry_on_ && steady && DG <= 4096u;
+  if (carry && carry_policy_.paused()) {
+    carry = false;
+    if (getenv("KMCUDA_AMD_CARRY_TRACE")) fprintf(stderr, "[carry] paused (%u more)\n", carry_policy_.pause);
+  }
+  if (carry && !ub_) {
+    if (alloc(&ub_, N_) != kSuccess || alloc(&lb_, N_) != kSuccess || alloc(&drift_, 2 * (size_t)K_) != kSuccess ||
+        alloc(&carry_list_, N_) != kSuccess || !(host_carry_ = pinned_words(2, &host_carry_dev_))) {
+      (void)hipGetLastError();   // (no memory: not an error, plain passes)
+      carry_on_ = false;
+      ub_ = nullptr;
+    } else {
+      host_carry_[0] = 0xFFFFFFFFu;
+      host_carry_[1] = 0;
+      if (const char *v = getenv("KMCUDA_AMD_CARRY_MAX")) carry_policy_.list_max = (float)atof(v);
+    }
+  }
   span_begin(3);   // the dominant kernels on their own, inside the filter span
-  KMX_HIP(launch_lloyd_wide(a, wide_rows16_, wide_meta_, DG, panelhi_, undecided_, und_thr_, wide_cont_, stream_), kRuntimeError);
+  if (carry && carry_on_) {
+    CarryArgs cy;
+    cy.ub = ub_; cy.lb = lb_; cy.host_report = host_carry_dev_; cy.seq = ++carry_seq_;
+    cy.angular = metric_ != 0;
+    const bool moved = carry_was_valid && carry_preps_ == 1;   // drift_ / stats_[6] belong to the bounds
+    bool listed = false;
+    if (moved) {
+      const uint32_t last = host_carry_[0], last_seq = host_carry_[1];
+      listed = carry_policy_.decide(last, last_seq, carry_seq_, N_);
+      KMX_HIP(launch_carry_skip(N_, K_, a.assignments, a.assignments_prev, cy, wide_meta_, drift_, stats_, tie_slack_,
+                                carry_list_, finite_, pairs_, counters_, !listed, stream_, DG),
+              kRuntimeError);
+      cy.n_list = counters_ + kCarryCursor;
+    }
+    if (listed) cy.row_list = carry_list_;
+    if (getenv("KMCUDA_AMD_CARRY_TRACE"))
+      fprintf(stderr, "[carry] streamed pass %u: bounds %s, %u preparation(s) since, last reported list %u (pass %u), %s\n",
+              carry_seq_, carry_was_valid ? "valid" : "void", carry_preps_, host_carry_[0], host_carry_[1],
+              listed ? "listed pass" : (moved ? "whole pass, list counted" : "whole pass"));
+    KMX_HIP(launch_lloyd_wide(a, wide_rows16_, wide_meta_, DG, panelhi_, undecided_, und_thr_, wide_cont_, stream_, &cy),
+            kRuntimeError);
+    carry_valid_ = true;
+  } else {
+    KMX_HIP(launch_lloyd_wide(a, wide_rows16_, wide_meta_, DG, panelhi_, undecided_, und_thr_, wide_cont_, stream_), kRuntimeError);
+  }
+  carry_preps_ = 0;
   span_end();
+  if (rows_on_side) KMX_HIP(hipStreamWaitEvent(stream_, ev_rows_, 0), kRuntimeError);   // csqr / ct: the exact chains
   KMX_HIP(launch_wide_contenders(metric_, a, centroids, DG, undecided_, wide_cont_, stream_), kRuntimeError);
   span_end();
   span_begin(1);
@@ -1084,12 +1108,12 @@ int kmamd_set_filter(kmamd_engine *e, int mode) {
 int kmamd_set_half_rows(kmamd_engine *e, const void *rows16) {
   e->e.half_rows_ = rows16;
   e->e.prepared_for_ = nullptr;
-  e->e.drop_row_copies();  // a cache built from other rows is stale
+  e->e.row_cache_valid_ = false;  // a cache built from other rows is stale
   return kmx::kSuccess;
 }
 int kmamd_set_row_cache(kmamd_engine *e, int on) {
   e->e.row_cache_on_ = on != 0 && e->e.row_cache_allowed_;
-  e->e.drop_row_copies();  // (re)built by the next kmamd_lloyd_assign
+  e->e.row_cache_valid_ = false;  // (re)built by the next kmamd_lloyd_assign
   e->e.prepared_for_ = nullptr;
   if (!e->e.row_cache_on_) e->e.mu_frozen_ = false;
   return kmx::kSuccess;

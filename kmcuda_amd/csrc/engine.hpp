@@ -46,9 +46,6 @@ struct CarryPolicy {
   // they are tried again.  (Round 4 only gave up beyond 90 %: config B's lists hover at 65-80 % from iteration 27 on and
   // twenty whole passes paid 0.5 ms each for bounds that spared nothing, profiles/r5ac_carry_trace_config_b.log.)
   uint32_t pause = 0, backoff = 4, hopeless = 0, seen_seq = 0;
-  // (an engine whose plain passes have a faster filter than the carried ones -- 257..512 features, Engine::init -- gives
-  //  up after one such count and pauses longer)
-  uint32_t hopeless_needed = 2, first_backoff = 4;
   static constexpr uint32_t kNoList = 0xFFFFFFFFu;   // the report of a pass that had no list to count
 
   // A pass is about to run with carrying switched on: true = it runs plain (one pass of a pause is used up).
@@ -67,7 +64,7 @@ struct CarryPolicy {
       seen_seq = last_seq;
       const float give_up = list_max > 0.f && list_max < 0.9f ? list_max : 0.9f;
       if ((float)last > give_up * (float)n_rows && list_max < 1.0f) {
-        if (++hopeless >= hopeless_needed) {
+        if (++hopeless >= 2) {
           pause = backoff;
           backoff = backoff < 32 ? 2 * backoff : 32;
           hopeless = 0;
@@ -75,7 +72,7 @@ struct CarryPolicy {
         }
       } else {
         hopeless = 0;
-        backoff = first_backoff;
+        backoff = 4;
       }
     }
     return listed;
@@ -170,20 +167,12 @@ class Engine {
   // D beyond the register-resident filters (lloyd_wide.hip): both operands streamed through LDS.  wide_dp_ = D rounded
   // up to 64 (0: not this path); KMCUDA_AMD_WIDE=0 leaves such shapes to the exact kernels (the cross-check)
   uint32_t wide_dp_ = 0;
-  // 257..512 features have BOTH filters: plain passes take the streamed one (faster there), carried passes the
-  // register-resident one (reg_dp_ = 512: the only one that leaves / reads bounds).  DP_ says which is selected (0:
-  // streamed); each keeps its own row copy over the same frozen mean (other_cache_valid_: the unselected one's).
-  uint32_t reg_dp_ = 0, dp_alloc_ = 0;
-  bool other_cache_valid_ = false;
-  bool both_filters() const { return reg_dp_ != 0 && wide_dp_ != 0; }
-  void select_filter(bool streamed);
-  void drop_row_copies() { row_cache_valid_ = other_cache_valid_ = false; }
   bool wide_ok_ = true;
   bool wide_failed_ = false;   // its buffers could not be allocated: the exact kernels serve the shape
   void *wide_rows16_ = nullptr;          // N x wide_dp_ halves: x - mu, row-major (this path's row cache)
   float *wide_meta_ = nullptr;       // 4 floats per row
   uint32_t *wide_cont_ = nullptr; // per listed row: the number of its contenders, then up to 16 of them
-  int lloyd_assign_wide(const LloydArgs &a, const float *centroids);
+  int lloyd_assign_wide(const LloydArgs &a, const float *centroids, bool steady, bool rows_on_side, bool carry_was_valid);
   // row cache of the coarse filter stage (lloyd_f16.hip: row_cache_kernel); set_row_cache()
   bool row_cache_allowed_ = true;   // KMCUDA_AMD_ROW_CACHE=0 vetoes it
   bool row_cache_on_ = false, row_cache_valid_ = false, mu_frozen_ = false;

@@ -119,7 +119,8 @@ hipError_t launch_lloyd_coarse_carry(const LloydArgs &a, const void *rows, bool 
 hipError_t launch_carry_skip(uint32_t N, uint32_t K, const uint32_t *assignments, uint32_t *assignments_prev,
                              const CarryArgs &cy, const float *xmeta, const float *drift, const uint32_t *stats,
                              float tie_slack, uint32_t *row_list, const uint32_t *finite, uint32_t *pairs,
-                             uint32_t *counters, bool probe, hipStream_t st);
+                             uint32_t *counters, bool probe, hipStream_t st, uint32_t wide_dg = 0);
+// (wide_dg != 0: xmeta is the streamed filter's record table, lloyd_wide.hip, rows padded to wide_dg features)
 // the reference's exact sum_squares (csqr) + the transposed panel (ct) alone: what the pair / exact kernels read
 hipError_t launch_centroid_rows(int metric, const float *centroids, uint32_t K, uint32_t D, uint32_t Kt, float *csqr,
                                 float *ct, hipStream_t st);
@@ -145,11 +146,14 @@ hipError_t launch_row_cache(const void *rows, bool half_rows, uint32_t N, uint32
 // LDS (256 rows x 256 centroids per block, 64-feature chunks), best / second-best per row in registers, no score ever
 // written; then the same sweep over the rows it listed for their contenders
 hipError_t launch_row_halves(const void *rows, bool half_rows, uint32_t N, uint32_t D, uint32_t DG, const float *mu,
-                             void *xg, float *meta /* 4 floats per row */, hipStream_t st);
+                             void *xg, float *meta /* 4 floats per row, N + 1 records: ||mu|| in the last */, hipStream_t st);
 size_t wide_cont_words(uint32_t N);   // contender table: (1 + 16) words per row
-// commits / lists (undecided, und_thr, counters[4]) every row, then writes the listed rows' contenders (und_cont)
+// commits / lists (undecided, und_thr, counters[4]) every row, then writes the listed rows' contenders (und_cont).
+// cy (carried bounds, as launch_lloyd_coarse_carry): every row (cy->row_list == nullptr) or the rows of cy->row_list,
+// and the rows the pass looks at leave with fresh bounds (cy->ub / lb; no pair certificates on this path)
 hipError_t launch_lloyd_wide(const LloydArgs &a, const void *xg, const float *meta, uint32_t DG /* % 64 == 0 */,
-                             const void *panelhi, uint32_t *undecided, float *und_thr, uint32_t *und_cont, hipStream_t st);
+                             const void *panelhi, uint32_t *undecided, float *und_thr, uint32_t *und_cont, hipStream_t st,
+                             const CarryArgs *cy = nullptr);
 hipError_t launch_wide_contenders(int metric, const LloydArgs &a, const float *centroids, uint32_t DG,
                                   const uint32_t *und_rows, const uint32_t *und_cont, hipStream_t st);
 

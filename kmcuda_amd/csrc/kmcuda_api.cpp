@@ -1220,7 +1220,7 @@ class Job {
     for (auto &s : shards) {
       if (after == 0) {
         s->eng->row_cache_on_ = s->eng->row_cache_allowed_;
-        s->eng->drop_row_copies();
+        s->eng->row_cache_valid_ = false;
       }
       RETERR(s->eng->stop_clear());
     }
@@ -2060,8 +2060,8 @@ KMCUDAResult kmeans_cuda(KMCUDAInitMethod init, const void *init_params, float t
       bool bounds = !adaptive;
       if (adaptive) {
         const char *cv = getenv("KMCUDA_AMD_CARRY");
-        // (rows of 257..512 features: streamed plain passes, register-resident carried ones -- engine.hpp: both_filters)
-        const bool carry = !(cv && atoi(cv) == 0) && (!wide || job.shards[0]->eng->both_filters());
+        // (rows wider than 256 features: the streamed filter carries the bounds itself, up to 4096 features)
+        const bool carry = !(cv && atoi(cv) == 0) && (!wide || job.shards[0]->eng->wide_dp_ <= 4096u);
         // The first carried pass only LEAVES bounds (and allocates them: 24 bytes per row); rows are spared from the
         // second one on.  A run that stops within a pass or two of the hand-over point never earns that back (round 4:
         // the 4M-row mixture at tolerance 0.01, one iteration after the hand-over, +12-16 %), and how long a run will

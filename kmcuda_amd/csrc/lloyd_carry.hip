@@ -49,23 +49,27 @@ namespace kmx {
 // pass follows and rewrites every bound).  The rows a listed pass spares are N - the list: the listed coarse kernel
 // adds them up (one thread), not 2000 blocks on one address.
 constexpr int kSkipRowsPerThread = 8, kSkipBlock = 256;
+// WIDE: the rows' records are the streamed filter's (lloyd_wide.hip: float4 = ||x'||^2, residual^2, x[0], ||x||^2 per row,
+// ||mu|| behind the last one); terms: the length of the fp32 sums behind a bias (padded features + 8)
+template <bool WIDE>
 __global__ __launch_bounds__(kSkipBlock) void carry_skip_kernel(
     uint32_t N, uint32_t K, const uint32_t *__restrict__ assignments, uint32_t *__restrict__ assignments_prev,
     CarryArgs cy, const float2 *__restrict__ xmeta, const float *__restrict__ drift, const uint32_t *__restrict__ stats,
     float tie_slack, uint32_t *__restrict__ row_list, const uint32_t *__restrict__ finite, uint32_t *__restrict__ pairs,
-    uint32_t *__restrict__ counters, int probe) {
+    uint32_t *__restrict__ counters, int probe, float terms) {
   if (counters[kStopFlag] != 0u) return;   // the run has stopped on the device: touch nothing
   float *__restrict__ ub = cy.ub, *__restrict__ lb = cy.lb, *__restrict__ l3 = cy.l3;
   const int angular = cy.angular;
   const float maxdrift = __uint_as_float(stats[6]);                       // +inf if any drift is not finite
   const float cmaxo = sqrtf(__uint_as_float(stats[2])) * 1.000001f;       // max ||c|| of THIS pass's centroids
-  const float mu_norm = reinterpret_cast<const float *>(xmeta)[2 * (((size_t)N + 255) / 256 * 256)];
+  const float4 *__restrict__ wmeta = reinterpret_cast<const float4 *>(xmeta);
+  const float mu_norm = WIDE ? wmeta[N].x : reinterpret_cast<const float *>(xmeta)[2 * (((size_t)N + 255) / 256 * 256)];
   const float u = 5.9604645e-8f;
   // angular: max(0, max_c db(c)) and the rounding of the four fp32 sums mu.c' behind two differences of them (each
-  // within (DP + 2) u ||mu|| ||c'||, DP <= 512; ||c'_old|| <= ||c'_new|| + drift)
+  // within (DP + 2) u ||mu|| ||c'||, terms >= DP + 8; ||c'_old|| <= ||c'_new|| + drift)
   const float maxdb = __uint_as_float(stats[7]);
   const float cmaxc = sqrtf(__uint_as_float(stats[0])) * 1.000001f;
-  const float eb = 4.0f * 520.0f * u * mu_norm * (cmaxc + maxdrift);
+  const float eb = 4.0f * terms * u * mu_norm * (cmaxc + maxdrift);
   const uint32_t chunk = kSkipBlock * kSkipRowsPerThread;
   const uint32_t base = blockIdx.x * chunk;
   // ONE cursor atomic per block and list: same-address atomics are served one at a time by L2 (~11 ns each), and a
@@ -83,13 +87,21 @@ __global__ __launch_bounds__(kSkipBlock) void carry_skip_kernel(
       // (a centroid that has turned non-finite while it still has members -- an overflow, inf features -- never wins in
       //  the reference (a NaN distance is never "<"): its rows are listed, whatever the drifts of its zeroed panel row say)
       if (a < K && finite[a] != 0u) {
-        const float xo = (sqrtf(xmeta[s].x) * 1.0001f + mu_norm) * 1.0001f;   // ||x|| <= ||x - mu|| + ||mu||
+        float xn2, xo;
+        if (WIDE) {
+          const float4 m = wmeta[s];
+          xn2 = m.x;
+          xo = sqrtf(m.w) * 1.0001f;                                // ||x||, measured
+        } else {
+          xn2 = xmeta[s].x;
+          xo = (sqrtf(xn2) * 1.0001f + mu_norm) * 1.0001f;          // ||x|| <= ||x - mu|| + ||mu||
+        }
         const float e_ref = u * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
         if (angular) {
           // score space: s(c) = x'.c' + mu.c' moves by at most ||x'|| ||c_new - c_old|| plus the change db(c) of its
           // second term, known per centroid: the certified gap shrinks by the first for the row's centroid and for the
           // best of the others, and by max_c db(c) - db(a)
-          const float xn = sqrtf(xmeta[s].x) * 1.0001f;
+          const float xn = sqrtf(xn2) * 1.0001f;
           const float g = ub[s] - (xn * (drift[a] + maxdrift) + (maxdb - drift[K + a]) + eb) * 1.000001f;
           keep = g > 4.1f * e_ref + 2.0f * tie_slack;   // (-inf, NaN: false)
           if (keep && !probe) {
@@ -187,11 +199,16 @@ __global__ __launch_bounds__(kSkipBlock) void carry_skip_kernel(
 hipError_t launch_carry_skip(uint32_t N, uint32_t K, const uint32_t *assignments, uint32_t *assignments_prev,
                              const CarryArgs &cy, const float *xmeta, const float *drift, const uint32_t *stats,
                              float tie_slack, uint32_t *row_list, const uint32_t *finite, uint32_t *pairs,
-                             uint32_t *counters, bool probe, hipStream_t st) {
+                             uint32_t *counters, bool probe, hipStream_t st, uint32_t wide_dg) {
   const uint32_t chunk = kSkipBlock * kSkipRowsPerThread;
-  hipLaunchKernelGGL(carry_skip_kernel, dim3((N + chunk - 1) / chunk), dim3(kSkipBlock), 0, st, N, K, assignments,
-                     assignments_prev, cy, reinterpret_cast<const float2 *>(xmeta), drift, stats, tie_slack, row_list,
-                     finite, pairs, counters, probe ? 1 : 0);
+  if (wide_dg)
+    hipLaunchKernelGGL(carry_skip_kernel<true>, dim3((N + chunk - 1) / chunk), dim3(kSkipBlock), 0, st, N, K, assignments,
+                       assignments_prev, cy, reinterpret_cast<const float2 *>(xmeta), drift, stats, tie_slack, row_list,
+                       finite, pairs, counters, probe ? 1 : 0, (float)(wide_dg + 8u));
+  else
+    hipLaunchKernelGGL(carry_skip_kernel<false>, dim3((N + chunk - 1) / chunk), dim3(kSkipBlock), 0, st, N, K, assignments,
+                       assignments_prev, cy, reinterpret_cast<const float2 *>(xmeta), drift, stats, tie_slack, row_list,
+                       finite, pairs, counters, probe ? 1 : 0, 520.0f);
   return hipGetLastError();
 }
 
@@ -255,7 +272,7 @@ hipError_t launch_lloyd_refine_carry(const LloydArgs &a, const void *rows, bool 
 
 hipError_t preload_lloyd_carry_code() {   // (kernels.hpp: preload_code_objects)
   hipFuncAttributes at;
-  return hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&carry_skip_kernel));
+  return hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&carry_skip_kernel<false>));
 }
 
 }  // namespace kmx

@@ -39,6 +39,13 @@ __global__ __launch_bounds__(256) void row_halves_kernel(const void *__restrict_
                                                          uint32_t DG, const float *__restrict__ mu,
                                                          _Float16 *__restrict__ xg, float4 *__restrict__ meta) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && wave == 0) {   // ||mu|| behind the rows' records (carry_skip_kernel: the angular bias sums)
+    float m2 = 0.f;
+    for (uint32_t f = lane; f < DG; f += 64) m2 = fmaf(mu[f], mu[f], m2);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m2 += __shfl_xor(m2, off);
+    if (lane == 0) meta[N] = make_float4(sqrtf(m2) * 1.0001f, 0.f, 0.f, 0.f);
+  }
   for (uint32_t r = blockIdx.x * 4 + wave; r < N; r += gridDim.x * 4) {   // (kernels.hpp: wave_row_grid)
     float n2 = 0.f, d2 = 0.f, o2 = 0.f, x0 = 0.f;
     for (uint32_t f = lane; f < DG; f += 64) {
@@ -99,18 +106,32 @@ __device__ __forceinline__ void lds_frag_wait6(f16x8 &a0, f16x8 &a1, f16x8 &a2, 
 
 // MODE 0: every row; commits the rows the bound decides, lists the others (undecided / und_thr, counters[4]).
 // MODE 1: the listed rows; writes their contenders (und_cont: kWideCap + 1 words per listed row: the count, the ids).
+// MODE 2 / 3 (carried bounds, lloyd_carry.hip): as MODE 0 over every row / over the rows of cy.row_list (the rows
+// whose bounds, moved by the centroids' drifts, no longer certify their assignment), and every row the pass looks at
+// leaves with fresh bounds read off its best two scores -- lloyd_coarse2_kernel<..., CARRY>'s statements word for word.
 template <int MODE>
 __global__ __launch_bounds__(512) void lloyd_wide_kernel(
     const _Float16 *__restrict__ xg, const float4 *__restrict__ meta, uint32_t N, uint32_t DG,
     const _Float16 *__restrict__ panelhi, uint32_t K_pad64, uint32_t K, const uint32_t *__restrict__ stats, float eps,
     float tie_slack, uint32_t *__restrict__ assignments, uint32_t *__restrict__ assignments_prev,
     uint32_t *__restrict__ undecided, float *__restrict__ und_thr, uint32_t *__restrict__ und_cont,
-    uint32_t *__restrict__ counters) {
+    uint32_t *__restrict__ counters, CarryArgs cy) {
+  constexpr bool BOUNDS = MODE >= 2, LISTED = MODE == 3;
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
   extern __shared__ __attribute__((aligned(1024))) unsigned char ldsw[];
   if (counters[kStopFlag] != 0u) return;   // the run has stopped on the device: touch nothing
   uint32_t total = N;
   if (MODE == 1) total = __builtin_amdgcn_readfirstlane(counters[4]);
+  if (LISTED) total = __builtin_amdgcn_readfirstlane(*cy.n_list);
+  if (BOUNDS && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (cy.host_report) {   // how long this pass's list was: the host sizes later passes by it
+      volatile uint32_t *hr = cy.host_report;
+      hr[0] = cy.n_list ? *cy.n_list : 0xFFFFFFFFu;   // (a pass without bounds to move has no list to report)
+      hr[1] = cy.seq;
+    }
+    if (LISTED)   // the rows this pass does not look at (statistics: kmamd_carry_stats)
+      *reinterpret_cast<unsigned long long *>(counters + kCarrySkipped) += (unsigned long long)(N - total);
+  }
   const uint32_t blk = blockIdx.x;
   if ((uint64_t)blk * kWideRows >= total) return;   // (block-uniform, in front of every barrier and DMA)
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte *)ldsw;
@@ -127,7 +148,7 @@ __global__ __launch_bounds__(512) void lloyd_wide_kernel(
   for (int s = 0; s < 2; s++) {
     pos[s] = blk * kWideRows + wm * 64 + s * 32 + col;
     live[s] = pos[s] < total;
-    srow[s] = live[s] ? (MODE == 1 ? undecided[pos[s]] : pos[s]) : 0u;
+    srow[s] = live[s] ? (MODE == 1 ? undecided[pos[s]] : (LISTED ? cy.row_list[pos[s]] : pos[s])) : 0u;
   }
   float cutv[2] = {0.f, 0.f};
   if (MODE == 1) {
@@ -148,7 +169,7 @@ __global__ __launch_bounds__(512) void lloyd_wide_kernel(
     const uint32_t R = (uint32_t)(wave + 8 * q) * 8u + (uint32_t)(lane >> 3);
     const uint32_t p = blk * kWideRows + R;
     uint32_t r = 0u;   // rows past the end read row 0: their scores are never used
-    if (p < total) r = MODE == 1 ? undecided[p] : p;
+    if (p < total) r = MODE == 1 ? undecided[p] : (LISTED ? cy.row_list[p] : p);
     boff[q] = (size_t)r * rowbytes + chunk16;
     aoff[q] = 0;
   }
@@ -280,7 +301,7 @@ __global__ __launch_bounds__(512) void lloyd_wide_kernel(
       }
     }
     // ---- the pass's 256 centroids are scored ----
-    if (MODE == 0) {
+    if (MODE != 1) {
 #pragma unroll
       for (int t = 0; t < 4; t++) {
         const uint32_t gt = pass * 8u + (uint32_t)(wn * 4 + t);   // global 32-centroid tile number
@@ -332,7 +353,7 @@ __global__ __launch_bounds__(512) void lloyd_wide_kernel(
     return;
   }
 
-  // ---- MODE 0: the two half-waves, then the two waves that share the rows, then the decision ----
+  // ---- MODE 0 / 2 / 3: the two half-waves, then the two waves that share the rows, then the decision ----
   float cut[2] = {0.f, 0.f};
   uint32_t i1v[2];
 #pragma unroll
@@ -392,6 +413,30 @@ __global__ __launch_bounds__(512) void lloyd_wide_kernel(
       bool changed = false;
       if (mine && certain) changed = commit_row(srow[s], insane ? K : i1, assignments, assignments_prev);
       und[s] = mine && !certain;
+      if (BOUNDS && mine) {
+        // lloyd_coarse2_kernel's statements (lloyd_coarse.hpp, CARRY): d(x, c)^2 = ||x'||^2 - 2 s(c), every coarse score
+        // within e_c of s(c), m.x within 2 eps of ||x'||^2, every centroid other than i1 scored <= b2.  A row the later
+        // stages decide may end on another contender than i1: its lower bound is void (0), its upper bound holds.
+        const float e = e_c * 1.001f;
+        if (cy.angular) {
+          float gapv = (certain && !insane && in_range) ? ((b1 - e) - (b2 + e)) * 0.999999f : -INFINITY;
+          if (!(gapv == gapv)) gapv = -INFINITY;
+          cy.ub[srow[s]] = gapv;
+        } else {
+          float ubv = INFINITY, lbv = 0.f;
+          if (!insane && in_range) {
+            const float d2u = fmaxf(m.x * (1.0f + 2.0f * eps) - 2.0f * (b1 - e), 0.f);
+            const float d2l = m.x * (1.0f - 2.0f * eps) - 2.0f * (b2 + e);
+            const float geo = 2.4e-7f * (xn + cmaxc);
+            ubv = sqrtf(d2u) * 1.000001f + geo;
+            if (certain && d2l > 0.f) lbv = fmaxf(sqrtf(d2l) * 0.999999f - geo, 0.f);
+            if (!(ubv == ubv)) ubv = INFINITY;
+            if (!(lbv == lbv)) lbv = 0.f;
+          }
+          cy.ub[srow[s]] = ubv;
+          cy.lb[srow[s]] = lbv;
+        }
+      }
       cut[s] = in_range ? b1 - thr : __builtin_nanf("");
       um[s] = __ballot(und[s]);
       changed_count += (uint32_t)__popcll(__ballot(changed));
@@ -631,7 +676,7 @@ size_t wide_cont_words(uint32_t N) { return (size_t)N * (kWideCap + 1); }
 
 // stage 1 over every row, then over the rows it listed (their contenders); DG: a multiple of 64
 hipError_t launch_lloyd_wide(const LloydArgs &a, const void *xg, const float *meta, uint32_t DG, const void *panelhi,
-                             uint32_t *undecided, float *und_thr, uint32_t *und_cont, hipStream_t st) {
+                             uint32_t *undecided, float *und_thr, uint32_t *und_cont, hipStream_t st, const CarryArgs *cy) {
   if (a.N == 0) return hipSuccess;
   if (DG % kWideBK != 0) return hipErrorInvalidValue;
   const uint32_t k_pad64 = (a.K_pad + 63u) / 64u * 64u;
@@ -640,16 +685,26 @@ hipError_t launch_lloyd_wide(const LloydArgs &a, const void *xg, const float *me
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lloyd_wide_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLds0);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lloyd_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLds1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lloyd_wide_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLds0);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lloyd_wide_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLds0);
     (void)hipGetLastError();
     attr_set = true;
   }
-  hipLaunchKernelGGL((lloyd_wide_kernel<0>), dim3(grid), dim3(512), kWideLds0, st, reinterpret_cast<const _Float16 *>(xg),
-                     reinterpret_cast<const float4 *>(meta), a.N, DG, reinterpret_cast<const _Float16 *>(panelhi), k_pad64, a.K,
-                     a.stats, a.eps, a.tie_slack, a.assignments, a.assignments_prev, undecided, und_thr, und_cont, a.counters);
-  // the listed rows: the grid covers the worst case, blocks past the (device-side) end of the list leave at once
-  hipLaunchKernelGGL((lloyd_wide_kernel<1>), dim3(grid), dim3(512), kWideLds1, st, reinterpret_cast<const _Float16 *>(xg),
-                     reinterpret_cast<const float4 *>(meta), a.N, DG, reinterpret_cast<const _Float16 *>(panelhi), k_pad64, a.K,
-                     a.stats, a.eps, a.tie_slack, a.assignments, a.assignments_prev, undecided, und_thr, und_cont, a.counters);
+#define KMX_WIDE_LAUNCH(MODE, LDS, CY)                                                                                \
+  hipLaunchKernelGGL((lloyd_wide_kernel<MODE>), dim3(grid), dim3(512), LDS, st, reinterpret_cast<const _Float16 *>(xg), \
+                     reinterpret_cast<const float4 *>(meta), a.N, DG, reinterpret_cast<const _Float16 *>(panelhi),      \
+                     k_pad64, a.K, a.stats, a.eps, a.tie_slack, a.assignments, a.assignments_prev, undecided, und_thr,  \
+                     und_cont, a.counters, CY)
+  if (!cy) {
+    KMX_WIDE_LAUNCH(0, kWideLds0, CarryArgs());
+  } else if (!cy->row_list) {   // every row, leaving bounds
+    KMX_WIDE_LAUNCH(2, kWideLds0, *cy);
+  } else {   // the rows carry_skip_kernel listed: blocks past the (device-side) end of the list leave at once
+    KMX_WIDE_LAUNCH(3, kWideLds0, *cy);
+  }
+  // the undecided rows: the grid covers the worst case, blocks past the (device-side) end of the list leave at once
+  KMX_WIDE_LAUNCH(1, kWideLds1, CarryArgs());
+#undef KMX_WIDE_LAUNCH
   return hipGetLastError();
 }
 

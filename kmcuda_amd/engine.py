@@ -205,8 +205,8 @@ class Engine:
         _lib.check(self.lib.kmamd_engine_sync(self.h), "kmamd_engine_sync")
 
     def filter_kind(self):
-        """(kind, padded width) of the filter the last pass ran: 1 register-resident, 2 LDS-streamed (features > 256;
-        up to 512 features carried passes take kind 1), 0 exact kernels alone (kmamd_filter_kind)."""
+        """(kind, padded width): 1 register-resident filter, 2 LDS-streamed filter (features > 256), 0 exact kernels
+        alone (kmamd_filter_kind)."""
         w = ctypes.c_uint32()
         kind = self.lib.kmamd_filter_kind(self.h, ctypes.byref(w))
         return kind, w.value

@@ -109,8 +109,11 @@ def _run_pair(x, k, iters, carry_from, fused, half=False, seed=5, monkeypatch=No
                          ids=lambda s: "%dx%d@%d" % s)
 def test_carried_passes_equal_plain_passes_on_clustered_rows(shape, fused, monkeypatch):
     n, d, k = shape
-    # (257..512 features: plain passes take the streamed filter, the carried ones change to the register-resident one
-    #  -- the engine keeps both row copies over one frozen mean, engine.hpp: both_filters; log of kinds below)
+    # (257..512 features: the streamed filter, as beyond 512 -- test_carried_passes_on_the_streamed_filter; the
+    #  register-resident filter's 512-wide instantiation carries bounds too: the parametrisation below runs these two
+    #  shapes on it, KMCUDA_AMD_WIDE_MIN_D=513)
+    if 256 < d <= 512:
+        monkeypatch.setenv("KMCUDA_AMD_WIDE_MIN_D", "513")
     # half as many blobs as centroids: most blobs are shared by two centroids, whose rows the bounds rarely decide;
     # as many blobs as centroids (the first shape): most rows are decided by their bounds from the first carried pass on
     x = _blobs(n, d, k if n == 60000 else max(8, k // 2), seed=n + d, spread=10.0 if n == 60000 else 6.0)
@@ -120,7 +123,7 @@ def test_carried_passes_equal_plain_passes_on_clustered_rows(shape, fused, monke
     log, spared, last = _run_pair(x, k, iters=14, carry_from=3, fused=fused, list_max=1.0 if padded else None)
     assert spared > 0, (log, spared, last)
     if 256 < d <= 512:
-        assert _run_pair.kinds[:3] == [(2, (d + 63) // 64 * 64)] * 3 and _run_pair.kinds[-1] == (1, 512), _run_pair.kinds
+        assert _run_pair.kinds[-1] == (1, 512), _run_pair.kinds
     if n == 60000:
         assert spared > 3 * n and last < n // 2, (log, spared, last)
 
@@ -184,19 +187,6 @@ def test_carried_passes_equal_plain_passes_on_unstructured_rows(list_max):
     assert last > 0
 
 
-def test_unstructured_rows_of_384_features_go_back_to_the_streamed_filter_while_the_bounds_pause():
-    """257..512 features: a carried pass costs more than a plain one there (the register-resident filter against the
-    streamed one), so lists beyond ~2/3 of the rows pause the bounds, the pause's passes are streamed ones, then the
-    bounds are tried again -- same states as plain passes throughout (and the oracle's, _run_pair)."""
-    x = _uniform(30000, 384, seed=8)
-    log, spared, last = _run_pair(x, 200, iters=19, carry_from=2, fused=True)
-    kinds = [k[0] for k in _run_pair.kinds]
-    assert kinds[:2] == [2, 2] and kinds[2] == 1, kinds
-    assert 2 in kinds[3:], kinds              # a pause ...
-    first_pause = 3 + kinds[3:].index(2)
-    assert 1 in kinds[first_pause:], kinds    # ... and the next attempt behind it
-
-
 def test_carried_passes_with_nan_rows_dead_clusters_and_halves():
     x = _blobs(40000, 64, 20, seed=77)
     x[5, 0] = numpy.nan          # kmeans.cu:312: assignment K
@@ -207,6 +197,64 @@ def test_carried_passes_with_nan_rows_dead_clusters_and_halves():
     xh = _blobs(40000, 64, 48, seed=78, spread=10.0)   # as many blobs as centroids: most rows are spared
     log, spared, _ = _run_pair(xh, 48, iters=10, carry_from=2, fused=True, half=True)
     assert spared > 0, log
+
+
+@pytest.mark.parametrize("case", [((20000, 640, 40), "L2", False, True), ((12000, 1024, 64), "L2", False, False),
+                                  ((16000, 768, 48), "cos", False, True), ((16000, 576, 30), "L2", True, True),
+                                  ((9000, 1536, 24), "cos", True, False), ((14000, 2048, 20), "L2", False, True),
+                                  ((30000, 512, 48), "L2", False, True), ((20000, 300, 24), "L2", False, False),
+                                  ((24000, 384, 32), "cos", True, True)],
+                         ids=lambda c: "%dx%d@%d-%s-%s-%s" % (c[0] + (c[1], "fp16" if c[2] else "fp32", "fused" if c[3] else "apply")))
+def test_carried_passes_on_the_streamed_filter(case):
+    """Rows wider than 256 features (lloyd_wide.hip, round 5): the streamed filter's passes leave the same two bounds per
+    row (MODE 2), carry_skip_kernel reads the rows' records from that filter's table, the listed rows are gathered by
+    index (MODE 3).  Every pass against plain passes and against the oracle, as everywhere in this file."""
+    (n, d, k), metric, half, fused = case
+    # (half as many blobs as centroids: most blobs are shared by two centroids and the run keeps moving)
+    x = _blobs(n, d, max(8, k // 2), seed=n + d, spread=6.0)
+    if metric == "cos":
+        x = (x / numpy.linalg.norm(x, axis=1, keepdims=True)).astype(numpy.float32)
+    # (list_max = 1: every pass with a counted list is a LISTED one -- shared blobs at these widths list ~60 % of the
+    #  rows, which the default policy answers with whole passes and then a pause: test_boundary_cpu.py has that logic)
+    log, spared, last = _run_pair(x, k, iters=12, carry_from=3, fused=fused, half=half, metric=metric, list_max=1.0)
+    assert spared > 0, (log, spared, last)
+    assert all(kind == (2, (d + 63) // 64 * 64) for kind in _run_pair.kinds), _run_pair.kinds
+
+
+def test_carried_passes_on_the_streamed_filter_with_nan_rows_ties_and_lists_of_every_length():
+    x = _blobs(15000, 600, 25, seed=31)
+    x[5, 0] = numpy.nan
+    x[9, 7] = numpy.nan
+    x[100:110] = 3.0e3
+    x[200:260] = x[200]          # identical rows: ties
+    for list_max in (None, 0.0, 1.0):
+        _run_pair(x, 40, iters=10, carry_from=2, fused=True, list_max=list_max)
+    xu = _uniform(12000, 704, seed=4)     # unstructured: the bounds decide next to nothing, the policy pauses them
+    _run_pair(xu, 60, iters=14, carry_from=2, fused=False)
+
+
+def test_kmeans_cuda_default_schedule_carries_on_1024_feature_rows(monkeypatch):
+    """kmeans_cuda(yinyang_t = 0.1) on 1024-feature rows: bounds carried by the streamed filter behind the hand-over
+    point; KMCUDA_AMD_CARRY=0 runs the same passes plain.  Same progress lines, same results."""
+    from kmcuda_amd import kmeans_cuda
+    from test_gpu_kmeans import StdoutListener
+    x = _blobs(30000, 1024, 40, seed=19, spread=8.0)
+    monkeypatch.setenv("KMCUDA_AMD_CARRY_MAX", "1.0")   # (listed passes whatever the list's length: see above)
+    outs = []
+    for carry in ("1", "0"):
+        monkeypatch.setenv("KMCUDA_AMD_CARRY", carry)
+        out = StdoutListener()
+        with out:
+            cen, asg = kmeans_cuda(x, 64, init="random", seed=3, tolerance=0.0005, yinyang_t=0.1, device=1, verbosity=2)
+        text = out.text
+        lines = [l for l in text.split("\n") if l.startswith("iteration")]
+        outs.append((cen, asg, lines, text))
+    assert outs[0][2] == outs[1][2]
+    assert (outs[0][1] == outs[1][1]).all()
+    assert (outs[0][0].view(numpy.uint32) == outs[1][0].view(numpy.uint32)).all()
+    assert "carrying per-sample distance bounds" in outs[0][3]
+    spared = [l for l in outs[0][3].split("\n") if l.startswith("carried bounds:")]
+    assert spared and int(spared[0].split()[2]) > 0, spared
 
 
 def test_kmeans_cuda_default_schedule_carries_and_equals_the_plain_schedule(monkeypatch):

@@ -61,6 +61,100 @@ def test_wide_rows_bit_exact(n, d, k, cached):
     assert got[0][2][1] < n // 4
 
 
+@pytest.mark.parametrize("switch", ["KMCUDA_AMD_WIDE", "KMCUDA_AMD_GEMM"])
+def test_wide_rows_filter_off_is_the_exact_kernel(monkeypatch, switch):
+    monkeypatch.setenv(switch, "0")
+    rs = numpy.random.RandomState(3)
+    x = rs.rand(700, 640).astype(numpy.float32)
+    c = x[rs.choice(700, 40, replace=False)].copy()
+    (asg, prev, counters), = _passes(x, [c])
+    ref, ref_prev, ref_changed = oracle.lloyd_assign(x, c)
+    assert (asg == ref).all() and (prev == ref_prev).all() and counters[0] == ref_changed
+
+
+def test_wide_rows_ties_nans_nonfinite_centroids():
+    rs = numpy.random.RandomState(11)
+    n, d, k = 2500, 800, 96
+    x = rs.rand(n, d).astype(numpy.float32)
+    c = x[rs.choice(n, k, replace=False)].copy()
+    c[40] = c[3]          # duplicate centroids: exact ties, the lower index must win
+    c[77] = c[3]
+    c[10, 5] = numpy.nan  # NaN centroid: never chosen (kmeans.cu:425-426)
+    c[11, :] = numpy.inf
+    x[5, 0] = numpy.nan   # "insane" sample -> assignment K (kmeans.cu:312, :349-356)
+    x[6, 17] = numpy.nan  # NaN elsewhere: search fails, row left untouched
+    x[7] = c[3]           # exact hit on a duplicated centroid
+    x[8, 3] = numpy.inf
+    x[9, :] = 1e30        # centred halves overflow: never decided from half scores
+    for cached in (False, True):
+        (asg, prev, counters), = _passes(x, [c], cached=cached)
+        ref, ref_prev, ref_changed = oracle.lloyd_assign(x, c)
+        assert (asg == ref).all()
+        assert (prev == ref_prev).all()
+        assert counters[0] == ref_changed
+        assert asg[5] == k and asg[6] == 0xFFFFFFFF and asg[7] == 3
+
+
+def test_wide_rows_angular_and_half_rows():
+    rs = numpy.random.RandomState(17)
+    x = rs.randn(2000, 768).astype(numpy.float32)
+    x /= numpy.linalg.norm(x, axis=1)[:, None]
+    c = x[rs.choice(2000, 64, replace=False)].copy()
+    (asg, _, _), = _passes(x, [c], metric="cos")
+    ref, _, _ = oracle.lloyd_assign(x, c, metric=oracle.COS)
+    assert (asg != ref).mean() < 1e-3     # acosf: libm vs ocml (tests/test_gpu_lloyd.py::test_assign_angular)
+    # fp16x2 path: the rows as halves feed the row operand; results as on the widened values
+    xh = x.astype(numpy.float16).astype(numpy.float32)
+    ch = c.astype(numpy.float16).astype(numpy.float32)
+    (asg, prev, counters), = _passes(xh, [ch], half=True)
+    ref, ref_prev, ref_changed = oracle.lloyd_assign(xh, ch)
+    assert (asg == ref).all() and counters[0] == ref_changed
+
+
+def test_wide_rows_whole_run_through_the_boundary():
+    """kmeans_cuda() on 1024-feature rows: the stop rule on the device, the fp64 update, the row copy kept across the
+    iterations -- against the oracle's run from the same seeds (same stop iteration; assignments equal up to the
+    update's last-bit differences)."""
+    from kmcuda_amd import kmeans_cuda
+    rs = numpy.random.RandomState(2)
+    centres = rs.rand(40, 1024).astype(numpy.float32) * 4
+    x = (centres[rs.randint(0, 40, 6000)] + 0.5 * rs.randn(6000, 1024)).astype(numpy.float32)
+    cen, asg = kmeans_cuda(x, 40, init="k-means++", seed=7, tolerance=0.001, yinyang_t=0, device=1)
+    ocen, oasg, olog = oracle.kmeans(x, 40, init="k-means++", seed=7, tolerance=0.001, yinyang_t=0)
+    assert (asg != oasg).mean() < 1e-3
+    numpy.testing.assert_allclose(cen, ocen, rtol=2e-4, atol=2e-4)
+    ref, _, _ = oracle.lloyd_assign(x, cen)
+    assert (ref == asg).all()     # the returned assignments ARE the reference's for the returned centroids
+
+
+def test_wide_rows_yinyang_schedules(monkeypatch):
+    """yinyang_t > 0 on 768-feature rows: the default schedule keeps running Lloyd passes through the wide filter
+    (carrying bounds once the run goes on, tests/test_gpu_carry.py); the reference schedule runs the exact Yinyang
+    kernels (its bounds have no matrix-core filter at this width).
+    Same hand-over point and lines up to it; equally good clusterings."""
+    from kmcuda_amd import kmeans_cuda
+    from test_gpu_kmeans import StdoutListener
+    rs = numpy.random.RandomState(8)
+    centres = rs.rand(24, 768).astype(numpy.float32) * 3
+    x = (centres[rs.randint(0, 24, 5000)] + 0.4 * rs.randn(5000, 768)).astype(numpy.float32)
+    res = {}
+    for schedule in ("default", "reference"):
+        monkeypatch.delenv("KMCUDA_AMD_YY", raising=False)
+        if schedule == "reference":
+            monkeypatch.setenv("KMCUDA_AMD_YY", "reference")
+        out = StdoutListener()
+        with out:
+            c, a = kmeans_cuda(x, 24, init="k-means++", seed=3, tolerance=0.0005, yinyang_t=0.2, device=1, verbosity=1)
+        lines = [ln for ln in out.text.splitlines() if ln.startswith("iteration")]
+        res[schedule] = (lines, c, a, "refreshing Yinyang bounds" in out.text)
+    assert res["reference"][3] or len(res["reference"][0]) == len(res["default"][0])
+    assert not res["default"][3]
+    assert abs(len(res["default"][0]) - len(res["reference"][0])) <= 3
+    assert (res["default"][2] != res["reference"][2]).mean() < 0.02
+    ref, _, _ = oracle.lloyd_assign(x, res["default"][1])
+    assert (ref == res["default"][2]).all()
+
+
 def test_which_filter_serves_which_width(monkeypatch):
     """<= 256 features: register-resident (padded to 16 .. 256); above: streamed, padded to 64; KMCUDA_AMD_WIDE_MIN_D
     moves the border (513: the register-resident filter's 512-wide instantiation; results the same either way)."""
@@ -90,12 +184,11 @@ def test_which_filter_serves_which_width(monkeypatch):
     assert (asg == ref).all() and (prev == ref_prev).all() and counters[0] == ref_changed
 
 
-@pytest.mark.parametrize("d,carries", [(640, False), (320, True)])
-def test_set_carry_on_streamed_rows(d, carries):
-    """kmamd_set_carry on an engine whose rows take the streamed filter.  Beyond 512 features: accepted, nothing
-    carried, every pass a plain one.  257..512 features: the carried passes change to the register-resident filter (the
-    one that leaves and reads bounds; its own row copy over the same frozen mean) and back when the bounds are switched
-    off (include/kmcuda_amd.h: kmamd_filter_kind).  The oracle's assignments either way."""
+@pytest.mark.parametrize("d", [640, 320])
+def test_set_carry_on_streamed_rows(d):
+    """kmamd_set_carry on an engine whose rows take the streamed filter: it carries the bounds itself (MODE 2 / 3 of
+    lloyd_wide_kernel; tests/test_gpu_carry.py has the side-by-side loops).  The oracle's assignments in every pass, rows
+    spared while the bounds are on."""
     from kmcuda_amd.engine import Engine
     dev = torch.device("cuda", 0)
     rs = numpy.random.RandomState(9)
@@ -106,10 +199,11 @@ def test_set_carry_on_streamed_rows(d, carries):
     asg = torch.full((n,), -1, dtype=torch.int32, device=dev)
     prev = torch.full((n,), -1, dtype=torch.int32, device=dev)
     eng = Engine(n, d, k, "L2", device=0)
+    assert eng.filter_kind() == (2, (d + 63) // 64 * 64)
     eng.set_row_cache(True)
     ref_asg = None
     c = x[rs.choice(n, k, replace=False)].copy()
-    kinds = []
+    spared = []
     for it in range(9):
         if it == 2:
             eng.set_carry(True)
@@ -119,13 +213,10 @@ def test_set_carry_on_streamed_rows(d, carries):
         eng.lloyd_assign(xs, torch.from_numpy(c).to(dev), asg, prev)
         ref, ref_prev, ref_changed = oracle.lloyd_assign(x, c, assignments=ref_asg)
         assert (asg.cpu().numpy().view(numpy.uint32) == ref).all() and eng.counters()[0] == ref_changed
+        assert (prev.cpu().numpy().view(numpy.uint32) == ref_prev).all()
         ref_asg = ref
-        kinds.append(eng.filter_kind())
+        spared.append(eng.carry_stats()[0])
         c = (c + rs.randn(k, d).astype(numpy.float32) * 0.002).astype(numpy.float32)
-    streamed = (2, (d + 63) // 64 * 64)
-    if carries:
-        assert kinds == [streamed] * 2 + [(1, 512)] * 5 + [streamed] * 2, kinds
-        assert eng.carry_stats()[0] > n, eng.carry_stats()     # (tight blobs, tiny drifts: the bounds decide most rows)
-    else:
-        assert kinds == [streamed] * 9 and eng.carry_stats()[0] == 0, kinds
+    # bounds on from pass 2, which leaves them; pass 3 moves them and counts its would-be list; 4, 5 and 6 are listed
+    assert spared[3] == 0 and spared[6] > n and spared[8] == spared[6], spared
     eng.close()
