@@ -39,7 +39,7 @@ def main():
     trials = failures = 0
     while time.time() - t0 < budget:
         n = int(rs.choice([1500, 7000, 30000, 90000, 250000]))
-        d = int(rs.choice([12, 16, 24, 32, 48, 64, 100, 128, 200, 256, 300, 320, 384, 448, 512]))   # (257..512: both filters)
+        d = int(rs.choice([12, 16, 24, 32, 48, 64, 100, 128, 200, 256, 300, 320, 384, 448, 512, 640, 1024]))   # (beyond 256: the streamed filter)
         k = int(rs.choice([3, 17, 40, 64, 130, 300, 600]))
         k = min(k, n // 8)
         metric = str(rs.choice(["L2", "cos"]))
