@@ -12,5 +12,12 @@ import json
 d=json.loads(open("$OUT/bench_$TAG.json").read().strip().splitlines()[-1])
 print({k:d[k] for k in ("value","ms_per_step")}, d["roofline"]["frac"], d["roofline"]["kernel_ms"], d["roofline"]["traffic_source"], d["breakdown_ms_per_step"], d.get("verify",{}).get("ok"), d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"])
 PY
-timeout 400 python scripts/stress_carry.py 240 55 > $OUT/stress_carry_$TAG.log 2>&1; echo "stress rc=$?"; tail -3 $OUT/stress_carry_$TAG.log
-timeout 300 python scripts/stress_carry_api.py 120 56 > $OUT/stress_carry_api_$TAG.log 2>&1; echo "stress api rc=$?"; tail -3 $OUT/stress_carry_api_$TAG.log
+timeout 400 python scripts/stress_carry.py 200 57 > $OUT/stress_carry_$TAG.log 2>&1; echo "stress rc=$?"; tail -3 $OUT/stress_carry_$TAG.log
+timeout 300 python scripts/stress_carry_api.py 60 58 > $OUT/stress_carry_api_$TAG.log 2>&1; echo "stress api rc=$?"; tail -3 $OUT/stress_carry_api_$TAG.log
+for shape in "2000000 1024 100000" "4000000 384 100000"; do set -- $shape
+timeout 300 python bench.py --samples $1 --features $2 --steps 10 --warmup 5 --no-cpu-baseline --no-api-leg --verify-rows $3 > $OUT/bench_wide_${1}x${2}_$TAG.json 2>/dev/null
+python3 -c "
+import json
+d=json.loads(open('$OUT/bench_wide_${1}x${2}_$TAG.json').read().strip().splitlines()[-1])
+print('$1 x $2', {k:d[k] for k in ('value','ms_per_step')}, d['breakdown_ms_per_step'], d.get('verify',{}).get('ok'))" | tee -a $OUT/wide_shapes_$TAG.log
+done
