@@ -112,10 +112,12 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if (getenv("KMCUDA_AMD_DEBUG")) g_verbosity = atoi(getenv("KMCUDA_AMD_DEBUG"));
   if (const char *f = getenv("KMCUDA_AMD_FILTER")) filter_mode_ = strcmp(f, "f32") == 0 ? 1 : 0;
   if (const char *c = getenv("KMCUDA_AMD_ROW_CACHE")) row_cache_allowed_ = atoi(c) != 0;
-  // Pair certificates: L2 only by default.  The angular ones (the gap by which both contenders' scores exceed every
-  // other centroid's) gave a whole call that differed from plain passes in one of round 5's randomised trials (300 000
-  // x 16 half rows, K = 130: scripts/stress_replay_api.py 58 ..., profiles/r5al_*; rounds 4's build differs on it
-  // too) and the flaw has not been found: KMCUDA_AMD_CARRY_PAIRS=1 switches them on for that search, =0 all of them off.
+  // Pair certificates: L2 only by default.  With the angular ones a whole call differed from plain passes in one of
+  // round 5's randomised trials (300 000 x 16 half rows, K = 130: scripts/stress_replay_api.py 58 ..., profiles/r5al_*;
+  // round 4's build too).  Cause (DESIGN_LOG 13.13): the reference's distance is p >= 1 ? 0 : acos(p), so centroids whose
+  // products with a row reach 1 tie and the lowest index wins; the pair kernel's exact arithmetic follows that, the
+  // filters of the plain passes commit the largest product.  Until the filters leave such rows to the exact kernels the
+  // default keeps "carried == plain": KMCUDA_AMD_CARRY_PAIRS=1 switches the angular certificates on, =0 all of them off.
   carry_pairs_ = metric == 0;
   if (const char *c = getenv("KMCUDA_AMD_CARRY_PAIRS")) carry_pairs_ = atoi(c) != 0;
   if (const char *c = getenv("KMCUDA_AMD_SETTLE")) settle_ = atoi(c) != 0;
