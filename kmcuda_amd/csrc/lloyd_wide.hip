@@ -1,6 +1,6 @@
-// lloyd_wide.hip -- the Lloyd assignment filter for feature counts beyond the register-resident kernels
-// (D > 512: lloyd_f16.hip keeps a wave's rows in registers as the matrix-core B operand, which stops at 512
-// features), reference: kmeans_assign_lloyd, src/kmeans.cu:293-364 (any D).
+// lloyd_wide.hip -- the Lloyd assignment filter for rows wider than 256 features (lloyd_f16.hip keeps a wave's rows
+// in registers as the matrix-core B operand: that stops at 512 features, and from 257 on this kernel is the faster
+// one -- engine.cpp, Engine::init), reference: kmeans_assign_lloyd, src/kmeans.cu:293-364 (any D).
 //
 // Same decision chain as the two-stage filter: coarse hi.hi scores on the f16 matrix cores with a
 // rigorous bound -> the contenders of the undecided rows in fp32 -> two exact chains / full exact scan.  Until round 4
@@ -15,6 +15,8 @@
 //                    best / second-best per row kept in registers across the K / 256 centroid blocks exactly as
 //                    lloyd_coarse2_kernel keeps them (index bits packed into the score); at the end the same bound
 //                    E_c decides: commit, or list the row with its CUT-OFF (best - 2 E_c)
+//   lloyd_wide<2/3>  <0> with carried bounds (lloyd_carry.hip): over every row / over the rows the moved bounds no
+//                    longer decide (gathered by index), each row leaving with fresh bounds from its best two scores
 //   lloyd_wide<1>    the listed rows only, the same sweep (same operands, same products, same order: the same
 //                    scores): every centroid whose score reaches the row's cut-off is a CONTENDER (<= 16 kept)
 //   wide_contenders  one wave per listed row: the contenders scored in fp32 (x' . c' + bias), decided with the f32

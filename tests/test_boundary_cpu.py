@@ -195,7 +195,7 @@ def test_carried_bounds_host_policy_without_gpu():
 
 
 def test_no_vendor_gemm_on_the_assignment_path():
-    """Round 5: the D > 512 filter is a hand-written kernel (lloyd_wide.hip); the library neither links nor dlopens
+    """Round 5: the D > 256 filter is a hand-written kernel (lloyd_wide.hip); the library neither links nor dlopens
     rocBLAS / hipBLASLt any more."""
     import os
     from kmcuda_amd import _lib
