@@ -112,13 +112,14 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   if (getenv("KMCUDA_AMD_DEBUG")) g_verbosity = atoi(getenv("KMCUDA_AMD_DEBUG"));
   if (const char *f = getenv("KMCUDA_AMD_FILTER")) filter_mode_ = strcmp(f, "f32") == 0 ? 1 : 0;
   if (const char *c = getenv("KMCUDA_AMD_ROW_CACHE")) row_cache_allowed_ = atoi(c) != 0;
-  // Pair certificates: L2 only by default.  With the angular ones a whole call differed from plain passes in one of
-  // round 5's randomised trials (300 000 x 16 half rows, K = 130: scripts/stress_replay_api.py 58 ..., profiles/r5al_*;
-  // round 4's build too).  Cause (DESIGN_LOG 13.13): the reference's distance is p >= 1 ? 0 : acos(p), so centroids whose
-  // products with a row reach 1 tie and the lowest index wins; the pair kernel's exact arithmetic follows that, the
-  // filters of the plain passes commit the largest product.  Until the filters leave such rows to the exact kernels the
-  // default keeps "carried == plain": KMCUDA_AMD_CARRY_PAIRS=1 switches the angular certificates on, =0 all of them off.
-  carry_pairs_ = metric == 0;
+  // Pair certificates (lloyd_carry.hip): on under both metrics; KMCUDA_AMD_CARRY_PAIRS=0 is the A/B.  (Round 5 had the
+  // angular ones off: a randomised whole call -- 300 000 x 16 half rows, K = 130 -- ended on other centroids with them
+  // than with plain passes.  Cause, DESIGN_LOG 13.13: the reference's distance is p >= 1 ? 0 : acos(p), centroids whose
+  // products with a row reach 1 tie and the lowest index wins; the pair kernel's exact arithmetic followed that, the
+  // filters of the plain passes committed the largest product -- and which rows went which way depended on the host's
+  // timing-dependent list reports, hence run-to-run differences.  Round 6: every filter leaves such rows to the exact
+  // kernels (filter_common.hpp: clamp_limits), so every path gives the reference's answer.)
+  carry_pairs_ = true;
   if (const char *c = getenv("KMCUDA_AMD_CARRY_PAIRS")) carry_pairs_ = atoi(c) != 0;
   if (const char *c = getenv("KMCUDA_AMD_SETTLE")) settle_ = atoi(c) != 0;
   if (const char *c = getenv("KMCUDA_AMD_WIDE")) wide_ok_ = atoi(c) != 0;
@@ -564,7 +565,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
         uint16_t *xc = nullptr;
         float *xm = nullptr;
         // no memory for the copy: not an error, the operands are converted from the rows every pass
-        if (alloc(&xc, npad * DP_) == kSuccess && alloc(&xm, npad * 2 + 2) == kSuccess) {
+        if (alloc(&xc, npad * DP_) == kSuccess && alloc(&xm, npad * 3 + 2) == kSuccess) {
           xcache_ = xc;
           xmeta_ = xm;
         } else {

@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_kernel(
   // kernel (the argmin is translation invariant; centring shrinks the norms in the error bound)
   float xb[NK];
   float xo2 = 0.f;  // squared norm of the ORIGINAL half row (bound on the reference's own error)
+  float xm = 0.f, xma = 0.f;  // x.mu and sum |x_f mu_f|: score + x.mu = the product (angular clamp, filter_common.hpp)
   {
     const bool live = s < N;
     if (FAST) {
@@ -243,6 +244,9 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_kernel(
       for (int j = 0; j < NK / 4; j++) {
         const f32x4 v = src[j], m = msrc[j];
         xo2 = fmaf(v.x, v.x, xo2); xo2 = fmaf(v.y, v.y, xo2); xo2 = fmaf(v.z, v.z, xo2); xo2 = fmaf(v.w, v.w, xo2);
+        xm = fmaf(v.x, m.x, xm); xm = fmaf(v.y, m.y, xm); xm = fmaf(v.z, m.z, xm); xm = fmaf(v.w, m.w, xm);
+        xma = fmaf(fabsf(v.x), fabsf(m.x), xma); xma = fmaf(fabsf(v.y), fabsf(m.y), xma);
+        xma = fmaf(fabsf(v.z), fabsf(m.z), xma); xma = fmaf(fabsf(v.w), fabsf(m.w), xma);
         xb[4 * j + 0] = live ? v.x - m.x : 0.f;
         xb[4 * j + 1] = live ? v.y - m.y : 0.f;
         xb[4 * j + 2] = live ? v.z - m.z : 0.f;
@@ -254,8 +258,11 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_kernel(
       for (int j = 0; j < NK; j++) {
         const uint32_t f = h * NK + j;
         const float v = (live && f < D) ? src[f] : 0.f;
+        const float mf = (f < D) ? mu[f] : 0.f;
         xo2 = fmaf(v, v, xo2);
-        xb[j] = (live && f < D) ? v - mu[f] : 0.f;
+        xm = fmaf(v, mf, xm);
+        xma = fmaf(fabsf(v), fabsf(mf), xma);
+        xb[j] = (live && f < D) ? v - mf : 0.f;
       }
     }
     if (!live) xo2 = 0.f;
@@ -266,6 +273,8 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_kernel(
   for (int j = 0; j < NK; j++) xn2 = fmaf(xb[j], xb[j], xn2);
   xn2 += __shfl_xor(xn2, 32);
   xo2 += __shfl_xor(xo2, 32);
+  xm += __shfl_xor(xm, 32);
+  xma += __shfl_xor(xma, 32);
   const float x0 = __shfl(xb[0], col);  // feature 0 lives in the lower half-wave (NaN - mu = NaN)
   const bool insane = (x0 != x0);
 
@@ -383,7 +392,9 @@ __global__ __launch_bounds__(256, 2) void lloyd_filter_kernel(
   const float e_mfma = 2.0f * eps * (xn * cmaxc + bmaxc);
   const float e_ref = 5.9604645e-8f * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
   const float thr = 2.0f * (e_mfma + e_ref) * 1.001f + tie_slack;
-  filter_finish(v1, v2, v3, c1, c2, h, lane, s, N, K, insane, thr, assignments, assignments_prev, flagged, pairs,
+  // (tie_slack != 0 <=> the angular metric, engine.cpp)
+  const ClampLimits lim = clamp_limits(tie_slack > 0.f, xm, dot_error(DP, xma), 0.5f * thr);
+  filter_finish(v1, v2, v3, c1, c2, h, lane, s, N, K, insane, thr, lim, assignments, assignments_prev, flagged, pairs,
                 counters);
 }
 

@@ -101,8 +101,15 @@ __global__ __launch_bounds__(kSkipBlock) void carry_skip_kernel(
           // score space: s(c) = x'.c' + mu.c' moves by at most ||x'|| ||c_new - c_old|| plus the change db(c) of its
           // second term, known per centroid: the certified gap shrinks by the first for the row's centroid and for the
           // best of the others, and by max_c db(c) - db(a)
+          // The stored gap is also the room of the other centroids' products below the clamp at 1 and of the row's own
+          // above the one at -1 (the reference's angular distance is flat beyond either, metric_abstraction.h:171-177:
+          // ties, lowest index wins -- filter_common.hpp).  Those two move by ONE side each -- the others' scores rise
+          // by at most B, the row's own falls by at most A -- so each side is charged at least 0: the sum bounds the
+          // gap's loss and either room's.
           const float xn = sqrtf(xn2) * 1.0001f;
-          const float g = ub[s] - (xn * (drift[a] + maxdrift) + (maxdb - drift[K + a]) + eb) * 1.000001f;
+          const float sideA = fmaxf(xn * drift[a] - drift[K + a] + 0.5f * eb, 0.f);
+          const float sideB = fmaxf(xn * maxdrift + maxdb + 0.5f * eb, 0.f);
+          const float g = ub[s] - (sideA + sideB) * 1.000001f;
           keep = g > 4.1f * e_ref + 2.0f * tie_slack;   // (-inf, NaN: false)
           if (keep && !probe) {
             ub[s] = g * 0.999999f;
@@ -114,8 +121,8 @@ __global__ __launch_bounds__(kSkipBlock) void carry_skip_kernel(
             if (l3s > 0.f) {
               const uint32_t q1 = cy.p1[s], q2 = cy.p2[s];
               if ((a == q1 || a == q2) && q1 < K && q2 < K && q1 != q2 && finite[q1] != 0u && finite[q2] != 0u) {
-                const float g2 = l3s - (xn * (fmaxf(drift[q1], drift[q2]) + maxdrift) +
-                                        (maxdb - fminf(drift[K + q1], drift[K + q2])) + eb) * 1.000001f;
+                const float sideP = fmaxf(xn * fmaxf(drift[q1], drift[q2]) - fminf(drift[K + q1], drift[K + q2]) + 0.5f * eb, 0.f);
+                const float g2 = l3s - (sideP + sideB) * 1.000001f;
                 pair = g2 > 4.1f * e_ref + 2.0f * tie_slack;
                 if (pair && !probe) l3[s] = g2 * 0.999999f;
               }

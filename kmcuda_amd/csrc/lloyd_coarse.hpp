@@ -110,6 +110,8 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
 
   f16x8 xa[KS], xb[TWO ? KS : 1];
   float xn2a = 0.f, x0a = 0.f, xn2b = 0.f, x0b = 0.f;
+  // x.mu and sum |x_f mu_f| per row: score + x.mu = the product, which the angular metric clamps (filter_common.hpp)
+  float xdma = 0.f, xdmb = 0.f, xaba = 0.f, xabb = 0.f;
   // both rows of a lane per k-step, sharing the mean chunk.  Lanes without a row read row 0: an MFMA
   // column only feeds its own outputs and theirs are never committed, so nothing is masked.
   auto load_chunk = [&](uint32_t s, bool live, int j, float (&xv)[8]) {
@@ -342,8 +344,10 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   uint32_t und_count = 0, changed_count = 0;
   unsigned long long uma = 0, umb = 0;
   bool unda = false, undb = false;
-  auto finish = [&](uint32_t s, bool live, float v1, float v2, uint32_t tb, float xn2, float x0, float dx2, bool &und,
-                    unsigned long long &um, float &cut) {
+  const bool angular = tie_slack > 0.f;   // (engine.cpp: the angular metric's plateau slack; 0 under L2)
+  // xdm = x.mu, xab >= sum |x_f mu_f| (< 0: not summed here -- the row cache's record: ||x|| ||mu|| bounds it)
+  auto finish = [&](uint32_t s, bool live, float v1, float v2, uint32_t tb, float xn2, float x0, float dx2, float xdm,
+                    float xab, bool &und, unsigned long long &um, float &cut) {
     const bool insane = (x0 != x0);  // kmeans.cu:312
     const uint32_t r = __float_as_uint(v1) & 15u;
     uint32_t i1 = tb * 32u + (r & 3u) + 8u * (r >> 2) + 4u * h;
@@ -368,7 +372,9 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     const float e_ref = u * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
     const float thr = 2.0f * (e_c + e_ref) * 1.001f + tie_slack;
     const bool in_range = (xn < 6.0e4f) && (cmaxc < 6.0e4f) && (v1 > -1.0e38f) && (i1 < K);
-    const bool certain = insane || (in_range && ((v1 - v2) > thr));  // NaN gap / thr => not certain
+    // angular: no centroid but the best may reach the clamp at product 1, the best not the one at -1 (filter_common.hpp)
+    const ClampLimits lim = clamp_limits(angular, xdm, dot_error(DP, xab >= 0.f ? xab : xo * mu_norm), 0.5f * thr);
+    const bool certain = insane || (in_range && ((v1 - v2) > thr) && (v2 < lim.hi) && (v1 > lim.lo));  // NaN anywhere => not certain
     const bool mine = (h == 0) && live;
     bool changed = false;
     if (mine && certain) changed = commit_row(s, insane ? K : i1, assignments, assignments_prev);
@@ -382,8 +388,11 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
       if (mine && cy.angular) {
         // the certified gap of the scores (= products up to a term constant in c): what is left of it after the
         // centroids' moves is what carry_skip_kernel tests
+        // (and the room of the others' products below 1 / of the best one's above -1, which the same drifts use up:
+        //  carry_skip_kernel charges the two sides' moves separately, each at least 0)
         const float e = e_c * 1.001f;
-        float gapv = (certain && !insane && in_range) ? ((v1 - e) - (v2 + e)) * 0.999999f : -INFINITY;
+        float gapv = (certain && !insane && in_range)
+                         ? fminf(fminf((v1 - e) - (v2 + e), lim.hi - v2), v1 - lim.lo) * 0.999999f : -INFINITY;
         if (!(gapv == gapv)) gapv = -INFINITY;
         cy.ub[s] = gapv;
         if (cy.l3) cy.l3[s] = 0.f;   // (no pair statement)
@@ -406,7 +415,9 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     }
     // what the refine stage may drop: a centroid whose coarse score is below best - thr cannot be the
     // reference's nearest (both scores are within thr / 2 of the reference's); NaN = no such statement
+    // (angular: nor one whose product may reach 1 -- every such centroid ties with the best at distance 0)
     cut = in_range ? v1 - thr : __builtin_nanf("");
+    if (angular) cut = (lim.hi == lim.hi) ? fminf(cut, lim.hi) : __builtin_nanf("");
     const unsigned long long cm = __ballot(changed);
     um = __ballot(und);
     changed_count += (uint32_t)__popcll(cm);
@@ -418,11 +429,30 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     xn2a = ma.x; dx2a = ma.y; xn2b = mb.x; dx2b = mb.y;
     x0a = (ma.y == -1.f) ? __builtin_nanf("") : 0.f;
     x0b = (mb.y == -1.f) ? __builtin_nanf("") : 0.f;
+    xaba = xabb = -1.f;
+    if (angular) {   // x.mu: the third table of the row cache (row_cache_kernel)
+      const float *xdot = xmeta + 2 * (((size_t)N + 255) / 256 * 256) + 2;
+      xdma = xdot[sA];
+      xdmb = xdot[TWO ? sB : sA];
+    }
+  } else if (angular) {   // no record: the rows once more (a loop of its own, the L2 passes keep their registers)
+    const uint32_t fb = (uint32_t)(h * NKH), fe = min(fb + (uint32_t)NKH, D);
+    if (fb < fe) {
+      if constexpr (HALF_ROWS) {
+        row_dot_mu(reinterpret_cast<const _Float16 *>(rows) + (size_t)(liveA ? sA : 0u) * D, mu, fb, fe, xdma, xaba);
+        if constexpr (TWO) row_dot_mu(reinterpret_cast<const _Float16 *>(rows) + (size_t)(liveB ? sB : 0u) * D, mu, fb, fe, xdmb, xabb);
+      } else {
+        row_dot_mu(reinterpret_cast<const float *>(rows) + (size_t)(liveA ? sA : 0u) * D, mu, fb, fe, xdma, xaba);
+        if constexpr (TWO) row_dot_mu(reinterpret_cast<const float *>(rows) + (size_t)(liveB ? sB : 0u) * D, mu, fb, fe, xdmb, xabb);
+      }
+    }
+    xdma += __shfl_xor(xdma, 32); xaba += __shfl_xor(xaba, 32);
+    xdmb += __shfl_xor(xdmb, 32); xabb += __shfl_xor(xabb, 32);
   }
   float cuta, cutb;
-  finish(sA, liveA, v1a, v2a, tba, xn2a, x0a, dx2a, unda, uma, cuta);
+  finish(sA, liveA, v1a, v2a, tba, xn2a, x0a, dx2a, xdma, xaba, unda, uma, cuta);
   cutb = 0.f;
-  if constexpr (TWO) finish(sB, liveB, v1b, v2b, tbb, xn2b, x0b, dx2b, undb, umb, cutb);
+  if constexpr (TWO) finish(sB, liveB, v1b, v2b, tbb, xn2b, x0b, dx2b, xdmb, xabb, undb, umb, cutb);
   // ONE pair of global atomics per block, not three per wave: the counters share a cache line, same-address
   // atomics are served one at a time by L2 (measured round 2: 11 ns each in a kernel that did nothing else), and
   // 125 K waves per launch all arrive with theirs at the end of the same scheduling round

@@ -307,6 +307,9 @@ template <int DP, bool HALF_ROWS, bool FAST>
 __global__ __launch_bounds__(256) void row_cache_kernel(const void *__restrict__ rows, uint32_t N, uint32_t D,
                                                         const float *__restrict__ mu, f16x8 *__restrict__ xcache,
                                                         float2 *__restrict__ xmeta, uint32_t nblocks32) {
+  // (x.mu per row behind the records and ||mu||: score + x.mu = the product, which the angular metric clamps at 1 / -1,
+  //  filter_common.hpp)
+  float *__restrict__ xdot = reinterpret_cast<float *>(xmeta) + 2 * ((size_t)nblocks32 * 32) + 2;
   constexpr int NKH = DP / 2, KS = NKH / 8;
   const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
   // (a wave per 32-row block, strided from a bounded grid: kernels.hpp, wave_row_grid)
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(256) void row_cache_kernel(const void *__restrict__
   const uint32_t s = b * 32u + col;
   const bool live = s < N;
   const size_t row = (size_t)(live ? s : 0);
-  float xn2 = 0.f, dx2 = 0.f, x0 = 0.f;
+  float xn2 = 0.f, dx2 = 0.f, x0 = 0.f, xdm = 0.f;
 #pragma unroll
   for (int j = 0; j < KS; j++) {
     float xv[8];
@@ -347,7 +350,9 @@ __global__ __launch_bounds__(256) void row_cache_kernel(const void *__restrict__
     f16x8 hi;
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-      const float xc = live ? xv[q] - mu[h * NKH + 8 * j + q] : 0.f;   // mu: DP floats, zero beyond D
+      const float mq = mu[h * NKH + 8 * j + q];                        // mu: DP floats, zero beyond D
+      const float xc = live ? xv[q] - mq : 0.f;
+      xdm = fmaf(live ? xv[q] : 0.f, mq, xdm);
       const _Float16 a = (_Float16)xc;
       const float r = xc - (float)a;   // exact; what the hi.hi products drop on this side
       hi[q] = a;
@@ -359,6 +364,8 @@ __global__ __launch_bounds__(256) void row_cache_kernel(const void *__restrict__
   }
   xn2 += __shfl_xor(xn2, 32);
   dx2 += __shfl_xor(dx2, 32);
+  xdm += __shfl_xor(xdm, 32);
+  if (h == 0) xdot[s] = xdm;
   // record = (||x'||^2, ||x' - hi(x')||^2); a NaN first feature (kmeans.cu:312) is flagged by -1
   if (h == 0) xmeta[s] = make_float2(xn2, (x0 != x0) ? -1.f : dx2 * 1.0001f);   // xmeta covers the padded row count
   }

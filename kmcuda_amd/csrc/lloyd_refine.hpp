@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
     // 8M-row pass, profiles/r3j_*.)
     constexpr int FC = NKH < 64 ? NKH : 64, NCHUNK = NKH / FC;
     float xn2 = 0.f, xo2 = 0.f, x0 = 0.f;
+    float xdm = 0.f, xab = 0.f;   // x.mu, sum |x_f mu_f|: the angular clamp (filter_common.hpp)
     float v1 = -INFINITY, v2 = -INFINITY, v3 = -INFINITY;
     uint32_t i1 = 0xFFFFFFFFu, i2 = 0xFFFFFFFFu;
     float part[kRefineCap];
@@ -326,6 +327,12 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
     }
     xn2 += __shfl_xor(xn2, 32);
     xo2 += __shfl_xor(xo2, 32);
+    if (tie_slack > 0.f) {   // angular (block-uniform): the row once more, from the caches
+      const uint32_t fb = (uint32_t)(h * NKH), fe = min(fb + (uint32_t)NKH, D);
+      if (fb < fe) row_dot_mu(samples + (size_t)s * D, mu, fb, fe, xdm, xab);
+      xdm += __shfl_xor(xdm, 32);
+      xab += __shfl_xor(xab, 32);
+    }
     x0 = __shfl(x0, col);   // feature 0 lives in the lower half-wave; only its NaN-ness matters (kmeans.cu:312)
     const bool insane = (x0 != x0);
     const float xn = sqrtf(xn2) * 1.0001f, xo = sqrtf(xo2) * 1.0001f;
@@ -334,8 +341,12 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
     const float thr = 2.0f * (e_mfma + e_ref) * 1.001f + tie_slack;
     // (ranges: the contender lists came out of half operands)
     const bool in_range = usable && (xn < 6.0e4f) && (cmaxc < 6.0e4f) && i1 < K;
-    const bool certain = insane || (in_range && ((v1 - v2) > thr));
-    const bool two = !certain && in_range && ((v1 - v3) > thr) && i2 < K;
+    // Angular: the centroids a decision rules out must stay below the clamp at product 1, its winner above the one at
+    // -1 (filter_common.hpp).  The centroids that are NOT on the list scored below stage 1's cut-off, which is at most
+    // stage 1's own limit: their products are below 1 already.
+    const ClampLimits lim = clamp_limits(tie_slack > 0.f, xdm, dot_error(DP, xab), 0.5f * thr);
+    const bool certain = insane || (in_range && ((v1 - v2) > thr) && (v2 < lim.hi) && (v1 > lim.lo));
+    const bool two = !certain && in_range && ((v1 - v3) > thr) && (v3 < lim.hi) && (v1 > lim.lo) && i2 < K;
     const bool mine = (h == 0) && live;
     const bool pair_now = mine && two, flag_now = mine && !certain && !two;
     bool changed = false;
@@ -359,8 +370,12 @@ __global__ __launch_bounds__(256, 2) void lloyd_refine_kernel(
           const float e_c = 2.0f * eps * (xn * cmaxc + bmaxc) + (xn * dcmax + dxw * cmaxc + dxw * dcmax) * 1.001f +
                             6e-8f * sqrtf((float)DP) * (xn + cmaxc) + 2.0e-6f * (1.001f * xn * cmaxc + bmaxc);
           const float w = fmaxf(rest + e_c * 1.001f, v3 + e);
-          if (n == 1) gapv = ((v1 - e) - w) * 0.999999f;
-          else if (i2 < K) pairg = ((v2 - e) - w) * 0.999999f;
+          // (and the rooms below the clamp at product 1 / above the one at -1, which the same drifts use up: the
+          //  others' upper bound w against lim.hi, the winner's / the weaker contender's score against lim.lo;
+          //  carry_skip_kernel charges the two sides' moves separately, each at least 0)
+          const float room_hi = lim.hi - w;
+          if (n == 1) gapv = fminf(fminf((v1 - e) - w, room_hi), v1 - lim.lo) * 0.999999f;
+          else if (i2 < K) pairg = fminf(fminf((v2 - e) - w, room_hi), v2 - lim.lo) * 0.999999f;
           if (!(gapv == gapv)) gapv = -INFINITY;
           if (!(pairg > 0.f)) pairg = 0.f;   // (NaN too)
         }

@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void row_halves_kernel(const void *__restrict_
     for (uint32_t f = lane; f < DG; f += 64) m2 = fmaf(mu[f], mu[f], m2);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m2 += __shfl_xor(m2, off);
-    if (lane == 0) meta[N] = make_float4(sqrtf(m2) * 1.0001f, 0.f, 0.f, 0.f);
+    // (.y: ||mu||^2 as summed -- x.mu = (||x||^2 + ||mu||^2 - ||x - mu||^2) / 2, the angular clamp, filter_common.hpp)
+    if (lane == 0) meta[N] = make_float4(sqrtf(m2) * 1.0001f, m2, 0.f, 0.f);
   }
   for (uint32_t r = blockIdx.x * 4 + wave; r < N; r += gridDim.x * 4) {   // (kernels.hpp: wave_row_grid)
     float n2 = 0.f, d2 = 0.f, o2 = 0.f, x0 = 0.f;
@@ -236,8 +237,10 @@ __global__ __launch_bounds__(512) void lloyd_wide_kernel(
   for (int q = 0; q < 4; q++) stage_piece(true, q, 0, 0);
 
   for (uint32_t pass = 0; pass < npass; pass++) {
-    // this pass's 256 biases (the floor past the panel); the last pass's readers have passed a barrier since (NC >= 2:
-    // these rows have more than 512 features)
+    // this pass's 256 biases (the floor past the panel); with two or more chunks per pass the last pass's readers have
+    // passed a barrier since -- with ONE (rows of up to 64 features: KMCUDA_AMD_WIDE_MIN_D, the tests' way to this filter
+    // at every width) a fast wave would overwrite the biases a slow one has not read yet
+    if (NC == 1 && pass != 0) __syncthreads();
     if (tid < 256) {
       const uint32_t c = pass * kWideCents + (uint32_t)tid;
       biasw[tid] = c < K_pad64 ? biashi[c] : -3.0e38f;
@@ -410,7 +413,12 @@ __global__ __launch_bounds__(512) void lloyd_wide_kernel(
       const float e_ref = u * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
       const float thr = 2.0f * (e_c + e_ref) * 1.001f + tie_slack;
       const bool in_range = (xn < 6.0e4f) && (cmaxc < 6.0e4f) && (b1 > -1.0e38f) && (i1 < K);
-      const bool certain = insane || (in_range && ((b1 - b2) > thr));   // NaN gap / thr => not certain
+      // angular: no centroid but the best may reach the clamp at product 1, the best not the one at -1
+      // (filter_common.hpp); x.mu from the three squared norms on record, each an fp32 sum of DG terms
+      const bool angular = tie_slack > 0.f;
+      const float mun2 = meta[N].y;
+      const ClampLimits lim = clamp_limits(angular, 0.5f * ((m.w + mun2) - m.x), dot_error((int)DG, (m.w + mun2) + m.x), 0.5f * thr);
+      const bool certain = insane || (in_range && ((b1 - b2) > thr) && (b2 < lim.hi) && (b1 > lim.lo));   // NaN anywhere => not certain
       const bool mine = (h == 0) && live[s];
       bool changed = false;
       if (mine && certain) changed = commit_row(srow[s], insane ? K : i1, assignments, assignments_prev);
@@ -421,7 +429,9 @@ __global__ __launch_bounds__(512) void lloyd_wide_kernel(
         // stages decide may end on another contender than i1: its lower bound is void (0), its upper bound holds.
         const float e = e_c * 1.001f;
         if (cy.angular) {
-          float gapv = (certain && !insane && in_range) ? ((b1 - e) - (b2 + e)) * 0.999999f : -INFINITY;
+          // (with the rooms below the clamp at product 1 / above the one at -1: lloyd_coarse.hpp)
+          float gapv = (certain && !insane && in_range)
+                           ? fminf(fminf((b1 - e) - (b2 + e), lim.hi - b2), b1 - lim.lo) * 0.999999f : -INFINITY;
           if (!(gapv == gapv)) gapv = -INFINITY;
           cy.ub[srow[s]] = gapv;
         } else {
@@ -440,6 +450,8 @@ __global__ __launch_bounds__(512) void lloyd_wide_kernel(
         }
       }
       cut[s] = in_range ? b1 - thr : __builtin_nanf("");
+      // (angular: a centroid whose product may reach 1 ties with the best at distance 0 -- a contender)
+      if (angular) cut[s] = (lim.hi == lim.hi) ? fminf(cut[s], lim.hi) : __builtin_nanf("");
       um[s] = __ballot(und[s]);
       changed_count += (uint32_t)__popcll(__ballot(changed));
       und_count += (uint32_t)__popcll(um[s]);
@@ -537,6 +549,7 @@ __global__ __launch_bounds__(256, 4) void wide_contenders_kernel(
 #pragma unroll
     for (int i = 0; i < kWideCap; i++) acc[i] = 0.f;
     float xn2 = 0.f, xo2 = 0.f, x0 = 0.f;
+    float xdm = 0.f, xab = 0.f;   // x.mu, sum |x_f mu_f|: the angular clamp (filter_common.hpp)
     const float *xr = samples + (size_t)s * D;
     // two 256-feature slices per trip, both slices' loads in flight before the first product: the stage is a chain
     // of round trips to L2 / the Infinity Cache (a 4-MB fp32 panel does not stay in L2), not arithmetic
@@ -588,6 +601,19 @@ __global__ __launch_bounds__(256, 4) void wide_contenders_kernel(
 #pragma unroll
       for (int i = 0; i < kWideCap; i++) acc[i] += __shfl_xor(acc[i], off);
     }
+    if (tie_slack > 0.f) {   // angular: the row once more, from the caches (a loop of its own: the L2 passes keep their registers)
+#pragma unroll 2
+      for (uint32_t f = lane; f < D; f += 64) {
+        const float x = xr[f], m = mu[f];
+        xdm = fmaf(x, m, xdm);
+        xab = fmaf(fabsf(x), fabsf(m), xab);
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        xdm += __shfl_xor(xdm, off);
+        xab += __shfl_xor(xab, off);
+      }
+    }
     x0 = __shfl(x0, 0);
     float v1 = -INFINITY, v2 = -INFINITY, v3 = -INFINITY;
     uint32_t i1 = 0xFFFFFFFFu, i2 = 0xFFFFFFFFu;
@@ -610,10 +636,16 @@ __global__ __launch_bounds__(256, 4) void wide_contenders_kernel(
     const float e_ref = u * (12.0f * xo * cmaxo + 4.0f * cmaxo * cmaxo);
     const float thr = 2.0f * (e_mfma + e_ref) * 1.001f + tie_slack;
     const bool in_range = usable && (xn < 6.0e4f) && (cmaxc < 6.0e4f) && i1 < K;
-    const bool certain = insane || (in_range && ((v1 - v2) > thr));
-    const bool two = !certain && in_range && ((v1 - v3) > thr) && i2 < K;
-    const bool multi = live && !certain && !two && usable;
-    const bool pair_now = live && two, flag_now = live && !certain && !two && !usable;
+    // Angular: what a decision rules out must stay below the clamp at product 1, its winner above the one at -1
+    // (filter_common.hpp); the centroids that are not on the list scored below stage 1's cut-off <= its own limit.
+    // The exact chains over a longer list follow the clamp themselves -- unless every product may sit at -1, where the
+    // lowest index of ALL centroids wins: the full scan's.
+    const bool angular = tie_slack > 0.f;
+    const ClampLimits lim = clamp_limits(angular, xdm, dot_error((int)DG, xab), 0.5f * thr);
+    const bool certain = insane || (in_range && ((v1 - v2) > thr) && (v2 < lim.hi) && (v1 > lim.lo));
+    const bool two = !certain && in_range && ((v1 - v3) > thr) && (v3 < lim.hi) && (v1 > lim.lo) && i2 < K;
+    const bool multi = live && !certain && !two && usable && (!angular || v1 > lim.lo);
+    const bool pair_now = live && two, flag_now = live && !certain && !two && !multi;
     bool changed = false;
     if (live && certain && lane == 0) changed = commit_row(s, insane ? K : i1, assignments, assignments_prev);
     if (multi) {   // wave-uniform
@@ -683,14 +715,18 @@ hipError_t launch_lloyd_wide(const LloydArgs &a, const void *xg, const float *me
   if (DG % kWideBK != 0) return hipErrorInvalidValue;
   const uint32_t k_pad64 = (a.K_pad + 63u) / 64u * 64u;
   const uint32_t grid = (a.N + kWideRows - 1) / kWideRows;
-  static bool attr_set = false;   // (dynamic LDS beyond 64 KB)
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lloyd_wide_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLds0);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lloyd_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLds1);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lloyd_wide_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLds0);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lloyd_wide_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLds0);
-    (void)hipGetLastError();
-    attr_set = true;
+  // Dynamic LDS beyond 64 KB is an opt-in that belongs to the CURRENT DEVICE's copy of the kernel (and shard workers
+  // launch from their own threads): set for the instantiations this call launches, on every launch, like the other
+  // launchers (lloyd.hip, update.hip, knn_f16.hip) -- and a refusal is the caller's error, not a launch failure later.
+  {
+    const int mode = !cy ? 0 : (!cy->row_list ? 2 : 3);
+    hipError_t e = hipSuccess;
+    if (mode == 0) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lloyd_wide_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLds0);
+    else if (mode == 2) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lloyd_wide_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLds0);
+    else e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lloyd_wide_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLds0);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lloyd_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLds1);
+    if (e != hipSuccess) return e;
   }
 #define KMX_WIDE_LAUNCH(MODE, LDS, CY)                                                                                \
   hipLaunchKernelGGL((lloyd_wide_kernel<MODE>), dim3(grid), dim3(512), LDS, st, reinterpret_cast<const _Float16 *>(xg), \

@@ -17,10 +17,18 @@ import torch.distributed as dist
 
 
 def row_block(n_total, rank, world):
-    """Contiguous balanced row blocks (same rule as the C++ host's row_plan())."""
-    lo = (n_total * rank) // world
-    hi = (n_total * (rank + 1)) // world
-    return lo, hi
+    """Contiguous balanced row blocks, the C++ host's rule (kmcuda_api.cpp: row_plan()): with more than one shard of
+    at least 1024 rows each, every shard start is rounded down to a multiple of 256 rows -- the sharded k-means++
+    chooser (launch_kmpp_choose) takes whole 256-row blocks from every shard but the last."""
+    align = world > 1 and n_total // world >= 1024
+
+    def start(i):
+        if i >= world:
+            return n_total
+        o = (n_total * i) // world
+        return (o & ~255) if align else o
+
+    return start(rank), start(rank + 1)
 
 
 class HipBackend:

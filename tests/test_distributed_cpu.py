@@ -142,7 +142,11 @@ def test_row_block_partition():
         blocks = [row_block(n, r, w) for r in range(w)]
         assert blocks[0][0] == 0 and blocks[-1][1] == n
         assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
-        assert max(b[1] - b[0] for b in blocks) - min(b[1] - b[0] for b in blocks) <= 1
+        # balanced up to the 256-row alignment of the shard starts (kmcuda_api.cpp: row_plan(), shards of >= 1024 rows)
+        aligned = w > 1 and n // w >= 1024
+        assert max(b[1] - b[0] for b in blocks) - min(b[1] - b[0] for b in blocks) <= (511 if aligned else 1)
+        if aligned:
+            assert all(b[0] % 256 == 0 for b in blocks)
 
 
 @pytest.mark.parametrize("kind", ["host-stop", "device-stop"])

@@ -43,7 +43,10 @@ def test_assign_passes(name, cached):
         got = asg.cpu().numpy().view(numpy.uint32)
         want = GOLDEN["%s/pass%d/assignments" % (name, p)]
         if metric == "cos":
-            assert (got != want).mean() <= COS_FLIPS
+            # only rows whose two candidates are a last place apart in the oracle's own arithmetic (the one use of the
+            # oracle in this file: the distances of the rows that differ, tests/_angular.py)
+            from _angular import assert_only_acos_matters
+            assert_only_acos_matters(x, c, got, want, "%s pass %d" % (name, p), max_fraction=COS_FLIPS)
             # later passes start from the engine's own previous assignments: put the vectors' in
             asg.copy_(torch.from_numpy(want.view(numpy.int32).copy()).to(dev))
         else:

@@ -137,9 +137,10 @@ def test_assign_angular():
     c = x[rs.choice(3000, 64, replace=False)].copy()
     got, _, _ = _assign(x, c, metric="cos")
     ref, _, _ = oracle.lloyd_assign(x, c, metric=oracle.COS)
-    # acosf is libm on the CPU and ocml on the GPU: ties inside an acos plateau may resolve to a
-    # different (equally distant) centroid; the reference's own bound for angular is loose.
-    assert (got != ref).mean() < 1e-3
+    # acosf is libm on the CPU and ocml on the GPU: a row whose two nearest centroids are within a last place of each
+    # other in the oracle's own arithmetic may resolve either way -- nothing else may differ (tests/_angular.py)
+    from _angular import assert_only_acos_matters
+    assert_only_acos_matters(x, c, got, ref, "test_assign_angular", max_fraction=1e-3)
 
 
 def test_update_matches_oracle():
