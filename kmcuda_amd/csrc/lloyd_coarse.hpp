@@ -8,6 +8,14 @@
 #include "filter_common.hpp"
 #include "kernels.hpp"
 
+// KMX_ABL: timing-only ablations for scripts/coarse_harness.hip (WRONG results; never defined in the library build;
+// what each part of the kernel costs on one box: DESIGN.md 4.5, profiles/r6c_*).
+//   1 no LDS-DMA behind super-tile 0   2 rows from 64 blocks' worth of the cache (L2 resident)   4 no bookkeeping
+//   8 no decision epilogue   16 no barrier per super-tile
+#ifndef KMX_ABL
+#define KMX_ABL 0
+#endif
+
 namespace kmx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
       // rows = the row cache: per 32-row block KS pieces of 64 lanes x 16 bytes, already centred halves
       // in operand order -> 2 KS fully coalesced 1-KB loads per wave straight into the operand
       // registers, no conversion; the norms wait in xmeta until the decision
-      const f16x8 *c = reinterpret_cast<const f16x8 *>(rows) + ((size_t)blockIdx.x * (4 * NSET) + wave * NSET) * (KS * 64) + lane;
+      const f16x8 *c = reinterpret_cast<const f16x8 *>(rows) + ((size_t)((KMX_ABL & 2) ? (blockIdx.x & 63u) : blockIdx.x) * (4 * NSET) + wave * NSET) * (KS * 64) + lane;
 #pragma unroll
       for (int j = 0; j < KS; j++) xa[j] = c[j * 64];
 #pragma unroll
@@ -304,17 +312,22 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
       // the bookkeeping phase instead -- the other block's MFMAs would cover the issue -- the kernel is 2 % slower:
       // 3.51 against 3.44 ms on the same box, profiles/r3d_*)
       constexpr int SPREAD = KS >= 8 ? KS / 8 : 1;            // a piece every SPREAD k-steps
-      if (stage && (j % SPREAD) == SPREAD / 2 && j / SPREAD < 8) {
+      if (!(KMX_ABL & 1) && stage && (j % SPREAD) == SPREAD / 2 && j / SPREAD < 8) {
         const int slot = j / SPREAD;                           // 0..7
         for (int p = slot * 4 + wave; p < NP; p += 32) stage_piece(sp_next, buf_next, p);
         if (slot == 0 && wave == 0) stage_bias(sp_next, buf_next);
       }
     }
     const float v1a_in = v1a, v1b_in = v1b;
+    if (KMX_ABL & 4) {
+      v1a = fmaxf(v1a, accA[0]); v2a = fmaxf(v2a, accA[15]);
+      if constexpr (TWO) { v1b = fmaxf(v1b, accB[0]); v2b = fmaxf(v2b, accB[15]); }
+    } else {
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      book2(accA[r], accA[r + 1], r, v1a, v2a);
-      if constexpr (TWO) book2(accB[r], accB[r + 1], r, v1b, v2b);
+      for (int r = 0; r < 16; r += 2) {
+        book2(accA[r], accA[r + 1], r, v1a, v2a);
+        if constexpr (TWO) book2(accB[r], accB[r + 1], r, v1b, v2b);
+      }
     }
     tba = (v1a != v1a_in) ? t : tba;
     tbb = (v1b != v1b_in) ? t : tbb;
@@ -327,7 +340,11 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     tile_pass(base, bb, 2 * sp, stage, sp + 1, buf ^ 1);
     tile_pass(base + 32 * ROWB, bb + 128, 2 * sp + 1, false, sp + 1, buf ^ 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (!(KMX_ABL & 16)) __syncthreads();
+  }
+  if (KMX_ABL & 8) {   // (keep the sweep alive, skip the epilogue)
+    if (v1a + v2a + v1b + v2b == 1.2345f) assignments[0] = tba + tbb;
+    return;
   }
 
   // |coarse score - reference score| <= E_c: the f32-accumulated hi.hi products (gamma_{DP+1}), the

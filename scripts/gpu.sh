@@ -9,8 +9,10 @@
 #   shard                     the 1M-row shard of the headline config (what one of 8 GPUs sees)
 #   api[:<args>]              bench.py --api (whole kmeans_cuda() calls)
 #   stats[:<bench.py args>]   rocprofv3 --kernel-trace --stats of the bench command -> kernel_stats_<tag>.csv
+#   timeline[:<bench.py args>] kernel trace of the bench (default: the 1M-row shard) -> the last 40 launches with their gaps
 #   pmc[:<bench.py args>]     PMC passes (one run per counter group, --kernel-trace only) -> pmc_<tag>_summary.json
-#   probe[:<iters>]           scripts/mfma_probe.hip built on the box and run
+#   hip:<file.hip>[,args]     a standalone .hip program (scripts/mfma_probe.hip, scripts/coarse_probe.hip) built on the box
+#                             with $HIPFLAGS and run -> <name>_<tag>.log
 #   configs                   whole calls: config B / mixtures / config C shape with yinyang_t = 0.1 and 0 (scripts/config_b.py)
 #   knn[:<config_d.py args>]  config D's share (scripts/config_d.py)
 #   scale:<N>                 scripts/scale_check.sh N
@@ -47,6 +49,9 @@ for step in "$@"; do
     stats) rm -rf $OUT/prof_$TAG
          timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o p -- python bench.py ${args:---steps 20 --warmup 5 --no-cpu-baseline --no-verify} > $OUT/prof_$TAG.log 2>&1; echo "rocprof rc=$?"
          python scripts/rocpd_stats.py $OUT/prof_$TAG/p_results.db $OUT/kernel_stats_$TAG.csv | head -12 | cut -c1-160; rm -rf $OUT/prof_$TAG ;;
+    timeline) rm -rf $OUT/prof_$TAG   # the last launches of the bench command as a timeline with gaps
+         timeout 900 rocprofv3 --kernel-trace -d $OUT/prof_$TAG -o p -- python bench.py ${args:---samples 1000000 --steps 6 --warmup 4 --no-cpu-baseline --no-verify --no-api-leg} > $OUT/prof_$TAG.log 2>&1; echo "rocprof rc=$?"
+         python scripts/rocpd_timeline.py $OUT/prof_$TAG/p_results.db 0 100000 | tail -40 | cut -c1-150 | tee $OUT/timeline_$TAG.log; rm -rf $OUT/prof_$TAG ;;
     pmc) CMD="python bench.py ${args:---steps 10 --warmup 5 --no-cpu-baseline --no-verify}"; i=0
          for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
                     "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
@@ -54,7 +59,8 @@ for step in "$@"; do
            timeout 400 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmc_$i -o pmc -- $CMD > /tmp/pmc_$i.log 2>&1; echo "pmc pass $i ($grp) rc=$?"
          done
          PMC_TAG=$TAG python scripts/pmc_summary.py $OUT/pmc_${TAG}_summary.json | cut -c1-600 ;;
-    probe) mkdir -p scratch/bin && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 scripts/mfma_probe.hip -o scratch/bin/mfma_probe && timeout 300 scratch/bin/mfma_probe ${args:-4000} | tee $OUT/mfma_probe_$TAG.log ;;
+    hip) src=${args%% *}; rest=""; [ "$src" != "$args" ] && rest=${args#* }; exe=scratch/bin/$(basename $src .hip); mkdir -p scratch/bin
+         /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -w ${HIPFLAGS:-} $src -o $exe && { echo "## flags: ${HIPFLAGS:-}" >> $OUT/$(basename $src .hip)_$TAG.log; timeout 600 $exe $rest | tee -a $OUT/$(basename $src .hip)_$TAG.log; } ;;
     configs) : > $OUT/configs_$TAG.log
          run() { echo "## $1" | tee -a $OUT/configs_$TAG.log; shift; ( "$@" ) 2>&1 | grep -E "kmeans_cuda wall|carried bounds|knn_cuda" | tee -a $OUT/configs_$TAG.log; }
          for rep in 1 2; do
