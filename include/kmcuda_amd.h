@@ -145,6 +145,12 @@ int kmamd_carry_stats(kmamd_engine *e, uint64_t *rows_spared, uint32_t *last_lis
  * through the filter.  rows_paired = such row passes since the engine was created (they are not in rows_spared).
  * KMCUDA_AMD_CARRY_PAIRS=0 in the environment: without (A/B). */
 int kmamd_carry_pair_stats(kmamd_engine *e, uint64_t *rows_paired);
+/* The default Lloyd filter's duo list (csrc/lloyd_duo.hip; the reference has no counterpart, its kmeans_assign_lloyd
+ * -- kmeans.cu:293-364 -- scans every centroid for every row): rows of the LAST assignment pass that stage 1 could
+ * not decide but whose two contenders it knew by index, so that stage 2 settled them without sweeping the centroids
+ * again.  The engine uses the list where it pays (lists beyond one round of stage-2 blocks); KMCUDA_AMD_DUO=0 / 2 in
+ * the environment: never / always. */
+int kmamd_duo_rows(kmamd_engine *e, uint32_t *rows);
 /* The host side of the carried bounds replayed without a device (tests): pass i + 1 would count list_len[i] rows if it
  * counts a list, a pass's report reaches the host `lag` >= 1 passes later; out[i] = 0 plain pass (the bounds are paused),
  * 1 whole pass that leaves bounds but has none to move, 2 whole pass that counts its would-be list, 3 listed pass. */

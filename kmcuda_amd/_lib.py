@@ -22,7 +22,7 @@ EXPORTS = [
     "kmamd_engine_create", "kmamd_engine_destroy", "kmamd_engine_stream", "kmamd_engine_sync",
     "kmamd_lloyd_assign", "kmamd_lloyd_assign_exact", "kmamd_set_half_rows", "kmamd_set_row_cache", "kmamd_profile_read_coarse", "kmamd_set_filter", "kmamd_counters_read", "kmamd_counters_reset", "kmamd_yy_hint_stats",
     "kmamd_move_deltas", "kmamd_apply_delta", "kmamd_transpose", "kmamd_reduce_len", "kmamd_reduce_fill",
-    "kmamd_reduce_apply", "kmamd_reduce_apply_stop", "kmamd_reduce_apply_prepare", "kmamd_stop_report", "kmamd_stop_clear", "kmamd_centroids_written", "kmamd_set_carry", "kmamd_carry_stats", "kmamd_carry_pair_stats", "kmamd_carry_policy_sim", "kmamd_set_update_mode", "kmamd_last_run_stats", "kmamd_last_run_collective", "kmamd_adjust_exact", "kmamd_yy_configure", "kmamd_yy_init", "kmamd_yy_drifts", "kmamd_yy_filters",
+    "kmamd_reduce_apply", "kmamd_reduce_apply_stop", "kmamd_reduce_apply_prepare", "kmamd_stop_report", "kmamd_stop_clear", "kmamd_centroids_written", "kmamd_set_carry", "kmamd_carry_stats", "kmamd_carry_pair_stats", "kmamd_duo_rows", "kmamd_carry_policy_sim", "kmamd_set_update_mode", "kmamd_last_run_stats", "kmamd_last_run_collective", "kmamd_adjust_exact", "kmamd_yy_configure", "kmamd_yy_init", "kmamd_yy_drifts", "kmamd_yy_filters",
     "kmamd_copy_to_device", "kmamd_profile_reset", "kmamd_profile_read", "kmamd_profile_enable", "kmamd_filter_kind", "kmamd_build_arch",
 ]
 
@@ -91,6 +91,8 @@ def lib():
     L.kmamd_carry_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
     L.kmamd_carry_pair_stats.restype = i32
     L.kmamd_carry_pair_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.kmamd_duo_rows.restype = i32
+    L.kmamd_duo_rows.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
     L.kmamd_carry_policy_sim.restype = i32
     L.kmamd_carry_policy_sim.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_float, ctypes.POINTER(ctypes.c_uint32),
                                          ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint8)]

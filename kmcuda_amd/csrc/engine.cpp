@@ -122,6 +122,7 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   carry_pairs_ = true;
   if (const char *c = getenv("KMCUDA_AMD_CARRY_PAIRS")) carry_pairs_ = atoi(c) != 0;
   if (const char *c = getenv("KMCUDA_AMD_SETTLE")) settle_ = atoi(c) != 0;
+  if (const char *c = getenv("KMCUDA_AMD_DUO")) { duo_on_ = atoi(c) != 0; duo_always_ = atoi(c) == 2; }
   if (const char *c = getenv("KMCUDA_AMD_WIDE")) wide_ok_ = atoi(c) != 0;
   if (const char *c = getenv("KMCUDA_AMD_GEMM")) wide_ok_ = atoi(c) != 0;   // (the switch's name while stage 1 was a library GEMM)
   if (const char *u = getenv("KMCUDA_AMD_UPDATE"))
@@ -197,9 +198,10 @@ int Engine::init(int device, uint32_t n_rows, uint32_t D, uint32_t K, int metric
   bucket_cap_ = move_bucket_cap(n_rows, K);
   if ((rc = alloc(&bucket_rows_, 2 * (size_t)K * bucket_cap_))) return rc;
   KMX_HIP(hipMemsetAsync(stats_base_, 0, 16 * sizeof(uint32_t), stream_), kRuntimeError);
-  host_move_count_ = pinned_words(4, &ms_.host_dev);
+  host_move_count_ = pinned_words(5, &ms_.host_dev);
   if (!host_move_count_) return kMemoryAllocationFailure;
   host_move_count_[2] = 0xFFFFFFFFu;   // undecided rows: not known yet
+  host_move_count_[4] = 0xFFFFFFFFu;   // duo rows: likewise
   ms_.host = host_move_count_;
   KMX_HIP(hipEventCreateWithFlags(&ev_rows_, hipEventDisableTiming), kRuntimeError);
   sort_temp_bytes_ = sort_temp_bytes(2 * (size_t)n_rows, 2 * K);
@@ -500,6 +502,11 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
     int rc = alloc(&phi, (size_t)((K_pad_ + 63u) / 64u * 64u) * (DP_ + 2));  // whole 64-row super-tiles + their biases
     if (rc) return rc;
     if (!undecided_ && ((rc = alloc(&undecided_, N_)) || (rc = alloc(&und_thr_, N_)))) return rc;
+    if (duo_on_ && !duo_ && alloc(&duo_, 4 * (size_t)N_) != kSuccess) {   // (an optimisation: without it stage 2 sweeps for every listed row)
+      (void)hipGetLastError();
+      duo_ = nullptr;
+      duo_on_ = false;
+    }
     panelhi_ = phi;
   }
   // Steady state of the two-stage filter (mean frozen, cache valid): ONE preparation kernel in front of
@@ -556,6 +563,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
   if (two_stage) {
     const void *rows = half_rows_ ? half_rows_ : (const void *)samples;
     const bool half = half_rows_ != nullptr;
+    bool duo_listed = false;   // stage 1 wrote a duo list (plain passes)
     if (!steady)
       KMX_HIP(launch_centroid_panelhi(centroids, K_, D_, K_pad_, DP_, finite_, mu_, bias_, panelhi_, stats_, stream_),
               kRuntimeError);
@@ -646,9 +654,27 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
               kRuntimeError);
       carry_valid_ = true;
     } else {
+      // The duo list pays when it takes whole ROUNDS of blocks off stage 2's sweep: a list that fits one round of its
+      // 128-row blocks (two per CU) is one sweep long either way, and the second kernel only adds its launch.  By an
+      // earlier pass's list lengths (whatever the update's report has delivered), the row count before any report.
+      duo_listed = duo_on_ && duo_;
+      if (duo_listed && !duo_always_) {
+        const uint32_t und_prev = host_move_count_[2], duo_prev = host_move_count_[4];
+        const uint64_t listed = (und_prev != 0xFFFFFFFFu && duo_prev != 0xFFFFFFFFu) ? (uint64_t)und_prev + duo_prev
+                                                                                       : (uint64_t)N_ / 16u;
+        duo_listed = listed > 512u * 128u;
+      }
       KMX_HIP(launch_lloyd_coarse(a, rows, half, cached ? xcache_ : nullptr, xmeta_, panelhi_, undecided_, und_thr_,
-                                  stream_),
+                                  duo_listed ? duo_ : nullptr, stream_),
               kRuntimeError);
+    }
+    // the rows stage 1 listed with their two contenders (lloyd_duo.hip): stage 2's decision without its sweep, beside
+    // stage 2's sweep over the rest (a round of 67-KB blocks that leaves most of the chip's waves free)
+    if (duo_listed) {
+      KMX_HIP(hipEventRecord(ev_fork_, stream_), kRuntimeError);
+      KMX_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0), kRuntimeError);
+      KMX_HIP(launch_lloyd_duo(a, duo_, side_stream_), kRuntimeError);
+      KMX_HIP(hipEventRecord(ev_join_, side_stream_), kRuntimeError);
     }
     carry_preps_ = 0;
     span_end();
@@ -665,6 +691,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
                                   stream_),
               kRuntimeError);
     }
+    if (duo_listed) KMX_HIP(hipStreamWaitEvent(stream_, ev_join_, 0), kRuntimeError);
   } else {
     KMX_HIP(launch_lloyd_filter(a, stream_), kRuntimeError);
   }
@@ -916,6 +943,15 @@ int Engine::carry_pair_stats(unsigned long long *rows_paired) {
   return kSuccess;
 }
 
+int Engine::duo_rows(uint32_t *rows) {
+  KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
+  uint32_t v = 0;
+  KMX_HIP(hipMemcpyAsync(&v, counters_ + kDuoCount, sizeof(v), hipMemcpyDeviceToHost, stream_), kMemoryCopyError);
+  KMX_HIP(hipStreamSynchronize(stream_), kRuntimeError);
+  if (rows) *rows = v;
+  return kSuccess;
+}
+
 int Engine::stop_clear() {
   KMX_HIP(hipSetDevice(device_), kNoSuchDevice);
   carry_valid_ = false;   // (a pass enqueued behind a raised flag wrote no bounds: start over)
@@ -1102,6 +1138,7 @@ int kmamd_carry_pair_stats(kmamd_engine *e, uint64_t *rows_paired) {
   if (rows_paired) *rows_paired = v;
   return rc;
 }
+int kmamd_duo_rows(kmamd_engine *e, uint32_t *rows) { return e->e.duo_rows(rows); }
 int kmamd_set_update_mode(kmamd_engine *e, int mode) {
   if (mode < 0 || mode > 3) return kmx::kInvalidArguments;
   e->e.ms_.force = mode;

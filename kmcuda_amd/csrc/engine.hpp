@@ -160,6 +160,9 @@ class Engine {
   void *panelhi_ = nullptr;
   uint32_t *undecided_ = nullptr;
   float *und_thr_ = nullptr;      // per undecided row: coarse scores below it are ruled out
+  uint32_t *duo_ = nullptr;       // 4 N: stage 1's rows with two contenders known by index (counters_[kDuoCount] of them)
+  bool duo_on_ = true;            // KMCUDA_AMD_DUO=0: every undecided row takes stage 2's sweep (the A/B)
+  bool duo_always_ = false;       // KMCUDA_AMD_DUO=2: the duo list whatever the lists' lengths (the tests); default: when it pays
   // 0: two-stage f16 matrix-core filter (hi.hi, then the contenders in fp32; default),
   // 1: f32 matrix-core filter (KMCUDA_AMD_FILTER=f32; cross-check)
   int filter_mode_ = 0;
@@ -197,6 +200,7 @@ class Engine {
   bool carry_usable() const;     // the state in which a pass can carry bounds
   int carry_stats(unsigned long long *rows_spared, uint32_t *last_list);
   int carry_pair_stats(unsigned long long *rows_paired);
+  int duo_rows(uint32_t *rows);   // the last assignment pass's duo list (lloyd_duo.hip)
   // stats_: the ACTIVE half of a double-buffered 2 x 8 words (stats_base_): every preparation flips to
   // the other half, which the invariant keeps zero (memset, or zeroed by centroid_prep_frozen_kernel)
   uint32_t *stats_base_ = nullptr, *stats_ = nullptr, *flagged_ = nullptr, *pairs_ = nullptr, *counters_ = nullptr;

@@ -43,6 +43,9 @@ constexpr uint32_t kCarryCursor = 9, kCarrySkipped = 10;
 // counters[kCarryPaired], [kCarryPaired + 1]: 64-bit total of the rows the carried PAIR certificates have sent straight to
 // the two-contender kernel (lloyd_carry.hip)
 constexpr uint32_t kCarryPaired = 12;
+// counters[kDuoCount]: length of stage 1's list of rows whose (two) contenders it knows by index (lloyd_coarse.hpp:
+// the four quarters' trackers); zeroed with counters[4] by the preparation kernels
+constexpr uint32_t kDuoCount = 14;
 // Bounds carried from one Lloyd pass to the next (lloyd_carry.hip): per row an upper bound of the distance to its
 // centroid and a lower bound of the distance to every other finite centroid.
 struct CarryArgs {
@@ -126,9 +129,14 @@ hipError_t launch_centroid_rows(int metric, const float *centroids, uint32_t K, 
                                 float *ct, hipStream_t st);
 // stage 1 of the default filter: hi.hi products only; rows it cannot decide -> undecided[counters[4]++].
 // xcache / xmeta: the engine's row cache (launch_row_cache) or nullptr (operands converted from rows)
+// (duo != nullptr: undecided rows whose two contenders stage 1 knows by index go to duo[4 counters[kDuoCount]++]
+//  = (row, contender, contender, best score of the others) instead, for launch_lloyd_duo)
 hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
                                const float *xmeta, const void *panelhi, uint32_t *undecided, float *und_thr,
-                               hipStream_t st);
+                               uint32_t *duo, hipStream_t st);
+// stage 2 without its sweep for the duo rows (lloyd_duo.hip): the two contenders scored in fp32, decided like
+// launch_lloyd_refine's rows
+hipError_t launch_lloyd_duo(const LloydArgs &a, const uint32_t *duo, hipStream_t st);
 // stage 2 of the default filter: the undecided rows' contenders (coarse score >= und_thr) scored in fp32
 hipError_t launch_lloyd_refine(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
                                const uint32_t *row_list, const float *thr_list, const uint32_t *n_list,
@@ -198,6 +206,7 @@ hipError_t preload_update_code();
 hipError_t preload_lloyd_f16_code();
 hipError_t preload_lloyd_code();
 hipError_t preload_lloyd_carry_code();
+hipError_t preload_lloyd_duo_code();
 hipError_t launch_gather_rows(const float *samples, const uint32_t *idx, uint32_t K, uint32_t D, float *out, hipStream_t st);
 // seeding.hip (reference: kmeans.cu:42-67 kmeans_plus_plus, transpose.cu:6-14 copy_sample_t,
 // kmeans.cu:674-691 kmeans_calc_average_distance)

@@ -1942,6 +1942,7 @@ void preload_code_objects(int dev, PreloadThreads *keep) {
     (void)preload_lloyd_f16_code();
     (void)preload_lloyd_code();
     (void)preload_lloyd_carry_code();
+    (void)preload_lloyd_duo_code();
     (void)hipGetLastError();
   });
 }

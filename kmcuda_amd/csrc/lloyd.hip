@@ -96,7 +96,7 @@ __global__ __launch_bounds__(1024) void centroid_mean_kernel(const float *__rest
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // the filter's per-pass list counters (saves two memset launches)
     if (zero_a) *zero_a = 0u;
     if (zero_b) *zero_b = 0u;
-    if (zero_c) *zero_c = 0u;
+    if (zero_c) { *zero_c = 0u; zero_c[kDuoCount - 4] = 0u; }   // (zero_c = counters + 4: the undecided list, and the duo list)
   }
   if (freeze_mu) return;  // the engine's row cache holds x - mu: mu stays what it was (any mu is valid)
   float sum = 0.f;

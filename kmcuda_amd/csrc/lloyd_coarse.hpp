@@ -32,6 +32,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // (16-byte chunk j of row r sits in slot j ^ (r & 15) of its half row) applied to the SOURCE address
 // and again by the fragment reads.
 // ---------------------------------------------------------------------------------------
+template <int P>
+struct TileParity { static constexpr int value = P; };   // (which of a lane's two trackers a tile's scores go into)
 // hand-issued LDS fragment read + counted wait (see lloyd_coarse2_kernel)
 __device__ __forceinline__ f16x8 lds_frag_issue(uint32_t addr) {
   f16x8 f;
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     const float *__restrict__ bias, const float *__restrict__ mu, uint32_t K_pad, uint32_t K,
     const uint32_t *__restrict__ stats, float eps, float tie_slack, uint32_t *__restrict__ assignments,
     uint32_t *__restrict__ assignments_prev, uint32_t *__restrict__ undecided, float *__restrict__ und_thr,
-    uint32_t *__restrict__ counters, CarryArgs cy) {
+    uint32_t *__restrict__ counters, CarryArgs cy, uint32_t *__restrict__ duo = nullptr) {
   static_assert(CARRY == 0 || CARRY == 1 || CARRY == 2, "CARRY");
   static_assert(CARRY != 2 || !CACHED, "listed rows are gathered from the rows, not streamed from the row cache");
   constexpr int NKH = DP / 2;
@@ -241,8 +243,12 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   stage_issue(0, 0, WV, wave);
   load_rows();   // waits for the DMA above and closes with a barrier after its first batch
 
-  float v1a = -INFINITY, v2a = -INFINITY, v1b = -INFINITY, v2b = -INFINITY;
-  uint32_t tba = 0, tbb = 0;
+  // FOUR top-2 trackers per row, not two: a lane keeps one for the even tiles and one for the odd tiles (the two
+  // halves of the wave see different centroids of a tile anyway).  Same work per score -- a tile's scores go into
+  // its parity's tracker -- and at the end the best of every quarter is known WITH its index: when the row's
+  // contenders sit in different quarters (3 cases of 4), stage 2 need not sweep the centroids again to find them.
+  float v1a[2] = {-INFINITY, -INFINITY}, v2a[2] = {-INFINITY, -INFINITY}, v1b[2] = {-INFINITY, -INFINITY}, v2b[2] = {-INFINITY, -INFINITY};
+  uint32_t tba[2] = {0, 0}, tbb[2] = {0, 0};
   // fragment address of k-step j: rowbase ^ swizzle ^ (16 j); (row, half) part fixed per lane
   const uint32_t fragbase = lds0 + (uint32_t)col * ROWB + (uint32_t)h * (KS * 16) + (uint32_t)((col & SWM) * 16);
   // max(v1, pk) as med3(v1, pk, +inf): fmaxf() costs a canonicalising v_max per operand on top
@@ -275,7 +281,8 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   // block, one per SIMD), so they are not in step: one's bookkeeping runs under the other's MFMAs.
   // (Double-buffered accumulators with the bookkeeping interleaved in-wave need ~230 registers: the
   // B operands spill, measured slower.)
-  auto tile_pass = [&](uint32_t ldsbase, uint32_t biasaddr, uint32_t t, bool stage, uint32_t sp_next, int buf_next) {
+  auto tile_pass = [&](uint32_t ldsbase, uint32_t biasaddr, uint32_t t, bool stage, uint32_t sp_next, int buf_next, auto parity) {
+    constexpr int PAR = decltype(parity)::value;
     f32x16 accA, accB;
     load_bias(biasaddr, accA);
     accB = accA;
@@ -318,32 +325,32 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
         if (slot == 0 && wave == 0) stage_bias(sp_next, buf_next);
       }
     }
-    const float v1a_in = v1a, v1b_in = v1b;
+    const float v1a_in = v1a[PAR], v1b_in = v1b[PAR];
     if (KMX_ABL & 4) {
-      v1a = fmaxf(v1a, accA[0]); v2a = fmaxf(v2a, accA[15]);
-      if constexpr (TWO) { v1b = fmaxf(v1b, accB[0]); v2b = fmaxf(v2b, accB[15]); }
+      v1a[PAR] = fmaxf(v1a[PAR], accA[0]); v2a[PAR] = fmaxf(v2a[PAR], accA[15]);
+      if constexpr (TWO) { v1b[PAR] = fmaxf(v1b[PAR], accB[0]); v2b[PAR] = fmaxf(v2b[PAR], accB[15]); }
     } else {
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        book2(accA[r], accA[r + 1], r, v1a, v2a);
-        if constexpr (TWO) book2(accB[r], accB[r + 1], r, v1b, v2b);
+        book2(accA[r], accA[r + 1], r, v1a[PAR], v2a[PAR]);
+        if constexpr (TWO) book2(accB[r], accB[r + 1], r, v1b[PAR], v2b[PAR]);
       }
     }
-    tba = (v1a != v1a_in) ? t : tba;
-    tbb = (v1b != v1b_in) ? t : tbb;
+    tba[PAR] = (v1a[PAR] != v1a_in) ? t : tba[PAR];
+    tbb[PAR] = (v1b[PAR] != v1b_in) ? t : tbb[PAR];
   };
 
   for (uint32_t sp = 0; sp < nsuper; sp++) {
     const int buf = sp & 1;
     const bool stage = sp + 1 < nsuper;
     const uint32_t base = buf * SUPB, bb = mybias + buf * 256;
-    tile_pass(base, bb, 2 * sp, stage, sp + 1, buf ^ 1);
-    tile_pass(base + 32 * ROWB, bb + 128, 2 * sp + 1, false, sp + 1, buf ^ 1);
+    tile_pass(base, bb, 2 * sp, stage, sp + 1, buf ^ 1, TileParity<0>());
+    tile_pass(base + 32 * ROWB, bb + 128, 2 * sp + 1, false, sp + 1, buf ^ 1, TileParity<1>());
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!(KMX_ABL & 16)) __syncthreads();
   }
   if (KMX_ABL & 8) {   // (keep the sweep alive, skip the epilogue)
-    if (v1a + v2a + v1b + v2b == 1.2345f) assignments[0] = tba + tbb;
+    if (v1a[0] + v2a[0] + v1b[0] + v2b[0] + v1a[1] + v2a[1] + v1b[1] + v2b[1] == 1.2345f) assignments[0] = tba[0] + tbb[0] + tba[1] + tbb[1];
     return;
   }
 
@@ -358,25 +365,41 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   const float mu_norm = (CACHED || CARRY == 2) ? xmeta[2 * (((size_t)N + 255) / 256 * 256)] : cmaxo;
   const float dcmax = sqrtf(__uint_as_float(stats[5])) * 1.000001f;   // max ||c' - hi(c')||; inf = no bound
   const float u = 5.9604645e-8f;
-  uint32_t und_count = 0, changed_count = 0;
-  unsigned long long uma = 0, umb = 0;
-  bool unda = false, undb = false;
+  uint32_t und_count = 0, changed_count = 0, duo_count = 0;
+  unsigned long long uma = 0, umb = 0, dma = 0, dmb = 0;
+  bool unda = false, undb = false, duoa = false, duob = false;
+  uint32_t d1a = 0, d2a = 0, d1b = 0, d2b = 0;
+  float dra = 0.f, drb = 0.f;
+  // rows whose contenders are known by index (DUO) leave on a list of their own -- plain passes only: a carried pass
+  // wants the bounds stage 2 derives while it sweeps
+  const bool want_duo = CARRY == 0 && duo != nullptr;
   const bool angular = tie_slack > 0.f;   // (engine.cpp: the angular metric's plateau slack; 0 under L2)
   // xdm = x.mu, xab >= sum |x_f mu_f| (< 0: not summed here -- the row cache's record: ||x|| ||mu|| bounds it)
-  auto finish = [&](uint32_t s, bool live, float v1, float v2, uint32_t tb, float xn2, float x0, float dx2, float xdm,
-                    float xab, bool &und, unsigned long long &um, float &cut) {
+  auto finish = [&](uint32_t s, bool live, const float (&q1)[2], const float (&q2)[2], const uint32_t (&qt)[2], float xn2,
+                    float x0, float dx2, float xdm, float xab, bool &und, unsigned long long &um, float &cut, bool &is_duo,
+                    unsigned long long &dm, uint32_t &dc1, uint32_t &dc2, float &drest) {
     const bool insane = (x0 != x0);  // kmeans.cu:312
-    const uint32_t r = __float_as_uint(v1) & 15u;
-    uint32_t i1 = tb * 32u + (r & 3u) + 8u * (r >> 2) + 4u * h;
-    {
-      const float pv1 = __shfl_xor(v1, 32), pv2 = __shfl_xor(v2, 32);
-      const uint32_t pi1 = __shfl_xor(i1, 32);
-      const bool g = pv1 > v1;
-      const float second = fmaxf(g ? v1 : pv1, fmaxf(v2, pv2));
-      i1 = g ? pi1 : i1;
-      v1 = g ? pv1 : v1;
-      v2 = second;
-    }
+    // the four quarters' bests with their centroids (mine: even / odd tiles; the other half-wave's), sorted; everything
+    // else the row has seen scored at most `others`
+    auto index_of = [&](float v, uint32_t tb, uint32_t hh) {
+      const uint32_t r = __float_as_uint(v) & 15u;
+      return tb * 32u + (r & 3u) + 8u * (r >> 2) + 4u * hh;
+    };
+    float k0 = q1[0], k1 = q1[1], k2 = __shfl_xor(q1[0], 32), k3 = __shfl_xor(q1[1], 32);
+    uint32_t j0 = index_of(k0, qt[0], h), j1 = index_of(k1, qt[1], h);
+    uint32_t j2 = __shfl_xor(j0, 32), j3 = __shfl_xor(j1, 32);
+    const float mine2 = fmaxf(q2[0], q2[1]);
+    const float others = fmaxf(mine2, __shfl_xor(mine2, 32));
+    auto order = [](float &a, uint32_t &ia, float &b, uint32_t &ib) {   // a >= b afterwards (a stays in front on ties)
+      const bool g = b > a;
+      const float ta = g ? b : a, tb2 = g ? a : b;
+      const uint32_t ja = g ? ib : ia, jb = g ? ia : ib;
+      a = ta; b = tb2; ia = ja; ib = jb;
+    };
+    order(k0, j0, k1, j1); order(k2, j2, k3, j3); order(k0, j0, k2, j2); order(k1, j1, k3, j3); order(k1, j1, k2, j2);
+    float v1 = k0;
+    const uint32_t i1 = j0;
+    const float v2 = fmaxf(k1, others);   // the row's second-best coarse score
     // ||x|| <= ||x'|| + ||mu||, and ||mu|| <= Cmax while mu is the mean of the current centroids
     // (with the row cache mu is frozen: its norm is stored behind the per-row records)
     const float xn = sqrtf(xn2) * 1.0001f, xo = (xn + mu_norm) * 1.0001f;
@@ -396,6 +419,17 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     bool changed = false;
     if (mine && certain) changed = commit_row(s, insane ? K : i1, assignments, assignments_prev);
     und = mine && !certain;
+    is_duo = false;
+    if constexpr (CARRY == 0) {
+      // undecided, a usable cut-off (below), and only the two best quarters' bests reach it: stage 2's answer -- the
+      // contenders are j0 and j1 -- without its sweep.  (The scores compared are the packed ones stage 1 decides on
+      // itself: e_c covers the index bits.)
+      float c0 = in_range ? v1 - thr : __builtin_nanf("");
+      if (angular) c0 = (lim.hi == lim.hi) ? fminf(c0, lim.hi) : __builtin_nanf("");
+      is_duo = want_duo && und && (k1 >= c0) && (k2 < c0) && (others < c0) && (j1 < K);   // (NaN cut-off: no)
+      if (is_duo) und = false;
+      dc1 = j0; dc2 = j1; drest = fmaxf(k2, others);
+    }
     if constexpr (CARRY != 0) {
       // d(x, c)^2 = ||x - mu||^2 - 2 s(c) with s(c) the exact score; |v - s(c)| <= e_c for every centroid (packed
       // index bits included), xn2 within 2 eps of ||x - mu||^2 (an fp32 sum of DP squares of rounded differences).
@@ -437,8 +471,10 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     if (angular) cut = (lim.hi == lim.hi) ? fminf(cut, lim.hi) : __builtin_nanf("");
     const unsigned long long cm = __ballot(changed);
     um = __ballot(und);
+    dm = __ballot(is_duo);
     changed_count += (uint32_t)__popcll(cm);
     und_count += (uint32_t)__popcll(um);
+    duo_count += (uint32_t)__popcll(dm);
   };
   float dx2a = -2.f, dx2b = -2.f;   // -2: not measured (no row cache) -> the worst case 2^-11 ||x'||
   if constexpr (CACHED || CARRY == 2) {   // (the listed pass runs beside a valid row cache: its records hold for these rows)
@@ -467,29 +503,45 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     xdmb += __shfl_xor(xdmb, 32); xabb += __shfl_xor(xabb, 32);
   }
   float cuta, cutb;
-  finish(sA, liveA, v1a, v2a, tba, xn2a, x0a, dx2a, xdma, xaba, unda, uma, cuta);
+  finish(sA, liveA, v1a, v2a, tba, xn2a, x0a, dx2a, xdma, xaba, unda, uma, cuta, duoa, dma, d1a, d2a, dra);
   cutb = 0.f;
-  if constexpr (TWO) finish(sB, liveB, v1b, v2b, tbb, xn2b, x0b, dx2b, xdmb, xabb, undb, umb, cutb);
+  if constexpr (TWO) finish(sB, liveB, v1b, v2b, tbb, xn2b, x0b, dx2b, xdmb, xabb, undb, umb, cutb, duob, dmb, d1b, d2b, drb);
   // ONE pair of global atomics per block, not three per wave: the counters share a cache line, same-address
   // atomics are served one at a time by L2 (measured round 2: 11 ns each in a kernel that did nothing else), and
   // 125 K waves per launch all arrive with theirs at the end of the same scheduling round
-  __shared__ uint32_t blk_und[WV], blk_changed[WV], blk_base;
+  __shared__ uint32_t blk_und[WV], blk_changed[WV], blk_duo[WV], blk_base, blk_duo_base;
   if (lane == 0) {
     blk_und[wave] = und_count;
     blk_changed[wave] = changed_count;
+    blk_duo[wave] = duo_count;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t tu = 0, tc = 0;
+    uint32_t tu = 0, tc = 0, td = 0;
 #pragma unroll
     for (int w = 0; w < WV; w++) {
       tu += blk_und[w];
       tc += blk_changed[w];
+      td += blk_duo[w];
     }
     if (tc) atomicAdd(&counters[0], tc);
     blk_base = tu ? atomicAdd(&counters[4], tu) : 0u;
+    blk_duo_base = td ? atomicAdd(&counters[kDuoCount], td) : 0u;
   }
   __syncthreads();
+  if (duo_count) {   // (row, contender, contender, the best score of all the others)
+    uint32_t base = blk_duo_base;
+    for (int w = 0; w < wave; w++) base += blk_duo[w];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (duoa) {
+      const uint32_t at = base + (uint32_t)__popcll(dma & below);
+      reinterpret_cast<uint4 *>(duo)[at] = make_uint4(sA, d1a, d2a, __float_as_uint(dra));
+    }
+    if (duob) {
+      const uint32_t at = base + (uint32_t)__popcll(dma) + (uint32_t)__popcll(dmb & below);
+      reinterpret_cast<uint4 *>(duo)[at] = make_uint4(sB, d1b, d2b, __float_as_uint(drb));
+    }
+  }
   if (und_count) {
     uint32_t base = blk_base;
     for (int w = 0; w < wave; w++) base += blk_und[w];

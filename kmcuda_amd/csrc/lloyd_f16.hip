@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void centroid_prep_frozen_kernel(
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (blockIdx.x == 0 && threadIdx.x < 8) {
     stats_next[threadIdx.x] = 0u;
-    if (threadIdx.x == 0) { *zero_a = 0u; *zero_b = 0u; *zero_c = 0u; if (zero_d) *zero_d = 0u; }
+    if (threadIdx.x == 0) { *zero_a = 0u; *zero_b = 0u; *zero_c = 0u; zero_c[kDuoCount - 4] = 0u; if (zero_d) *zero_d = 0u; }   // (zero_c = counters + 4)
   }
   bool update = APPLY;
   if (APPLY && ctl.counters) {   // as apply_delta_kernel
@@ -255,7 +255,7 @@ bool lloyd_filter_f16_supported(uint32_t D, uint32_t DP) { return DP >= 16 && D 
 template <int DP>
 static hipError_t launch_coarse2_dp(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
                                     const float *xmeta, const void *panelhi, uint32_t *undecided, float *und_thr,
-                                    hipStream_t st) {
+                                    uint32_t *duo, hipStream_t st) {
   constexpr int NSET = DP <= 256 ? 2 : 1;
   const size_t lds_bytes = 2 * 64 * (size_t)(DP * 2) + 512 + 64 + (size_t)DP * 4;
   const uint32_t rows_per_block = 128u * NSET;
@@ -264,7 +264,7 @@ static hipError_t launch_coarse2_dp(const LloydArgs &a, const void *rows, bool h
 #define KMX_CRS2_LAUNCH(H, F, C, SRC)                                                                              \
   hipLaunchKernelGGL((lloyd_coarse2_kernel<DP, H, F, C, NSET>), dim3(grid), dim3(256), lds_bytes, st, SRC, xmeta,   \
                      a.N, a.D, reinterpret_cast<const float *>(panelhi), a.bias, a.mu, a.K_pad, a.K, a.stats,       \
-                     a.eps, a.tie_slack, a.assignments, a.assignments_prev, undecided, und_thr, a.counters, CarryArgs())
+                     a.eps, a.tie_slack, a.assignments, a.assignments_prev, undecided, und_thr, a.counters, CarryArgs(), duo)
   if (xcache) {
     KMX_CRS2_LAUNCH(false, true, true, xcache);
   } else if (half_rows) {
@@ -278,14 +278,14 @@ static hipError_t launch_coarse2_dp(const LloydArgs &a, const void *rows, bool h
 
 hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
                                const float *xmeta, const void *panelhi, uint32_t *undecided, float *und_thr,
-                               hipStream_t st) {
+                               uint32_t *duo, hipStream_t st) {
   switch (a.DP) {
-    case 16: return launch_coarse2_dp<16>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, und_thr, st);
-    case 32: return launch_coarse2_dp<32>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, und_thr, st);
-    case 64: return launch_coarse2_dp<64>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, und_thr, st);
-    case 128: return launch_coarse2_dp<128>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, und_thr, st);
-    case 256: return launch_coarse2_dp<256>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, und_thr, st);
-    case 512: return launch_coarse2_dp<512>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, und_thr, st);
+    case 16: return launch_coarse2_dp<16>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, und_thr, duo, st);
+    case 32: return launch_coarse2_dp<32>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, und_thr, duo, st);
+    case 64: return launch_coarse2_dp<64>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, und_thr, duo, st);
+    case 128: return launch_coarse2_dp<128>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, und_thr, duo, st);
+    case 256: return launch_coarse2_dp<256>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, und_thr, duo, st);
+    case 512: return launch_coarse2_dp<512>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, und_thr, duo, st);
     default: return hipErrorInvalidValue;
   }
 }

@@ -302,7 +302,7 @@ struct SumArgs {
   double *tail;                         // may be null: [dcount K | counters 4] behind delta
   const uint32_t *counters;
   uint32_t *res;                        // device: [0] events, [1] largest list, [2] ticket, [3] overflow cursor
-  uint32_t *host;                       // pinned, device-visible: [0] events, [1] largest list, [2] counters[4]
+  uint32_t *host;                       // pinned, device-visible: [0] events, [1] largest list, [2] counters[4], [4] counters[kDuoCount]
 };
 
 __device__ __forceinline__ double list_sum(const float *__restrict__ samples, uint32_t D, const uint32_t *rows,
@@ -540,6 +540,7 @@ __global__ __launch_bounds__(kSumThreads) void cluster_sums_kernel(SumArgs a) {
         h[0] = atomicAdd(&a.res[0], 0u);
         h[1] = atomicAdd(&a.res[1], 0u);
         h[2] = a.counters[4];
+        h[4] = a.counters[kDuoCount];   // (engine.cpp: whether the duo list pays is judged by both lengths)
       }
       a.res[0] = 0u; a.res[1] = 0u; a.res[2] = 0u; a.res[3] = 0u;
     }

@@ -105,6 +105,12 @@ class Engine:
         _lib.check(self.lib.kmamd_carry_pair_stats(self.h, ctypes.byref(paired)), "kmamd_carry_pair_stats")
         return int(paired.value)
 
+    def duo_rows(self):
+        """Rows of the last assignment pass settled from stage 1's duo list (lloyd_duo.hip), without stage 2's sweep."""
+        rows = ctypes.c_uint32(0)
+        _lib.check(self.lib.kmamd_duo_rows(self.h, ctypes.byref(rows)), "kmamd_duo_rows")
+        return int(rows.value)
+
     def counters(self):
         out = (ctypes.c_uint32 * 4)()
         _lib.check(self.lib.kmamd_counters_read(self.h, out), "kmamd_counters_read")

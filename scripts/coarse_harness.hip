@@ -129,6 +129,16 @@ int main(int argc, char **argv) {
     uint32_t hc[16];
     CHECK(hipMemcpy(hc, counters, 64, hipMemcpyDeviceToHost));
     const double flop = 2.0 * DP * K * (double)N;
+    // what the launch left behind, as one number per table (the variants must agree with variant 0)
+    std::vector<uint32_t> ha(N), hu(hc[4]);
+    std::vector<float> ht(hc[4]);
+    CHECK(hipMemcpy(ha.data(), asg, (size_t)N * 4, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(hu.data(), und, (size_t)hc[4] * 4, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(ht.data(), und_thr, (size_t)hc[4] * 4, hipMemcpyDeviceToHost));
+    uint64_t sa = 0, su = 0;
+    for (uint32_t i = 0; i < N; i++) sa += (uint64_t)ha[i] * (i % 1000003u + 1u);
+    for (uint32_t i = 0; i < hc[4]; i++) { uint32_t b; memcpy(&b, &ht[i], 4); su += (uint64_t)(hu[i] + 1u) * (uint64_t)(b % 65521u + 1u); }
+    printf("sums %016llx %016llx  ", (unsigned long long)sa, (unsigned long long)su);
     printf("%-34s abl %2d  N %u : avg %.3f ms  min %.3f  median %.3f  -> %.1f TFLOP/s = %.3f of 2500   changed %u undecided %u\n", what, KMX_ABL, N,
            avg, ms[0], ms[reps / 2], flop / (avg * 1e-3) / 1e12, flop / (avg * 1e-3) / 1e12 / 2500.0, hc[0], hc[4]);
     fflush(stdout);

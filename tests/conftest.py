@@ -11,6 +11,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # The duo list of the default Lloyd filter (lloyd_duo.hip) is switched on by the engine only where it pays --
+    # lists longer than one round of stage-2 blocks, i.e. millions of rows.  The suite's inputs are small: run them
+    # WITH the list (=2: always), so that every parity case covers the longer path; tests/test_gpu_duo.py runs the
+    # other two settings.
+    os.environ.setdefault("KMCUDA_AMD_DUO", "2")
 
 
 def reference_fixture():
