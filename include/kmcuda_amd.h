@@ -189,6 +189,12 @@ int kmamd_yy_filters(kmamd_engine *e, const float *samples, const float *centroi
                      const float *gdrifts, uint32_t *assignments, uint32_t *assignments_prev, float *bounds,
                      uint32_t *passed);
 
+/* AFK-MC2's random numbers (reference: kmeans_afkmc2_random_step, kmeans.cu:107-116: curand_init(seed, thread, step)):
+ * out[t * n + i] = draw i of the XORWOW stream (seed, subsequence t, offset), t < threads, as the seeding kernels
+ * generate them -- cuRAND's seed scrambling in front of the generator cuRAND and rocRAND share (csrc/seeding.hip).
+ * A window for tests: the draws must equal the oracle's restatement (tests/test_gpu_afkmc2_rng.py). */
+int kmamd_afkmc2_draws(kmamd_engine *e, uint64_t seed, uint64_t offset, uint32_t threads, uint32_t n, uint32_t *out);
+
 /* out[c][r] = in[r][c], 4-byte elements (reference: cuda_transpose, transpose.cu:83-117). */
 int kmamd_transpose(kmamd_engine *e, const float *in, uint32_t rows, uint32_t cols, float *out);
 

@@ -21,7 +21,7 @@ EXPORTS = [
     "kmeans_cuda", "knn_cuda",
     "kmamd_engine_create", "kmamd_engine_destroy", "kmamd_engine_stream", "kmamd_engine_sync",
     "kmamd_lloyd_assign", "kmamd_lloyd_assign_exact", "kmamd_set_half_rows", "kmamd_set_row_cache", "kmamd_profile_read_coarse", "kmamd_set_filter", "kmamd_counters_read", "kmamd_counters_reset", "kmamd_yy_hint_stats",
-    "kmamd_move_deltas", "kmamd_apply_delta", "kmamd_transpose", "kmamd_reduce_len", "kmamd_reduce_fill",
+    "kmamd_move_deltas", "kmamd_apply_delta", "kmamd_transpose", "kmamd_afkmc2_draws", "kmamd_reduce_len", "kmamd_reduce_fill",
     "kmamd_reduce_apply", "kmamd_reduce_apply_stop", "kmamd_reduce_apply_prepare", "kmamd_stop_report", "kmamd_stop_clear", "kmamd_centroids_written", "kmamd_set_carry", "kmamd_carry_stats", "kmamd_carry_pair_stats", "kmamd_duo_rows", "kmamd_carry_policy_sim", "kmamd_set_update_mode", "kmamd_last_run_stats", "kmamd_last_run_collective", "kmamd_adjust_exact", "kmamd_yy_configure", "kmamd_yy_init", "kmamd_yy_drifts", "kmamd_yy_filters",
     "kmamd_copy_to_device", "kmamd_profile_reset", "kmamd_profile_read", "kmamd_profile_enable", "kmamd_filter_kind", "kmamd_build_arch",
 ]
@@ -103,6 +103,8 @@ def lib():
                                        ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u32), ctypes.POINTER(u32)]
     L.kmamd_last_run_collective.restype = i32
     L.kmamd_last_run_collective.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u32)]
+    L.kmamd_afkmc2_draws.restype = i32
+    L.kmamd_afkmc2_draws.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, u32, u32, vp]
     L.kmamd_transpose.restype = i32
     L.kmamd_transpose.argtypes = [vp, vp, u32, u32, vp]
     L.kmamd_adjust_exact.restype = i32

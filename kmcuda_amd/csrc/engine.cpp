@@ -1167,6 +1167,10 @@ int kmamd_adjust_exact(kmamd_engine *e, const float *samples, const uint32_t *as
                        const uint32_t *assignments, float *centroids, uint32_t *ccounts) {
   return e->e.adjust_exact(samples, assignments_prev, assignments, centroids, ccounts);
 }
+int kmamd_afkmc2_draws(kmamd_engine *e, uint64_t seed, uint64_t offset, uint32_t threads, uint32_t n, uint32_t *out) {
+  if (hipSetDevice(e->e.device_) != hipSuccess) return kmx::kNoSuchDevice;
+  return kmx::launch_afk_draws(seed, offset, threads, n, out, e->e.stream_) == hipSuccess ? kmx::kSuccess : kmx::kRuntimeError;
+}
 int kmamd_transpose(kmamd_engine *e, const float *in, uint32_t rows, uint32_t cols, float *out) {
   if (hipSetDevice(e->e.device_) != hipSuccess) return kmx::kNoSuchDevice;
   return kmx::launch_transpose(in, rows, cols, out, e->e.stream_) == hipSuccess ? kmx::kSuccess : kmx::kRuntimeError;

@@ -264,6 +264,9 @@ size_t kmpp_prefix_doubles(uint32_t N);   // doubles of `bpre`
 hipError_t launch_afk_qdist(int metric, const float *samples, uint32_t N, uint32_t D, const float *c1, float *dists,
                             hipStream_t st);
 hipError_t launch_afk_q(float *q, uint32_t N, float dsum, hipStream_t st);
+// n draws of each of `threads` streams (seed, subsequence = thread, offset): out[thread * n + i] (tests)
+hipError_t launch_afk_draws(unsigned long long seed, unsigned long long offset, uint32_t threads, uint32_t n, uint32_t *out,
+                            hipStream_t st);
 hipError_t launch_afk_random_step(uint32_t m, uint64_t seed, uint64_t seq, const float *q, uint32_t N,
                                   uint32_t *choices, float *rand_a, hipStream_t st);
 hipError_t launch_afk_min_dist(int metric, uint32_t m, uint32_t k, const float *samples, uint32_t D,

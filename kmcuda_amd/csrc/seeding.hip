@@ -1140,12 +1140,50 @@ size_t kmpp_prefix_doubles(uint32_t N) {
 // ---------------------------------------------------------------------------------------
 // AFK-MC2 seeding (reference: kmeans.cu:69-212, host chain kmcuda.cc:337-396).
 // The reference draws from cuRAND's XORWOW (curand_init(seed, thread, step), two curand_uniform per
-// thread).  Here: the same generator as published (Marsaglia xorwow + Weyl sequence, state seeded and
-// jumped as rocRAND's xorwow_engine does -- subsequence = thread, offset = step) and cuRAND's
-// documented uint -> (0, 1] mapping x * 2^-32 + 2^-33.  Bit-compatibility of the SEQUENCE with CUDA's
-// cannot be checked without CUDA: the reference's pins for this init (4 / 4 / 4 iterations,
-// test.py:248-289) are met, nothing stronger is claimed.
+// thread).  Here: the same generator as published -- Marsaglia's xorwow + Weyl sequence and the jumps
+// (subsequence = thread: 2^67 draws; offset = step) are rocRAND's xorwow_engine, whose lines and skip
+// matrices are the recurrence's own -- but SEEDED cuRAND's way: the two libraries scramble the seed
+// with different constants (curand_kernel.h _curand_init_scratch: 0xaad26b49 / 0xf7dcefdd,
+// 1099087573 / 2591861531; rocrand_xorwow.h: 0x2c7f967f / 0xa03697cb, 1228688033 / 2073658381), so
+// rocRAND's engine as it comes is NOT sequence-compatible with the reference's library.  cuRAND's
+// documented uint -> (0, 1] mapping x * 2^-32 + 2^-33.  The device draws equal the oracle's restatement
+// (tests/test_gpu_afkmc2_rng.py, which also holds the restatement's generator and jumps to rocRAND's
+// host generator); no cuRAND output vector exists offline, so the constants rest on their source:
+// the reference's pins for this init (4 / 4 / 4 iterations, test.py:248-289) are met, nothing
+// stronger is claimed.
 // ---------------------------------------------------------------------------------------
+struct CurandSeededXorwow : rocrand_device::xorwow_engine {
+  __device__ CurandSeededXorwow(unsigned long long seed, unsigned long long subsequence, unsigned long long offset)
+      : rocrand_device::xorwow_engine(0ull, 0ull, 0ull) {   // (no jumps; the state is set below)
+    const unsigned int s0 = static_cast<unsigned int>(seed) ^ 0xaad26b49u;
+    const unsigned int s1 = static_cast<unsigned int>(seed >> 32) ^ 0xf7dcefddu;
+    const unsigned int t0 = 1099087573u * s0, t1 = 2591861531u * s1;
+    m_state.d = 6615241u + t1 + t0;
+    m_state.x[0] = 123456789u + t0;
+    m_state.x[1] = 362436069u ^ t0;
+    m_state.x[2] = 521288629u + t1;
+    m_state.x[3] = 88675123u ^ t1;
+    m_state.x[4] = 5783321u + t0;
+    discard_subsequence(subsequence);
+    discard(offset);
+  }
+};
+
+// the first n draws of the stream (seed, subsequence = thread, offset): the tests' window on the device generator
+__global__ void afk_draws_kernel(unsigned long long seed, unsigned long long offset, uint32_t threads, uint32_t n,
+                                 uint32_t *__restrict__ out) {
+  const uint32_t ti = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ti >= threads) return;
+  CurandSeededXorwow eng(seed, ti, offset);
+  for (uint32_t i = 0; i < n; i++) out[(size_t)ti * n + i] = eng.next();
+}
+hipError_t launch_afk_draws(unsigned long long seed, unsigned long long offset, uint32_t threads, uint32_t n, uint32_t *out,
+                            hipStream_t st) {
+  if (threads == 0 || n == 0) return hipSuccess;
+  hipLaunchKernelGGL(afk_draws_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, seed, offset, threads, n, out);
+  return hipGetLastError();
+}
+
 template <int METRIC>
 __global__ void afk_qdist_kernel(const float *__restrict__ samples, uint32_t N, uint32_t D,
                                  const float *__restrict__ c1, float *__restrict__ dists) {
@@ -1170,7 +1208,7 @@ __global__ void afk_random_step_kernel(uint32_t m, unsigned long long seed, unsi
                                        float *__restrict__ rand_a) {
   const uint32_t ti = blockIdx.x * blockDim.x + threadIdx.x;
   if (ti >= m) return;
-  rocrand_device::xorwow_engine eng(seed, ti, seq);
+  CurandSeededXorwow eng(seed, ti, seq);
   const float part = afk_uniform(eng.next());
   rand_a[ti] = afk_uniform(eng.next());
   float accum = 0.f, corr = 0.f;

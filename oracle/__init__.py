@@ -271,3 +271,15 @@ def yy_filters(samples, centroids, groups, n_groups, drifts, assignments, bounds
     changed = lib().kmo_yy_local_filter(m, n, x.shape[1], c.shape[0], n_groups, _fp(x), _up(passed), npassed,
                                         _fp(c), _up(g), _fp(dr), _up(a), _fp(b))
     return a, prev, b, np.sort(passed[:npassed]), changed
+
+
+def xorwow_draws(seed, subsequence, offset, n, curand_seeding=True):
+    """n raw 32-bit draws of the XORWOW stream (seed, subsequence, offset) as AFK-MC2 seeds it (kmeans.cu:112-116:
+    curand_init(seed, thread, step)).  curand_seeding=False: rocRAND's seed scrambling instead (kmcuda_oracle.c: the
+    one place the two libraries' XORWOW differ), for checks against rocRAND's own generator."""
+    out = np.empty(n, np.uint32)
+    f = lib().kmo_xorwow_draws
+    f.restype = None
+    f.argtypes = [i32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, u32, _u32p]
+    f(1 if curand_seeding else 0, seed, subsequence, offset, n, _up(out))
+    return out

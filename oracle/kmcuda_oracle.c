@@ -688,13 +688,25 @@ static double kmpp_step(int metric, uint32_t N, uint32_t D, uint32_t cc, const f
 /* AFK-MC2 seeding: kmeans.cu:69-212 (kernels), kmcuda.cc:337-396 (host chain).            */
 /* Third-party arithmetic: the reference draws from cuRAND's XORWOW (CUDA toolkit 8.0,    */
 /* curand_init(seed, thread, step) + curand_uniform), which is not in /root/reference.    */
-/* Restated from the published algorithm: Marsaglia's xorwow (5 x 32-bit xorshift + a     */
-/* Weyl sequence, increment 362437), state seeded and advanced as rocRAND 7.2's           */
-/* xorwow_engine documents it (rocrand_xorwow.h: seed scrambling constants; subsequence   */
-/* = 2^67 draws via precomputed jump matrices, taken from the system header               */
-/* rocrand_xorwow_precomputed.h), and cuRAND's uint -> (0,1] map x*2^-32 + 2^-33.          */
-/* Whether CUDA's sequence is bit-identical cannot be checked here: PARITY UNPINNED       */
-/* beyond the reference's 4 / 4 / 4 iteration pins (test.py:248-289).                     */
+/* Restated from the published algorithm, piece by piece:                                 */
+/*  - the generator: Marsaglia's xorwow (5 x 32-bit xorshift + a Weyl sequence, increment */
+/*    362437), output d + x[4] -- the same lines in curand_kernel.h and rocrand_xorwow.h;  */
+/*  - skipping: subsequence = 2^67 draws, offset = single draws, both as powers of the    */
+/*    recurrence's matrix (a property of the recurrence, not of a library); the powers    */
+/*    come from the system header rocrand_xorwow_precomputed.h; the Weyl value moves by   */
+/*    offset * 362437;                                                                    */
+/*  - the SEED SCRAMBLING is where the two libraries differ: cuRAND (curand_kernel.h,     */
+/*    _curand_init_scratch) salts the seed's halves with 0xaad26b49 / 0xf7dcefdd and      */
+/*    multiplies by 1099087573 / 2591861531; rocRAND's xorwow_engine uses 0x2c7f967f /    */
+/*    0xa03697cb and 1228688033 / 2073658381 -- rocRAND's XORWOW is NOT sequence-         */
+/*    compatible with cuRAND's for a given seed.  The reference calls cuRAND, so AFK-MC2  */
+/*    here seeds the state cuRAND's way (flavour 1); flavour 0 (rocRAND's constants)      */
+/*    exists so that everything else in this restatement can be checked against a second  */
+/*    implementation: rocRAND's host generator (tests/test_gpu_afkmc2_rng.py);            */
+/*  - cuRAND's uint -> (0,1] map x * 2^-32 + 2^-33.                                        */
+/* No cuRAND output vector is available offline, so the constants above are checked by    */
+/* nothing but their source: PARITY UNPINNED beyond the reference's 4 / 4 / 4 iteration   */
+/* pins (test.py:248-289), which both flavours meet.                                      */
 /* ------------------------------------------------------------------------------------ */
 #define __device__
 #include <rocrand/rocrand_xorwow_precomputed.h>
@@ -721,16 +733,22 @@ static void xorwow_jump(xorwow_t *st, unsigned long long v, const unsigned int m
   }
 }
 
-static void xorwow_init(xorwow_t *st, unsigned long long seed, unsigned long long subsequence, unsigned long long offset) {
+static void xorwow_init_flavour(xorwow_t *st, int curand_seeding, unsigned long long seed, unsigned long long subsequence,
+                                unsigned long long offset) {
   st->x[0] = 123456789u; st->x[1] = 362436069u; st->x[2] = 521288629u; st->x[3] = 88675123u; st->x[4] = 5783321u;
   st->d = 6615241u;
-  const uint32_t s0 = (uint32_t)seed ^ 0x2c7f967fu, s1 = (uint32_t)(seed >> 32) ^ 0xa03697cbu;
-  const uint32_t t0 = 1228688033u * s0, t1 = 2073658381u * s1;
+  const uint32_t s0 = (uint32_t)seed ^ (curand_seeding ? 0xaad26b49u : 0x2c7f967fu);
+  const uint32_t s1 = (uint32_t)(seed >> 32) ^ (curand_seeding ? 0xf7dcefddu : 0xa03697cbu);
+  const uint32_t t0 = (curand_seeding ? 1099087573u : 1228688033u) * s0, t1 = (curand_seeding ? 2591861531u : 2073658381u) * s1;
   st->x[0] += t0; st->x[1] ^= t0; st->x[2] += t1; st->x[3] ^= t1; st->x[4] += t0;
   st->d += t1 + t0;
   xorwow_jump(st, subsequence, h_xorwow_sequence_jump_matrices);
   xorwow_jump(st, offset, h_xorwow_jump_matrices);
   st->d += (uint32_t)offset * 362437u;
+}
+
+static void xorwow_init(xorwow_t *st, unsigned long long seed, unsigned long long subsequence, unsigned long long offset) {
+  xorwow_init_flavour(st, 1, seed, subsequence, offset);   /* the reference's library: cuRAND */
 }
 
 static uint32_t xorwow_next(xorwow_t *st) {
@@ -739,6 +757,14 @@ static uint32_t xorwow_next(xorwow_t *st) {
   st->x[4] = (st->x[4] ^ (st->x[4] << 4)) ^ (t ^ (t << 1));
   st->d += 362437u;
   return st->d + st->x[4];
+}
+
+/* n raw draws of the stream (seed, subsequence, offset) -- the tests' window on the restatement */
+void kmo_xorwow_draws(int curand_seeding, unsigned long long seed, unsigned long long subsequence,
+                      unsigned long long offset, uint32_t n, uint32_t *out) {
+  xorwow_t st;
+  xorwow_init_flavour(&st, curand_seeding, seed, subsequence, offset);
+  for (uint32_t i = 0; i < n; i++) out[i] = xorwow_next(&st);
 }
 
 static float afk_uniform(uint32_t x) { return fmaf((float)x, 2.3283064e-10f, 2.3283064e-10f / 2.0f); }

@@ -374,3 +374,17 @@ def test_half2_knn_against_a_numpy_restatement(metric):
     # the mode is reset: an fp32 call afterwards is the fp32 arithmetic
     plain, _ = oracle.knn(k, x.astype(numpy.float32), cen.astype(numpy.float32), a, metric=metric)
     assert plain.shape == got.shape
+
+
+def test_xorwow_restatement_is_self_consistent_and_pinned():
+    """AFK-MC2's generator (oracle/kmcuda_oracle.c): jumping `offset` draws ahead equals drawing them, under both seed
+    scramblings; the first draws of (seed 3, subsequence 0, offset 0) as a regression pin (cuRAND's constants: what the
+    seeding uses; rocRAND's: what tests/test_gpu_afkmc2_rng.py checks against rocRAND's host generator)."""
+    for flavour in (True, False):
+        for seed, t in ((3, 0), (0xFFFFFFFF, 5), (2**40 + 9, 199)):
+            base = oracle.xorwow_draws(seed, t, 0, 1100, curand_seeding=flavour)
+            for k in (1, 2, 63, 1024):
+                assert (oracle.xorwow_draws(seed, t, k, 8, curand_seeding=flavour) == base[k:k + 8]).all()
+        assert not (oracle.xorwow_draws(3, 0, 0, 4, curand_seeding=flavour) == oracle.xorwow_draws(3, 1, 0, 4, curand_seeding=flavour)).any()
+    assert list(oracle.xorwow_draws(3, 0, 0, 4, curand_seeding=True)) == [3846186680, 2306068187, 4034236305, 1721582715]
+    assert list(oracle.xorwow_draws(3, 0, 0, 4, curand_seeding=False)) == [1865448851, 3091812441, 3400940839, 786499017]
