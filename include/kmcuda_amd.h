@@ -153,9 +153,11 @@ int kmamd_carry_pair_stats(kmamd_engine *e, uint64_t *rows_paired);
 int kmamd_duo_rows(kmamd_engine *e, uint32_t *rows);
 /* The host side of the carried bounds replayed without a device (tests): pass i + 1 would count list_len[i] rows if it
  * counts a list, a pass's report reaches the host `lag` >= 1 passes later; out[i] = 0 plain pass (the bounds are paused),
- * 1 whole pass that leaves bounds but has none to move, 2 whole pass that counts its would-be list, 3 listed pass. */
+ * 1 whole pass that leaves bounds but has none to move, 2 whole pass that counts its would-be list, 3 listed pass.
+ * changed (may be null): the passes' reassignment counts, which the host judges `lag` passes late too -- a run that
+ * converges slowly (counts falling by less than a third per pass) answers two hopeless lists with one long pause. */
 int kmamd_carry_policy_sim(uint32_t n_passes, uint32_t n_rows, float list_max, const uint32_t *list_len, uint32_t lag,
-                           uint8_t *out);
+                           uint8_t *out, const uint32_t *changed);
 /* Test / A-B hook for the update's host logic: 0 default, 1 radix path always, 2 always read the
  * counts before choosing (the pre-round-2 behaviour), 3 bucket path always without reading (exercises
  * the device-side fallback of oversized buckets).  Env KMCUDA_AMD_UPDATE=radix|sync|bucket sets it at

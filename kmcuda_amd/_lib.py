@@ -95,7 +95,7 @@ def lib():
     L.kmamd_duo_rows.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
     L.kmamd_carry_policy_sim.restype = i32
     L.kmamd_carry_policy_sim.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_float, ctypes.POINTER(ctypes.c_uint32),
-                                         ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint8)]
+                                         ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint32)]
     L.kmamd_set_update_mode.restype = i32
     L.kmamd_set_update_mode.argtypes = [vp, i32]
     L.kmamd_last_run_stats.restype = i32

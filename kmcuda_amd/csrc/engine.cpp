@@ -614,6 +614,16 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
       }
     }
     span_begin(3);  // the dominant kernel on its own, inside the filter span
+    // The duo list pays when it takes whole ROUNDS of blocks off stage 2's sweep: a list that fits one round of its
+    // 128-row blocks (two per CU) is one sweep long either way, and the second kernel only adds its launch.  By an
+    // earlier pass's list lengths (whatever the update's report has delivered), the row count before any report.
+    duo_listed = duo_on_ && duo_;
+    if (duo_listed && !duo_always_) {
+      const uint32_t und_prev = host_move_count_[2], duo_prev = host_move_count_[4];
+      const uint64_t listed_rows = (und_prev != 0xFFFFFFFFu && duo_prev != 0xFFFFFFFFu) ? (uint64_t)und_prev + duo_prev
+                                                                                          : (uint64_t)N_ / 16u;
+      duo_listed = listed_rows > 512u * 128u;
+    }
     CarryArgs cy_refine;   // (stage 2 leaves bounds only in a carried pass)
     if (carry && carry_on_) {
       CarryArgs cy;
@@ -650,20 +660,11 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
         fprintf(stderr, "[carry] pass %u: bounds %s, %u preparation(s) since, last reported list %u (pass %u), %s\n",
                 carry_seq_, carry_was_valid ? "valid" : "void", carry_preps_, host_carry_[0], host_carry_[1],
                 listed ? "listed pass" : (moved ? "whole pass, list counted" : "whole pass"));
-      KMX_HIP(launch_lloyd_coarse_carry(a, rows, half, xcache_, xmeta_, panelhi_, undecided_, und_thr_, cy, hint, stream_),
+      KMX_HIP(launch_lloyd_coarse_carry(a, rows, half, xcache_, xmeta_, panelhi_, undecided_, und_thr_, cy, hint,
+                                        duo_listed ? duo_ : nullptr, stream_),
               kRuntimeError);
       carry_valid_ = true;
     } else {
-      // The duo list pays when it takes whole ROUNDS of blocks off stage 2's sweep: a list that fits one round of its
-      // 128-row blocks (two per CU) is one sweep long either way, and the second kernel only adds its launch.  By an
-      // earlier pass's list lengths (whatever the update's report has delivered), the row count before any report.
-      duo_listed = duo_on_ && duo_;
-      if (duo_listed && !duo_always_) {
-        const uint32_t und_prev = host_move_count_[2], duo_prev = host_move_count_[4];
-        const uint64_t listed = (und_prev != 0xFFFFFFFFu && duo_prev != 0xFFFFFFFFu) ? (uint64_t)und_prev + duo_prev
-                                                                                       : (uint64_t)N_ / 16u;
-        duo_listed = listed > 512u * 128u;
-      }
       KMX_HIP(launch_lloyd_coarse(a, rows, half, cached ? xcache_ : nullptr, xmeta_, panelhi_, undecided_, und_thr_,
                                   duo_listed ? duo_ : nullptr, stream_),
               kRuntimeError);
@@ -673,7 +674,7 @@ int Engine::lloyd_assign(const float *samples, const float *centroids, uint32_t 
     if (duo_listed) {
       KMX_HIP(hipEventRecord(ev_fork_, stream_), kRuntimeError);
       KMX_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0), kRuntimeError);
-      KMX_HIP(launch_lloyd_duo(a, duo_, side_stream_), kRuntimeError);
+      KMX_HIP(launch_lloyd_duo(a, duo_, side_stream_, cy_refine.l3 ? &cy_refine : nullptr), kRuntimeError);
       KMX_HIP(hipEventRecord(ev_join_, side_stream_), kRuntimeError);
     }
     carry_preps_ = 0;
@@ -1102,7 +1103,7 @@ int kmamd_carry_stats(kmamd_engine *e, uint64_t *rows_spared, uint32_t *last_lis
 // (paused), 1 a whole pass that leaves bounds (none were valid: nothing to count), 2 a whole pass that counts its
 // would-be list, 3 a listed pass.
 int kmamd_carry_policy_sim(uint32_t n_passes, uint32_t n_rows, float list_max, const uint32_t *list_len, uint32_t lag,
-                           uint8_t *out) {
+                           uint8_t *out, const uint32_t *changed) {
   if (!list_len || !out || lag == 0) return kmx::kInvalidArguments;
   kmx::CarryPolicy policy;
   policy.list_max = list_max;
@@ -1111,6 +1112,8 @@ int kmamd_carry_policy_sim(uint32_t n_passes, uint32_t n_rows, float list_max, c
   bool valid = false;
   for (uint32_t i = 0; i < n_passes; i++) {
     const uint32_t seq = i + 1;
+    // (the host has judged the passes at least `lag` back: their reassignment counts)
+    if (changed && i >= lag) policy.note_changed(changed[i - lag]);
     if (policy.paused()) {
       out[i] = 0;
       valid = false;

@@ -47,6 +47,25 @@ struct CarryPolicy {
   // twenty whole passes paid 0.5 ms each for bounds that spared nothing, profiles/r5ac_carry_trace_config_b.log.)
   uint32_t pause = 0, backoff = 4, hopeless = 0, seen_seq = 0;
   static constexpr uint32_t kNoList = 0xFFFFFFFFu;   // the report of a pass that had no list to count
+  // When pausing is not enough.  Uniform rows (BASELINE config B) never get short lists: 98 % -> 92 % -> 81 % of the rows
+  // over twenty iterations, while the reassignments fall 1.1x per iteration; the doubling pauses above still probed
+  // thirteen times in its 46 iterations (round 5: 0.236 s against 0.231 for yinyang_t = 0).  So: a SECOND pause in a row
+  // whose hopeless list is barely shorter than the one that started the first (> 90 % of it), in a run whose
+  // reassignment count falls by less than a third per iteration (note_changed: the counts the host judges anyway), is
+  // a long one (kSlowPause).  Both conditions are needed -- a run can converge slowly with short lists (a mixture's
+  // tail: never paused), and right behind the hand-over point a mixture lists every row for a pass or two (large
+  // drifts) before its lists collapse: its second episode is nothing like its first.  (Tried first: the long pause on
+  // the first hopeless count of any slowly converging run -- it switched the bounds off for a whole angular mixture run
+  // whose early reassignments fall slowly, tests/test_gpu_carry.py.)
+  static constexpr uint32_t kSlowPause = 64;
+  uint32_t changed_prev = 0, changed_last = 0, episode_list = 0;
+  void note_changed(uint32_t changed) {
+    changed_prev = changed_last;
+    changed_last = changed;
+  }
+  bool converging_slowly() const {
+    return changed_prev != 0 && changed_last != 0 && (float)changed_prev < 1.5f * (float)changed_last;
+  }
 
   // A pass is about to run with carrying switched on: true = it runs plain (one pass of a pause is used up).
   bool paused() {
@@ -65,7 +84,9 @@ struct CarryPolicy {
       const float give_up = list_max > 0.f && list_max < 0.9f ? list_max : 0.9f;
       if ((float)last > give_up * (float)n_rows && list_max < 1.0f) {
         if (++hopeless >= 2) {
-          pause = backoff;
+          const bool flat = episode_list != 0 && (float)last > 0.9f * (float)episode_list;
+          pause = flat && converging_slowly() ? kSlowPause : backoff;
+          episode_list = last;
           backoff = backoff < 32 ? 2 * backoff : 32;
           hopeless = 0;
           seen_seq = this_seq;
@@ -73,6 +94,7 @@ struct CarryPolicy {
       } else {
         hopeless = 0;
         backoff = 4;
+        episode_list = 0;
       }
     }
     return listed;

@@ -117,7 +117,7 @@ hipError_t launch_apply_prep_frozen(const double *delta, const double *dcount_d,
 // counters[kCarryCursor] (probe: only counts them)
 hipError_t launch_lloyd_coarse_carry(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
                                      const float *xmeta, const void *panelhi, uint32_t *undecided, float *und_thr,
-                                     const CarryArgs &cy, uint32_t rows_hint, hipStream_t st);
+                                     const CarryArgs &cy, uint32_t rows_hint, uint32_t *duo, hipStream_t st);
 // (cy.l3 / p1 / p2 / finite / pairs: the pair certificates; pairs[3 counters[3]++] = (row, p1, p2))
 hipError_t launch_carry_skip(uint32_t N, uint32_t K, const uint32_t *assignments, uint32_t *assignments_prev,
                              const CarryArgs &cy, const float *xmeta, const float *drift, const uint32_t *stats,
@@ -136,7 +136,8 @@ hipError_t launch_lloyd_coarse(const LloydArgs &a, const void *rows, bool half_r
                                uint32_t *duo, hipStream_t st);
 // stage 2 without its sweep for the duo rows (lloyd_duo.hip): the two contenders scored in fp32, decided like
 // launch_lloyd_refine's rows
-hipError_t launch_lloyd_duo(const LloydArgs &a, const uint32_t *duo, hipStream_t st);
+// cy (a carried pass with pair certificates: cy->l3 != nullptr): the rows leave with stage 2's bounds and certificates
+hipError_t launch_lloyd_duo(const LloydArgs &a, const uint32_t *duo, hipStream_t st, const CarryArgs *cy = nullptr);
 // stage 2 of the default filter: the undecided rows' contenders (coarse score >= und_thr) scored in fp32
 hipError_t launch_lloyd_refine(const LloydArgs &a, const void *rows, bool half_rows, const void *panelhi,
                                const uint32_t *row_list, const float *thr_list, const uint32_t *n_list,

@@ -1101,6 +1101,7 @@ class Job {
     if (passed_total) *passed_total = overall_passed;
     if (print) INFO("iteration %d: %u reassignments\n", iter, overall_changed);
     stamp(iter);
+    for (auto &s : shards) s->eng->carry_policy_.note_changed(overall_changed);   // (how fast the run converges: engine.hpp)
     if (overall_changed <= tolerance * N) return 1;  // counters are NOT zeroed on stop (kmeans.cu:707-709)
     for (auto &s : shards)
       if (s->eng->counters_reset(0) != 0) return -kmcudaRuntimeError;
@@ -1297,6 +1298,7 @@ class Job {
     INFO("iteration %d: %u reassignments\n", iter, t[0]);
     stamp(iter);
     if (changed) *changed = t[0];
+    for (auto &s : shards) s->eng->carry_policy_.note_changed(t[0]);
     stats.iterations++;
     return t[4] ? 1 : 0;
   }

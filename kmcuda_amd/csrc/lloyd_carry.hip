@@ -222,7 +222,7 @@ hipError_t launch_carry_skip(uint32_t N, uint32_t K, const uint32_t *assignments
 template <int DP>
 static hipError_t launch_coarse_carry_dp(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
                                          const float *xmeta, const void *panelhi, uint32_t *undecided, float *und_thr,
-                                         const CarryArgs &cy, uint32_t rows_hint, hipStream_t st) {
+                                         const CarryArgs &cy, uint32_t rows_hint, uint32_t *duo, hipStream_t st) {
   constexpr int NSET = DP <= 256 ? 2 : 1;
   const size_t lds_bytes = 2 * 64 * (size_t)(DP * 2) + 512 + 64 + (size_t)DP * 4;
   const uint32_t rows_per_block = 128u * NSET;
@@ -231,7 +231,7 @@ static hipError_t launch_coarse_carry_dp(const LloydArgs &a, const void *rows, b
 #define KMX_CARRY_LAUNCH(H, F, C, MODE, SRC)                                                                          \
   hipLaunchKernelGGL((lloyd_coarse2_kernel<DP, H, F, C, NSET, MODE>), dim3(grid), dim3(256), lds_bytes, st, SRC,      \
                      xmeta, a.N, a.D, reinterpret_cast<const float *>(panelhi), a.bias, a.mu, a.K_pad, a.K, a.stats,   \
-                     a.eps, a.tie_slack, a.assignments, a.assignments_prev, undecided, und_thr, a.counters, cy)
+                     a.eps, a.tie_slack, a.assignments, a.assignments_prev, undecided, und_thr, a.counters, cy, duo)
   if (!cy.row_list) {   // every row, streamed from the row cache
     KMX_CARRY_LAUNCH(false, true, true, 1, xcache);
     return hipGetLastError();
@@ -260,10 +260,10 @@ static hipError_t launch_coarse_carry_dp(const LloydArgs &a, const void *rows, b
 // cy.row_list == nullptr: a whole pass from the row cache (xcache) that leaves bounds; else the listed rows
 hipError_t launch_lloyd_coarse_carry(const LloydArgs &a, const void *rows, bool half_rows, const void *xcache,
                                      const float *xmeta, const void *panelhi, uint32_t *undecided, float *und_thr,
-                                     const CarryArgs &cy, uint32_t rows_hint, hipStream_t st) {
+                                     const CarryArgs &cy, uint32_t rows_hint, uint32_t *duo, hipStream_t st) {
   switch (a.DP) {
 #define KMX_CARRY_CASE(dp) \
-    case dp: return launch_coarse_carry_dp<dp>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, und_thr, cy, rows_hint, st)
+    case dp: return launch_coarse_carry_dp<dp>(a, rows, half_rows, xcache, xmeta, panelhi, undecided, und_thr, cy, rows_hint, duo, st)
     KMX_CARRY_CASE(16); KMX_CARRY_CASE(32); KMX_CARRY_CASE(64); KMX_CARRY_CASE(128); KMX_CARRY_CASE(256); KMX_CARRY_CASE(512);
 #undef KMX_CARRY_CASE
     default: return hipErrorInvalidValue;

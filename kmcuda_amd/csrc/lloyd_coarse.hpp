@@ -370,9 +370,10 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
   bool unda = false, undb = false, duoa = false, duob = false;
   uint32_t d1a = 0, d2a = 0, d1b = 0, d2b = 0;
   float dra = 0.f, drb = 0.f;
-  // rows whose contenders are known by index (DUO) leave on a list of their own -- plain passes only: a carried pass
-  // wants the bounds stage 2 derives while it sweeps
-  const bool want_duo = CARRY == 0 && duo != nullptr;
+  // rows whose contenders are known by index (DUO) leave on a list of their own (lloyd_duo.hip; in a carried pass the
+  // duo kernel also leaves the bounds / pair certificates stage 2 would have: the record carries the best score of
+  // all the other centroids)
+  const bool want_duo = duo != nullptr;
   const bool angular = tie_slack > 0.f;   // (engine.cpp: the angular metric's plateau slack; 0 under L2)
   // xdm = x.mu, xab >= sum |x_f mu_f| (< 0: not summed here -- the row cache's record: ||x|| ||mu|| bounds it)
   auto finish = [&](uint32_t s, bool live, const float (&q1)[2], const float (&q2)[2], const uint32_t (&qt)[2], float xn2,
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void lloyd_coarse2_kernel(
     if (mine && certain) changed = commit_row(s, insane ? K : i1, assignments, assignments_prev);
     und = mine && !certain;
     is_duo = false;
-    if constexpr (CARRY == 0) {
+    {
       // undecided, a usable cut-off (below), and only the two best quarters' bests reach it: stage 2's answer -- the
       // contenders are j0 and j1 -- without its sweep.  (The scores compared are the packed ones stage 1 decides on
       // itself: e_c covers the index bits.)

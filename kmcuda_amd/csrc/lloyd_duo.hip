@@ -31,13 +31,16 @@ __device__ __forceinline__ float row16_sum(float v) {
 constexpr uint32_t kDuoPend = 64;   // pair / full-scan records a wave holds back before it asks for list slots
 
 // NI: 64-feature slices per row (the padded width / 64, at least 1).  FAST: D == DP and 16-byte aligned rows.
-template <int NI, bool FAST>
+// BOUNDS: a carried pass (lloyd_carry.hip) -- the rows leave with what lloyd_refine_kernel<..., PAIRS> leaves for a row
+// with two contenders: an upper bound of BOTH distances, a lower bound for every other centroid (from the record's
+// best score of the others), the pair itself (angular: the gap by which both scores exceed every other centroid's).
+template <int NI, bool FAST, bool BOUNDS = false>
 __global__ __launch_bounds__(256, NI >= 4 ? 2 : 4) void lloyd_duo_kernel(
     const float *__restrict__ samples, uint32_t D, uint32_t DP, uint32_t K, const float *__restrict__ cfil,
     const float *__restrict__ bias, const float *__restrict__ mu, const uint32_t *__restrict__ stats, float eps,
     float tie_slack, const uint4 *__restrict__ duo, uint32_t *__restrict__ assignments,
     uint32_t *__restrict__ assignments_prev, uint32_t *__restrict__ flagged, uint32_t *__restrict__ pairs,
-    uint32_t *__restrict__ counters) {
+    uint32_t *__restrict__ counters, CarryArgs cy) {
   if (counters[kStopFlag] != 0u) return;   // (block-uniform: the run has stopped on the device)
   constexpr int SLOTS = NI >= 8 ? 1 : 2;   // groups of four rows in flight per wave
   const uint32_t total = counters[kDuoCount];
@@ -160,6 +163,40 @@ __global__ __launch_bounds__(256, NI >= 4 ? 2 : 4) void lloyd_duo_kernel(
       const bool mine = live[k] && l == 0;
       const bool pair_now = mine && two, flag_now = mine && !certain && !two;
       if (mine && certain && commit_row(s, insane ? K : i1, assignments, assignments_prev)) nchg++;
+      if constexpr (BOUNDS) {   // lloyd_refine_kernel's statements for n = 2 contenders (its comments hold the derivation)
+        if (mine) {
+          const float rest = __uint_as_float(rec[k].w);
+          const bool ok = !insane && in_range && (certain || two);
+          const float e = e_mfma * 1.001f;
+          const float dcmax = sqrtf(__uint_as_float(stats[5])) * 1.000001f, dxw = 4.8829e-4f * xn;
+          const float e_c = 2.0f * eps * (xn * cmaxc + bmaxc) + (xn * dcmax + dxw * cmaxc + dxw * dcmax) * 1.001f +
+                            6e-8f * sqrtf((float)DP) * (xn + cmaxc) + 2.0e-6f * (1.001f * xn * cmaxc + bmaxc);
+          const float w = fmaxf(rest + e_c * 1.001f, v3 + e);
+          if (cy.angular) {
+            float pairg = 0.f;
+            if (ok && i2 < K) pairg = fminf(fminf((v2 - e) - w, lim.hi - w), v2 - lim.lo) * 0.999999f;
+            if (!(pairg > 0.f)) pairg = 0.f;   // (NaN too)
+            cy.ub[s] = -INFINITY;              // (no single-contender gap: the row has two)
+            cy.l3[s] = pairg;
+            if (pairg > 0.f) { cy.p1[s] = i1; cy.p2[s] = i2; }
+          } else {
+            float ubv = INFINITY, l3v = 0.f;
+            if (ok) {
+              const float geo = 2.4e-7f * (xn + cmaxc);
+              const float d2l = xn2 * (1.0f - 2.0f * eps) - 2.0f * w;
+              float low = d2l > 0.f ? fmaxf(sqrtf(d2l) * 0.999999f - geo, 0.f) : 0.f;
+              if (!(low == low)) low = 0.f;
+              ubv = sqrtf(fmaxf(xn2 * (1.0f + 2.0f * eps) - 2.0f * (v2 - e), 0.f)) * 1.000001f + geo;
+              if (!(ubv == ubv)) ubv = INFINITY;
+              if (i2 < K) l3v = low;
+            }
+            cy.ub[s] = ubv;
+            cy.lb[s] = 0.f;
+            cy.l3[s] = l3v;
+            if (l3v > 0.f) { cy.p1[s] = i1; cy.p2[s] = i2; }
+          }
+        }
+      }
       const unsigned long long pm = __ballot(pair_now), fm = __ballot(flag_now);
       if (pm) {   // wave-uniform
         if (np + 4 > kDuoPend) flush(&counters[3], pairs, mypairs, 3, np);
@@ -196,28 +233,32 @@ __global__ __launch_bounds__(256, NI >= 4 ? 2 : 4) void lloyd_duo_kernel(
 }
 
 template <int NI>
-static hipError_t launch_duo_ni(const LloydArgs &a, const uint32_t *duo, hipStream_t st) {
+static hipError_t launch_duo_ni(const LloydArgs &a, const uint32_t *duo, hipStream_t st, const CarryArgs *cy) {
   const bool fast = a.D == a.DP && (((uintptr_t)a.samples) & 15u) == 0 && a.DP % 4 == 0;
   // the waves that are resident at once at this kernel's register count (2 or 4 blocks per CU of 256); every wave
   // strides over the device-side count
   const uint32_t want = (a.N + 31u) / 32u, full = NI >= 4 ? 512u : 1024u;
   const dim3 grid(want < full ? (want ? want : 1u) : full);
-#define KMX_DUO_LAUNCH(F)                                                                                          \
-  hipLaunchKernelGGL((lloyd_duo_kernel<NI, F>), grid, dim3(256), 0, st, a.samples, a.D, a.DP, a.K, a.cfil, a.bias, a.mu, \
-                     a.stats, a.eps, a.tie_slack, reinterpret_cast<const uint4 *>(duo), a.assignments,             \
-                     a.assignments_prev, a.flagged, a.pairs, a.counters)
-  if (fast) KMX_DUO_LAUNCH(true); else KMX_DUO_LAUNCH(false);
+#define KMX_DUO_LAUNCH(F, B, CY)                                                                                      \
+  hipLaunchKernelGGL((lloyd_duo_kernel<NI, F, B>), grid, dim3(256), 0, st, a.samples, a.D, a.DP, a.K, a.cfil, a.bias,    \
+                     a.mu, a.stats, a.eps, a.tie_slack, reinterpret_cast<const uint4 *>(duo), a.assignments,          \
+                     a.assignments_prev, a.flagged, a.pairs, a.counters, CY)
+  if (cy && cy->l3) {
+    if (fast) KMX_DUO_LAUNCH(true, true, *cy); else KMX_DUO_LAUNCH(false, true, *cy);
+  } else {
+    if (fast) KMX_DUO_LAUNCH(true, false, CarryArgs()); else KMX_DUO_LAUNCH(false, false, CarryArgs());
+  }
 #undef KMX_DUO_LAUNCH
   return hipGetLastError();
 }
 
-hipError_t launch_lloyd_duo(const LloydArgs &a, const uint32_t *duo, hipStream_t st) {
+hipError_t launch_lloyd_duo(const LloydArgs &a, const uint32_t *duo, hipStream_t st, const CarryArgs *cy) {
   if (a.N == 0) return hipSuccess;
   switch (a.DP) {
-    case 16: case 32: case 64: return launch_duo_ni<1>(a, duo, st);
-    case 128: return launch_duo_ni<2>(a, duo, st);
-    case 256: return launch_duo_ni<4>(a, duo, st);
-    case 512: return launch_duo_ni<8>(a, duo, st);
+    case 16: case 32: case 64: return launch_duo_ni<1>(a, duo, st, cy);
+    case 128: return launch_duo_ni<2>(a, duo, st, cy);
+    case 256: return launch_duo_ni<4>(a, duo, st, cy);
+    case 512: return launch_duo_ni<8>(a, duo, st, cy);
     default: return hipErrorInvalidValue;
   }
 }

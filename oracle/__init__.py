@@ -273,10 +273,16 @@ def yy_filters(samples, centroids, groups, n_groups, drifts, assignments, bounds
     return a, prev, b, np.sort(passed[:npassed]), changed
 
 
-def xorwow_draws(seed, subsequence, offset, n, curand_seeding=True):
-    """n raw 32-bit draws of the XORWOW stream (seed, subsequence, offset) as AFK-MC2 seeds it (kmeans.cu:112-116:
-    curand_init(seed, thread, step)).  curand_seeding=False: rocRAND's seed scrambling instead (kmcuda_oracle.c: the
-    one place the two libraries' XORWOW differ), for checks against rocRAND's own generator."""
+def set_afkmc2_seeding(curand):
+    """AFK-MC2's seed scrambling: False = rocRAND's constants (default), True = cuRAND's as quoted in kmcuda_oracle.c."""
+    lib().kmo_set_afkmc2_seeding.argtypes = [i32]
+    lib().kmo_set_afkmc2_seeding(1 if curand else 0)
+
+
+def xorwow_draws(seed, subsequence, offset, n, curand_seeding=False):
+    """n raw 32-bit draws of the XORWOW stream (seed, subsequence, offset) of AFK-MC2's generator (kmeans.cu:112-116:
+    curand_init(seed, thread, step)) under rocRAND's seed scrambling (default) or cuRAND's (kmcuda_oracle.c: the one
+    place the two libraries' XORWOW differ)."""
     out = np.empty(n, np.uint32)
     f = lib().kmo_xorwow_draws
     f.restype = None

@@ -98,8 +98,10 @@ float kmo_h_rn(double v);
 float kmo_h_from_int_rd(long long v);
 /* m of init = KMO_INIT_AFKMC2 (0 => 200), kmcuda.h:89-92 */
 void kmo_set_afkmc2_m(uint32_t m);
-/* raw XORWOW draws of the stream (seed, subsequence, offset); curand_seeding: 1 = cuRAND's seed scrambling (what AFK-MC2
- * uses, as the reference does), 0 = rocRAND's (kmcuda_oracle.c: the one place the two libraries differ) */
+/* AFK-MC2's seed scrambling: 0 = rocRAND's constants (default: meets all four of the reference's pins), 1 = cuRAND's as
+ * quoted in kmcuda_oracle.c (three of four) */
+void kmo_set_afkmc2_seeding(int curand);
+/* raw XORWOW draws of the stream (seed, subsequence, offset) under either seed scrambling */
 void kmo_xorwow_draws(int curand_seeding, unsigned long long seed, unsigned long long subsequence,
                       unsigned long long offset, uint32_t n, uint32_t *out);
 float kmo_quantize_half(float x);

@@ -151,14 +151,15 @@ def test_native_cpython_module_in_the_library():
     assert not [l for l in syms.splitlines() if " Py" in l or "_Py" in l]
 
 
-def _policy(list_len, n_rows=1000, list_max=0.5, lag=1):
+def _policy(list_len, n_rows=1000, list_max=0.5, lag=1, changed=None):
     import ctypes
     from kmcuda_amd import _lib
     L = _lib.lib()
     n = len(list_len)
     arr = (ctypes.c_uint32 * n)(*list_len)
     out = (ctypes.c_uint8 * n)()
-    assert L.kmamd_carry_policy_sim(n, n_rows, ctypes.c_float(list_max), arr, lag, out) == 0
+    chg = (ctypes.c_uint32 * n)(*changed) if changed is not None else None
+    assert L.kmamd_carry_policy_sim(n, n_rows, ctypes.c_float(list_max), arr, lag, out, chg) == 0
     return list(out)
 
 
@@ -189,6 +190,24 @@ def test_carried_bounds_host_policy_without_gpu():
     # a single hopeless count between good ones (a cluster died: every row listed once) pauses nothing
     out = _policy([0, 100, 100, 1000, 100, 100, 100, 100], lag=1)
     assert 0 not in out and out[-2:] == [3, 3]
+    # Uniform rows (BASELINE config B): lists that stay hopeless AND reassignments that fall 1.1x per pass -- the second
+    # pause in a row is a long one (round 5: thirteen probing passes in its 46 iterations, 0.236 s against 0.231 for
+    # yinyang_t = 0).  The first is the usual four passes: a mixture right behind the hand-over point looks the same there.
+    slow = [int(1000 * 0.9 ** i) + 1 for i in range(90)]
+    out = _policy([980] * 90, lag=1, changed=slow)
+    assert out[:4] == [1, 2, 2, 2] and out[4:8] == [0] * 4 and out[8:12] == [1, 2, 2, 2], out
+    assert out[12:76] == [0] * 64 and out[76] == 1, out
+    # ... not when the second episode's list is clearly shorter than the first's (the doubling pauses go on) ...
+    out = _policy([980] * 8 + [800] * 82, lag=1, changed=slow)
+    assert out[12:20] == [0] * 8 and out[20] == 1, out
+    # ... nor when the reassignments collapse (the lists will, too) ...
+    fast = [1000, 400, 90, 30, 12, 9, 8, 7] + [7] * 82
+    out = _policy([980] * 90, lag=1, changed=[max(1, int(4e9 * 0.5 ** i)) for i in range(90)])
+    assert out[12:20] == [0] * 8 and out[20] == 1, out
+    lens = [0, 1000, 1000] + [120] * 20
+    assert _policy(lens, lag=1, changed=fast[:len(lens)]).count(0) == 4
+    # ... and slowly converging runs with SHORT lists (a mixture's tail) are never paused
+    assert 0 not in _policy([120] * 30, lag=1, changed=slow[:30])
     # list_max = 1 (tests): always listed once a count is known, never paused; list_max = 0: never listed
     assert 0 not in _policy([1000] * 12, list_max=1.0) and _policy([1000] * 12, list_max=1.0)[-1] == 3
     assert 3 not in _policy([10] * 12, list_max=0.0)

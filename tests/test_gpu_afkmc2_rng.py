@@ -2,14 +2,17 @@
 curand_uniform; host chain kmcuda.cc:337-396).
 
 cuRAND is not in /root/reference and not on this box, so the generator is a restatement (oracle/kmcuda_oracle.c has the
-piece-by-piece account).  What CAN be pinned, and is here:
+piece-by-piece account: cuRAND and rocRAND share the generator and the jumps and differ in the seed scrambling; the
+reference's four iteration pins are met by rocRAND's constants -- the default -- and three of them by cuRAND's as
+quoted there; `KMCUDA_AMD_AFKMC2_SEEDING=curand` / `oracle.set_afkmc2_seeding(True)` select those).  What CAN be pinned,
+and is here:
   1. the restatement's generator, its 2^67-draw subsequence jumps, its offset jumps and its Weyl bookkeeping equal a
-     second, independent implementation -- rocRAND's HOST generator (librocrand through ctypes, ROCRAND_RNG_PSEUDO_XORWOW)
-     -- when the restatement is given rocRAND's seed-scrambling constants (the one place the two libraries differ);
-  2. the DEVICE generator of the seeding kernels (csrc/seeding.hip: rocRAND's engine, state seeded cuRAND's way) equals the
-     restatement with cuRAND's constants, stream by stream, at the (seed, thread, step) triples the reference uses;
-  3. cuRAND's and rocRAND's seedings do give different streams (so the distinction is not academic).
-What cannot: that cuRAND's constants are the ones quoted -- no cuRAND output vector exists offline (parity unpinned)."""
+     second, independent implementation -- rocRAND's HOST generator (librocrand through ctypes, ROCRAND_RNG_PSEUDO_XORWOW);
+  2. the DEVICE generator of the seeding kernels (csrc/seeding.hip: rocRAND's engine, the state seeded either way) equals
+     the restatement, stream by stream, at the (seed, thread, step) triples the reference uses, under BOTH seedings;
+  3. the two seedings do give different streams (so the distinction is not academic);
+  4. whole AFK-MC2 calls equal the oracle's seed for seed under both.
+What cannot: which stream CUDA's library produced for the reference's authors (parity unpinned)."""
 import ctypes
 
 import numpy
@@ -64,12 +67,17 @@ def test_restatement_equals_rocrand_host_generator_under_rocrand_seeding(seed, o
         assert (mine == ref).all(), (seed, offset, t, T)
 
 
+@pytest.mark.parametrize("curand", [False, True])
 @pytest.mark.parametrize("seed,step", [(3, 0), (3, 1), (3, 49), (777, 199), (0xFFFFFFFF, 12345), (2**40 + 5, 7)])
-def test_device_draws_equal_the_restatement_under_curand_seeding(seed, step):
+def test_device_draws_equal_the_restatement(seed, step, curand, monkeypatch):
     """The triples of the reference's call: seed = the API's 32-bit seed (widened), subsequence = thread < m (m up to
     N / 2), offset = the seeding step."""
     from kmcuda_amd import _lib
     from kmcuda_amd.engine import Engine
+    if curand:
+        monkeypatch.setenv("KMCUDA_AMD_AFKMC2_SEEDING", "curand")
+    else:
+        monkeypatch.delenv("KMCUDA_AMD_AFKMC2_SEEDING", raising=False)
     dev = torch.device("cuda", 0)
     threads, n = 4096, 6
     out = torch.zeros(threads * n, dtype=torch.int32, device=dev)
@@ -79,18 +87,27 @@ def test_device_draws_equal_the_restatement_under_curand_seeding(seed, step):
     got = out.cpu().numpy().view(numpy.uint32).reshape(threads, n)
     eng.close()
     for t in list(range(0, 64)) + list(range(64, threads, 61)) + [threads - 1]:
-        ref = oracle.xorwow_draws(seed, t, step, n, curand_seeding=True)
+        ref = oracle.xorwow_draws(seed, t, step, n, curand_seeding=curand)
         assert (got[t] == ref).all(), (seed, step, t)
-    other = oracle.xorwow_draws(seed, 0, step, n, curand_seeding=False)
+    other = oracle.xorwow_draws(seed, 0, step, n, curand_seeding=not curand)
     assert not (got[0] == other).all()   # the two libraries' seedings are different streams
 
 
-def test_afkmc2_whole_call_still_equals_the_oracle(fixture13k):
-    """kmeans_cuda(init=afkmc2) seed for seed against the oracle (both on cuRAND's seeding now), the reference's pin of 4
-    iterations with it (test.py:248-262)."""
+@pytest.mark.parametrize("curand", [False, True])
+def test_afkmc2_whole_call_equals_the_oracle_under_both_seedings(fixture13k, curand, monkeypatch):
+    """kmeans_cuda(init=afkmc2) seed for seed against the oracle; the reference's pin of 4 iterations (test.py:248-262)
+    holds under both (under the default seeding so do the other three pins: tests/test_gpu_kmeans.py, test_gpu_fp16.py)."""
     from kmcuda_amd import kmeans_cuda
-    cen, asg = kmeans_cuda(fixture13k, 50, init=("afkmc2", 200), seed=3, tolerance=0.05, yinyang_t=0, device=1, verbosity=0)
-    ocen, oasg, log = oracle.kmeans(fixture13k, 50, init=("afkmc2", 200), seed=3, tolerance=0.05, yinyang_t=0)
+    if curand:
+        monkeypatch.setenv("KMCUDA_AMD_AFKMC2_SEEDING", "curand")
+    else:
+        monkeypatch.delenv("KMCUDA_AMD_AFKMC2_SEEDING", raising=False)
+    oracle.set_afkmc2_seeding(curand)
+    try:
+        cen, asg = kmeans_cuda(fixture13k, 50, init=("afkmc2", 200), seed=3, tolerance=0.05, yinyang_t=0, device=1, verbosity=0)
+        ocen, oasg, log = oracle.kmeans(fixture13k, 50, init=("afkmc2", 200), seed=3, tolerance=0.05, yinyang_t=0)
+    finally:
+        oracle.set_afkmc2_seeding(False)
     assert len(log) == 4
     assert (asg == oasg).mean() > 0.999
     numpy.testing.assert_allclose(cen, ocen, rtol=2e-4, atol=1e-5)

@@ -378,8 +378,9 @@ def test_half2_knn_against_a_numpy_restatement(metric):
 
 def test_xorwow_restatement_is_self_consistent_and_pinned():
     """AFK-MC2's generator (oracle/kmcuda_oracle.c): jumping `offset` draws ahead equals drawing them, under both seed
-    scramblings; the first draws of (seed 3, subsequence 0, offset 0) as a regression pin (cuRAND's constants: what the
-    seeding uses; rocRAND's: what tests/test_gpu_afkmc2_rng.py checks against rocRAND's host generator)."""
+    scramblings; the first draws of (seed 3, subsequence 0, offset 0) as a regression pin (rocRAND's constants: the
+    default, and what tests/test_gpu_afkmc2_rng.py checks against rocRAND's host generator; cuRAND's as quoted in the
+    oracle: the alternative).  The reference's fp32 AFK-MC2 pins hold under both (the fp16 one under the default only)."""
     for flavour in (True, False):
         for seed, t in ((3, 0), (0xFFFFFFFF, 5), (2**40 + 9, 199)):
             base = oracle.xorwow_draws(seed, t, 0, 1100, curand_seeding=flavour)
@@ -388,3 +389,10 @@ def test_xorwow_restatement_is_self_consistent_and_pinned():
         assert not (oracle.xorwow_draws(3, 0, 0, 4, curand_seeding=flavour) == oracle.xorwow_draws(3, 1, 0, 4, curand_seeding=flavour)).any()
     assert list(oracle.xorwow_draws(3, 0, 0, 4, curand_seeding=True)) == [3846186680, 2306068187, 4034236305, 1721582715]
     assert list(oracle.xorwow_draws(3, 0, 0, 4, curand_seeding=False)) == [1865448851, 3091812441, 3400940839, 786499017]
+    oracle.set_afkmc2_seeding(True)
+    try:
+        for init, k in ((("afkmc2", 200), 50), ("afkmc2", 50), (("afkmc2", 100), 200)):
+            from conftest import reference_fixture
+            assert len(oracle.kmeans(reference_fixture(), k, init=init, seed=3, tolerance=0.05, yinyang_t=0)[2]) == 4
+    finally:
+        oracle.set_afkmc2_seeding(False)
