@@ -47,12 +47,12 @@ for step in "$@"; do
     api) timeout 900 python bench.py --api --steps 20 $args > $OUT/bench_api_$TAG.json 2> $OUT/bench_api_$TAG.err; echo "rc=$?"
          python -c "import json;d=json.loads(open('$OUT/bench_api_$TAG.json').read().strip().splitlines()[-1]);print('api', d['ms_per_step'], [(c['iterations'],round(c['loop_s'],4),round(c['wall_s'],3)) for c in d['calls']])" ;;
     stats) rm -rf $OUT/prof_$TAG
-         timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o p -- python bench.py ${args:---steps 20 --warmup 5 --no-cpu-baseline --no-verify} > $OUT/prof_$TAG.log 2>&1; echo "rocprof rc=$?"
+         timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o p -- python bench.py ${args:---steps 20 --warmup 5 --no-cpu-baseline --no-verify --no-api-leg} > $OUT/prof_$TAG.log 2>&1; echo "rocprof rc=$?"
          python scripts/rocpd_stats.py $OUT/prof_$TAG/p_results.db $OUT/kernel_stats_$TAG.csv | head -12 | cut -c1-160; rm -rf $OUT/prof_$TAG ;;
     timeline) rm -rf $OUT/prof_$TAG   # the last launches of the bench command as a timeline with gaps
          timeout 900 rocprofv3 --kernel-trace -d $OUT/prof_$TAG -o p -- python bench.py ${args:---samples 1000000 --steps 6 --warmup 4 --no-cpu-baseline --no-verify --no-api-leg} > $OUT/prof_$TAG.log 2>&1; echo "rocprof rc=$?"
          python scripts/rocpd_timeline.py $OUT/prof_$TAG/p_results.db 0 100000 | tail -40 | cut -c1-150 | tee $OUT/timeline_$TAG.log; rm -rf $OUT/prof_$TAG ;;
-    pmc) CMD="python bench.py ${args:---steps 10 --warmup 5 --no-cpu-baseline --no-verify}"; i=0
+    pmc) CMD="python bench.py ${args:---steps 10 --warmup 5 --no-cpu-baseline --no-verify --no-api-leg}"; i=0
          for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
                     "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
            i=$((i+1)); rm -rf /tmp/pmc_$i

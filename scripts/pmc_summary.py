@@ -19,7 +19,7 @@ for f in glob.glob("/tmp/pmc_*/**/*counter_collection.csv", recursive=True):
         if r["Counter_Name"] in ("GRBM_GUI_ACTIVE",):
             dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 out = {"source": "scripts/gpu.sh pmc: rocprofv3 --pmc <group> --kernel-trace, one run per group, "
-                 "python bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-verify; per-launch means over each kernel's LAST 10 launches (the timed iterations)",
+                 "python bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-verify --no-api-leg; per-launch means over each kernel's LAST 10 launches (the timed iterations)",
        "units": "FETCH_SIZE/WRITE_SIZE in KB as reported; fetch_bytes_corrected = 2 x FETCH_SIZE x 1024 (gfx950: "
                 "wide streaming reads are tallied at half, MI355X_MICROARCH.md HBM); SQ_* summed over SIMDs "
                 "(quad-cycles for *_CYCLES waits per the guide); GRBM_GUI_ACTIVE summed over 8 XCDs",
