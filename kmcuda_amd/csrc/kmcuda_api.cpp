@@ -341,17 +341,36 @@ class Job {
   size_t coll_used = 0;
   int collective_mark(bool begin) {
     if (!time_collective) return 0;
+    // (the caller's current device is its own business: the events belong to the first shard's device, and the device
+    //  that was current comes back -- the grouped all-reduce sets its own per shard, the stand-in has set the first's)
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
     (void)hipSetDevice(shards[0]->dev);
+    int rc = 0;
     if (begin) {
       if (coll_used == coll_events.size()) {
-        if (coll_events.size() >= 4096) { time_collective = false; return 0; }   // (enough of a sample)
-        hipEvent_t a = nullptr, b = nullptr;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return kmcudaRuntimeError;
-        coll_events.emplace_back(a, b);
+        if (coll_events.size() >= 4096) {   // (enough of a sample)
+          time_collective = false;
+        } else {
+          hipEvent_t a = nullptr, b = nullptr;
+          if (hipEventCreate(&a) != hipSuccess) {
+            rc = kmcudaRuntimeError;
+          } else if (hipEventCreate(&b) != hipSuccess) {
+            (void)hipEventDestroy(a);   // (a pair or nothing: ~Job destroys pairs)
+            rc = kmcudaRuntimeError;
+          } else {
+            coll_events.emplace_back(a, b);
+          }
+        }
       }
-      return hipEventRecord(coll_events[coll_used].first, shards[0]->eng->stream_) == hipSuccess ? 0 : (int)kmcudaRuntimeError;
+      if (rc == 0 && time_collective &&
+          hipEventRecord(coll_events[coll_used].first, shards[0]->eng->stream_) != hipSuccess)
+        rc = kmcudaRuntimeError;
+    } else if (coll_used < coll_events.size()) {
+      if (hipEventRecord(coll_events[coll_used++].second, shards[0]->eng->stream_) != hipSuccess) rc = kmcudaRuntimeError;
     }
-    return hipEventRecord(coll_events[coll_used++].second, shards[0]->eng->stream_) == hipSuccess ? 0 : (int)kmcudaRuntimeError;
+    if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
+    return rc;
   }
   void collective_collect() {   // after sync_all()
     for (size_t i = 0; i < coll_used; i++) {
