@@ -13,6 +13,7 @@
 #   pmc[:<bench.py args>]     PMC passes (one run per counter group, --kernel-trace only) -> pmc_<tag>_summary.json
 #   hip:<file.hip>[,args]     a standalone .hip program (scripts/mfma_probe.hip, scripts/coarse_probe.hip) built on the box
 #                             with $HIPFLAGS and run -> <name>_<tag>.log
+#   hippmc:<file.hip>[,args]  the same program under rocprofv3 --pmc (MFMA busy, clock per launch: scripts/probe_pmc.py)
 #   configs                   whole calls: config B / mixtures / config C shape with yinyang_t = 0.1 and 0 (scripts/config_b.py)
 #   knn[:<config_d.py args>]  config D's share (scripts/config_d.py)
 #   scale:<N>                 scripts/scale_check.sh N
@@ -61,6 +62,10 @@ for step in "$@"; do
          PMC_TAG=$TAG python scripts/pmc_summary.py $OUT/pmc_${TAG}_summary.json | cut -c1-600 ;;
     hip) src=${args%% *}; rest=""; [ "$src" != "$args" ] && rest=${args#* }; exe=scratch/bin/$(basename $src .hip); mkdir -p scratch/bin
          /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -w ${HIPFLAGS:-} $src -o $exe && { echo "## flags: ${HIPFLAGS:-}" >> $OUT/$(basename $src .hip)_$TAG.log; timeout 600 $exe $rest | tee -a $OUT/$(basename $src .hip)_$TAG.log; } ;;
+    hippmc) src=${args%% *}; rest=""; [ "$src" != "$args" ] && rest=${args#* }; exe=scratch/bin/$(basename $src .hip); mkdir -p scratch/bin   # a probe under the MFMA-busy / clock counters
+         /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -w ${HIPFLAGS:-} $src -o $exe && { rm -rf /tmp/hippmc_$TAG
+           timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/hippmc_$TAG -o pmc -- $exe $rest > $OUT/$(basename $src .hip)_pmc_$TAG.log 2>&1
+           python scripts/probe_pmc.py /tmp/hippmc_$TAG | tee -a $OUT/$(basename $src .hip)_pmc_$TAG.log; } ;;
     configs) : > $OUT/configs_$TAG.log
          run() { echo "## $1" | tee -a $OUT/configs_$TAG.log; shift; ( "$@" ) 2>&1 | grep -E "kmeans_cuda wall|carried bounds|knn_cuda" | tee -a $OUT/configs_$TAG.log; }
          for rep in 1 2; do
