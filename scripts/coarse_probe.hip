@@ -7,7 +7,8 @@
 //   PIPE  0 = today's order (a tile's products, then its bookkeeping), 1 = the bookkeeping of tile t - 1 between the
 //         products of tile t (double accumulators)
 //   BOOK  0 none, 1 = 2.5 VALU per score (pack + med3 + med3 + max3 per pair), 2 = 1.5 (no index bits: value-only)
-//   SYNC  a block barrier every second tile (the super-tile hand-over of the real kernel)
+//   SYNC  a block barrier every second tile (the super-tile hand-over of the real kernel); 2: every fourth
+//   BW    waves per block: 4 (two blocks per CU at WPS 2) or 8 (one block: both waves of a SIMD meet at its barriers)
 // Prints TFLOP/s, the fraction of 2500 and the clock implied if the matrix pipe never idled.
 //   hipcc -O3 --offload-arch=gfx950 scripts/coarse_probe.hip -o scratch/bin/coarse_probe && scratch/bin/coarse_probe [tiles]
 #include <hip/hip_runtime.h>
@@ -33,18 +34,18 @@ __device__ __forceinline__ void lds_frag_wait(f16x8 &f) {
 
 constexpr int KS = 16, ROWB = 512, TILEB = 32 * ROWB;
 
-template <int WPS, int NSET, int PIPE, int BOOK, int SYNC>
-__global__ __launch_bounds__(256, WPS) void probe(const f16x8 *__restrict__ ops, const f16x8 *__restrict__ panel, int tiles,
+template <int WPS, int NSET, int PIPE, int BOOK, int SYNC, int BW = 4>
+__global__ __launch_bounds__(BW * 64, BW == 8 ? 1 : WPS) void probe(const f16x8 *__restrict__ ops, const f16x8 *__restrict__ panel, int tiles,
                                                   float *__restrict__ out) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte *)lds;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
   // four tiles = 64 KB of random halves
-  for (int i = tid; i < 4 * TILEB / 16; i += 256) reinterpret_cast<f16x8 *>(lds)[i] = panel[i];
+  for (int i = tid; i < 4 * TILEB / 16; i += BW * 64) reinterpret_cast<f16x8 *>(lds)[i] = panel[i];
   __syncthreads();
   f16x8 x[NSET][KS];
-  const size_t base = ((size_t)blockIdx.x * 4 + wave) * (NSET * KS) * 64 + lane;
+  const size_t base = ((size_t)blockIdx.x * BW + wave) * (NSET * KS) * 64 + lane;
 #pragma unroll
   for (int s = 0; s < NSET; s++)
 #pragma unroll
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256, WPS) void probe(const f16x8 *__restrict__ ops,
   for (int t = 0; t < tiles; t += 2) {
     tile(t, std::integral_constant<int, 0>(), t > 0);
     tile(t + 1, std::integral_constant<int, 1>(), true);
-    if (SYNC) __syncthreads();
+    if (SYNC == 1 || (SYNC == 2 && (t & 2))) __syncthreads();   // (SYNC 2: a barrier every 4 tiles)
   }
   float sum = 0;
 #pragma unroll
@@ -143,21 +144,21 @@ static uint16_t f2h(float f) {
   return u;
 }
 
-template <int WPS, int NSET, int PIPE, int BOOK, int SYNC>
+template <int WPS, int NSET, int PIPE, int BOOK, int SYNC, int BW = 4>
 static void run(const char *what, int cus, const f16x8 *ops, const f16x8 *panel, int tiles, float *out) {
-  const int blocks = cus * WPS;
+  const int blocks = cus * WPS * 4 / BW;
   const size_t ldsb = WPS == 1 ? 96 * 1024 : 4 * TILEB;   // (one block per CU when a wave is to have its SIMD to itself)
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&probe<WPS, NSET, PIPE, BOOK, SYNC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&probe<WPS, NSET, PIPE, BOOK, SYNC, BW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  hipLaunchKernelGGL((probe<WPS, NSET, PIPE, BOOK, SYNC>), dim3(blocks), dim3(256), ldsb, 0, ops, panel, tiles / 4, out);
+  hipLaunchKernelGGL((probe<WPS, NSET, PIPE, BOOK, SYNC, BW>), dim3(blocks), dim3(BW * 64), ldsb, 0, ops, panel, tiles / 4, out);
   hipDeviceSynchronize();
   float sum = 0, best = 1e30f;
   const int reps = 3;
   for (int r = 0; r < reps; r++) {
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((probe<WPS, NSET, PIPE, BOOK, SYNC>), dim3(blocks), dim3(256), ldsb, 0, ops, panel, tiles, out);
+    hipLaunchKernelGGL((probe<WPS, NSET, PIPE, BOOK, SYNC, BW>), dim3(blocks), dim3(BW * 64), ldsb, 0, ops, panel, tiles, out);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms;
@@ -167,7 +168,7 @@ static void run(const char *what, int cus, const f16x8 *ops, const f16x8 *panel,
   }
   hipError_t err = hipGetLastError();
   const double mfmas_per_wave = (double)tiles * KS * NSET;
-  const double flop = mfmas_per_wave * blocks * 4 * 32768.0;
+  const double flop = mfmas_per_wave * blocks * BW * 32768.0;
   const double ms = sum / reps;
   const double cyc = mfmas_per_wave * WPS * 32.0;
   printf("%-46s wps %d nset %d pipe %d book %d sync %d : %8.3f ms  %7.1f TFLOP/s  (%.3f of 2500)  pipe-saturated clock >= %.2f GHz %s\n", what,
@@ -211,5 +212,9 @@ int main(int argc, char **argv) {
   run<1, 4, 1, 1, 1>("  + barrier per 2 tiles", cus, ops, panel, tiles, out);
   run<1, 4, 1, 2, 1>("  4 sets, value-only bookkeeping, pipelined", cus, ops, panel, tiles, out);
   run<1, 3, 1, 1, 1>("  3 sets, pipelined bookkeeping, barrier", cus, ops, panel, tiles, out);
+  // ONE 8-wave block per CU (both waves of a SIMD in the same block: half the staging traffic per row in the real kernel)
+  run<2, 2, 0, 1, 1, 8>("8-wave block, today's mix, barrier per 2 tiles", cus, ops, panel, tiles, out);
+  run<2, 2, 0, 1, 2, 8>("8-wave block, today's mix, barrier per 4 tiles", cus, ops, panel, tiles, out);
+  run<2, 2, 0, 1, 0, 8>("8-wave block, today's mix, no barrier", cus, ops, panel, tiles, out);
   return 0;
 }
