@@ -84,12 +84,22 @@ __global__ __launch_bounds__(256, NI >= 4 ? 2 : 4) void lloyd_duo_kernel(
     uint4 rec[SLOTS];
     bool live[SLOTS];
     f32x4 xv[SLOTS][NI], c1v[SLOTS][NI], c2v[SLOTS][NI];
+    uint32_t old_asg[SLOTS];
+    float bias_a[SLOTS], bias_b[SLOTS];
 #pragma unroll
     for (int k = 0; k < SLOTS; k++) {
       live[k] = base + 4u * k + g < total;
       rec[k] = rec_next[k];
     }
     request(base + gridDim.x * 4u * per_iter);
+    // everything the decision will need leaves with the rows: the previous assignment (commit_row's read) and the two
+    // biases behind the products would each be a round trip of their own at the end of the trip
+#pragma unroll
+    for (int k = 0; k < SLOTS; k++) {
+      old_asg[k] = assignments[rec[k].x];
+      bias_a[k] = bias[rec[k].y];
+      bias_b[k] = bias[rec[k].z];
+    }
 #pragma unroll
     for (int k = 0; k < SLOTS; k++) {
       const float *xr = samples + (size_t)rec[k].x * D;
@@ -137,7 +147,7 @@ __global__ __launch_bounds__(256, NI >= 4 ? 2 : 4) void lloyd_duo_kernel(
       if (angular) { xdm = row16_sum(xdm); xab = row16_sum(xab); }
       // ---- the decision: lloyd_refine_kernel's, for a list of two ----
       const uint32_t s = rec[k].x, ca = rec[k].y, cb = rec[k].z;
-      const float va = p1 + bias[ca], vb = p2 + bias[cb];
+      const float va = p1 + bias_a[k], vb = p2 + bias_b[k];
       float v1 = va, v2 = -INFINITY;
       const float v3 = -INFINITY;
       uint32_t i1 = ca, i2 = 0xFFFFFFFFu;
@@ -162,7 +172,14 @@ __global__ __launch_bounds__(256, NI >= 4 ? 2 : 4) void lloyd_duo_kernel(
       const bool two = !certain && in_range && ((v1 - v3) > thr) && (v3 < lim.hi) && (v1 > lim.lo) && i2 < K;
       const bool mine = live[k] && l == 0;
       const bool pair_now = mine && two, flag_now = mine && !certain && !two;
-      if (mine && certain && commit_row(s, insane ? K : i1, assignments, assignments_prev)) nchg++;
+      if (mine && certain) {   // commit_row() with the previous assignment already here
+        const uint32_t nearest = insane ? K : i1;
+        assignments_prev[s] = old_asg[k];
+        if (old_asg[k] != nearest) {
+          assignments[s] = nearest;
+          nchg++;
+        }
+      }
       if constexpr (BOUNDS) {   // lloyd_refine_kernel's statements for n = 2 contenders (its comments hold the derivation)
         if (mine) {
           const float rest = __uint_as_float(rec[k].w);
