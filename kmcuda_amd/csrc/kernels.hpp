@@ -406,7 +406,8 @@ hipError_t launch_knn_centroid_bounds(const float *xs, uint32_t D, uint32_t DP, 
                                       hipStream_t st);
 bool launch_knn_query_order(const float *lb, size_t stride, const uint32_t *offsets, uint32_t K, uint32_t p_base,
                             uint32_t p_end, uint32_t *keys_tmp, uint32_t *vals_tmp, uint32_t *keys_sorted,
-                            uint32_t *qperm, void *temp, size_t temp_bytes, hipStream_t st);
+                            uint32_t *qperm, void *temp, size_t temp_bytes, hipStream_t st, int mode,
+                            const float *mydist, const float *R);
 // strict_h2 (both): the reference's half2 arithmetic on rows that hold half values (KMCUDA_AMD_FP16_STRICT)
 hipError_t launch_knn_exact(int metric, const KnnArgs &a, bool strict_h2, hipStream_t st);
 hipError_t launch_knn_split(int metric, const float *xs, uint32_t N, uint32_t D, uint32_t DP, const float *mu,

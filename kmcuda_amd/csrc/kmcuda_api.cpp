@@ -1821,13 +1821,16 @@ class KnnJob {
               return kmcudaRuntimeError;
             a.lb = lb;
             a.lb_stride = len;
-            // queries that want the same clusters into the same waves (update.hip: launch_knn_query_order);
-            // KMCUDA_AMD_KNN_ORDER=0: sorted-position order (A/B)
+            // queries that want the same clusters into the same waves (update.hip: launch_knn_query_order): by the
+            // other cluster that can come closest, then by their distance to their own centroid (mode 3);
+            // KMCUDA_AMD_KNN_ORDER=0: sorted-position order, 1: the closest other cluster alone (rounds 4-5), 2: the
+            // distance alone (A/B: 1.911 / 1.882 / 1.860 / 1.839e12 pairs scored for config D's share, profiles/r6aj_*)
             const char *ord = getenv("KMCUDA_AMD_KNN_ORDER");
             uint32_t *qperm = nullptr;
-            if (!(ord && atoi(ord) == 0) && s.alloc(&qperm, len) == 0) {
+            const int ord_mode = ord ? atoi(ord) : 3;
+            if (ord_mode != 0 && s.alloc(&qperm, len) == 0) {
               if (launch_knn_query_order(lb, len, s.offsets, K, s.p_base, s.p_end, s.keys_tmp, s.vals_tmp, s.keys_sorted,
-                                         qperm, s.sort_temp, sort_bytes, s.stream))
+                                         qperm, s.sort_temp, sort_bytes, s.stream, ord_mode, s.mydist, s.R))
                 a.qperm = qperm;
               else
                 (void)hipGetLastError();

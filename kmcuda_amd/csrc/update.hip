@@ -100,9 +100,14 @@ hipError_t launch_inverse_assignments(const uint32_t *assignments, uint32_t N, u
 // side of their cluster want the same clusters: key = (own cluster, the OTHER cluster whose members can come closest,
 // argmin_c lb[c][q]); sorting the positions by it groups them.  Only the grouping of queries into waves changes:
 // every query still scans all clusters in the reference's order against its own heap.
+// mode 1: the key above.  mode 2: key = (own cluster, the query's distance to its own centroid, 15 bits of the float) --
+// under the reference's prune rule (C[c][mine] - d(q, c_mine) - R[c] > kth) a cluster's queries visit NESTED sets of
+// clusters, the farther from their centroid the more.  mode 3: (own cluster, argmin as mode 1, 6 bits of that distance
+// relative to the cluster's radius).  mydist: per sorted position; R: per cluster.
 __global__ void knn_query_keys_kernel(const float *__restrict__ lb, size_t stride, const uint32_t *__restrict__ offsets,
                                       uint32_t K, uint32_t p_base, uint32_t p_end, uint32_t *__restrict__ keys,
-                                      uint32_t *__restrict__ vals) {
+                                      uint32_t *__restrict__ vals, int mode, const float *__restrict__ mydist,
+                                      const float *__restrict__ R) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p_end - p_base) return;
   const uint32_t p = p_base + i;
@@ -112,33 +117,49 @@ __global__ void knn_query_keys_kernel(const float *__restrict__ lb, size_t strid
     if (offsets[mid] <= p) lo = mid; else hi = mid;
   }
   const uint32_t cls = lo;
+  vals[i] = p;
+  if (mode == 2) {
+    const float md = mydist[p];
+    const uint32_t q = (md == md && md > 0.f) ? ((__float_as_uint(md) >> 16) & 0x7FFFu) : 0u;
+    keys[i] = (cls << 15) | q;
+    return;
+  }
   float best = INFINITY;
   uint32_t arg = 0;
   for (uint32_t c = 0; c < K; c++) {
     const float v = lb[(size_t)c * stride + i];   // coalesced across the block's queries
     if (c != cls && v < best) { best = v; arg = c; }
   }
+  if (mode == 3) {
+    const float r = R[cls], md = mydist[p];
+    uint32_t q = 0;
+    if (r > 0.f && md == md) q = (uint32_t)fminf(63.f, fmaxf(0.f, md / r * 63.f));
+    keys[i] = ((cls * K + arg) << 6) | q;
+    return;
+  }
   keys[i] = cls * K + arg;
-  vals[i] = p;
 }
 
 // qperm[i] = the sorted position of the query that slot p_base + i of the block plan handles.  false: not possible
-// here (K * K does not fit the key, or the sort's scratch is too small): the caller keeps the identity order
+// here (the key does not fit 32 bits, or the sort's scratch is too small): the caller keeps the identity order
 bool launch_knn_query_order(const float *lb, size_t stride, const uint32_t *offsets, uint32_t K, uint32_t p_base,
                             uint32_t p_end, uint32_t *keys_tmp, uint32_t *vals_tmp, uint32_t *keys_sorted,
-                            uint32_t *qperm, void *temp, size_t temp_bytes, hipStream_t st) {
+                            uint32_t *qperm, void *temp, size_t temp_bytes, hipStream_t st, int mode,
+                            const float *mydist, const float *R) {
   if (p_end <= p_base || K > 65535u) return false;
+  const uint64_t key_max = mode == 2 ? ((uint64_t)K << 15) : (mode == 3 ? ((uint64_t)K * K) << 6 : (uint64_t)K * K);
+  if (key_max > 0xFFFFFFFFull) return false;
   const uint32_t n = p_end - p_base;
   size_t need = 0;
   if (rocprim::radix_sort_pairs(nullptr, need, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
-                                (uint32_t *)nullptr, (size_t)n, 0u, bits_for((uint64_t)K * K), st) != hipSuccess ||
+                                (uint32_t *)nullptr, (size_t)n, 0u, bits_for(key_max), st) != hipSuccess ||
       need > temp_bytes)
     return false;
   hipLaunchKernelGGL(knn_query_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, lb, stride, offsets, K, p_base,
-                     p_end, keys_tmp, vals_tmp);
+                     p_end, keys_tmp, vals_tmp, mode, mydist, R);
   size_t bytes = temp_bytes;
   return rocprim::radix_sort_pairs(temp, bytes, (const uint32_t *)keys_tmp, keys_sorted, (const uint32_t *)vals_tmp,
-                                   qperm, (size_t)n, 0u, bits_for((uint64_t)K * K), st) == hipSuccess &&
+                                   qperm, (size_t)n, 0u, bits_for(key_max), st) == hipSuccess &&
          hipGetLastError() == hipSuccess;
 }
 
