@@ -359,6 +359,7 @@ constexpr int knn16_waves(int DP) { return DP > 256 ? 4 : KNN16_WAVES_NARROW; }
 constexpr int knn16_blocks_per_cu(int DP) { return DP > 512 ? 1 : (DP > 256 ? 2 : (KNN16_WAVES_NARROW > 4 ? 1 : 2)); }
 constexpr int knn16_nset(int DP) { return DP > 256 ? 1 : KNN16_NSET; }
 constexpr int knn16_sub(int DP) { return DP > 256 ? 1 : KNN16_SUB; }
+constexpr int knn16_nbuf(int DP) { return DP > 256 ? 2 : KNN16_NBUF; }   // (the wide instantiations' tiles: two buffers fill their LDS)
 constexpr uint32_t KNN_QPB_F32 = 128;
 constexpr uint32_t knn_qpb_f16(uint32_t DP) { return (uint32_t)knn16_waves((int)DP) * (uint32_t)knn16_nset((int)DP) * 32u; }
 struct KnnArgs {

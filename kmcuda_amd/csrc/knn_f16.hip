@@ -113,7 +113,7 @@ __global__ __launch_bounds__(knn16_waves(DP) * 64, knn16_blocks_per_cu(DP)) void
   constexpr int TILEB = 32 * SUB * ROWB;
   constexpr int NP = (TILEB + 1023) / 1024;   // 1-KB LDS-DMA pieces per tile
   constexpr int SWM = (KS < 16 ? KS : 16) - 1;
-  constexpr int NBUF = KNN16_NBUF;            // ring of tile buffers: NBUF - 1 tiles in flight
+  constexpr int NBUF = knn16_nbuf(DP);        // ring of tile buffers: NBUF - 1 tiles in flight
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds2[];
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte *)lds2;
@@ -507,7 +507,7 @@ hipError_t launch_knn_split(int metric, const float *xs, uint32_t N, uint32_t D,
 
 template <int DP, int METRIC>
 static hipError_t launch_knn_f16_t(const KnnArgs &a, uint32_t nblocks, hipStream_t st) {
-  const size_t lds_bytes = (size_t)KNN16_NBUF * (32 * knn16_sub(DP) * DP * 2) + KNN16_NBUF * 256 + 2 * knn16_waves(DP) * 4;
+  const size_t lds_bytes = (size_t)knn16_nbuf(DP) * (32 * knn16_sub(DP) * DP * 2) + knn16_nbuf(DP) * 256 + 2 * knn16_waves(DP) * 4;
   if (lds_bytes > 65536) {   // (per launch: the attribute belongs to the current device's copy of the kernel)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_filter_f16_kernel<DP, METRIC, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

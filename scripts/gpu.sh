@@ -11,6 +11,7 @@
 #   stats[:<bench.py args>]   rocprofv3 --kernel-trace --stats of the bench command -> kernel_stats_<tag>.csv
 #   timeline[:<bench.py args>] kernel trace of the bench (default: the 1M-row shard) -> the last 40 launches with their gaps
 #   pmc[:<bench.py args>]     PMC passes (one run per counter group, --kernel-trace only) -> pmc_<tag>_summary.json
+#   pmc:cmd=<command>         the same passes over any command, e.g. pmc:cmd=python,scripts/config_d.py,--samples,8000000,--shard,0/8
 #   hip:<file.hip>[,args]     a standalone .hip program (scripts/mfma_probe.hip, scripts/coarse_probe.hip) built on the box
 #                             with $HIPFLAGS and run -> <name>_<tag>.log
 #   hippmc:<file.hip>[,args]  the same program under rocprofv3 --pmc (MFMA busy, clock per launch: scripts/probe_pmc.py)
@@ -54,6 +55,7 @@ for step in "$@"; do
          timeout 900 rocprofv3 --kernel-trace -d $OUT/prof_$TAG -o p -- python bench.py ${args:---samples 1000000 --steps 6 --warmup 4 --no-cpu-baseline --no-verify --no-api-leg} > $OUT/prof_$TAG.log 2>&1; echo "rocprof rc=$?"
          python scripts/rocpd_timeline.py $OUT/prof_$TAG/p_results.db 0 100000 | tail -40 | cut -c1-150 | tee $OUT/timeline_$TAG.log; rm -rf $OUT/prof_$TAG ;;
     pmc) CMD="python bench.py ${args:---steps 10 --warmup 5 --no-cpu-baseline --no-verify --no-api-leg}"; i=0
+         case "$args" in cmd=*) CMD="${args#cmd=}" ;; esac   # pmc:cmd=<any command>: the same passes over another program (k-NN: scripts/config_d.py)
          for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
                     "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
            i=$((i+1)); rm -rf /tmp/pmc_$i

@@ -44,5 +44,5 @@ for k, v in sorted(agg.items()):
     out["kernels"][k] = e
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 for k in out["kernels"]:
-    if "lloyd" in k:
+    if "lloyd" in k or "knn_filter" in k:
         print(k, {a: (round(b, 4) if b < 100 else float("%.4g" % b)) for a, b in out["kernels"][k].items()})
